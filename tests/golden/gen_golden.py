@@ -1,0 +1,431 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REAL reference.
+
+Runs only in the build container (needs /root/reference, which never travels to the GPU box); the
+`.npz` files it writes are committed.  Nothing here is imported by the product or by the tests.
+
+The reference (`/root/reference/monoforce/src/monoforce`) is imported unmodified.  Import shims, all
+for packages that are absent from this image:
+  * `open3d`                       empty module (only used for mesh I/O, `dphys_config.py:5,26-30`)
+  * `torchdiffeq.odeint`           this file's `_fixed_grid_euler`: a restatement of torchdiffeq==0.2.3's
+                                   fixed-grid `euler` solver (third-party, not vendored -> "parity unpinned"
+                                   for that boundary; everything the derivative function computes IS reference code)
+  * `dphys_config.get_points_from_robot_mesh`  replaced by synthetic points (`config/meshes/marv.obj` is a
+                                   missing large blob and `dphysics.py:145` / `lss.py:15` build a DPhysConfig at import)
+  * `efficientnet_pytorch`, `torchvision`   stubs; only LSS geometry / voxel pooling is exercised.
+
+Usage:  python tests/golden/gen_golden.py            (writes tests/golden/*.npz)
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+from monoforce_amd import synthetic as syn  # noqa: E402  (input generators only; no kernels)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# shims
+# ----------------------------------------------------------------------------------------------------------
+def _mod(name, **kw):
+    m = types.ModuleType(name)
+    m.__dict__.update(kw)
+    sys.modules[name] = m
+    return m
+
+
+def _fixed_grid_euler(func, y0, t, method='euler', **unused):
+    assert method == 'euler'
+    ys, y = [y0], y0
+    for i in range(len(t) - 1):
+        f = func(t[i], y)
+        h = t[i + 1] - t[i]
+        y = tuple(a + h * b for a, b in zip(y, f))
+        ys.append(y)
+    return tuple(torch.stack([s[k] for s in ys], 0) for k in range(len(y0)))
+
+
+_mod('torchdiffeq', odeint=_fixed_grid_euler)
+_mod('open3d')
+
+
+class _FakeEffNet(torch.nn.Module):
+    @staticmethod
+    def from_pretrained(*a, **k):
+        return torch.nn.Identity()
+
+
+class _FakeResnet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.bn1 = torch.nn.BatchNorm2d(64)
+        self.relu = torch.nn.ReLU()
+        self.layer1 = self.layer2 = self.layer3 = torch.nn.Identity()
+
+
+class _Noop:
+    def __init__(self, *a, **k):
+        pass
+
+    def __call__(self, x):
+        return x
+
+
+_noop = _Noop
+_mod('efficientnet_pytorch', EfficientNet=_FakeEffNet)
+_tv = _mod('torchvision')
+_tv.transforms = _mod('torchvision.transforms', Normalize=_noop, Compose=_noop, ToTensor=_noop, ToPILImage=_noop,
+                      Resize=_noop)
+_tv.models = _mod('torchvision.models')
+_tv.models.resnet = _mod('torchvision.models.resnet', resnet18=lambda **k: _FakeResnet())
+
+sys.path.insert(0, '/root/reference/monoforce/src')
+from monoforce.models.traj_predictor import dphys_config as ref_cfg  # noqa: E402
+
+ref_cfg.get_points_from_robot_mesh = lambda robot, voxel_size=0.1, return_mesh=False: torch.rand(64, 3) - 0.5
+from monoforce.models.traj_predictor import dphysics as ref_dp  # noqa: E402
+from monoforce.models.terrain_encoder import lss as ref_lss  # noqa: E402
+from monoforce.models.terrain_encoder import utils as ref_lss_utils  # noqa: E402
+from monoforce.losses import physics_loss as ref_physics_loss  # noqa: E402
+
+assert ref_dp.__file__.startswith('/root/reference/'), ref_dp.__file__
+
+
+# ----------------------------------------------------------------------------------------------------------
+# reference config construction
+# ----------------------------------------------------------------------------------------------------------
+def make_ref_cfg(points, masks, dtype, grid_res, d_max, use_odeint, mass=40.0, robot='tradr', T=5.0, dt=0.01):
+    c = ref_cfg.DPhysConfig.__new__(ref_cfg.DPhysConfig)
+    pts = torch.as_tensor(points, dtype=torch.float32)      # the mesh loader returns float32 (dphys_config.py:31)
+    c.robot = robot
+    c.vel_max, c.omega_max = 1.0, 2.0
+    c.robot_mass = mass
+    c.joint_positions = {'fl': [0.25, 0.272, 0.019], 'fr': [0.25, -0.272, 0.019],
+                         'rl': [-0.25, 0.272, 0.019], 'rr': [-0.25, -0.272, 0.019]}
+    c.robot_points = pts.to(dtype)
+    c.driving_parts = [torch.as_tensor(m) for m in masks]
+    c.robot_size = ((pts[:, 0].max() - pts[:, 0].min()).to(dtype), (pts[:, 1].max() - pts[:, 1].min()).to(dtype))
+    c.gravity = 9.81
+    c.gravity_direction = torch.tensor([0., 0., -1.], dtype=dtype)
+    c.grid_res, c.r_min, c.d_max, c.h_max = grid_res, 0.6, d_max, 2.0
+    n = int(round(2 * d_max / grid_res))
+    c.z_grid = torch.zeros(n, n, dtype=dtype)
+    c.x_grid = c.y_grid = c.z_grid
+    c.friction = torch.ones(n, n, dtype=dtype)
+    c.stiffness = 50_000.
+    c.damping = np.sqrt(4 * c.robot_mass * c.stiffness)
+    c.hm_interp_method = None
+    c.traj_sim_time, c.dt, c.n_sim_trajs = T, dt, 64
+    c.integration_mode = 'euler'
+    c.use_odeint = use_odeint
+    return c
+
+
+class default_dtype:
+    def __init__(self, dt):
+        self.dt = dt
+
+    def __enter__(self):
+        self.old = torch.get_default_dtype()
+        torch.set_default_dtype(self.dt)
+
+    def __exit__(self, *a):
+        torch.set_default_dtype(self.old)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def run_ref(points, masks, dtype, integ, z, ctrl, state, mu, grid_res, d_max, grads=False, loss_kind='probe',
+            n_tracks_robot='tradr'):
+    """Run the reference forward (and backward). integ: 0 = dynamics(), 1 = odeint-euler (oracle numbering)."""
+    with default_dtype(dtype):
+        cfg = make_ref_cfg(points, masks, dtype, grid_res, d_max, use_odeint=(integ == 1), robot=n_tracks_robot)
+        dp = ref_dp.DPhysics(cfg, device='cpu')
+        z = z.clone().to(dtype).requires_grad_(grads)
+        ctrl = ctrl.clone().to(dtype).requires_grad_(grads)
+        mu_in = None if mu is None else mu.clone().to(dtype).requires_grad_(grads)
+        st = None if state is None else tuple(s.clone().to(dtype) for s in state)
+        states, forces = dp(z_grid=z, controls=ctrl, state=st, friction=mu_in)
+        outs = list(states) + list(forces)
+        res = {k: npy(v) for k, v in zip(['Xs', 'Xds', 'Rs', 'Om', 'Fs', 'Ff'], outs)}
+        if st is not None:
+            res['x0_after'] = npy(st[0])        # the reference overwrote x0[:, 2] in place (dphysics.py:571)
+        if grads:
+            scales = [1.0, 1.0, 1.0, 1.0, 1e-3, 1e-3]
+            loss = 0
+            for i, (o, s) in enumerate(zip(outs, scales)):
+                loss = loss + (o * syn.probe_weights(o.shape, phase=0.5 + i, dtype=dtype)).sum() * s
+            loss.backward()
+            res['loss'] = npy(loss)
+            res['g_z'] = npy(z.grad)
+            res['g_ctrl'] = npy(ctrl.grad)
+            if mu_in is not None:
+                res['g_mu'] = npy(mu_in.grad)
+    return res
+
+
+# ----------------------------------------------------------------------------------------------------------
+# fixture 1: interpolate_grid unit vectors
+# ----------------------------------------------------------------------------------------------------------
+def gen_interp(out):
+    pts, masks = syn.robot_points_4()
+    H, d_max, res = 8, 0.4, 0.1
+    for dtype, tag in ((torch.float32, 'f32'), (torch.float64, 'f64')):
+        with default_dtype(dtype):
+            dp = ref_dp.DPhysics(make_ref_cfg(pts, masks, dtype, res, d_max, True), device='cpu')
+            ii, jj = np.meshgrid(np.arange(H), np.arange(H), indexing='ij')
+            g0 = torch.as_tensor(10.0 * ii + jj, dtype=dtype)                 # the SURVEY probe grid
+            g1 = torch.as_tensor(np.sin(0.9 * ii) * np.cos(0.7 * jj) + 0.05 * ii, dtype=dtype)
+            grid = torch.stack([g0, g1])
+            # interior points, exact nodes, cell edges, negative / beyond-range queries (extrapolation + index clamp)
+            q = np.array([[0.013, 0.027], [-0.4, -0.4], [-0.35, 0.0], [0.05, -0.049999], [0.1, 0.1], [0.299, 0.301],
+                          [0.39, 0.39], [0.395, -0.2], [-0.2, 0.399], [0.41, 0.0], [0.0, 0.47], [0.55, 0.55],
+                          [-0.43, 0.1], [0.1, -0.47], [-0.52, -0.61], [0.2999999, 0.1000001]], np.float64)
+            qx = torch.as_tensor(q[:, 0], dtype=dtype).repeat(2, 1)
+            qy = torch.as_tensor(q[:, 1], dtype=dtype).repeat(2, 1)
+            zq, n = dp.interpolate_grid(grid, qx, qy, return_normals=True)
+            out[f'{tag}/grid'] = npy(grid); out[f'{tag}/qx'] = npy(qx); out[f'{tag}/qy'] = npy(qy)
+            out[f'{tag}/z'] = npy(zq); out[f'{tag}/n'] = npy(n)
+    out['d_max'] = np.float64(d_max); out['grid_res'] = np.float64(res)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# fixture 2/3: small rollouts (+ grads) and teacher-forced single steps
+# ----------------------------------------------------------------------------------------------------------
+SMALL = dict(grid_res=0.1, d_max=1.6, T=48)
+
+
+def small_case_inputs(name):
+    """Inputs of the small cases as float64 torch tensors + robot; shared with tests via the stored arrays."""
+    H = int(round(2 * SMALL['d_max'] / SMALL['grid_res']))
+    T = SMALL['T']
+    if name == 'A':     # N=4, default state, friction None, constant controls, shared-looking but per-rollout maps
+        B = 3
+        pts, masks = syn.robot_points_4()
+        z = torch.stack([syn.bump_terrain(np.array([[0.15, 0.6, 0.1, 0.5], [0.1, -0.3, -0.5, 0.3]]), 1.6, 0.1, torch.float64),
+                         syn.bump_terrain(np.array([[0.2, 0.4, -0.2, 0.4]]), 1.6, 0.1, torch.float64),
+                         torch.zeros(H, H, dtype=torch.float64)])
+        ctrl = syn.const_controls(B, T, seed=1, dtype=torch.float64)
+        return pts, masks, z, ctrl, None, None, 'tradr'
+    if name == 'B':     # N=32 two tracks (some points not driving), given state, friction map, varying controls
+        B = 3
+        pts, masks = syn.robot_points_box(32, seed=3, n_tracks=2)
+        z = torch.stack([syn.bump_terrain(np.array([[0.12, 0.5, 0.2, 0.6], [0.08, -0.4, 0.3, 0.2]]), 1.6, 0.1, torch.float64) + 0.02 * k
+                         for k in range(B)])
+        mu = torch.stack([syn.wave_friction(1.6, 0.1, 0.4, 1.0, 2.1 + k, 1.7, torch.float64) for k in range(B)])
+        ctrl = syn.varying_controls(B, T, seed=2, dtype=torch.float64)
+        return pts, masks, z, ctrl, given_state(B, edge=False), mu, 'tradr'
+    if name == 'C':     # N=32 four tracks, starts near the map edge -> out-of-range queries, friction map
+        B = 2
+        pts, masks = syn.robot_points_box(32, seed=5, n_tracks=4)
+        z = torch.stack([syn.bump_terrain(np.array([[0.1, 1.2, 1.0, 0.5]]), 1.6, 0.1, torch.float64),
+                         syn.bump_terrain(np.array([[0.15, -1.3, -1.1, 0.4]]), 1.6, 0.1, torch.float64)])
+        mu = torch.stack([syn.wave_friction(1.6, 0.1, 0.5, 1.0, 1.1, 2.3, torch.float64) for k in range(B)])
+        ctrl = syn.const_controls(B, T, seed=4, dtype=torch.float64)
+        return pts, masks, z, ctrl, given_state(B, edge=True), mu, 'husky'
+    raise KeyError(name)
+
+
+def given_state(B, edge):
+    x = torch.zeros(B, 3, dtype=torch.float64)
+    R = torch.zeros(B, 3, 3, dtype=torch.float64)
+    for b in range(B):
+        yaw, pitch = 0.4 * (b + 1) * (-1) ** b, 0.05 * (b + 1)
+        Rz = np.array([[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1]])
+        Ry = np.array([[np.cos(pitch), 0, np.sin(pitch)], [0, 1, 0], [-np.sin(pitch), 0, np.cos(pitch)]])
+        R[b] = torch.as_tensor(Rz @ Ry)
+        if edge:
+            x[b] = torch.tensor([1.45, 1.3, 0.0]) * (1 if b == 0 else -1)
+        else:
+            x[b] = torch.tensor([0.2 * b - 0.1, -0.15 * b, 0.0])
+    xd = torch.tensor([[0.3, 0.05, 0.0]], dtype=torch.float64).repeat(B, 1) * torch.arange(1, B + 1).unsqueeze(1)
+    w = torch.tensor([[0.02, -0.03, 0.3]], dtype=torch.float64).repeat(B, 1)
+    return (x, xd, R, w)
+
+
+def gen_small(out):
+    for name in 'ABC':
+        pts, masks, z, ctrl, state, mu, robot = small_case_inputs(name)
+        out[f'{name}/points'] = pts
+        out[f'{name}/masks'] = np.stack(masks)
+        out[f'{name}/z'] = npy(z); out[f'{name}/ctrl'] = npy(ctrl)
+        if mu is not None:
+            out[f'{name}/mu'] = npy(mu)
+        if state is not None:
+            for k, s in zip(('x0', 'xd0', 'R0', 'w0'), state):
+                out[f'{name}/{k}'] = npy(s)
+        for dtype, tag in ((torch.float32, 'f32'), (torch.float64, 'f64')):
+            for integ in (0, 1):
+                r = run_ref(pts, masks, dtype, integ, z, ctrl, state, mu, SMALL['grid_res'], SMALL['d_max'],
+                            grads=True, n_tracks_robot=robot)
+                for k, v in r.items():
+                    out[f'{name}/{tag}/i{integ}/{k}'] = v
+                print(f'small {name} {tag} integ={integ}: |Xs|max={np.abs(r["Xs"]).max():.3f} '
+                      f'|Fs|max={np.abs(r["Fs"]).max():.1f} |g_z|max={np.abs(r["g_z"]).max():.3e}')
+
+
+def gen_step(out):
+    """Teacher-forced single steps: forward_kinematics + update_state called directly on mid-rollout states."""
+    pts, masks, z, ctrl, state, mu, robot = small_case_inputs('B')
+    ref64 = run_ref(pts, masks, torch.float64, 0, z, ctrl, state, mu, SMALL['grid_res'], SMALL['d_max'])
+    sel = [0, 5, 17, 30, 46]
+    for dtype, tag in ((torch.float32, 'f32'), (torch.float64, 'f64')):
+        with default_dtype(dtype):
+            cfg = make_ref_cfg(pts, masks, dtype, SMALL['grid_res'], SMALL['d_max'], use_odeint=False, robot=robot)
+            dp = ref_dp.DPhysics(cfg, device='cpu')
+            dp.z_grid, dp.friction = z.to(dtype), mu.to(dtype)
+            dp.controls = ctrl.to(dtype)
+            dp.joint_angles = torch.zeros(ctrl.shape[0], ctrl.shape[1], 4, dtype=dtype)
+            sink = cfg.robot_mass * cfg.gravity / (cfg.stiffness + 1e-6)
+            for t in sel:
+                Rt = torch.as_tensor(ref64['Rs'][:, t]).to(dtype)
+                st = (torch.as_tensor(ref64['Xs'][:, t] - ref64['Rs'][:, t, :, 2] * sink).to(dtype),
+                      torch.as_tensor(ref64['Xds'][:, t]).to(dtype), Rt, torch.as_tensor(ref64['Om'][:, t]).to(dtype))
+                dstate, forces = dp.forward_kinematics(dp.ts[t + 1], st)
+                nxt = dp.update_state(st, dstate, cfg.dt)
+                for k, v in zip(('x', 'xd', 'R', 'w'), st):
+                    out[f'{tag}/t{t}/in_{k}'] = npy(v)
+                for k, v in zip(('xd', 'xdd', 'dR', 'wd'), dstate):
+                    out[f'{tag}/t{t}/d_{k}'] = npy(v)
+                out[f'{tag}/t{t}/Fs'] = npy(forces[0]); out[f'{tag}/t{t}/Ff'] = npy(forces[1])
+                for k, v in zip(('x', 'xd', 'R', 'w'), nxt):
+                    out[f'{tag}/t{t}/next_{k}'] = npy(v)
+    out['sel'] = np.array(sel)
+    out['ctrl_index_offset'] = np.int64(1)   # the step at stored state t uses controls[:, t+1]
+
+
+# ----------------------------------------------------------------------------------------------------------
+# fixture 4: full horizon (T=500, 256x256), inputs regenerated from parameters
+# ----------------------------------------------------------------------------------------------------------
+FULL = dict(grid_res=0.05, d_max=6.4, T=500, B=4)
+
+
+def full_inputs():
+    pts, masks = syn.robot_points_4()
+    pr = [syn.bump_params(11), syn.bump_params(12), syn.bump_params(0, smooth=True), np.array([[0.0, 0.0, 0.0, 1.0]])]
+    z = torch.stack([syn.bump_terrain(p, FULL['d_max'], FULL['grid_res'], torch.float64) for p in pr])
+    mu = torch.stack([syn.wave_friction(FULL['d_max'], FULL['grid_res'], 0.5, 1.0, 1.3 + 0.1 * k, 0.9, torch.float64)
+                      for k in range(FULL['B'])])
+    ctrl = syn.const_controls(FULL['B'], FULL['T'], seed=7, dtype=torch.float64)
+    return pts, masks, z, mu, ctrl
+
+
+def gen_full(out):
+    pts, masks, z, mu, ctrl = full_inputs()
+    out['points'] = pts; out['masks'] = np.stack(masks); out['ctrl'] = npy(ctrl)
+    for dtype, tag in ((torch.float32, 'f32'), (torch.float64, 'f64')):
+        for integ in (0, 1):
+            r = run_ref(pts, masks, dtype, integ, z, ctrl, None, mu, FULL['grid_res'], FULL['d_max'],
+                        grads=(dtype == torch.float64))
+            for k in ('Xs', 'Xds', 'Rs', 'Om'):
+                out[f'{tag}/i{integ}/{k}'] = r[k]
+            out[f'{tag}/i{integ}/Fs_10'] = r['Fs'][:, ::10]
+            out[f'{tag}/i{integ}/Ff_10'] = r['Ff'][:, ::10]
+            if 'g_z' in r:
+                out[f'{tag}/i{integ}/loss'] = r['loss']
+                out[f'{tag}/i{integ}/g_ctrl'] = r['g_ctrl']
+                for nm in ('g_z', 'g_mu'):
+                    g = r[nm].reshape(-1)
+                    nz = np.nonzero(g)[0]
+                    out[f'{tag}/i{integ}/{nm}_idx'] = nz.astype(np.int32)
+                    out[f'{tag}/i{integ}/{nm}_val'] = g[nz]
+                    print(f'full {tag} integ={integ} {nm}: nnz={nz.size} max={np.abs(g).max():.3e}')
+            print(f'full {tag} integ={integ}: x_end={r["Xs"][:, -1]}')
+
+
+# ----------------------------------------------------------------------------------------------------------
+# fixture 5: LSS frustum / geometry / voxel pooling
+# ----------------------------------------------------------------------------------------------------------
+LSS_SMALL = dict(
+    grid_conf=dict(xbound=[-3.2, 3.2, 0.2], ybound=[-3.2, 3.2, 0.2], zbound=[-2.0, 2.0, 2.0], dbound=[0.6, 3.4, 0.4]),
+    data_aug_conf=dict(final_dim=(64, 96), H=64, W=96))
+
+
+def gen_lss(out):
+    torch.manual_seed(0)
+    gc, dc = LSS_SMALL['grid_conf'], LSS_SMALL['data_aug_conf']
+    B, ncam, C = 2, 2, 8
+    rots, trans, intrins, post_rots, post_trans = syn.lss_camera_rig(B, ncam, H=64, W=96, f=40.0)
+    # non-trivial augmentation on sample 1
+    post_rots[1, :, 0, 0] = 0.9; post_rots[1, :, 1, 1] = 1.1; post_trans[1, :, 0] = 3.0; post_trans[1, :, 1] = -2.0
+    with default_dtype(torch.float32):
+        m = ref_lss.LiftSplatShoot(gc, dc, outC=1)
+        m.camC = C
+        out['dx'], out['bx'], out['nx'] = npy(m.dx), npy(m.bx), npy(m.nx)
+        out['frustum'] = npy(m.frustum)
+        geom = m.get_geometry(rots, trans, intrins, post_rots, post_trans)
+        D, fH, fW = m.frustum.shape[:3]
+        rng = np.random.RandomState(0)
+        x = torch.as_tensor(rng.randn(B, ncam, D, fH, fW, C).astype(np.float32))
+        # some points exactly on / just below the lower bound (trunc-toward-zero keeps them in voxel 0)
+        geom[0, 0, 0, 0, 0] = torch.tensor([-3.25, 0.0, -1.0]); geom[0, 0, 0, 0, 1] = torch.tensor([-3.41, 0.0, -1.0])
+        geom[0, 0, 0, 0, 2] = torch.tensor([3.2, 0.0, 0.0]); geom[0, 0, 0, 0, 3] = torch.tensor([0.0, -3.39, 3.9])
+        xg = x.clone().requires_grad_(True)
+        m.use_quickcumsum = True
+        pooled = m.voxel_pooling(geom, xg)
+        w = syn.probe_weights(pooled.shape, phase=0.3, dtype=torch.float32)
+        (pooled * w).sum().backward()
+        m.use_quickcumsum = False
+        pooled_ag = m.voxel_pooling(geom, x)
+    for k, v in dict(rots=rots, trans=trans, intrins=intrins, post_rots=post_rots, post_trans=post_trans, geom=geom, x=x,
+                     pooled_ref_f32=pooled, pooled_ref_autograd_f32=pooled_ag, g_x=xg.grad).items():
+        out[k] = npy(v)
+    # exact segmented sum: reference float32 index arithmetic, float64 accumulation
+    idx = ((geom - (m.bx - m.dx / 2.)) / m.dx).long().view(-1, 3)
+    nx = m.nx
+    bidx = torch.arange(B).repeat_interleave(idx.shape[0] // B)
+    kept = (idx[:, 0] >= 0) & (idx[:, 0] < nx[0]) & (idx[:, 1] >= 0) & (idx[:, 1] < nx[1]) & (idx[:, 2] >= 0) & (idx[:, 2] < nx[2])
+    nX, nY, nZ = int(nx[0]), int(nx[1]), int(nx[2])
+    lin = ((bidx * nZ + idx[:, 2]) * nX + idx[:, 0]) * nY + idx[:, 1]
+    exact = torch.zeros(B * nZ * nX * nY, C, dtype=torch.float64)
+    exact.index_add_(0, lin[kept], x.view(-1, C).double()[kept])
+    exact = exact.view(B, nZ, nX, nY, C).permute(0, 4, 1, 2, 3).contiguous()      # B x C x Z x X x Y
+    out['pooled_exact_f64'] = npy(torch.cat(exact.unbind(2), 1))
+    out['kept'] = npy(kept)
+    out['voxel_idx'] = npy(idx)
+    print('lss: geom', tuple(geom.shape), 'kept', int(kept.sum()), '/', kept.numel(),
+          'max|ref-exact|', float((pooled.double() - torch.cat(exact.unbind(2), 1)).abs().max()))
+    # full-size frustum depth count (D == 59 for dbound [0.6, 6.4, 0.1])
+    out['D_full'] = np.int64(torch.arange(0.6, 6.4, 0.1, dtype=torch.float).numel())
+
+
+# ----------------------------------------------------------------------------------------------------------
+# fixture 6: physics_loss
+# ----------------------------------------------------------------------------------------------------------
+def gen_loss(out):
+    rng = np.random.RandomState(3)
+    B, T1, T2 = 3, 48, 7
+    X = torch.as_tensor(rng.randn(B, T1, 3).astype(np.float32)).requires_grad_(True)
+    Xgt = torch.as_tensor(rng.randn(B, T2, 3).astype(np.float32))
+    pred_ts = torch.linspace(0, 5, 500)[:T1].repeat(B, 1)
+    gt_ts = torch.as_tensor(np.sort(rng.rand(B, T2) * 0.5, 1).astype(np.float32))
+    loss = ref_physics_loss([X], [Xgt], pred_ts, gt_ts, gamma=0.9)
+    loss.backward()
+    for k, v in dict(X=X, Xgt=Xgt, pred_ts=pred_ts, gt_ts=gt_ts, loss=loss, g_X=X.grad).items():
+        out[k] = npy(v)
+
+
+def main():
+    jobs = dict(interp=gen_interp, rollout_small=gen_small, step=gen_step, rollout_full=gen_full, lss=gen_lss,
+                physics_loss=gen_loss)
+    only = sys.argv[1:]
+    for name, fn in jobs.items():
+        if only and name not in only:
+            continue
+        out = {}
+        fn(out)
+        path = os.path.join(HERE, name + '.npz')
+        np.savez_compressed(path, **out)
+        print(f'wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB, {len(out)} arrays')
+
+
+if __name__ == '__main__':
+    main()

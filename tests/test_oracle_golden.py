@@ -1,0 +1,97 @@
+"""Pin the CPU oracle (oracle/dphysics_oracle.py) against golden vectors produced by the real reference."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dphysics_oracle as orc
+from tests import helpers as hp
+
+
+@pytest.mark.parametrize('tag', ['f32', 'f64'])
+def test_sample_grid_matches_reference(tag):
+    g = hp.load('interp')
+    dt = hp.DT[tag]
+    grid, qx, qy = (torch.as_tensor(g[f'{tag}/{k}']) for k in ('grid', 'qx', 'qy'))
+    z, n = orc.sample_grid(grid, qx, qy, float(g['d_max']), float(g['grid_res']), normals=True)
+    assert z.dtype == dt
+    # identical op sequence -> bitwise in practice; allow 2 ulp
+    tol = 3e-7 if tag == 'f32' else 1e-15
+    assert hp.rel_err(z, g[f'{tag}/z']) <= tol
+    assert hp.rel_err(n, g[f'{tag}/n']) <= tol
+
+
+def test_sample_grid_swapped_weights_probe():
+    """SURVEY A.1 probe: on G[ix,iy]=10ix+iy, (fx,fy)=(0.5,0) gives 57.5-like values, not the true bilinear."""
+    ii, jj = np.meshgrid(np.arange(8), np.arange(8), indexing='ij')
+    G = torch.as_tensor(10.0 * ii + jj, dtype=torch.float64).unsqueeze(0)
+    # cell (5,7)->flat; query at ix=5.5, iy=7 is out of this 8x8 grid; use ix=2.5, iy=3: true bilinear = 28, reference = 23.5
+    qx = torch.tensor([[-0.4 + 0.1 * 2.5]], dtype=torch.float64); qy = torch.tensor([[-0.4 + 0.1 * 3.0]], dtype=torch.float64)
+    z = orc.sample_grid(G, qx, qy, 0.4, 0.1)
+    assert abs(float(z) - 23.5) < 1e-9
+
+
+@pytest.mark.parametrize('name', ['A', 'B', 'C'])
+@pytest.mark.parametrize('tag', ['f32', 'f64'])
+@pytest.mark.parametrize('integ', [0, 1])
+def test_small_rollout_and_grads(name, tag, integ):
+    g = hp.load('rollout_small')
+    dt = hp.DT[tag]
+    pts, masks, z, ctrl, state, mu = hp.small_case(g, name, dt)
+    spec = hp.spec_from(pts, masks, integ, hp.SMALL['grid_res'], hp.SMALL['d_max'])
+    z.requires_grad_(True); ctrl.requires_grad_(True)
+    if mu is not None:
+        mu.requires_grad_(True)
+    states, forces = orc.rollout(spec, z, ctrl, state=state, friction=mu)
+    outs = list(states) + list(forces)
+    # fp64: restatement vs reference to rounding; fp32: same op order -> near-bitwise, allow a few ulp of drift over 48 steps
+    tol = 1e-11 if tag == 'f64' else 2e-5
+    for k, o in zip(hp.OUT_KEYS, outs):
+        ref = g[f'{name}/{tag}/i{integ}/{k}']
+        assert o.shape == ref.shape
+        assert hp.rel_err(o.detach(), ref) <= tol, (k, hp.rel_err(o.detach(), ref))
+    if state is not None:
+        assert hp.rel_err(state[0], g[f'{name}/{tag}/i{integ}/x0_after']) <= tol
+    loss = hp.probe_loss(outs, dt)
+    loss.backward()
+    gtol = 1e-9 if tag == 'f64' else 2e-3
+    assert hp.rel_err(z.grad, g[f'{name}/{tag}/i{integ}/g_z']) <= gtol
+    assert hp.rel_err(ctrl.grad, g[f'{name}/{tag}/i{integ}/g_ctrl']) <= gtol
+    if mu is not None:
+        assert hp.rel_err(mu.grad, g[f'{name}/{tag}/i{integ}/g_mu']) <= gtol
+
+
+@pytest.mark.parametrize('tag', ['f32', 'f64'])
+def test_teacher_forced_step(tag):
+    g = hp.load('step'); gs = hp.load('rollout_small')
+    dt = hp.DT[tag]
+    pts, masks, z, ctrl, _, mu = hp.small_case(gs, 'B', dt)
+    spec = hp.spec_from(pts, masks, orc.DYNAMICS, hp.SMALL['grid_res'], hp.SMALL['d_max'])
+    P = spec.points.to(dt).unsqueeze(0)
+    Iinv = torch.linalg.inv(orc.point_inertia(spec.mass, P))
+    tol = 1e-12 if tag == 'f64' else 1e-5
+    for t in g['sel']:
+        st = [torch.as_tensor(g[f'{tag}/t{t}/in_{k}']) for k in ('x', 'xd', 'R', 'w')]
+        (xdd, dR, wd), (Fs, Ff) = orc.rhs(spec, Iinv, P, None, z, mu, ctrl[:, t + 1], *st)
+        for k, v in (('xdd', xdd), ('dR', dR), ('wd', wd)):
+            assert hp.rel_err(v, g[f'{tag}/t{t}/d_{k}']) <= tol, k
+        assert hp.rel_err(Fs, g[f'{tag}/t{t}/Fs']) <= tol
+        assert hp.rel_err(Ff, g[f'{tag}/t{t}/Ff']) <= tol
+        h = spec.dt
+        xd1 = st[1] + xdd * h; x1 = st[0] + xd1 * h; w1 = st[3] + wd * h
+        R1 = orc.rodrigues_step(st[2], w1, h)
+        for k, v in (('x', x1), ('xd', xd1), ('R', R1), ('w', w1)):
+            assert hp.rel_err(v, g[f'{tag}/t{t}/next_{k}']) <= tol, k
+
+
+@pytest.mark.parametrize('integ', [0, 1])
+def test_full_horizon_f64(integ):
+    """T=500 on 256x256: fp64 oracle vs fp64 reference (chaos-proof at fp64)."""
+    g = hp.load('rollout_full')
+    pts, masks, z, mu, ctrl = hp.full_inputs(torch.float64)
+    spec = hp.spec_from(pts, masks, integ, hp.FULL['grid_res'], hp.FULL['d_max'])
+    with torch.no_grad():
+        states, forces = orc.rollout(spec, z, ctrl, friction=mu)
+    for k, o in zip(hp.OUT_KEYS[:4], states):
+        assert hp.rel_err(o, g[f'f64/i{integ}/{k}']) <= 1e-8, k
+    assert hp.rel_err(forces[0][:, ::10], g[f'f64/i{integ}/Fs_10']) <= 1e-7
+    assert hp.rel_err(forces[1][:, ::10], g[f'f64/i{integ}/Ff_10']) <= 1e-7
