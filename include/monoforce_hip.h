@@ -1,0 +1,104 @@
+/*
+ * monoforce_hip.h -- C ABI of libmonoforce_hip.so (gfx950 / MI355X).
+ *
+ * The drop-in boundary of the MonoForce hot path.  Every entry point takes plain device pointers, sizes and a
+ * HIP stream (as void*); nothing here knows about torch.  All launches are asynchronous on the given stream; no
+ * entry point synchronises or allocates.  Return value: MF_OK or an MF_ERR_* code (text via mf_last_error()).
+ *
+ * Reference interfaces replaced (paths under /root/reference/monoforce/src/monoforce/models/):
+ *   mf_rollout_fwd_*   traj_predictor/dphysics.py:530-594  DPhysics.dphysics()  = forward_kinematics (:172-272)
+ *                      + dynamics (:467-497) / dynamics_odeint (:499-528) + interpolate_grid (:385-455)
+ *   mf_rollout_bwd_*   the autograd graph the reference builds through the same functions (loss.backward(),
+ *                      scripts/fit_terrain.py:53-62, scripts/train.py:399-406)
+ *   mf_bev_splat_*     terrain_encoder/lss.py:238-280 LiftSplatShoot.voxel_pooling() + terrain_encoder/utils.py:144-181
+ *                      (cumsum_trick / QuickCumsum forward and backward)
+ *   mf_lss_geometry_*  terrain_encoder/lss.py:204-224 LiftSplatShoot.get_geometry()
+ */
+#ifndef MONOFORCE_HIP_H
+#define MONOFORCE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  MF_OK = 0,
+  MF_ERR_INVALID = 1,     /* bad argument (shape / null pointer / enum) */
+  MF_ERR_UNSUPPORTED = 2, /* valid request outside what the kernels cover (e.g. > 512 contact points) */
+  MF_ERR_LAUNCH = 3       /* HIP reported an error at launch */
+};
+
+/* Integrators of DPhysics (dphys_config.py:150-153). */
+enum {
+  MF_INTEG_DYNAMICS = 0,    /* use_odeint=False: dynamics() -- semi-implicit Euler + Rodrigues, records state AFTER each step */
+  MF_INTEG_ODEINT_EULER = 1 /* use_odeint=True (reference default): torchdiffeq fixed-grid explicit Euler on the
+                               extended state; output 0 = initial state; "forces" are running impulses */
+};
+
+/* Output layout.  The reference's default path returns permuted views of time-major tensors (dphysics.py:515-526),
+ * its dynamics() path returns contiguous [B,T,...] stacks (dphysics.py:490-495).  Both are supported; time-major lets a
+ * wavefront's per-step stores land in one contiguous segment. */
+enum {
+  MF_LAYOUT_BATCH_MAJOR = 0, /* X[b][t][...] */
+  MF_LAYOUT_TIME_MAJOR = 1   /* X[t][b][...] */
+};
+
+/* Shapes and physical constants of one rollout launch.  Scalars are double here and are rounded ONCE to the
+ * kernel's arithmetic type, like the Python floats of DPhysConfig are when they meet a tensor. */
+typedef struct MfRolloutDesc {
+  int32_t B;          /* rollouts */
+  int32_t T;          /* grid points N_ts = outputs per rollout (dphysics.py:573) */
+  int32_t N;          /* contact points (cfg.robot_points.shape[0]) */
+  int32_t H, W;       /* grid size; flat index = iy + H*ix, first grid axis = x (dphysics.py:427-430) */
+  int32_t n_tracks;   /* len(cfg.driving_parts): 2 or 4 (dphysics.py:75-104) */
+  int32_t integrator; /* MF_INTEG_* */
+  int32_t layout;     /* MF_LAYOUT_* of all outputs */
+  int32_t map_shared; /* 1: z/mu are one [H,W] map shared by all rollouts; 0: [B,H,W] */
+  int32_t block;      /* threads per workgroup: 0 = default (64); otherwise 64, 128 or 256 */
+  int32_t skip_snap;  /* 1: do NOT move x0.z onto the terrain first (dphysics.py:567-571) -- for continuing a rollout
+                         from a mid-trajectory state (chunked horizons, teacher-forced single steps) */
+  int32_t reserved;   /* keep the doubles 8-byte aligned; must be 0 */
+  double mass, gravity, stiffness, damping, omega_max;
+  double grid_res, d_max;
+  double dt;           /* cfg.dt: step of MF_INTEG_DYNAMICS (ODEINT takes its steps from ts[]) */
+  double robot_size_y; /* Ly = cfg.robot_size[1] */
+  double Iinv[9];      /* inverse body inertia, row-major (dphysics.py:152-153) */
+} MfRolloutDesc;
+
+/* Device buffers of the forward rollout; S = float for _f32, double for _f64.  All contiguous. */
+typedef struct MfRolloutFwdBufs {
+  const void* z;        /* S[map_shared ? 1 : B][H][W] height map */
+  const void* mu;       /* same shape friction map, or NULL = all ones (cfg.friction, dphysics.py:562) */
+  const void* controls; /* S[B][T][2] = (v, w) */
+  const void* ts;       /* S[T] time grid (dphysics.py:167,581); only its differences are used (ODEINT) */
+  const void* points;   /* S[N][3] body-frame contact points */
+  const int32_t* part;  /* int32[N]: index of the LAST driving mask holding the point, -1 = not driving (:242-246) */
+  void* x0;             /* S[B][3] IN/OUT: z component is overwritten with the terrain height under the robot (:567-571) */
+  const void* xd0;      /* S[B][3] */
+  const void* R0;       /* S[B][3][3] */
+  const void* w0;       /* S[B][3] */
+  void* Xs;             /* S[..][3]   positions, already shifted by R[:,2]*m*g/(k+1e-6) (:587-589) */
+  void* Xds;            /* S[..][3]   */
+  void* Rs;             /* S[..][3][3]*/
+  void* Omegas;         /* S[..][3]   */
+  void* Fs;             /* S[..][N][3] spring forces (DYNAMICS) or their running impulses (ODEINT) */
+  void* Ff;             /* S[..][N][3] friction forces / impulses */
+  void* Xraw;           /* optional S[..][3]: unshifted positions saved for the backward pass; may be NULL */
+} MfRolloutFwdBufs;
+
+int mf_rollout_fwd_f32(const MfRolloutDesc* desc, const MfRolloutFwdBufs* bufs, void* hip_stream);
+int mf_rollout_fwd_f64(const MfRolloutDesc* desc, const MfRolloutFwdBufs* bufs, void* hip_stream);
+
+/* Text of the calling thread's last error ("" if none). */
+const char* mf_last_error(void);
+/* Library version, e.g. "monoforce_hip 0.1 gfx950". */
+const char* mf_version(void);
+/* sizeof() of an ABI struct by name ("MfRolloutDesc", ...), -1 if unknown: lets bindings verify their mirrors. */
+int mf_sizeof(const char* struct_name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MONOFORCE_HIP_H */

@@ -1,0 +1,85 @@
+"""ctypes binding of libmonoforce_hip.so (the C ABI declared in include/monoforce_hip.h).
+
+There is no CPU fallback: if the library has not been built (`python -c "import __graft_entry__ as g; g.build()"`
+or `make -C monoforce_amd/csrc`) every entry point raises.
+"""
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libmonoforce_hip.so')
+
+MF_INTEG_DYNAMICS, MF_INTEG_ODEINT_EULER = 0, 1
+MF_LAYOUT_BATCH_MAJOR, MF_LAYOUT_TIME_MAJOR = 0, 1
+
+
+class MfRolloutDesc(C.Structure):
+    _fields_ = [('B', C.c_int32), ('T', C.c_int32), ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
+                ('n_tracks', C.c_int32), ('integrator', C.c_int32), ('layout', C.c_int32), ('map_shared', C.c_int32),
+                ('block', C.c_int32), ('skip_snap', C.c_int32), ('reserved', C.c_int32),
+                ('mass', C.c_double), ('gravity', C.c_double), ('stiffness', C.c_double), ('damping', C.c_double),
+                ('omega_max', C.c_double), ('grid_res', C.c_double), ('d_max', C.c_double), ('dt', C.c_double),
+                ('robot_size_y', C.c_double), ('Iinv', C.c_double * 9)]
+
+
+class MfRolloutFwdBufs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('z', 'mu', 'controls', 'ts', 'points', 'part', 'x0', 'xd0', 'R0', 'w0',
+                                          'Xs', 'Xds', 'Rs', 'Omegas', 'Fs', 'Ff', 'Xraw')]
+
+
+class MfRolloutBwdBufs(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ('z', 'mu', 'controls', 'ts', 'points', 'part', 'x_init', 'xd0', 'R0', 'w0',
+                                          'Xraw', 'Xds', 'Rs', 'Omegas',
+                                          'gXs', 'gXds', 'gRs', 'gOmegas', 'gFs', 'gFf',
+                                          'gz', 'gmu', 'gcontrols', 'gx0', 'gxd0', 'gR0', 'gw0')]
+
+
+class MfSplatDesc(C.Structure):
+    _fields_ = [('B', C.c_int32), ('n_per_sample', C.c_int32), ('C', C.c_int32),
+                ('nx', C.c_int32), ('ny', C.c_int32), ('nz', C.c_int32),
+                ('off', C.c_float * 3), ('dx', C.c_float * 3)]
+
+
+# every symbol include/monoforce_hip.h declares; tests check the library exports all of them
+SYMBOLS = ['mf_rollout_fwd_f32', 'mf_rollout_fwd_f64', 'mf_last_error', 'mf_version', 'mf_sizeof']
+
+_lib = None
+_lock = threading.Lock()
+
+
+def lib():
+    """Load (once) and return the HIP library; raise loudly if it is not there."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise RuntimeError(
+                        f'{LIB_PATH} is missing: build the HIP extension first (make -C monoforce_amd/csrc). '
+                        'monoforce_amd has no CPU fallback.')
+                L = C.CDLL(LIB_PATH)
+                L.mf_last_error.restype = C.c_char_p
+                L.mf_version.restype = C.c_char_p
+                for name in SYMBOLS:
+                    fn = getattr(L, name)   # AttributeError if the build is stale
+                    if name.startswith(('mf_rollout', 'mf_bev', 'mf_lss')):
+                        fn.restype = C.c_int
+                _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f'{what} failed (code {rc}): {lib().mf_last_error().decode()}')
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def require_hip_tensor(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f'{name} is on {t.device}: monoforce_amd computes on the MI355X HIP path only '
+                           '(no CPU fallback); move inputs to "cuda".')

@@ -1,0 +1,18 @@
+// Library-wide pieces of the C ABI: error text and version.
+#include "mf_common.h"
+
+namespace mf {
+static thread_local std::string g_last_error;
+void set_error(const std::string& msg) { g_last_error = msg; }
+}  // namespace mf
+
+extern "C" const char* mf_last_error(void) { return mf::g_last_error.c_str(); }
+extern "C" const char* mf_version(void) { return "monoforce_hip 0.1 gfx950"; }
+
+// sizeof() of the ABI structs, so language bindings can verify their mirrors (tests/test_capi_cpu.py)
+#include <string.h>
+extern "C" int mf_sizeof(const char* name) {
+  if (!strcmp(name, "MfRolloutDesc")) return (int)sizeof(MfRolloutDesc);
+  if (!strcmp(name, "MfRolloutFwdBufs")) return (int)sizeof(MfRolloutFwdBufs);
+  return -1;
+}

@@ -1,0 +1,72 @@
+// Shared device helpers for the monoforce gfx950 kernels: cross-lane reductions on DPP, small vector math,
+// error plumbing.  CDNA4 only (wave64); no other target is supported.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/monoforce_hip.h"
+
+namespace mf {
+
+void set_error(const std::string& msg);  // capi.hip
+
+#define MF_REQUIRE(cond, code, msg)        \
+  do {                                     \
+    if (!(cond)) {                         \
+      ::mf::set_error(msg);                \
+      return (code);                       \
+    }                                      \
+  } while (0)
+
+// ---------------------------------------------------------------------------------------------------------
+// DPP lane permutes.  dpp_ctrl encodings (gfx9): quad_perm = sel0 | sel1<<2 | sel2<<4 | sel3<<6,
+// row_mirror = 0x140 (lane i <-> 15-i of a 16-lane row), row_half_mirror = 0x141 (i <-> 7-i of an 8-lane half row).
+// ---------------------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  int2 p = __builtin_bit_cast(int2, v);
+  p.x = __builtin_amdgcn_update_dpp(0, p.x, CTRL, 0xF, 0xF, true);
+  p.y = __builtin_amdgcn_update_dpp(0, p.y, CTRL, 0xF, 0xF, true);
+  return __builtin_bit_cast(double, p);
+}
+__device__ __forceinline__ float lane_xor(float v, int m) { return __shfl_xor(v, m, 64); }
+__device__ __forceinline__ double lane_xor(double v, int m) { return __shfl_xor(v, m, 64); }
+
+// All-reduce (sum) over aligned groups of G consecutive lanes; every lane of the group gets the total.
+// G <= 16 stays on DPP (no LDS crossbar round trip): the butterfly xor1, xor2, then the mirror steps, which
+// are valid because after each step the already-merged sub-groups hold identical values.
+template <int G, typename S>
+__device__ __forceinline__ S group_sum(S v) {
+  static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "G must be a power of two <= 64");
+  if (G >= 2) v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  if (G >= 4) v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  if (G >= 8) v += dpp_mov<0x141>(v);  // row_half_mirror
+  if (G >= 16) v += dpp_mov<0x140>(v); // row_mirror
+  if (G >= 32) v += lane_xor(v, 16);
+  if (G >= 64) v += lane_xor(v, 32);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// scalar helpers, overloaded on the arithmetic type
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float mf_sqrt(float v) { return sqrtf(v); }
+__device__ __forceinline__ double mf_sqrt(double v) { return sqrt(v); }
+__device__ __forceinline__ float mf_exp(float v) { return expf(v); }
+__device__ __forceinline__ double mf_exp(double v) { return exp(v); }
+__device__ __forceinline__ void mf_sincos(float v, float* s, float* c) { sincosf(v, s, c); }
+__device__ __forceinline__ void mf_sincos(double v, double* s, double* c) { sincos(v, s, c); }
+template <typename S>
+__device__ __forceinline__ S mf_clamp(S v, S lo, S hi) {
+  // torch.clamp semantics: min(max(v, lo), hi); NaN propagates
+  return v < lo ? lo : (v > hi ? hi : v);
+}
+template <typename S>
+__device__ __forceinline__ S mf_max(S a, S b) { return a > b ? a : b; }
+
+}  // namespace mf

@@ -1,0 +1,410 @@
+// Fused DPhysics rollout, forward pass (gfx950).
+//
+// One kernel runs the whole T-step scan of `DPhysics.dphysics()`
+// (/root/reference/monoforce/src/monoforce/models/traj_predictor/dphysics.py:530-594): per step it does the
+// per-contact-point height/friction sample (`interpolate_grid`, :385-455, bug-for-bug), the spring-damper + friction
+// contact forces and the rigid-body update (`forward_kinematics`, :172-272), then one Euler step of either integrator
+// (`dynamics` :467-497 / `dynamics_odeint` :499-528), and streams the six API outputs.
+//
+// Mapping (wave64): a rollout is owned by a group of G consecutive lanes (G = 4, 16 or 64), each lane owning PPL
+// contact points (point i -> lane i % G, slot i / G).  The 18-float rigid-body state is replicated in every lane of
+// the group, so the only cross-lane traffic per step is two all-reduces (sum of contact weights; 9-component wrench),
+// done on DPP for G <= 16.  The time axis is a dependent chain and stays serial inside the lane; parallelism is
+// over rollouts (and points).  Map cells are gathered straight from global memory: both maps are read-only and at
+// 256x256x4 B x 2 = 512 KiB they live in every XCD's 4 MiB L2, with the few cells under a slowly moving robot
+// (<= 0.2 cell per step) staying in the CU's L1 -- see DESIGN.md for why a per-workgroup LDS tile does not pay at N=4.
+// Outputs are written time-major by default so a wave's stores of one step form contiguous segments.
+#include "mf_common.h"
+
+namespace mf {
+
+template <typename S>
+struct RolloutArgs {
+  int B, T, N, H, W, n_tracks, layout, map_shared, skip_snap;
+  S mass, mg, k, damp, omega_max, res, d_max, dt, half_ly, sink;
+  S Iinv[9];
+  const S* z;
+  const S* mu;
+  const S* controls;
+  const S* ts;
+  const S* points;
+  const int* part;
+  S* x0;
+  const S* xd0;
+  const S* R0;
+  const S* w0;
+  S* Xs;
+  S* Xds;
+  S* Rs;
+  S* Om;
+  S* Fs;
+  S* Ff;
+  S* Xraw;
+};
+
+// Cell indices and fractions of `interpolate_grid` (dphysics.py:419-435).  Index arithmetic is done in int32 after
+// clamping the cell coordinate to +-2^18 (the reference uses int64; results are identical while the robot is within
+// 2^18 cells of the map, far beyond which the flat-index clamp pins everything to cell 0 / HW-1 anyway).
+template <typename S>
+struct Cell {
+  int ic, i_f, il, ifl;
+  S fx, fy;
+};
+
+template <typename S>
+__device__ __forceinline__ Cell<S> locate(S qx, S qy, S d_max, S res, int H, int last) {
+  const S lim = (S)262144.0;
+  S ux = (qx + d_max) / res;
+  S uy = (qy + d_max) / res;
+  int ix = (int)mf_clamp(ux, -lim, lim);  // trunc toward zero, like .long()
+  int iy = (int)mf_clamp(uy, -lim, lim);
+  Cell<S> c;
+  c.fx = ux - (S)ix;
+  c.fy = uy - (S)iy;
+  int base = iy + H * ix;
+  c.ic = min(max(base, 0), last);
+  c.i_f = min(max(base + H, 0), last);
+  c.il = min(max(base + 1, 0), last);
+  c.ifl = min(max(base + 1 + H, 0), last);
+  return c;
+}
+
+template <typename S>
+__device__ __forceinline__ S blend(const Cell<S>& c, S vc, S vf, S vl, S vfl) {
+  // NB: the x-fraction weights the +y ("left") neighbour and vice versa (dphysics.py:442-445).
+  const S one = (S)1;
+  return (one - c.fx) * (one - c.fy) * vc + (one - c.fx) * c.fy * vf + c.fx * (one - c.fy) * vl + c.fx * c.fy * vfl;
+}
+
+template <typename S, int G, int PPL, int INTEG>
+__global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a) {
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = tid / G;
+  const int gl = tid % G;
+  if (b >= a.B) return;  // whole groups leave together; live groups never read dead lanes
+  const S one = (S)1, zero = (S)0;
+  const int HW = a.H * a.W, last = HW - 1;
+  const S* zmap = a.z + (a.map_shared ? 0 : (size_t)b * HW);
+  const S* mumap = a.mu ? a.mu + (a.map_shared ? 0 : (size_t)b * HW) : nullptr;
+
+  // this lane's contact points
+  S P[PPL][3];
+  int part[PPL];
+  bool act[PPL];
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) {
+    int i = gl + j * G;
+    act[j] = i < a.N;
+    int ii = act[j] ? i : 0;
+    P[j][0] = a.points[ii * 3 + 0];
+    P[j][1] = a.points[ii * 3 + 1];
+    P[j][2] = a.points[ii * 3 + 2];
+    part[j] = act[j] ? a.part[ii] : -1;
+  }
+
+  // state, replicated across the group
+  S x[3], xd[3], R[9], w[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    x[c] = a.x0[b * 3 + c];
+    xd[c] = a.xd0[b * 3 + c];
+    w[c] = a.w0[b * 3 + c];
+  }
+#pragma unroll
+  for (int c = 0; c < 9; ++c) R[c] = a.R0[b * 9 + c];
+
+  // start at the terrain height: x.z <- mean_i interp(z, (P R^T + x)_i)   (dphysics.py:567-571)
+  if (!a.skip_snap) {
+    S acc = zero;
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      S px = P[j][0] * R[0] + P[j][1] * R[1] + P[j][2] * R[2] + x[0];
+      S py = P[j][0] * R[3] + P[j][1] * R[4] + P[j][2] * R[5] + x[1];
+      Cell<S> c = locate(px, py, a.d_max, a.res, a.H, last);
+      S v = blend(c, zmap[c.ic], zmap[c.i_f], zmap[c.il], zmap[c.ifl]);
+      acc += act[j] ? v : zero;
+    }
+    acc = group_sum<G>(acc);
+    x[2] = acc / (S)a.N;
+    if (gl == 0) a.x0[b * 3 + 2] = x[2];
+  }
+
+  const size_t row_stride = (a.layout == MF_LAYOUT_TIME_MAJOR) ? (size_t)a.B : 1;  // rows between consecutive t
+  const size_t row0 = (a.layout == MF_LAYOUT_TIME_MAJOR) ? (size_t)b : (size_t)b * a.T;
+
+  S accFs[PPL][3], accFf[PPL][3];  // ODEINT: running impulses (extended state, dphysics.py:506-509)
+#pragma unroll
+  for (int j = 0; j < PPL; ++j)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) accFs[j][c] = accFf[j][c] = zero;
+
+  // Stores of one output row.  Lanes 0/1/2 of the group write (Xs + R row 0) / (Xds + R row 1) / (Omegas + R row 2).
+  auto emit_state = [&](size_t row) {
+    if (gl < 3) {
+      S v0, v1, v2;
+      S* dst;
+      if (gl == 0) {
+        v0 = x[0] + R[2] * a.sink;  // Xs += Rs[..., :, 2] * m g / (k + 1e-6)   (dphysics.py:587-589)
+        v1 = x[1] + R[5] * a.sink;
+        v2 = x[2] + R[8] * a.sink;
+        dst = a.Xs;
+      } else if (gl == 1) {
+        v0 = xd[0]; v1 = xd[1]; v2 = xd[2];
+        dst = a.Xds;
+      } else {
+        v0 = w[0]; v1 = w[1]; v2 = w[2];
+        dst = a.Om;
+      }
+      S* p = dst + row * 3;
+      p[0] = v0; p[1] = v1; p[2] = v2;
+      S* q = a.Rs + row * 9 + gl * 3;
+      q[0] = R[gl * 3 + 0]; q[1] = R[gl * 3 + 1]; q[2] = R[gl * 3 + 2];
+      if (gl == 0 && a.Xraw) {
+        S* r = a.Xraw + row * 3;
+        r[0] = x[0]; r[1] = x[1]; r[2] = x[2];
+      }
+    }
+  };
+  auto emit_forces = [&](size_t row, const S (*fs)[3], const S (*ff)[3]) {
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      if (act[j]) {
+        size_t o = (row * a.N + (gl + j * G)) * 3;
+        a.Fs[o + 0] = fs[j][0]; a.Fs[o + 1] = fs[j][1]; a.Fs[o + 2] = fs[j][2];
+        a.Ff[o + 0] = ff[j][0]; a.Ff[o + 1] = ff[j][1]; a.Ff[o + 2] = ff[j][2];
+      }
+    }
+  };
+
+  int n_steps = a.T;
+  if (INTEG == MF_INTEG_ODEINT_EULER) {
+    emit_state(row0);           // y_0
+    emit_forces(row0, accFs, accFf);
+    n_steps = a.T - 1;
+  }
+
+  const S* ctrl = a.controls + (size_t)b * a.T * 2;
+  S cv = ctrl[0], cw = ctrl[1];
+
+  for (int n = 0; n < n_steps; ++n) {
+    // prefetch the next step's controls (the lookup argmin|t - ts| is the step index on the grid, dphysics.py:183)
+    const int nn = min(n + 1, a.T - 1);
+    const S cv_next = ctrl[nn * 2 + 0], cw_next = ctrl[nn * 2 + 1];
+
+    S r[PPL][3], vp[PPL][3], nrm[PPL][3], muq[PPL], cw8[PPL], Fr[PPL][3];
+    S csum = zero;
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      // p = P R^T + x ; r = p - x   (:200)
+      S px = P[j][0] * R[0] + P[j][1] * R[1] + P[j][2] * R[2] + x[0];
+      S py = P[j][0] * R[3] + P[j][1] * R[4] + P[j][2] * R[5] + x[1];
+      S pz = P[j][0] * R[6] + P[j][1] * R[7] + P[j][2] * R[8] + x[2];
+      r[j][0] = px - x[0]; r[j][1] = py - x[1]; r[j][2] = pz - x[2];
+      // v_p = xd + w x r   (:204)
+      vp[j][0] = xd[0] + (w[1] * r[j][2] - w[2] * r[j][1]);
+      vp[j][1] = xd[1] + (w[2] * r[j][0] - w[0] * r[j][2]);
+      vp[j][2] = xd[2] + (w[0] * r[j][1] - w[1] * r[j][0]);
+      // height, normal, friction under the point   (:211-216)
+      Cell<S> c = locate(px, py, a.d_max, a.res, a.H, last);
+      S zc = zmap[c.ic], zf = zmap[c.i_f], zl = zmap[c.il], zfl = zmap[c.ifl];
+      S mc = one, mf_ = one, ml = one, mfl = one;
+      if (mumap) { mc = mumap[c.ic]; mf_ = mumap[c.i_f]; ml = mumap[c.il]; mfl = mumap[c.ifl]; }
+      S zq = blend(c, zc, zf, zl, zfl);
+      muq[j] = blend(c, mc, mf_, ml, mfl);
+      S gx = (zf - zc) / a.res, gy = (zl - zc) / a.res;
+      S nl = mf_max(mf_sqrt(gx * gx + gy * gy + one), (S)1e-6);
+      nrm[j][0] = -gx / nl; nrm[j][1] = -gy / nl; nrm[j][2] = one / nl;
+      // soft contact + spring-damper along the normal   (:220-230)
+      S dh = pz - zq;
+      S cj = one / (one + mf_exp((S)10 * dh));  // sigmoid(-10 dh)
+      cj = act[j] ? cj : zero;
+      cw8[j] = cj;
+      csum += cj;
+      S vn = vp[j][0] * nrm[j][0] + vp[j][1] * nrm[j][1] + vp[j][2] * nrm[j][2];
+      S A = a.k * dh + a.damp * vn;
+      Fr[j][0] = -(A * nrm[j][0]); Fr[j][1] = -(A * nrm[j][1]); Fr[j][2] = -(A * nrm[j][2]);
+    }
+    csum = group_sum<G>(csum);  // n_contact_pts (:231)
+
+    // thrust direction = normalized first column of R   (:237)
+    S el = mf_max(mf_sqrt(R[0] * R[0] + R[3] * R[3] + R[6] * R[6]), (S)1e-6);
+    S e0 = R[0] / el, e1 = R[3] / el, e2 = R[6] / el;
+    S tv_lo = cv - cw * a.half_ly, tv_hi = cv + cw * a.half_ly;  // (:75-104)
+
+    S sFr[3] = {zero, zero, zero}, sFf[3] = {zero, zero, zero}, sTau[3] = {zero, zero, zero};
+    S Ff[PPL][3];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Fr[j][c] = mf_clamp(Fr[j][c] * cw8[j] / csum, -a.mg, a.mg);  // (:232-233)
+      S Nn = mf_sqrt(Fr[j][0] * Fr[j][0] + Fr[j][1] * Fr[j][1] + Fr[j][2] * Fr[j][2]);          // (:238)
+      S tv = (part[j] < 0) ? zero : ((part[j] & 1) ? tv_hi : tv_lo);
+      S s0 = muq[j] * (tv * e0 - vp[j][0]);  // slip (:247); cmd = 0 for non-driving points
+      S s1 = muq[j] * (tv * e1 - vp[j][1]);
+      S s2 = muq[j] * (tv * e2 - vp[j][2]);
+      S sn = s0 * nrm[j][0] + s1 * nrm[j][1] + s2 * nrm[j][2];
+      Ff[j][0] = mf_clamp(Nn * (s0 - sn * nrm[j][0]), -a.mg, a.mg);  // (:248-251)
+      Ff[j][1] = mf_clamp(Nn * (s1 - sn * nrm[j][1]), -a.mg, a.mg);
+      Ff[j][2] = mf_clamp(Nn * (s2 - sn * nrm[j][2]), -a.mg, a.mg);
+      if (!act[j]) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Fr[j][c] = Ff[j][c] = zero;
+      }
+      S f0 = Fr[j][0] + Ff[j][0], f1 = Fr[j][1] + Ff[j][1], f2 = Fr[j][2] + Ff[j][2];
+      sTau[0] += r[j][1] * f2 - r[j][2] * f1;  // r x (Fs + Ff)   (:255)
+      sTau[1] += r[j][2] * f0 - r[j][0] * f2;
+      sTau[2] += r[j][0] * f1 - r[j][1] * f0;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { sFr[c] += Fr[j][c]; sFf[c] += Ff[j][c]; }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      sFr[c] = group_sum<G>(sFr[c]);
+      sFf[c] = group_sum<G>(sFf[c]);
+      sTau[c] = group_sum<G>(sTau[c]);
+    }
+    // omega_d = clamp(I^-1 tau) (body-frame I with world-frame torque, as the reference)   (:256-257)
+    S wd[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      wd[c] = mf_clamp(a.Iinv[c * 3 + 0] * sTau[0] + a.Iinv[c * 3 + 1] * sTau[1] + a.Iinv[c * 3 + 2] * sTau[2],
+                       -a.omega_max, a.omega_max);
+    // xdd = (m g ghat + sum Fs + sum Ff) / m   (:264-266)
+    S xdd[3] = {(sFr[0] + sFf[0]) / a.mass, (sFr[1] + sFf[1]) / a.mass, ((-a.mg + sFr[2]) + sFf[2]) / a.mass};
+
+    const size_t row = row0 + (size_t)(INTEG == MF_INTEG_ODEINT_EULER ? n + 1 : n) * row_stride;
+    if (INTEG == MF_INTEG_DYNAMICS) {
+      // update_state (:274-288): xd += xdd h ; x += xd_new h ; w += wd h ; R <- R (I + K sin + K^2 (1 - cos))
+      const S h = a.dt;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        xd[c] = xd[c] + xdd[c] * h;
+        x[c] = x[c] + xd[c] * h;
+        w[c] = w[c] + wd[c] * h;
+      }
+      S th = mf_sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+      S den = mf_max(th, (S)1e-6);
+      S k0 = w[0] / den, k1 = w[1] / den, k2 = w[2] / den;  // K = [w]x / max(|w|, eps)
+      S sn, cs;
+      mf_sincos(th * h, &sn, &cs);
+      S oc = one - cs;
+      // K = [[0,-k2,k1],[k2,0,-k0],[-k1,k0,0]];  K^2 = k k^T - |k|^2 I (computed as the explicit product)
+      S K[9] = {zero, -k2, k1, k2, zero, -k0, -k1, k0, zero};
+      S M[9];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j2 = 0; j2 < 3; ++j2) {
+          S kk = K[i * 3 + 0] * K[0 * 3 + j2] + K[i * 3 + 1] * K[1 * 3 + j2] + K[i * 3 + 2] * K[2 * 3 + j2];
+          M[i * 3 + j2] = ((i == j2 ? one : zero) + K[i * 3 + j2] * sn) + kk * oc;
+        }
+      S Rn[9];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j2 = 0; j2 < 3; ++j2)
+          Rn[i * 3 + j2] = R[i * 3 + 0] * M[0 * 3 + j2] + R[i * 3 + 1] * M[1 * 3 + j2] + R[i * 3 + 2] * M[2 * 3 + j2];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) R[c] = Rn[c];
+      emit_state(row);
+      emit_forces(row, Fr, Ff);
+    } else {
+      // torchdiffeq fixed-grid euler: y_{n+1} = y_n + (t_{n+1} - t_n) f(t_n, y_n), f = (xd, xdd, [w]x R, wd, Fs, Ff)
+      const S h = a.ts[n + 1] - a.ts[n];
+      S dR[9];
+#pragma unroll
+      for (int j2 = 0; j2 < 3; ++j2) {
+        dR[0 * 3 + j2] = w[1] * R[2 * 3 + j2] - w[2] * R[1 * 3 + j2];
+        dR[1 * 3 + j2] = w[2] * R[0 * 3 + j2] - w[0] * R[2 * 3 + j2];
+        dR[2 * 3 + j2] = w[0] * R[1 * 3 + j2] - w[1] * R[0 * 3 + j2];
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        x[c] = x[c] + h * xd[c];  // OLD xd moves x
+        xd[c] = xd[c] + h * xdd[c];
+        w[c] = w[c] + h * wd[c];
+      }
+#pragma unroll
+      for (int c = 0; c < 9; ++c) R[c] = R[c] + h * dR[c];
+#pragma unroll
+      for (int j = 0; j < PPL; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          accFs[j][c] = accFs[j][c] + h * Fr[j][c];
+          accFf[j][c] = accFf[j][c] + h * Ff[j][c];
+        }
+      emit_state(row);
+      emit_forces(row, accFs, accFf);
+    }
+    cv = cv_next; cw = cw_next;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+template <typename S, int G, int PPL>
+static int launch_gp(const RolloutArgs<S>& a, int integ, int block, hipStream_t st) {
+  const long long threads = (long long)a.B * G;
+  const unsigned grid = (unsigned)((threads + block - 1) / block);
+  if (integ == MF_INTEG_DYNAMICS)
+    hipLaunchKernelGGL((rollout_fwd_kernel<S, G, PPL, MF_INTEG_DYNAMICS>), dim3(grid), dim3(block), 0, st, a);
+  else
+    hipLaunchKernelGGL((rollout_fwd_kernel<S, G, PPL, MF_INTEG_ODEINT_EULER>), dim3(grid), dim3(block), 0, st, a);
+  hipError_t e = hipGetLastError();
+  MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("rollout_fwd launch: ") + hipGetErrorString(e));
+  return MF_OK;
+}
+
+template <typename S>
+int rollout_fwd(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, void* stream) {
+  MF_REQUIRE(d && p, MF_ERR_INVALID, "rollout_fwd: null descriptor");
+  MF_REQUIRE(d->B > 0 && d->N > 0 && d->H > 1 && d->W > 0, MF_ERR_INVALID, "rollout_fwd: B, N, H, W must be positive");
+  MF_REQUIRE(d->T >= 1, MF_ERR_INVALID, "rollout_fwd: T must be >= 1");
+  MF_REQUIRE(d->n_tracks == 2 || d->n_tracks == 4, MF_ERR_INVALID, "n_tracks must be 2 or 4");
+  MF_REQUIRE(d->integrator == MF_INTEG_DYNAMICS || d->integrator == MF_INTEG_ODEINT_EULER, MF_ERR_INVALID,
+             "rollout_fwd: unknown integrator");
+  MF_REQUIRE(d->layout == MF_LAYOUT_BATCH_MAJOR || d->layout == MF_LAYOUT_TIME_MAJOR, MF_ERR_INVALID,
+             "rollout_fwd: unknown layout");
+  MF_REQUIRE(p->z && p->controls && p->ts && p->points && p->part && p->x0 && p->xd0 && p->R0 && p->w0, MF_ERR_INVALID,
+             "rollout_fwd: null input buffer");
+  MF_REQUIRE(p->Xs && p->Xds && p->Rs && p->Omegas && p->Fs && p->Ff, MF_ERR_INVALID, "rollout_fwd: null output buffer");
+  MF_REQUIRE((long long)d->H * d->W < (1ll << 30), MF_ERR_UNSUPPORTED, "rollout_fwd: grid too large");
+  MF_REQUIRE(d->N <= 512, MF_ERR_UNSUPPORTED, "rollout_fwd: more than 512 contact points");
+  int block = d->block ? d->block : 64;
+  MF_REQUIRE(block == 64 || block == 128 || block == 256, MF_ERR_INVALID, "rollout_fwd: block must be 64, 128 or 256");
+
+  RolloutArgs<S> a;
+  a.B = d->B; a.T = d->T; a.N = d->N; a.H = d->H; a.W = d->W;
+  a.n_tracks = d->n_tracks; a.layout = d->layout; a.map_shared = d->map_shared; a.skip_snap = d->skip_snap;
+  a.mass = (S)d->mass; a.mg = (S)(d->mass * d->gravity); a.k = (S)d->stiffness; a.damp = (S)d->damping;
+  a.omega_max = (S)d->omega_max; a.res = (S)d->grid_res; a.d_max = (S)d->d_max; a.dt = (S)d->dt;
+  a.half_ly = (S)(d->robot_size_y / 2.0);
+  a.sink = (S)(d->mass * d->gravity / (d->stiffness + 1e-6));
+  for (int i = 0; i < 9; ++i) a.Iinv[i] = (S)d->Iinv[i];
+  a.z = (const S*)p->z; a.mu = (const S*)p->mu; a.controls = (const S*)p->controls; a.ts = (const S*)p->ts;
+  a.points = (const S*)p->points; a.part = p->part;
+  a.x0 = (S*)p->x0; a.xd0 = (const S*)p->xd0; a.R0 = (const S*)p->R0; a.w0 = (const S*)p->w0;
+  a.Xs = (S*)p->Xs; a.Xds = (S*)p->Xds; a.Rs = (S*)p->Rs; a.Om = (S*)p->Omegas; a.Fs = (S*)p->Fs; a.Ff = (S*)p->Ff;
+  a.Xraw = (S*)p->Xraw;
+
+  hipStream_t st = (hipStream_t)stream;
+  const int N = d->N, integ = d->integrator;
+  if (N <= 4) return launch_gp<S, 4, 1>(a, integ, block, st);
+  if (N <= 8) return launch_gp<S, 4, 2>(a, integ, block, st);
+  if (N <= 16) return launch_gp<S, 16, 1>(a, integ, block, st);
+  if (N <= 32) return launch_gp<S, 16, 2>(a, integ, block, st);
+  if (N <= 64) return launch_gp<S, 64, 1>(a, integ, block, st);
+  if (N <= 128) return launch_gp<S, 64, 2>(a, integ, block, st);
+  if (N <= 256) return launch_gp<S, 64, 4>(a, integ, block, st);
+  return launch_gp<S, 64, 8>(a, integ, block, st);
+}
+
+}  // namespace mf
+
+extern "C" int mf_rollout_fwd_f32(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, void* s) {
+  return mf::rollout_fwd<float>(d, p, s);
+}
+extern "C" int mf_rollout_fwd_f64(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, void* s) {
+  return mf::rollout_fwd<double>(d, p, s);
+}

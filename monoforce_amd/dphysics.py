@@ -1,0 +1,298 @@
+"""DPhysics: differentiable-physics trajectory rollout on the MI355X HIP kernels.
+
+Host-side mirror of `/root/reference/monoforce/src/monoforce/models/traj_predictor/dphysics.py` (class `DPhysics`
+:144-605 and the module-level helpers).  Same constructor, same `forward(z_grid, controls, joint_angles=None,
+state=None, vis=False, friction=None)` signature, same return structure
+`((Xs, Xds, Rs, Omegas), (F_springs, F_frictions))`, same shape asserts and messages, same side effects
+(`state[0][:, 2]` is overwritten with the terrain height, `self.ts` is truncated to the controls' length).
+What differs is where the work happens: the whole T-step scan is ONE kernel launch through the C ABI
+(`mf_rollout_fwd_*`, include/monoforce_hip.h); there is no CPU path.
+
+Outputs are `[B, T, ...]` *views* of time-major buffers -- exactly the layout the reference's default integrator
+returns (`dphysics.py:515-526` permutes torchdiffeq's `[T, B, ...]` stacks); pass `contiguous_outputs=True` to the
+constructor to get batch-major contiguous tensors instead.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .dphys_config import DPhysConfig
+
+__all__ = ['DPhysics', 'generate_controls', 'vw_to_track_vels', 'inertia_tensor', 'normalized', 'skew_symmetric']
+
+
+# ------------------------------------------------------------------------------------------------------------
+# module-level helpers of the reference API (plain torch; tiny, host side)
+# ------------------------------------------------------------------------------------------------------------
+def normalized(x, eps=1e-6, dim=-1):
+    """x / max(|x|, eps) (dphysics.py:7-19)."""
+    return x / torch.clamp(torch.norm(x, dim=dim, keepdim=True), min=eps)
+
+
+def skew_symmetric(v):
+    """[v]x for v[B,3] (dphysics.py:22-40)."""
+    assert v.dim() == 2 and v.shape[1] == 3
+    U = torch.zeros(v.shape[0], 3, 3, device=v.device, dtype=v.dtype)
+    U[:, 0, 1], U[:, 0, 2], U[:, 1, 2] = -v[:, 2], v[:, 1], -v[:, 0]
+    U[:, 1, 0], U[:, 2, 0], U[:, 2, 1] = v[:, 2], -v[:, 1], v[:, 0]
+    return U
+
+
+def generate_controls(n_trajs=10, time_horizon=5.0, dt=0.01, v_range=(-1.0, 1.0), w_range=(-1.0, 1.0)):
+    """Constant-in-time (v, w) per trajectory, uniformly sampled; returns ([n, N, 2], stamps[N]) (dphysics.py:42-72)."""
+    N = int(time_horizon / dt)
+    stamps = torch.linspace(0, time_horizon, N)
+    v = torch.rand(n_trajs) * (v_range[1] - v_range[0]) + v_range[0]
+    w = torch.rand(n_trajs) * (w_range[1] - w_range[0]) + w_range[0]
+    vw = torch.stack([v, w], dim=-1)                       # [n, 2]
+    return vw.unsqueeze(1).repeat(1, N, 1), stamps
+
+
+def vw_to_track_vels(v, w, robot_size, n_tracks):
+    """(v, w) -> track speeds: [L, R] or [FL, FR, RL, RR] (dphysics.py:75-104)."""
+    Ly = robot_size[1]
+    if n_tracks == 2:
+        return torch.stack([v - w * (Ly / 2.0), v + w * (Ly / 2.0)], dim=-1)
+    if n_tracks == 4:
+        lo, hi = v - w * Ly / 2.0, v + w * Ly / 2.0
+        return torch.stack([lo, hi, lo, hi], dim=-1)
+    raise ValueError('n_tracks must be 2 or 4')
+
+
+def inertia_tensor(mass, points):
+    """Inertia [B,3,3] of N equal point masses (total `mass`) about the body origin, points[B,N,3] (dphysics.py:107-141)."""
+    assert points.dim() == 3
+    mp = mass / points.shape[1]
+    x, y, z = points.unbind(-1)
+    d = [(mp * (y ** 2 + z ** 2)).sum(1), (mp * (x ** 2 + z ** 2)).sum(1), (mp * (x ** 2 + y ** 2)).sum(1)]
+    xy, xz, yz = -(mp * x * y).sum(1), -(mp * x * z).sum(1), -(mp * y * z).sum(1)
+    I = torch.stack([torch.stack([d[0], xy, xz], 1), torch.stack([xy, d[1], yz], 1), torch.stack([xz, yz, d[2]], 1)], 1)
+    assert I.shape == (points.shape[0], 3, 3)
+    return I
+
+
+# ------------------------------------------------------------------------------------------------------------
+# the op
+# ------------------------------------------------------------------------------------------------------------
+def _scalar_suffix(dtype):
+    if dtype == torch.float32:
+        return 'f32'
+    if dtype == torch.float64:
+        return 'f64'
+    raise TypeError(f'DPhysics computes in float32 or float64, got {dtype}')
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _is_shared_map(t):
+    """True if a [B,H,W] map is one [H,W] map broadcast over the batch (`expand`, stride 0) -- read once, not B times."""
+    return t.dim() == 3 and (t.shape[0] == 1 or t.stride(0) == 0)
+
+
+class _RolloutFn(torch.autograd.Function):
+    """forward = mf_rollout_fwd_*; backward = mf_rollout_bwd_* (reverse-time adjoint of the same scan)."""
+
+    @staticmethod
+    def forward(ctx, mod, z, mu, controls, x0, xd0, R0, w0, ts, want_grad):
+        desc, keep = mod._make_desc(z, mu, controls)
+        B, T, N = desc.B, desc.T, desc.N
+        dt, dev = z.dtype, z.device
+        tm = desc.layout == _lib.MF_LAYOUT_TIME_MAJOR
+        lead = (T, B) if tm else (B, T)
+        new = lambda *tail: torch.empty(*lead, *tail, dtype=dt, device=dev)  # noqa: E731
+        Xs, Xds, Rs, Om, Fs, Ff = new(3), new(3), new(3, 3), new(3), new(N, 3), new(N, 3)
+        Xraw = new(3) if want_grad else None
+        bufs = _lib.MfRolloutFwdBufs(
+            z=_lib.ptr(keep['z']), mu=_lib.ptr(keep['mu']), controls=_lib.ptr(controls), ts=_lib.ptr(ts),
+            points=_lib.ptr(keep['points']), part=_lib.ptr(mod._part_dev(dev)),
+            x0=_lib.ptr(x0), xd0=_lib.ptr(xd0), R0=_lib.ptr(R0), w0=_lib.ptr(w0),
+            Xs=_lib.ptr(Xs), Xds=_lib.ptr(Xds), Rs=_lib.ptr(Rs), Omegas=_lib.ptr(Om), Fs=_lib.ptr(Fs), Ff=_lib.ptr(Ff),
+            Xraw=_lib.ptr(Xraw))
+        fn = getattr(_lib.lib(), 'mf_rollout_fwd_' + _scalar_suffix(dt))
+        with torch.cuda.device(dev):
+            _lib.check(fn(C.byref(desc), C.byref(bufs), _stream_ptr(dev)), 'mf_rollout_fwd')
+        outs = (Xs, Xds, Rs, Om, Fs, Ff)
+        if tm:
+            outs = tuple(o.transpose(0, 1) for o in outs)
+        if want_grad:
+            ctx.mod, ctx.desc, ctx.keep = mod, desc, keep
+            ctx.z_shape, ctx.mu_given = z.shape, mu is not None
+            ctx.save_for_backward(controls, x0.clone(), xd0, R0, w0, ts, Xraw, Xds, Rs, Om)
+        return outs
+
+    @staticmethod
+    def backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf):
+        from .dphysics_bwd import rollout_backward
+        return rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf)
+
+
+class DPhysics(torch.nn.Module):
+    """Drop-in for the reference `DPhysics` (dphysics.py:144); no parameters, all state is configuration."""
+
+    def __init__(self, dphys_cfg=None, device='cpu', contiguous_outputs=False, block=0, snap_to_terrain=True):
+        super().__init__()
+        self.dphys_cfg = dphys_cfg if dphys_cfg is not None else DPhysConfig()
+        self.device = device
+        self.x_points = self.dphys_cfg.robot_points.to(self.device).unsqueeze(0)         # (1, N, 3)
+        self.I = inertia_tensor(mass=self.dphys_cfg.robot_mass, points=self.x_points)
+        self.I_inv = torch.linalg.inv(self.I)
+        self.z_grid = None
+        self.friction = None
+        self.stiffness = self.dphys_cfg.stiffness
+        self.damping = self.dphys_cfg.damping
+        self.controls = None
+        self.joint_angles = None
+        # time grid snapshot at construction, like the reference (dphysics.py:166-167)
+        T, dt = self.dphys_cfg.traj_sim_time, self.dphys_cfg.dt
+        self._ts_full_len = int(T / dt)
+        self._ts_T = T
+        self.ts = torch.linspace(0, T, self._ts_full_len).to(self.device)
+        self.contiguous_outputs = contiguous_outputs
+        self.block = block
+        self.snap_to_terrain = snap_to_terrain     # False: continue from `state` as is (no reference equivalent)
+        self._cache = {}
+
+    # -- constants marshalled for the C ABI ---------------------------------------------------------------
+    def _part_dev(self, dev):
+        key = ('part', str(dev))
+        if key not in self._cache:
+            N = self.x_points.shape[1]
+            part = torch.full((N,), -1, dtype=torch.int32)
+            for j, mask in enumerate(self.dphys_cfg.driving_parts):       # later masks overwrite earlier (:243-246)
+                m = torch.as_tensor(mask).cpu()
+                assert m.dim() == 1 and m.shape[0] == N
+                part[m] = j
+            self._cache[key] = part.to(dev)
+        return self._cache[key]
+
+    def _points_dev(self, dev, dtype):
+        key = ('pts', str(dev), dtype)
+        if key not in self._cache:
+            self._cache[key] = self.dphys_cfg.robot_points.to(device=dev, dtype=dtype).contiguous()
+        return self._cache[key]
+
+    def _iinv(self, dtype):
+        key = ('iinv', dtype)
+        if key not in self._cache:
+            P = self.dphys_cfg.robot_points.detach().cpu().to(dtype).unsqueeze(0)
+            self._cache[key] = torch.linalg.inv(inertia_tensor(self.dphys_cfg.robot_mass, P))[0].double().flatten().tolist()
+        return self._cache[key]
+
+    def _make_desc(self, z, mu, controls):
+        cfg = self.dphys_cfg
+        shared = _is_shared_map(z) and (mu is None or _is_shared_map(mu))
+        if shared:
+            zc = z[0].contiguous()
+            muc = None if mu is None else mu[0].contiguous()
+        else:
+            zc = z.contiguous()
+            muc = None if mu is None else mu.contiguous()
+        _, H, W = z.shape
+        integ = _lib.MF_INTEG_ODEINT_EULER if cfg.use_odeint else _lib.MF_INTEG_DYNAMICS
+        if cfg.integration_mode != 'euler':
+            # the reference's 'rk4' is a degenerate formula on the custom loop and an adaptive-free torchdiffeq solver on
+            # the other; neither is part of the parity scope
+            raise ValueError(f'Unknown integration mode: {cfg.integration_mode}' if cfg.integration_mode != 'rk4' else
+                             "integration_mode 'rk4' is not supported by the HIP rollout (only 'euler')")
+        desc = _lib.MfRolloutDesc(
+            B=controls.shape[0], T=controls.shape[1], N=self.x_points.shape[1], H=H, W=W,
+            n_tracks=len(cfg.driving_parts), integrator=integ,
+            layout=_lib.MF_LAYOUT_BATCH_MAJOR if self.contiguous_outputs else _lib.MF_LAYOUT_TIME_MAJOR,
+            map_shared=int(shared), block=self.block, skip_snap=int(not self.snap_to_terrain),
+            mass=float(cfg.robot_mass), gravity=float(cfg.gravity), stiffness=float(self.stiffness),
+            damping=float(self.damping), omega_max=float(cfg.omega_max), grid_res=float(cfg.grid_res),
+            d_max=float(cfg.d_max), dt=float(cfg.dt), robot_size_y=float(cfg.robot_size[1]))
+        for i, v in enumerate(self._iinv(z.dtype)):
+            desc.Iinv[i] = v
+        keep = dict(z=zc, mu=muc, points=self._points_dev(z.device, z.dtype))
+        return desc, keep
+
+    # -- reference API --------------------------------------------------------------------------------------
+    def dphysics(self, z_grid, controls, joint_angles=None, state=None, friction=None):
+        """Simulate the robot on the terrain (dphysics.py:530-594).
+
+        z_grid (B,H,W), controls (B,N,2), joint_angles (B,N,4) or None, state=(x,xd,R,omega) or None, friction (B,H,W).
+        Returns ((Xs,Xds,Rs,Omegas), (F_springs,F_frictions)).
+        """
+        cfg = self.dphys_cfg
+        dev = torch.device(self.device)
+        dt_, T_ = cfg.dt, cfg.traj_sim_time
+        batch_size = z_grid.shape[0]
+        z_grid = z_grid.to(dev)
+        _lib.require_hip_tensor(z_grid, 'z_grid')
+        dtype = z_grid.dtype
+        controls = controls.to(device=dev, dtype=dtype)
+
+        if state is None:                                                            # (:554-559)
+            x = torch.zeros(batch_size, 3, dtype=dtype, device=dev)
+            xd = torch.zeros_like(x)
+            xd[:, 0] = controls[:, 0, 0]
+            R = torch.eye(3, dtype=dtype, device=dev).repeat(batch_size, 1, 1)
+            omega = torch.zeros_like(x)
+            omega[:, 2] = controls[:, 0, 1]
+            state = (x, xd, R, omega)
+        if friction is not None:
+            friction = friction.to(device=dev, dtype=dtype)
+        self.z_grid = z_grid
+        self.friction = friction if friction is not None else cfg.friction      # all-ones default (:562), never expanded
+
+        N_ts = min(int(T_ / dt_), controls.shape[1])                                 # (:573)
+        B = state[0].shape[0]
+        assert controls.shape == (B, N_ts, 2), f'Controls shape {controls.shape} != {(B, N_ts, 2)}'
+        self.controls = controls
+        if joint_angles is not None:
+            assert joint_angles.shape == (B, N_ts, 4), f'Joint angles shape {joint_angles.shape} != {(B, N_ts, 4)}'
+            if cfg.robot == 'marv' and not torch.allclose(joint_angles, torch.zeros_like(joint_angles)):
+                raise NotImplementedError('non-zero flipper joint angles (update_joints, dphysics.py:326-358) are not '
+                                          'implemented in the HIP rollout yet')
+        self.joint_angles = joint_angles
+        self.ts = self.ts[:N_ts]                                                     # permanent, like the reference (:581)
+        ts = self._time_grid(N_ts, dtype, dev)
+
+        # kernel inputs: contiguous, right dtype; x0's z component is written by the kernel (:567-571)
+        x_in = state[0]
+        x0 = x_in.detach().to(device=dev, dtype=dtype).contiguous()
+        aliased = x0.data_ptr() == x_in.data_ptr()
+        if aliased and x_in.requires_grad:
+            x0 = x0.clone(); aliased = False
+        xd0, R0, w0 = (s.to(device=dev, dtype=dtype).contiguous() for s in state[1:])
+        want_grad = torch.is_grad_enabled() and any(
+            t is not None and t.requires_grad for t in (z_grid, friction, controls, xd0, R0, w0))
+        outs = _RolloutFn.apply(self, z_grid, friction, controls.contiguous(), x0, xd0, R0, w0, ts, want_grad)
+        if not aliased:
+            with torch.no_grad():
+                x_in[..., 2] = x0[..., 2].to(device=x_in.device, dtype=x_in.dtype)   # the reference's in-place write
+        Xs, Xds, Rs, Omegas, F_springs, F_frictions = outs
+        return (Xs, Xds, Rs, Omegas), (F_springs, F_frictions)
+
+    def _time_grid(self, n, dtype, dev):
+        key = ('ts', n, dtype, str(dev))
+        if key not in self._cache:
+            self._cache[key] = torch.linspace(0, self._ts_T, self._ts_full_len, dtype=dtype)[:n].to(dev).contiguous()
+        return self._cache[key]
+
+    def forward(self, z_grid, controls, joint_angles=None, state=None, vis=False, friction=None):
+        states, forces = self.dphysics(z_grid=z_grid, controls=controls, joint_angles=joint_angles, state=state,
+                                       friction=friction)
+        if vis:
+            with torch.no_grad():
+                self.visualize(states=states, z_grid=z_grid)
+        return states, forces
+
+    def visualize(self, states, z_grid, forces=None, states_gt=None, friction=None):
+        """Matplotlib stand-in for the reference's mayavi animation (dphysics.py:607-669): plots one rollout's path."""
+        import matplotlib.pyplot as plt
+        Xs = states[0].detach().cpu().numpy()
+        b = 0
+        plt.figure()
+        plt.imshow(z_grid[b].detach().cpu().numpy().T, origin='lower',
+                   extent=[-self.dphys_cfg.d_max, self.dphys_cfg.d_max] * 2, cmap='terrain')
+        plt.plot(Xs[b, :, 0], Xs[b, :, 1], 'k-')
+        if states_gt is not None:
+            G = states_gt[0].detach().cpu().numpy()
+            plt.plot(G[b, :, 0], G[b, :, 1], 'b--')
+        plt.xlabel('x [m]'); plt.ylabel('y [m]')
+        plt.show()

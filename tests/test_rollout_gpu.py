@@ -1,0 +1,195 @@
+"""Parity of the HIP rollout (through the C ABI) against the reference's golden vectors and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as hp
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def make_dphysics(points, masks, integ, grid_res, d_max, **kw):
+    from monoforce_amd.dphys_config import DPhysConfig
+    from monoforce_amd.dphysics import DPhysics
+    n_tracks = len(masks)
+    cfg = DPhysConfig(robot='tradr' if n_tracks == 2 else 'husky', grid_res=grid_res, robot_points=points, driving_parts=masks)
+    cfg.robot_mass = 40.0
+    cfg.damping = float(np.sqrt(4 * cfg.robot_mass * cfg.stiffness))
+    cfg.d_max = d_max
+    cfg.use_odeint = (integ == 1)
+    return DPhysics(cfg, device=DEV, **kw)
+
+
+def run_hip(dp, z, ctrl, state, mu):
+    st = None if state is None else tuple(s.clone().to(DEV) for s in state)
+    states, forces = dp(z_grid=z.to(DEV), controls=ctrl.to(DEV), state=st, friction=None if mu is None else mu.to(DEV))
+    torch.cuda.synchronize()
+    return [o.cpu() for o in list(states) + list(forces)], st
+
+
+@pytest.mark.parametrize('name', ['A', 'B', 'C'])
+@pytest.mark.parametrize('tag', ['f32', 'f64'])
+@pytest.mark.parametrize('integ', [0, 1])
+def test_small_rollout_vs_reference_golden(name, tag, integ):
+    """B<=3, T=48, 32x32: all six outputs of the HIP path vs the reference's own outputs."""
+    g = hp.load('rollout_small')
+    dt = hp.DT[tag]
+    pts, masks, z, ctrl, state, mu = hp.small_case(g, name, dt)
+    dp = make_dphysics(pts, masks, integ, hp.SMALL['grid_res'], hp.SMALL['d_max'])
+    outs, st = run_hip(dp, z, ctrl, state, mu)
+    # float64: agreement to rounding.  float32: north_star's bar, <= 1e-4 rel on poses and forces.
+    tol = 1e-9 if tag == 'f64' else 1e-4
+    for k, o in zip(hp.OUT_KEYS, outs):
+        ref = g[f'{name}/{tag}/i{integ}/{k}']
+        assert tuple(o.shape) == ref.shape
+        assert hp.rel_err(o, ref) <= tol, (k, hp.rel_err(o, ref))
+    if st is not None:      # the in-place terrain snap of the caller's x (dphysics.py:571)
+        assert hp.rel_err(st[0].cpu(), g[f'{name}/{tag}/i{integ}/x0_after']) <= tol
+
+
+@pytest.mark.parametrize('tag', ['f32', 'f64'])
+def test_teacher_forced_single_step(tag):
+    """One step from the reference's own mid-rollout states: state -> forces, next state (<= 1e-5 rel in fp32)."""
+    g = hp.load('step'); gs = hp.load('rollout_small')
+    dt = hp.DT[tag]
+    pts, masks, z, ctrl, _, mu = hp.small_case(gs, 'B', dt)
+    dp = make_dphysics(pts, masks, 0, hp.SMALL['grid_res'], hp.SMALL['d_max'], snap_to_terrain=False)
+    tol = 1e-11 if tag == 'f64' else 1e-5
+    for t in g['sel']:
+        st = tuple(torch.as_tensor(g[f'{tag}/t{t}/in_{k}']) for k in ('x', 'xd', 'R', 'w'))
+        outs, _ = run_hip(dp, z, ctrl[:, t + 1:t + 2], st, mu)
+        sink = 40.0 * 9.81 / (50_000. + 1e-6)
+        nxt = {k: g[f'{tag}/t{t}/next_{k}'] for k in ('x', 'xd', 'R', 'w')}
+        assert hp.rel_err(outs[0][:, 0], nxt['x'] + nxt['R'][:, :, 2] * sink) <= tol
+        assert hp.rel_err(outs[1][:, 0], nxt['xd']) <= tol
+        assert hp.rel_err(outs[2][:, 0], nxt['R']) <= tol
+        assert hp.rel_err(outs[3][:, 0], nxt['w']) <= tol
+        assert hp.rel_err(outs[4][:, 0], g[f'{tag}/t{t}/Fs']) <= tol
+        assert hp.rel_err(outs[5][:, 0], g[f'{tag}/t{t}/Ff']) <= tol
+
+
+@pytest.mark.parametrize('integ', [0, 1])
+def test_full_horizon_f64_vs_reference(integ):
+    """T=500 on 256x256 in float64: chaos-proof full-horizon parity with the reference (<= 1e-8 rel)."""
+    g = hp.load('rollout_full')
+    pts, masks, z, mu, ctrl = hp.full_inputs(torch.float64)
+    dp = make_dphysics(pts, masks, integ, hp.FULL['grid_res'], hp.FULL['d_max'])
+    outs, _ = run_hip(dp, z, ctrl, None, mu)
+    for k, o in zip(hp.OUT_KEYS[:4], outs[:4]):
+        assert hp.rel_err(o, g[f'f64/i{integ}/{k}']) <= 1e-8, k
+    assert hp.rel_err(outs[4][:, ::10], g[f'f64/i{integ}/Fs_10']) <= 1e-7
+    assert hp.rel_err(outs[5][:, ::10], g[f'f64/i{integ}/Ff_10']) <= 1e-7
+
+
+@pytest.mark.parametrize('integ', [0, 1])
+def test_full_horizon_f32_within_reference_envelope(integ):
+    """T=500 free-run in float32.  The rollout is chaotic: the reference's own fp32 and fp64 runs drift
+    apart, so the bar is: <= 1e-4 rel for as long as the reference's fp32-vs-fp64 envelope itself stays <= 1e-5, and never
+    worse than 10x that envelope (+1e-4) afterwards."""
+    g = hp.load('rollout_full')
+    pts, masks, z, mu, ctrl = hp.full_inputs(torch.float32)
+    dp = make_dphysics(pts, masks, integ, hp.FULL['grid_res'], hp.FULL['d_max'])
+    outs, _ = run_hip(dp, z, ctrl, None, mu)
+    for k, o in zip(hp.OUT_KEYS[:4], outs[:4]):
+        r32, r64 = g[f'f32/i{integ}/{k}'].astype(np.float64), g[f'f64/i{integ}/{k}']
+        o = o.numpy().astype(np.float64)
+        B, T = r32.shape[:2]
+        scale = np.abs(r64).reshape(B, -1).max(1).clip(1e-30)[:, None]
+        env = np.abs(r32 - r64).reshape(B, T, -1).max(2) / scale          # reference fp32 vs fp64, per rollout and step
+        err = np.abs(o - r32).reshape(B, T, -1).max(2) / scale            # ours vs reference fp32
+        env_run = np.maximum.accumulate(env, axis=1)
+        calm = env_run <= 1e-5
+        assert calm[:, :50].all(), 'envelope should be calm at the start'
+        assert (err[calm] <= 1e-4).all(), (k, float(err[calm].max()))
+        assert (err <= 10 * env_run + 1e-4).all(), (k, float((err - 10 * env_run).max()))
+
+
+@pytest.mark.parametrize('N,n_tracks', [(1, 2), (7, 2), (16, 2), (33, 4), (64, 2), (100, 4), (175, 2), (223, 4), (300, 2)])
+def test_point_counts_vs_oracle_f64(N, n_tracks):
+    """Every lane-group / points-per-lane instantiation (N = 175 tradr, 223 marv in the reference) vs the CPU oracle."""
+    from monoforce_amd import synthetic as syn
+    from oracle import dphysics_oracle as orc
+    pts, masks = syn.robot_points_box(N, seed=N, n_tracks=n_tracks)
+    if N == 1:
+        masks = [np.array([True]), np.array([False])]
+    B, T = 3, 40
+    z = torch.stack([syn.bump_terrain(syn.bump_params(20 + b), 3.2, 0.1, torch.float64) * 0.3 for b in range(B)])
+    mu = torch.stack([syn.wave_friction(3.2, 0.1, 0.5, 1.0, 1.0 + b, 0.8, torch.float64) for b in range(B)])
+    ctrl = syn.varying_controls(B, T, seed=N, dtype=torch.float64)
+    for integ in (0, 1):
+        spec = hp.spec_from(pts, masks, integ, 0.1, 3.2)
+        with torch.no_grad():
+            st, fo = orc.rollout(spec, z, ctrl, friction=mu)
+        dp = make_dphysics(pts, masks, integ, 0.1, 3.2)
+        outs, _ = run_hip(dp, z, ctrl, None, mu)
+        for k, o, r in zip(hp.OUT_KEYS, outs, list(st) + list(fo)):
+            assert hp.rel_err(o, r) <= 1e-9, (N, integ, k, hp.rel_err(o, r))
+
+
+def _c2_inputs(B, T=500, dtype=torch.float32):
+    from monoforce_amd import synthetic as syn
+    pts, masks = syn.robot_points_4()
+    z = syn.bump_terrain(syn.bump_params(0), 6.4, 0.05, dtype)
+    mu = syn.wave_friction(6.4, 0.05, dtype=dtype)
+    ctrl = syn.const_controls(B, T, seed=0, dtype=dtype)
+    return pts, masks, z, mu, ctrl
+
+
+@pytest.mark.parametrize('integ', [0, 1])
+def test_full_size_properties(integ):
+    """BASELINE config sizes (B=1024, T=500, N=4, 256x256): size-independent properties.
+    determinism; shared (expanded) map == per-rollout copies; time-major == batch-major; workgroup size irrelevant;
+    rollouts independent of their batch neighbours; finite outputs."""
+    B = 1024
+    pts, masks, z, mu, ctrl = _c2_inputs(B)
+    zs, ms = z.to(DEV).unsqueeze(0).expand(B, -1, -1), mu.to(DEV).unsqueeze(0).expand(B, -1, -1)
+    dp = make_dphysics(pts, masks, integ, 0.05, 6.4)
+    ref, _ = run_hip(dp, zs, ctrl, None, ms)
+    assert all(torch.isfinite(o).all() for o in ref)
+    again, _ = run_hip(dp, zs, ctrl, None, ms)
+    per_rollout, _ = run_hip(dp, zs.contiguous(), ctrl, None, ms.contiguous())
+    bm, _ = run_hip(make_dphysics(pts, masks, integ, 0.05, 6.4, contiguous_outputs=True), zs, ctrl, None, ms)
+    wg256, _ = run_hip(make_dphysics(pts, masks, integ, 0.05, 6.4, block=256), zs, ctrl, None, ms)
+    sub, _ = run_hip(dp, zs[:100], ctrl[37:137], None, ms[:100])
+    for k, a, b, c, d, e, f in zip(hp.OUT_KEYS, ref, again, per_rollout, bm, wg256, sub):
+        assert torch.equal(a, b), f'{k}: not deterministic'
+        assert torch.equal(a, c), f'{k}: shared map != per-rollout map'
+        assert torch.equal(a, d), f'{k}: layouts differ'
+        assert d.is_contiguous() and not a.is_contiguous()
+        assert torch.equal(a, e), f'{k}: workgroup size changes results'
+        assert torch.equal(a[37:137], f), f'{k}: rollouts are not independent'
+    # physical sanity: the robot stays on the map and moves
+    X = ref[0]
+    assert float(X[..., :2].abs().max()) < 6.4 and float((X[:, -1, :2] - X[:, 0, :2]).norm(dim=-1).mean()) > 0.3
+
+
+def test_edge_cases_and_errors():
+    from monoforce_amd import synthetic as syn
+    pts, masks = syn.robot_points_4()
+    z = torch.zeros(1, 16, 16)
+    dp = make_dphysics(pts, masks, 1, 0.1, 0.8)
+    # T = 1 with the default integrator: only the initial state comes back
+    (Xs, Xds, Rs, Om), (Fs, Ff) = dp(z.to(DEV), torch.tensor([[[0.5, 0.1]]]).to(DEV))
+    assert Xs.shape == (1, 1, 3) and Fs.shape == (1, 1, 4, 3)
+    assert torch.equal(Rs[0, 0].cpu(), torch.eye(3)) and float(Fs.abs().max()) == 0.0
+    assert abs(float(Xds[0, 0, 0]) - 0.5) < 1e-7 and abs(float(Om[0, 0, 2]) - 0.1) < 1e-7
+    # shape assert with the reference's message (dphysics.py:575)
+    dp2 = make_dphysics(pts, masks, 1, 0.1, 0.8)
+    with pytest.raises(AssertionError, match='Controls shape'):
+        dp2(torch.zeros(2, 16, 16).to(DEV), torch.zeros(3, 10, 2).to(DEV))
+    # self.ts is truncated for good, as in the reference (dphysics.py:581): a longer horizon afterwards trips the assert
+    dp2(torch.zeros(2, 16, 16).to(DEV), torch.zeros(2, 10, 2).to(DEV))
+    assert dp2.ts.shape[0] == 10
+    # CPU tensors are refused -- there is no CPU fallback
+    dp3 = make_dphysics(pts, masks, 1, 0.1, 0.8)
+    dp3.device = 'cpu'
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        dp3(torch.zeros(1, 16, 16), torch.zeros(1, 10, 2))
+    # friction=None equals an all-ones friction map (cfg.friction, dphysics.py:562)
+    ctrl = syn.const_controls(4, 60, seed=3).to(DEV)
+    zz = syn.bump_terrain(syn.bump_params(3), 0.8, 0.1).to(DEV).unsqueeze(0).expand(4, -1, -1) * 0.2
+    a = make_dphysics(pts, masks, 0, 0.1, 0.8)(zz, ctrl)
+    b = make_dphysics(pts, masks, 0, 0.1, 0.8)(zz, ctrl, friction=torch.ones(4, 16, 16, device=DEV))
+    for u, v in zip(a[0] + a[1], b[0] + b[1]):
+        assert torch.equal(u, v)
