@@ -91,6 +91,43 @@ typedef struct MfRolloutFwdBufs {
 int mf_rollout_fwd_f32(const MfRolloutDesc* desc, const MfRolloutFwdBufs* bufs, void* hip_stream);
 int mf_rollout_fwd_f64(const MfRolloutDesc* desc, const MfRolloutFwdBufs* bufs, void* hip_stream);
 
+/* Device buffers of the backward rollout (reverse-time adjoint of the same scan; per-step intermediates are
+ * recomputed from the saved per-step states, which are the forward's own outputs).  `desc` must be the forward's.
+ * Upstream gradients use the outputs' layout and may each be NULL (= zeros).  Gradient outputs: gz/gmu are
+ * ACCUMULATED with atomic adds (zero them first; S[1 or B][H][W] like z/mu); the others are overwritten. */
+typedef struct MfRolloutBwdBufs {
+  const void* z;        /* as forward */
+  const void* mu;       /* as forward (NULL = ones) */
+  const void* controls; /* S[B][T][2] */
+  const void* ts;       /* S[T] */
+  const void* points;   /* S[N][3] */
+  const int32_t* part;  /* int32[N] */
+  const void* x_init;   /* S[B][3] x0 AFTER the forward's terrain snap (the forward's in/out x0 buffer) */
+  const void* xd0;      /* S[B][3] */
+  const void* R0;       /* S[B][3][3] */
+  const void* w0;       /* S[B][3] */
+  const void* Xraw;     /* saved forward outputs: unshifted positions, */
+  const void* Xds;      /*   velocities, */
+  const void* Rs;       /*   rotations, */
+  const void* Omegas;   /*   angular velocities */
+  const void* gXs;      /* upstream dL/dXs (the SHIFTED positions the API returned) ... */
+  const void* gXds;
+  const void* gRs;
+  const void* gOmegas;
+  const void* gFs;
+  const void* gFf;
+  void* gz;             /* out (atomic accumulate): dL/dz */
+  void* gmu;            /* out (atomic accumulate): dL/dmu; NULL to skip */
+  void* gcontrols;      /* out: S[B][T][2] */
+  void* gx0;            /* out: S[B][3] (z component is 0 unless skip_snap); NULL to skip */
+  void* gxd0;           /* out: S[B][3] */
+  void* gR0;            /* out: S[B][3][3] */
+  void* gw0;            /* out: S[B][3] */
+} MfRolloutBwdBufs;
+
+int mf_rollout_bwd_f32(const MfRolloutDesc* desc, const MfRolloutBwdBufs* bufs, void* hip_stream);
+int mf_rollout_bwd_f64(const MfRolloutDesc* desc, const MfRolloutBwdBufs* bufs, void* hip_stream);
+
 /* Text of the calling thread's last error ("" if none). */
 const char* mf_last_error(void);
 /* Library version, e.g. "monoforce_hip 0.1 gfx950". */

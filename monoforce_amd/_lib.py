@@ -42,7 +42,7 @@ class MfSplatDesc(C.Structure):
 
 
 # every symbol include/monoforce_hip.h declares; tests check the library exports all of them
-SYMBOLS = ['mf_rollout_fwd_f32', 'mf_rollout_fwd_f64', 'mf_last_error', 'mf_version', 'mf_sizeof']
+SYMBOLS = ['mf_rollout_fwd_f32', 'mf_rollout_fwd_f64', 'mf_rollout_bwd_f32', 'mf_rollout_bwd_f64', 'mf_last_error', 'mf_version', 'mf_sizeof']
 
 _lib = None
 _lock = threading.Lock()
@@ -58,6 +58,9 @@ def lib():
                     raise RuntimeError(
                         f'{LIB_PATH} is missing: build the HIP extension first (make -C monoforce_amd/csrc). '
                         'monoforce_amd has no CPU fallback.')
+                # torch bundles its own libamdhip64.so.7; import it FIRST so this library binds to the same HIP runtime
+                # instance (loading /opt/rocm's copy first leaves the process with two runtimes and no device).
+                import torch  # noqa: F401
                 L = C.CDLL(LIB_PATH)
                 L.mf_last_error.restype = C.c_char_p
                 L.mf_version.restype = C.c_char_p

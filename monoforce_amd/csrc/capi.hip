@@ -14,5 +14,6 @@ extern "C" const char* mf_version(void) { return "monoforce_hip 0.1 gfx950"; }
 extern "C" int mf_sizeof(const char* name) {
   if (!strcmp(name, "MfRolloutDesc")) return (int)sizeof(MfRolloutDesc);
   if (!strcmp(name, "MfRolloutFwdBufs")) return (int)sizeof(MfRolloutFwdBufs);
+  if (!strcmp(name, "MfRolloutBwdBufs")) return (int)sizeof(MfRolloutBwdBufs);
   return -1;
 }

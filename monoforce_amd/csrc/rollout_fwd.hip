@@ -14,7 +14,7 @@
 // 256x256x4 B x 2 = 512 KiB they live in every XCD's 4 MiB L2, with the few cells under a slowly moving robot
 // (<= 0.2 cell per step) staying in the CU's L1 -- see DESIGN.md for why a per-workgroup LDS tile does not pay at N=4.
 // Outputs are written time-major by default so a wave's stores of one step form contiguous segments.
-#include "mf_common.h"
+#include "rollout_common.h"
 
 namespace mf {
 
@@ -41,40 +41,6 @@ struct RolloutArgs {
   S* Ff;
   S* Xraw;
 };
-
-// Cell indices and fractions of `interpolate_grid` (dphysics.py:419-435).  Index arithmetic is done in int32 after
-// clamping the cell coordinate to +-2^18 (the reference uses int64; results are identical while the robot is within
-// 2^18 cells of the map, far beyond which the flat-index clamp pins everything to cell 0 / HW-1 anyway).
-template <typename S>
-struct Cell {
-  int ic, i_f, il, ifl;
-  S fx, fy;
-};
-
-template <typename S>
-__device__ __forceinline__ Cell<S> locate(S qx, S qy, S d_max, S res, int H, int last) {
-  const S lim = (S)262144.0;
-  S ux = (qx + d_max) / res;
-  S uy = (qy + d_max) / res;
-  int ix = (int)mf_clamp(ux, -lim, lim);  // trunc toward zero, like .long()
-  int iy = (int)mf_clamp(uy, -lim, lim);
-  Cell<S> c;
-  c.fx = ux - (S)ix;
-  c.fy = uy - (S)iy;
-  int base = iy + H * ix;
-  c.ic = min(max(base, 0), last);
-  c.i_f = min(max(base + H, 0), last);
-  c.il = min(max(base + 1, 0), last);
-  c.ifl = min(max(base + 1 + H, 0), last);
-  return c;
-}
-
-template <typename S>
-__device__ __forceinline__ S blend(const Cell<S>& c, S vc, S vf, S vl, S vfl) {
-  // NB: the x-fraction weights the +y ("left") neighbour and vice versa (dphysics.py:442-445).
-  const S one = (S)1;
-  return (one - c.fx) * (one - c.fy) * vc + (one - c.fx) * c.fy * vf + c.fx * (one - c.fy) * vl + c.fx * c.fy * vfl;
-}
 
 template <typename S, int G, int PPL, int INTEG>
 __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a) {

@@ -220,7 +220,8 @@ class DPhysics(torch.nn.Module):
         cfg = self.dphys_cfg
         dev = torch.device(self.device)
         dt_, T_ = cfg.dt, cfg.traj_sim_time
-        batch_size = z_grid.shape[0]
+        # extension over the reference: a [1,H,W] map with B > 1 controls is ONE terrain shared by all rollouts
+        batch_size = z_grid.shape[0] if z_grid.shape[0] != 1 else controls.shape[0]
         z_grid = z_grid.to(dev)
         _lib.require_hip_tensor(z_grid, 'z_grid')
         dtype = z_grid.dtype

@@ -1,0 +1,58 @@
+"""Backward of the fused rollout: marshals `_RolloutFn`'s saved tensors into `mf_rollout_bwd_*` (include/monoforce_hip.h).
+
+Replaces the T x ~300-node autograd graph of the reference (`loss.backward()` through
+`/root/reference/monoforce/src/monoforce/models/traj_predictor/dphysics.py:172-272,467-528`) with one kernel launch.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf):
+    from .dphysics import _scalar_suffix, _stream_ptr
+    controls, x_init, xd0, R0, w0, ts, Xraw, Xds, Rs, Om = ctx.saved_tensors
+    desc, keep, mod = ctx.desc, ctx.keep, ctx.mod
+    dev, dt = controls.device, controls.dtype
+    B, T = desc.B, desc.T
+    tm = desc.layout == _lib.MF_LAYOUT_TIME_MAJOR
+
+    def up(g):     # upstream gradient -> the kernel's layout, contiguous; None stays NULL (= zeros)
+        if g is None:
+            return None
+        g = g.to(dt)
+        return (g.transpose(0, 1) if tm else g).contiguous()
+
+    ups = [up(g) for g in (gXs, gXds, gRs, gOm, gFs, gFf)]
+    z, mu = keep['z'], keep['mu']
+    gz = torch.zeros_like(z)
+    gmu = torch.zeros_like(mu) if (mu is not None and ctx.needs_input_grad[2]) else None
+    gcontrols = torch.empty_like(controls)
+    gxd0, gR0, gw0 = torch.empty_like(xd0), torch.empty_like(R0), torch.empty_like(w0)
+    bufs = _lib.MfRolloutBwdBufs(
+        z=_lib.ptr(z), mu=_lib.ptr(mu), controls=_lib.ptr(controls), ts=_lib.ptr(ts), points=_lib.ptr(keep['points']),
+        part=_lib.ptr(mod._part_dev(dev)), x_init=_lib.ptr(x_init), xd0=_lib.ptr(xd0), R0=_lib.ptr(R0), w0=_lib.ptr(w0),
+        Xraw=_lib.ptr(Xraw), Xds=_lib.ptr(Xds), Rs=_lib.ptr(Rs), Omegas=_lib.ptr(Om),
+        gXs=_lib.ptr(ups[0]), gXds=_lib.ptr(ups[1]), gRs=_lib.ptr(ups[2]), gOmegas=_lib.ptr(ups[3]),
+        gFs=_lib.ptr(ups[4]), gFf=_lib.ptr(ups[5]),
+        gz=_lib.ptr(gz), gmu=_lib.ptr(gmu), gcontrols=_lib.ptr(gcontrols), gx0=None,
+        gxd0=_lib.ptr(gxd0), gR0=_lib.ptr(gR0), gw0=_lib.ptr(gw0))
+    fn = getattr(_lib.lib(), 'mf_rollout_bwd_' + _scalar_suffix(dt))
+    with torch.cuda.device(dev):
+        _lib.check(fn(C.byref(desc), C.byref(bufs), _stream_ptr(dev)), 'mf_rollout_bwd')
+
+    def to_input_shape(g, shape):
+        """Gradient of a map input.  A shared map ([1,H,W], or one [H,W] map expanded over the batch) gets ONE [H,W]
+        gradient; for the expanded case it is handed back as a stride-0 expand of g/B, which autograd's ExpandBackward
+        sums over the batch back to g (exact for power-of-two B) without materialising B copies."""
+        if g is None:
+            return None
+        if g.dim() == 3:
+            return g
+        return g.unsqueeze(0) if shape[0] == 1 else (g / shape[0]).unsqueeze(0).expand(shape)
+
+    return (None, to_input_shape(gz, ctx.z_shape) if ctx.needs_input_grad[1] else None,
+            to_input_shape(gmu, ctx.z_shape), gcontrols if ctx.needs_input_grad[3] else None, None,
+            gxd0 if ctx.needs_input_grad[5] else None, gR0 if ctx.needs_input_grad[6] else None,
+            gw0 if ctx.needs_input_grad[7] else None, None, None)

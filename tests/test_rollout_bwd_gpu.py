@@ -1,0 +1,138 @@
+"""Gradients of the HIP rollout (mf_rollout_bwd_*) vs the reference's autograd (golden vectors) and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as hp
+from tests.test_rollout_gpu import make_dphysics
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def hip_grads(dp, z, ctrl, state, mu, dtype):
+    z = z.to(DEV).requires_grad_(True)
+    ctrl = ctrl.to(DEV).requires_grad_(True)
+    mu = None if mu is None else mu.to(DEV).requires_grad_(True)
+    st = None if state is None else tuple(s.clone().to(DEV) for s in state)
+    states, forces = dp(z_grid=z, controls=ctrl, state=st, friction=mu)
+    loss = hp.probe_loss(list(states) + list(forces), dtype)
+    loss.backward()
+    torch.cuda.synchronize()
+    return loss.item(), z.grad.cpu(), ctrl.grad.cpu(), None if mu is None else mu.grad.cpu()
+
+
+@pytest.mark.parametrize('name', ['A', 'B', 'C'])
+@pytest.mark.parametrize('tag', ['f32', 'f64'])
+@pytest.mark.parametrize('integ', [0, 1])
+def test_small_grads_vs_reference_autograd(name, tag, integ):
+    """dL/dz, dL/dmu, dL/dcontrols for a loss touching all six outputs, vs the reference's loss.backward() (T=48)."""
+    g = hp.load('rollout_small')
+    dt = hp.DT[tag]
+    pts, masks, z, ctrl, state, mu = hp.small_case(g, name, dt)
+    dp = make_dphysics(pts, masks, integ, hp.SMALL['grid_res'], hp.SMALL['d_max'])
+    loss, gz, gc, gm = hip_grads(dp, z, ctrl, state, mu, dt)
+    pre = f'{name}/{tag}/i{integ}/'
+    # float64: to rounding.  float32: SURVEY A.2 bar (<= 1e-4 rel at T <= 100; the reference's own fp32-vs-fp64 is ~1e-5)
+    tol = 1e-8 if tag == 'f64' else 2e-4
+    assert abs(loss - float(g[pre + 'loss'])) <= tol * abs(float(g[pre + 'loss'])) + tol
+    assert hp.rel_err(gz, g[pre + 'g_z']) <= tol, hp.rel_err(gz, g[pre + 'g_z'])
+    assert hp.rel_err(gc, g[pre + 'g_ctrl']) <= tol, hp.rel_err(gc, g[pre + 'g_ctrl'])
+    if gm is not None:
+        assert hp.rel_err(gm, g[pre + 'g_mu']) <= tol, hp.rel_err(gm, g[pre + 'g_mu'])
+
+
+@pytest.mark.parametrize('integ', [0, 1])
+def test_full_horizon_grads_f64(integ):
+    """T=500 BPTT on 256x256 in float64 vs the reference (gradients explode to 1e3..1e6 there; still <= 1e-6 rel)."""
+    g = hp.load('rollout_full')
+    pts, masks, z, mu, ctrl = hp.full_inputs(torch.float64)
+    dp = make_dphysics(pts, masks, integ, hp.FULL['grid_res'], hp.FULL['d_max'])
+    loss, gz, gc, gm = hip_grads(dp, z, ctrl, None, mu, torch.float64)
+    pre = f'f64/i{integ}/'
+    assert abs(loss - float(g[pre + 'loss'])) <= 1e-7 * abs(float(g[pre + 'loss']))
+    assert hp.rel_err(gc, g[pre + 'g_ctrl']) <= 1e-6
+    for nm, got in (('g_z', gz), ('g_mu', gm)):
+        ref = np.zeros(got.numel())
+        ref[g[pre + nm + '_idx']] = g[pre + nm + '_val']
+        assert hp.rel_err(got.reshape(-1), ref) <= 1e-6, (nm, hp.rel_err(got.reshape(-1), ref))
+
+
+@pytest.mark.parametrize('N,n_tracks', [(7, 2), (33, 4), (100, 2), (223, 4), (300, 2)])
+def test_grads_all_lane_mappings_vs_oracle_f64(N, n_tracks):
+    """Every (G, PPL) instantiation of the backward kernel, including gradients w.r.t. a given initial state."""
+    from monoforce_amd import synthetic as syn
+    from oracle import dphysics_oracle as orc
+    pts, masks = syn.robot_points_box(N, seed=N, n_tracks=n_tracks)
+    B, T = 2, 30
+    z = torch.stack([syn.bump_terrain(syn.bump_params(20 + b), 3.2, 0.1, torch.float64) * 0.3 for b in range(B)])
+    mu = torch.stack([syn.wave_friction(3.2, 0.1, 0.5, 1.0, 1.0 + b, 0.8, torch.float64) for b in range(B)])
+    ctrl = syn.varying_controls(B, T, seed=N, dtype=torch.float64)
+    from tests.golden_state import given_state
+    for integ in (0, 1):
+        spec = hp.spec_from(pts, masks, integ, 0.1, 3.2)
+        leaves = [t.clone().requires_grad_(True) for t in (z, mu, ctrl)]
+        st = [s.clone() for s in given_state(B)]
+        for s in st[1:]:
+            s.requires_grad_(True)
+        so, fo = orc.rollout(spec, leaves[0], leaves[2], state=tuple(st), friction=leaves[1])
+        hp.probe_loss(list(so) + list(fo), torch.float64).backward()
+        ref = [l.grad for l in leaves] + [s.grad for s in st[1:]]
+
+        dp = make_dphysics(pts, masks, integ, 0.1, 3.2)
+        dl = [t.clone().to(DEV).requires_grad_(True) for t in (z, mu, ctrl)]
+        ds = [s.clone().to(DEV) for s in given_state(B)]
+        for s in ds[1:]:
+            s.requires_grad_(True)
+        states, forces = dp(dl[0], dl[2], state=tuple(ds), friction=dl[1])
+        hp.probe_loss(list(states) + list(forces), torch.float64).backward()
+        got = [l.grad.cpu() for l in dl] + [s.grad.cpu() for s in ds[1:]]
+        for nm, a, b in zip(('z', 'mu', 'controls', 'xd0', 'R0', 'w0'), got, ref):
+            assert hp.rel_err(a, b) <= 1e-8, (N, integ, nm, hp.rel_err(a, b))
+
+
+@pytest.mark.parametrize('integ', [0, 1])
+def test_shared_map_gradient_is_sum_over_rollouts(integ):
+    """One terrain shared by B rollouts ([1,H,W], and the expanded [B,H,W] view): dL/dz == sum_b of per-rollout grads."""
+    from monoforce_amd import synthetic as syn
+    pts, masks = syn.robot_points_4()
+    B, T, dt = 16, 60, torch.float64
+    z1 = syn.bump_terrain(syn.bump_params(5), 3.2, 0.1, dt) * 0.3
+    m1 = syn.wave_friction(3.2, 0.1, dtype=dt)
+    ctrl = syn.const_controls(B, T, seed=9, dtype=dt).to(DEV)
+
+    def run(zin, min_):
+        dp = make_dphysics(pts, masks, integ, 0.1, 3.2)
+        states, forces = dp(zin, ctrl, friction=min_)
+        hp.probe_loss(list(states) + list(forces), dt).backward()
+
+    zb = z1.to(DEV).repeat(B, 1, 1).requires_grad_(True); mb = m1.to(DEV).repeat(B, 1, 1).requires_grad_(True)
+    run(zb, mb)
+    zs = z1.to(DEV).unsqueeze(0).requires_grad_(True); ms = m1.to(DEV).unsqueeze(0).requires_grad_(True)
+    run(zs, ms)
+    ze = z1.to(DEV).requires_grad_(True); me = m1.to(DEV).requires_grad_(True)
+    run(ze.unsqueeze(0).expand(B, -1, -1), me.unsqueeze(0).expand(B, -1, -1))
+    assert hp.rel_err(zs.grad[0].cpu(), zb.grad.sum(0).cpu()) <= 1e-9
+    assert hp.rel_err(ms.grad[0].cpu(), mb.grad.sum(0).cpu()) <= 1e-9
+    assert hp.rel_err(ze.grad.cpu(), zb.grad.sum(0).cpu()) <= 1e-9
+    assert hp.rel_err(me.grad.cpu(), mb.grad.sum(0).cpu()) <= 1e-9
+
+
+def test_physics_loss_style_sparse_upstream():
+    """Only Xs at a few time stamps carries gradient (losses.py:102-127); unused outputs arrive as None."""
+    from monoforce_amd import synthetic as syn
+    from oracle import dphysics_oracle as orc
+    pts, masks = syn.robot_points_4()
+    B, T, dt = 4, 80, torch.float64
+    z = torch.stack([syn.bump_terrain(syn.bump_params(30 + b), 3.2, 0.1, dt) * 0.3 for b in range(B)])
+    ctrl = syn.const_controls(B, T, seed=2, dtype=dt)
+    idx = torch.tensor([5, 20, 41, 79])
+    tgt = syn.probe_weights((B, 4, 3), 0.1, dt)
+    for integ in (0, 1):
+        zo = z.clone().requires_grad_(True)
+        (Xo, _, _, _), _ = orc.rollout(hp.spec_from(pts, masks, integ, 0.1, 3.2), zo, ctrl)
+        ((Xo[:, idx] - tgt) ** 2).mean().backward()
+        zd = z.clone().to(DEV).requires_grad_(True)
+        (Xd, _, _, _), _ = make_dphysics(pts, masks, integ, 0.1, 3.2)(zd, ctrl.to(DEV))
+        ((Xd[:, idx.to(DEV)] - tgt.to(DEV)) ** 2).mean().backward()
+        assert hp.rel_err(zd.grad.cpu(), zo.grad) <= 1e-8
