@@ -1,0 +1,34 @@
+"""Optional per-kernel HIP-event timing of the C-ABI launches (used by bench.py; off by default, zero cost when off)."""
+import contextlib
+
+import torch
+
+_records = None     # None = off; else list of (name, start_event, end_event)
+
+
+def start():
+    global _records
+    _records = []
+
+
+def stop():
+    """Stop recording and return {name: [ms, ...]} (synchronises)."""
+    global _records
+    recs, _records = _records or [], None
+    torch.cuda.synchronize()
+    out = {}
+    for name, a, b in recs:
+        out.setdefault(name, []).append(a.elapsed_time(b))
+    return out
+
+
+@contextlib.contextmanager
+def timed(name, device):
+    if _records is None:
+        yield
+        return
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(torch.cuda.current_stream(device))     # the stream the kernel is launched on
+    yield
+    b.record(torch.cuda.current_stream(device))
+    _records.append((name, a, b))

@@ -16,7 +16,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib
+from . import _lib, _timing
 from .dphys_config import DPhysConfig
 
 __all__ = ['DPhysics', 'generate_controls', 'vw_to_track_vels', 'inertia_tensor', 'normalized', 'skew_symmetric']
@@ -112,7 +112,7 @@ class _RolloutFn(torch.autograd.Function):
             Xs=_lib.ptr(Xs), Xds=_lib.ptr(Xds), Rs=_lib.ptr(Rs), Omegas=_lib.ptr(Om), Fs=_lib.ptr(Fs), Ff=_lib.ptr(Ff),
             Xraw=_lib.ptr(Xraw))
         fn = getattr(_lib.lib(), 'mf_rollout_fwd_' + _scalar_suffix(dt))
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), _timing.timed('rollout_fwd_kernel', dev):
             _lib.check(fn(C.byref(desc), C.byref(bufs), _stream_ptr(dev)), 'mf_rollout_fwd')
         outs = (Xs, Xds, Rs, Om, Fs, Ff)
         if tm:

@@ -7,7 +7,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib
+from . import _lib, _timing
 
 
 def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf):
@@ -39,7 +39,7 @@ def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf):
         gz=_lib.ptr(gz), gmu=_lib.ptr(gmu), gcontrols=_lib.ptr(gcontrols), gx0=None,
         gxd0=_lib.ptr(gxd0), gR0=_lib.ptr(gR0), gw0=_lib.ptr(gw0))
     fn = getattr(_lib.lib(), 'mf_rollout_bwd_' + _scalar_suffix(dt))
-    with torch.cuda.device(dev):
+    with torch.cuda.device(dev), _timing.timed('rollout_bwd_kernel', dev):
         _lib.check(fn(C.byref(desc), C.byref(bufs), _stream_ptr(dev)), 'mf_rollout_bwd')
 
     def to_input_shape(g, shape):

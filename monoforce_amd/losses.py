@@ -1,0 +1,57 @@
+"""Losses that sit directly on top of the rollout / encoder outputs (plain torch; they run on whatever device the
+tensors are on).  Semantics of `/root/reference/monoforce/src/monoforce/losses.py`: `physics_loss` :102-138, `hm_loss`
+:77-99, `total_variation` :68-74.
+"""
+import torch
+
+__all__ = ['physics_loss', 'hm_loss', 'total_variation', 'rotation_difference']
+
+
+def total_variation(heightmap):
+    """(sum |d/dy| + sum |d/dx|) / (h w) (losses.py:68-74)."""
+    h, w = heightmap.shape[-2:]
+    dv = (heightmap[..., :, 1:] - heightmap[..., :, :-1]).abs().sum()
+    dh = (heightmap[..., 1:, :] - heightmap[..., :-1, :]).abs().sum()
+    return (dv + dh) / (h * w)
+
+
+def hm_loss(height_pred, height_gt, weights=None, h_max=None):
+    """Weighted MSE between height maps over the cells where both are finite (losses.py:77-99)."""
+    assert height_pred.shape == height_gt.shape, 'Height prediction and ground truth must have the same shape'
+    if weights is None:
+        weights = torch.ones_like(height_gt)
+    assert weights.shape == height_gt.shape, 'Weights and height ground truth must have the same shape'
+    if h_max is not None:
+        height_pred = h_max * torch.tanh(height_pred)
+    ok = ~(torch.isnan(height_pred) | torch.isnan(height_gt))
+    diff = height_pred[ok] * weights[ok] - height_gt[ok] * weights[ok]
+    return (diff ** 2).mean()
+
+
+def physics_loss(states_pred, states_gt, pred_ts, gt_ts, gamma=0.9, rotation_loss=False):
+    """Time-discounted position MSE at the predicted steps closest to the ground-truth stamps (losses.py:102-138).
+
+    states_*[0]: positions [N,T1,3] / [N,T2,3]; pred_ts [N,T1]; gt_ts [N,T2]; weight 1 / (1 + gamma t).
+    """
+    X_gt, X_pred = states_gt[0], states_pred[0]
+    nearest = (pred_ts.unsqueeze(1) - gt_ts.unsqueeze(2)).abs().argmin(dim=2)          # [N,T2]
+    rows = torch.arange(X_gt.shape[0], device=nearest.device).unsqueeze(1)
+    X_sel = X_pred[rows, nearest]
+    wt = 1. / (1. + gamma * gt_ts.unsqueeze(2))
+    loss = ((X_sel * wt - X_gt * wt) ** 2).mean()
+    if not rotation_loss:
+        return loss
+    R_gt, R_sel = states_gt[2], states_pred[2][rows, nearest]
+    return loss, (rotation_difference(R_sel, R_gt, reduction='none') * wt).mean()
+
+
+def rotation_difference(R1, R2, reduction='mean'):
+    """Squared geodesic angle between rotations, theta = arccos((tr(R1 R2^T) - 1) / 2) (losses.py:48-65)."""
+    assert R1.shape == R2.shape and R1.shape[-2:] == (3, 3)
+    tr = (R1 @ R2.transpose(-2, -1)).diagonal(dim1=-2, dim2=-1).sum(dim=-1, keepdim=True)
+    theta2 = torch.arccos(torch.clip((tr - 1) / 2., min=-1, max=1.)) ** 2
+    if reduction == 'mean':
+        return theta2.mean()
+    if reduction == 'sum':
+        return theta2.sum()
+    return theta2
