@@ -17,6 +17,7 @@
 #ifndef MONOFORCE_HIP_H
 #define MONOFORCE_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -127,6 +128,31 @@ typedef struct MfRolloutBwdBufs {
 
 int mf_rollout_bwd_f32(const MfRolloutDesc* desc, const MfRolloutBwdBufs* bufs, void* hip_stream);
 int mf_rollout_bwd_f64(const MfRolloutDesc* desc, const MfRolloutBwdBufs* bufs, void* hip_stream);
+
+/* ---- LSS BEV voxel pooling (lss.py:238-280) ------------------------------------------------------------------
+ * Points are the B * n_per_sample frustum points of a batch (n_per_sample = cams * D * fH * fW), in the reference's
+ * flattening order; features are row-major [point][C]; the output is the reference's [B][nz*C][nx][ny] grid
+ * (channel index = iz*C + c, lss.py:274-278).  Voxel index = trunc((geom - off) / dx) in float32 with
+ * off = bx - dx/2 (lss.py:246); points outside [0,n) on any axis are dropped (lss.py:253-255).
+ * Usage: workspace = mf_bev_splat_workspace_bytes(desc) bytes of device memory; mf_bev_splat_prepare() once per
+ * geometry; then any number of _fwd / _bwd calls with that workspace. */
+typedef struct MfSplatDesc {
+  int32_t B;            /* samples */
+  int32_t n_per_sample; /* frustum points per sample */
+  int32_t C;            /* feature channels per point */
+  int32_t nx, ny, nz;   /* BEV grid (gen_dx_bx, terrain_encoder/utils.py:136-141) */
+  float off[3];         /* bx - dx/2, computed in float32 like the reference */
+  float dx[3];          /* voxel size */
+} MfSplatDesc;
+
+size_t mf_bev_splat_workspace_bytes(const MfSplatDesc* desc); /* 0 on a bad descriptor */
+int mf_bev_splat_prepare(const MfSplatDesc* desc, const float* geom /* [B*n_per_sample][3] */, void* workspace, void* hip_stream);
+/* out[B][nz*C][nx][ny] = per-voxel sums of x[B*n_per_sample][C]; every output element is written (zeros where empty) */
+int mf_bev_splat_fwd_f32(const MfSplatDesc* desc, const float* x, const void* workspace, float* out, void* hip_stream);
+int mf_bev_splat_fwd_f64(const MfSplatDesc* desc, const double* x, const void* workspace, double* out, void* hip_stream);
+/* gx[B*n_per_sample][C] = gout at the point's voxel, 0 for dropped points (QuickCumsum.backward, utils.py:174-181) */
+int mf_bev_splat_bwd_f32(const MfSplatDesc* desc, const float* gout, const void* workspace, float* gx, void* hip_stream);
+int mf_bev_splat_bwd_f64(const MfSplatDesc* desc, const double* gout, const void* workspace, double* gx, void* hip_stream);
 
 /* Text of the calling thread's last error ("" if none). */
 const char* mf_last_error(void);

@@ -42,7 +42,8 @@ class MfSplatDesc(C.Structure):
 
 
 # every symbol include/monoforce_hip.h declares; tests check the library exports all of them
-SYMBOLS = ['mf_rollout_fwd_f32', 'mf_rollout_fwd_f64', 'mf_rollout_bwd_f32', 'mf_rollout_bwd_f64', 'mf_last_error', 'mf_version', 'mf_sizeof']
+SYMBOLS = ['mf_rollout_fwd_f32', 'mf_rollout_fwd_f64', 'mf_rollout_bwd_f32', 'mf_rollout_bwd_f64', 'mf_bev_splat_workspace_bytes', 'mf_bev_splat_prepare',
+           'mf_bev_splat_fwd_f32', 'mf_bev_splat_fwd_f64', 'mf_bev_splat_bwd_f32', 'mf_bev_splat_bwd_f64', 'mf_last_error', 'mf_version', 'mf_sizeof']
 
 _lib = None
 _lock = threading.Lock()
@@ -68,6 +69,7 @@ def lib():
                     fn = getattr(L, name)   # AttributeError if the build is stale
                     if name.startswith(('mf_rollout', 'mf_bev', 'mf_lss')):
                         fn.restype = C.c_int
+                L.mf_bev_splat_workspace_bytes.restype = C.c_size_t
                 _lib = L
     return _lib
 

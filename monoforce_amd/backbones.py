@@ -1,0 +1,165 @@
+"""Convolutional backbones of the terrain encoder, re-stated in plain `torch.nn` (they run on MIOpen / rocBLAS, where the
+MFMA units are used; no hand kernels here -- BASELINE.json north_star keeps the encoder backbone on the vendor libraries).
+
+The reference gets these from third-party packages that are NOT part of /root/reference and are not installed here:
+  * `efficientnet_pytorch==0.7.1`  `EfficientNet.from_pretrained("efficientnet-b0")` (lss.py:55), used through its
+    private members `_conv_stem`, `_bn0`, `_swish`, `_blocks`, `_global_params.drop_connect_rate` (lss.py:73-94)
+  * `torchvision.models.resnet.resnet18(zero_init_residual=True)` `layer1..3`, `bn1`, `relu` (lss.py:105-112)
+They are restated from the published architectures with the SAME module / parameter names, so a reference checkpoint's
+`state_dict` keys and shapes line up (`from_pretrained`, lss.py:293-302).  Numerical parity of these blocks is
+"unpinned": neither the packages nor any weights are available offline; only names/shapes are tested.
+"""
+import math
+
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+
+# ------------------------------------------------------------------------------------------------------------
+# EfficientNet-B0 (Tan & Le 2019), efficientnet_pytorch naming
+# ------------------------------------------------------------------------------------------------------------
+class Swish(nn.Module):
+    def forward(self, x):
+        return x * torch.sigmoid(x)
+
+
+class Conv2dStaticSame(nn.Conv2d):
+    """Conv with TensorFlow-style "same" padding fixed at construction for even feature maps: total pad k - stride,
+    the extra pixel on the bottom/right (k3 s2 -> (0,1), k5 s2 -> (1,2), stride 1 -> symmetric)."""
+
+    def __init__(self, cin, cout, k, stride=1, groups=1, bias=False):
+        super().__init__(cin, cout, k, stride=stride, groups=groups, bias=bias)
+        total = max(k - stride, 0)
+        lo = total // 2
+        self.static_padding = nn.ZeroPad2d((lo, total - lo, lo, total - lo)) if total > 0 else nn.Identity()
+
+    def forward(self, x):
+        return F.conv2d(self.static_padding(x), self.weight, self.bias, self.stride, 0, self.dilation, self.groups)
+
+
+def drop_connect(x, p, training):
+    if not training or not p:
+        return x
+    keep = 1.0 - p
+    mask = torch.floor(keep + torch.rand(x.shape[0], 1, 1, 1, dtype=x.dtype, device=x.device))
+    return x / keep * mask
+
+
+class MBConvBlock(nn.Module):
+    """Mobile inverted bottleneck with squeeze-excitation (expand 1x1 -> depthwise kxk -> SE -> project 1x1)."""
+
+    def __init__(self, cin, cout, k, stride, expand, se_ratio=0.25, bn_mom=0.01, bn_eps=1e-3):
+        super().__init__()
+        self.stride, self.cin, self.cout, self.expand = stride, cin, cout, expand
+        mid = cin * expand
+        if expand != 1:
+            self._expand_conv = Conv2dStaticSame(cin, mid, 1)
+            self._bn0 = nn.BatchNorm2d(mid, momentum=bn_mom, eps=bn_eps)
+        self._depthwise_conv = Conv2dStaticSame(mid, mid, k, stride=stride, groups=mid)
+        self._bn1 = nn.BatchNorm2d(mid, momentum=bn_mom, eps=bn_eps)
+        sq = max(1, int(cin * se_ratio))
+        self._se_reduce = Conv2dStaticSame(mid, sq, 1, bias=True)
+        self._se_expand = Conv2dStaticSame(sq, mid, 1, bias=True)
+        self._project_conv = Conv2dStaticSame(mid, cout, 1)
+        self._bn2 = nn.BatchNorm2d(cout, momentum=bn_mom, eps=bn_eps)
+        self._swish = Swish()
+
+    def forward(self, inputs, drop_connect_rate=None):
+        x = inputs
+        if self.expand != 1:
+            x = self._swish(self._bn0(self._expand_conv(x)))
+        x = self._swish(self._bn1(self._depthwise_conv(x)))
+        s = F.adaptive_avg_pool2d(x, 1)
+        s = self._se_expand(self._swish(self._se_reduce(s)))
+        x = torch.sigmoid(s) * x
+        x = self._bn2(self._project_conv(x))
+        if self.stride == 1 and self.cin == self.cout:
+            x = drop_connect(x, drop_connect_rate, self.training) + inputs
+        return x
+
+
+class _GlobalParams:
+    drop_connect_rate = 0.2
+
+
+# (repeats, kernel, stride, expand, in, out)
+B0_STAGES = [(1, 3, 1, 1, 32, 16), (2, 3, 2, 6, 16, 24), (2, 5, 2, 6, 24, 40), (3, 3, 2, 6, 40, 80),
+             (3, 5, 1, 6, 80, 112), (4, 5, 2, 6, 112, 192), (1, 3, 1, 6, 192, 320)]
+
+
+class EfficientNetB0(nn.Module):
+    """Trunk with the member names lss.py:73-94 walks (`_conv_stem`, `_bn0`, `_swish`, `_blocks`, `_global_params`), plus
+    the unused head (`_conv_head`, `_bn1`, `_fc`) so checkpoints load strictly."""
+
+    def __init__(self, in_channels=3, num_classes=1000):
+        super().__init__()
+        self._global_params = _GlobalParams()
+        self._conv_stem = Conv2dStaticSame(in_channels, 32, 3, stride=2)
+        self._bn0 = nn.BatchNorm2d(32, momentum=0.01, eps=1e-3)
+        blocks = []
+        for r, k, s, e, ci, co in B0_STAGES:
+            for i in range(r):
+                blocks.append(MBConvBlock(ci if i == 0 else co, co, k, s if i == 0 else 1, e))
+        self._blocks = nn.ModuleList(blocks)
+        self._conv_head = Conv2dStaticSame(320, 1280, 1)
+        self._bn1 = nn.BatchNorm2d(1280, momentum=0.01, eps=1e-3)
+        self._fc = nn.Linear(1280, num_classes)
+        self._swish = Swish()
+        for m in self.modules():     # TF-style init (the reference overwrites it with ImageNet weights it downloads)
+            if isinstance(m, nn.Conv2d):
+                fan_out = m.kernel_size[0] * m.kernel_size[1] * m.out_channels // m.groups
+                nn.init.normal_(m.weight, 0, math.sqrt(2.0 / fan_out))
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    @classmethod
+    def from_pretrained(cls, name='efficientnet-b0', in_channels=3, **kw):
+        """API-compatible constructor.  ImageNet weights cannot be downloaded here: random init (documented in DESIGN.md)."""
+        assert name == 'efficientnet-b0'
+        return cls(in_channels=in_channels)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# ResNet-18 pieces (He et al. 2015), torchvision naming
+# ------------------------------------------------------------------------------------------------------------
+class BasicBlock(nn.Module):
+    def __init__(self, cin, cout, stride=1):
+        super().__init__()
+        self.conv1 = nn.Conv2d(cin, cout, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(cout)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout)
+        self.downsample = None
+        if stride != 1 or cin != cout:
+            self.downsample = nn.Sequential(nn.Conv2d(cin, cout, 1, stride, bias=False), nn.BatchNorm2d(cout))
+
+    def forward(self, x):
+        idt = x if self.downsample is None else self.downsample(x)
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.bn2(self.conv2(out))
+        return self.relu(out + idt)
+
+
+class ResNet18Trunk(nn.Module):
+    """`bn1`, `relu`, `layer1..3` of torchvision's resnet18(zero_init_residual=True)."""
+
+    def __init__(self, zero_init_residual=True):
+        super().__init__()
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.layer1 = nn.Sequential(BasicBlock(64, 64), BasicBlock(64, 64))
+        self.layer2 = nn.Sequential(BasicBlock(64, 128, 2), BasicBlock(128, 128))
+        self.layer3 = nn.Sequential(BasicBlock(128, 256, 2), BasicBlock(256, 256))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode='fan_out', nonlinearity='relu')
+        if zero_init_residual:
+            for m in self.modules():
+                if isinstance(m, BasicBlock):
+                    nn.init.zeros_(m.bn2.weight)
+
+
+def resnet18(zero_init_residual=True):
+    return ResNet18Trunk(zero_init_residual)

@@ -1,0 +1,335 @@
+// LSS BEV voxel pooling ("splat") for gfx950: sum the lifted camera features of all frustum points that fall into the
+// same BEV voxel.  Replaces `LiftSplatShoot.voxel_pooling`
+// (/root/reference/monoforce/src/monoforce/models/terrain_encoder/lss.py:238-280) and its `cumsum_trick` / `QuickCumsum`
+// helpers (terrain_encoder/utils.py:144-181: argsort by voxel rank, prefix sum over ALL kept points, first-difference at
+// run ends -- an fp32 prefix sum that loses ~1e-3 relative accuracy).
+//
+// Design (HBM-bound: read x once, write the dense BEV grid once, both fully coalesced):
+//   prepare  (geometry only; reusable by forward AND backward, and across steps while the calibration is unchanged)
+//     keys      one thread per point: voxel index with the reference's float32 arithmetic, trunc-toward-zero, in-bounds
+//               mask -> linear voxel id (or -1); integer histogram of points per voxel
+//     scan      exclusive prefix sum of the histogram -> CSR offsets
+//     fill      CSR lists of point ids per voxel
+//   forward   one workgroup per tile of 64 consecutive voxels of one BEV plane; a wave owns a voxel at a time with
+//             lane = channel: it reads the voxel's points' feature rows (C contiguous floats = one coalesced 256 B
+//             access per point), accumulating in ascending point order (deterministic, bit-reproducible); the
+//             [channel][voxel] tile is transposed through LDS so every output row segment (64 voxels of one channel
+//             plane) is written as one contiguous 256 B store.  Empty voxels cost one offsets read.
+//   backward  the same tiling in reverse: the grad tile is loaded coalesced per channel plane, and each kept point's
+//             feature-gradient row is written as one coalesced row (QuickCumsum.backward is exactly this gather);
+//             rows of dropped points are zero-filled by the keys pass of the backward.
+#include "mf_common.h"
+
+namespace mf {
+
+constexpr int kTileVox = 64;
+
+struct SplatWs {        // carve-up of the caller's workspace (all int32)
+  int* keys;            // [P]      linear voxel id of each point, -1 = dropped
+  int* count;           // [V]      points per voxel
+  int* cursor;          // [V]      fill cursors
+  int* offsets;         // [V + 1]  CSR offsets
+  int* list;            // [P]      point ids grouped by voxel
+  int* block_sums;      // [ceil(V / 2048) + 1]
+};
+
+static inline size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+static size_t carve(const MfSplatDesc* d, void* base, SplatWs* ws) {
+  const size_t P = (size_t)d->B * d->n_per_sample;
+  const size_t V = (size_t)d->B * d->nz * d->nx * d->ny;
+  const size_t nblk = (V + 2047) / 2048 + 1;
+  size_t off = 0;
+  char* b = (char*)base;
+  auto take = [&](size_t n_int) { int* p = (int*)(b + off); off += align256(n_int * sizeof(int)); return p; };
+  int* keys = take(P);
+  int* count = take(V);      // count and cursor are adjacent so one memset clears both
+  int* cursor = take(V);
+  int* offsets = take(V + 1);
+  int* list = take(P);
+  int* bs = take(nblk);
+  if (ws) { ws->keys = keys; ws->count = count; ws->cursor = cursor; ws->offsets = offsets; ws->list = list; ws->block_sums = bs; }
+  return off;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// prepare
+// ---------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) splat_keys_kernel(const float* __restrict__ geom, int P, int n_per_sample, int nx, int ny,
+                                                        int nz, float ox, float oy, float oz, float dx, float dy, float dz,
+                                                        int* __restrict__ keys, int* __restrict__ count) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  // idx = ((geom - (bx - dx/2)) / dx).long()   (lss.py:246): float32 subtract, IEEE divide, trunc toward zero
+  const float vx = (geom[(size_t)p * 3 + 0] - ox) / dx;
+  const float vy = (geom[(size_t)p * 3 + 1] - oy) / dy;
+  const float vz = (geom[(size_t)p * 3 + 2] - oz) / dz;
+  const float lim = 1073741824.0f;  // NaN / +-inf / huge values fail these tests and are dropped, as in the reference
+  int key = -1;
+  if (vx > -lim && vx < lim && vy > -lim && vy < lim && vz > -lim && vz < lim) {
+    const int ix = (int)vx, iy = (int)vy, iz = (int)vz;
+    if (ix >= 0 && ix < nx && iy >= 0 && iy < ny && iz >= 0 && iz < nz) {   // (lss.py:253-255)
+      const int b = p / n_per_sample;
+      key = ((b * nz + iz) * nx + ix) * ny + iy;
+      atomicAdd(count + key, 1);
+    }
+  }
+  keys[p] = key;
+}
+
+// exclusive scan, 3 passes: 2048 elements per 256-thread block
+__global__ void __launch_bounds__(256) scan_block_kernel(const int* __restrict__ in, int n, int* __restrict__ out, int* __restrict__ block_sums) {
+  __shared__ int wave_tot[4];
+  const int base = blockIdx.x * 2048 + threadIdx.x * 8;
+  int v[8], s = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { v[i] = (base + i < n) ? in[base + i] : 0; s += v[i]; }
+  // inclusive scan of s across the wave, then across the 4 waves
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = s;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  int wave_off = 0;
+  for (int w = 0; w < wave; ++w) wave_off += wave_tot[w];
+  int run = wave_off + inc - s;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { if (base + i < n) out[base + i] = run; run += v[i]; }
+  if (threadIdx.x == 255) block_sums[blockIdx.x] = wave_off + inc;
+}
+
+__global__ void __launch_bounds__(256) scan_sums_kernel(int* __restrict__ block_sums, int nblk, int* __restrict__ total_out) {
+  // single workgroup: serial over chunks of 256 block sums (nblk <= a few thousand)
+  __shared__ int wave_tot[4];
+  __shared__ int carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < nblk; c0 += 256) {
+    const int i = c0 + threadIdx.x;
+    const int s = (i < nblk) ? block_sums[i] : 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = s;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    int wave_off = 0;
+    for (int w = 0; w < wave; ++w) wave_off += wave_tot[w];
+    const int carry = carry_s;
+    if (i < nblk) block_sums[i] = carry + wave_off + inc - s;
+    __syncthreads();
+    if (threadIdx.x == 255) carry_s = carry + wave_off + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *total_out = carry_s;
+}
+
+__global__ void __launch_bounds__(256) scan_add_kernel(int* __restrict__ out, int n, const int* __restrict__ block_sums) {
+  const int base = blockIdx.x * 2048 + threadIdx.x * 8;
+  const int add = block_sums[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) if (base + i < n) out[base + i] += add;
+}
+
+__global__ void __launch_bounds__(256) splat_fill_kernel(const int* __restrict__ keys, int P, const int* __restrict__ offsets,
+                                                        int* __restrict__ cursor, int* __restrict__ list) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int key = keys[p];
+  if (key >= 0) list[offsets[key] + atomicAdd(cursor + key, 1)] = p;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// in-wave ordering of one voxel's point list (ascending point id => deterministic summation order)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
+  return v;
+}
+
+// Calls f(p) for every point id in list[start, start+cnt) in ascending order.  All 64 lanes must call it together.
+template <typename F>
+__device__ __forceinline__ void for_each_point_sorted(const int* __restrict__ list, int start, int cnt, int lane, F&& f) {
+  if (cnt <= 64) {
+    const int mine = (lane < cnt) ? list[start + lane] : 0x7fffffff;
+    int rank = 0;
+    for (int j = 0; j < cnt; ++j) rank += (__builtin_amdgcn_readlane(mine, j) < mine) ? 1 : 0;
+    const int sorted = __builtin_amdgcn_ds_permute(rank << 2, mine);   // lane `rank` receives `mine`
+    for (int k = 0; k < cnt; ++k) f(__builtin_amdgcn_readlane(sorted, k));
+  } else {
+    int last = -1;                        // rare dense voxel: selection by repeated wave-min
+    for (int k = 0; k < cnt; ++k) {
+      int best = 0x7fffffff;
+      for (int i = lane; i < cnt; i += 64) { const int q = list[start + i]; if (q > last && q < best) best = q; }
+      best = wave_min_i32(best);
+      last = best;
+      f(best);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward / backward tiles
+// ---------------------------------------------------------------------------------------------------------
+template <typename S>
+__global__ void __launch_bounds__(256) splat_fwd_kernel(const S* __restrict__ x, const int* __restrict__ offsets,
+                                                       const int* __restrict__ list, int C, int plane, int tiles_per_plane,
+                                                       S* __restrict__ out) {
+  __shared__ S tile[64][kTileVox + 1];      // [channel][voxel], +1 pad: conflict-free column writes and row reads
+  const int bz = blockIdx.x / tiles_per_plane;                 // (sample, z-slab) plane
+  const int vid0 = (blockIdx.x % tiles_per_plane) * kTileVox;  // first voxel of the tile inside the plane
+  const int nvox = min(kTileVox, plane - vid0);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int key0 = bz * plane + vid0;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int c = c0 + lane;
+    for (int v = wave * 16; v < wave * 16 + 16; ++v) {
+      S acc = (S)0;
+      if (v < nvox) {
+        const int start = offsets[key0 + v];
+        const int cnt = offsets[key0 + v + 1] - start;
+        if (cnt > 0) {
+          for_each_point_sorted(list, start, cnt, lane, [&](int p) {
+            if (c < C) acc += x[(size_t)p * C + c];
+          });
+        }
+      }
+      tile[lane][v] = acc;
+    }
+    __syncthreads();
+    // out[(bz*C + c) * plane + vid]: 64 consecutive voxels of one channel plane per store
+    const int nch = min(64, C - c0);
+    for (int cc = wave; cc < nch; cc += 4)
+      if (lane < nvox) out[((size_t)bz * C + c0 + cc) * plane + vid0 + lane] = tile[cc][lane];
+    __syncthreads();
+  }
+}
+
+template <typename S>
+__global__ void __launch_bounds__(256) splat_bwd_kernel(const S* __restrict__ gout, const int* __restrict__ offsets,
+                                                       const int* __restrict__ list, int C, int plane, int tiles_per_plane,
+                                                       S* __restrict__ gx) {
+  __shared__ S tile[64][kTileVox + 1];
+  const int bz = blockIdx.x / tiles_per_plane;
+  const int vid0 = (blockIdx.x % tiles_per_plane) * kTileVox;
+  const int nvox = min(kTileVox, plane - vid0);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int key0 = bz * plane + vid0;
+  // skip tiles without points (most of the BEV plane is outside the camera frusta)
+  if (offsets[key0 + nvox] == offsets[key0]) return;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int nch = min(64, C - c0);
+    for (int cc = wave; cc < nch; cc += 4)
+      tile[cc][lane] = (lane < nvox) ? gout[((size_t)bz * C + c0 + cc) * plane + vid0 + lane] : (S)0;
+    __syncthreads();
+    const int c = c0 + lane;
+    for (int v = wave * 16; v < wave * 16 + 16 && v < nvox; ++v) {
+      const int start = offsets[key0 + v];
+      const int cnt = offsets[key0 + v + 1] - start;
+      const S g = tile[lane][v];
+      for (int i = 0; i < cnt; ++i) {          // order is irrelevant for a gather
+        const int p = list[start + i];
+        if (c < C) gx[(size_t)p * C + c] = g;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// rows of dropped points get zero gradient (x[kept] in the reference: no gradient reaches the others)
+template <typename S>
+__global__ void __launch_bounds__(256) splat_bwd_zero_kernel(const int* __restrict__ keys, int P, int C, S* __restrict__ gx) {
+  const int lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= P || keys[p] >= 0) return;
+  for (int c = lane; c < C; c += 64) gx[(size_t)p * C + c] = (S)0;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+static int check_desc(const MfSplatDesc* d) {
+  MF_REQUIRE(d, MF_ERR_INVALID, "bev_splat: null descriptor");
+  MF_REQUIRE(d->B > 0 && d->n_per_sample > 0 && d->C > 0 && d->nx > 0 && d->ny > 0 && d->nz > 0, MF_ERR_INVALID,
+             "bev_splat: B, n_per_sample, C, nx, ny, nz must be positive");
+  MF_REQUIRE((long long)d->B * d->n_per_sample < (1ll << 31) && (long long)d->B * d->nz * d->nx * d->ny < (1ll << 31) - 4096,
+             MF_ERR_UNSUPPORTED, "bev_splat: more than 2^31 points or voxels");
+  MF_REQUIRE(d->dx[0] != 0.f && d->dx[1] != 0.f && d->dx[2] != 0.f, MF_ERR_INVALID, "bev_splat: zero voxel size");
+  return MF_OK;
+}
+
+#define MF_LAUNCH_OK(what)                                                                             \
+  do {                                                                                                 \
+    hipError_t e_ = hipGetLastError();                                                                 \
+    MF_REQUIRE(e_ == hipSuccess, MF_ERR_LAUNCH, std::string(what) + ": " + hipGetErrorString(e_));     \
+  } while (0)
+
+static int splat_prepare(const MfSplatDesc* d, const float* geom, void* workspace, hipStream_t st) {
+  SplatWs ws;
+  carve(d, workspace, &ws);
+  const int P = d->B * d->n_per_sample;
+  const int V = d->B * d->nz * d->nx * d->ny;
+  hipError_t e = hipMemsetAsync(ws.count, 0, (char*)ws.offsets - (char*)ws.count, st);   // count + cursor
+  MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("bev_splat memset: ") + hipGetErrorString(e));
+  hipLaunchKernelGGL(splat_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, st, geom, P, d->n_per_sample, d->nx, d->ny, d->nz,
+                     d->off[0], d->off[1], d->off[2], d->dx[0], d->dx[1], d->dx[2], ws.keys, ws.count);
+  MF_LAUNCH_OK("splat_keys");
+  const int nblk = (V + 2047) / 2048;
+  hipLaunchKernelGGL(scan_block_kernel, dim3(nblk), dim3(256), 0, st, ws.count, V, ws.offsets, ws.block_sums);
+  hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, st, ws.block_sums, nblk, ws.offsets + V);
+  hipLaunchKernelGGL(scan_add_kernel, dim3(nblk), dim3(256), 0, st, ws.offsets, V, ws.block_sums);
+  MF_LAUNCH_OK("splat_scan");
+  hipLaunchKernelGGL(splat_fill_kernel, dim3((P + 255) / 256), dim3(256), 0, st, ws.keys, P, ws.offsets, ws.cursor, ws.list);
+  MF_LAUNCH_OK("splat_fill");
+  return MF_OK;
+}
+
+template <typename S>
+static int splat_fwd(const MfSplatDesc* d, const S* x, const void* workspace, S* out, hipStream_t st) {
+  SplatWs ws;
+  carve(d, const_cast<void*>(workspace), &ws);
+  const int plane = d->nx * d->ny;
+  const int tpp = (plane + kTileVox - 1) / kTileVox;
+  hipLaunchKernelGGL((splat_fwd_kernel<S>), dim3(d->B * d->nz * tpp), dim3(256), 0, st, x, ws.offsets, ws.list, d->C, plane, tpp, out);
+  MF_LAUNCH_OK("splat_fwd");
+  return MF_OK;
+}
+
+template <typename S>
+static int splat_bwd(const MfSplatDesc* d, const S* gout, const void* workspace, S* gx, hipStream_t st) {
+  SplatWs ws;
+  carve(d, const_cast<void*>(workspace), &ws);
+  const int P = d->B * d->n_per_sample;
+  const int plane = d->nx * d->ny;
+  const int tpp = (plane + kTileVox - 1) / kTileVox;
+  hipLaunchKernelGGL((splat_bwd_zero_kernel<S>), dim3((P + 3) / 4), dim3(256), 0, st, ws.keys, P, d->C, gx);
+  hipLaunchKernelGGL((splat_bwd_kernel<S>), dim3(d->B * d->nz * tpp), dim3(256), 0, st, gout, ws.offsets, ws.list, d->C, plane, tpp, gx);
+  MF_LAUNCH_OK("splat_bwd");
+  return MF_OK;
+}
+
+}  // namespace mf
+
+extern "C" size_t mf_bev_splat_workspace_bytes(const MfSplatDesc* d) {
+  if (mf::check_desc(d) != MF_OK) return 0;
+  return mf::carve(d, nullptr, nullptr);
+}
+extern "C" int mf_bev_splat_prepare(const MfSplatDesc* d, const float* geom, void* ws, void* s) {
+  int rc = mf::check_desc(d);
+  if (rc != MF_OK) return rc;
+  MF_REQUIRE(geom && ws, MF_ERR_INVALID, "bev_splat_prepare: null buffer");
+  return mf::splat_prepare(d, geom, ws, (hipStream_t)s);
+}
+#define MF_SPLAT_ENTRY(name, S, impl)                                                           \
+  extern "C" int name(const MfSplatDesc* d, const S* in, const void* ws, S* out, void* s) {     \
+    int rc = mf::check_desc(d);                                                                 \
+    if (rc != MF_OK) return rc;                                                                 \
+    MF_REQUIRE(in && ws && out, MF_ERR_INVALID, #name ": null buffer");                         \
+    return mf::impl<S>(d, in, ws, out, (hipStream_t)s);                                         \
+  }
+MF_SPLAT_ENTRY(mf_bev_splat_fwd_f32, float, splat_fwd)
+MF_SPLAT_ENTRY(mf_bev_splat_fwd_f64, double, splat_fwd)
+MF_SPLAT_ENTRY(mf_bev_splat_bwd_f32, float, splat_bwd)
+MF_SPLAT_ENTRY(mf_bev_splat_bwd_f64, double, splat_bwd)

@@ -15,5 +15,6 @@ extern "C" int mf_sizeof(const char* name) {
   if (!strcmp(name, "MfRolloutDesc")) return (int)sizeof(MfRolloutDesc);
   if (!strcmp(name, "MfRolloutFwdBufs")) return (int)sizeof(MfRolloutFwdBufs);
   if (!strcmp(name, "MfRolloutBwdBufs")) return (int)sizeof(MfRolloutBwdBufs);
+  if (!strcmp(name, "MfSplatDesc")) return (int)sizeof(MfSplatDesc);
   return -1;
 }

@@ -1,0 +1,79 @@
+"""BEV voxel pooling on the HIP kernels: `voxel_pooling(geom, x, dx, bx, nx)` == `LiftSplatShoot.voxel_pooling`
+(`/root/reference/monoforce/src/monoforce/models/terrain_encoder/lss.py:238-280`) with exact per-voxel sums.
+
+`SplatPlan` is the geometry-only part (voxel keys + CSR lists); it is built once per `geom` and shared by forward and
+backward, and can be reused across steps while the camera calibration / augmentation is unchanged.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib, _timing
+
+
+def _stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class SplatPlan:
+    def __init__(self, geom, dx, bx, nx):
+        """geom [B, ..., 3] float32 on the GPU; dx, bx (float32 tensors), nx (int64 tensor) as produced by gen_dx_bx."""
+        _lib.require_hip_tensor(geom, 'geom')
+        B = geom.shape[0]
+        g = geom.detach().to(torch.float32).contiguous().view(-1, 3)
+        dxc, bxc = dx.detach().float().cpu(), bx.detach().float().cpu()
+        off = bxc - dxc / 2.                                        # float32, like lss.py:246
+        n = [int(v) for v in nx.detach().cpu().tolist()]
+        self.B, self.n_per_sample = B, g.shape[0] // B
+        self.nx, self.ny, self.nz = n
+        self.device = geom.device
+        self._desc_args = dict(B=B, n_per_sample=self.n_per_sample, nx=n[0], ny=n[1], nz=n[2],
+                               off=(C.c_float * 3)(*off.tolist()), dx=(C.c_float * 3)(*dxc.tolist()))
+        d = self.desc(1)
+        nbytes = _lib.lib().mf_bev_splat_workspace_bytes(C.byref(d))
+        if nbytes == 0:
+            raise RuntimeError('mf_bev_splat_workspace_bytes: ' + _lib.lib().mf_last_error().decode())
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=geom.device)
+        with torch.cuda.device(geom.device), _timing.timed('splat_prepare', geom.device):
+            _lib.check(_lib.lib().mf_bev_splat_prepare(C.byref(d), _lib.ptr(g), _lib.ptr(self.workspace), _stream_ptr(geom.device)),
+                       'mf_bev_splat_prepare')
+        self._geom_keepalive = g
+
+    def desc(self, C_):
+        return _lib.MfSplatDesc(C=C_, **self._desc_args)
+
+
+class _Pool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, plan):
+        Cc = x.shape[-1]
+        xf = x.contiguous().view(-1, Cc)
+        assert xf.shape[0] == plan.B * plan.n_per_sample, 'features and geometry disagree on the number of points'
+        sfx = {torch.float32: 'f32', torch.float64: 'f64'}[xf.dtype]
+        out = torch.empty(plan.B, plan.nz * Cc, plan.nx, plan.ny, dtype=xf.dtype, device=xf.device)
+        d = plan.desc(Cc)
+        with torch.cuda.device(xf.device), _timing.timed('splat_fwd_kernel', xf.device):
+            _lib.check(getattr(_lib.lib(), 'mf_bev_splat_fwd_' + sfx)(C.byref(d), _lib.ptr(xf), _lib.ptr(plan.workspace),
+                                                                       _lib.ptr(out), _stream_ptr(xf.device)), 'mf_bev_splat_fwd')
+        ctx.plan, ctx.x_shape, ctx.sfx = plan, x.shape, sfx
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        plan = ctx.plan
+        Cc = ctx.x_shape[-1]
+        g = gout.contiguous()
+        gx = torch.empty(plan.B * plan.n_per_sample, Cc, dtype=g.dtype, device=g.device)
+        d = plan.desc(Cc)
+        with torch.cuda.device(g.device), _timing.timed('splat_bwd_kernel', g.device):
+            _lib.check(getattr(_lib.lib(), 'mf_bev_splat_bwd_' + ctx.sfx)(C.byref(d), _lib.ptr(g), _lib.ptr(plan.workspace),
+                                                                           _lib.ptr(gx), _stream_ptr(g.device)), 'mf_bev_splat_bwd')
+        return gx.view(ctx.x_shape), None
+
+
+def voxel_pooling(geom, x, dx, bx, nx, plan=None):
+    """geom [B,N,D,H,W,3], x [B,N,D,H,W,C] -> [B, C*nz, nx, ny] (lss.py:238-280).  No gradient to geom, as in the reference."""
+    _lib.require_hip_tensor(x, 'x')
+    if plan is None:
+        plan = SplatPlan(geom, dx, bx, nx)
+    return _Pool.apply(x, plan)

@@ -1,0 +1,177 @@
+"""LiftSplatShoot terrain encoder with the BEV splat on the HIP kernels.
+
+Host-side mirror of `/root/reference/monoforce/src/monoforce/models/terrain_encoder/lss.py` (itself derived from
+nv-tlabs/lift-splat-shoot): same class names, constructor `LiftSplatShoot(grid_conf, data_aug_conf, outC=1)`, same
+`forward(x, rots, trans, intrins, post_rots, post_trans) -> {'geom','terrain','diff','friction'}`, same sub-module and
+parameter names (`camencode.trunk._blocks...`, `bevencode.up_friction`, non-grad parameters `dx`, `bx`, `nx`,
+`frustum`), so reference checkpoints load through `from_pretrained`.  What changes: `voxel_pooling` runs
+`mf_bev_splat_*` (exact per-voxel sums, coalesced reads and writes) instead of argsort + prefix-sum trick; the
+backbones are the plain-torch restatements in `backbones.py` (MIOpen / rocBLAS).
+"""
+import torch
+from torch import nn
+
+from .backbones import EfficientNetB0, resnet18
+from .lss_utils import gen_dx_bx
+from . import splat
+
+H_MAX = 2.0      # DPhysConfig().h_max, which the reference reads at import time for ScaledTanh's default (lss.py:15-19)
+
+
+class ScaledTanh(nn.Module):
+    def __init__(self, min_val=-H_MAX, max_val=H_MAX):
+        super().__init__()
+        self.min_val, self.max_val = min_val, max_val
+
+    def forward(self, x):
+        return self.min_val + (self.max_val - self.min_val) * (torch.tanh(x) + 1) / 2
+
+
+class Up(nn.Module):
+    """Bilinear upsample of the coarse map, concat [skip, up], two conv3x3-BN-GELU (lss.py:27-46)."""
+
+    def __init__(self, in_channels, out_channels, scale_factor=2):
+        super().__init__()
+        self.up = nn.Upsample(scale_factor=scale_factor, mode='bilinear', align_corners=True)
+        self.conv = nn.Sequential(
+            nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1, bias=False), nn.BatchNorm2d(out_channels), nn.GELU(),
+            nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=1, bias=False), nn.BatchNorm2d(out_channels), nn.GELU())
+
+    def forward(self, x1, x2):
+        return self.conv(torch.cat([x2, self.up(x1)], dim=1))
+
+
+class CamEncode(nn.Module):
+    """EfficientNet-b0 features at 1/16 -> D depth logits + C context channels; lift = softmax(depth) (x) context (lss.py:49-99)."""
+
+    def __init__(self, D, C, in_channels=3):
+        super().__init__()
+        self.D, self.C = D, C
+        self.trunk = EfficientNetB0.from_pretrained('efficientnet-b0', in_channels=in_channels)
+        self.up1 = Up(320 + 112, 512)
+        self.depthnet = nn.Conv2d(512, self.D + self.C, kernel_size=1, padding=0)
+
+    def get_depth_dist(self, x, eps=1e-20):
+        return x.softmax(dim=1)
+
+    def get_eff_depth(self, x):
+        """Walk the trunk keeping the last feature map of every resolution; fuse reductions 5 (1/32) and 4 (1/16)."""
+        t = self.trunk
+        x = t._swish(t._bn0(t._conv_stem(x)))
+        endpoints, prev = [], x
+        n = len(t._blocks)
+        for i, block in enumerate(t._blocks):
+            rate = t._global_params.drop_connect_rate
+            if rate:
+                rate *= float(i) / n
+            x = block(x, drop_connect_rate=rate)
+            if prev.size(2) > x.size(2):
+                endpoints.append(prev)
+            prev = x
+        endpoints.append(x)
+        return self.up1(endpoints[4], endpoints[3])
+
+    def get_depth_feat(self, x):
+        x = self.depthnet(self.get_eff_depth(x))
+        depth = self.get_depth_dist(x[:, :self.D])
+        return depth, depth.unsqueeze(1) * x[:, self.D:self.D + self.C].unsqueeze(2)
+
+    def forward(self, x):
+        return self.get_depth_feat(x)[1]
+
+
+def _head(outC, act):
+    return nn.Sequential(nn.Upsample(scale_factor=2, mode='bilinear', align_corners=True),
+                         nn.Conv2d(256, 128, kernel_size=3, padding=1, bias=False), nn.BatchNorm2d(128), nn.GELU(),
+                         nn.Conv2d(128, outC, kernel_size=1, padding=0), act)
+
+
+class BevEncode(nn.Module):
+    """conv7x7/2 + resnet18 layer1-3 + Up(x4) + three heads; terrain = geom - diff (lss.py:101-165)."""
+
+    def __init__(self, inC, outC):
+        super().__init__()
+        trunk = resnet18(zero_init_residual=True)
+        self.conv1 = nn.Conv2d(inC, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1, self.relu = trunk.bn1, trunk.relu
+        self.layer1, self.layer2, self.layer3 = trunk.layer1, trunk.layer2, trunk.layer3
+        self.up1 = Up(64 + 256, 256, scale_factor=4)
+        self.up_geom = _head(outC, ScaledTanh(-1, 1))
+        self.up_diff = _head(outC, nn.ReLU())
+        self.up_friction = _head(outC, nn.ReLU())
+
+    def backbone(self, x):
+        x1 = self.layer1(self.relu(self.bn1(self.conv1(x))))
+        return self.up1(self.layer3(self.layer2(x1)), x1)
+
+    def forward(self, x):
+        x = self.backbone(x)
+        geom, diff = self.up_geom(x), self.up_diff(x)
+        return {'geom': geom, 'terrain': geom - diff, 'diff': diff, 'friction': self.up_friction(x)}
+
+
+class LiftSplatShoot(nn.Module):
+    def __init__(self, grid_conf, data_aug_conf, outC=1, build_backbones=True):
+        super().__init__()
+        self.grid_conf, self.data_aug_conf = grid_conf, data_aug_conf
+        dx, bx, nx = gen_dx_bx(self.grid_conf['xbound'], self.grid_conf['ybound'], self.grid_conf['zbound'])
+        self.dx = nn.Parameter(dx, requires_grad=False)
+        self.bx = nn.Parameter(bx, requires_grad=False)
+        self.nx = nn.Parameter(nx, requires_grad=False)
+        self.downsample = 16
+        self.camC = 64
+        self.frustum = self.create_frustum()
+        self.D = self.frustum.shape[0]
+        if build_backbones:
+            self.camencode = CamEncode(self.D, self.camC)
+            self.bevencode = BevEncode(inC=self.camC, outC=outC)
+        self.use_quickcumsum = True      # accepted for compatibility; both reference paths compute the same sums
+
+    def create_frustum(self):
+        """(u, v, d) of every lifted point: pixel centres on the /16 feature grid x depth bins (lss.py:191-202)."""
+        ogfH, ogfW = self.data_aug_conf['final_dim']
+        fH, fW = ogfH // self.downsample, ogfW // self.downsample
+        ds = torch.arange(*self.grid_conf['dbound'], dtype=torch.float).view(-1, 1, 1).expand(-1, fH, fW)
+        D = ds.shape[0]
+        xs = torch.linspace(0, ogfW - 1, fW, dtype=torch.float).view(1, 1, fW).expand(D, fH, fW)
+        ys = torch.linspace(0, ogfH - 1, fH, dtype=torch.float).view(1, fH, 1).expand(D, fH, fW)
+        return nn.Parameter(torch.stack((xs, ys, ds), -1), requires_grad=False)
+
+    def get_geometry(self, rots, trans, intrins, post_rots, post_trans):
+        """Ego-frame (x,y,z) of the frustum points, B x N x D x fH x fW x 3 (lss.py:204-224): undo the image augmentation,
+        un-project through the pinhole model, camera -> ego.  Tiny (3x3 algebra on ~1e5 points); plain torch ops in the
+        reference's order so the float32 coordinates -- and hence the voxel indices -- agree."""
+        B, N, _ = trans.shape
+        pts = self.frustum - post_trans.view(B, N, 1, 1, 1, 3)
+        pts = torch.inverse(post_rots).view(B, N, 1, 1, 1, 3, 3).matmul(pts.unsqueeze(-1))
+        pts = torch.cat((pts[..., :2, :] * pts[..., 2:3, :], pts[..., 2:3, :]), 5)
+        combine = rots.matmul(torch.inverse(intrins))
+        pts = combine.view(B, N, 1, 1, 1, 3, 3).matmul(pts).squeeze(-1)
+        pts += trans.view(B, N, 1, 1, 1, 3)
+        return pts
+
+    def get_cam_feats(self, x):
+        """B x N x D x fH x fW x C lifted features (lss.py:226-236)."""
+        B, N, C, imH, imW = x.shape
+        x = self.camencode(x.view(B * N, C, imH, imW))
+        x = x.view(B, N, self.camC, self.D, imH // self.downsample, imW // self.downsample)
+        return x.permute(0, 1, 3, 4, 5, 2)
+
+    def voxel_pooling(self, geom_feats, x, plan=None):
+        return splat.voxel_pooling(geom_feats, x, self.dx, self.bx, self.nx, plan=plan)
+
+    def get_voxels(self, x, rots, trans, intrins, post_rots, post_trans):
+        geom = self.get_geometry(rots, trans, intrins, post_rots, post_trans)
+        return self.voxel_pooling(geom, self.get_cam_feats(x))
+
+    def forward(self, x, rots, trans, intrins, post_rots, post_trans):
+        return self.bevencode(self.get_voxels(x, rots, trans, intrins, post_rots, post_trans))
+
+    def from_pretrained(self, modelf):
+        if not modelf:
+            return self
+        print(f'Loading pretrained {self.__class__.__name__} model from', modelf)
+        sd = self.state_dict()
+        sd.update(torch.load(modelf, map_location='cpu'))
+        self.load_state_dict(sd)
+        return self

@@ -1,0 +1,116 @@
+"""Parity of the HIP BEV splat (through the C ABI) against the reference's golden vectors and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import splat_oracle as so
+from tests import helpers as hp
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def pool(geom, x, dx, bx, nx, requires_grad=False):
+    from monoforce_amd.splat import voxel_pooling
+    xg = torch.as_tensor(x).to(DEV).requires_grad_(requires_grad)
+    out = voxel_pooling(torch.as_tensor(geom).to(DEV), xg, torch.as_tensor(dx), torch.as_tensor(bx), torch.as_tensor(nx))
+    return out, xg
+
+
+@pytest.mark.parametrize('tag', ['f32', 'f64'])
+def test_golden_forward_backward(tag):
+    g = hp.load('lss')
+    x = g['x'].astype(np.float32 if tag == 'f32' else np.float64)
+    out, xg = pool(g['geom'], x, g['dx'], g['bx'], g['nx'], requires_grad=True)
+    assert tuple(out.shape) == g['pooled_exact_f64'].shape
+    # vs the exact (float64-accumulated) sums: float32 accumulation of <= ~30 terms per voxel
+    assert hp.rel_err(out, g['pooled_exact_f64']) <= (3e-7 if tag == 'f32' else 1e-15)
+    # and as close to the reference's own float32 output as that output is to the truth
+    assert hp.rel_err(out, g['pooled_ref_f32']) <= 1e-5
+    from monoforce_amd import synthetic as syn
+    w = syn.probe_weights(out.shape, phase=0.3, dtype=out.dtype).to(DEV)
+    (out * w).sum().backward()
+    assert np.array_equal(xg.grad.cpu().numpy().astype(np.float32), g['g_x'])     # pure gather: bit-exact with QuickCumsum.backward
+    out2, _ = pool(g['geom'], x, g['dx'], g['bx'], g['nx'])
+    assert torch.equal(out, out2), 'forward must be bit-reproducible (sorted per-voxel summation order)'
+
+
+def _c4_problem(B=1, C=64, seed=0, n=256, res=0.05):
+    """BASELINE config-4 shapes: 4 cams x 3x256x512 images /16 -> fH=16, fW=32, D=59; 256x256 BEV at 0.05 m."""
+    from monoforce_amd import synthetic as syn
+    from monoforce_amd.terrain_encoder import LiftSplatShoot
+    grid_conf = dict(xbound=[-6.4, 6.4, res], ybound=[-6.4, 6.4, res], zbound=[-3.2, 3.2, 6.4], dbound=[0.6, 6.4, 0.1])
+    m = LiftSplatShoot(grid_conf, dict(final_dim=(256, 512)), outC=1, build_backbones=False)
+    rig = syn.lss_camera_rig(B, 4, 256, 512, 300.0)
+    geom = m.get_geometry(*rig)
+    rng = np.random.RandomState(seed)
+    x = rng.randn(*geom.shape[:-1], C).astype(np.float32)
+    return m, geom, x
+
+
+def test_full_size_vs_oracle():
+    m, geom, x = _c4_problem()
+    assert geom.shape == (1, 4, 59, 16, 32, 3)
+    out, xg = pool(geom, x, m.dx, m.bx, m.nx, requires_grad=True)
+    ref, kept = so.voxel_pooling(geom.numpy(), x, m.dx.numpy(), m.bx.numpy(), m.nx.numpy())
+    assert 0.2 < kept.mean() <= 1.0
+    assert hp.rel_err(out, ref) <= 5e-7
+    gout = torch.randn(out.shape, generator=torch.Generator().manual_seed(1))
+    out.backward(gout.to(DEV))
+    gref = so.voxel_pooling_grad(geom.numpy(), gout.numpy(), m.dx.numpy(), m.bx.numpy(), m.nx.numpy(), C=64)
+    assert np.array_equal(xg.grad.cpu().numpy().reshape(gref.shape), gref)
+
+
+def test_size_independent_properties():
+    m, geom, x = _c4_problem(B=2, C=64, seed=3)
+    xd = x.astype(np.float64)
+    out, _ = pool(geom, xd, m.dx, m.bx, m.nx)
+    _, kept = so.voxel_pooling(geom.numpy(), x[..., :1], m.dx.numpy(), m.bx.numpy(), m.nx.numpy())
+    # conservation: everything that was kept ends up in the grid, nothing else does
+    assert abs(float(out.sum()) - xd.reshape(2, -1, 64)[kept].sum()) <= 1e-8 * np.abs(xd).sum()
+    # linearity
+    y = np.random.RandomState(9).randn(*x.shape)
+    a, _ = pool(geom, 2.0 * xd - 3.0 * y, m.dx, m.bx, m.nx)
+    b, _ = pool(geom, y, m.dx, m.bx, m.nx)
+    assert hp.rel_err(a, (2.0 * out - 3.0 * b).cpu()) <= 1e-12
+    # batch independence: sample 1 alone gives the same slab
+    o1, _ = pool(geom[1:], xd[1:], m.dx, m.bx, m.nx)
+    assert torch.equal(o1[0], out[1])
+    # zero features -> zero grid; every cell is written (no stale memory)
+    z, _ = pool(geom, np.zeros_like(x), m.dx, m.bx, m.nx)
+    assert float(z.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('C,nxy,nz', [(8, 16, 1), (80, 50, 1), (64, 40, 3), (1, 7, 2), (130, 12, 1)])
+def test_ragged_shapes_and_edges(C, nxy, nz):
+    """Channel counts that are not multiples of 64, planes that are not multiples of the 64-voxel tile, nz > 1,
+    NaN / inf / far-away / exactly-on-the-boundary coordinates, all-dropped and single-voxel pile-ups (> 64 points)."""
+    rng = np.random.RandomState(C + nxy)
+    B, P = 2, 700
+    dx = np.array([0.5, 0.5, 1.0], np.float32)
+    bx = np.array([-nxy * 0.25 + 0.25, -nxy * 0.25 + 0.25, -nz * 0.5 + 0.5], np.float32)
+    nx = np.array([nxy, nxy, nz])
+    geom = (rng.rand(B, P, 3).astype(np.float32) - 0.5) * np.array([nxy * 0.6, nxy * 0.6, nz * 1.2], np.float32)
+    geom[0, :100] = np.array([0.1, 0.1, 0.0], np.float32)                 # 100 points piled into one voxel
+    geom[0, 100] = [np.nan, 0, 0]; geom[0, 101] = [np.inf, 0, 0]; geom[0, 102] = [0, -np.inf, 0]; geom[0, 103] = [1e30, 0, 0]
+    geom[0, 104] = [-nxy * 0.25, 0, 0]; geom[0, 105] = [-nxy * 0.25 - 0.49, 0, 0]   # on / just below the lower bound: kept (trunc)
+    geom[1, :] += 1000.0                                                  # sample 1: everything dropped
+    x = rng.randn(B, P, C)
+    out, xg = pool(geom, x, dx, bx, nx, requires_grad=True)
+    ref, kept = so.voxel_pooling(geom, x, dx, bx, nx)
+    assert kept[0, 104] and kept[0, 105] and not kept[0, 100:104].any() and not kept[1].any()
+    assert hp.rel_err(out, ref) <= 1e-13
+    assert float(out[1].abs().max()) == 0.0
+    gout = rng.randn(*out.shape)
+    out.backward(torch.as_tensor(gout).to(DEV))
+    assert np.array_equal(xg.grad.cpu().numpy(), so.voxel_pooling_grad(geom, gout, dx, bx, nx, C))
+
+
+def test_plan_reuse():
+    from monoforce_amd.splat import SplatPlan, voxel_pooling
+    m, geom, x = _c4_problem(seed=5)
+    plan = SplatPlan(geom.to(DEV), m.dx, m.bx, m.nx)
+    a = voxel_pooling(None, torch.as_tensor(x).to(DEV), None, None, None, plan=plan)
+    b = voxel_pooling(geom.to(DEV), torch.as_tensor(x).to(DEV), m.dx, m.bx, m.nx)
+    c = voxel_pooling(None, torch.as_tensor(x[..., :16].copy()).to(DEV), None, None, None, plan=plan)   # other C, same plan
+    assert torch.equal(a, b) and torch.equal(c, a[:, :16])

@@ -1,0 +1,80 @@
+"""Host-side logic of the terrain encoder (no GPU): grid constants, frustum and geometry vs the reference's golden
+vectors; backbone parameter names / shapes (state_dict compatibility with reference checkpoints)."""
+import numpy as np
+import torch
+
+from tests import helpers as hp
+
+LSS_SMALL = dict(
+    grid_conf=dict(xbound=[-3.2, 3.2, 0.2], ybound=[-3.2, 3.2, 0.2], zbound=[-2.0, 2.0, 2.0], dbound=[0.6, 3.4, 0.4]),
+    data_aug_conf=dict(final_dim=(64, 96), H=64, W=96))
+
+
+def test_grid_constants_and_frustum_match_reference():
+    from monoforce_amd.terrain_encoder import LiftSplatShoot
+    g = hp.load('lss')
+    m = LiftSplatShoot(LSS_SMALL['grid_conf'], LSS_SMALL['data_aug_conf'], build_backbones=False)
+    assert np.array_equal(m.dx.numpy(), g['dx']) and np.array_equal(m.bx.numpy(), g['bx']) and np.array_equal(m.nx.numpy(), g['nx'])
+    assert np.array_equal(m.frustum.numpy(), g['frustum'])
+    assert m.nx.dtype == torch.int64 and not m.dx.requires_grad and 'frustum' in m.state_dict()
+
+
+def test_get_geometry_matches_reference():
+    from monoforce_amd.terrain_encoder import LiftSplatShoot
+    g = hp.load('lss')
+    m = LiftSplatShoot(LSS_SMALL['grid_conf'], LSS_SMALL['data_aug_conf'], build_backbones=False)
+    geom = m.get_geometry(*(torch.as_tensor(g[k]) for k in ('rots', 'trans', 'intrins', 'post_rots', 'post_trans'))).numpy()
+    ref = g['geom'].copy()
+    mask = np.ones(ref.shape[:-1], bool)
+    mask[0, 0, 0, 0, :4] = False            # the generator overwrote these four points with hand-made edge cases
+    assert np.array_equal(geom[mask], ref[mask])      # same torch ops in the same order -> bit-exact on CPU
+
+
+def test_full_size_depth_bins():
+    from monoforce_amd.terrain_encoder import LiftSplatShoot
+    gc = dict(xbound=[-6.4, 6.4, 0.05], ybound=[-6.4, 6.4, 0.05], zbound=[-3.2, 3.2, 6.4], dbound=[0.6, 6.4, 0.1])
+    m = LiftSplatShoot(gc, dict(final_dim=(256, 512)), build_backbones=False)
+    assert m.D == 59 and tuple(m.frustum.shape) == (59, 16, 32, 3) and m.nx.tolist() == [256, 256, 1]
+
+
+def test_backbone_state_dict_names_and_shapes():
+    """Keys a reference checkpoint carries, incl. the unused EfficientNet head."""
+    from monoforce_amd.terrain_encoder import LiftSplatShoot
+    m = LiftSplatShoot(LSS_SMALL['grid_conf'], LSS_SMALL['data_aug_conf'], outC=1)
+    sd = m.state_dict()
+    expect = {
+        'camencode.trunk._conv_stem.weight': (32, 3, 3, 3), 'camencode.trunk._bn0.running_mean': (32,),
+        'camencode.trunk._blocks.0._depthwise_conv.weight': (32, 1, 3, 3), 'camencode.trunk._blocks.0._se_reduce.weight': (8, 32, 1, 1),
+        'camencode.trunk._blocks.0._project_conv.weight': (16, 32, 1, 1), 'camencode.trunk._blocks.1._expand_conv.weight': (96, 16, 1, 1),
+        'camencode.trunk._blocks.1._se_reduce.bias': (4,), 'camencode.trunk._blocks.3._depthwise_conv.weight': (144, 1, 5, 5),
+        'camencode.trunk._blocks.10._project_conv.weight': (112, 672, 1, 1), 'camencode.trunk._blocks.15._project_conv.weight': (320, 1152, 1, 1),
+        'camencode.trunk._conv_head.weight': (1280, 320, 1, 1), 'camencode.trunk._fc.weight': (1000, 1280),
+        'camencode.up1.conv.0.weight': (512, 432, 3, 3), 'camencode.depthnet.weight': (7 + 64, 512, 1, 1), 'camencode.depthnet.bias': (71,),
+        'bevencode.conv1.weight': (64, 64, 7, 7), 'bevencode.layer1.0.conv1.weight': (64, 64, 3, 3),
+        'bevencode.layer2.0.downsample.0.weight': (128, 64, 1, 1), 'bevencode.layer3.1.bn2.weight': (256,),
+        'bevencode.up1.conv.0.weight': (256, 320, 3, 3), 'bevencode.up_geom.1.weight': (128, 256, 3, 3),
+        'bevencode.up_friction.4.weight': (1, 128, 1, 1), 'bevencode.up_diff.4.bias': (1,), 'dx': (3,), 'bx': (3,), 'nx': (3,),
+    }
+    for k, shp in expect.items():
+        assert k in sd, k
+        assert tuple(sd[k].shape) == shp, (k, tuple(sd[k].shape))
+    assert '_expand_conv.weight' not in ' '.join(k for k in sd if k.startswith('camencode.trunk._blocks.0.'))
+    assert len([k for k in sd if k.startswith('camencode.trunk._blocks.')]) > 0 and len(m.camencode.trunk._blocks) == 16
+    n_params = sum(p.numel() for p in m.parameters() if p.requires_grad)
+    assert 12e6 < n_params < 16e6          # SURVEY 8e estimate: ~13.6 M
+    assert float(m.bevencode.layer1[0].bn2.weight.abs().sum()) == 0.0      # zero_init_residual
+
+
+def test_encoder_runs_on_cpu_and_head_ranges():
+    """The torch.nn parts are device-agnostic; only the splat needs the GPU.  Check lift shapes and head activations."""
+    from monoforce_amd.terrain_encoder import CamEncode, BevEncode
+    ce = CamEncode(D=7, C=64).eval()
+    with torch.no_grad():
+        lifted = ce(torch.randn(2, 3, 64, 96))
+    assert tuple(lifted.shape) == (2, 64, 7, 4, 6)
+    be = BevEncode(inC=64, outC=1).eval()
+    with torch.no_grad():
+        out = be(torch.randn(1, 64, 32, 32))
+    assert set(out) == {'geom', 'terrain', 'diff', 'friction'} and tuple(out['geom'].shape) == (1, 1, 32, 32)
+    assert float(out['geom'].abs().max()) <= 1.0 and float(out['diff'].min()) >= 0.0 and float(out['friction'].min()) >= 0.0
+    assert torch.equal(out['terrain'], out['geom'] - out['diff'])
