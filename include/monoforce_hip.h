@@ -60,7 +60,9 @@ typedef struct MfRolloutDesc {
   int32_t block;      /* threads per workgroup: 0 = default (64); otherwise 64, 128 or 256 */
   int32_t skip_snap;  /* 1: do NOT move x0.z onto the terrain first (dphysics.py:567-571) -- for continuing a rollout
                          from a mid-trajectory state (chunked horizons, teacher-forced single steps) */
-  int32_t reserved;   /* keep the doubles 8-byte aligned; must be 0 */
+  int32_t points_per_lane; /* lane mapping: 0 = choose from B and N; 1 = one contact point per lane (fewest instructions per
+                         wave, best when the launch is latency-bound); 4 = four points per lane (least redundant work,
+                         best when the chip is full).  Results differ only in float summation order. */
   double mass, gravity, stiffness, damping, omega_max;
   double grid_res, d_max;
   double dt;           /* cfg.dt: step of MF_INTEG_DYNAMICS (ODEINT takes its steps from ts[]) */

@@ -42,6 +42,7 @@ __device__ __forceinline__ double lane_xor(double v, int m) { return __shfl_xor(
 // are valid because after each step the already-merged sub-groups hold identical values.
 template <int G, typename S>
 __device__ __forceinline__ S group_sum(S v) {
+  if (G == 1) return v;
   static_assert(G == 1 || G == 2 || G == 4 || G == 8 || G == 16 || G == 32 || G == 64, "G must be a power of two <= 64");
   if (G >= 2) v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
   if (G >= 4) v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]

@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
   bool act[PPL];
 #pragma unroll
   for (int j = 0; j < PPL; ++j) {
-    int i = gl + j * G;
+    int i = gl * PPL + j;       // blocked, as in the forward
     act[j] = i < a.N;
     int ii = act[j] ? i : 0;
     P[j][0] = a.points[ii * 3 + 0];
@@ -220,7 +220,7 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
 #pragma unroll
         for (int j = 0; j < PPL; ++j)
           if (act[j]) {
-            const size_t o = (out_row * a.N + (gl + j * G)) * 3;
+            const size_t o = (out_row * a.N + (gl * PPL + j)) * 3;
 #pragma unroll
             for (int c = 0; c < 3; ++c) laFs[j][c] += a.gFs[o + c];
           }
@@ -229,7 +229,7 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
 #pragma unroll
         for (int j = 0; j < PPL; ++j)
           if (act[j]) {
-            const size_t o = (out_row * a.N + (gl + j * G)) * 3;
+            const size_t o = (out_row * a.N + (gl * PPL + j)) * 3;
 #pragma unroll
             for (int c = 0; c < 3; ++c) laFf[j][c] += a.gFf[o + c];
           }
@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
       // forces of this step are outputs themselves
 #pragma unroll
       for (int j = 0; j < PPL; ++j) {
-        const size_t o = (out_row * a.N + (gl + j * G)) * 3;
+        const size_t o = (out_row * a.N + (gl * PPL + j)) * 3;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
           gFr[j][c] = (a.gFs && act[j]) ? a.gFs[o + c] : zero;
@@ -471,7 +471,7 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
     } else {
       lR[0] += ge[0] / el; lR[3] += ge[1] / el; lR[6] += ge[2] / el;
     }
-    if (gl == 0) { gctrl[n * 2 + 0] = gv; gctrl[n * 2 + 1] = gwc; }
+    if (G == 1 || gl == 0) { gctrl[n * 2 + 0] = gv; gctrl[n * 2 + 1] = gwc; }
   }
 
   if (INTEG == MF_INTEG_ODEINT_EULER) add_upstream_state(row0);   // output 0 is the initial state itself
@@ -569,14 +569,25 @@ int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* stream)
 
   hipStream_t st = (hipStream_t)stream;
   const int N = d->N, integ = d->integrator;
-  if (N <= 4) return launch_bwd<S, 4, 1>(a, integ, block, st);
-  if (N <= 8) return launch_bwd<S, 4, 2>(a, integ, block, st);
-  if (N <= 16) return launch_bwd<S, 16, 1>(a, integ, block, st);
-  if (N <= 32) return launch_bwd<S, 16, 2>(a, integ, block, st);
-  if (N <= 64) return launch_bwd<S, 64, 1>(a, integ, block, st);
-  if (N <= 128) return launch_bwd<S, 64, 2>(a, integ, block, st);
-  if (N <= 256) return launch_bwd<S, 64, 4>(a, integ, block, st);
-  return launch_bwd<S, 64, 8>(a, integ, block, st);
+  // Lane mapping: G lanes per rollout x PPL points per lane.  A single wave issues roughly one instruction per
+  // 4-5 cycles whatever the dependences, so while the launch has few waves per SIMD (latency-bound, e.g. B = 1024, N = 4)
+  // one point per lane minimises the instructions a wave must issue per step; once the chip is full the redundant
+  // per-lane state update of that mapping costs throughput and 4 points per lane wins (measured crossover ~4 waves/SIMD).
+  int g1 = 4;
+  while (g1 < N) g1 <<= 1;                                   // lanes per rollout at one point per lane
+  bool wide = g1 <= 64 && (long long)a.B * g1 / 64 <= 4096;
+  if (d->points_per_lane == 1 && g1 <= 64) wide = true;
+  if (d->points_per_lane == 4) wide = false;
+#define MF_GO(G_, P_) return launch_bwd<S, G_, P_>(a, integ, block, st)
+  if (N <= 4) { if (wide) MF_GO(4, 1); MF_GO(1, 4); }
+  if (N <= 8) { if (wide) MF_GO(8, 1); MF_GO(2, 4); }
+  if (N <= 16) { if (wide) MF_GO(16, 1); MF_GO(4, 4); }
+  if (N <= 32) { if (wide) MF_GO(32, 1); MF_GO(8, 4); }
+  if (N <= 64) { if (wide) MF_GO(64, 1); MF_GO(16, 4); }
+  if (N <= 128) { if (d->points_per_lane != 4 && (long long)a.B * 2 <= 4096) MF_GO(64, 2); MF_GO(32, 4); }
+  if (N <= 256) MF_GO(64, 4);
+  MF_GO(64, 8);
+#undef MF_GO
 }
 
 }  // namespace mf

@@ -6,8 +6,9 @@
 // contact forces and the rigid-body update (`forward_kinematics`, :172-272), then one Euler step of either integrator
 // (`dynamics` :467-497 / `dynamics_odeint` :499-528), and streams the six API outputs.
 //
-// Mapping (wave64): a rollout is owned by a group of G consecutive lanes (G = 4, 16 or 64), each lane owning PPL
-// contact points (point i -> lane i % G, slot i / G).  The 18-float rigid-body state is replicated in every lane of
+// Mapping (wave64): a rollout is owned by a group of G consecutive lanes (G = 1 .. 64), each lane owning PPL = 4
+// consecutive contact points (N = 4: one lane per rollout).  Several points per lane give the in-order SIMD
+// independent instruction streams to interleave -- the step is a latency-bound dependent chain otherwise.  The 18-float rigid-body state is replicated in every lane of
 // the group, so the only cross-lane traffic per step is two all-reduces (sum of contact weights; 9-component wrench),
 // done on DPP for G <= 16.  The time axis is a dependent chain and stays serial inside the lane; parallelism is
 // over rollouts (and points).  Map cells are gathered straight from global memory: both maps are read-only and at
@@ -59,7 +60,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
   bool act[PPL];
 #pragma unroll
   for (int j = 0; j < PPL; ++j) {
-    int i = gl + j * G;
+    int i = gl * PPL + j;       // blocked: a lane owns PPL consecutive points (contiguous force rows per lane)
     act[j] = i < a.N;
     int ii = act[j] ? i : 0;
     P[j][0] = a.points[ii * 3 + 0];
@@ -104,28 +105,22 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
 #pragma unroll
     for (int c = 0; c < 3; ++c) accFs[j][c] = accFf[j][c] = zero;
 
-  // Stores of one output row.  Lanes 0/1/2 of the group write (Xs + R row 0) / (Xds + R row 1) / (Omegas + R row 2).
+  // Stores of one output row, by lane 0 of the group (G == 1: every lane): no per-lane value selection on the
+  // dependent issue stream; a wave's 64/G rows are contiguous in the time-major layout.
   auto emit_state = [&](size_t row) {
-    if (gl < 3) {
-      S v0, v1, v2;
-      S* dst;
-      if (gl == 0) {
-        v0 = x[0] + R[2] * a.sink;  // Xs += Rs[..., :, 2] * m g / (k + 1e-6)   (dphysics.py:587-589)
-        v1 = x[1] + R[5] * a.sink;
-        v2 = x[2] + R[8] * a.sink;
-        dst = a.Xs;
-      } else if (gl == 1) {
-        v0 = xd[0]; v1 = xd[1]; v2 = xd[2];
-        dst = a.Xds;
-      } else {
-        v0 = w[0]; v1 = w[1]; v2 = w[2];
-        dst = a.Om;
-      }
-      S* p = dst + row * 3;
-      p[0] = v0; p[1] = v1; p[2] = v2;
-      S* q = a.Rs + row * 9 + gl * 3;
-      q[0] = R[gl * 3 + 0]; q[1] = R[gl * 3 + 1]; q[2] = R[gl * 3 + 2];
-      if (gl == 0 && a.Xraw) {
+    if (G == 1 || gl == 0) {
+      S* p = a.Xs + row * 3;
+      p[0] = x[0] + R[2] * a.sink;  // Xs += Rs[..., :, 2] * m g / (k + 1e-6)   (dphysics.py:587-589)
+      p[1] = x[1] + R[5] * a.sink;
+      p[2] = x[2] + R[8] * a.sink;
+      S* q = a.Xds + row * 3;
+      q[0] = xd[0]; q[1] = xd[1]; q[2] = xd[2];
+      S* o = a.Om + row * 3;
+      o[0] = w[0]; o[1] = w[1]; o[2] = w[2];
+      S* rr = a.Rs + row * 9;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) rr[c] = R[c];
+      if (a.Xraw) {
         S* r = a.Xraw + row * 3;
         r[0] = x[0]; r[1] = x[1]; r[2] = x[2];
       }
@@ -135,7 +130,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
       if (act[j]) {
-        size_t o = (row * a.N + (gl + j * G)) * 3;
+        size_t o = (row * a.N + (gl * PPL + j)) * 3;
         a.Fs[o + 0] = fs[j][0]; a.Fs[o + 1] = fs[j][1]; a.Fs[o + 2] = fs[j][2];
         a.Ff[o + 0] = ff[j][0]; a.Ff[o + 1] = ff[j][1]; a.Ff[o + 2] = ff[j][2];
       }
@@ -356,14 +351,25 @@ int rollout_fwd(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, void* stream)
 
   hipStream_t st = (hipStream_t)stream;
   const int N = d->N, integ = d->integrator;
-  if (N <= 4) return launch_gp<S, 4, 1>(a, integ, block, st);
-  if (N <= 8) return launch_gp<S, 4, 2>(a, integ, block, st);
-  if (N <= 16) return launch_gp<S, 16, 1>(a, integ, block, st);
-  if (N <= 32) return launch_gp<S, 16, 2>(a, integ, block, st);
-  if (N <= 64) return launch_gp<S, 64, 1>(a, integ, block, st);
-  if (N <= 128) return launch_gp<S, 64, 2>(a, integ, block, st);
-  if (N <= 256) return launch_gp<S, 64, 4>(a, integ, block, st);
-  return launch_gp<S, 64, 8>(a, integ, block, st);
+  // Lane mapping: G lanes per rollout x PPL points per lane.  A single wave issues roughly one instruction per
+  // 4-5 cycles whatever the dependences, so while the launch has few waves per SIMD (latency-bound, e.g. B = 1024, N = 4)
+  // one point per lane minimises the instructions a wave must issue per step; once the chip is full the redundant
+  // per-lane state update of that mapping costs throughput and 4 points per lane wins (measured crossover ~4 waves/SIMD).
+  int g1 = 4;
+  while (g1 < N) g1 <<= 1;                                   // lanes per rollout at one point per lane
+  bool wide = g1 <= 64 && (long long)a.B * g1 / 64 <= 4096;
+  if (d->points_per_lane == 1 && g1 <= 64) wide = true;
+  if (d->points_per_lane == 4) wide = false;
+#define MF_GO(G_, P_) return launch_gp<S, G_, P_>(a, integ, block, st)
+  if (N <= 4) { if (wide) MF_GO(4, 1); MF_GO(1, 4); }
+  if (N <= 8) { if (wide) MF_GO(8, 1); MF_GO(2, 4); }
+  if (N <= 16) { if (wide) MF_GO(16, 1); MF_GO(4, 4); }
+  if (N <= 32) { if (wide) MF_GO(32, 1); MF_GO(8, 4); }
+  if (N <= 64) { if (wide) MF_GO(64, 1); MF_GO(16, 4); }
+  if (N <= 128) { if (d->points_per_lane != 4 && (long long)a.B * 2 <= 4096) MF_GO(64, 2); MF_GO(32, 4); }
+  if (N <= 256) MF_GO(64, 4);
+  MF_GO(64, 8);
+#undef MF_GO
 }
 
 }  // namespace mf

@@ -132,7 +132,8 @@ class _RolloutFn(torch.autograd.Function):
 class DPhysics(torch.nn.Module):
     """Drop-in for the reference `DPhysics` (dphysics.py:144); no parameters, all state is configuration."""
 
-    def __init__(self, dphys_cfg=None, device='cpu', contiguous_outputs=False, block=0, snap_to_terrain=True):
+    def __init__(self, dphys_cfg=None, device='cpu', contiguous_outputs=False, block=0, snap_to_terrain=True,
+                 points_per_lane=0):
         super().__init__()
         self.dphys_cfg = dphys_cfg if dphys_cfg is not None else DPhysConfig()
         self.device = device
@@ -153,6 +154,7 @@ class DPhysics(torch.nn.Module):
         self.contiguous_outputs = contiguous_outputs
         self.block = block
         self.snap_to_terrain = snap_to_terrain     # False: continue from `state` as is (no reference equivalent)
+        self.points_per_lane = points_per_lane     # kernel lane mapping: 0 auto, 1 latency-oriented, 4 throughput-oriented
         self._cache = {}
 
     # -- constants marshalled for the C ABI ---------------------------------------------------------------
@@ -201,7 +203,7 @@ class DPhysics(torch.nn.Module):
             B=controls.shape[0], T=controls.shape[1], N=self.x_points.shape[1], H=H, W=W,
             n_tracks=len(cfg.driving_parts), integrator=integ,
             layout=_lib.MF_LAYOUT_BATCH_MAJOR if self.contiguous_outputs else _lib.MF_LAYOUT_TIME_MAJOR,
-            map_shared=int(shared), block=self.block, skip_snap=int(not self.snap_to_terrain),
+            map_shared=int(shared), block=self.block, skip_snap=int(not self.snap_to_terrain), points_per_lane=self.points_per_lane,
             mass=float(cfg.robot_mass), gravity=float(cfg.gravity), stiffness=float(self.stiffness),
             damping=float(self.damping), omega_max=float(cfg.omega_max), grid_res=float(cfg.grid_res),
             d_max=float(cfg.d_max), dt=float(cfg.dt), robot_size_y=float(cfg.robot_size[1]))

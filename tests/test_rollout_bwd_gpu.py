@@ -25,12 +25,13 @@ def hip_grads(dp, z, ctrl, state, mu, dtype):
 @pytest.mark.parametrize('name', ['A', 'B', 'C'])
 @pytest.mark.parametrize('tag', ['f32', 'f64'])
 @pytest.mark.parametrize('integ', [0, 1])
-def test_small_grads_vs_reference_autograd(name, tag, integ):
+@pytest.mark.parametrize('ppl', [1, 4])
+def test_small_grads_vs_reference_autograd(name, tag, integ, ppl):
     """dL/dz, dL/dmu, dL/dcontrols for a loss touching all six outputs, vs the reference's loss.backward() (T=48)."""
     g = hp.load('rollout_small')
     dt = hp.DT[tag]
     pts, masks, z, ctrl, state, mu = hp.small_case(g, name, dt)
-    dp = make_dphysics(pts, masks, integ, hp.SMALL['grid_res'], hp.SMALL['d_max'])
+    dp = make_dphysics(pts, masks, integ, hp.SMALL['grid_res'], hp.SMALL['d_max'], points_per_lane=ppl)
     loss, gz, gc, gm = hip_grads(dp, z, ctrl, state, mu, dt)
     pre = f'{name}/{tag}/i{integ}/'
     # float64: to rounding.  float32: SURVEY A.2 bar (<= 1e-4 rel at T <= 100; the reference's own fp32-vs-fp64 is ~1e-5)
@@ -43,11 +44,12 @@ def test_small_grads_vs_reference_autograd(name, tag, integ):
 
 
 @pytest.mark.parametrize('integ', [0, 1])
-def test_full_horizon_grads_f64(integ):
+@pytest.mark.parametrize('ppl', [1, 4])
+def test_full_horizon_grads_f64(integ, ppl):
     """T=500 BPTT on 256x256 in float64 vs the reference (gradients explode to 1e3..1e6 there; still <= 1e-6 rel)."""
     g = hp.load('rollout_full')
     pts, masks, z, mu, ctrl = hp.full_inputs(torch.float64)
-    dp = make_dphysics(pts, masks, integ, hp.FULL['grid_res'], hp.FULL['d_max'])
+    dp = make_dphysics(pts, masks, integ, hp.FULL['grid_res'], hp.FULL['d_max'], points_per_lane=ppl)
     loss, gz, gc, gm = hip_grads(dp, z, ctrl, None, mu, torch.float64)
     pre = f'f64/i{integ}/'
     assert abs(loss - float(g[pre + 'loss'])) <= 1e-7 * abs(float(g[pre + 'loss']))
@@ -59,7 +61,8 @@ def test_full_horizon_grads_f64(integ):
 
 
 @pytest.mark.parametrize('N,n_tracks', [(7, 2), (33, 4), (100, 2), (223, 4), (300, 2)])
-def test_grads_all_lane_mappings_vs_oracle_f64(N, n_tracks):
+@pytest.mark.parametrize('ppl', [1, 4])
+def test_grads_all_lane_mappings_vs_oracle_f64(N, n_tracks, ppl):
     """Every (G, PPL) instantiation of the backward kernel, including gradients w.r.t. a given initial state."""
     from monoforce_amd import synthetic as syn
     from oracle import dphysics_oracle as orc
@@ -79,7 +82,7 @@ def test_grads_all_lane_mappings_vs_oracle_f64(N, n_tracks):
         hp.probe_loss(list(so) + list(fo), torch.float64).backward()
         ref = [l.grad for l in leaves] + [s.grad for s in st[1:]]
 
-        dp = make_dphysics(pts, masks, integ, 0.1, 3.2)
+        dp = make_dphysics(pts, masks, integ, 0.1, 3.2, points_per_lane=ppl)
         dl = [t.clone().to(DEV).requires_grad_(True) for t in (z, mu, ctrl)]
         ds = [s.clone().to(DEV) for s in given_state(B)]
         for s in ds[1:]:
