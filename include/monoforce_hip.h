@@ -46,6 +46,13 @@ enum {
   MF_LAYOUT_TIME_MAJOR = 1   /* X[t][b][...] */
 };
 
+/* Arithmetic of the float32 kernels (float64 is always exact). */
+enum {
+  MF_MATH_EXACT = 0, /* IEEE divide/sqrt, libm exp/sincos, no FMA contraction: the reference's eager op sequence, bit-for-bit
+                        for the first ~100 steps of a rollout */
+  MF_MATH_FAST = 1   /* hardware rcp/rsq/exp2 (1 ulp) + FMA: ~1.5x faster per step; same parity tolerances hold */
+};
+
 /* Shapes and physical constants of one rollout launch.  Scalars are double here and are rounded ONCE to the
  * kernel's arithmetic type, like the Python floats of DPhysConfig are when they meet a tensor. */
 typedef struct MfRolloutDesc {
@@ -63,6 +70,9 @@ typedef struct MfRolloutDesc {
   int32_t points_per_lane; /* lane mapping: 0 = choose from B and N; 1 = one contact point per lane (fewest instructions per
                          wave, best when the launch is latency-bound); 4 = four points per lane (least redundant work,
                          best when the chip is full).  Results differ only in float summation order. */
+  int32_t math_mode;    /* MF_MATH_* */
+  int32_t force_stride; /* point slots per row of the Fs / Ff buffers, >= mf_rollout_force_stride(desc); 0 means N
+                           (only valid when N is a multiple of the lane tile, e.g. N = 4).  Padding slots get zeros. */
   double mass, gravity, stiffness, damping, omega_max;
   double grid_res, d_max;
   double dt;           /* cfg.dt: step of MF_INTEG_DYNAMICS (ODEINT takes its steps from ts[]) */
@@ -86,11 +96,13 @@ typedef struct MfRolloutFwdBufs {
   void* Xds;            /* S[..][3]   */
   void* Rs;             /* S[..][3][3]*/
   void* Omegas;         /* S[..][3]   */
-  void* Fs;             /* S[..][N][3] spring forces (DYNAMICS) or their running impulses (ODEINT) */
-  void* Ff;             /* S[..][N][3] friction forces / impulses */
+  void* Fs;             /* S[..][force_stride][3] spring forces (DYNAMICS) or their running impulses (ODEINT) */
+  void* Ff;             /* S[..][force_stride][3] friction forces / impulses */
   void* Xraw;           /* optional S[..][3]: unshifted positions saved for the backward pass; may be NULL */
 } MfRolloutFwdBufs;
 
+/* Point slots per Fs/Ff row the kernels chosen for (B, N, points_per_lane) need (>= N; -1 on a bad descriptor). */
+int mf_rollout_force_stride(const MfRolloutDesc* desc);
 int mf_rollout_fwd_f32(const MfRolloutDesc* desc, const MfRolloutFwdBufs* bufs, void* hip_stream);
 int mf_rollout_fwd_f64(const MfRolloutDesc* desc, const MfRolloutFwdBufs* bufs, void* hip_stream);
 

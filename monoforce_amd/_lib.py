@@ -12,12 +12,13 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libmonoforce_hip.so')
 
 MF_INTEG_DYNAMICS, MF_INTEG_ODEINT_EULER = 0, 1
 MF_LAYOUT_BATCH_MAJOR, MF_LAYOUT_TIME_MAJOR = 0, 1
+MF_MATH_EXACT, MF_MATH_FAST = 0, 1
 
 
 class MfRolloutDesc(C.Structure):
     _fields_ = [('B', C.c_int32), ('T', C.c_int32), ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
                 ('n_tracks', C.c_int32), ('integrator', C.c_int32), ('layout', C.c_int32), ('map_shared', C.c_int32),
-                ('block', C.c_int32), ('skip_snap', C.c_int32), ('points_per_lane', C.c_int32),
+                ('block', C.c_int32), ('skip_snap', C.c_int32), ('points_per_lane', C.c_int32), ('math_mode', C.c_int32), ('force_stride', C.c_int32),
                 ('mass', C.c_double), ('gravity', C.c_double), ('stiffness', C.c_double), ('damping', C.c_double),
                 ('omega_max', C.c_double), ('grid_res', C.c_double), ('d_max', C.c_double), ('dt', C.c_double),
                 ('robot_size_y', C.c_double), ('Iinv', C.c_double * 9)]
@@ -42,7 +43,7 @@ class MfSplatDesc(C.Structure):
 
 
 # every symbol include/monoforce_hip.h declares; tests check the library exports all of them
-SYMBOLS = ['mf_rollout_fwd_f32', 'mf_rollout_fwd_f64', 'mf_rollout_bwd_f32', 'mf_rollout_bwd_f64', 'mf_bev_splat_workspace_bytes', 'mf_bev_splat_prepare',
+SYMBOLS = ['mf_rollout_force_stride', 'mf_rollout_fwd_f32', 'mf_rollout_fwd_f64', 'mf_rollout_bwd_f32', 'mf_rollout_bwd_f64', 'mf_bev_splat_workspace_bytes', 'mf_bev_splat_prepare',
            'mf_bev_splat_fwd_f32', 'mf_bev_splat_fwd_f64', 'mf_bev_splat_bwd_f32', 'mf_bev_splat_bwd_f64', 'mf_last_error', 'mf_version', 'mf_sizeof']
 
 _lib = None

@@ -1,0 +1,9 @@
+// Forward rollout, float32 fast-math instantiations: this TU is compiled with -ffp-contract=fast (FMA), and the
+// kernels use the hardware reciprocal / rsqrt / exp2 (Mth<float, true> in rollout_fwd_kernel.h).
+#include "rollout_fwd_kernel.h"
+
+namespace mf {
+int launch_rollout_fwd_fast_f32(const RolloutArgs<float>& a, LaneMap m, int integ, int block, hipStream_t st) {
+  return launch_rollout_fwd<float, true>(a, m, integ, block, st);
+}
+}  // namespace mf

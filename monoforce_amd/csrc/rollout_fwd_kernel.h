@@ -1,0 +1,442 @@
+// Fused DPhysics rollout, forward pass (gfx950) -- kernel template, instantiated by rollout_fwd.hip (reference-order
+// float32/float64 arithmetic) and rollout_fwd_fast.hip (float32 with hardware reciprocal / rsqrt / exp and FMA contraction).
+//
+// One kernel runs the whole T-step scan of `DPhysics.dphysics()`
+// (/root/reference/monoforce/src/monoforce/models/traj_predictor/dphysics.py:530-594): per step the per-contact-point
+// height/friction sample (`interpolate_grid`, :385-455, bug-for-bug), the spring-damper + friction contact forces and the
+// rigid-body wrench (`forward_kinematics`, :172-272), one Euler step of either integrator (`dynamics` :467-497 /
+// `dynamics_odeint` :499-528), and the six API outputs.
+//
+// Mapping (wave64): a rollout is owned by G consecutive lanes, each lane owning PPL consecutive contact points; the
+// 18-float rigid-body state is replicated in the G lanes, so the only cross-lane traffic per step is two all-reduces (sum
+// of contact weights; wrench), on DPP for G <= 16.  The time axis is a dependent chain and stays serial in the lane.
+// A single wave issues about one instruction per 4-5 cycles whatever the dependences, so a latency-bound launch (few waves
+// per SIMD, e.g. B = 1024 x N = 4) wants the FEWEST instructions per wave and step (PPL = 1), while a launch that fills
+// the chip wants the least redundant work (PPL = 4: the replicated state update is amortised over 4 points).
+//
+// Memory: map cells are gathered straight from global memory (both maps are read-only; 2 x 256 x 256 x 4 B = 512 KiB lives
+// in every XCD's L2, the handful of cells under a slowly moving robot in the CU's L1 -- DESIGN.md discusses why an LDS
+// tile does not pay).  Outputs are time-major by default: the rows a wave writes in one step are contiguous.  The stores
+// of step n-1 are issued right AFTER the gathers of step n: CDNA's vmcnt counts loads and stores in order, so a wait for
+// the gathers then never includes the previous step's stores.
+#pragma once
+#include "rollout_common.h"
+
+namespace mf {
+
+template <typename S>
+struct RolloutArgs {
+  int B, T, N, H, W, n_tracks, layout, map_shared, skip_snap, fstride;
+  S mass, inv_mass, mg, k, damp, omega_max, res, inv_res, d_max, dt, half_ly, sink;
+  S Iinv[9];
+  const S* z;
+  const S* mu;
+  const S* controls;
+  const S* ts;
+  const S* points;
+  const int* part;
+  S* x0;
+  const S* xd0;
+  const S* R0;
+  const S* w0;
+  S* Xs;
+  S* Xds;
+  S* Rs;
+  S* Om;
+  S* Fs;
+  S* Ff;
+  S* Xraw;
+};
+
+// Arithmetic policy.  Exact: IEEE divide / sqrt, libm exp and sincos, un-fused mul+add (the TU is built with
+// -ffp-contract=off) -- tracks the reference's eager float32 op sequence to the last bit for ~100 steps.
+// Fast (float32 only): v_rcp / v_rsq / v_exp (1 ulp), FMA contraction; same tolerances hold (DESIGN.md "Numerics").
+template <typename S, bool FAST>
+struct Mth {
+  static __device__ __forceinline__ S div(S a, S b) { return a / b; }
+  static __device__ __forceinline__ S cell_coord(S q, S d_max, S res, S) { return (q + d_max) / res; }
+  static __device__ __forceinline__ S sqrt(S v) { return mf_sqrt(v); }
+  static __device__ __forceinline__ S sigmoid_m10(S dh) { return (S)1 / ((S)1 + mf_exp((S)10 * dh)); }
+  // v / max(|v|, eps) given |v|^2
+  static __device__ __forceinline__ S inv_len(S len2) { return (S)1 / mf_max(mf_sqrt(len2), (S)1e-6); }
+  static constexpr bool kReciprocalNorm = false;
+  static __device__ __forceinline__ void sincos_small(S v, S* s, S* omc) { S c; mf_sincos(v, s, &c); *omc = (S)1 - c; }
+};
+template <>
+struct Mth<float, true> {
+  static __device__ __forceinline__ float div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+  static __device__ __forceinline__ float cell_coord(float q, float d_max, float, float inv_res) { return (q + d_max) * inv_res; }
+  static __device__ __forceinline__ float sqrt(float v) { return __builtin_amdgcn_sqrtf(v); }
+  static __device__ __forceinline__ float sigmoid_m10(float dh) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(14.426950408889634f * dh));  // exp(10 dh) = 2^(10 log2(e) dh)
+  }
+  static __device__ __forceinline__ float inv_len(float len2) { return __builtin_amdgcn_rsqf(fmaxf(len2, 1e-12f)); }
+  static constexpr bool kReciprocalNorm = true;
+  static __device__ __forceinline__ void sincos_small(float v, float* s, float* omc) {
+    if (fabsf(v) < 0.25f) {  // |w| dt is ~1e-2: short Taylor series, and 1 - cos without the cancellation
+      const float v2 = v * v;
+      *s = v * (1.0f + v2 * (-1.0f / 6 + v2 * (1.0f / 120 - v2 * (1.0f / 5040))));
+      *omc = v2 * (0.5f + v2 * (-1.0f / 24 + v2 * (1.0f / 720 - v2 * (1.0f / 40320))));
+    } else {
+      float c;
+      sincosf(v, s, &c);
+      *omc = 1.0f - c;
+    }
+  }
+};
+
+template <typename S, bool FAST>
+__device__ __forceinline__ Cell<S> locate_m(S qx, S qy, S d_max, S res, S inv_res, int H, int last) {
+  const S lim = (S)262144.0;
+  S ux = Mth<S, FAST>::cell_coord(qx, d_max, res, inv_res);
+  S uy = Mth<S, FAST>::cell_coord(qy, d_max, res, inv_res);
+  int ix = (int)mf_clamp(ux, -lim, lim);  // trunc toward zero, like .long()
+  int iy = (int)mf_clamp(uy, -lim, lim);
+  Cell<S> c;
+  c.fx = ux - (S)ix;
+  c.fy = uy - (S)iy;
+  int base = iy + H * ix;
+  c.ic = min(max(base, 0), last);
+  c.i_f = min(max(base + H, 0), last);
+  c.il = min(max(base + 1, 0), last);
+  c.ifl = min(max(base + 1 + H, 0), last);
+  return c;
+}
+
+template <typename S, int G, int PPL, int INTEG, bool FAST>
+__global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a) {
+  using M = Mth<S, FAST>;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = tid / G;
+  const int gl = tid % G;
+  if (b >= a.B) return;  // whole groups leave together; live groups never read dead lanes
+  const S one = (S)1, zero = (S)0;
+  const int HW = a.H * a.W, last = HW - 1;
+  const bool has_mu = a.mu != nullptr;  // wave-uniform
+  const S* zmap = a.z + (a.map_shared ? 0 : (size_t)b * HW);
+  const S* mumap = has_mu ? a.mu + (a.map_shared ? 0 : (size_t)b * HW) : a.z;
+
+  // this lane's contact points
+  S P[PPL][3];
+  int part[PPL];
+  bool act[PPL];
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) {
+    int i = gl * PPL + j;  // blocked: a lane owns PPL consecutive points (contiguous force rows per lane)
+    act[j] = i < a.N;
+    int ii = act[j] ? i : 0;
+    P[j][0] = a.points[ii * 3 + 0];
+    P[j][1] = a.points[ii * 3 + 1];
+    P[j][2] = a.points[ii * 3 + 2];
+    part[j] = act[j] ? a.part[ii] : -1;
+  }
+
+  // state, replicated across the group
+  S x[3], xd[3], R[9], w[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    x[c] = a.x0[b * 3 + c];
+    xd[c] = a.xd0[b * 3 + c];
+    w[c] = a.w0[b * 3 + c];
+  }
+#pragma unroll
+  for (int c = 0; c < 9; ++c) R[c] = a.R0[b * 9 + c];
+
+  // start at the terrain height: x.z <- mean_i interp(z, (P R^T + x)_i)   (dphysics.py:567-571)
+  if (!a.skip_snap) {
+    S acc = zero;
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      S px = P[j][0] * R[0] + P[j][1] * R[1] + P[j][2] * R[2] + x[0];
+      S py = P[j][0] * R[3] + P[j][1] * R[4] + P[j][2] * R[5] + x[1];
+      Cell<S> c = locate_m<S, FAST>(px, py, a.d_max, a.res, a.inv_res, a.H, last);
+      S v = blend(c, zmap[(unsigned)c.ic], zmap[(unsigned)c.i_f], zmap[(unsigned)c.il], zmap[(unsigned)c.ifl]);
+      acc += act[j] ? v : zero;
+    }
+    acc = group_sum<G>(acc);
+    x[2] = acc / (S)a.N;
+    if (gl == 0) a.x0[b * 3 + 2] = x[2];
+  }
+
+  // running output pointers (one bump per step instead of 64-bit index arithmetic)
+  const size_t row_stride = (a.layout == MF_LAYOUT_TIME_MAJOR) ? (size_t)a.B : 1;  // rows between consecutive t
+  const size_t row0 = (a.layout == MF_LAYOUT_TIME_MAJOR) ? (size_t)b : (size_t)b * a.T;
+  S* pXs = a.Xs + row0 * 3;
+  S* pXds = a.Xds + row0 * 3;
+  S* pOm = a.Om + row0 * 3;
+  S* pRs = a.Rs + row0 * 9;
+  S* pXraw = a.Xraw ? a.Xraw + row0 * 3 : nullptr;
+  const size_t frow = (size_t)a.fstride * 3;  // floats per force row (>= G * PPL points: stores need no predication)
+  S* pFs = a.Fs + row0 * frow + (size_t)gl * PPL * 3;
+  S* pFf = a.Ff + row0 * frow + (size_t)gl * PPL * 3;
+  const bool want_raw = a.Xraw != nullptr;  // wave-uniform
+
+  S oFs[PPL][3], oFf[PPL][3];  // forces of the pending output row (ODEINT: running impulses, dphysics.py:506-509)
+#pragma unroll
+  for (int j = 0; j < PPL; ++j)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) oFs[j][c] = oFf[j][c] = zero;
+
+  // Stores of the pending output row (the state registers ARE that row).  Every lane of the group stores the same state
+  // values to the same addresses (no exec-mask branch on the issue stream; the coalescer merges them) and its own forces.
+  auto emit_row = [&]() {
+    pXs[0] = x[0] + R[2] * a.sink;  // Xs += Rs[..., :, 2] * m g / (k + 1e-6)   (dphysics.py:587-589)
+    pXs[1] = x[1] + R[5] * a.sink;
+    pXs[2] = x[2] + R[8] * a.sink;
+    pXds[0] = xd[0]; pXds[1] = xd[1]; pXds[2] = xd[2];
+    pOm[0] = w[0]; pOm[1] = w[1]; pOm[2] = w[2];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) pRs[c] = R[c];
+    if (want_raw) { pXraw[0] = x[0]; pXraw[1] = x[1]; pXraw[2] = x[2]; }
+#pragma unroll
+    for (int j = 0; j < PPL; ++j)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { pFs[j * 3 + c] = oFs[j][c]; pFf[j * 3 + c] = oFf[j][c]; }
+    pXs += row_stride * 3; pXds += row_stride * 3; pOm += row_stride * 3; pRs += row_stride * 9;
+    if (want_raw) pXraw += row_stride * 3;
+    pFs += row_stride * frow; pFf += row_stride * frow;
+  };
+
+  const int n_steps = (INTEG == MF_INTEG_ODEINT_EULER) ? a.T - 1 : a.T;
+  bool pending = (INTEG == MF_INTEG_ODEINT_EULER);  // ODEINT: row 0 is the initial state y_0 with zero impulses
+
+  const S* ctrl = a.controls + (size_t)b * a.T * 2;
+  S cv = ctrl[0], cw = ctrl[1];
+
+  for (int n = 0; n < n_steps; ++n) {
+    // ---- geometry of the contact points and the gathers that depend only on it ----
+    S r[PPL][3], pz[PPL];
+    Cell<S> cell[PPL];
+    S zc[PPL][4], mc[PPL][4];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      // p = P R^T + x ; r = p - x   (:200)
+      S px = P[j][0] * R[0] + P[j][1] * R[1] + P[j][2] * R[2] + x[0];
+      S py = P[j][0] * R[3] + P[j][1] * R[4] + P[j][2] * R[5] + x[1];
+      pz[j] = P[j][0] * R[6] + P[j][1] * R[7] + P[j][2] * R[8] + x[2];
+      r[j][0] = px - x[0]; r[j][1] = py - x[1]; r[j][2] = pz[j] - x[2];
+      cell[j] = locate_m<S, FAST>(px, py, a.d_max, a.res, a.inv_res, a.H, last);
+      const Cell<S>& c = cell[j];
+      zc[j][0] = zmap[(unsigned)c.ic]; zc[j][1] = zmap[(unsigned)c.i_f]; zc[j][2] = zmap[(unsigned)c.il]; zc[j][3] = zmap[(unsigned)c.ifl];
+    }
+    if (has_mu) {
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        const Cell<S>& c = cell[j];
+        mc[j][0] = mumap[(unsigned)c.ic]; mc[j][1] = mumap[(unsigned)c.i_f]; mc[j][2] = mumap[(unsigned)c.il]; mc[j][3] = mumap[(unsigned)c.ifl];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) mc[j][0] = mc[j][1] = mc[j][2] = mc[j][3] = one;
+    }
+    // next step's controls (the lookup argmin|t - ts| is the step index on the grid, dphysics.py:183)
+    const int nn = min(n + 1, a.T - 1);
+    const S cv_next = ctrl[nn * 2 + 0], cw_next = ctrl[nn * 2 + 1];
+
+    // ---- stores of the previous step's row: younger than the gathers above ----
+    if (pending) emit_row();
+    pending = true;
+
+    // ---- work that does not need the gathered cells ----
+    S vp[PPL][3];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {  // v_p = xd + w x r   (:204)
+      vp[j][0] = xd[0] + (w[1] * r[j][2] - w[2] * r[j][1]);
+      vp[j][1] = xd[1] + (w[2] * r[j][0] - w[0] * r[j][2]);
+      vp[j][2] = xd[2] + (w[0] * r[j][1] - w[1] * r[j][0]);
+    }
+    // thrust direction = normalized first column of R   (:237)
+    const S il = M::inv_len(R[0] * R[0] + R[3] * R[3] + R[6] * R[6]);
+    S e0, e1, e2;
+    if (M::kReciprocalNorm) { e0 = R[0] * il; e1 = R[3] * il; e2 = R[6] * il; }
+    else { const S el = mf_max(M::sqrt(R[0] * R[0] + R[3] * R[3] + R[6] * R[6]), (S)1e-6); e0 = R[0] / el; e1 = R[3] / el; e2 = R[6] / el; }
+    const S tv_lo = cv - cw * a.half_ly, tv_hi = cv + cw * a.half_ly;  // (:75-104)
+
+    // ---- contact model ----
+    S nrm[PPL][3], muq[PPL], cw8[PPL], Fr[PPL][3];
+    S csum = zero;
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      const Cell<S>& c = cell[j];
+      S zq = blend(c, zc[j][0], zc[j][1], zc[j][2], zc[j][3]);  // height, normal, friction under the point (:211-216)
+      muq[j] = blend(c, mc[j][0], mc[j][1], mc[j][2], mc[j][3]);
+      S gx = M::div(zc[j][1] - zc[j][0], a.res), gy = M::div(zc[j][2] - zc[j][0], a.res);
+      if (M::kReciprocalNorm) {
+        const S inl = M::inv_len(gx * gx + gy * gy + one);
+        nrm[j][0] = -gx * inl; nrm[j][1] = -gy * inl; nrm[j][2] = inl;
+      } else {
+        const S nl = mf_max(M::sqrt(gx * gx + gy * gy + one), (S)1e-6);
+        nrm[j][0] = -gx / nl; nrm[j][1] = -gy / nl; nrm[j][2] = one / nl;
+      }
+      S dh = pz[j] - zq;  // soft contact + spring-damper along the normal   (:220-230)
+      S cj = M::sigmoid_m10(dh);
+      cj = act[j] ? cj : zero;
+      cw8[j] = cj;
+      csum += cj;
+      S vn = vp[j][0] * nrm[j][0] + vp[j][1] * nrm[j][1] + vp[j][2] * nrm[j][2];
+      S A = a.k * dh + a.damp * vn;
+      Fr[j][0] = -(A * nrm[j][0]); Fr[j][1] = -(A * nrm[j][1]); Fr[j][2] = -(A * nrm[j][2]);
+    }
+    csum = group_sum<G>(csum);  // n_contact_pts (:231)
+    const S inv_csum = FAST ? M::div(one, csum) : one;
+
+    S sFr[3] = {zero, zero, zero}, sFf[3] = {zero, zero, zero}, sTau[3] = {zero, zero, zero};
+    S Ff[PPL][3];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {  // (:232-233)
+        S f = FAST ? Fr[j][c] * cw8[j] * inv_csum : Fr[j][c] * cw8[j] / csum;
+        Fr[j][c] = mf_clamp(f, -a.mg, a.mg);
+      }
+      S Nn = M::sqrt(Fr[j][0] * Fr[j][0] + Fr[j][1] * Fr[j][1] + Fr[j][2] * Fr[j][2]);  // (:238)
+      S tv = (part[j] < 0) ? zero : ((part[j] & 1) ? tv_hi : tv_lo);
+      S s0 = muq[j] * (tv * e0 - vp[j][0]);  // slip (:247); cmd = 0 for non-driving points
+      S s1 = muq[j] * (tv * e1 - vp[j][1]);
+      S s2 = muq[j] * (tv * e2 - vp[j][2]);
+      S sn = s0 * nrm[j][0] + s1 * nrm[j][1] + s2 * nrm[j][2];
+      Ff[j][0] = mf_clamp(Nn * (s0 - sn * nrm[j][0]), -a.mg, a.mg);  // (:248-251)
+      Ff[j][1] = mf_clamp(Nn * (s1 - sn * nrm[j][1]), -a.mg, a.mg);
+      Ff[j][2] = mf_clamp(Nn * (s2 - sn * nrm[j][2]), -a.mg, a.mg);
+      if (!act[j]) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Fr[j][c] = Ff[j][c] = zero;
+      }
+      S f0 = Fr[j][0] + Ff[j][0], f1 = Fr[j][1] + Ff[j][1], f2 = Fr[j][2] + Ff[j][2];
+      sTau[0] += r[j][1] * f2 - r[j][2] * f1;  // r x (Fs + Ff)   (:255)
+      sTau[1] += r[j][2] * f0 - r[j][0] * f2;
+      sTau[2] += r[j][0] * f1 - r[j][1] * f0;
+      if (FAST) { sFr[0] += f0; sFr[1] += f1; sFr[2] += f2; }
+      else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { sFr[c] += Fr[j][c]; sFf[c] += Ff[j][c]; }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      sFr[c] = group_sum<G>(sFr[c]);
+      if (!FAST) sFf[c] = group_sum<G>(sFf[c]);  // exact mode keeps the reference's two separate sums
+      sTau[c] = group_sum<G>(sTau[c]);
+    }
+    // omega_d = clamp(I^-1 tau) (body-frame I with world-frame torque, as the reference)   (:256-257)
+    S wd[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      wd[c] = mf_clamp(a.Iinv[c * 3 + 0] * sTau[0] + a.Iinv[c * 3 + 1] * sTau[1] + a.Iinv[c * 3 + 2] * sTau[2],
+                       -a.omega_max, a.omega_max);
+    // xdd = (m g ghat + sum Fs + sum Ff) / m   (:264-266)
+    S xdd[3];
+    if (FAST) { xdd[0] = sFr[0] * a.inv_mass; xdd[1] = sFr[1] * a.inv_mass; xdd[2] = (sFr[2] - a.mg) * a.inv_mass; }
+    else { xdd[0] = (sFr[0] + sFf[0]) / a.mass; xdd[1] = (sFr[1] + sFf[1]) / a.mass; xdd[2] = ((-a.mg + sFr[2]) + sFf[2]) / a.mass; }
+
+    if (INTEG == MF_INTEG_DYNAMICS) {
+      // update_state (:274-288): xd += xdd h ; x += xd_new h ; w += wd h ; R <- R (I + K sin + K^2 (1 - cos))
+      const S h = a.dt;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        xd[c] = xd[c] + xdd[c] * h;
+        x[c] = x[c] + xd[c] * h;
+        w[c] = w[c] + wd[c] * h;
+      }
+      const S th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+      const S th = M::sqrt(th2);
+      S k0, k1, k2;  // K = [w]x / max(|w|, eps)
+      if (M::kReciprocalNorm) { const S id = M::inv_len(th2); k0 = w[0] * id; k1 = w[1] * id; k2 = w[2] * id; }
+      else { const S den = mf_max(th, (S)1e-6); k0 = w[0] / den; k1 = w[1] / den; k2 = w[2] / den; }
+      S sn, oc;
+      M::sincos_small(th * h, &sn, &oc);
+      // K = [[0,-k2,k1],[k2,0,-k0],[-k1,k0,0]];  M = I + K sin + (K K) (1 - cos)
+      S K[9] = {zero, -k2, k1, k2, zero, -k0, -k1, k0, zero};
+      S Mx[9];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j2 = 0; j2 < 3; ++j2) {
+          S kk = K[i * 3 + 0] * K[0 * 3 + j2] + K[i * 3 + 1] * K[1 * 3 + j2] + K[i * 3 + 2] * K[2 * 3 + j2];
+          Mx[i * 3 + j2] = ((i == j2 ? one : zero) + K[i * 3 + j2] * sn) + kk * oc;
+        }
+      S Rn[9];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j2 = 0; j2 < 3; ++j2)
+          Rn[i * 3 + j2] = R[i * 3 + 0] * Mx[0 * 3 + j2] + R[i * 3 + 1] * Mx[1 * 3 + j2] + R[i * 3 + 2] * Mx[2 * 3 + j2];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) R[c] = Rn[c];
+#pragma unroll
+      for (int j = 0; j < PPL; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { oFs[j][c] = Fr[j][c]; oFf[j][c] = Ff[j][c]; }  // true forces of this step
+    } else {
+      // torchdiffeq fixed-grid euler: y_{n+1} = y_n + (t_{n+1} - t_n) f(t_n, y_n), f = (xd, xdd, [w]x R, wd, Fs, Ff)
+      const S h = a.ts[n + 1] - a.ts[n];
+      S dR[9];
+#pragma unroll
+      for (int j2 = 0; j2 < 3; ++j2) {
+        dR[0 * 3 + j2] = w[1] * R[2 * 3 + j2] - w[2] * R[1 * 3 + j2];
+        dR[1 * 3 + j2] = w[2] * R[0 * 3 + j2] - w[0] * R[2 * 3 + j2];
+        dR[2 * 3 + j2] = w[0] * R[1 * 3 + j2] - w[1] * R[0 * 3 + j2];
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        x[c] = x[c] + h * xd[c];  // OLD xd moves x
+        xd[c] = xd[c] + h * xdd[c];
+        w[c] = w[c] + h * wd[c];
+      }
+#pragma unroll
+      for (int c = 0; c < 9; ++c) R[c] = R[c] + h * dR[c];
+#pragma unroll
+      for (int j = 0; j < PPL; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          oFs[j][c] = oFs[j][c] + h * Fr[j][c];
+          oFf[j][c] = oFf[j][c] + h * Ff[j][c];
+        }
+    }
+    cv = cv_next; cw = cw_next;
+  }
+  if (pending) emit_row();
+}
+
+// Lane mapping for (B, N): G lanes per rollout x PPL points per lane (see the header comment).
+struct LaneMap { int G, PPL; };
+static inline LaneMap choose_lane_map(int B, int N, int points_per_lane) {
+  int g1 = 4;
+  while (g1 < N) g1 <<= 1;  // lanes per rollout at one point per lane
+  bool wide = g1 <= 64 && (long long)B * g1 / 64 <= 4096;   // measured crossover: ~4 waves per SIMD
+  if (points_per_lane == 1 && g1 <= 64) wide = true;
+  if (points_per_lane == 4) wide = false;
+  if (N <= 4) return wide ? LaneMap{4, 1} : LaneMap{1, 4};
+  if (N <= 8) return wide ? LaneMap{8, 1} : LaneMap{2, 4};
+  if (N <= 16) return wide ? LaneMap{16, 1} : LaneMap{4, 4};
+  if (N <= 32) return wide ? LaneMap{32, 1} : LaneMap{8, 4};
+  if (N <= 64) return wide ? LaneMap{64, 1} : LaneMap{16, 4};
+  if (N <= 128) return (points_per_lane != 4 && (long long)B * 2 <= 4096) ? LaneMap{64, 2} : LaneMap{32, 4};
+  if (N <= 256) return LaneMap{64, 4};
+  return LaneMap{64, 8};
+}
+
+template <typename S, bool FAST>
+int launch_rollout_fwd(const RolloutArgs<S>& a, LaneMap m, int integ, int block, hipStream_t st) {
+  const long long threads = (long long)a.B * m.G;
+  const unsigned grid = (unsigned)((threads + block - 1) / block);
+#define MF_CASE(G_, P_)                                                                                                   \
+  if (m.G == G_ && m.PPL == P_) {                                                                                          \
+    if (integ == MF_INTEG_DYNAMICS)                                                                                        \
+      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_DYNAMICS, FAST>), dim3(grid), dim3(block), 0, st, a);      \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_ODEINT_EULER, FAST>), dim3(grid), dim3(block), 0, st, a);  \
+  } else
+  MF_CASE(4, 1) MF_CASE(8, 1) MF_CASE(16, 1) MF_CASE(32, 1) MF_CASE(64, 1) MF_CASE(64, 2)
+  MF_CASE(1, 4) MF_CASE(2, 4) MF_CASE(4, 4) MF_CASE(8, 4) MF_CASE(16, 4) MF_CASE(32, 4) MF_CASE(64, 4) MF_CASE(64, 8)
+  { set_error("rollout_fwd: no kernel for this lane mapping"); return MF_ERR_UNSUPPORTED; }
+#undef MF_CASE
+  hipError_t e = hipGetLastError();
+  MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("rollout_fwd launch: ") + hipGetErrorString(e));
+  return MF_OK;
+}
+
+// defined in rollout_fwd_fast.hip
+int launch_rollout_fwd_fast_f32(const RolloutArgs<float>& a, LaneMap m, int integ, int block, hipStream_t st);
+
+}  // namespace mf

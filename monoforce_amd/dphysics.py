@@ -103,7 +103,11 @@ class _RolloutFn(torch.autograd.Function):
         tm = desc.layout == _lib.MF_LAYOUT_TIME_MAJOR
         lead = (T, B) if tm else (B, T)
         new = lambda *tail: torch.empty(*lead, *tail, dtype=dt, device=dev)  # noqa: E731
-        Xs, Xds, Rs, Om, Fs, Ff = new(3), new(3), new(3, 3), new(3), new(N, 3), new(N, 3)
+        Np = _lib.lib().mf_rollout_force_stride(C.byref(desc))      # point slots per force row the chosen kernel writes
+        if Np < N:
+            raise RuntimeError('mf_rollout_force_stride rejected the descriptor')
+        desc.force_stride = Np
+        Xs, Xds, Rs, Om, Fs, Ff = new(3), new(3), new(3, 3), new(3), new(Np, 3), new(Np, 3)
         Xraw = new(3) if want_grad else None
         bufs = _lib.MfRolloutFwdBufs(
             z=_lib.ptr(keep['z']), mu=_lib.ptr(keep['mu']), controls=_lib.ptr(controls), ts=_lib.ptr(ts),
@@ -114,7 +118,7 @@ class _RolloutFn(torch.autograd.Function):
         fn = getattr(_lib.lib(), 'mf_rollout_fwd_' + _scalar_suffix(dt))
         with torch.cuda.device(dev), _timing.timed('rollout_fwd_kernel', dev):
             _lib.check(fn(C.byref(desc), C.byref(bufs), _stream_ptr(dev)), 'mf_rollout_fwd')
-        outs = (Xs, Xds, Rs, Om, Fs, Ff)
+        outs = (Xs, Xds, Rs, Om, Fs[..., :N, :], Ff[..., :N, :])
         if tm:
             outs = tuple(o.transpose(0, 1) for o in outs)
         if want_grad:
@@ -133,7 +137,7 @@ class DPhysics(torch.nn.Module):
     """Drop-in for the reference `DPhysics` (dphysics.py:144); no parameters, all state is configuration."""
 
     def __init__(self, dphys_cfg=None, device='cpu', contiguous_outputs=False, block=0, snap_to_terrain=True,
-                 points_per_lane=0):
+                 points_per_lane=0, precise=False):
         super().__init__()
         self.dphys_cfg = dphys_cfg if dphys_cfg is not None else DPhysConfig()
         self.device = device
@@ -155,6 +159,7 @@ class DPhysics(torch.nn.Module):
         self.block = block
         self.snap_to_terrain = snap_to_terrain     # False: continue from `state` as is (no reference equivalent)
         self.points_per_lane = points_per_lane     # kernel lane mapping: 0 auto, 1 latency-oriented, 4 throughput-oriented
+        self.precise = precise      # True: float32 kernels in the reference's exact op order (IEEE div/sqrt, no FMA); ~1.5x slower
         self._cache = {}
 
     # -- constants marshalled for the C ABI ---------------------------------------------------------------
@@ -204,6 +209,7 @@ class DPhysics(torch.nn.Module):
             n_tracks=len(cfg.driving_parts), integrator=integ,
             layout=_lib.MF_LAYOUT_BATCH_MAJOR if self.contiguous_outputs else _lib.MF_LAYOUT_TIME_MAJOR,
             map_shared=int(shared), block=self.block, skip_snap=int(not self.snap_to_terrain), points_per_lane=self.points_per_lane,
+            math_mode=_lib.MF_MATH_EXACT if self.precise else _lib.MF_MATH_FAST,
             mass=float(cfg.robot_mass), gravity=float(cfg.gravity), stiffness=float(self.stiffness),
             damping=float(self.damping), omega_max=float(cfg.omega_max), grid_res=float(cfg.grid_res),
             d_max=float(cfg.d_max), dt=float(cfg.dt), robot_size_y=float(cfg.robot_size[1]))

@@ -56,6 +56,14 @@ def test_argument_validation_without_gpu(built_lib):
     assert rc == 1 and b'null input' in built_lib.mf_last_error()
 
 
+def test_force_stride_query(built_lib):
+    from monoforce_amd import _lib
+    q = lambda **kw: built_lib.mf_rollout_force_stride(ctypes.byref(_lib.MfRolloutDesc(**kw)))  # noqa: E731
+    assert q(B=1024, N=4) == 4 and q(B=10 ** 6, N=4) == 4
+    assert q(B=8, N=223) == 256 and q(B=8, N=33) == 64 and q(B=8, N=33, points_per_lane=4) == 64
+    assert q(B=8, N=300) == 512 and q(B=0, N=4) == -1 and q(B=1, N=513) == -1
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from monoforce_amd import _lib
     monkeypatch.setattr(_lib, '_lib', None)

@@ -26,12 +26,13 @@ def hip_grads(dp, z, ctrl, state, mu, dtype):
 @pytest.mark.parametrize('tag', ['f32', 'f64'])
 @pytest.mark.parametrize('integ', [0, 1])
 @pytest.mark.parametrize('ppl', [1, 4])
-def test_small_grads_vs_reference_autograd(name, tag, integ, ppl):
+@pytest.mark.parametrize('precise', [False, True])
+def test_small_grads_vs_reference_autograd(name, tag, integ, ppl, precise):
     """dL/dz, dL/dmu, dL/dcontrols for a loss touching all six outputs, vs the reference's loss.backward() (T=48)."""
     g = hp.load('rollout_small')
     dt = hp.DT[tag]
     pts, masks, z, ctrl, state, mu = hp.small_case(g, name, dt)
-    dp = make_dphysics(pts, masks, integ, hp.SMALL['grid_res'], hp.SMALL['d_max'], points_per_lane=ppl)
+    dp = make_dphysics(pts, masks, integ, hp.SMALL['grid_res'], hp.SMALL['d_max'], points_per_lane=ppl, precise=precise)
     loss, gz, gc, gm = hip_grads(dp, z, ctrl, state, mu, dt)
     pre = f'{name}/{tag}/i{integ}/'
     # float64: to rounding.  float32: SURVEY A.2 bar (<= 1e-4 rel at T <= 100; the reference's own fp32-vs-fp64 is ~1e-5)

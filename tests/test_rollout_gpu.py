@@ -32,12 +32,13 @@ def run_hip(dp, z, ctrl, state, mu):
 @pytest.mark.parametrize('tag', ['f32', 'f64'])
 @pytest.mark.parametrize('integ', [0, 1])
 @pytest.mark.parametrize('ppl', [1, 4])
-def test_small_rollout_vs_reference_golden(name, tag, integ, ppl):
+@pytest.mark.parametrize('precise', [False, True])
+def test_small_rollout_vs_reference_golden(name, tag, integ, ppl, precise):
     """B<=3, T=48, 32x32: all six outputs of the HIP path vs the reference's own outputs."""
     g = hp.load('rollout_small')
     dt = hp.DT[tag]
     pts, masks, z, ctrl, state, mu = hp.small_case(g, name, dt)
-    dp = make_dphysics(pts, masks, integ, hp.SMALL['grid_res'], hp.SMALL['d_max'], points_per_lane=ppl)
+    dp = make_dphysics(pts, masks, integ, hp.SMALL['grid_res'], hp.SMALL['d_max'], points_per_lane=ppl, precise=precise)
     outs, st = run_hip(dp, z, ctrl, state, mu)
     # float64: agreement to rounding.  float32: north_star's bar, <= 1e-4 rel on poses and forces.
     tol = 1e-9 if tag == 'f64' else 1e-4
@@ -51,12 +52,13 @@ def test_small_rollout_vs_reference_golden(name, tag, integ, ppl):
 
 @pytest.mark.parametrize('tag', ['f32', 'f64'])
 @pytest.mark.parametrize('ppl', [1, 4])
-def test_teacher_forced_single_step(tag, ppl):
+@pytest.mark.parametrize('precise', [False, True])
+def test_teacher_forced_single_step(tag, ppl, precise):
     """One step from the reference's own mid-rollout states: state -> forces, next state (<= 1e-5 rel in fp32)."""
     g = hp.load('step'); gs = hp.load('rollout_small')
     dt = hp.DT[tag]
     pts, masks, z, ctrl, _, mu = hp.small_case(gs, 'B', dt)
-    dp = make_dphysics(pts, masks, 0, hp.SMALL['grid_res'], hp.SMALL['d_max'], snap_to_terrain=False, points_per_lane=ppl)
+    dp = make_dphysics(pts, masks, 0, hp.SMALL['grid_res'], hp.SMALL['d_max'], snap_to_terrain=False, points_per_lane=ppl, precise=precise)
     tol = 1e-11 if tag == 'f64' else 1e-5
     for t in g['sel']:
         st = tuple(torch.as_tensor(g[f'{tag}/t{t}/in_{k}']) for k in ('x', 'xd', 'R', 'w'))
@@ -87,7 +89,8 @@ def test_full_horizon_f64_vs_reference(integ, ppl):
 
 @pytest.mark.parametrize('integ', [0, 1])
 @pytest.mark.parametrize('ppl', [1, 4])
-def test_full_horizon_f32_within_reference_envelope(integ, ppl):
+@pytest.mark.parametrize('precise', [False, True])
+def test_full_horizon_f32_within_reference_envelope(integ, ppl, precise):
     """T=500 free-run in float32.  The rollout is chaotic: the reference's own fp32 and fp64 runs drift
     apart exponentially, and so does any other float32 evaluation order (e.g. the two lane mappings of the kernel).
     Bar: north_star's <= 1e-4 rel on every step up to which the reference itself is reproducible across precisions
@@ -95,7 +98,7 @@ def test_full_horizon_f32_within_reference_envelope(integ, ppl):
     rollouts (default integrator on smooth / flat terrain) must meet 1e-4 over the whole 500-step horizon."""
     g = hp.load('rollout_full')
     pts, masks, z, mu, ctrl = hp.full_inputs(torch.float32)
-    dp = make_dphysics(pts, masks, integ, hp.FULL['grid_res'], hp.FULL['d_max'], points_per_lane=ppl)
+    dp = make_dphysics(pts, masks, integ, hp.FULL['grid_res'], hp.FULL['d_max'], points_per_lane=ppl, precise=precise)
     outs, _ = run_hip(dp, z, ctrl, None, mu)
     n_calm = 0
     for k, o in zip(hp.OUT_KEYS[:4], outs[:4]):
