@@ -1,0 +1,608 @@
+// Fused DPhysics rollout, backward pass (gfx950): reverse-time adjoint of rollout_fwd.hip.
+//
+// Replaces the autograd graph the reference builds through `forward_kinematics` / `dynamics` / `dynamics_odeint`
+// (/root/reference/monoforce/src/monoforce/models/traj_predictor/dphysics.py:172-272, :467-528; T x ~300 nodes) with one
+// kernel: walk the steps backwards, reload the state each step started from (they are the forward's own outputs, so
+// checkpoints are free), recompute that step's intermediates, and apply the hand-derived vector-Jacobian product.
+// Same lane mapping as the forward (G lanes per rollout, PPL points per lane, adjoint state replicated across the group,
+// cross-lane sums on DPP).  Gradients w.r.t. the height / friction cells are scattered with hardware float atomics.
+//
+// Autograd conventions reproduced: clamp passes gradient iff lo <= x <= hi; `.long()` cell indices are
+// constants (queries influence samples only through the fractions); |v| has zero gradient at v = 0;
+// x / clamp(|x|, eps) differentiates through |x| only when |x| >= eps.
+#pragma once
+#include "rollout_fwd_kernel.h"   // Mth<>, locate_m<>, LaneMap
+
+namespace mf {
+
+template <typename S>
+struct RolloutBwdArgs {
+  int B, T, N, H, W, n_tracks, layout, map_shared, skip_snap;
+  S mass, inv_mass, mg, k, damp, omega_max, res, inv_res, d_max, dt, half_ly, sink;
+  S Iinv[9];
+  const S *z, *mu, *controls, *ts, *points;
+  const int* part;
+  const S *x_init, *xd0, *R0, *w0;
+  const S *Xraw, *Xds, *Rs, *Om;
+  const S *gXs, *gXds, *gRs, *gOm, *gFs, *gFf;
+  S *gz, *gmu, *gcontrols, *gx0, *gxd0, *gR0, *gw0;
+};
+
+#ifdef MF_NO_ATOMICS
+__device__ __forceinline__ void atomic_add(float* p, float v) { if (v == 1.2345e-30f) *p = v; }
+#else
+__device__ __forceinline__ void atomic_add(float* p, float v) { unsafeAtomicAdd(p, v); }
+#endif
+__device__ __forceinline__ void atomic_add(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+template <typename S>
+__device__ __forceinline__ bool inside(S v, S lo, S hi) { return v >= lo && v <= hi; }
+
+#define MF_CROSS(o, a, b)                    \
+  do {                                       \
+    (o)[0] = (a)[1] * (b)[2] - (a)[2] * (b)[1]; \
+    (o)[1] = (a)[2] * (b)[0] - (a)[0] * (b)[2]; \
+    (o)[2] = (a)[0] * (b)[1] - (a)[1] * (b)[0]; \
+  } while (0)
+
+template <typename S, int G, int PPL, int INTEG, bool FAST>
+__global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S> a) {
+  using M = Mth<S, FAST>;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = tid / G;
+  const int gl = tid % G;
+  if (b >= a.B) return;
+  const S one = (S)1, zero = (S)0;
+  const int HW = a.H * a.W, last = HW - 1;
+  const size_t map_off = a.map_shared ? 0 : (size_t)b * HW;
+  const S* zmap = a.z + map_off;
+  const bool has_mu = a.mu != nullptr;  // wave-uniform
+  const S* mumap = has_mu ? a.mu + map_off : a.z;
+  S* gzmap = a.gz + map_off;
+  const bool want_gmu = a.gmu != nullptr && has_mu;  // wave-uniform
+  S* gmumap = want_gmu ? a.gmu + map_off : a.gz;
+
+  S P[PPL][3];
+  int part[PPL];
+  bool act[PPL];
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) {
+    int i = gl * PPL + j;       // blocked, as in the forward
+    act[j] = i < a.N;
+    int ii = act[j] ? i : 0;
+    P[j][0] = a.points[ii * 3 + 0];
+    P[j][1] = a.points[ii * 3 + 1];
+    P[j][2] = a.points[ii * 3 + 2];
+    part[j] = act[j] ? a.part[ii] : -1;
+  }
+
+  const size_t row_stride = (a.layout == MF_LAYOUT_TIME_MAJOR) ? (size_t)a.B : 1;
+  const size_t row0 = (a.layout == MF_LAYOUT_TIME_MAJOR) ? (size_t)b : (size_t)b * a.T;
+  const S* ctrl = a.controls + (size_t)b * a.T * 2;
+  S* gctrl = a.gcontrols + (size_t)b * a.T * 2;
+
+  // adjoint of the state (x, xd, R, w) [+ the impulse accumulators of the ODEINT extended state]
+  S lx[3] = {zero, zero, zero}, lxd[3] = {zero, zero, zero}, lw[3] = {zero, zero, zero}, lR[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) lR[c] = zero;
+  S laFs[PPL][3], laFf[PPL][3];
+#pragma unroll
+  for (int j = 0; j < PPL; ++j)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) laFs[j][c] = laFf[j][c] = zero;
+
+  // Memory inputs of a step that do not depend on the adjoint are loaded AHEAD of their use and always BEFORE the step's
+  // atomics in program order: vmcnt is an in-order counter over loads, stores and atomics, so a load issued after the
+  // atomics could only be waited for together with them (~1 us under contention).
+  //   StateIn  the state step n started from (a saved forward output), its controls and step size -- prefetched one
+  //            iteration ahead, right after the gathers;
+  //   UpIn     the upstream gradients of the output row a step produced -- loaded just before the atomics of the
+  //            following (later-time) step and folded into the adjoint at the top of the next iteration.
+  struct StateIn {
+    S x[3], xd[3], R[9], w[3];
+    S cv, cw, h;
+  };
+  struct UpIn {
+    S gXs[3], gXds[3], gRs[9], gOm[3];
+    S gFs[PPL][3], gFf[PPL][3];
+  };
+  const int n_steps = (INTEG == MF_INTEG_ODEINT_EULER) ? a.T - 1 : a.T;
+  auto out_row_of = [&](int n) { return row0 + (size_t)(INTEG == MF_INTEG_ODEINT_EULER ? n + 1 : n) * row_stride; };
+  auto load_state = [&](int n, StateIn& s) {
+    if (INTEG == MF_INTEG_DYNAMICS && n == 0) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { s.x[c] = a.x_init[b * 3 + c]; s.xd[c] = a.xd0[b * 3 + c]; s.w[c] = a.w0[b * 3 + c]; }
+#pragma unroll
+      for (int c = 0; c < 9; ++c) s.R[c] = a.R0[b * 9 + c];
+    } else {
+      const size_t in_row = row0 + (size_t)(INTEG == MF_INTEG_ODEINT_EULER ? n : n - 1) * row_stride;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { s.x[c] = a.Xraw[in_row * 3 + c]; s.xd[c] = a.Xds[in_row * 3 + c]; s.w[c] = a.Om[in_row * 3 + c]; }
+#pragma unroll
+      for (int c = 0; c < 9; ++c) s.R[c] = a.Rs[in_row * 9 + c];
+    }
+    s.cv = ctrl[n * 2 + 0]; s.cw = ctrl[n * 2 + 1];
+    s.h = (INTEG == MF_INTEG_ODEINT_EULER) ? a.ts[n + 1] - a.ts[n] : a.dt;
+  };
+  const bool up_x = a.gXs != nullptr, up_xd = a.gXds != nullptr, up_R = a.gRs != nullptr, up_w = a.gOm != nullptr,
+             up_fs = a.gFs != nullptr, up_ff = a.gFf != nullptr;   // wave-uniform; NULL upstream = zeros
+  auto load_upstream = [&](size_t row, UpIn& u) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) u.gXs[c] = u.gXds[c] = u.gOm[c] = zero;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) u.gRs[c] = zero;
+    if (up_x) { const S* g = a.gXs + row * 3; u.gXs[0] = g[0]; u.gXs[1] = g[1]; u.gXs[2] = g[2]; }
+    if (up_xd) { const S* g = a.gXds + row * 3; u.gXds[0] = g[0]; u.gXds[1] = g[1]; u.gXds[2] = g[2]; }
+    if (up_w) { const S* g = a.gOm + row * 3; u.gOm[0] = g[0]; u.gOm[1] = g[1]; u.gOm[2] = g[2]; }
+    if (up_R) {
+      const S* g = a.gRs + row * 9;
+#pragma unroll
+      for (int c = 0; c < 9; ++c) u.gRs[c] = g[c];
+    }
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      const size_t o = (row * a.N + min(gl * PPL + j, a.N - 1)) * 3;   // clamped: inactive slots read a valid row, masked below
+#pragma unroll
+      for (int c = 0; c < 3; ++c) u.gFs[j][c] = u.gFf[j][c] = zero;
+      if (up_fs) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { S v = a.gFs[o + c]; u.gFs[j][c] = act[j] ? v : zero; }
+      }
+      if (up_ff) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { S v = a.gFf[o + c]; u.gFf[j][c] = act[j] ? v : zero; }
+      }
+    }
+  };
+  auto add_upstream_state = [&](const UpIn& u) {
+    lx[0] += u.gXs[0]; lx[1] += u.gXs[1]; lx[2] += u.gXs[2];
+    lR[2] += u.gXs[0] * a.sink; lR[5] += u.gXs[1] * a.sink; lR[8] += u.gXs[2] * a.sink;   // Xs = x + R[:,2] * sink
+    lxd[0] += u.gXds[0]; lxd[1] += u.gXds[1]; lxd[2] += u.gXds[2];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) lR[c] += u.gRs[c];
+    lw[0] += u.gOm[0]; lw[1] += u.gOm[1]; lw[2] += u.gOm[2];
+  };
+
+  if (INTEG == MF_INTEG_ODEINT_EULER) {
+    // the last control of the grid is never used by the explicit scheme
+    if (gl == 0) { gctrl[(a.T - 1) * 2 + 0] = zero; gctrl[(a.T - 1) * 2 + 1] = zero; }
+  }
+
+  // scatter-add of one step's cell gradients, deferred by one iteration (see the loop)
+  unsigned st_idx[PPL][4];
+  S st_z[PPL][4], st_m[PPL][4];
+  bool stash_valid = false;
+  auto flush_stash = [&]() {
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      if (act[j]) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) atomic_add(gzmap + st_idx[j][q], st_z[j][q]);
+        if (want_gmu) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) atomic_add(gmumap + st_idx[j][q], st_m[j][q]);
+        }
+      }
+    }
+  };
+
+  StateIn cur;
+  UpIn up;
+  if (n_steps > 0) { load_state(n_steps - 1, cur); load_upstream(out_row_of(n_steps - 1), up); }
+  for (int n = n_steps - 1; n >= 0; --n) {
+    add_upstream_state(up);
+    S x[3], xd[3], R[9], w[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { x[c] = cur.x[c]; xd[c] = cur.xd[c]; w[c] = cur.w[c]; }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) R[c] = cur.R[c];
+    const S cv = cur.cv, cw = cur.cw;
+
+    // ---------------------------------------------------------------------------------------------------
+    // forward recompute (identical arithmetic to rollout_fwd.hip)
+    // ---------------------------------------------------------------------------------------------------
+    Cell<S> cell[PPL];
+    S zc4[PPL][4], mc4[PPL][4];
+    S r[PPL][3], vp[PPL][3], nrm[PPL][3], nl[PPL], muq[PPL], cj[PPL], Aj[PPL], F0[PPL][3], pzv[PPL];
+    S csum = zero;
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      S px = P[j][0] * R[0] + P[j][1] * R[1] + P[j][2] * R[2] + x[0];
+      S py = P[j][0] * R[3] + P[j][1] * R[4] + P[j][2] * R[5] + x[1];
+      S pz = P[j][0] * R[6] + P[j][1] * R[7] + P[j][2] * R[8] + x[2];
+      pzv[j] = pz;
+      r[j][0] = px - x[0]; r[j][1] = py - x[1]; r[j][2] = pz - x[2];
+      vp[j][0] = xd[0] + (w[1] * r[j][2] - w[2] * r[j][1]);
+      vp[j][1] = xd[1] + (w[2] * r[j][0] - w[0] * r[j][2]);
+      vp[j][2] = xd[2] + (w[0] * r[j][1] - w[1] * r[j][0]);
+      cell[j] = locate_m<S, FAST>(px, py, a.d_max, a.res, a.inv_res, a.H, last);
+      const Cell<S>& c = cell[j];
+      zc4[j][0] = zmap[(unsigned)c.ic]; zc4[j][1] = zmap[(unsigned)c.i_f]; zc4[j][2] = zmap[(unsigned)c.il]; zc4[j][3] = zmap[(unsigned)c.ifl];
+      if (has_mu) { mc4[j][0] = mumap[(unsigned)c.ic]; mc4[j][1] = mumap[(unsigned)c.i_f]; mc4[j][2] = mumap[(unsigned)c.il]; mc4[j][3] = mumap[(unsigned)c.ifl]; }
+      else { mc4[j][0] = mc4[j][1] = mc4[j][2] = mc4[j][3] = one; }
+    }
+    StateIn nxt;
+    if (n > 0) load_state(n - 1, nxt);      // younger than the gathers above
+    // The map-gradient atomics of the PREVIOUS iteration are issued here, after this step's loads: nothing this
+    // iteration waits for is younger than them, and by the next iteration's loads they have long completed.
+    if (stash_valid) flush_stash();
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      const Cell<S>& c = cell[j];
+      S zq = blend(c, zc4[j][0], zc4[j][1], zc4[j][2], zc4[j][3]);
+      muq[j] = blend(c, mc4[j][0], mc4[j][1], mc4[j][2], mc4[j][3]);
+      S gx = M::div(zc4[j][1] - zc4[j][0], a.res), gy = M::div(zc4[j][2] - zc4[j][0], a.res);
+      nl[j] = mf_max(M::sqrt(gx * gx + gy * gy + one), (S)1e-6);
+      nrm[j][0] = M::div(-gx, nl[j]); nrm[j][1] = M::div(-gy, nl[j]); nrm[j][2] = M::div(one, nl[j]);
+      S dh = pzv[j] - zq;
+      S cc = M::sigmoid_m10(dh);
+      cj[j] = act[j] ? cc : zero;
+      csum += cj[j];
+      S vn = vp[j][0] * nrm[j][0] + vp[j][1] * nrm[j][1] + vp[j][2] * nrm[j][2];
+      Aj[j] = a.k * dh + a.damp * vn;
+      F0[j][0] = -(Aj[j] * nrm[j][0]); F0[j][1] = -(Aj[j] * nrm[j][1]); F0[j][2] = -(Aj[j] * nrm[j][2]);
+    }
+    csum = group_sum<G>(csum);
+
+    const S coln = M::sqrt(R[0] * R[0] + R[3] * R[3] + R[6] * R[6]);
+    const S el = mf_max(coln, (S)1e-6);
+    const S e[3] = {M::div(R[0], el), M::div(R[3], el), M::div(R[6], el)};
+    const S inv_csum = M::div(one, csum);
+    const S tv_lo = cv - cw * a.half_ly, tv_hi = cv + cw * a.half_ly;
+
+    S F1[PPL][3], Fr[PPL][3], Ff[PPL][3], Gf[PPL][3], st[PPL][3], slip[PPL][3], sn[PPL], Nn[PPL], tv[PPL];
+    S sTau[3] = {zero, zero, zero};
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        F1[j][c] = FAST ? F0[j][c] * cj[j] * inv_csum : F0[j][c] * cj[j] / csum;
+        Fr[j][c] = mf_clamp(F1[j][c], -a.mg, a.mg);
+      }
+      Nn[j] = M::sqrt(Fr[j][0] * Fr[j][0] + Fr[j][1] * Fr[j][1] + Fr[j][2] * Fr[j][2]);
+      tv[j] = (part[j] < 0) ? zero : ((part[j] & 1) ? tv_hi : tv_lo);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) slip[j][c] = muq[j] * (tv[j] * e[c] - vp[j][c]);
+      sn[j] = slip[j][0] * nrm[j][0] + slip[j][1] * nrm[j][1] + slip[j][2] * nrm[j][2];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        st[j][c] = slip[j][c] - sn[j] * nrm[j][c];
+        Gf[j][c] = Nn[j] * st[j][c];
+        Ff[j][c] = mf_clamp(Gf[j][c], -a.mg, a.mg);
+      }
+      if (!act[j]) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) Fr[j][c] = Ff[j][c] = zero;
+      }
+      S f[3] = {Fr[j][0] + Ff[j][0], Fr[j][1] + Ff[j][1], Fr[j][2] + Ff[j][2]};
+      sTau[0] += r[j][1] * f[2] - r[j][2] * f[1];
+      sTau[1] += r[j][2] * f[0] - r[j][0] * f[2];
+      sTau[2] += r[j][0] * f[1] - r[j][1] * f[0];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) sTau[c] = group_sum<G>(sTau[c]);
+    S wraw[3], wd[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      wraw[c] = a.Iinv[c * 3 + 0] * sTau[0] + a.Iinv[c * 3 + 1] * sTau[1] + a.Iinv[c * 3 + 2] * sTau[2];
+      wd[c] = mf_clamp(wraw[c], -a.omega_max, a.omega_max);
+    }
+
+    // ---------------------------------------------------------------------------------------------------
+    // integrator backward: adjoint of the step's outputs -> (g_xdd, g_wd, g_Fs_i, g_Ff_i) + adjoint of its inputs
+    // ---------------------------------------------------------------------------------------------------
+    S gxdd[3], gwd[3], gFr[PPL][3], gFf[PPL][3];
+    if (INTEG == MF_INTEG_ODEINT_EULER) {
+      const S h = cur.h;
+#pragma unroll
+      for (int j = 0; j < PPL; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { laFs[j][c] += up.gFs[j][c]; laFf[j][c] += up.gFf[j][c]; }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        gxdd[c] = h * lxd[c];
+        gwd[c] = h * lw[c];
+        lxd[c] += h * lx[c];               // x' = x + h xd
+      }
+#pragma unroll
+      for (int j = 0; j < PPL; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { gFr[j][c] = h * laFs[j][c]; gFf[j][c] = h * laFf[j][c]; }
+      // R' = R + h [w]x R : column-wise dR_c = w x R_c
+      S lRn[9];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        S gcol[3] = {h * lR[0 * 3 + c], h * lR[1 * 3 + c], h * lR[2 * 3 + c]};
+        S rc[3] = {R[0 * 3 + c], R[1 * 3 + c], R[2 * 3 + c]};
+        S t1[3], t2[3];
+        MF_CROSS(t1, rc, gcol);            // d/dw of (w x R_c) . g  =  R_c x g
+        lw[0] += t1[0]; lw[1] += t1[1]; lw[2] += t1[2];
+        MF_CROSS(t2, gcol, w);             // d/dR_c                  =  g x w
+        lRn[0 * 3 + c] = lR[0 * 3 + c] + t2[0];
+        lRn[1 * 3 + c] = lR[1 * 3 + c] + t2[1];
+        lRn[2 * 3 + c] = lR[2 * 3 + c] + t2[2];
+      }
+#pragma unroll
+      for (int c = 0; c < 9; ++c) lR[c] = lRn[c];
+    } else {
+      const S h = cur.h;
+      // forces of this step are outputs themselves
+#pragma unroll
+      for (int j = 0; j < PPL; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { gFr[j][c] = up.gFs[j][c]; gFf[j][c] = up.gFf[j][c]; }
+      // R' = R M(w'),  w' = w + wd h,  M = I + K sin(th h) + K^2 (1 - cos(th h)),  K = [w']x / max(|w'|, eps)
+      S wn[3] = {w[0] + wd[0] * h, w[1] + wd[1] * h, w[2] + wd[2] * h};
+      S th = M::sqrt(wn[0] * wn[0] + wn[1] * wn[1] + wn[2] * wn[2]);
+      S den = mf_max(th, (S)1e-6);
+      S kv[3] = {M::div(wn[0], den), M::div(wn[1], den), M::div(wn[2], den)};
+      S sn_, oc;
+      M::sincos_small(th * h, &sn_, &oc);
+      S cs_ = one - oc;
+      S K[9] = {zero, -kv[2], kv[1], kv[2], zero, -kv[0], -kv[1], kv[0], zero};
+      S K2[9], M[9];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j2 = 0; j2 < 3; ++j2) {
+          K2[i * 3 + j2] = K[i * 3 + 0] * K[0 * 3 + j2] + K[i * 3 + 1] * K[1 * 3 + j2] + K[i * 3 + 2] * K[2 * 3 + j2];
+          M[i * 3 + j2] = ((i == j2 ? one : zero) + K[i * 3 + j2] * sn_) + K2[i * 3 + j2] * oc;
+        }
+      S gM[9], lRn[9];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j2 = 0; j2 < 3; ++j2) {
+          gM[i * 3 + j2] = R[0 * 3 + i] * lR[0 * 3 + j2] + R[1 * 3 + i] * lR[1 * 3 + j2] + R[2 * 3 + i] * lR[2 * 3 + j2];   // R^T lR
+          lRn[i * 3 + j2] = lR[i * 3 + 0] * M[j2 * 3 + 0] + lR[i * 3 + 1] * M[j2 * 3 + 1] + lR[i * 3 + 2] * M[j2 * 3 + 2];  // lR M^T
+        }
+      S ga = zero, gb = zero, gK[9];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) { ga += gM[c] * K[c]; gb += gM[c] * K2[c]; }
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j2 = 0; j2 < 3; ++j2) {
+          // d(K K) -> gM K^T + K^T gM
+          S t = zero;
+#pragma unroll
+          for (int m = 0; m < 3; ++m) t += gM[i * 3 + m] * K[j2 * 3 + m] + K[m * 3 + i] * gM[m * 3 + j2];
+          gK[i * 3 + j2] = sn_ * gM[i * 3 + j2] + oc * t;
+        }
+      S gk[3] = {gK[7] - gK[5], gK[2] - gK[6], gK[3] - gK[1]};
+      S gth = ga * h * cs_ + gb * h * sn_;
+      S gwn[3] = {M::div(gk[0], den), M::div(gk[1], den), M::div(gk[2], den)};
+      if (th >= (S)1e-6) gth += M::div(-(gk[0] * wn[0] + gk[1] * wn[1] + gk[2] * wn[2]), den * den);
+      if (th > zero) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gwn[c] += M::div(gth * wn[c], th);
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        lw[c] += gwn[c];
+        gwd[c] = h * lw[c];                // w' = w + wd h
+        lxd[c] += h * lx[c];               // x' = x + xd' h
+        gxdd[c] = h * lxd[c];              // xd' = xd + xdd h
+      }
+#pragma unroll
+      for (int c = 0; c < 9; ++c) lR[c] = lRn[c];
+    }
+
+    // ---------------------------------------------------------------------------------------------------
+    // RHS backward
+    // ---------------------------------------------------------------------------------------------------
+    S gtau[3];
+    {
+      S m0 = inside(wraw[0], -a.omega_max, a.omega_max) ? gwd[0] : zero;
+      S m1 = inside(wraw[1], -a.omega_max, a.omega_max) ? gwd[1] : zero;
+      S m2 = inside(wraw[2], -a.omega_max, a.omega_max) ? gwd[2] : zero;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gtau[c] = a.Iinv[0 * 3 + c] * m0 + a.Iinv[1 * 3 + c] * m1 + a.Iinv[2 * 3 + c] * m2;   // Iinv^T
+    }
+    const S gsum[3] = {FAST ? gxdd[0] * a.inv_mass : gxdd[0] / a.mass, FAST ? gxdd[1] * a.inv_mass : gxdd[1] / a.mass,
+                       FAST ? gxdd[2] * a.inv_mass : gxdd[2] / a.mass};
+
+    S ge[3] = {zero, zero, zero}, gv = zero, gwc = zero, gS = zero;
+    S gdh_p[PPL], gc_p[PPL], gn[PPL][3], gvp[PPL][3], gmuq[PPL], gr[PPL][3];
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      S f[3] = {Fr[j][0] + Ff[j][0], Fr[j][1] + Ff[j][1], Fr[j][2] + Ff[j][2]};
+      S gf[3];
+      MF_CROSS(gf, gtau, r[j]);            // tau += r x f : df = gtau x r
+      MF_CROSS(gr[j], f, gtau);            //                dr = f x gtau
+      S gFr_[3], gG[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        gFr_[c] = gFr[j][c] + gsum[c] + gf[c];
+        S gFf_ = gFf[j][c] + gsum[c] + gf[c];
+        gG[c] = inside(Gf[j][c], -a.mg, a.mg) ? gFf_ : zero;
+      }
+      S gNn = gG[0] * st[j][0] + gG[1] * st[j][1] + gG[2] * st[j][2];
+      S gst[3] = {Nn[j] * gG[0], Nn[j] * gG[1], Nn[j] * gG[2]};
+      S gsn = -(gst[0] * nrm[j][0] + gst[1] * nrm[j][1] + gst[2] * nrm[j][2]);
+      S gslip[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        gn[j][c] = -sn[j] * gst[c] + gsn * slip[j][c];
+        gslip[c] = gst[c] + gsn * nrm[j][c];
+      }
+      S cmdv[3] = {tv[j] * e[0] - vp[j][0], tv[j] * e[1] - vp[j][1], tv[j] * e[2] - vp[j][2]};
+      gmuq[j] = gslip[0] * cmdv[0] + gslip[1] * cmdv[1] + gslip[2] * cmdv[2];
+      S gcmd[3] = {muq[j] * gslip[0], muq[j] * gslip[1], muq[j] * gslip[2]};
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gvp[j][c] = -gcmd[c];
+      if (part[j] >= 0 && act[j]) {
+        S gtv = gcmd[0] * e[0] + gcmd[1] * e[1] + gcmd[2] * e[2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) ge[c] += tv[j] * gcmd[c];
+        gv += gtv;
+        gwc += ((part[j] & 1) ? a.half_ly : -a.half_ly) * gtv;
+      }
+      if (Nn[j] > zero) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gFr_[c] += M::div(gNn * Fr[j][c], Nn[j]);
+      }
+      S gF1[3], d = zero, gA = zero;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        gF1[c] = inside(F1[j][c], -a.mg, a.mg) ? gFr_[c] : zero;
+        d += gF1[c] * F0[j][c];
+      }
+      gc_p[j] = FAST ? d * inv_csum : d / csum;
+      gS += FAST ? -(d * cj[j]) * inv_csum * inv_csum : -(d * cj[j]) / (csum * csum);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        S gF0 = FAST ? gF1[c] * cj[j] * inv_csum : gF1[c] * cj[j] / csum;
+        gA += -(gF0 * nrm[j][c]);
+        gn[j][c] += -Aj[j] * gF0;
+      }
+      gdh_p[j] = a.k * gA;
+      S gvn = a.damp * gA;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        gvp[j][c] += gvn * nrm[j][c];
+        gn[j][c] += gvn * vp[j][c];
+      }
+    }
+    gS = group_sum<G>(gS);
+
+    if (n > 0) load_upstream(out_row_of(n - 1), up);   // `up` is dead by now; older than the atomics below
+    S gx_[3] = {zero, zero, zero}, gxd_[3] = {zero, zero, zero}, gw_[3] = {zero, zero, zero}, gR_[9];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) gR_[c] = zero;
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      if (act[j]) {
+        const Cell<S>& c = cell[j];
+        S gc = gc_p[j] + gS;
+        S gdh = gdh_p[j] + gc * ((S)-10) * cj[j] * (one - cj[j]);
+        S gzq = -gdh;
+        // n = u / |u|, u = (-gx, -gy, 1)
+        S dotn = gn[j][0] * nrm[j][0] + gn[j][1] * nrm[j][1] + gn[j][2] * nrm[j][2];
+        S gu0 = M::div(gn[j][0] - dotn * nrm[j][0], nl[j]), gu1 = M::div(gn[j][1] - dotn * nrm[j][1], nl[j]);
+        S ggx = M::div(-gu0, a.res), ggy = M::div(-gu1, a.res);
+        const S w00 = (one - c.fx) * (one - c.fy), w01 = (one - c.fx) * c.fy, w10 = c.fx * (one - c.fy), w11 = c.fx * c.fy;
+        st_idx[j][0] = (unsigned)c.ic; st_idx[j][1] = (unsigned)c.i_f; st_idx[j][2] = (unsigned)c.il; st_idx[j][3] = (unsigned)c.ifl;
+        st_z[j][0] = gzq * w00 - ggx - ggy; st_z[j][1] = gzq * w01 + ggx; st_z[j][2] = gzq * w10 + ggy; st_z[j][3] = gzq * w11;
+        st_m[j][0] = gmuq[j] * w00; st_m[j][1] = gmuq[j] * w01; st_m[j][2] = gmuq[j] * w10; st_m[j][3] = gmuq[j] * w11;
+        S zfx, zfy, mfx, mfy;
+        blend_grad(c, zc4[j][0], zc4[j][1], zc4[j][2], zc4[j][3], &zfx, &zfy);
+        blend_grad(c, mc4[j][0], mc4[j][1], mc4[j][2], mc4[j][3], &mfx, &mfy);
+        S gp[3] = {M::div(gzq * zfx + gmuq[j] * mfx, a.res), M::div(gzq * zfy + gmuq[j] * mfy, a.res), gdh};
+        // v_p = xd + w x r
+        S t1[3], t2[3];
+        MF_CROSS(t1, gvp[j], w);           // dr += gvp x w
+        MF_CROSS(t2, r[j], gvp[j]);        // dw += r x gvp
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          gr[j][q] += t1[q];
+          gw_[q] += t2[q];
+          gxd_[q] += gvp[j][q];
+          gx_[q] += gp[q];
+          S qa = gp[q] + gr[j][q];         // p = R P + x,  r = p - x
+          gR_[q * 3 + 0] += qa * P[j][0];
+          gR_[q * 3 + 1] += qa * P[j][1];
+          gR_[q * 3 + 2] += qa * P[j][2];
+        }
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      lx[c] += group_sum<G>(gx_[c]);
+      lxd[c] += group_sum<G>(gxd_[c]);
+      lw[c] += group_sum<G>(gw_[c]);
+      ge[c] = group_sum<G>(ge[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) lR[c] += group_sum<G>(gR_[c]);
+    gv = group_sum<G>(gv);
+    gwc = group_sum<G>(gwc);
+    if (coln >= (S)1e-6) {                 // e = col0(R) / max(|col0|, eps)
+      S dote = ge[0] * e[0] + ge[1] * e[1] + ge[2] * e[2];
+      lR[0] += M::div(ge[0] - dote * e[0], coln);
+      lR[3] += M::div(ge[1] - dote * e[1], coln);
+      lR[6] += M::div(ge[2] - dote * e[2], coln);
+    } else {
+      lR[0] += M::div(ge[0], el); lR[3] += M::div(ge[1], el); lR[6] += M::div(ge[2], el);
+    }
+    if (G == 1 || gl == 0) { gctrl[n * 2 + 0] = gv; gctrl[n * 2 + 1] = gwc; }
+    stash_valid = true;
+    if (n > 0) cur = nxt;
+  }
+  if (stash_valid) flush_stash();
+
+  if (INTEG == MF_INTEG_ODEINT_EULER) {   // output 0 is the initial state itself (its forces are constant zeros)
+    load_upstream(row0, up);
+    add_upstream_state(up);
+  }
+
+  // terrain snap of the initial height: x.z = mean_i blend(z; cell((R0 P_i + x0).xy))   (dphysics.py:567-571)
+  S gx0[3] = {lx[0], lx[1], lx[2]};
+  if (!a.skip_snap) {
+    S R0[9], x0[2];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) R0[c] = a.R0[b * 9 + c];
+    x0[0] = a.x_init[b * 3 + 0]; x0[1] = a.x_init[b * 3 + 1];
+    const S g = lx[2] / (S)a.N;
+    S sx = zero, sy = zero, sR[6] = {zero, zero, zero, zero, zero, zero};
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      if (act[j]) {
+        S px = P[j][0] * R0[0] + P[j][1] * R0[1] + P[j][2] * R0[2] + x0[0];
+        S py = P[j][0] * R0[3] + P[j][1] * R0[4] + P[j][2] * R0[5] + x0[1];
+        Cell<S> c = locate_m<S, FAST>(px, py, a.d_max, a.res, a.inv_res, a.H, last);
+        S v0 = zmap[(unsigned)c.ic], v1 = zmap[(unsigned)c.i_f], v2 = zmap[(unsigned)c.il], v3 = zmap[(unsigned)c.ifl];
+        atomic_add(gzmap + (unsigned)c.ic, g * (one - c.fx) * (one - c.fy));
+        atomic_add(gzmap + (unsigned)c.i_f, g * (one - c.fx) * c.fy);
+        atomic_add(gzmap + (unsigned)c.il, g * c.fx * (one - c.fy));
+        atomic_add(gzmap + (unsigned)c.ifl, g * c.fx * c.fy);
+        S dfx, dfy;
+        blend_grad(c, v0, v1, v2, v3, &dfx, &dfy);
+        S gpx = M::div(g * dfx, a.res), gpy = M::div(g * dfy, a.res);
+        sx += gpx; sy += gpy;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { sR[q] += gpx * P[j][q]; sR[3 + q] += gpy * P[j][q]; }
+      }
+    }
+    gx0[0] += group_sum<G>(sx);
+    gx0[1] += group_sum<G>(sy);
+    gx0[2] = zero;                          // the caller's x0.z is overwritten, so nothing flows to it
+#pragma unroll
+    for (int q = 0; q < 6; ++q) lR[q] += group_sum<G>(sR[q]);
+  }
+  if (gl == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if (a.gx0) a.gx0[b * 3 + c] = gx0[c];
+      a.gxd0[b * 3 + c] = lxd[c];
+      a.gw0[b * 3 + c] = lw[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) a.gR0[b * 9 + c] = lR[c];
+  }
+}
+
+template <typename S, bool FAST>
+int launch_rollout_bwd(const RolloutBwdArgs<S>& a, LaneMap m, int integ, int block, hipStream_t st) {
+  const long long threads = (long long)a.B * m.G;
+  const unsigned grid = (unsigned)((threads + block - 1) / block);
+#define MF_CASE(G_, P_)                                                                                                   \
+  if (m.G == G_ && m.PPL == P_) {                                                                                          \
+    if (integ == MF_INTEG_DYNAMICS)                                                                                        \
+      hipLaunchKernelGGL((rollout_bwd_kernel<S, G_, P_, MF_INTEG_DYNAMICS, FAST>), dim3(grid), dim3(block), 0, st, a);      \
+    else                                                                                                                   \
+      hipLaunchKernelGGL((rollout_bwd_kernel<S, G_, P_, MF_INTEG_ODEINT_EULER, FAST>), dim3(grid), dim3(block), 0, st, a);  \
+  } else
+  MF_CASE(4, 1) MF_CASE(8, 1) MF_CASE(16, 1) MF_CASE(32, 1) MF_CASE(64, 1) MF_CASE(64, 2)
+  MF_CASE(1, 4) MF_CASE(2, 4) MF_CASE(4, 4) MF_CASE(8, 4) MF_CASE(16, 4) MF_CASE(32, 4) MF_CASE(64, 4) MF_CASE(64, 8)
+  { set_error("rollout_bwd: no kernel for this lane mapping"); return MF_ERR_UNSUPPORTED; }
+#undef MF_CASE
+  hipError_t e = hipGetLastError();
+  MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("rollout_bwd launch: ") + hipGetErrorString(e));
+  return MF_OK;
+}
+
+// defined in rollout_bwd_fast.hip
+int launch_rollout_bwd_fast_f32(const RolloutBwdArgs<float>& a, LaneMap m, int integ, int block, hipStream_t st);
+
+}  // namespace mf
