@@ -73,6 +73,10 @@ typedef struct MfRolloutDesc {
   int32_t math_mode;    /* MF_MATH_* */
   int32_t force_stride; /* point slots per row of the Fs / Ff buffers, >= mf_rollout_force_stride(desc); 0 means N
                            (only valid when N is a multiple of the lane tile, e.g. N = 4).  Padding slots get zeros. */
+  int32_t grad_copies;  /* backward, shared map only: number of private copies of the gz / gmu maps (rollout b scatters into
+                           copy b % grad_copies; the caller sums the copies).  Thousands of rollouts of one batch cross the
+                           same cells, and same-address float atomics serialise in L2 at ~20 ns each; 0 or 1 = one copy. */
+  int32_t reserved;     /* must be 0 */
   double mass, gravity, stiffness, damping, omega_max;
   double grid_res, d_max;
   double dt;           /* cfg.dt: step of MF_INTEG_DYNAMICS (ODEINT takes its steps from ts[]) */
@@ -131,8 +135,9 @@ typedef struct MfRolloutBwdBufs {
   const void* gOmegas;
   const void* gFs;
   const void* gFf;
-  void* gz;             /* out (atomic accumulate): dL/dz */
-  void* gmu;            /* out (atomic accumulate): dL/dmu; NULL to skip */
+  const void* zeros;    /* >= 9 zero scalars of type S; required when any of the six upstream pointers is NULL */
+  void* gz;             /* out (atomic accumulate): dL/dz, S[map_shared ? max(grad_copies,1) : B][H][W] */
+  void* gmu;            /* out (atomic accumulate): dL/dmu, same shape; NULL to skip */
   void* gcontrols;      /* out: S[B][T][2] */
   void* gx0;            /* out: S[B][3] (z component is 0 unless skip_snap); NULL to skip */
   void* gxd0;           /* out: S[B][3] */

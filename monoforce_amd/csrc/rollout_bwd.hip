@@ -22,6 +22,7 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
   RolloutBwdArgs<S> a;
   a.B = d->B; a.T = d->T; a.N = d->N; a.H = d->H; a.W = d->W;
   a.n_tracks = d->n_tracks; a.layout = d->layout; a.map_shared = d->map_shared; a.skip_snap = d->skip_snap;
+  a.grad_copies = d->grad_copies > 1 ? d->grad_copies : 1;
   a.mass = (S)d->mass; a.inv_mass = (S)(1.0 / d->mass); a.inv_res = (S)(1.0 / d->grid_res); a.mg = (S)(d->mass * d->gravity); a.k = (S)d->stiffness; a.damp = (S)d->damping;
   a.omega_max = (S)d->omega_max; a.res = (S)d->grid_res; a.d_max = (S)d->d_max; a.dt = (S)d->dt;
   a.half_ly = (S)(d->robot_size_y / 2.0);
@@ -31,8 +32,16 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
   a.points = (const S*)p->points; a.part = p->part;
   a.x_init = (const S*)p->x_init; a.xd0 = (const S*)p->xd0; a.R0 = (const S*)p->R0; a.w0 = (const S*)p->w0;
   a.Xraw = (const S*)p->Xraw; a.Xds = (const S*)p->Xds; a.Rs = (const S*)p->Rs; a.Om = (const S*)p->Omegas;
-  a.gXs = (const S*)p->gXs; a.gXds = (const S*)p->gXds; a.gRs = (const S*)p->gRs; a.gOm = (const S*)p->gOmegas;
-  a.gFs = (const S*)p->gFs; a.gFf = (const S*)p->gFf;
+  const bool any_null = !p->gXs || !p->gXds || !p->gRs || !p->gOmegas || !p->gFs || !p->gFf;
+  MF_REQUIRE(!any_null || p->zeros, MF_ERR_INVALID,
+             "rollout_bwd: an upstream gradient is NULL but `zeros` (>= max(9, 3) zero scalars) was not provided");
+  const S* zr = (const S*)p->zeros;
+  a.gXs = p->gXs ? (const S*)p->gXs : zr;       a.sXs = p->gXs ? 3 : 0;
+  a.gXds = p->gXds ? (const S*)p->gXds : zr;    a.sXds = p->gXds ? 3 : 0;
+  a.gOm = p->gOmegas ? (const S*)p->gOmegas : zr; a.sOm = p->gOmegas ? 3 : 0;
+  a.gRs = p->gRs ? (const S*)p->gRs : zr;       a.sRs = p->gRs ? 9 : 0;
+  a.gFs = p->gFs ? (const S*)p->gFs : zr;       a.sFs = p->gFs ? 3 : 0;
+  a.gFf = p->gFf ? (const S*)p->gFf : zr;       a.sFf = p->gFf ? 3 : 0;
   a.gz = (S*)p->gz; a.gmu = (S*)p->gmu; a.gcontrols = (S*)p->gcontrols;
   a.gx0 = (S*)p->gx0; a.gxd0 = (S*)p->gxd0; a.gR0 = (S*)p->gR0; a.gw0 = (S*)p->gw0;
 

@@ -17,14 +17,15 @@ namespace mf {
 
 template <typename S>
 struct RolloutBwdArgs {
-  int B, T, N, H, W, n_tracks, layout, map_shared, skip_snap;
+  int B, T, N, H, W, n_tracks, layout, map_shared, skip_snap, grad_copies;
   S mass, inv_mass, mg, k, damp, omega_max, res, inv_res, d_max, dt, half_ly, sink;
   S Iinv[9];
   const S *z, *mu, *controls, *ts, *points;
   const int* part;
   const S *x_init, *xd0, *R0, *w0;
   const S *Xraw, *Xds, *Rs, *Om;
-  const S *gXs, *gXds, *gRs, *gOm, *gFs, *gFf;
+  const S *gXs, *gXds, *gRs, *gOm, *gFs, *gFf;   // never NULL here: the host substitutes `zeros` with a zero stride
+  int sXs, sXds, sRs, sOm, sFs, sFf;              // floats per row element group: 3 / 9 (present) or 0 (absent -> zeros)
   S *gz, *gmu, *gcontrols, *gx0, *gxd0, *gR0, *gw0;
 };
 
@@ -58,9 +59,11 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
   const S* zmap = a.z + map_off;
   const bool has_mu = a.mu != nullptr;  // wave-uniform
   const S* mumap = has_mu ? a.mu + map_off : a.z;
-  S* gzmap = a.gz + map_off;
+  // shared map: rollout b scatters into private copy b % grad_copies (summed by the caller) -- see monoforce_hip.h
+  const size_t gmap_off = a.map_shared ? (size_t)(b % a.grad_copies) * HW : (size_t)b * HW;
+  S* gzmap = a.gz + gmap_off;
   const bool want_gmu = a.gmu != nullptr && has_mu;  // wave-uniform
-  S* gmumap = want_gmu ? a.gmu + map_off : a.gz;
+  S* gmumap = want_gmu ? a.gmu + gmap_off : a.gz + gmap_off;
 
   S P[PPL][3];
   int part[PPL];
@@ -100,7 +103,7 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
   //            following (later-time) step and folded into the adjoint at the top of the next iteration.
   struct StateIn {
     S x[3], xd[3], R[9], w[3];
-    S cv, cw, h;
+    S cv, cw, t0, t1;   // raw loads only: nothing here is touched before its use, so no wait is pulled forward
   };
   struct UpIn {
     S gXs[3], gXds[3], gRs[9], gOm[3];
@@ -109,49 +112,34 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
   const int n_steps = (INTEG == MF_INTEG_ODEINT_EULER) ? a.T - 1 : a.T;
   auto out_row_of = [&](int n) { return row0 + (size_t)(INTEG == MF_INTEG_ODEINT_EULER ? n + 1 : n) * row_stride; };
   auto load_state = [&](int n, StateIn& s) {
-    if (INTEG == MF_INTEG_DYNAMICS && n == 0) {
+    // DYNAMICS step 0 starts from the initial state, every other step from a saved row: pointer selects, no branch
+    const bool init = (INTEG == MF_INTEG_DYNAMICS) && n == 0;
+    const size_t in_row = row0 + (size_t)(INTEG == MF_INTEG_ODEINT_EULER ? n : max(n - 1, 0)) * row_stride;
+    const S* sx = init ? a.x_init + b * 3 : a.Xraw + in_row * 3;
+    const S* sxd = init ? a.xd0 + b * 3 : a.Xds + in_row * 3;
+    const S* sw = init ? a.w0 + b * 3 : a.Om + in_row * 3;
+    const S* sR = init ? a.R0 + b * 9 : a.Rs + in_row * 9;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { s.x[c] = a.x_init[b * 3 + c]; s.xd[c] = a.xd0[b * 3 + c]; s.w[c] = a.w0[b * 3 + c]; }
+    for (int c = 0; c < 3; ++c) { s.x[c] = sx[c]; s.xd[c] = sxd[c]; s.w[c] = sw[c]; }
 #pragma unroll
-      for (int c = 0; c < 9; ++c) s.R[c] = a.R0[b * 9 + c];
-    } else {
-      const size_t in_row = row0 + (size_t)(INTEG == MF_INTEG_ODEINT_EULER ? n : n - 1) * row_stride;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) { s.x[c] = a.Xraw[in_row * 3 + c]; s.xd[c] = a.Xds[in_row * 3 + c]; s.w[c] = a.Om[in_row * 3 + c]; }
-#pragma unroll
-      for (int c = 0; c < 9; ++c) s.R[c] = a.Rs[in_row * 9 + c];
-    }
+    for (int c = 0; c < 9; ++c) s.R[c] = sR[c];
     s.cv = ctrl[n * 2 + 0]; s.cw = ctrl[n * 2 + 1];
-    s.h = (INTEG == MF_INTEG_ODEINT_EULER) ? a.ts[n + 1] - a.ts[n] : a.dt;
+    s.t0 = a.ts[n]; s.t1 = a.ts[min(n + 1, a.T - 1)];
   };
-  const bool up_x = a.gXs != nullptr, up_xd = a.gXds != nullptr, up_R = a.gRs != nullptr, up_w = a.gOm != nullptr,
-             up_fs = a.gFs != nullptr, up_ff = a.gFf != nullptr;   // wave-uniform; NULL upstream = zeros
   auto load_upstream = [&](size_t row, UpIn& u) {
+    // absent upstream gradients point at a zero row with stride 0 (host side), so these loads are unconditional
+    const S* g1 = a.gXs + row * a.sXs; const S* g2 = a.gXds + row * a.sXds; const S* g3 = a.gOm + row * a.sOm;
+    const S* g4 = a.gRs + row * a.sRs;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) u.gXs[c] = u.gXds[c] = u.gOm[c] = zero;
+    for (int c = 0; c < 3; ++c) { u.gXs[c] = g1[c]; u.gXds[c] = g2[c]; u.gOm[c] = g3[c]; }
 #pragma unroll
-    for (int c = 0; c < 9; ++c) u.gRs[c] = zero;
-    if (up_x) { const S* g = a.gXs + row * 3; u.gXs[0] = g[0]; u.gXs[1] = g[1]; u.gXs[2] = g[2]; }
-    if (up_xd) { const S* g = a.gXds + row * 3; u.gXds[0] = g[0]; u.gXds[1] = g[1]; u.gXds[2] = g[2]; }
-    if (up_w) { const S* g = a.gOm + row * 3; u.gOm[0] = g[0]; u.gOm[1] = g[1]; u.gOm[2] = g[2]; }
-    if (up_R) {
-      const S* g = a.gRs + row * 9;
-#pragma unroll
-      for (int c = 0; c < 9; ++c) u.gRs[c] = g[c];
-    }
+    for (int c = 0; c < 9; ++c) u.gRs[c] = g4[c];
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
-      const size_t o = (row * a.N + min(gl * PPL + j, a.N - 1)) * 3;   // clamped: inactive slots read a valid row, masked below
+      const size_t pt = row * a.N + min(gl * PPL + j, a.N - 1);   // clamped: inactive slots read a valid row, masked below
+      const S* f1 = a.gFs + pt * a.sFs; const S* f2 = a.gFf + pt * a.sFf;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) u.gFs[j][c] = u.gFf[j][c] = zero;
-      if (up_fs) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { S v = a.gFs[o + c]; u.gFs[j][c] = act[j] ? v : zero; }
-      }
-      if (up_ff) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { S v = a.gFf[o + c]; u.gFf[j][c] = act[j] ? v : zero; }
-      }
+      for (int c = 0; c < 3; ++c) { u.gFs[j][c] = f1[c]; u.gFf[j][c] = f2[c]; }   // masked by act[] where they are consumed
     }
   };
   auto add_upstream_state = [&](const UpIn& u) {
@@ -168,27 +156,29 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
     if (gl == 0) { gctrl[(a.T - 1) * 2 + 0] = zero; gctrl[(a.T - 1) * 2 + 1] = zero; }
   }
 
-  // scatter-add of one step's cell gradients, deferred by one iteration (see the loop)
+  // scatter-add of one step's cell gradients, deferred by one iteration (see the loop).  Unpredicated: inactive slots
+  // and the not-yet-filled stash of the first iteration add 0.0; without a friction-gradient output the friction values
+  // are replaced by 0.0 added to the height gradient (a no-op) -- the loop body stays a single basic block.
   unsigned st_idx[PPL][4];
   S st_z[PPL][4], st_m[PPL][4];
-  bool stash_valid = false;
+#pragma unroll
+  for (int j = 0; j < PPL; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { st_idx[j][q] = 0u; st_z[j][q] = zero; st_m[j][q] = zero; }
   auto flush_stash = [&]() {
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
-      if (act[j]) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) atomic_add(gzmap + st_idx[j][q], st_z[j][q]);
-        if (want_gmu) {
+      for (int q = 0; q < 4; ++q) atomic_add(gzmap + st_idx[j][q], st_z[j][q]);
 #pragma unroll
-          for (int q = 0; q < 4; ++q) atomic_add(gmumap + st_idx[j][q], st_m[j][q]);
-        }
-      }
+      for (int q = 0; q < 4; ++q) atomic_add(gmumap + st_idx[j][q], want_gmu ? st_m[j][q] : zero);
     }
   };
 
   StateIn cur;
   UpIn up;
-  if (n_steps > 0) { load_state(n_steps - 1, cur); load_upstream(out_row_of(n_steps - 1), up); }
+  load_state(max(n_steps - 1, 0), cur);
+  load_upstream(out_row_of(max(n_steps - 1, 0)), up);
   for (int n = n_steps - 1; n >= 0; --n) {
     add_upstream_state(up);
     S x[3], xd[3], R[9], w[3];
@@ -218,14 +208,19 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
       cell[j] = locate_m<S, FAST>(px, py, a.d_max, a.res, a.inv_res, a.H, last);
       const Cell<S>& c = cell[j];
       zc4[j][0] = zmap[(unsigned)c.ic]; zc4[j][1] = zmap[(unsigned)c.i_f]; zc4[j][2] = zmap[(unsigned)c.il]; zc4[j][3] = zmap[(unsigned)c.ifl];
-      if (has_mu) { mc4[j][0] = mumap[(unsigned)c.ic]; mc4[j][1] = mumap[(unsigned)c.i_f]; mc4[j][2] = mumap[(unsigned)c.il]; mc4[j][3] = mumap[(unsigned)c.ifl]; }
-      else { mc4[j][0] = mc4[j][1] = mc4[j][2] = mc4[j][3] = one; }
+      // unconditional (mumap aliases z when there is no friction map), then a uniform select: keeps the loop one basic block
+      {
+        S m0 = mumap[(unsigned)c.ic], m1 = mumap[(unsigned)c.i_f], m2 = mumap[(unsigned)c.il], m3 = mumap[(unsigned)c.ifl];
+        mc4[j][0] = has_mu ? m0 : one; mc4[j][1] = has_mu ? m1 : one; mc4[j][2] = has_mu ? m2 : one; mc4[j][3] = has_mu ? m3 : one;
+      }
     }
     StateIn nxt;
-    if (n > 0) load_state(n - 1, nxt);      // younger than the gathers above
+    load_state(max(n - 1, 0), nxt);      // prefetch (step 0 harmlessly reloads itself); younger than the gathers above
+    UpIn up_next;
+    load_upstream(out_row_of(max(n - 1, 0)), up_next);
     // The map-gradient atomics of the PREVIOUS iteration are issued here, after this step's loads: nothing this
     // iteration waits for is younger than them, and by the next iteration's loads they have long completed.
-    if (stash_valid) flush_stash();
+    flush_stash();
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
       const Cell<S>& c = cell[j];
@@ -293,11 +288,11 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
     // ---------------------------------------------------------------------------------------------------
     S gxdd[3], gwd[3], gFr[PPL][3], gFf[PPL][3];
     if (INTEG == MF_INTEG_ODEINT_EULER) {
-      const S h = cur.h;
+      const S h = cur.t1 - cur.t0;
 #pragma unroll
       for (int j = 0; j < PPL; ++j)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { laFs[j][c] += up.gFs[j][c]; laFf[j][c] += up.gFf[j][c]; }
+        for (int c = 0; c < 3; ++c) { laFs[j][c] += act[j] ? up.gFs[j][c] : zero; laFf[j][c] += act[j] ? up.gFf[j][c] : zero; }
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         gxdd[c] = h * lxd[c];
@@ -325,12 +320,12 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
 #pragma unroll
       for (int c = 0; c < 9; ++c) lR[c] = lRn[c];
     } else {
-      const S h = cur.h;
+      const S h = a.dt;
       // forces of this step are outputs themselves
 #pragma unroll
       for (int j = 0; j < PPL; ++j)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { gFr[j][c] = up.gFs[j][c]; gFf[j][c] = up.gFf[j][c]; }
+        for (int c = 0; c < 3; ++c) { gFr[j][c] = act[j] ? up.gFs[j][c] : zero; gFf[j][c] = act[j] ? up.gFf[j][c] : zero; }
       // R' = R M(w'),  w' = w + wd h,  M = I + K sin(th h) + K^2 (1 - cos(th h)),  K = [w']x / max(|w'|, eps)
       S wn[3] = {w[0] + wd[0] * h, w[1] + wd[1] * h, w[2] + wd[2] * h};
       S th = M::sqrt(wn[0] * wn[0] + wn[1] * wn[1] + wn[2] * wn[2]);
@@ -466,13 +461,12 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
     }
     gS = group_sum<G>(gS);
 
-    if (n > 0) load_upstream(out_row_of(n - 1), up);   // `up` is dead by now; older than the atomics below
     S gx_[3] = {zero, zero, zero}, gxd_[3] = {zero, zero, zero}, gw_[3] = {zero, zero, zero}, gR_[9];
 #pragma unroll
     for (int c = 0; c < 9; ++c) gR_[c] = zero;
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
-      if (act[j]) {
+      {   // inactive slots carry cj = 0 and zero forces, so all of their contributions below are exactly 0
         const Cell<S>& c = cell[j];
         S gc = gc_p[j] + gS;
         S gdh = gdh_p[j] + gc * ((S)-10) * cj[j] * (one - cj[j]);
@@ -517,19 +511,17 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
     for (int c = 0; c < 9; ++c) lR[c] += group_sum<G>(gR_[c]);
     gv = group_sum<G>(gv);
     gwc = group_sum<G>(gwc);
-    if (coln >= (S)1e-6) {                 // e = col0(R) / max(|col0|, eps)
-      S dote = ge[0] * e[0] + ge[1] * e[1] + ge[2] * e[2];
-      lR[0] += M::div(ge[0] - dote * e[0], coln);
-      lR[3] += M::div(ge[1] - dote * e[1], coln);
-      lR[6] += M::div(ge[2] - dote * e[2], coln);
-    } else {
-      lR[0] += M::div(ge[0], el); lR[3] += M::div(ge[1], el); lR[6] += M::div(ge[2], el);
+    {   // e = col0(R) / max(|col0|, eps): through |col0| only when it is >= eps
+      const S dote = (coln >= (S)1e-6) ? ge[0] * e[0] + ge[1] * e[1] + ge[2] * e[2] : zero;
+      lR[0] += M::div(ge[0] - dote * e[0], el);
+      lR[3] += M::div(ge[1] - dote * e[1], el);
+      lR[6] += M::div(ge[2] - dote * e[2], el);
     }
-    if (G == 1 || gl == 0) { gctrl[n * 2 + 0] = gv; gctrl[n * 2 + 1] = gwc; }
-    stash_valid = true;
-    if (n > 0) cur = nxt;
+    gctrl[n * 2 + 0] = gv; gctrl[n * 2 + 1] = gwc;   // every lane of the group, same values
+    cur = nxt;
+    up = up_next;
   }
-  if (stash_valid) flush_stash();
+  flush_stash();
 
   if (INTEG == MF_INTEG_ODEINT_EULER) {   // output 0 is the initial state itself (its forces are constant zeros)
     load_upstream(row0, up);

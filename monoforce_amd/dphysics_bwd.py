@@ -9,6 +9,8 @@ import torch
 
 from . import _lib, _timing
 
+GRAD_COPIES = 64      # private copies of a shared map's gradient (2 x 256 KiB each at 256x256)
+
 
 def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf):
     from .dphysics import _scalar_suffix, _stream_ptr
@@ -26,8 +28,16 @@ def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf):
 
     ups = [up(g) for g in (gXs, gXds, gRs, gOm, gFs, gFf)]
     z, mu = keep['z'], keep['mu']
-    gz = torch.zeros_like(z)
-    gmu = torch.zeros_like(mu) if (mu is not None and ctx.needs_input_grad[2]) else None
+    want_gmu = mu is not None and ctx.needs_input_grad[2]
+    if desc.map_shared:
+        # private gradient copies: rollout b scatters into copy b % copies, summed below (same-address atomics serialise)
+        copies = max(1, min(GRAD_COPIES, B))
+        desc.grad_copies = copies
+        gz = torch.zeros((copies,) + tuple(z.shape), dtype=dt, device=dev)
+        gmu = torch.zeros_like(gz) if want_gmu else None
+    else:
+        gz = torch.zeros_like(z)
+        gmu = torch.zeros_like(mu) if want_gmu else None
     gcontrols = torch.empty_like(controls)
     gxd0, gR0, gw0 = torch.empty_like(xd0), torch.empty_like(R0), torch.empty_like(w0)
     bufs = _lib.MfRolloutBwdBufs(
@@ -35,12 +45,16 @@ def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf):
         part=_lib.ptr(mod._part_dev(dev)), x_init=_lib.ptr(x_init), xd0=_lib.ptr(xd0), R0=_lib.ptr(R0), w0=_lib.ptr(w0),
         Xraw=_lib.ptr(Xraw), Xds=_lib.ptr(Xds), Rs=_lib.ptr(Rs), Omegas=_lib.ptr(Om),
         gXs=_lib.ptr(ups[0]), gXds=_lib.ptr(ups[1]), gRs=_lib.ptr(ups[2]), gOmegas=_lib.ptr(ups[3]),
-        gFs=_lib.ptr(ups[4]), gFf=_lib.ptr(ups[5]),
+        gFs=_lib.ptr(ups[4]), gFf=_lib.ptr(ups[5]), zeros=_lib.ptr(torch.zeros(16, dtype=dt, device=dev)),
         gz=_lib.ptr(gz), gmu=_lib.ptr(gmu), gcontrols=_lib.ptr(gcontrols), gx0=None,
         gxd0=_lib.ptr(gxd0), gR0=_lib.ptr(gR0), gw0=_lib.ptr(gw0))
     fn = getattr(_lib.lib(), 'mf_rollout_bwd_' + _scalar_suffix(dt))
     with torch.cuda.device(dev), _timing.timed('rollout_bwd_kernel', dev):
         _lib.check(fn(C.byref(desc), C.byref(bufs), _stream_ptr(dev)), 'mf_rollout_bwd')
+
+    if desc.map_shared:
+        gz = gz.sum(0)
+        gmu = None if gmu is None else gmu.sum(0)
 
     def to_input_shape(g, shape):
         """Gradient of a map input.  A shared map ([1,H,W], or one [H,W] map expanded over the batch) gets ONE [H,W]

@@ -1,0 +1,16 @@
+"""Summarise a rocprofv3 --pmc counter_collection.csv: per-kernel mean of each counter over dispatches."""
+import collections
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.defaultdict(collections.Counter)
+for r in rows:
+    k = r['Kernel_Name'].split('(')[0][-60:]
+    if len(sys.argv) > 2 and sys.argv[2] not in k:
+        continue
+    agg[k][r['Counter_Name']] += float(r['Counter_Value'])
+    cnt[k][r['Counter_Name']] += 1
+for k, v in agg.items():
+    print(k, {a: round(b / cnt[k][a]) for a, b in v.items()})
