@@ -165,11 +165,12 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
   S* pXds = a.Xds + row0 * 3;
   S* pOm = a.Om + row0 * 3;
   S* pRs = a.Rs + row0 * 9;
-  S* pXraw = a.Xraw ? a.Xraw + row0 * 3 : nullptr;
+  // without a request for the unshifted positions they are written to the Xs row itself and then overwritten by the shifted
+  // ones (same lane, same address, program order): no branch in the store sequence, no extra HBM traffic
+  S* pXraw = (a.Xraw ? a.Xraw : a.Xs) + row0 * 3;
   const size_t frow = (size_t)a.fstride * 3;  // floats per force row (>= G * PPL points: stores need no predication)
   S* pFs = a.Fs + row0 * frow + (size_t)gl * PPL * 3;
   S* pFf = a.Ff + row0 * frow + (size_t)gl * PPL * 3;
-  const bool want_raw = a.Xraw != nullptr;  // wave-uniform
 
   S oFs[PPL][3], oFf[PPL][3];  // forces of the pending output row (ODEINT: running impulses, dphysics.py:506-509)
 #pragma unroll
@@ -179,7 +180,8 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
 
   // Stores of the pending output row (the state registers ARE that row).  Every lane of the group stores the same state
   // values to the same addresses (no exec-mask branch on the issue stream; the coalescer merges them) and its own forces.
-  auto emit_row = [&]() {
+  auto emit_row = [&](size_t adv) {
+    pXraw[0] = x[0]; pXraw[1] = x[1]; pXraw[2] = x[2];
     pXs[0] = x[0] + R[2] * a.sink;  // Xs += Rs[..., :, 2] * m g / (k + 1e-6)   (dphysics.py:587-589)
     pXs[1] = x[1] + R[5] * a.sink;
     pXs[2] = x[2] + R[8] * a.sink;
@@ -187,18 +189,15 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
     pOm[0] = w[0]; pOm[1] = w[1]; pOm[2] = w[2];
 #pragma unroll
     for (int c = 0; c < 9; ++c) pRs[c] = R[c];
-    if (want_raw) { pXraw[0] = x[0]; pXraw[1] = x[1]; pXraw[2] = x[2]; }
 #pragma unroll
     for (int j = 0; j < PPL; ++j)
 #pragma unroll
       for (int c = 0; c < 3; ++c) { pFs[j * 3 + c] = oFs[j][c]; pFf[j * 3 + c] = oFf[j][c]; }
-    pXs += row_stride * 3; pXds += row_stride * 3; pOm += row_stride * 3; pRs += row_stride * 9;
-    if (want_raw) pXraw += row_stride * 3;
-    pFs += row_stride * frow; pFf += row_stride * frow;
+    pXs += adv * 3; pXds += adv * 3; pOm += adv * 3; pRs += adv * 9; pXraw += adv * 3;
+    pFs += adv * frow; pFf += adv * frow;
   };
 
   const int n_steps = (INTEG == MF_INTEG_ODEINT_EULER) ? a.T - 1 : a.T;
-  bool pending = (INTEG == MF_INTEG_ODEINT_EULER);  // ODEINT: row 0 is the initial state y_0 with zero impulses
 
   const S* ctrl = a.controls + (size_t)b * a.T * 2;
   S cv = ctrl[0], cw = ctrl[1];
@@ -219,23 +218,20 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
       const Cell<S>& c = cell[j];
       zc[j][0] = zmap[(unsigned)c.ic]; zc[j][1] = zmap[(unsigned)c.i_f]; zc[j][2] = zmap[(unsigned)c.il]; zc[j][3] = zmap[(unsigned)c.ifl];
     }
-    if (has_mu) {
 #pragma unroll
-      for (int j = 0; j < PPL; ++j) {
-        const Cell<S>& c = cell[j];
-        mc[j][0] = mumap[(unsigned)c.ic]; mc[j][1] = mumap[(unsigned)c.i_f]; mc[j][2] = mumap[(unsigned)c.il]; mc[j][3] = mumap[(unsigned)c.ifl];
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < PPL; ++j) mc[j][0] = mc[j][1] = mc[j][2] = mc[j][3] = one;
+    for (int j = 0; j < PPL; ++j) {   // unconditional (mumap aliases z without a friction map) + uniform select: no branch
+      const Cell<S>& c = cell[j];
+      S m0 = mumap[(unsigned)c.ic], m1 = mumap[(unsigned)c.i_f], m2 = mumap[(unsigned)c.il], m3 = mumap[(unsigned)c.ifl];
+      mc[j][0] = has_mu ? m0 : one; mc[j][1] = has_mu ? m1 : one; mc[j][2] = has_mu ? m2 : one; mc[j][3] = has_mu ? m3 : one;
     }
     // next step's controls (the lookup argmin|t - ts| is the step index on the grid, dphysics.py:183)
     const int nn = min(n + 1, a.T - 1);
     const S cv_next = ctrl[nn * 2 + 0], cw_next = ctrl[nn * 2 + 1];
 
     // ---- stores of the previous step's row: younger than the gathers above ----
-    if (pending) emit_row();
-    pending = true;
+    // DYNAMICS has nothing pending at n = 0: it writes the initial state into row 0 without advancing, and the real row 0
+    // overwrites it one iteration later (same lane, same addresses, program order) -- keeps the loop one basic block
+    emit_row((INTEG == MF_INTEG_ODEINT_EULER || n > 0) ? row_stride : 0);
 
     // ---- work that does not need the gathered cells ----
     S vp[PPL][3];
@@ -395,7 +391,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
     }
     cv = cv_next; cw = cw_next;
   }
-  if (pending) emit_row();
+  if (n_steps > 0 || INTEG == MF_INTEG_ODEINT_EULER) emit_row(row_stride);
 }
 
 // Lane mapping for (B, N): G lanes per rollout x PPL points per lane (see the header comment).
