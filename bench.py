@@ -35,6 +35,8 @@ WORKLOADS = {
     'c2': dict(B=256, T=500, N=4, backward=False, desc='BASELINE configs[1]: 256 rollouts x 500 steps, forward'),
     'c3f': dict(B=1024, T=500, N=4, backward=False, desc='north_star shape: 1024 rollouts x 500 steps x 4 points, forward'),
     'c3': dict(B=1024, T=500, N=4, backward=True, desc='BASELINE configs[2]: 1024 rollouts x 500 steps, forward + backward to terrain'),
+    'c4': dict(B=1024, T=500, N=4, backward=True, encoder=True,
+               desc='BASELINE configs[3]/[4]: TerrainEncoder (4 cams 3x256x512 -> 256x256 BEV) + 1024 rollouts per GPU, end-to-end train step'),
 }
 
 
@@ -104,12 +106,18 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs an MI355X (no CPU fallback)'
+    if os.environ.get('MF_BENCH_SINGLE_DEVICE'):      # test rig: all ranks on GPU 0, gloo instead of RCCL
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    backend = os.environ.get('MF_BENCH_BACKEND', 'nccl')      # "nccl" is RCCL on ROCm
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=dev)
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     wl = dict(WORKLOADS[args.workload])
@@ -123,7 +131,15 @@ def main():
     zd = z.to(dev).unsqueeze(0).expand(B, -1, -1)       # one terrain shared by the rollouts (stride-0 batch)
     md = mu.to(dev).unsqueeze(0).expand(B, -1, -1)
     cd = ctrl.to(dev)
-    if wl['backward']:
+    if wl.get('encoder'):
+        from monoforce_amd.terrain_encoder import LiftSplatShoot
+        from monoforce_amd.train import EncoderTrainStep, synthetic_encoder_batch
+        torch.manual_seed(0)        # identical initial weights on every rank (DDP convention)
+        gc = dict(xbound=[-6.4, 6.4, 0.05], ybound=[-6.4, 6.4, 0.05], zbound=[-3.2, 3.2, 6.4], dbound=[0.6, 6.4, 0.1])
+        enc = LiftSplatShoot(gc, dict(final_dim=(256, 512))).to(dev).train()
+        ebatch = synthetic_encoder_batch(enc, dp, n_rollouts=B, device=dev, seed=rank)
+        estep = EncoderTrainStep(enc, dp, lr=1e-4)
+    elif wl['backward']:
         from monoforce_amd.train import TerrainFitProblem
         from monoforce_amd import synthetic as syn
         z_true = syn.bump_terrain(syn.bump_params(100), 6.4, 0.05).to(dev)       # GT trajectories come from another terrain
@@ -132,6 +148,8 @@ def main():
         mleaf = mu.to(dev).clone().requires_grad_(True)
 
     def step():
+        if wl.get('encoder'):
+            return estep.step(ebatch)
         if wl['backward']:
             return prob.step(zleaf, mleaf)
         with torch.no_grad():
@@ -154,14 +172,18 @@ def main():
     elapsed = time.perf_counter() - t0
     kern = {k: float(np.mean(v)) for k, v in _timing.stop().items()}       # average launch duration per kernel, ms
     if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=dev if backend == 'nccl' else 'cpu', dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     if rank == 0:
         units = B * T * world * args.steps
         alg = {'rollout_fwd_kernel': fwd_bytes_per_rollout_step(N) * B * T, 'rollout_bwd_kernel': bwd_bytes_per_rollout_step(N) * B * T}
-        dom = max(kern, key=kern.get)                      # the dominant kernel of the step
+        P4 = 4 * 59 * 16 * 32                                  # frustum points per sample at the config-4 shapes
+        alg.update({'splat_fwd_kernel': 4 * 64 * P4 + 12 * P4 + 4 * 64 * 256 * 256, 'splat_bwd_kernel': 4 * 64 * 256 * 256 + 4 * 64 * P4,
+                    'splat_prepare': 20 * P4})
+        kern = {k: v for k, v in kern.items() if k in alg}
+        dom = max(kern, key=kern.get)                      # the dominant hand-written kernel of the step
         kern_ms, alg_bytes = kern[dom], alg[dom]
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         per_kernel = {k: {'ms': v, 'algorithmic_bytes': alg[k], 'GB/s': alg[k] / (v * 1e-3) / 1e9,
@@ -174,7 +196,7 @@ def main():
             'config': {'workload': f'{args.workload}: B={B}/GPU x T={T} x N={N} contact points, 256x256 grid (res 0.05 m), '
                                    f'one shared terrain+friction map, integrator='
                                    f'{"odeint-euler (reference default)" if args.integrator == 1 else "dynamics()"}, '
-                                   f'{"forward+backward" if wl["backward"] else "forward"}; {wl["desc"]}',
+                                   f'{"encoder train step (fwd+bwd+Adam)" if wl.get("encoder") else "forward+backward" if wl["backward"] else "forward"}; {wl["desc"]}',
                        'rollouts_per_gpu': B, 'horizon': T, 'contact_points': N, 'grid': [256, 256],
                        'parallelism': f'rollout-sharded x{world}'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

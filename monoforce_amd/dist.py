@@ -81,7 +81,12 @@ def allreduce_sum_(tensors, bucket=None, average=False):
     if bucket is None:
         bucket = FlatBucket(tensors)
     buf = bucket.pack(tensors)
-    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    if buf.is_cuda and dist.get_backend() == 'gloo':      # CPU-only test rigs: stage through the host
+        host = buf.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        buf.copy_(host)
+    else:
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)        # RCCL over xGMI
     if average:
         buf.div_(world())
     bucket.unpack_into(tensors)

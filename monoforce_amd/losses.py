@@ -4,7 +4,7 @@ tensors are on).  Semantics of `/root/reference/monoforce/src/monoforce/losses.p
 """
 import torch
 
-__all__ = ['physics_loss', 'hm_loss', 'total_variation', 'rotation_difference']
+__all__ = ['nearest_steps', 'physics_loss', 'hm_loss', 'total_variation', 'rotation_difference']
 
 
 def total_variation(heightmap):
@@ -28,13 +28,19 @@ def hm_loss(height_pred, height_gt, weights=None, h_max=None):
     return (diff ** 2).mean()
 
 
-def physics_loss(states_pred, states_gt, pred_ts, gt_ts, gamma=0.9, rotation_loss=False):
+def nearest_steps(pred_ts, gt_ts):
+    """Index of the predicted step closest in time to every ground-truth stamp, [N,T2] (losses.py:116)."""
+    return (pred_ts.unsqueeze(1) - gt_ts.unsqueeze(2)).abs().argmin(dim=2)
+
+
+def physics_loss(states_pred, states_gt, pred_ts, gt_ts, gamma=0.9, rotation_loss=False, nearest=None):
     """Time-discounted position MSE at the predicted steps closest to the ground-truth stamps (losses.py:102-138).
 
     states_*[0]: positions [N,T1,3] / [N,T2,3]; pred_ts [N,T1]; gt_ts [N,T2]; weight 1 / (1 + gamma t).
     """
     X_gt, X_pred = states_gt[0], states_pred[0]
-    nearest = (pred_ts.unsqueeze(1) - gt_ts.unsqueeze(2)).abs().argmin(dim=2)          # [N,T2]
+    if nearest is None:     # callers with fixed time stamps may pass the cached result of nearest_steps()
+        nearest = nearest_steps(pred_ts, gt_ts)
     rows = torch.arange(X_gt.shape[0], device=nearest.device).unsqueeze(1)
     X_sel = X_pred[rows, nearest]
     wt = 1. / (1. + gamma * gt_ts.unsqueeze(2))

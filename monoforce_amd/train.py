@@ -4,7 +4,7 @@ the physics) and `scripts/train.py:377-410` (physics loss on predicted terrain),
 import torch
 
 from . import dist as mfdist
-from .losses import physics_loss
+from .losses import nearest_steps, physics_loss
 
 
 class TerrainFitProblem:
@@ -26,6 +26,7 @@ class TerrainFitProblem:
         sel = torch.arange(gt_every - 1, T, gt_every, device=controls.device)
         self.gt_ts = full_ts[sel].unsqueeze(0).expand(B, -1).contiguous()
         self.states_gt = [Xs[:, sel].contiguous(), Xds[:, sel].contiguous(), Rs[:, sel].contiguous(), Om[:, sel].contiguous()]
+        self.nearest = nearest_steps(self.pred_ts, self.gt_ts)      # time stamps are fixed: computed once
         self.bucket = None
 
     def step(self, z, mu):
@@ -33,8 +34,87 @@ class TerrainFitProblem:
         z.grad = None
         mu.grad = None
         states, _ = self.dp(z.unsqueeze(0), self.controls, friction=mu.unsqueeze(0))
-        loss = physics_loss(states_pred=states, states_gt=self.states_gt, pred_ts=self.pred_ts, gt_ts=self.gt_ts)
+        loss = physics_loss(states_pred=states, states_gt=self.states_gt, pred_ts=self.pred_ts, gt_ts=self.gt_ts,
+                            nearest=self.nearest)
         loss.backward()
         # the one exchange step of the backward: 2 x H x W floats over RCCL
         self.bucket = mfdist.allreduce_sum_([z.grad, mu.grad], self.bucket)
         return loss
+
+
+class EncoderTrainStep:
+    """The reference's end-to-end training step (`scripts/train.py:377-410, 231-246, 142-185`) on one GPU / one rank:
+
+        terrain = encoder(imgs, rots, trans, intrins, post_rots, post_trans)        # LiftSplatShoot, HIP BEV splat inside
+        loss = w_g * hm_loss(geom) + w_t * hm_loss(terrain) + w_p * physics_loss(dphysics(terrain, friction), gt)
+        loss.backward(); [all-reduce encoder grads over RCCL]; clip_grad_norm_(1.0); Adam(lr, betas=(0.8, 0.999), wd=1e-7)
+
+    The predicted terrain / friction of each sample is shared by `rollouts_per_sample` control sequences (BASELINE config 4:
+    one 4-camera sample, 1024 rollouts), which maps onto the rollout kernels' shared-map path.
+    """
+
+    def __init__(self, encoder, dphysics, lr=1e-3, geom_weight=1.0, terrain_weight=1.0, phys_weight=1.0):
+        self.enc, self.dp = encoder, dphysics
+        self.w = (geom_weight, terrain_weight, phys_weight)
+        self.opt = torch.optim.Adam(encoder.parameters(), lr=lr, betas=(0.8, 0.999), weight_decay=1e-7)   # train.py:374-375
+        self.params = [p for p in encoder.parameters() if p.requires_grad]
+        self.bucket = None
+
+    def losses(self, batch):
+        from .losses import hm_loss
+        (inputs, hm_geom, hm_terrain, controls, pose0, states_gt, pred_ts, gt_ts, nearest) = batch
+        terrain = self.enc(*inputs)
+        l_geom = hm_loss(terrain['geom'], hm_geom[:, 0:1], hm_geom[:, 1:2])                  # train.py:388-392
+        l_terr = hm_loss(terrain['terrain'], hm_terrain[:, 0:1], hm_terrain[:, 1:2])         # train.py:395-398
+        # one predicted map per sample; B controls per sample share it ([1,H,W] map + [B,T,2] controls)
+        z = terrain['terrain'].squeeze(1)
+        mu = terrain['friction'].squeeze(1)
+        x0 = pose0[:, :3, 3].clone()
+        state0 = (x0, torch.zeros_like(x0), pose0[:, :3, :3].contiguous(), torch.zeros_like(x0))   # train.py:237-241
+        states, _ = self.dp(z_grid=z, controls=controls, state=state0, friction=mu)
+        l_phys = physics_loss(states_pred=states, states_gt=states_gt, pred_ts=pred_ts, gt_ts=gt_ts, nearest=nearest)
+        return l_geom, l_terr, l_phys
+
+    def step(self, batch):
+        self.opt.zero_grad(set_to_none=False)
+        l_geom, l_terr, l_phys = self.losses(batch)
+        loss = self.w[0] * l_geom + self.w[1] * l_terr + self.w[2] * l_phys
+        loss.backward()
+        grads = [p.grad for p in self.params]
+        self.bucket = mfdist.allreduce_sum_(grads, self.bucket, average=True)      # DDP-style, one flat bucket over RCCL
+        torch.nn.utils.clip_grad_norm_(self.params, max_norm=1.0)                   # train.py:167
+        self.opt.step()
+        return loss.detach(), (l_geom.detach(), l_terr.detach(), l_phys.detach())
+
+
+def synthetic_encoder_batch(encoder, dphysics, n_rollouts, device, seed=0, img_hw=(256, 512)):
+    """Synthetic stand-in for a ROUGH sample (`datasets/rough.py:651-663`): 4 cameras, random images, a "true" bump
+    terrain as height-map labels, ground-truth poses from rolling the controls out on that terrain (HIP forward)."""
+    from . import synthetic as syn
+    from .losses import nearest_steps
+    g = torch.Generator().manual_seed(seed)
+    H, W = img_hw
+    imgs = torch.randn(1, 4, 3, H, W, generator=g).to(device)
+    rig = [t.to(device) for t in syn.lss_camera_rig(1, 4, H, W, 300.0)]
+    cfg = dphysics.dphys_cfg
+    nxy = int(encoder.nx[0])
+    res = float(encoder.dx[0])
+    z_true = syn.bump_terrain(syn.bump_params(100 + seed), cfg.d_max, res).to(device)
+    mu_true = syn.wave_friction(cfg.d_max, res).to(device)
+    assert z_true.shape == (nxy, nxy)
+    ones = torch.ones_like(z_true)
+    hm_geom = torch.stack([z_true.clamp(-1, 1), ones]).unsqueeze(0)          # [1, 2, H, W]: value, weight (train.py:390)
+    hm_terrain = torch.stack([z_true.clamp(-1, 1) * 0.9, ones]).unsqueeze(0)
+    T = int(cfg.traj_sim_time / cfg.dt)
+    controls = syn.const_controls(n_rollouts, T, seed=seed).to(device)
+    pose0 = torch.eye(4, device=device).repeat(n_rollouts, 1, 1)
+    with torch.no_grad():
+        st = (pose0[:, :3, 3].clone(), torch.zeros(n_rollouts, 3, device=device), pose0[:, :3, :3].contiguous(),
+              torch.zeros(n_rollouts, 3, device=device))
+        (Xs, Xds, Rs, Om), _ = dphysics(z_true.unsqueeze(0), controls, state=st, friction=mu_true.unsqueeze(0))
+    ts = torch.linspace(0, cfg.traj_sim_time, T, device=device)
+    sel = torch.arange(9, T, 10, device=device)                               # 10 Hz poses (rough.py:217,238)
+    pred_ts = ts.unsqueeze(0).expand(n_rollouts, -1)
+    gt_ts = ts[sel].unsqueeze(0).expand(n_rollouts, -1).contiguous()
+    states_gt = [Xs[:, sel].contiguous(), Xds[:, sel].contiguous(), Rs[:, sel].contiguous(), Om[:, sel].contiguous()]
+    return ((imgs, *rig), hm_geom, hm_terrain, controls, pose0, states_gt, pred_ts, gt_ts, nearest_steps(pred_ts, gt_ts))
