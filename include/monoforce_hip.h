@@ -76,12 +76,13 @@ typedef struct MfRolloutDesc {
   int32_t grad_copies;  /* backward, shared map only: number of private copies of the gz / gmu maps (rollout b scatters into
                            copy b % grad_copies; the caller sums the copies).  Thousands of rollouts of one batch cross the
                            same cells, and same-address float atomics serialise in L2 at ~20 ns each; 0 or 1 = one copy. */
-  int32_t reserved;     /* must be 0 */
+  int32_t has_joints;   /* 1: MfRolloutFwdBufs.joint_angles will be given (selects the articulated kernels / force stride) */
   double mass, gravity, stiffness, damping, omega_max;
   double grid_res, d_max;
   double dt;           /* cfg.dt: step of MF_INTEG_DYNAMICS (ODEINT takes its steps from ts[]) */
   double robot_size_y; /* Ly = cfg.robot_size[1] */
   double Iinv[9];      /* inverse body inertia, row-major (dphysics.py:152-153) */
+  double joint_xyz[12]; /* joint positions of the 4 driving parts [fl, fr, rl, rr][xyz] (cfg.joint_positions); has_joints only */
 } MfRolloutDesc;
 
 /* Device buffers of the forward rollout; S = float for _f32, double for _f64.  All contiguous. */
@@ -103,6 +104,10 @@ typedef struct MfRolloutFwdBufs {
   void* Fs;             /* S[..][force_stride][3] spring forces (DYNAMICS) or their running impulses (ODEINT) */
   void* Ff;             /* S[..][force_stride][3] friction forces / impulses */
   void* Xraw;           /* optional S[..][3]: unshifted positions saved for the backward pass; may be NULL */
+  const void* joint_angles; /* optional S[B][T][4] flipper angles: each driving part is rotated about the y-axis through
+                           its joint and the body inertia recomputed EVERY step (update_joints, dphysics.py:192-197,
+                           326-358; the reference does this for robot == 'marv' and non-zero angles).  Forward only,
+                           exact arithmetic.  NULL = rigid body. */
 } MfRolloutFwdBufs;
 
 /* Point slots per Fs/Ff row the kernels chosen for (B, N, points_per_lane) need (>= N; -1 on a bad descriptor). */

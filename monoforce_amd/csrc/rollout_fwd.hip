@@ -41,6 +41,13 @@ static int fill_args(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutA
   a->x0 = (S*)p->x0; a->xd0 = (const S*)p->xd0; a->R0 = (const S*)p->R0; a->w0 = (const S*)p->w0;
   a->Xs = (S*)p->Xs; a->Xds = (S*)p->Xds; a->Rs = (S*)p->Rs; a->Om = (S*)p->Omegas; a->Fs = (S*)p->Fs; a->Ff = (S*)p->Ff;
   a->Xraw = (S*)p->Xraw;
+  a->joint_angles = (const S*)p->joint_angles;
+  for (int i = 0; i < 12; ++i) a->joint_xyz[i] = (S)d->joint_xyz[i];
+  if (p->joint_angles) {
+    MF_REQUIRE(d->n_tracks == 4, MF_ERR_UNSUPPORTED, "rollout_fwd: joint angles need 4 driving parts (fl, fr, rl, rr)");
+    *m = choose_lane_map(d->B, d->N, 4);     // the articulated kernels exist for the 4-points-per-lane mappings
+    MF_REQUIRE(fstride >= m->G * m->PPL, MF_ERR_INVALID, "rollout_fwd: force_stride too small for the articulated kernels");
+  }
   return MF_OK;
 }
 
@@ -48,7 +55,7 @@ static int fill_args(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutA
 
 extern "C" int mf_rollout_force_stride(const MfRolloutDesc* d) {
   if (!d || d->B <= 0 || d->N <= 0 || d->N > 512) return -1;
-  mf::LaneMap m = mf::choose_lane_map(d->B, d->N, d->points_per_lane);
+  mf::LaneMap m = mf::choose_lane_map(d->B, d->N, d->has_joints ? 4 : d->points_per_lane);
   const int lanes = m.G * m.PPL;
   return lanes > d->N ? lanes : d->N;
 }
@@ -59,6 +66,7 @@ extern "C" int mf_rollout_fwd_f32(const MfRolloutDesc* d, const MfRolloutFwdBufs
   int block;
   int rc = mf::fill_args<float>(d, p, &a, &m, &block);
   if (rc != MF_OK) return rc;
+  if (p->joint_angles) return mf::launch_rollout_fwd<float, false, true>(a, m, d->integrator, block, (hipStream_t)s);  // exact math
   if (d->math_mode == MF_MATH_FAST) return mf::launch_rollout_fwd_fast_f32(a, m, d->integrator, block, (hipStream_t)s);
   return mf::launch_rollout_fwd<float, false>(a, m, d->integrator, block, (hipStream_t)s);
 }
@@ -69,5 +77,6 @@ extern "C" int mf_rollout_fwd_f64(const MfRolloutDesc* d, const MfRolloutFwdBufs
   int block;
   int rc = mf::fill_args<double>(d, p, &a, &m, &block);
   if (rc != MF_OK) return rc;
+  if (p->joint_angles) return mf::launch_rollout_fwd<double, false, true>(a, m, d->integrator, block, (hipStream_t)s);
   return mf::launch_rollout_fwd<double, false>(a, m, d->integrator, block, (hipStream_t)s);   // float64 is always exact
 }

@@ -46,6 +46,8 @@ struct RolloutArgs {
   S* Fs;
   S* Ff;
   S* Xraw;
+  const S* joint_angles;  // S[B][T][4] flipper angles (JOINTS kernels only)
+  S joint_xyz[12];        // joint positions of the (up to 4) driving parts
 };
 
 // Arithmetic policy.  Exact: IEEE divide / sqrt, libm exp and sincos, un-fused mul+add (the TU is built with
@@ -103,7 +105,7 @@ __device__ __forceinline__ Cell<S> locate_m(S qx, S qy, S d_max, S res, S inv_re
   return c;
 }
 
-template <typename S, int G, int PPL, int INTEG, bool FAST>
+template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS = false>
 __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a) {
   using M = Mth<S, FAST>;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -117,7 +119,9 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
   const S* mumap = has_mu ? a.mu + (a.map_shared ? 0 : (size_t)b * HW) : a.z;
 
   // this lane's contact points
-  S P[PPL][3];
+  S P[PPL][3];   // contact points used by the step (articulated per step when JOINTS)
+  S P0[PPL][3];  // rest configuration (cfg.robot_points)
+  S Iv[9];       // inverse inertia used by the step
   int part[PPL];
   bool act[PPL];
 #pragma unroll
@@ -129,7 +133,11 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
     P[j][1] = a.points[ii * 3 + 1];
     P[j][2] = a.points[ii * 3 + 2];
     part[j] = act[j] ? a.part[ii] : -1;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) P0[j][c] = P[j][c];
   }
+#pragma unroll
+  for (int c = 0; c < 9; ++c) Iv[c] = a.Iinv[c];
 
   // state, replicated across the group
   S x[3], xd[3], R[9], w[3];
@@ -203,6 +211,41 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
   S cv = ctrl[0], cw = ctrl[1];
 
   for (int n = 0; n < n_steps; ++n) {
+    if (JOINTS) {
+      // update_joints (dphysics.py:326-358): rotate every driving part about the y-axis through its joint, then the
+      // inertia of the articulated body and its inverse (dphysics.py:196-197), all per step and per rollout
+      const S* ja = a.joint_angles + ((size_t)b * a.T + n) * 4;
+      S sj[4], cj4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mf_sincos(ja[q], &sj[q], &cj4[q]);
+      S I6[6] = {zero, zero, zero, zero, zero, zero};   // xx, yy, zz, xy, xz, yz
+      const S mp = a.mass / (S)a.N;
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        const int q = max(part[j], 0);
+        const S sn = sj[q], cs = cj4[q];
+        const S jx = a.joint_xyz[q * 3 + 0], jz = a.joint_xyz[q * 3 + 2];
+        const S dx = P0[j][0] - jx, dz = P0[j][2] - jz;
+        const S rx = (dx * cs + dz * sn) + jx, rz = (-(dx * sn) + dz * cs) + jz;   // (p - xyz) @ Ry^T + xyz
+        P[j][0] = part[j] >= 0 ? rx : P0[j][0];
+        P[j][1] = P0[j][1];
+        P[j][2] = part[j] >= 0 ? rz : P0[j][2];
+        const S px = P[j][0], py = P[j][1], pzz = P[j][2];
+        const S wgt = act[j] ? mp : zero;
+        I6[0] += wgt * (py * py + pzz * pzz); I6[1] += wgt * (px * px + pzz * pzz); I6[2] += wgt * (px * px + py * py);
+        I6[3] -= wgt * px * py; I6[4] -= wgt * px * pzz; I6[5] -= wgt * py * pzz;
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) I6[c] = group_sum<G>(I6[c]);
+      // inverse of the symmetric 3x3 by cofactors
+      const S a00 = I6[0], a11 = I6[1], a22 = I6[2], a01 = I6[3], a02 = I6[4], a12 = I6[5];
+      const S c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+      const S c11 = a00 * a22 - a02 * a02, c12 = a01 * a02 - a00 * a12, c22 = a00 * a11 - a01 * a01;
+      const S idet = one / (a00 * c00 + a01 * c01 + a02 * c02);
+      Iv[0] = c00 * idet; Iv[1] = c01 * idet; Iv[2] = c02 * idet;
+      Iv[3] = c01 * idet; Iv[4] = c11 * idet; Iv[5] = c12 * idet;
+      Iv[6] = c02 * idet; Iv[7] = c12 * idet; Iv[8] = c22 * idet;
+    }
     // ---- geometry of the contact points and the gathers that depend only on it ----
     S r[PPL][3], pz[PPL];
     Cell<S> cell[PPL];
@@ -318,7 +361,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
     S wd[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-      wd[c] = mf_clamp(a.Iinv[c * 3 + 0] * sTau[0] + a.Iinv[c * 3 + 1] * sTau[1] + a.Iinv[c * 3 + 2] * sTau[2],
+      wd[c] = mf_clamp(Iv[c * 3 + 0] * sTau[0] + Iv[c * 3 + 1] * sTau[1] + Iv[c * 3 + 2] * sTau[2],
                        -a.omega_max, a.omega_max);
     // xdd = (m g ghat + sum Fs + sum Ff) / m   (:264-266)
     S xdd[3];
@@ -412,20 +455,20 @@ static inline LaneMap choose_lane_map(int B, int N, int points_per_lane) {
   return LaneMap{64, 8};
 }
 
-template <typename S, bool FAST>
+template <typename S, bool FAST, bool JOINTS = false>
 int launch_rollout_fwd(const RolloutArgs<S>& a, LaneMap m, int integ, int block, hipStream_t st) {
   const long long threads = (long long)a.B * m.G;
   const unsigned grid = (unsigned)((threads + block - 1) / block);
-#define MF_CASE(G_, P_)                                                                                                   \
-  if (m.G == G_ && m.PPL == P_) {                                                                                          \
-    if (integ == MF_INTEG_DYNAMICS)                                                                                        \
-      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_DYNAMICS, FAST>), dim3(grid), dim3(block), 0, st, a);      \
-    else                                                                                                                   \
-      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_ODEINT_EULER, FAST>), dim3(grid), dim3(block), 0, st, a);  \
+#define MF_CASE(G_, P_)                                                                                                            \
+  if (m.G == G_ && m.PPL == P_) {                                                                                                   \
+    if (integ == MF_INTEG_DYNAMICS)                                                                                                 \
+      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_DYNAMICS, FAST, JOINTS>), dim3(grid), dim3(block), 0, st, a);       \
+    else                                                                                                                            \
+      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_ODEINT_EULER, FAST, JOINTS>), dim3(grid), dim3(block), 0, st, a);   \
   } else
-  MF_CASE(4, 1) MF_CASE(8, 1) MF_CASE(16, 1) MF_CASE(32, 1) MF_CASE(64, 1) MF_CASE(64, 2)
+  if (!JOINTS) { MF_CASE(4, 1) MF_CASE(8, 1) MF_CASE(16, 1) MF_CASE(32, 1) MF_CASE(64, 1) MF_CASE(64, 2) {} }
   MF_CASE(1, 4) MF_CASE(2, 4) MF_CASE(4, 4) MF_CASE(8, 4) MF_CASE(16, 4) MF_CASE(32, 4) MF_CASE(64, 4) MF_CASE(64, 8)
-  { set_error("rollout_fwd: no kernel for this lane mapping"); return MF_ERR_UNSUPPORTED; }
+  if (JOINTS || !(m.PPL < 4)) { set_error("rollout_fwd: no kernel for this lane mapping"); return MF_ERR_UNSUPPORTED; }
 #undef MF_CASE
   hipError_t e = hipGetLastError();
   MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("rollout_fwd launch: ") + hipGetErrorString(e));

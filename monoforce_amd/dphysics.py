@@ -96,8 +96,12 @@ class _RolloutFn(torch.autograd.Function):
     """forward = mf_rollout_fwd_*; backward = mf_rollout_bwd_* (reverse-time adjoint of the same scan)."""
 
     @staticmethod
-    def forward(ctx, mod, z, mu, controls, x0, xd0, R0, w0, ts, want_grad):
+    def forward(ctx, mod, z, mu, controls, x0, xd0, R0, w0, ts, want_grad, joint_angles=None):
         desc, keep = mod._make_desc(z, mu, controls)
+        if joint_angles is not None:
+            desc.has_joints = 1
+            for i, v in enumerate(sum((list(p) for p in mod.dphys_cfg.joint_positions.values()), [])[:12]):
+                desc.joint_xyz[i] = float(v)
         B, T, N = desc.B, desc.T, desc.N
         dt, dev = z.dtype, z.device
         tm = desc.layout == _lib.MF_LAYOUT_TIME_MAJOR
@@ -114,7 +118,7 @@ class _RolloutFn(torch.autograd.Function):
             points=_lib.ptr(keep['points']), part=_lib.ptr(mod._part_dev(dev)),
             x0=_lib.ptr(x0), xd0=_lib.ptr(xd0), R0=_lib.ptr(R0), w0=_lib.ptr(w0),
             Xs=_lib.ptr(Xs), Xds=_lib.ptr(Xds), Rs=_lib.ptr(Rs), Omegas=_lib.ptr(Om), Fs=_lib.ptr(Fs), Ff=_lib.ptr(Ff),
-            Xraw=_lib.ptr(Xraw))
+            Xraw=_lib.ptr(Xraw), joint_angles=_lib.ptr(joint_angles))
         fn = getattr(_lib.lib(), 'mf_rollout_fwd_' + _scalar_suffix(dt))
         with torch.cuda.device(dev), _timing.timed('rollout_fwd_kernel', dev):
             _lib.check(fn(C.byref(desc), C.byref(bufs), _stream_ptr(dev)), 'mf_rollout_fwd')
@@ -130,7 +134,7 @@ class _RolloutFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf):
         from .dphysics_bwd import rollout_backward
-        return rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf)
+        return rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf) + (None,)
 
 
 class DPhysics(torch.nn.Module):
@@ -252,11 +256,12 @@ class DPhysics(torch.nn.Module):
         B = state[0].shape[0]
         assert controls.shape == (B, N_ts, 2), f'Controls shape {controls.shape} != {(B, N_ts, 2)}'
         self.controls = controls
+        ja_dev = None
         if joint_angles is not None:
             assert joint_angles.shape == (B, N_ts, 4), f'Joint angles shape {joint_angles.shape} != {(B, N_ts, 4)}'
+            # the reference re-articulates the body only for robot == 'marv' and non-zero angles (dphysics.py:340)
             if cfg.robot == 'marv' and not torch.allclose(joint_angles, torch.zeros_like(joint_angles)):
-                raise NotImplementedError('non-zero flipper joint angles (update_joints, dphysics.py:326-358) are not '
-                                          'implemented in the HIP rollout yet')
+                ja_dev = joint_angles.detach().to(device=dev, dtype=dtype).contiguous()
         self.joint_angles = joint_angles
         self.ts = self.ts[:N_ts]                                                     # permanent, like the reference (:581)
         ts = self._time_grid(N_ts, dtype, dev)
@@ -270,7 +275,10 @@ class DPhysics(torch.nn.Module):
         xd0, R0, w0 = (s.to(device=dev, dtype=dtype).contiguous() for s in state[1:])
         want_grad = torch.is_grad_enabled() and any(
             t is not None and t.requires_grad for t in (z_grid, friction, controls, xd0, R0, w0))
-        outs = _RolloutFn.apply(self, z_grid, friction, controls.contiguous(), x0, xd0, R0, w0, ts, want_grad)
+        if ja_dev is not None and want_grad:
+            raise NotImplementedError('backward through an articulated rollout (non-zero flipper joint angles) is not '
+                                      'implemented: run it under torch.no_grad()')
+        outs = _RolloutFn.apply(self, z_grid, friction, controls.contiguous(), x0, xd0, R0, w0, ts, want_grad, ja_dev)
         if not aliased:
             with torch.no_grad():
                 x_in[..., 2] = x0[..., 2].to(device=x_in.device, dtype=x_in.dtype)   # the reference's in-place write

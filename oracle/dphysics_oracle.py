@@ -43,6 +43,7 @@ class RolloutSpec:
     dt: float = 0.01
     traj_sim_time: float = 5.0
     integrator: int = ODEINT_EULER
+    joint_positions: Optional[list] = None   # [[x,y,z]] * n_parts (cfg.joint_positions.values()), only with joint angles
 
     def __post_init__(self):
         if self.damping is None:
@@ -108,6 +109,20 @@ def sample_grid(grid, qx, qy, d_max, res, normals=False):
     return z, n
 
 
+def articulate(spec, P, joint_angles_t):
+    """`update_joints` (dphysics.py:326-358): rotate each driving part about the y-axis through its joint position.
+    P[1,N,3], joint_angles_t[B,4] -> points[B,N,3].  The reference applies this only for robot == 'marv' and angles != 0."""
+    B = joint_angles_t.shape[0]
+    pts = P.repeat(B, 1, 1)
+    for i, mask in enumerate(spec.driving_parts):
+        xyz = torch.as_tensor(spec.joint_positions[i], dtype=pts.dtype).view(1, 1, 3)
+        a = joint_angles_t[:, i]
+        o, z = torch.ones_like(a), torch.zeros_like(a)
+        Ry = torch.stack([torch.cos(a), z, torch.sin(a), z, o, z, -torch.sin(a), z, torch.cos(a)], 1).view(B, 3, 3)
+        pts[:, mask] = (pts[:, mask] - xyz) @ Ry.transpose(1, 2) + xyz
+    return pts
+
+
 def rhs(spec, Iinv, P, part_id, z_grid, mu_grid, ctrl, x, xd, R, w):
     """One evaluation of `forward_kinematics` (dphysics.py:172-272) with joint angles == 0.
 
@@ -159,7 +174,7 @@ def time_grid(spec, n_controls, dtype):
     return ts[:min(n_full, n_controls)]
 
 
-def rollout(spec: RolloutSpec, z_grid, controls, state=None, friction=None, ts=None):
+def rollout(spec: RolloutSpec, z_grid, controls, state=None, friction=None, ts=None, joint_angles=None):
     """`DPhysics.dphysics` (dphysics.py:530-594) for joint angles == 0.
 
     z_grid[B,H,W], controls[B,T,2], optional state=(x[B,3], xd[B,3], R[B,3,3], w[B,3]), friction[B,H,W].
@@ -193,11 +208,19 @@ def rollout(spec: RolloutSpec, z_grid, controls, state=None, friction=None, ts=N
     T = ts.shape[0]
     assert controls.shape == (B, T, 2), f'Controls shape {tuple(controls.shape)} != {(B, T, 2)}'   # :575
 
+    def body(n):
+        # points and inverse inertia of step n: constants, or re-articulated flippers (dphysics.py:192-197)
+        if joint_angles is None:
+            return P, Iinv
+        Pn = articulate(spec, P, joint_angles[:, n])
+        return Pn, torch.linalg.inv(point_inertia(spec.mass, Pn))
+
     out = [[] for _ in range(6)]
     if spec.integrator == DYNAMICS:                                               # :467-497, :274-288
         h = spec.dt
         for n in range(T):
-            (xdd, _, wd), (Fs, Ff) = rhs(spec, Iinv, P, part_id, z_grid, friction, controls[:, n], x, xd, R, w)
+            Pn, In = body(n)
+            (xdd, _, wd), (Fs, Ff) = rhs(spec, In, Pn, part_id, z_grid, friction, controls[:, n], x, xd, R, w)
             xd = xd + xdd * h
             x = x + xd * h
             w = w + wd * h
@@ -210,7 +233,8 @@ def rollout(spec: RolloutSpec, z_grid, controls, state=None, friction=None, ts=N
             lst.append(v)
         for n in range(T - 1):
             h = ts[n + 1] - ts[n]
-            (xdd, dR, wd), (Fs, Ff) = rhs(spec, Iinv, P, part_id, z_grid, friction, controls[:, n], *y[:4])
+            Pn, In = body(n)
+            (xdd, dR, wd), (Fs, Ff) = rhs(spec, In, Pn, part_id, z_grid, friction, controls[:, n], *y[:4])
             f = (y[1], xdd, dR, wd, Fs, Ff)
             y = tuple(a + h * b for a, b in zip(y, f))
             for lst, v in zip(out, y):

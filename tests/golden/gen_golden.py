@@ -413,9 +413,34 @@ def gen_loss(out):
         out[k] = npy(v)
 
 
+# ----------------------------------------------------------------------------------------------------------
+# fixture 7: flipper joint angles (robot == 'marv', update_joints + per-step inertia, dphysics.py:192-197,326-358)
+# ----------------------------------------------------------------------------------------------------------
+def gen_joints(out):
+    pts, masks = syn.robot_points_box(32, seed=8, n_tracks=4)
+    B, T = 3, 40
+    z = torch.stack([syn.bump_terrain(np.array([[0.12, 0.5, 0.2, 0.6]]), 1.6, 0.1, torch.float64) + 0.01 * k for k in range(B)])
+    mu = torch.stack([syn.wave_friction(1.6, 0.1, 0.5, 1.0, 1.5 + k, 1.1, torch.float64) for k in range(B)])
+    ctrl = syn.varying_controls(B, T, seed=6, dtype=torch.float64)
+    t = torch.linspace(0, 1, T, dtype=torch.float64).view(1, T, 1)
+    ja = 0.6 * torch.sin(2 * np.pi * (t * torch.tensor([1.0, 0.7, 1.3, 0.5]) + torch.arange(B).view(B, 1, 1) * 0.2))   # [B,T,4]
+    out['points'] = pts; out['masks'] = np.stack(masks); out['z'] = npy(z); out['mu'] = npy(mu); out['ctrl'] = npy(ctrl)
+    out['joint_angles'] = npy(ja)
+    for dtype, tag in ((torch.float32, 'f32'), (torch.float64, 'f64')):
+        for integ in (0, 1):
+            with default_dtype(dtype):
+                cfg = make_ref_cfg(pts, masks, dtype, 0.1, 1.6, use_odeint=(integ == 1), robot='marv')
+                out['joint_positions'] = np.array(list(cfg.joint_positions.values()))
+                dp = ref_dp.DPhysics(cfg, device='cpu')
+                states, forces = dp(z_grid=z.to(dtype), controls=ctrl.to(dtype), joint_angles=ja.to(dtype), friction=mu.to(dtype))
+            for k, v in zip(['Xs', 'Xds', 'Rs', 'Om', 'Fs', 'Ff'], list(states) + list(forces)):
+                out[f'{tag}/i{integ}/{k}'] = npy(v)
+            print(f'joints {tag} integ={integ}: |Xs|max={float(states[0].abs().max()):.3f}')
+
+
 def main():
     jobs = dict(interp=gen_interp, rollout_small=gen_small, step=gen_step, rollout_full=gen_full, lss=gen_lss,
-                physics_loss=gen_loss)
+                physics_loss=gen_loss, rollout_joints=gen_joints)
     only = sys.argv[1:]
     for name, fn in jobs.items():
         if only and name not in only:

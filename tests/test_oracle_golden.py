@@ -95,3 +95,19 @@ def test_full_horizon_f64(integ):
         assert hp.rel_err(o, g[f'f64/i{integ}/{k}']) <= 1e-8, k
     assert hp.rel_err(forces[0][:, ::10], g[f'f64/i{integ}/Fs_10']) <= 1e-7
     assert hp.rel_err(forces[1][:, ::10], g[f'f64/i{integ}/Ff_10']) <= 1e-7
+
+
+@pytest.mark.parametrize('tag', ['f32', 'f64'])
+@pytest.mark.parametrize('integ', [0, 1])
+def test_flipper_joint_angles(tag, integ):
+    """robot == 'marv' with moving flippers: update_joints + per-step inertia (dphysics.py:192-197, 326-358)."""
+    g = hp.load('rollout_joints')
+    dt = hp.DT[tag]
+    spec = hp.spec_from(g['points'], g['masks'], integ, 0.1, 1.6)
+    spec.joint_positions = g['joint_positions'].tolist()
+    t = lambda k: torch.as_tensor(g[k]).to(dt)  # noqa: E731
+    with torch.no_grad():
+        st, fo = orc.rollout(spec, t('z'), t('ctrl'), friction=t('mu'), joint_angles=t('joint_angles'))
+    tol = 1e-10 if tag == 'f64' else 5e-5
+    for k, o in zip(hp.OUT_KEYS, list(st) + list(fo)):
+        assert hp.rel_err(o, g[f'{tag}/i{integ}/{k}']) <= tol, (k, hp.rel_err(o, g[f'{tag}/i{integ}/{k}']))
