@@ -156,22 +156,32 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
     if (gl == 0) { gctrl[(a.T - 1) * 2 + 0] = zero; gctrl[(a.T - 1) * 2 + 1] = zero; }
   }
 
-  // scatter-add of one step's cell gradients, deferred by one iteration (see the loop).  Unpredicated: inactive slots
-  // and the not-yet-filled stash of the first iteration add 0.0; without a friction-gradient output the friction values
-  // are replaced by 0.0 added to the height gradient (a no-op) -- the loop body stays a single basic block.
-  unsigned st_idx[PPL][4];
-  S st_z[PPL][4], st_m[PPL][4];
+  // Scatter-add of the cell gradients.  Device-scope float atomics execute at the memory side (the per-XCD L2s are not
+  // coherent): every one is a fabric transaction (PMC: WRITE_SIZE = 32 B per atomic, 0.5 GB per launch at B = 1024), and
+  // same-address ones serialise.  A robot moves <= 0.2 cell per step, so consecutive steps of a point hit the SAME four
+  // cells: their contributions are accumulated in registers (acc_*) and only written when the point changes cell
+  // (about every 5th step).  The write is deferred to the next iteration (st_*), after that step's loads were issued.
+  unsigned acc_idx[PPL][4], st_idx[PPL][4];
+  S acc_z[PPL][4], acc_m[PPL][4], st_z[PPL][4], st_m[PPL][4];
+  bool st_pending[PPL];
 #pragma unroll
-  for (int j = 0; j < PPL; ++j)
+  for (int j = 0; j < PPL; ++j) {
+    st_pending[j] = false;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { st_idx[j][q] = 0u; st_z[j][q] = zero; st_m[j][q] = zero; }
+    for (int q = 0; q < 4; ++q) { acc_idx[j][q] = st_idx[j][q] = 0u; acc_z[j][q] = acc_m[j][q] = st_z[j][q] = st_m[j][q] = zero; }
+  }
   auto flush_stash = [&]() {
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
+      if (st_pending[j]) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) atomic_add(gzmap + st_idx[j][q], st_z[j][q]);
+        for (int q = 0; q < 4; ++q) atomic_add(gzmap + st_idx[j][q], st_z[j][q]);
+        if (want_gmu) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) atomic_add(gmumap + st_idx[j][q], want_gmu ? st_m[j][q] : zero);
+          for (int q = 0; q < 4; ++q) atomic_add(gmumap + st_idx[j][q], st_m[j][q]);
+        }
+      }
+      st_pending[j] = false;
     }
   };
 
@@ -476,9 +486,20 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
         S gu0 = M::div(gn[j][0] - dotn * nrm[j][0], nl[j]), gu1 = M::div(gn[j][1] - dotn * nrm[j][1], nl[j]);
         S ggx = M::div(-gu0, a.res), ggy = M::div(-gu1, a.res);
         const S w00 = (one - c.fx) * (one - c.fy), w01 = (one - c.fx) * c.fy, w10 = c.fx * (one - c.fy), w11 = c.fx * c.fy;
-        st_idx[j][0] = (unsigned)c.ic; st_idx[j][1] = (unsigned)c.i_f; st_idx[j][2] = (unsigned)c.il; st_idx[j][3] = (unsigned)c.ifl;
-        st_z[j][0] = gzq * w00 - ggx - ggy; st_z[j][1] = gzq * w01 + ggx; st_z[j][2] = gzq * w10 + ggy; st_z[j][3] = gzq * w11;
-        st_m[j][0] = gmuq[j] * w00; st_m[j][1] = gmuq[j] * w01; st_m[j][2] = gmuq[j] * w10; st_m[j][3] = gmuq[j] * w11;
+        {
+          const unsigned ni[4] = {(unsigned)c.ic, (unsigned)c.i_f, (unsigned)c.il, (unsigned)c.ifl};
+          const S nz[4] = {gzq * w00 - ggx - ggy, gzq * w01 + ggx, gzq * w10 + ggy, gzq * w11};
+          const S nm[4] = {gmuq[j] * w00, gmuq[j] * w01, gmuq[j] * w10, gmuq[j] * w11};
+          const bool same = !act[j] || (ni[0] == acc_idx[j][0] && ni[1] == acc_idx[j][1] && ni[2] == acc_idx[j][2] && ni[3] == acc_idx[j][3]);
+          st_pending[j] = !same;                 // the stash was flushed at the top of this iteration, so it is free
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            st_idx[j][q] = acc_idx[j][q]; st_z[j][q] = acc_z[j][q]; st_m[j][q] = acc_m[j][q];
+            acc_idx[j][q] = same ? acc_idx[j][q] : ni[q];
+            acc_z[j][q] = same ? acc_z[j][q] + nz[q] : nz[q];
+            acc_m[j][q] = same ? acc_m[j][q] + nm[q] : nm[q];
+          }
+        }
         S zfx, zfy, mfx, mfy;
         blend_grad(c, zc4[j][0], zc4[j][1], zc4[j][2], zc4[j][3], &zfx, &zfy);
         blend_grad(c, mc4[j][0], mc4[j][1], mc4[j][2], mc4[j][3], &mfx, &mfy);
@@ -522,6 +543,17 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
     up = up_next;
   }
   flush_stash();
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) {          // what is still accumulated in registers
+    if (act[j]) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) atomic_add(gzmap + acc_idx[j][q], acc_z[j][q]);
+      if (want_gmu) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) atomic_add(gmumap + acc_idx[j][q], acc_m[j][q]);
+      }
+    }
+  }
 
   if (INTEG == MF_INTEG_ODEINT_EULER) {   // output 0 is the initial state itself (its forces are constant zeros)
     load_upstream(row0, up);

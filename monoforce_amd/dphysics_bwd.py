@@ -9,7 +9,10 @@ import torch
 
 from . import _lib, _timing
 
-GRAD_COPIES = 64      # private copies of a shared map's gradient (2 x 256 KiB each at 256x256)
+import os
+
+# private copies of a shared map's gradient (2 x 256 KiB each at 256x256); MF_GRAD_COPIES overrides (tuning)
+GRAD_COPIES = int(os.environ.get('MF_GRAD_COPIES', '64'))
 
 
 def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf):
