@@ -10,9 +10,11 @@
 //               mask -> linear voxel id (or -1); integer histogram of points per voxel
 //     scan      exclusive prefix sum of the histogram -> CSR offsets
 //     fill      CSR lists of point ids per voxel
-//   forward   one workgroup per tile of 64 consecutive voxels of one BEV plane; a wave owns a voxel at a time with
-//             lane = channel: it reads the voxel's points' feature rows (C contiguous floats = one coalesced 256 B
-//             access per point), accumulating in ascending point order (deterministic, bit-reproducible); the
+//     rank      order each voxel's CSR segment by point id (thread per point: rank inside its short segment)
+//   forward   one workgroup per tile of 64 consecutive voxels of one BEV plane, 16 voxels per wave, lane = channel:
+//             the wave's points are one contiguous sorted range of the CSR list; their feature rows (C contiguous floats
+//             = one coalesced 256 B access per point) stream through a 4-deep load pipeline and are accumulated in
+//             ascending point order (deterministic, bit-reproducible); the
 //             [channel][voxel] tile is transposed through LDS so every output row segment (64 voxels of one channel
 //             plane) is written as one contiguous 256 B store.  Empty voxels cost one offsets read.
 //   backward  the same tiling in reverse: the grad tile is loaded coalesced per channel plane, and each kept point's
@@ -29,7 +31,8 @@ struct SplatWs {        // carve-up of the caller's workspace (all int32)
   int* count;           // [V]      points per voxel
   int* cursor;          // [V]      fill cursors
   int* offsets;         // [V + 1]  CSR offsets
-  int* list;            // [P]      point ids grouped by voxel
+  int* list;            // [P]      point ids grouped by voxel, ascending inside each voxel
+  int* scratch;         // [P]      the same in arrival order (before the rank pass)
   int* block_sums;      // [ceil(V / 2048) + 1]
 };
 
@@ -47,8 +50,9 @@ static size_t carve(const MfSplatDesc* d, void* base, SplatWs* ws) {
   int* cursor = take(V);
   int* offsets = take(V + 1);
   int* list = take(P);
+  int* scratch = take(P);
   int* bs = take(nblk);
-  if (ws) { ws->keys = keys; ws->count = count; ws->cursor = cursor; ws->offsets = offsets; ws->list = list; ws->block_sums = bs; }
+  if (ws) { ws->keys = keys; ws->count = count; ws->cursor = cursor; ws->offsets = offsets; ws->list = list; ws->scratch = scratch; ws->block_sums = bs; }
   return off;
 }
 
@@ -140,39 +144,29 @@ __global__ void __launch_bounds__(256) splat_fill_kernel(const int* __restrict__
   if (key >= 0) list[offsets[key] + atomicAdd(cursor + key, 1)] = p;
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// in-wave ordering of one voxel's point list (ascending point id => deterministic summation order)
-// ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int wave_min_i32(int v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v = min(v, __shfl_xor(v, d, 64));
-  return v;
-}
-
-// Calls f(p) for every point id in list[start, start+cnt) in ascending order.  All 64 lanes must call it together.
-template <typename F>
-__device__ __forceinline__ void for_each_point_sorted(const int* __restrict__ list, int start, int cnt, int lane, F&& f) {
-  if (cnt <= 64) {
-    const int mine = (lane < cnt) ? list[start + lane] : 0x7fffffff;
-    int rank = 0;
-    for (int j = 0; j < cnt; ++j) rank += (__builtin_amdgcn_readlane(mine, j) < mine) ? 1 : 0;
-    const int sorted = __builtin_amdgcn_ds_permute(rank << 2, mine);   // lane `rank` receives `mine`
-    for (int k = 0; k < cnt; ++k) f(__builtin_amdgcn_readlane(sorted, k));
-  } else {
-    int last = -1;                        // rare dense voxel: selection by repeated wave-min
-    for (int k = 0; k < cnt; ++k) {
-      int best = 0x7fffffff;
-      for (int i = lane; i < cnt; i += 64) { const int q = list[start + i]; if (q > last && q < best) best = q; }
-      best = wave_min_i32(best);
-      last = best;
-      f(best);
-    }
-  }
+// Order every voxel's CSR segment by point id (the atomic fill leaves it in arrival order): one thread per list slot
+// computes the rank of its point inside its voxel's segment (segments are short: <= ~30 points at the reference's grids)
+// and writes it to its sorted position in a second list.  Afterwards every voxel is summed in ascending point order =>
+// bit-reproducible results with no sorting in the hot kernels.
+__global__ void __launch_bounds__(256) splat_rank_kernel(const int* __restrict__ keys, const int* __restrict__ offsets, int V,
+                                                        const int* __restrict__ list, int* __restrict__ sorted) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= offsets[V]) return;
+  const int p = list[i];
+  const int key = keys[p];
+  const int s = offsets[key], e = offsets[key + 1];
+  int rank = 0;
+  for (int j = s; j < e; ++j) rank += (list[j] < p) ? 1 : 0;
+  sorted[s + rank] = p;
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // forward / backward tiles
 // ---------------------------------------------------------------------------------------------------------
+// A workgroup owns a tile of 64 consecutive voxels of one BEV plane, each of its 4 waves 16 of them.  The CSR segments of
+// consecutive voxels are contiguous, so a wave's points are ONE contiguous, (voxel, point)-sorted range of `list`: it is
+// fetched 64 ids at a time with one coalesced load, and the feature rows (lane = channel: one 256 B row per point) are
+// streamed through a 4-deep register pipeline so that four row loads are always in flight -- no per-voxel latency chain.
 template <typename S>
 __global__ void __launch_bounds__(256) splat_fwd_kernel(const S* __restrict__ x, const int* __restrict__ offsets,
                                                        const int* __restrict__ list, int C, int plane, int tiles_per_plane,
@@ -183,21 +177,42 @@ __global__ void __launch_bounds__(256) splat_fwd_kernel(const S* __restrict__ x,
   const int nvox = min(kTileVox, plane - vid0);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int key0 = bz * plane + vid0;
+  const int v_lo = wave * 16, v_hi = min(v_lo + 16, nvox);     // this wave's voxels (may be empty at a ragged plane end)
+  // offsets of the wave's voxels: lane v holds offsets[first + v], v = 0..16
+  const int my_off = (v_lo + lane <= nvox && lane <= 16) ? offsets[key0 + v_lo + lane] : 0;
+  const int start = __builtin_amdgcn_readfirstlane(my_off);
+  const int n = (v_hi > v_lo) ? __builtin_amdgcn_readlane(my_off, v_hi - v_lo) - start : 0;
   for (int c0 = 0; c0 < C; c0 += 64) {
-    const int c = c0 + lane;
-    for (int v = wave * 16; v < wave * 16 + 16; ++v) {
-      S acc = (S)0;
-      if (v < nvox) {
-        const int start = offsets[key0 + v];
-        const int cnt = offsets[key0 + v + 1] - start;
-        if (cnt > 0) {
-          for_each_point_sorted(list, start, cnt, lane, [&](int p) {
-            if (c < C) acc += x[(size_t)p * C + c];
-          });
+    const int c = min(c0 + lane, C - 1);                       // lanes beyond C read a valid channel and are not stored
+    const S* xc = x + c;
+    S acc = (S)0;
+    int v = v_lo;                                              // voxel being accumulated
+    int bound = (v_hi > v_lo) ? __builtin_amdgcn_readlane(my_off, 1) - start : 0;   // first point index NOT in voxel v
+    for (int k0 = 0; k0 < n; k0 += 64) {
+      const int m = min(64, n - k0);
+      const int pid = (lane < m) ? list[start + k0 + lane] : 0;
+      // 4-deep pipeline over the m points of this chunk
+      S b0 = (S)0, b1 = (S)0, b2 = (S)0, b3 = (S)0;
+      if (0 < m) b0 = xc[(size_t)__builtin_amdgcn_readlane(pid, 0) * C];
+      if (1 < m) b1 = xc[(size_t)__builtin_amdgcn_readlane(pid, 1) * C];
+      if (2 < m) b2 = xc[(size_t)__builtin_amdgcn_readlane(pid, 2) * C];
+      if (3 < m) b3 = xc[(size_t)__builtin_amdgcn_readlane(pid, 3) * C];
+      for (int k = 0; k < m; k += 4) {
+#define MF_STEP(BUF, I)                                                                             \
+        if (k + I < m) {                                                                            \
+          const S val = BUF;                                                                        \
+          if (k + I + 4 < m) BUF = xc[(size_t)__builtin_amdgcn_readlane(pid, k + I + 4) * C];       \
+          while (k0 + k + I >= bound) {          /* wave-uniform: close voxel v (possibly empty) */ \
+            tile[lane][v] = acc; acc = (S)0; ++v;                                                   \
+            bound = __builtin_amdgcn_readlane(my_off, v - v_lo + 1) - start;                        \
+          }                                                                                         \
+          acc += val;                                                                               \
         }
+        MF_STEP(b0, 0) MF_STEP(b1, 1) MF_STEP(b2, 2) MF_STEP(b3, 3)
+#undef MF_STEP
       }
-      tile[lane][v] = acc;
     }
+    for (; v < v_hi; ++v) { tile[lane][v] = acc; acc = (S)0; }   // last voxel with points + trailing empty ones
     __syncthreads();
     // out[(bz*C + c) * plane + vid]: 64 consecutive voxels of one channel plane per store
     const int nch = min(64, C - c0);
@@ -219,19 +234,28 @@ __global__ void __launch_bounds__(256) splat_bwd_kernel(const S* __restrict__ go
   const int key0 = bz * plane + vid0;
   // skip tiles without points (most of the BEV plane is outside the camera frusta)
   if (offsets[key0 + nvox] == offsets[key0]) return;
+  const int v_lo = wave * 16, v_hi = min(v_lo + 16, nvox);
+  const int my_off = (v_lo + lane <= nvox && lane <= 16) ? offsets[key0 + v_lo + lane] : 0;
+  const int start = __builtin_amdgcn_readfirstlane(my_off);
+  const int n = (v_hi > v_lo) ? __builtin_amdgcn_readlane(my_off, v_hi - v_lo) - start : 0;
   for (int c0 = 0; c0 < C; c0 += 64) {
     const int nch = min(64, C - c0);
     for (int cc = wave; cc < nch; cc += 4)
       tile[cc][lane] = (lane < nvox) ? gout[((size_t)bz * C + c0 + cc) * plane + vid0 + lane] : (S)0;
     __syncthreads();
     const int c = c0 + lane;
-    for (int v = wave * 16; v < wave * 16 + 16 && v < nvox; ++v) {
-      const int start = offsets[key0 + v];
-      const int cnt = offsets[key0 + v + 1] - start;
-      const S g = tile[lane][v];
-      for (int i = 0; i < cnt; ++i) {          // order is irrelevant for a gather
-        const int p = list[start + i];
-        if (c < C) gx[(size_t)p * C + c] = g;
+    int v = v_lo;
+    int bound = (v_hi > v_lo) ? __builtin_amdgcn_readlane(my_off, 1) - start : 0;
+    S g = tile[lane][v_lo < nvox ? v_lo : 0];
+    for (int k0 = 0; k0 < n; k0 += 64) {
+      const int m = min(64, n - k0);
+      const int pid = (lane < m) ? list[start + k0 + lane] : 0;
+      for (int k = 0; k < m; ++k) {
+        if (k0 + k >= bound) {                       // wave-uniform: advance to the voxel that owns point k
+          do { ++v; bound = __builtin_amdgcn_readlane(my_off, v - v_lo + 1) - start; } while (k0 + k >= bound);
+          g = tile[lane][v];
+        }
+        if (c < C) gx[(size_t)__builtin_amdgcn_readlane(pid, k) * C + c] = g;     // one coalesced row per point
       }
     }
     __syncthreads();
@@ -281,8 +305,10 @@ static int splat_prepare(const MfSplatDesc* d, const float* geom, void* workspac
   hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(256), 0, st, ws.block_sums, nblk, ws.offsets + V);
   hipLaunchKernelGGL(scan_add_kernel, dim3(nblk), dim3(256), 0, st, ws.offsets, V, ws.block_sums);
   MF_LAUNCH_OK("splat_scan");
-  hipLaunchKernelGGL(splat_fill_kernel, dim3((P + 255) / 256), dim3(256), 0, st, ws.keys, P, ws.offsets, ws.cursor, ws.list);
+  hipLaunchKernelGGL(splat_fill_kernel, dim3((P + 255) / 256), dim3(256), 0, st, ws.keys, P, ws.offsets, ws.cursor, ws.scratch);
   MF_LAUNCH_OK("splat_fill");
+  hipLaunchKernelGGL(splat_rank_kernel, dim3((P + 255) / 256), dim3(256), 0, st, ws.keys, ws.offsets, V, ws.scratch, ws.list);
+  MF_LAUNCH_OK("splat_sort");
   return MF_OK;
 }
 

@@ -442,7 +442,10 @@ struct LaneMap { int G, PPL; };
 static inline LaneMap choose_lane_map(int B, int N, int points_per_lane) {
   int g1 = 4;
   while (g1 < N) g1 <<= 1;  // lanes per rollout at one point per lane
-  bool wide = g1 <= 64 && (long long)B * g1 / 64 <= 4096;   // measured crossover: ~4 waves per SIMD
+  // One point per lane whenever the body fits a wave: measured faster than 4 points per lane over the whole range
+  // B = 256 .. 65536 (N = 4) once the fast-math kernels cut the per-lane instruction count (tools/sweep_mapping.py).
+  (void)B;
+  bool wide = g1 <= 64;
   if (points_per_lane == 1 && g1 <= 64) wide = true;
   if (points_per_lane == 4) wide = false;
   if (N <= 4) return wide ? LaneMap{4, 1} : LaneMap{1, 4};
@@ -450,7 +453,7 @@ static inline LaneMap choose_lane_map(int B, int N, int points_per_lane) {
   if (N <= 16) return wide ? LaneMap{16, 1} : LaneMap{4, 4};
   if (N <= 32) return wide ? LaneMap{32, 1} : LaneMap{8, 4};
   if (N <= 64) return wide ? LaneMap{64, 1} : LaneMap{16, 4};
-  if (N <= 128) return (points_per_lane != 4 && (long long)B * 2 <= 4096) ? LaneMap{64, 2} : LaneMap{32, 4};
+  if (N <= 128) return points_per_lane != 4 ? LaneMap{64, 2} : LaneMap{32, 4};
   if (N <= 256) return LaneMap{64, 4};
   return LaneMap{64, 8};
 }
