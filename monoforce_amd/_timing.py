@@ -4,10 +4,13 @@ import contextlib
 import torch
 
 _records = None     # None = off; else list of (name, start_event, end_event)
+_pool = []          # pre-created events (creating them inside a timed region costs host time)
 
 
-def start():
+def start(capacity=4096):
     global _records
+    while len(_pool) < 2 * capacity:
+        _pool.append(torch.cuda.Event(enable_timing=True))
     _records = []
 
 
@@ -27,7 +30,11 @@ def timed(name, device):
     if _records is None:
         yield
         return
-    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    i = 2 * len(_records)
+    if i + 1 < len(_pool):
+        a, b = _pool[i], _pool[i + 1]
+    else:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(torch.cuda.current_stream(device))     # the stream the kernel is launched on
     yield
     b.record(torch.cuda.current_stream(device))
