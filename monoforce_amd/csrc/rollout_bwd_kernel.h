@@ -38,6 +38,10 @@ __device__ __forceinline__ void atomic_add(double* p, double v) { unsafeAtomicAd
 
 template <typename S>
 __device__ __forceinline__ bool inside(S v, S lo, S hi) { return v >= lo && v <= hi; }
+template <typename S>
+__device__ __forceinline__ S* at32(S* base, unsigned elem) {
+  return reinterpret_cast<S*>(reinterpret_cast<char*>(base) + (size_t)(elem * (unsigned)sizeof(S)));
+}
 
 #define MF_CROSS(o, a, b)                    \
   do {                                       \
@@ -55,15 +59,16 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
   if (b >= a.B) return;
   const S one = (S)1, zero = (S)0;
   const int HW = a.H * a.W, last = HW - 1;
-  const size_t map_off = a.map_shared ? 0 : (size_t)b * HW;
-  const S* zmap = a.z + map_off;
+  // uniform base pointers + 32-bit element offsets (host guarantees < 4 GiB per array): scalar-base loads and atomics
+  const unsigned moff = a.map_shared ? 0u : (unsigned)b * (unsigned)HW;
+  const S* zmap = a.z;
   const bool has_mu = a.mu != nullptr;  // wave-uniform
-  const S* mumap = has_mu ? a.mu + map_off : a.z;
+  const S* mumap = has_mu ? a.mu : a.z;
   // shared map: rollout b scatters into private copy b % grad_copies (summed by the caller) -- see monoforce_hip.h
-  const size_t gmap_off = a.map_shared ? (size_t)(b % a.grad_copies) * HW : (size_t)b * HW;
-  S* gzmap = a.gz + gmap_off;
+  const unsigned goff = a.map_shared ? (unsigned)(b % a.grad_copies) * (unsigned)HW : (unsigned)b * (unsigned)HW;
+  S* gzmap = a.gz;
   const bool want_gmu = a.gmu != nullptr && has_mu;  // wave-uniform
-  S* gmumap = want_gmu ? a.gmu + gmap_off : a.gz + gmap_off;
+  S* gmumap = want_gmu ? a.gmu : a.gz;
 
   S P[PPL][3];
   int part[PPL];
@@ -175,10 +180,10 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
     for (int j = 0; j < PPL; ++j) {
       if (st_pending[j]) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) atomic_add(gzmap + st_idx[j][q], st_z[j][q]);
+        for (int q = 0; q < 4; ++q) atomic_add(at32(gzmap, goff + st_idx[j][q]), st_z[j][q]);
         if (want_gmu) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) atomic_add(gmumap + st_idx[j][q], st_m[j][q]);
+          for (int q = 0; q < 4; ++q) atomic_add(at32(gmumap, goff + st_idx[j][q]), st_m[j][q]);
         }
       }
       st_pending[j] = false;
@@ -217,10 +222,10 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
       vp[j][2] = xd[2] + (w[0] * r[j][1] - w[1] * r[j][0]);
       cell[j] = locate_m<S, FAST>(px, py, a.d_max, a.res, a.inv_res, a.H, last);
       const Cell<S>& c = cell[j];
-      zc4[j][0] = zmap[(unsigned)c.ic]; zc4[j][1] = zmap[(unsigned)c.i_f]; zc4[j][2] = zmap[(unsigned)c.il]; zc4[j][3] = zmap[(unsigned)c.ifl];
+      zc4[j][0] = ld32(zmap, moff + (unsigned)c.ic); zc4[j][1] = ld32(zmap, moff + (unsigned)c.i_f); zc4[j][2] = ld32(zmap, moff + (unsigned)c.il); zc4[j][3] = ld32(zmap, moff + (unsigned)c.ifl);
       // unconditional (mumap aliases z when there is no friction map), then a uniform select: keeps the loop one basic block
       {
-        S m0 = mumap[(unsigned)c.ic], m1 = mumap[(unsigned)c.i_f], m2 = mumap[(unsigned)c.il], m3 = mumap[(unsigned)c.ifl];
+        S m0 = ld32(mumap, moff + (unsigned)c.ic), m1 = ld32(mumap, moff + (unsigned)c.i_f), m2 = ld32(mumap, moff + (unsigned)c.il), m3 = ld32(mumap, moff + (unsigned)c.ifl);
         mc4[j][0] = has_mu ? m0 : one; mc4[j][1] = has_mu ? m1 : one; mc4[j][2] = has_mu ? m2 : one; mc4[j][3] = has_mu ? m3 : one;
       }
     }
@@ -547,10 +552,10 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
   for (int j = 0; j < PPL; ++j) {          // what is still accumulated in registers
     if (act[j]) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) atomic_add(gzmap + acc_idx[j][q], acc_z[j][q]);
+      for (int q = 0; q < 4; ++q) atomic_add(at32(gzmap, goff + acc_idx[j][q]), acc_z[j][q]);
       if (want_gmu) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) atomic_add(gmumap + acc_idx[j][q], acc_m[j][q]);
+        for (int q = 0; q < 4; ++q) atomic_add(at32(gmumap, goff + acc_idx[j][q]), acc_m[j][q]);
       }
     }
   }
@@ -575,11 +580,11 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
         S px = P[j][0] * R0[0] + P[j][1] * R0[1] + P[j][2] * R0[2] + x0[0];
         S py = P[j][0] * R0[3] + P[j][1] * R0[4] + P[j][2] * R0[5] + x0[1];
         Cell<S> c = locate_m<S, FAST>(px, py, a.d_max, a.res, a.inv_res, a.H, last);
-        S v0 = zmap[(unsigned)c.ic], v1 = zmap[(unsigned)c.i_f], v2 = zmap[(unsigned)c.il], v3 = zmap[(unsigned)c.ifl];
-        atomic_add(gzmap + (unsigned)c.ic, g * (one - c.fx) * (one - c.fy));
-        atomic_add(gzmap + (unsigned)c.i_f, g * (one - c.fx) * c.fy);
-        atomic_add(gzmap + (unsigned)c.il, g * c.fx * (one - c.fy));
-        atomic_add(gzmap + (unsigned)c.ifl, g * c.fx * c.fy);
+        S v0 = ld32(zmap, moff + (unsigned)c.ic), v1 = ld32(zmap, moff + (unsigned)c.i_f), v2 = ld32(zmap, moff + (unsigned)c.il), v3 = ld32(zmap, moff + (unsigned)c.ifl);
+        atomic_add(at32(gzmap, goff + (unsigned)c.ic), g * (one - c.fx) * (one - c.fy));
+        atomic_add(at32(gzmap, goff + (unsigned)c.i_f), g * (one - c.fx) * c.fy);
+        atomic_add(at32(gzmap, goff + (unsigned)c.il), g * c.fx * (one - c.fy));
+        atomic_add(at32(gzmap, goff + (unsigned)c.ifl), g * c.fx * c.fy);
         S dfx, dfy;
         blend_grad(c, v0, v1, v2, v3, &dfx, &dfy);
         S gpx = M::div(g * dfx, a.res), gpy = M::div(g * dfy, a.res);

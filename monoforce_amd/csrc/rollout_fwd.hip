@@ -20,6 +20,8 @@ static int fill_args(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutA
   MF_REQUIRE(p->Xs && p->Xds && p->Rs && p->Omegas && p->Fs && p->Ff, MF_ERR_INVALID, "rollout_fwd: null output buffer");
   MF_REQUIRE((long long)d->H * d->W < (1ll << 30), MF_ERR_UNSUPPORTED, "rollout_fwd: grid too large");
   MF_REQUIRE(d->N <= 512, MF_ERR_UNSUPPORTED, "rollout_fwd: more than 512 contact points");
+  MF_REQUIRE(d->map_shared || (long long)d->B * d->H * d->W * (long long)sizeof(S) < (1ll << 32), MF_ERR_UNSUPPORTED,
+             "rollout_fwd: per-rollout maps of 4 GiB or more in total (use a shared map or split the batch)");
   *block = d->block ? d->block : 64;
   MF_REQUIRE(*block == 64 || *block == 128 || *block == 256, MF_ERR_INVALID, "rollout_fwd: block must be 64, 128 or 256");
   *m = choose_lane_map(d->B, d->N, d->points_per_lane);

@@ -63,6 +63,7 @@ struct Mth {
   static __device__ __forceinline__ S inv_len(S len2) { return (S)1 / mf_max(mf_sqrt(len2), (S)1e-6); }
   static constexpr bool kReciprocalNorm = false;
   static __device__ __forceinline__ void sincos_small(S v, S* s, S* omc) { S c; mf_sincos(v, s, &c); *omc = (S)1 - c; }
+  static __device__ __forceinline__ S clamp(S v, S lo, S hi) { return mf_clamp(v, lo, hi); }   // torch.clamp, NaN propagates
 };
 template <>
 struct Mth<float, true> {
@@ -74,6 +75,7 @@ struct Mth<float, true> {
   }
   static __device__ __forceinline__ float inv_len(float len2) { return __builtin_amdgcn_rsqf(fmaxf(len2, 1e-12f)); }
   static constexpr bool kReciprocalNorm = true;
+  static __device__ __forceinline__ float clamp(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }  // 1 instr
   static __device__ __forceinline__ void sincos_small(float v, float* s, float* omc) {
     if (fabsf(v) < 0.25f) {  // |w| dt is ~1e-2: short Taylor series, and 1 - cos without the cancellation
       const float v2 = v * v;
@@ -92,8 +94,8 @@ __device__ __forceinline__ Cell<S> locate_m(S qx, S qy, S d_max, S res, S inv_re
   const S lim = (S)262144.0;
   S ux = Mth<S, FAST>::cell_coord(qx, d_max, res, inv_res);
   S uy = Mth<S, FAST>::cell_coord(qy, d_max, res, inv_res);
-  int ix = (int)mf_clamp(ux, -lim, lim);  // trunc toward zero, like .long()
-  int iy = (int)mf_clamp(uy, -lim, lim);
+  int ix = (int)Mth<S, FAST>::clamp(ux, -lim, lim);  // trunc toward zero, like .long()
+  int iy = (int)Mth<S, FAST>::clamp(uy, -lim, lim);
   Cell<S> c;
   c.fx = ux - (S)ix;
   c.fy = uy - (S)iy;
@@ -103,6 +105,13 @@ __device__ __forceinline__ Cell<S> locate_m(S qx, S qy, S d_max, S res, S inv_re
   c.il = min(max(base + 1, 0), last);
   c.ifl = min(max(base + 1 + H, 0), last);
   return c;
+}
+
+// Load base[elem] with a wave-uniform base pointer and a 32-bit element offset: the byte offset is formed in 32 bits (the
+// host guarantees B*H*W*sizeof(S) < 4 GiB for per-rollout maps) so the access uses the scalar-base + 32-bit-offset form.
+template <typename S>
+__device__ __forceinline__ S ld32(const S* base, unsigned elem) {
+  return *reinterpret_cast<const S*>(reinterpret_cast<const char*>(base) + (size_t)(elem * (unsigned)sizeof(S)));
 }
 
 template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS = false>
@@ -115,8 +124,10 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
   const S one = (S)1, zero = (S)0;
   const int HW = a.H * a.W, last = HW - 1;
   const bool has_mu = a.mu != nullptr;  // wave-uniform
-  const S* zmap = a.z + (a.map_shared ? 0 : (size_t)b * HW);
-  const S* mumap = has_mu ? a.mu + (a.map_shared ? 0 : (size_t)b * HW) : a.z;
+  // uniform base pointer + 32-bit element offset (the host guarantees B*H*W < 2^31 for per-rollout maps): scalar-base loads
+  const unsigned moff = a.map_shared ? 0u : (unsigned)b * (unsigned)HW;
+  const S* zmap = a.z;
+  const S* mumap = has_mu ? a.mu : a.z;
 
   // this lane's contact points
   S P[PPL][3];   // contact points used by the step (articulated per step when JOINTS)
@@ -158,7 +169,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
       S px = P[j][0] * R[0] + P[j][1] * R[1] + P[j][2] * R[2] + x[0];
       S py = P[j][0] * R[3] + P[j][1] * R[4] + P[j][2] * R[5] + x[1];
       Cell<S> c = locate_m<S, FAST>(px, py, a.d_max, a.res, a.inv_res, a.H, last);
-      S v = blend(c, zmap[(unsigned)c.ic], zmap[(unsigned)c.i_f], zmap[(unsigned)c.il], zmap[(unsigned)c.ifl]);
+      S v = blend(c, ld32(zmap, moff + (unsigned)c.ic), ld32(zmap, moff + (unsigned)c.i_f), ld32(zmap, moff + (unsigned)c.il), ld32(zmap, moff + (unsigned)c.ifl));
       acc += act[j] ? v : zero;
     }
     acc = group_sum<G>(acc);
@@ -259,12 +270,12 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
       r[j][0] = px - x[0]; r[j][1] = py - x[1]; r[j][2] = pz[j] - x[2];
       cell[j] = locate_m<S, FAST>(px, py, a.d_max, a.res, a.inv_res, a.H, last);
       const Cell<S>& c = cell[j];
-      zc[j][0] = zmap[(unsigned)c.ic]; zc[j][1] = zmap[(unsigned)c.i_f]; zc[j][2] = zmap[(unsigned)c.il]; zc[j][3] = zmap[(unsigned)c.ifl];
+      zc[j][0] = ld32(zmap, moff + (unsigned)c.ic); zc[j][1] = ld32(zmap, moff + (unsigned)c.i_f); zc[j][2] = ld32(zmap, moff + (unsigned)c.il); zc[j][3] = ld32(zmap, moff + (unsigned)c.ifl);
     }
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {   // unconditional (mumap aliases z without a friction map) + uniform select: no branch
       const Cell<S>& c = cell[j];
-      S m0 = mumap[(unsigned)c.ic], m1 = mumap[(unsigned)c.i_f], m2 = mumap[(unsigned)c.il], m3 = mumap[(unsigned)c.ifl];
+      S m0 = ld32(mumap, moff + (unsigned)c.ic), m1 = ld32(mumap, moff + (unsigned)c.i_f), m2 = ld32(mumap, moff + (unsigned)c.il), m3 = ld32(mumap, moff + (unsigned)c.ifl);
       mc[j][0] = has_mu ? m0 : one; mc[j][1] = has_mu ? m1 : one; mc[j][2] = has_mu ? m2 : one; mc[j][3] = has_mu ? m3 : one;
     }
     // next step's controls (the lookup argmin|t - ts| is the step index on the grid, dphysics.py:183)
@@ -326,7 +337,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
 #pragma unroll
       for (int c = 0; c < 3; ++c) {  // (:232-233)
         S f = FAST ? Fr[j][c] * cw8[j] * inv_csum : Fr[j][c] * cw8[j] / csum;
-        Fr[j][c] = mf_clamp(f, -a.mg, a.mg);
+        Fr[j][c] = M::clamp(f, -a.mg, a.mg);
       }
       S Nn = M::sqrt(Fr[j][0] * Fr[j][0] + Fr[j][1] * Fr[j][1] + Fr[j][2] * Fr[j][2]);  // (:238)
       S tv = (part[j] < 0) ? zero : ((part[j] & 1) ? tv_hi : tv_lo);
@@ -334,9 +345,9 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
       S s1 = muq[j] * (tv * e1 - vp[j][1]);
       S s2 = muq[j] * (tv * e2 - vp[j][2]);
       S sn = s0 * nrm[j][0] + s1 * nrm[j][1] + s2 * nrm[j][2];
-      Ff[j][0] = mf_clamp(Nn * (s0 - sn * nrm[j][0]), -a.mg, a.mg);  // (:248-251)
-      Ff[j][1] = mf_clamp(Nn * (s1 - sn * nrm[j][1]), -a.mg, a.mg);
-      Ff[j][2] = mf_clamp(Nn * (s2 - sn * nrm[j][2]), -a.mg, a.mg);
+      Ff[j][0] = M::clamp(Nn * (s0 - sn * nrm[j][0]), -a.mg, a.mg);  // (:248-251)
+      Ff[j][1] = M::clamp(Nn * (s1 - sn * nrm[j][1]), -a.mg, a.mg);
+      Ff[j][2] = M::clamp(Nn * (s2 - sn * nrm[j][2]), -a.mg, a.mg);
       if (!act[j]) {
 #pragma unroll
         for (int c = 0; c < 3; ++c) Fr[j][c] = Ff[j][c] = zero;
@@ -361,7 +372,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
     S wd[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
-      wd[c] = mf_clamp(Iv[c * 3 + 0] * sTau[0] + Iv[c * 3 + 1] * sTau[1] + Iv[c * 3 + 2] * sTau[2],
+      wd[c] = M::clamp(Iv[c * 3 + 0] * sTau[0] + Iv[c * 3 + 1] * sTau[1] + Iv[c * 3 + 2] * sTau[2],
                        -a.omega_max, a.omega_max);
     // xdd = (m g ghat + sum Fs + sum Ff) / m   (:264-266)
     S xdd[3];
