@@ -140,3 +140,59 @@ def test_physics_loss_style_sparse_upstream():
         (Xd, _, _, _), _ = make_dphysics(pts, masks, integ, 0.1, 3.2)(zd, ctrl.to(DEV))
         ((Xd[:, idx.to(DEV)] - tgt.to(DEV)) ** 2).mean().backward()
         assert hp.rel_err(zd.grad.cpu(), zo.grad) <= 1e-8
+
+
+@pytest.mark.parametrize('integ', [0, 1])
+def test_backward_layout_and_mode_invariance(integ):
+    """Gradients do not depend on the output layout, the workgroup size, or friction=None vs an all-ones map; the exact and
+    fast float32 kernels agree to float32 accuracy; float32 agrees with float64."""
+    from monoforce_amd import synthetic as syn
+    pts, masks = syn.robot_points_4()
+    B, T = 8, 64
+    z = torch.stack([syn.bump_terrain(syn.bump_params(50 + b), 3.2, 0.1, torch.float64) * 0.3 for b in range(B)])
+    ctrl = syn.varying_controls(B, T, seed=4, dtype=torch.float64)
+
+    def grads(dtype, friction, **kw):
+        dp = make_dphysics(pts, masks, integ, 0.1, 3.2, **kw)
+        zd = z.to(dtype).to(DEV).requires_grad_(True)
+        cd = ctrl.to(dtype).to(DEV).requires_grad_(True)
+        mu = None if friction is None else torch.ones(B, 64, 64, dtype=dtype, device=DEV)
+        states, forces = dp(zd, cd, friction=mu)
+        hp.probe_loss(list(states) + list(forces), dtype).backward()
+        return zd.grad.double().cpu(), cd.grad.double().cpu()
+
+    ref = grads(torch.float64, None)
+    for other in (grads(torch.float64, None, contiguous_outputs=True), grads(torch.float64, None, block=256),
+                  grads(torch.float64, 'ones')):
+        assert hp.rel_err(other[0], ref[0]) <= 1e-12 and hp.rel_err(other[1], ref[1]) <= 1e-12
+    exact = grads(torch.float32, None, precise=True)
+    fast = grads(torch.float32, None)
+    for g in (exact, fast):
+        assert hp.rel_err(g[0], ref[0]) <= 5e-4 and hp.rel_err(g[1], ref[1]) <= 5e-4
+    assert hp.rel_err(fast[0], exact[0]) <= 5e-4
+
+
+def test_gradient_descent_recovers_terrain_offset():
+    """fit_terrain.py in miniature: optimise a terrain so that rollouts match trajectories recorded on another terrain.
+    The physics loss must decrease under Adam steps on z (end-to-end sanity of forward + backward + optimiser)."""
+    from monoforce_amd import synthetic as syn
+    from monoforce_amd.losses import physics_loss
+    pts, masks = syn.robot_points_4()
+    B, T = 32, 200
+    dp = make_dphysics(pts, masks, 1, 0.1, 3.2)
+    z_true = (syn.bump_terrain(np.array([[0.25, 1.0, 0.0, 0.8]]), 3.2, 0.1) ).to(DEV)
+    ctrl = syn.const_controls(B, T, seed=11, v_range=(0.6, 1.0), w_range=(-0.6, 0.6)).to(DEV)
+    with torch.no_grad():
+        (Xt, _, _, _), _ = dp(z_true.unsqueeze(0), ctrl)
+    ts = torch.linspace(0, 5, 500, device=DEV)[:T].unsqueeze(0).expand(B, -1)
+    z = torch.zeros_like(z_true).requires_grad_(True)
+    opt = torch.optim.Adam([z], lr=0.01)
+    losses = []
+    for _ in range(30):
+        opt.zero_grad()
+        (Xs, _, _, _), _ = dp(z.unsqueeze(0), ctrl)
+        loss = physics_loss([Xs], [Xt], ts, ts)
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+    assert np.isfinite(losses).all() and losses[-1] < 0.8 * losses[0], (losses[0], losses[-1])

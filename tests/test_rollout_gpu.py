@@ -243,3 +243,28 @@ def test_flipper_joint_angles_vs_reference(tag, integ):
     # gradients through an articulated rollout are refused, not silently wrong
     with pytest.raises(NotImplementedError):
         dp(t('z').requires_grad_(True), t('ctrl'), joint_angles=t('joint_angles'), friction=t('mu'))
+
+
+def test_dtype_device_and_stride_handling():
+    """Inputs that are non-contiguous, on the wrong device or of mixed dtype are normalised like `.to(device)` would."""
+    from monoforce_amd import synthetic as syn
+    pts, masks = syn.robot_points_4()
+    B, T = 5, 50
+    dp = make_dphysics(pts, masks, 1, 0.1, 3.2)
+    z = torch.stack([syn.bump_terrain(syn.bump_params(70 + b), 3.2, 0.1) * 0.3 for b in range(B)])
+    ctrl = syn.varying_controls(B, T, seed=1)
+    ref = dp(z.to(DEV), ctrl.to(DEV))
+    # CPU inputs are moved; float64 controls are cast to the map's dtype; a transposed-storage map is made contiguous
+    zt = z.transpose(1, 2).contiguous().transpose(1, 2)
+    out = dp(zt, ctrl.double())
+    for a, b in zip(ref[0] + ref[1], out[0] + out[1]):
+        assert a.dtype == torch.float32 and torch.equal(a, b)
+    # a given state whose x is a non-contiguous view still receives the terrain snap in place (dphysics.py:571)
+    pose = torch.eye(4).repeat(B, 1, 1).to(DEV)
+    x_view = pose[:, :3, 3]
+    st = (x_view, torch.zeros(B, 3, device=DEV), pose[:, :3, :3], torch.zeros(B, 3, device=DEV))
+    dp(z.to(DEV), ctrl.to(DEV), state=st)
+    assert float(pose[:, 2, 3].abs().max()) > 0 and torch.equal(pose[:, 2, 3], x_view[:, 2])
+    # half precision is refused loudly
+    with pytest.raises(TypeError):
+        dp(z.half().to(DEV), ctrl.to(DEV))
