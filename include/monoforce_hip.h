@@ -101,7 +101,9 @@ typedef struct MfRolloutFwdBufs {
   void* Xds;            /* S[..][3]   */
   void* Rs;             /* S[..][3][3]*/
   void* Omegas;         /* S[..][3]   */
-  void* Fs;             /* S[..][force_stride][3] spring forces (DYNAMICS) or their running impulses (ODEINT) */
+  void* Fs;             /* S[..][force_stride][3] spring forces (DYNAMICS) or their running impulses (ODEINT).  Fs and Ff
+                           may both be NULL for float32 MF_MATH_FAST rigid-body rollouts: states-only kernels that skip
+                           24 N of the 80 + 56 N bytes per step (training consumes only the states, scripts/train.py:243) */
   void* Ff;             /* S[..][force_stride][3] friction forces / impulses */
   void* Xraw;           /* optional S[..][3]: unshifted positions saved for the backward pass; may be NULL */
   const void* joint_angles; /* optional S[B][T][4] flipper angles: each driving part is rotated about the y-axis through

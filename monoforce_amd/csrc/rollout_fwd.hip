@@ -17,7 +17,8 @@ static int fill_args(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutA
   MF_REQUIRE(d->math_mode == MF_MATH_EXACT || d->math_mode == MF_MATH_FAST, MF_ERR_INVALID, "rollout_fwd: unknown math_mode");
   MF_REQUIRE(p->z && p->controls && p->ts && p->points && p->part && p->x0 && p->xd0 && p->R0 && p->w0, MF_ERR_INVALID,
              "rollout_fwd: null input buffer");
-  MF_REQUIRE(p->Xs && p->Xds && p->Rs && p->Omegas && p->Fs && p->Ff, MF_ERR_INVALID, "rollout_fwd: null output buffer");
+  MF_REQUIRE(p->Xs && p->Xds && p->Rs && p->Omegas, MF_ERR_INVALID, "rollout_fwd: null output buffer");
+  MF_REQUIRE((p->Fs != nullptr) == (p->Ff != nullptr), MF_ERR_INVALID, "rollout_fwd: pass both force buffers or neither");
   MF_REQUIRE((long long)d->H * d->W < (1ll << 30), MF_ERR_UNSUPPORTED, "rollout_fwd: grid too large");
   MF_REQUIRE(d->N <= 512, MF_ERR_UNSUPPORTED, "rollout_fwd: more than 512 contact points");
   MF_REQUIRE(d->map_shared || (long long)d->B * d->H * d->W * (long long)sizeof(S) < (1ll << 32), MF_ERR_UNSUPPORTED,
@@ -69,7 +70,15 @@ extern "C" int mf_rollout_fwd_f32(const MfRolloutDesc* d, const MfRolloutFwdBufs
   int rc = mf::fill_args<float>(d, p, &a, &m, &block);
   if (rc != MF_OK) return rc;
   if (p->joint_angles) return mf::launch_rollout_fwd<float, false, true>(a, m, d->integrator, block, (hipStream_t)s);  // exact math
-  if (d->math_mode == MF_MATH_FAST) return mf::launch_rollout_fwd_fast_f32(a, m, d->integrator, block, (hipStream_t)s);
+  const bool forces = p->Fs != nullptr;
+  if (!forces && (d->math_mode != MF_MATH_FAST || p->joint_angles)) {
+    mf::set_error("rollout_fwd: the states-only kernels (Fs = Ff = NULL) exist for float32 MF_MATH_FAST rigid-body rollouts only");
+    return MF_ERR_UNSUPPORTED;
+  }
+  if (d->math_mode == MF_MATH_FAST) {
+    if (!forces && m.PPL == 4 && m.G < 64) m = mf::choose_lane_map(d->B, d->N, 1);
+    return mf::launch_rollout_fwd_fast_f32(a, m, d->integrator, block, forces, (hipStream_t)s);
+  }
   return mf::launch_rollout_fwd<float, false>(a, m, d->integrator, block, (hipStream_t)s);
 }
 
@@ -79,6 +88,7 @@ extern "C" int mf_rollout_fwd_f64(const MfRolloutDesc* d, const MfRolloutFwdBufs
   int block;
   int rc = mf::fill_args<double>(d, p, &a, &m, &block);
   if (rc != MF_OK) return rc;
+  if (!p->Fs) { mf::set_error("rollout_fwd: float64 needs the force buffers"); return MF_ERR_UNSUPPORTED; }
   if (p->joint_angles) return mf::launch_rollout_fwd<double, false, true>(a, m, d->integrator, block, (hipStream_t)s);
   return mf::launch_rollout_fwd<double, false>(a, m, d->integrator, block, (hipStream_t)s);   // float64 is always exact
 }

@@ -3,7 +3,8 @@
 #include "rollout_fwd_kernel.h"
 
 namespace mf {
-int launch_rollout_fwd_fast_f32(const RolloutArgs<float>& a, LaneMap m, int integ, int block, hipStream_t st) {
+int launch_rollout_fwd_fast_f32(const RolloutArgs<float>& a, LaneMap m, int integ, int block, bool forces, hipStream_t st) {
+  if (!forces) return launch_rollout_fwd<float, true, false, false>(a, m, integ, block, st);   // states only
   return launch_rollout_fwd<float, true>(a, m, integ, block, st);
 }
 }  // namespace mf

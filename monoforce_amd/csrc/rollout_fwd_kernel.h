@@ -114,7 +114,7 @@ __device__ __forceinline__ S ld32(const S* base, unsigned elem) {
   return *reinterpret_cast<const S*>(reinterpret_cast<const char*>(base) + (size_t)(elem * (unsigned)sizeof(S)));
 }
 
-template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS = false>
+template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS = false, bool FORCES = true>
 __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a) {
   using M = Mth<S, FAST>;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -208,12 +208,14 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
     pOm[0] = w[0]; pOm[1] = w[1]; pOm[2] = w[2];
 #pragma unroll
     for (int c = 0; c < 9; ++c) pRs[c] = R[c];
+    if (FORCES) {   // compile-time: callers that only consume the states (training) skip 24 N of the 80 + 56 N bytes per step
 #pragma unroll
-    for (int j = 0; j < PPL; ++j)
+      for (int j = 0; j < PPL; ++j)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { pFs[j * 3 + c] = oFs[j][c]; pFf[j * 3 + c] = oFf[j][c]; }
+        for (int c = 0; c < 3; ++c) { pFs[j * 3 + c] = oFs[j][c]; pFf[j * 3 + c] = oFf[j][c]; }
+      pFs += adv * frow; pFf += adv * frow;
+    }
     pXs += adv * 3; pXds += adv * 3; pOm += adv * 3; pRs += adv * 9; pXraw += adv * 3;
-    pFs += adv * frow; pFf += adv * frow;
   };
 
   const int n_steps = (INTEG == MF_INTEG_ODEINT_EULER) ? a.T - 1 : a.T;
@@ -469,27 +471,32 @@ static inline LaneMap choose_lane_map(int B, int N, int points_per_lane) {
   return LaneMap{64, 8};
 }
 
-template <typename S, bool FAST, bool JOINTS = false>
+// Instantiated mappings: one point per lane (G = 4..64) and (64, 2/4/8) always; the 4-points-per-lane mappings with G < 64
+// only for the full-output rigid-body kernels (they are a tuning / test option, see choose_lane_map).
+template <typename S, bool FAST, bool JOINTS = false, bool FORCES = true>
 int launch_rollout_fwd(const RolloutArgs<S>& a, LaneMap m, int integ, int block, hipStream_t st) {
   const long long threads = (long long)a.B * m.G;
   const unsigned grid = (unsigned)((threads + block - 1) / block);
-#define MF_CASE(G_, P_)                                                                                                            \
-  if (m.G == G_ && m.PPL == P_) {                                                                                                   \
-    if (integ == MF_INTEG_DYNAMICS)                                                                                                 \
-      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_DYNAMICS, FAST, JOINTS>), dim3(grid), dim3(block), 0, st, a);       \
-    else                                                                                                                            \
-      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_ODEINT_EULER, FAST, JOINTS>), dim3(grid), dim3(block), 0, st, a);   \
-  } else
-  if (!JOINTS) { MF_CASE(4, 1) MF_CASE(8, 1) MF_CASE(16, 1) MF_CASE(32, 1) MF_CASE(64, 1) MF_CASE(64, 2) {} }
-  MF_CASE(1, 4) MF_CASE(2, 4) MF_CASE(4, 4) MF_CASE(8, 4) MF_CASE(16, 4) MF_CASE(32, 4) MF_CASE(64, 4) MF_CASE(64, 8)
-  if (JOINTS || !(m.PPL < 4)) { set_error("rollout_fwd: no kernel for this lane mapping"); return MF_ERR_UNSUPPORTED; }
+  bool launched = false;
+#define MF_CASE(G_, P_)                                                                                                                   \
+  if (!launched && m.G == G_ && m.PPL == P_) {                                                                                             \
+    launched = true;                                                                                                                       \
+    if (integ == MF_INTEG_DYNAMICS)                                                                                                        \
+      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_DYNAMICS, FAST, JOINTS, FORCES>), dim3(grid), dim3(block), 0, st, a);      \
+    else                                                                                                                                   \
+      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_ODEINT_EULER, FAST, JOINTS, FORCES>), dim3(grid), dim3(block), 0, st, a);  \
+  }
+  if (!JOINTS) { MF_CASE(4, 1) MF_CASE(8, 1) MF_CASE(16, 1) MF_CASE(32, 1) MF_CASE(64, 1) MF_CASE(64, 2) }
+  if (FORCES) { MF_CASE(1, 4) MF_CASE(2, 4) MF_CASE(4, 4) MF_CASE(8, 4) MF_CASE(16, 4) MF_CASE(32, 4) }
+  MF_CASE(64, 4) MF_CASE(64, 8)
 #undef MF_CASE
+  MF_REQUIRE(launched, MF_ERR_UNSUPPORTED, "rollout_fwd: no kernel for this lane mapping");
   hipError_t e = hipGetLastError();
   MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("rollout_fwd launch: ") + hipGetErrorString(e));
   return MF_OK;
 }
 
 // defined in rollout_fwd_fast.hip
-int launch_rollout_fwd_fast_f32(const RolloutArgs<float>& a, LaneMap m, int integ, int block, hipStream_t st);
+int launch_rollout_fwd_fast_f32(const RolloutArgs<float>& a, LaneMap m, int integ, int block, bool forces, hipStream_t st);
 
 }  // namespace mf

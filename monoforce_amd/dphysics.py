@@ -96,7 +96,7 @@ class _RolloutFn(torch.autograd.Function):
     """forward = mf_rollout_fwd_*; backward = mf_rollout_bwd_* (reverse-time adjoint of the same scan)."""
 
     @staticmethod
-    def forward(ctx, mod, z, mu, controls, x0, xd0, R0, w0, ts, want_grad, joint_angles=None):
+    def forward(ctx, mod, z, mu, controls, x0, xd0, R0, w0, ts, want_grad, joint_angles=None, want_forces=True):
         desc, keep = mod._make_desc(z, mu, controls)
         if joint_angles is not None:
             desc.has_joints = 1
@@ -111,7 +111,8 @@ class _RolloutFn(torch.autograd.Function):
         if Np < N:
             raise RuntimeError('mf_rollout_force_stride rejected the descriptor')
         desc.force_stride = Np
-        Xs, Xds, Rs, Om, Fs, Ff = new(3), new(3), new(3, 3), new(3), new(Np, 3), new(Np, 3)
+        Xs, Xds, Rs, Om = new(3), new(3), new(3, 3), new(3)
+        Fs, Ff = (new(Np, 3), new(Np, 3)) if want_forces else (None, None)
         Xraw = new(3) if want_grad else None
         bufs = _lib.MfRolloutFwdBufs(
             z=_lib.ptr(keep['z']), mu=_lib.ptr(keep['mu']), controls=_lib.ptr(controls), ts=_lib.ptr(ts),
@@ -122,9 +123,10 @@ class _RolloutFn(torch.autograd.Function):
         fn = getattr(_lib.lib(), 'mf_rollout_fwd_' + _scalar_suffix(dt))
         with torch.cuda.device(dev), _timing.timed('rollout_fwd_kernel', dev):
             _lib.check(fn(C.byref(desc), C.byref(bufs), _stream_ptr(dev)), 'mf_rollout_fwd')
-        outs = (Xs, Xds, Rs, Om, Fs[..., :N, :], Ff[..., :N, :])
+        outs = (Xs, Xds, Rs, Om) + ((Fs[..., :N, :], Ff[..., :N, :]) if want_forces else ())
         if tm:
             outs = tuple(o.transpose(0, 1) for o in outs)
+        ctx.n_force_outs = 2 if want_forces else 0
         if want_grad:
             ctx.mod, ctx.desc, ctx.keep = mod, desc, keep
             ctx.z_shape, ctx.mu_given = z.shape, mu is not None
@@ -132,16 +134,16 @@ class _RolloutFn(torch.autograd.Function):
         return outs
 
     @staticmethod
-    def backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf):
+    def backward(ctx, gXs, gXds, gRs, gOm, gFs=None, gFf=None):
         from .dphysics_bwd import rollout_backward
-        return rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf) + (None,)
+        return rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf) + (None, None)
 
 
 class DPhysics(torch.nn.Module):
     """Drop-in for the reference `DPhysics` (dphysics.py:144); no parameters, all state is configuration."""
 
     def __init__(self, dphys_cfg=None, device='cpu', contiguous_outputs=False, block=0, snap_to_terrain=True,
-                 points_per_lane=0, precise=False):
+                 points_per_lane=0, precise=False, return_forces=True):
         super().__init__()
         self.dphys_cfg = dphys_cfg if dphys_cfg is not None else DPhysConfig()
         self.device = device
@@ -163,6 +165,9 @@ class DPhysics(torch.nn.Module):
         self.block = block
         self.snap_to_terrain = snap_to_terrain     # False: continue from `state` as is (no reference equivalent)
         self.points_per_lane = points_per_lane     # kernel lane mapping: 0 auto, 1 latency-oriented, 4 throughput-oriented
+        # False: skip the force outputs (forward returns (states, (None, None))): training only consumes the states
+        # (scripts/train.py:243 `states_pred, _ = self.dphysics(...)`); 57 % less output traffic.  float32 fast math only.
+        self.return_forces = return_forces
         self.precise = precise      # True: float32 kernels in the reference's exact op order (IEEE div/sqrt, no FMA); ~1.5x slower
         self._cache = {}
 
@@ -237,6 +242,7 @@ class DPhysics(torch.nn.Module):
         z_grid = z_grid.to(dev)
         _lib.require_hip_tensor(z_grid, 'z_grid')
         dtype = z_grid.dtype
+        _scalar_suffix(dtype)        # float32 / float64 only: anything else is refused here, loudly
         controls = controls.to(device=dev, dtype=dtype)
 
         if state is None:                                                            # (:554-559)
@@ -278,11 +284,13 @@ class DPhysics(torch.nn.Module):
         if ja_dev is not None and want_grad:
             raise NotImplementedError('backward through an articulated rollout (non-zero flipper joint angles) is not '
                                       'implemented: run it under torch.no_grad()')
-        outs = _RolloutFn.apply(self, z_grid, friction, controls.contiguous(), x0, xd0, R0, w0, ts, want_grad, ja_dev)
+        want_forces = self.return_forces or self.precise or dtype != torch.float32 or ja_dev is not None
+        outs = _RolloutFn.apply(self, z_grid, friction, controls.contiguous(), x0, xd0, R0, w0, ts, want_grad, ja_dev, want_forces)
         if not aliased:
             with torch.no_grad():
                 x_in[..., 2] = x0[..., 2].to(device=x_in.device, dtype=x_in.dtype)   # the reference's in-place write
-        Xs, Xds, Rs, Omegas, F_springs, F_frictions = outs
+        Xs, Xds, Rs, Omegas = outs[:4]
+        F_springs, F_frictions = outs[4:] if len(outs) == 6 else (None, None)
         return (Xs, Xds, Rs, Omegas), (F_springs, F_frictions)
 
     def _time_grid(self, n, dtype, dev):

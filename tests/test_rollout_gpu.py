@@ -268,3 +268,32 @@ def test_dtype_device_and_stride_handling():
     # half precision is refused loudly
     with pytest.raises(TypeError):
         dp(z.half().to(DEV), ctrl.to(DEV))
+
+
+@pytest.mark.parametrize('integ', [0, 1])
+def test_states_only_kernels_match_full_output(integ):
+    """`return_forces=False` (training only consumes the states): identical states, no force tensors, gradients unchanged."""
+    from monoforce_amd import synthetic as syn
+    pts, masks = syn.robot_points_4()
+    B, T = 64, 120
+    z = (syn.bump_terrain(syn.bump_params(9), 3.2, 0.1) * 0.3).to(DEV)
+    mu = syn.wave_friction(3.2, 0.1).to(DEV)
+    ctrl = syn.varying_controls(B, T, seed=3).to(DEV)
+    grads = []
+    outs = []
+    for rf in (True, False):
+        dp = make_dphysics(pts, masks, integ, 0.1, 3.2, return_forces=rf)
+        zl = z.clone().requires_grad_(True)
+        states, forces = dp(zl.unsqueeze(0), ctrl, friction=mu.unsqueeze(0))
+        (states[0][:, ::7] ** 2).sum().backward()
+        outs.append((states, forces)); grads.append(zl.grad)
+    assert outs[1][1] == (None, None) and outs[0][1][0].shape == (B, T, 4, 3)
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert torch.equal(a, b)
+    assert hp.rel_err(grads[1].cpu(), grads[0].cpu()) <= 1e-5     # atomics order only
+    # N = 33 (padded lane tile) and float64 / exact mode fall back to the full-output kernels transparently
+    p33, m33 = syn.robot_points_box(33, seed=2, n_tracks=2)
+    st, fo = make_dphysics(p33, m33, integ, 0.1, 3.2, return_forces=False)(z.unsqueeze(0), ctrl)
+    assert fo == (None, None) and torch.isfinite(st[0]).all()
+    st, fo = make_dphysics(pts, masks, integ, 0.1, 3.2, return_forces=False, precise=True)(z.unsqueeze(0), ctrl)
+    assert fo[0] is not None
