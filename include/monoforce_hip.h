@@ -180,6 +180,22 @@ int mf_bev_splat_fwd_f64(const MfSplatDesc* desc, const double* x, const void* w
 int mf_bev_splat_bwd_f32(const MfSplatDesc* desc, const float* gout, const void* workspace, float* gx, void* hip_stream);
 int mf_bev_splat_bwd_f64(const MfSplatDesc* desc, const double* gout, const void* workspace, double* gx, void* hip_stream);
 
+/* ---- fused physics loss (losses.py:102-127) -------------------------------------------------------------------
+ * loss = mean_{b,j,c} ((Xs[b, nearest[b,j], c] - Xgt[b,j,c]) * w[b,j])^2,  w = 1 / (1 + gamma * gt_ts[b,j]).
+ * Xs is addressed as Xs[b*x_stride_b + t*x_stride_t + c] (elements), so both rollout output layouts work in place.
+ * _fwd writes ceil(B*T2/256) per-workgroup partial sums (loss = sum(partial) / (B*T2*3)); _bwd ACCUMULATES d loss/d Xs into gXs (same
+ * strides as Xs, zero it first) given the upstream scalar gradient gloss[0]. */
+typedef struct MfLossDesc {
+  int32_t B, T1, T2;            /* rollouts, predicted steps, ground-truth stamps */
+  int32_t reserved;
+  int64_t x_stride_b, x_stride_t;
+  double gamma;
+} MfLossDesc;
+int mf_physics_loss_fwd_f32(const MfLossDesc* desc, const float* Xs, const float* Xgt, const float* gt_ts, const int32_t* nearest, float* partial, void* hip_stream);
+int mf_physics_loss_fwd_f64(const MfLossDesc* desc, const double* Xs, const double* Xgt, const double* gt_ts, const int32_t* nearest, double* partial, void* hip_stream);
+int mf_physics_loss_bwd_f32(const MfLossDesc* desc, const float* Xs, const float* Xgt, const float* gt_ts, const int32_t* nearest, const float* gloss, float* gXs, void* hip_stream);
+int mf_physics_loss_bwd_f64(const MfLossDesc* desc, const double* Xs, const double* Xgt, const double* gt_ts, const int32_t* nearest, const double* gloss, double* gXs, void* hip_stream);
+
 /* Text of the calling thread's last error ("" if none). */
 const char* mf_last_error(void);
 /* Library version, e.g. "monoforce_hip 0.1 gfx950". */

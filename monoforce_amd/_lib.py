@@ -36,6 +36,11 @@ class MfRolloutBwdBufs(C.Structure):
                                           'gz', 'gmu', 'gcontrols', 'gx0', 'gxd0', 'gR0', 'gw0')]
 
 
+class MfLossDesc(C.Structure):
+    _fields_ = [('B', C.c_int32), ('T1', C.c_int32), ('T2', C.c_int32), ('reserved', C.c_int32),
+                ('x_stride_b', C.c_int64), ('x_stride_t', C.c_int64), ('gamma', C.c_double)]
+
+
 class MfSplatDesc(C.Structure):
     _fields_ = [('B', C.c_int32), ('n_per_sample', C.c_int32), ('C', C.c_int32),
                 ('nx', C.c_int32), ('ny', C.c_int32), ('nz', C.c_int32),
@@ -44,7 +49,8 @@ class MfSplatDesc(C.Structure):
 
 # every symbol include/monoforce_hip.h declares; tests check the library exports all of them
 SYMBOLS = ['mf_rollout_force_stride', 'mf_rollout_fwd_f32', 'mf_rollout_fwd_f64', 'mf_rollout_bwd_f32', 'mf_rollout_bwd_f64', 'mf_bev_splat_workspace_bytes', 'mf_bev_splat_prepare',
-           'mf_bev_splat_fwd_f32', 'mf_bev_splat_fwd_f64', 'mf_bev_splat_bwd_f32', 'mf_bev_splat_bwd_f64', 'mf_last_error', 'mf_version', 'mf_sizeof']
+           'mf_bev_splat_fwd_f32', 'mf_bev_splat_fwd_f64', 'mf_bev_splat_bwd_f32', 'mf_bev_splat_bwd_f64',
+           'mf_physics_loss_fwd_f32', 'mf_physics_loss_fwd_f64', 'mf_physics_loss_bwd_f32', 'mf_physics_loss_bwd_f64', 'mf_last_error', 'mf_version', 'mf_sizeof']
 
 _lib = None
 _lock = threading.Lock()
@@ -68,7 +74,7 @@ def lib():
                 L.mf_version.restype = C.c_char_p
                 for name in SYMBOLS:
                     fn = getattr(L, name)   # AttributeError if the build is stale
-                    if name.startswith(('mf_rollout', 'mf_bev', 'mf_lss')):
+                    if name.startswith(('mf_rollout', 'mf_bev', 'mf_lss', 'mf_physics')):
                         fn.restype = C.c_int
                 L.mf_bev_splat_workspace_bytes.restype = C.c_size_t
                 _lib = L

@@ -16,5 +16,6 @@ extern "C" int mf_sizeof(const char* name) {
   if (!strcmp(name, "MfRolloutFwdBufs")) return (int)sizeof(MfRolloutFwdBufs);
   if (!strcmp(name, "MfRolloutBwdBufs")) return (int)sizeof(MfRolloutBwdBufs);
   if (!strcmp(name, "MfSplatDesc")) return (int)sizeof(MfSplatDesc);
+  if (!strcmp(name, "MfLossDesc")) return (int)sizeof(MfLossDesc);
   return -1;
 }

@@ -1,0 +1,86 @@
+// Fused physics loss: the time-discounted position MSE of
+// /root/reference/monoforce/src/monoforce/losses.py:102-127 as one gather-reduce kernel and one scatter kernel, instead of
+// ~25 small ATen kernels (gather, broadcasts, pow, mean, and an index_put backward that sorts).  The backward writes
+// d loss / d Xs directly in the rollout's own (time-major) layout, so the rollout backward consumes it without a copy.
+//   loss = mean_{b,j,c} ( (Xs[b, nearest[b,j], c] - Xgt[b,j,c]) * w[b,j] )^2,   w = 1 / (1 + gamma * gt_ts[b,j])
+#include "mf_common.h"
+
+namespace mf {
+
+__device__ __forceinline__ void atomic_add_s(float* p, float v) { unsafeAtomicAdd(p, v); }
+__device__ __forceinline__ void atomic_add_s(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+// one thread per (rollout, ground-truth stamp); per-block partial sums in a fixed order => deterministic loss
+template <typename S>
+__global__ void __launch_bounds__(256) physics_loss_fwd_kernel(const S* __restrict__ Xs, long long sb, long long st,
+                                                              const S* __restrict__ Xgt, const S* __restrict__ gt_ts,
+                                                              const int* __restrict__ nearest, int B, int T2, S gamma,
+                                                              S* __restrict__ partial) {
+  __shared__ S wave_sum[4];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;        // = b * T2 + j
+  S acc = (S)0;
+  if (i < B * T2) {
+    const int b = i / T2;
+    const S w = (S)1 / ((S)1 + gamma * gt_ts[i]);
+    const S* x = Xs + b * sb + (long long)nearest[i] * st;
+    const S* g = Xgt + (size_t)i * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { const S d = x[c] * w - g[c] * w; acc += d * d; }   // (pred*w - gt*w)^2, as the reference
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3]);
+}
+
+template <typename S>
+__global__ void __launch_bounds__(256) physics_loss_bwd_kernel(const S* __restrict__ Xs, long long sb, long long st,
+                                                              const S* __restrict__ Xgt, const S* __restrict__ gt_ts,
+                                                              const int* __restrict__ nearest, int B, int T2, S gamma,
+                                                              const S* __restrict__ gloss, S inv_count, S* __restrict__ gXs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * T2) return;
+  const int b = i / T2;
+  const S scale = (S)2 * gloss[0] * inv_count;
+  const S w = (S)1 / ((S)1 + gamma * gt_ts[i]);
+  const long long o = b * sb + (long long)nearest[i] * st;
+  const S* g = Xgt + (size_t)i * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) atomic_add_s(gXs + o + c, scale * w * (Xs[o + c] * w - g[c] * w));   // stamps may share a step
+}
+
+template <typename S>
+static int loss_fwd(const MfLossDesc* d, const S* Xs, const S* Xgt, const S* gt_ts, const int* nearest, S* partial, hipStream_t st) {
+  MF_REQUIRE(d && Xs && Xgt && gt_ts && nearest && partial, MF_ERR_INVALID, "physics_loss_fwd: null argument");
+  MF_REQUIRE(d->B > 0 && d->T1 > 0 && d->T2 > 0, MF_ERR_INVALID, "physics_loss_fwd: B, T1, T2 must be positive");
+  hipLaunchKernelGGL((physics_loss_fwd_kernel<S>), dim3((d->B * d->T2 + 255) / 256), dim3(256), 0, st, Xs, (long long)d->x_stride_b,
+                     (long long)d->x_stride_t, Xgt, gt_ts, nearest, d->B, d->T2, (S)d->gamma, partial);
+  hipError_t e = hipGetLastError();
+  MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("physics_loss_fwd launch: ") + hipGetErrorString(e));
+  return MF_OK;
+}
+
+template <typename S>
+static int loss_bwd(const MfLossDesc* d, const S* Xs, const S* Xgt, const S* gt_ts, const int* nearest, const S* gloss, S* gXs,
+                    hipStream_t st) {
+  MF_REQUIRE(d && Xs && Xgt && gt_ts && nearest && gloss && gXs, MF_ERR_INVALID, "physics_loss_bwd: null argument");
+  MF_REQUIRE(d->B > 0 && d->T1 > 0 && d->T2 > 0, MF_ERR_INVALID, "physics_loss_bwd: B, T1, T2 must be positive");
+  const double count = (double)d->B * d->T2 * 3;
+  hipLaunchKernelGGL((physics_loss_bwd_kernel<S>), dim3((d->B * d->T2 + 255) / 256), dim3(256), 0, st, Xs, (long long)d->x_stride_b,
+                     (long long)d->x_stride_t, Xgt, gt_ts, nearest, d->B, d->T2, (S)d->gamma, gloss, (S)(1.0 / count), gXs);
+  hipError_t e = hipGetLastError();
+  MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("physics_loss_bwd launch: ") + hipGetErrorString(e));
+  return MF_OK;
+}
+
+}  // namespace mf
+
+extern "C" int mf_physics_loss_fwd_f32(const MfLossDesc* d, const float* Xs, const float* Xgt, const float* gt_ts, const int32_t* nearest,
+                                       float* partial, void* s) { return mf::loss_fwd<float>(d, Xs, Xgt, gt_ts, nearest, partial, (hipStream_t)s); }
+extern "C" int mf_physics_loss_fwd_f64(const MfLossDesc* d, const double* Xs, const double* Xgt, const double* gt_ts, const int32_t* nearest,
+                                       double* partial, void* s) { return mf::loss_fwd<double>(d, Xs, Xgt, gt_ts, nearest, partial, (hipStream_t)s); }
+extern "C" int mf_physics_loss_bwd_f32(const MfLossDesc* d, const float* Xs, const float* Xgt, const float* gt_ts, const int32_t* nearest,
+                                       const float* gloss, float* gXs, void* s) { return mf::loss_bwd<float>(d, Xs, Xgt, gt_ts, nearest, gloss, gXs, (hipStream_t)s); }
+extern "C" int mf_physics_loss_bwd_f64(const MfLossDesc* d, const double* Xs, const double* Xgt, const double* gt_ts, const int32_t* nearest,
+                                       const double* gloss, double* gXs, void* s) { return mf::loss_bwd<double>(d, Xs, Xgt, gt_ts, nearest, gloss, gXs, (hipStream_t)s); }

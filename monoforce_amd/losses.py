@@ -4,7 +4,7 @@ tensors are on).  Semantics of `/root/reference/monoforce/src/monoforce/losses.p
 """
 import torch
 
-__all__ = ['nearest_steps', 'physics_loss', 'hm_loss', 'total_variation', 'rotation_difference']
+__all__ = ['nearest_steps', 'physics_loss', 'physics_loss_fused', 'hm_loss', 'total_variation', 'rotation_difference']
 
 
 def total_variation(heightmap):
@@ -61,3 +61,54 @@ def rotation_difference(R1, R2, reduction='mean'):
     if reduction == 'sum':
         return theta2.sum()
     return theta2
+
+
+class _FusedPhysicsLoss(torch.autograd.Function):
+    """`mf_physics_loss_fwd/bwd_*`: one gather-reduce kernel forward, one scatter kernel backward; the gradient comes back
+    with the SAME strides as `X_pred` (for the rollout's time-major outputs: ready for `mf_rollout_bwd_*` without a copy)."""
+
+    @staticmethod
+    def forward(ctx, X_pred, X_gt, gt_ts, nearest, gamma):
+        import ctypes as C
+        from . import _lib, _timing
+        _lib.require_hip_tensor(X_pred, 'X_pred')
+        B, T1, _ = X_pred.shape
+        T2 = X_gt.shape[1]
+        assert X_pred.stride(2) == 1, 'positions must have their xyz components contiguous'
+        sfx = {torch.float32: 'f32', torch.float64: 'f64'}[X_pred.dtype]
+        Xg = X_gt.to(X_pred.dtype).contiguous()
+        ts = gt_ts.to(X_pred.dtype).contiguous()
+        near = nearest if nearest.dtype == torch.int32 else nearest.to(torch.int32)
+        near = near.contiguous()
+        desc = _lib.MfLossDesc(B=B, T1=T1, T2=T2, x_stride_b=X_pred.stride(0), x_stride_t=X_pred.stride(1), gamma=float(gamma))
+        partial = torch.empty((B * T2 + 255) // 256, dtype=X_pred.dtype, device=X_pred.device)
+        stream = C.c_void_p(torch.cuda.current_stream(X_pred.device).cuda_stream)
+        with torch.cuda.device(X_pred.device), _timing.timed('physics_loss_fwd', X_pred.device):
+            _lib.check(getattr(_lib.lib(), 'mf_physics_loss_fwd_' + sfx)(C.byref(desc), _lib.ptr(X_pred), _lib.ptr(Xg), _lib.ptr(ts),
+                                                                         _lib.ptr(near), _lib.ptr(partial), stream), 'mf_physics_loss_fwd')
+        ctx.save_for_backward(X_pred, Xg, ts, near)
+        ctx.desc, ctx.sfx = desc, sfx
+        return partial.sum() / (B * T2 * 3)
+
+    @staticmethod
+    def backward(ctx, gloss):
+        import ctypes as C
+        from . import _lib, _timing
+        X_pred, Xg, ts, near = ctx.saved_tensors
+        gX = torch.zeros_like(X_pred)                     # preserve_format: same (dense) strides as X_pred
+        if gX.stride() != X_pred.stride():
+            gX = torch.empty_strided(X_pred.shape, X_pred.stride(), dtype=X_pred.dtype, device=X_pred.device).zero_()
+        gl = gloss.to(X_pred.dtype).reshape(1).contiguous()
+        stream = C.c_void_p(torch.cuda.current_stream(X_pred.device).cuda_stream)
+        with torch.cuda.device(X_pred.device), _timing.timed('physics_loss_bwd', X_pred.device):
+            _lib.check(getattr(_lib.lib(), 'mf_physics_loss_bwd_' + ctx.sfx)(C.byref(ctx.desc), _lib.ptr(X_pred), _lib.ptr(Xg), _lib.ptr(ts),
+                                                                             _lib.ptr(near), _lib.ptr(gl), _lib.ptr(gX), stream),
+                       'mf_physics_loss_bwd')
+        return gX, None, None, None, None
+
+
+def physics_loss_fused(states_pred, states_gt, pred_ts, gt_ts, gamma=0.9, nearest=None):
+    """`physics_loss` (position term) on the HIP kernels `mf_physics_loss_*`; same value and gradient."""
+    if nearest is None:
+        nearest = nearest_steps(pred_ts, gt_ts)
+    return _FusedPhysicsLoss.apply(states_pred[0], states_gt[0], gt_ts, nearest, gamma)

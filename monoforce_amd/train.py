@@ -4,7 +4,7 @@ the physics) and `scripts/train.py:377-410` (physics loss on predicted terrain),
 import torch
 
 from . import dist as mfdist
-from .losses import nearest_steps, physics_loss
+from .losses import nearest_steps, physics_loss, physics_loss_fused
 
 
 class TerrainFitProblem:
@@ -14,8 +14,9 @@ class TerrainFitProblem:
     The ground truth is a rollout of the same controls on a "true" terrain, generated once with the HIP forward.
     """
 
-    def __init__(self, dphysics, z_true, mu_true, controls, gt_every=10):
+    def __init__(self, dphysics, z_true, mu_true, controls, gt_every=10, fused_loss=True):
         self.dp = dphysics
+        self.fused_loss = fused_loss      # mf_physics_loss_* instead of ~25 small ATen kernels (same value and gradient)
         self.controls = controls
         B, T = controls.shape[:2]
         cfg = dphysics.dphys_cfg
@@ -26,7 +27,7 @@ class TerrainFitProblem:
         sel = torch.arange(gt_every - 1, T, gt_every, device=controls.device)
         self.gt_ts = full_ts[sel].unsqueeze(0).expand(B, -1).contiguous()
         self.states_gt = [Xs[:, sel].contiguous(), Xds[:, sel].contiguous(), Rs[:, sel].contiguous(), Om[:, sel].contiguous()]
-        self.nearest = nearest_steps(self.pred_ts, self.gt_ts)      # time stamps are fixed: computed once
+        self.nearest = nearest_steps(self.pred_ts, self.gt_ts).to(torch.int32)      # time stamps are fixed: computed once
         self.bucket = None
 
     def step(self, z, mu):
@@ -34,8 +35,9 @@ class TerrainFitProblem:
         z.grad = None
         mu.grad = None
         states, _ = self.dp(z.unsqueeze(0), self.controls, friction=mu.unsqueeze(0))
-        loss = physics_loss(states_pred=states, states_gt=self.states_gt, pred_ts=self.pred_ts, gt_ts=self.gt_ts,
-                            nearest=self.nearest)
+        loss_fn = physics_loss_fused if self.fused_loss else physics_loss
+        loss = loss_fn(states, self.states_gt, self.pred_ts, self.gt_ts,
+                       nearest=self.nearest if self.fused_loss else self.nearest.long())
         loss.backward()
         # the one exchange step of the backward: 2 x H x W floats over RCCL
         self.bucket = mfdist.allreduce_sum_([z.grad, mu.grad], self.bucket)
@@ -72,7 +74,7 @@ class EncoderTrainStep:
         x0 = pose0[:, :3, 3].clone()
         state0 = (x0, torch.zeros_like(x0), pose0[:, :3, :3].contiguous(), torch.zeros_like(x0))   # train.py:237-241
         states, _ = self.dp(z_grid=z, controls=controls, state=state0, friction=mu)
-        l_phys = physics_loss(states_pred=states, states_gt=states_gt, pred_ts=pred_ts, gt_ts=gt_ts, nearest=nearest)
+        l_phys = physics_loss_fused(states, states_gt, pred_ts, gt_ts, nearest=nearest)       # losses.py:102-127 on mf_physics_loss_*
         return l_geom, l_terr, l_phys
 
     def step(self, batch):
