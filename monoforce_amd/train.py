@@ -57,6 +57,9 @@ class EncoderTrainStep:
 
     def __init__(self, encoder, dphysics, lr=1e-3, geom_weight=1.0, terrain_weight=1.0, phys_weight=1.0):
         self.enc, self.dp = encoder, dphysics
+        # coarser grid for the physics than for the encoder: average pooling (scripts/train.py:93-99, 233-235)
+        k = max(int(round(dphysics.dphys_cfg.grid_res / float(encoder.dx[0]))), 1)
+        self.terrain_preproc = torch.nn.AvgPool2d(kernel_size=k, stride=k) if k > 1 else torch.nn.Identity()
         self.w = (geom_weight, terrain_weight, phys_weight)
         self.opt = torch.optim.Adam(encoder.parameters(), lr=lr, betas=(0.8, 0.999), weight_decay=1e-7)   # train.py:374-375
         self.params = [p for p in encoder.parameters() if p.requires_grad]
@@ -69,8 +72,8 @@ class EncoderTrainStep:
         l_geom = hm_loss(terrain['geom'], hm_geom[:, 0:1], hm_geom[:, 1:2])                  # train.py:388-392
         l_terr = hm_loss(terrain['terrain'], hm_terrain[:, 0:1], hm_terrain[:, 1:2])         # train.py:395-398
         # one predicted map per sample; B controls per sample share it ([1,H,W] map + [B,T,2] controls)
-        z = terrain['terrain'].squeeze(1)
-        mu = terrain['friction'].squeeze(1)
+        z = self.terrain_preproc(terrain['terrain']).squeeze(1)
+        mu = self.terrain_preproc(terrain['friction']).squeeze(1)
         x0 = pose0[:, :3, 3].clone()
         state0 = (x0, torch.zeros_like(x0), pose0[:, :3, :3].contiguous(), torch.zeros_like(x0))   # train.py:237-241
         states, _ = self.dp(z_grid=z, controls=controls, state=state0, friction=mu)
