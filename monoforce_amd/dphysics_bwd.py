@@ -34,7 +34,8 @@ def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf):
     want_gmu = mu is not None and ctx.needs_input_grad[2]
     if desc.map_shared:
         # private gradient copies: rollout b scatters into copy b % copies, summed below (same-address atomics serialise)
-        copies = max(1, min(GRAD_COPIES, B))
+        # ~64 rollouts per copy (same-address atomics serialise), between GRAD_COPIES and 256 copies
+        copies = max(1, min(max(GRAD_COPIES, B // 64), 256, B))
         desc.grad_copies = copies
         gz = torch.zeros((copies,) + tuple(z.shape), dtype=dt, device=dev)
         gmu = torch.zeros_like(gz) if want_gmu else None
