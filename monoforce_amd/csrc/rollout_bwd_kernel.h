@@ -115,37 +115,58 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
     S gFs[PPL][3], gFf[PPL][3];
   };
   const int n_steps = (INTEG == MF_INTEG_ODEINT_EULER) ? a.T - 1 : a.T;
-  auto out_row_of = [&](int n) { return row0 + (size_t)(INTEG == MF_INTEG_ODEINT_EULER ? n + 1 : n) * row_stride; };
-  auto load_state = [&](int n, StateIn& s) {
+  // Running pointers to the rows of the step being prefetched: stepping them back by wave-uniform deltas replaces a dozen
+  // 64-bit row * stride multiplications per iteration.
+  struct Ptrs {
+    const S *x, *xd, *w, *R, *c, *t, *g1, *g2, *g3, *g4;
+    const S* f1[PPL];
+    const S* f2[PPL];
+  };
+  auto make_ptrs = [&](int m, Ptrs& p) {       // rows of step m: the state it started from, the upstream of the row it produced
+    const size_t in_row = row0 + (size_t)(INTEG == MF_INTEG_ODEINT_EULER ? m : m - 1) * row_stride;   // (m - 1 unused for m = 0)
+    const size_t out_row = row0 + (size_t)(INTEG == MF_INTEG_ODEINT_EULER ? m + 1 : m) * row_stride;
+    p.x = a.Xraw + in_row * 3; p.xd = a.Xds + in_row * 3; p.w = a.Om + in_row * 3; p.R = a.Rs + in_row * 9;
+    p.c = ctrl + (size_t)m * 2; p.t = a.ts + m;
+    p.g1 = a.gXs + out_row * a.sXs; p.g2 = a.gXds + out_row * a.sXds; p.g3 = a.gOm + out_row * a.sOm; p.g4 = a.gRs + out_row * a.sRs;
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) {
+      const size_t pt = out_row * a.N + min(gl * PPL + j, a.N - 1);   // clamped: inactive slots read a valid row, masked at use
+      p.f1[j] = a.gFs + pt * a.sFs; p.f2[j] = a.gFf + pt * a.sFf;
+    }
+  };
+  const size_t d3 = row_stride * 3, d9 = row_stride * 9;
+  const size_t dg1 = row_stride * a.sXs, dg2 = row_stride * a.sXds, dg3 = row_stride * a.sOm, dg4 = row_stride * a.sRs;
+  const size_t df1 = row_stride * a.N * a.sFs, df2 = row_stride * a.N * a.sFf;
+  auto step_back = [&](Ptrs& p, size_t k) {    // k = 1: one step earlier; k = 0: stay (the prefetch of step 0 repeats itself)
+    p.x -= k * d3; p.xd -= k * d3; p.w -= k * d3; p.R -= k * d9; p.c -= k * 2; p.t -= k;
+    p.g1 -= k * dg1; p.g2 -= k * dg2; p.g3 -= k * dg3; p.g4 -= k * dg4;
+#pragma unroll
+    for (int j = 0; j < PPL; ++j) { p.f1[j] -= k * df1; p.f2[j] -= k * df2; }
+  };
+  auto load_state = [&](const Ptrs& p, int m, StateIn& s) {
     // DYNAMICS step 0 starts from the initial state, every other step from a saved row: pointer selects, no branch
-    const bool init = (INTEG == MF_INTEG_DYNAMICS) && n == 0;
-    const size_t in_row = row0 + (size_t)(INTEG == MF_INTEG_ODEINT_EULER ? n : max(n - 1, 0)) * row_stride;
-    const S* sx = init ? a.x_init + b * 3 : a.Xraw + in_row * 3;
-    const S* sxd = init ? a.xd0 + b * 3 : a.Xds + in_row * 3;
-    const S* sw = init ? a.w0 + b * 3 : a.Om + in_row * 3;
-    const S* sR = init ? a.R0 + b * 9 : a.Rs + in_row * 9;
+    const bool init = (INTEG == MF_INTEG_DYNAMICS) && m == 0;
+    const S* sx = init ? a.x_init + b * 3 : p.x;
+    const S* sxd = init ? a.xd0 + b * 3 : p.xd;
+    const S* sw = init ? a.w0 + b * 3 : p.w;
+    const S* sR = init ? a.R0 + b * 9 : p.R;
 #pragma unroll
     for (int c = 0; c < 3; ++c) { s.x[c] = sx[c]; s.xd[c] = sxd[c]; s.w[c] = sw[c]; }
 #pragma unroll
     for (int c = 0; c < 9; ++c) s.R[c] = sR[c];
-    s.cv = ctrl[n * 2 + 0]; s.cw = ctrl[n * 2 + 1];
-    s.t0 = a.ts[n]; s.t1 = a.ts[min(n + 1, a.T - 1)];
+    s.cv = p.c[0]; s.cw = p.c[1];
+    s.t0 = p.t[0]; s.t1 = p.t[m + 1 < a.T ? 1 : 0];
   };
-  auto load_upstream = [&](size_t row, UpIn& u) {
+  auto load_upstream = [&](const Ptrs& p, UpIn& u) {
     // absent upstream gradients point at a zero row with stride 0 (host side), so these loads are unconditional
-    const S* g1 = a.gXs + row * a.sXs; const S* g2 = a.gXds + row * a.sXds; const S* g3 = a.gOm + row * a.sOm;
-    const S* g4 = a.gRs + row * a.sRs;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { u.gXs[c] = g1[c]; u.gXds[c] = g2[c]; u.gOm[c] = g3[c]; }
+    for (int c = 0; c < 3; ++c) { u.gXs[c] = p.g1[c]; u.gXds[c] = p.g2[c]; u.gOm[c] = p.g3[c]; }
 #pragma unroll
-    for (int c = 0; c < 9; ++c) u.gRs[c] = g4[c];
+    for (int c = 0; c < 9; ++c) u.gRs[c] = p.g4[c];
 #pragma unroll
-    for (int j = 0; j < PPL; ++j) {
-      const size_t pt = row * a.N + min(gl * PPL + j, a.N - 1);   // clamped: inactive slots read a valid row, masked below
-      const S* f1 = a.gFs + pt * a.sFs; const S* f2 = a.gFf + pt * a.sFf;
+    for (int j = 0; j < PPL; ++j)
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { u.gFs[j][c] = f1[c]; u.gFf[j][c] = f2[c]; }   // masked by act[] where they are consumed
-    }
+      for (int c = 0; c < 3; ++c) { u.gFs[j][c] = p.f1[j][c]; u.gFf[j][c] = p.f2[j][c]; }   // masked by act[] where they are consumed
   };
   auto add_upstream_state = [&](const UpIn& u) {
     lx[0] += u.gXs[0]; lx[1] += u.gXs[1]; lx[2] += u.gXs[2];
@@ -192,8 +213,10 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
 
   StateIn cur;
   UpIn up;
-  load_state(max(n_steps - 1, 0), cur);
-  load_upstream(out_row_of(max(n_steps - 1, 0)), up);
+  Ptrs rp;
+  make_ptrs(max(n_steps - 1, 0), rp);
+  load_state(rp, max(n_steps - 1, 0), cur);
+  load_upstream(rp, up);
   for (int n = n_steps - 1; n >= 0; --n) {
     add_upstream_state(up);
     S x[3], xd[3], R[9], w[3];
@@ -230,9 +253,10 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
       }
     }
     StateIn nxt;
-    load_state(max(n - 1, 0), nxt);      // prefetch (step 0 harmlessly reloads itself); younger than the gathers above
+    step_back(rp, n > 0 ? 1 : 0);
+    load_state(rp, max(n - 1, 0), nxt);      // prefetch (step 0 harmlessly reloads itself); younger than the gathers above
     UpIn up_next;
-    load_upstream(out_row_of(max(n - 1, 0)), up_next);
+    load_upstream(rp, up_next);
     // The map-gradient atomics of the PREVIOUS iteration are issued here, after this step's loads: nothing this
     // iteration waits for is younger than them, and by the next iteration's loads they have long completed.
     flush_stash();
@@ -561,7 +585,8 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
   }
 
   if (INTEG == MF_INTEG_ODEINT_EULER) {   // output 0 is the initial state itself (its forces are constant zeros)
-    load_upstream(row0, up);
+    make_ptrs(-1, rp);              // ODEINT: the output row of "step -1" is row 0
+    load_upstream(rp, up);
     add_upstream_state(up);
   }
 

@@ -303,6 +303,23 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
     if (M::kReciprocalNorm) { e0 = R[0] * il; e1 = R[3] * il; e2 = R[6] * il; }
     else { const S el = mf_max(M::sqrt(R[0] * R[0] + R[3] * R[3] + R[6] * R[6]), (S)1e-6); e0 = R[0] / el; e1 = R[3] / el; e2 = R[6] / el; }
     const S tv_lo = cv - cw * a.half_ly, tv_hi = cv + cw * a.half_ly;  // (:75-104)
+    // The explicit scheme moves x with the OLD xd and R with the OLD w: neither depends on this step's forces, so that half
+    // of the update is done here, under the latency of the gathers (x, R are not read again below; r, pz, e are taken).
+    S h_ode = (S)0;
+    if (INTEG == MF_INTEG_ODEINT_EULER) {
+      h_ode = a.ts[n + 1] - a.ts[n];
+      S dR[9];
+#pragma unroll
+      for (int j2 = 0; j2 < 3; ++j2) {
+        dR[0 * 3 + j2] = w[1] * R[2 * 3 + j2] - w[2] * R[1 * 3 + j2];
+        dR[1 * 3 + j2] = w[2] * R[0 * 3 + j2] - w[0] * R[2 * 3 + j2];
+        dR[2 * 3 + j2] = w[0] * R[1 * 3 + j2] - w[1] * R[0 * 3 + j2];
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) x[c] = x[c] + h_ode * xd[c];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) R[c] = R[c] + h_ode * dR[c];
+    }
 
     // ---- contact model ----
     S nrm[PPL][3], muq[PPL], cw8[PPL], Fr[PPL][3];
@@ -421,22 +438,12 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
         for (int c = 0; c < 3; ++c) { oFs[j][c] = Fr[j][c]; oFf[j][c] = Ff[j][c]; }  // true forces of this step
     } else {
       // torchdiffeq fixed-grid euler: y_{n+1} = y_n + (t_{n+1} - t_n) f(t_n, y_n), f = (xd, xdd, [w]x R, wd, Fs, Ff)
-      const S h = a.ts[n + 1] - a.ts[n];
-      S dR[9];
-#pragma unroll
-      for (int j2 = 0; j2 < 3; ++j2) {
-        dR[0 * 3 + j2] = w[1] * R[2 * 3 + j2] - w[2] * R[1 * 3 + j2];
-        dR[1 * 3 + j2] = w[2] * R[0 * 3 + j2] - w[0] * R[2 * 3 + j2];
-        dR[2 * 3 + j2] = w[0] * R[1 * 3 + j2] - w[1] * R[0 * 3 + j2];
-      }
+      const S h = h_ode;          // x and R were advanced above; the force-dependent half follows
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        x[c] = x[c] + h * xd[c];  // OLD xd moves x
         xd[c] = xd[c] + h * xdd[c];
         w[c] = w[c] + h * wd[c];
       }
-#pragma unroll
-      for (int c = 0; c < 9; ++c) R[c] = R[c] + h * dR[c];
 #pragma unroll
       for (int j = 0; j < PPL; ++j)
 #pragma unroll
