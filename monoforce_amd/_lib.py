@@ -69,7 +69,7 @@ def lib():
                 # torch bundles its own libamdhip64.so.7; import it FIRST so this library binds to the same HIP runtime
                 # instance (loading /opt/rocm's copy first leaves the process with two runtimes and no device).
                 import torch  # noqa: F401
-                L = C.CDLL(LIB_PATH)
+                L = C.CDLL(os.environ.get('MONOFORCE_HIP_LIB', LIB_PATH))   # override: A/B builds of the kernels (tools/)
                 L.mf_last_error.restype = C.c_char_p
                 L.mf_version.restype = C.c_char_p
                 for name in SYMBOLS:

@@ -14,13 +14,33 @@ struct Cell {
   S fx, fy;
 };
 
+// The four bilinear weights, each one product rounded on its own (also in the FMA-contracted kernels: contraction would turn
+// (1 - fx) * y into fma(-fx, y, y) and make a map of ones blend differently from the weights' own sum).
+// NB: the x-fraction weights the +y ("left") neighbour and vice versa (dphysics.py:442-445).
 template <typename S>
-__device__ __forceinline__ S blend(const Cell<S>& c, S vc, S vf, S vl, S vfl) {
-  // NB: the x-fraction weights the +y ("left") neighbour and vice versa (dphysics.py:442-445).
+struct BlendW { S w00, w01, w10, w11; };
+template <typename S>
+__device__ __forceinline__ BlendW<S> blend_weights(const Cell<S>& c) {
+#pragma clang fp contract(off)
   const S one = (S)1;
-  return (one - c.fx) * (one - c.fy) * vc + (one - c.fx) * c.fy * vf + c.fx * (one - c.fy) * vl + c.fx * c.fy * vfl;
+  BlendW<S> w;
+  w.w00 = (one - c.fx) * (one - c.fy); w.w01 = (one - c.fx) * c.fy; w.w10 = c.fx * (one - c.fy); w.w11 = c.fx * c.fy;
+  return w;
 }
 
+template <typename S>
+__device__ __forceinline__ S blend(const Cell<S>& c, S vc, S vf, S vl, S vfl) {
+  const BlendW<S> w = blend_weights(c);
+  return w.w00 * vc + w.w01 * vf + w.w10 * vl + w.w11 * vfl;
+}
+
+// blend() of a map of ones (no friction map = cfg.friction = ones, dphysics.py:141,562): the sum of the weights in blend()'s
+// order, bit-identical to blend(c, 1, 1, 1, 1) with or without contraction.
+template <typename S>
+__device__ __forceinline__ S blend_ones(const Cell<S>& c) {
+  const BlendW<S> w = blend_weights(c);
+  return ((w.w00 + w.w01) + w.w10) + w.w11;
+}
 
 // d(blend)/d(fx), d(blend)/d(fy): the only way a query position influences a sampled value (indices are constants).
 template <typename S>

@@ -20,6 +20,7 @@ static int fill_args(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutA
   MF_REQUIRE(p->Xs && p->Xds && p->Rs && p->Omegas, MF_ERR_INVALID, "rollout_fwd: null output buffer");
   MF_REQUIRE((p->Fs != nullptr) == (p->Ff != nullptr), MF_ERR_INVALID, "rollout_fwd: pass both force buffers or neither");
   MF_REQUIRE((long long)d->H * d->W < (1ll << 30), MF_ERR_UNSUPPORTED, "rollout_fwd: grid too large");
+  MF_REQUIRE(d->H < (1 << 23), MF_ERR_UNSUPPORTED, "rollout_fwd: grid too large (H must be below 2^23)");
   MF_REQUIRE(d->N <= 512, MF_ERR_UNSUPPORTED, "rollout_fwd: more than 512 contact points");
   MF_REQUIRE(d->map_shared || (long long)d->B * d->H * d->W * (long long)sizeof(S) < (1ll << 32), MF_ERR_UNSUPPORTED,
              "rollout_fwd: per-rollout maps of 4 GiB or more in total (use a shared map or split the batch)");

@@ -99,7 +99,7 @@ __device__ __forceinline__ Cell<S> locate_m(S qx, S qy, S d_max, S res, S inv_re
   Cell<S> c;
   c.fx = ux - (S)ix;
   c.fy = uy - (S)iy;
-  int base = iy + H * ix;
+  int base = iy + __mul24(H, ix);   // |ix| <= 2^18 and H < 2^23 (host-checked): the 24-bit multiply is exact, one v_mad_i32_i24
   c.ic = min(max(base, 0), last);
   c.i_f = min(max(base + H, 0), last);
   c.il = min(max(base + 1, 0), last);
@@ -199,30 +199,46 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
 
   // Stores of the pending output row (the state registers ARE that row).  Every lane of the group stores the same state
   // values to the same addresses (no exec-mask branch on the issue stream; the coalescer merges them) and its own forces.
+  // (Splitting the 21 state floats over the lanes of the group -- 2 stores instead of 7 -- was measured: same store
+  // bandwidth, more selects; tools/microbench/store_patterns.hip.)
   auto emit_row = [&](size_t adv) {
-    pXraw[0] = x[0]; pXraw[1] = x[1]; pXraw[2] = x[2];
-    pXs[0] = x[0] + R[2] * a.sink;  // Xs += Rs[..., :, 2] * m g / (k + 1e-6)   (dphysics.py:587-589)
-    pXs[1] = x[1] + R[5] * a.sink;
-    pXs[2] = x[2] + R[8] * a.sink;
-    pXds[0] = xd[0]; pXds[1] = xd[1]; pXds[2] = xd[2];
-    pOm[0] = w[0]; pOm[1] = w[1]; pOm[2] = w[2];
+#ifdef MF_DBG_NOSTORE   // A/B hook (tools/ab_rollout.py): time the kernel without its output stream
+    if (a.B > 0) return;
+#endif
+    // streaming (non-temporal) stores: the rows are never read again by this kernel and must not evict the map cells the
+    // gathers keep hitting in L1 / L2
+    auto st = [](S* p, S v) { __builtin_nontemporal_store(v, p); };
+    st(pXraw + 0, x[0]); st(pXraw + 1, x[1]); st(pXraw + 2, x[2]);
+    st(pXs + 0, x[0] + R[2] * a.sink);  // Xs += Rs[..., :, 2] * m g / (k + 1e-6)   (dphysics.py:587-589)
+    st(pXs + 1, x[1] + R[5] * a.sink);
+    st(pXs + 2, x[2] + R[8] * a.sink);
+    st(pXds + 0, xd[0]); st(pXds + 1, xd[1]); st(pXds + 2, xd[2]);
+    st(pOm + 0, w[0]); st(pOm + 1, w[1]); st(pOm + 2, w[2]);
 #pragma unroll
-    for (int c = 0; c < 9; ++c) pRs[c] = R[c];
+    for (int c = 0; c < 9; ++c) st(pRs + c, R[c]);
+    pXs += adv * 3; pXds += adv * 3; pOm += adv * 3; pRs += adv * 9; pXraw += adv * 3;
     if (FORCES) {   // compile-time: callers that only consume the states (training) skip 24 N of the 80 + 56 N bytes per step
 #pragma unroll
       for (int j = 0; j < PPL; ++j)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { pFs[j * 3 + c] = oFs[j][c]; pFf[j * 3 + c] = oFf[j][c]; }
+        for (int c = 0; c < 3; ++c) st(pFs + j * 3 + c, oFs[j][c]);
+#pragma unroll
+      for (int j = 0; j < PPL; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) st(pFf + j * 3 + c, oFf[j][c]);
       pFs += adv * frow; pFf += adv * frow;
     }
-    pXs += adv * 3; pXds += adv * 3; pOm += adv * 3; pRs += adv * 9; pXraw += adv * 3;
   };
 
   const int n_steps = (INTEG == MF_INTEG_ODEINT_EULER) ? a.T - 1 : a.T;
 
   const S* ctrl = a.controls + (size_t)b * a.T * 2;
   S cv = ctrl[0], cw = ctrl[1];
+  S h_ode = (INTEG == MF_INTEG_ODEINT_EULER && a.T > 1) ? a.ts[1] - a.ts[0] : zero;   // step size of the current step
 
+  // everything loaded so far is complete before the loop: otherwise the waits inside it also have to cover these loads, and a
+  // conservative in-loop wait is a wait for the previous step's stores
+  __builtin_amdgcn_s_waitcnt(0);
   for (int n = 0; n < n_steps; ++n) {
     if (JOINTS) {
       // update_joints (dphysics.py:326-358): rotate every driving part about the y-axis through its joint, then the
@@ -275,14 +291,17 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
       zc[j][0] = ld32(zmap, moff + (unsigned)c.ic); zc[j][1] = ld32(zmap, moff + (unsigned)c.i_f); zc[j][2] = ld32(zmap, moff + (unsigned)c.il); zc[j][3] = ld32(zmap, moff + (unsigned)c.ifl);
     }
 #pragma unroll
-    for (int j = 0; j < PPL; ++j) {   // unconditional (mumap aliases z without a friction map) + uniform select: no branch
+    for (int j = 0; j < PPL; ++j) {   // unconditional (mumap aliases z without a friction map; selected after the blend): no branch
       const Cell<S>& c = cell[j];
-      S m0 = ld32(mumap, moff + (unsigned)c.ic), m1 = ld32(mumap, moff + (unsigned)c.i_f), m2 = ld32(mumap, moff + (unsigned)c.il), m3 = ld32(mumap, moff + (unsigned)c.ifl);
-      mc[j][0] = has_mu ? m0 : one; mc[j][1] = has_mu ? m1 : one; mc[j][2] = has_mu ? m2 : one; mc[j][3] = has_mu ? m3 : one;
+      mc[j][0] = ld32(mumap, moff + (unsigned)c.ic); mc[j][1] = ld32(mumap, moff + (unsigned)c.i_f); mc[j][2] = ld32(mumap, moff + (unsigned)c.il); mc[j][3] = ld32(mumap, moff + (unsigned)c.ifl);
     }
     // next step's controls (the lookup argmin|t - ts| is the step index on the grid, dphysics.py:183)
     const int nn = min(n + 1, a.T - 1);
     const S cv_next = ctrl[nn * 2 + 0], cw_next = ctrl[nn * 2 + 1];
+    // ... and its step size h = ts[n+2] - ts[n+1] (torchdiffeq's fixed grid): loaded HERE, before the stores below -- a load
+    // issued after them would make its wait (vmcnt is in-order) a wait for this step's stores as well
+    S ts_a = zero, ts_b = zero;
+    if (INTEG == MF_INTEG_ODEINT_EULER) { ts_a = a.ts[nn]; ts_b = a.ts[min(n + 2, a.T - 1)]; }
 
     // ---- stores of the previous step's row: younger than the gathers above ----
     // DYNAMICS has nothing pending at n = 0: it writes the initial state into row 0 without advancing, and the real row 0
@@ -305,9 +324,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
     const S tv_lo = cv - cw * a.half_ly, tv_hi = cv + cw * a.half_ly;  // (:75-104)
     // The explicit scheme moves x with the OLD xd and R with the OLD w: neither depends on this step's forces, so that half
     // of the update is done here, under the latency of the gathers (x, R are not read again below; r, pz, e are taken).
-    S h_ode = (S)0;
     if (INTEG == MF_INTEG_ODEINT_EULER) {
-      h_ode = a.ts[n + 1] - a.ts[n];
       S dR[9];
 #pragma unroll
       for (int j2 = 0; j2 < 3; ++j2) {
@@ -328,7 +345,8 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
     for (int j = 0; j < PPL; ++j) {
       const Cell<S>& c = cell[j];
       S zq = blend(c, zc[j][0], zc[j][1], zc[j][2], zc[j][3]);  // height, normal, friction under the point (:211-216)
-      muq[j] = blend(c, mc[j][0], mc[j][1], mc[j][2], mc[j][3]);
+      // no friction map = a map of ones (dphysics.py:562): its blend is the (rounded) sum of the four weights, no loads involved
+      muq[j] = has_mu ? blend(c, mc[j][0], mc[j][1], mc[j][2], mc[j][3]) : blend_ones(c);
       S gx = M::div(zc[j][1] - zc[j][0], a.res), gy = M::div(zc[j][2] - zc[j][0], a.res);
       if (M::kReciprocalNorm) {
         const S inl = M::inv_len(gx * gx + gy * gy + one);
@@ -453,6 +471,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
         }
     }
     cv = cv_next; cw = cw_next;
+    h_ode = ts_b - ts_a;
   }
   if (n_steps > 0 || INTEG == MF_INTEG_ODEINT_EULER) emit_row(row_stride);
 }
