@@ -211,12 +211,17 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
     }
   };
 
+  // control gradient of the previous iteration, stored one iteration late; before the first one it rewrites the last row with
+  // zeros (ODEINT: that row IS zero; DYNAMICS: the first iteration's own result overwrites it, same lanes, program order)
+  S* gctrl_pending = gctrl + (size_t)(a.T - 1) * 2;
+  S gv_pending = zero, gwc_pending = zero;
   StateIn cur;
   UpIn up;
   Ptrs rp;
   make_ptrs(max(n_steps - 1, 0), rp);
   load_state(rp, max(n_steps - 1, 0), cur);
   load_upstream(rp, up);
+  __builtin_amdgcn_s_waitcnt(0);   // nothing loaded before the loop is still in flight when the in-loop waits are counted
   for (int n = n_steps - 1; n >= 0; --n) {
     add_upstream_state(up);
     S x[3], xd[3], R[9], w[3];
@@ -246,25 +251,26 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
       cell[j] = locate_m<S, FAST>(px, py, a.d_max, a.res, a.inv_res, a.H, last);
       const Cell<S>& c = cell[j];
       zc4[j][0] = ld32(zmap, moff + (unsigned)c.ic); zc4[j][1] = ld32(zmap, moff + (unsigned)c.i_f); zc4[j][2] = ld32(zmap, moff + (unsigned)c.il); zc4[j][3] = ld32(zmap, moff + (unsigned)c.ifl);
-      // unconditional (mumap aliases z when there is no friction map), then a uniform select: keeps the loop one basic block
-      {
-        S m0 = ld32(mumap, moff + (unsigned)c.ic), m1 = ld32(mumap, moff + (unsigned)c.i_f), m2 = ld32(mumap, moff + (unsigned)c.il), m3 = ld32(mumap, moff + (unsigned)c.ifl);
-        mc4[j][0] = has_mu ? m0 : one; mc4[j][1] = has_mu ? m1 : one; mc4[j][2] = has_mu ? m2 : one; mc4[j][3] = has_mu ? m3 : one;
-      }
+      // unconditional (mumap aliases z when there is no friction map; the select follows the blend): one basic block, and
+      // no consumer of the gathers ahead of the loads and atomics issued below
+      mc4[j][0] = ld32(mumap, moff + (unsigned)c.ic); mc4[j][1] = ld32(mumap, moff + (unsigned)c.i_f); mc4[j][2] = ld32(mumap, moff + (unsigned)c.il); mc4[j][3] = ld32(mumap, moff + (unsigned)c.ifl);
     }
+    // Issue order of a step's memory operations (vmcnt retires loads, stores and atomics in order, so a wait for a load is
+    // a wait for everything issued before it): gathers of this step | map-gradient atomics and control-gradient store
+    // deferred from the PREVIOUS step | prefetch of the next step's rows.  Nothing is younger than the prefetch, so the
+    // wait for it at the top of the next iteration is not also a wait for a store issued a few instructions earlier.
+    flush_stash();
+    gctrl_pending[0] = gv_pending; gctrl_pending[1] = gwc_pending;   // every lane of the group, same values
     StateIn nxt;
     step_back(rp, n > 0 ? 1 : 0);
     load_state(rp, max(n - 1, 0), nxt);      // prefetch (step 0 harmlessly reloads itself); younger than the gathers above
     UpIn up_next;
     load_upstream(rp, up_next);
-    // The map-gradient atomics of the PREVIOUS iteration are issued here, after this step's loads: nothing this
-    // iteration waits for is younger than them, and by the next iteration's loads they have long completed.
-    flush_stash();
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
       const Cell<S>& c = cell[j];
       S zq = blend(c, zc4[j][0], zc4[j][1], zc4[j][2], zc4[j][3]);
-      muq[j] = blend(c, mc4[j][0], mc4[j][1], mc4[j][2], mc4[j][3]);
+      muq[j] = has_mu ? blend(c, mc4[j][0], mc4[j][1], mc4[j][2], mc4[j][3]) : blend_ones(c);
       S gx = M::div(zc4[j][1] - zc4[j][0], a.res), gy = M::div(zc4[j][2] - zc4[j][0], a.res);
       nl[j] = mf_max(M::sqrt(gx * gx + gy * gy + one), (S)1e-6);
       nrm[j][0] = M::div(-gx, nl[j]); nrm[j][1] = M::div(-gy, nl[j]); nrm[j][2] = M::div(one, nl[j]);
@@ -531,7 +537,12 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
         }
         S zfx, zfy, mfx, mfy;
         blend_grad(c, zc4[j][0], zc4[j][1], zc4[j][2], zc4[j][3], &zfx, &zfy);
-        blend_grad(c, mc4[j][0], mc4[j][1], mc4[j][2], mc4[j][3], &mfx, &mfy);
+        {
+          S ofx, ofy;                     // a map of ones without a friction map (its blend still moves with fx, fy by rounding)
+          blend_grad(c, mc4[j][0], mc4[j][1], mc4[j][2], mc4[j][3], &mfx, &mfy);
+          blend_grad(c, one, one, one, one, &ofx, &ofy);
+          mfx = has_mu ? mfx : ofx; mfy = has_mu ? mfy : ofy;
+        }
         S gp[3] = {M::div(gzq * zfx + gmuq[j] * mfx, a.res), M::div(gzq * zfy + gmuq[j] * mfy, a.res), gdh};
         // v_p = xd + w x r
         S t1[3], t2[3];
@@ -567,11 +578,12 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
       lR[3] += M::div(ge[1] - dote * e[1], el);
       lR[6] += M::div(ge[2] - dote * e[2], el);
     }
-    gctrl[n * 2 + 0] = gv; gctrl[n * 2 + 1] = gwc;   // every lane of the group, same values
+    gctrl_pending = gctrl + n * 2; gv_pending = gv; gwc_pending = gwc;   // stored by the next iteration (or after the loop)
     cur = nxt;
     up = up_next;
   }
   flush_stash();
+  gctrl_pending[0] = gv_pending; gctrl_pending[1] = gwc_pending;
 #pragma unroll
   for (int j = 0; j < PPL; ++j) {          // what is still accumulated in registers
     if (act[j]) {
