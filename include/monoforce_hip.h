@@ -150,6 +150,8 @@ typedef struct MfRolloutBwdBufs {
   void* gxd0;           /* out: S[B][3] */
   void* gR0;            /* out: S[B][3][3] */
   void* gw0;            /* out: S[B][3] */
+  const void* joint_angles; /* the forward's S[B][T][4] flipper angles (desc->has_joints), else NULL.  They are constants of the
+                           rollout: no gradient is produced for them (the reference's datasets feed measured angles) */
 } MfRolloutBwdBufs;
 
 int mf_rollout_bwd_f32(const MfRolloutDesc* desc, const MfRolloutBwdBufs* bufs, void* hip_stream);

@@ -33,6 +33,10 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
   a.half_ly = (S)(d->robot_size_y / 2.0);
   a.sink = (S)(d->mass * d->gravity / (d->stiffness + 1e-6));
   for (int i = 0; i < 9; ++i) a.Iinv[i] = (S)d->Iinv[i];
+  for (int i = 0; i < 12; ++i) a.joint_xyz[i] = (S)d->joint_xyz[i];
+  a.joint_angles = (const S*)p->joint_angles;
+  MF_REQUIRE(!d->has_joints == !p->joint_angles, MF_ERR_INVALID, "rollout_bwd: joint_angles must be given exactly when desc->has_joints is set");
+  MF_REQUIRE(!p->joint_angles || d->n_tracks == 4, MF_ERR_INVALID, "rollout_bwd: joint angles need the 4 driving parts of robot 'marv'");
   a.z = (const S*)p->z; a.mu = (const S*)p->mu; a.controls = (const S*)p->controls; a.ts = (const S*)p->ts;
   a.points = (const S*)p->points; a.part = p->part;
   a.x_init = (const S*)p->x_init; a.xd0 = (const S*)p->xd0; a.R0 = (const S*)p->R0; a.w0 = (const S*)p->w0;
@@ -51,6 +55,12 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
   a.gx0 = (S*)p->gx0; a.gxd0 = (S*)p->gxd0; a.gR0 = (S*)p->gR0; a.gw0 = (S*)p->gw0;
 
   hipStream_t st = (hipStream_t)stream;
+  if (p->joint_angles) {   // articulated body: exact arithmetic, default lane mappings (the backward recomputes every step, so it
+                           // need not mirror the forward's mapping)
+    const LaneMap mj = choose_lane_map(d->B, d->N, 0);
+    if (sizeof(S) == 4) return launch_rollout_bwd_joints_f32(*reinterpret_cast<const RolloutBwdArgs<float>*>(&a), mj, d->integrator, block, st);
+    return launch_rollout_bwd_joints_f64(*reinterpret_cast<const RolloutBwdArgs<double>*>(&a), mj, d->integrator, block, st);
+  }
   const LaneMap m = choose_lane_map(d->B, d->N, d->points_per_lane);   // the forward's mapping (same rule, same descriptor)
   if (sizeof(S) == 4 && d->math_mode == MF_MATH_FAST)
     return launch_rollout_bwd_fast_f32(*reinterpret_cast<const RolloutBwdArgs<float>*>(&a), m, d->integrator, block, st);

@@ -27,6 +27,8 @@ struct RolloutBwdArgs {
   const S *gXs, *gXds, *gRs, *gOm, *gFs, *gFf;   // never NULL here: the host substitutes `zeros` with a zero stride
   int sXs, sXds, sRs, sOm, sFs, sFf;              // floats per row element group: 3 / 9 (present) or 0 (absent -> zeros)
   S *gz, *gmu, *gcontrols, *gx0, *gxd0, *gR0, *gw0;
+  const S* joint_angles;   // [B,T,4] flipper angles (constants of the rollout: no gradient), or NULL
+  S joint_xyz[12];
 };
 
 #ifdef MF_NO_ATOMICS
@@ -50,7 +52,7 @@ __device__ __forceinline__ S* at32(S* base, unsigned elem) {
     (o)[2] = (a)[0] * (b)[1] - (a)[1] * (b)[0]; \
   } while (0)
 
-template <typename S, int G, int PPL, int INTEG, bool FAST>
+template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS = false>
 __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S> a) {
   using M = Mth<S, FAST>;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -70,7 +72,9 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
   const bool want_gmu = a.gmu != nullptr && has_mu;  // wave-uniform
   S* gmumap = want_gmu ? a.gmu : a.gz;
 
-  S P[PPL][3];
+  S P[PPL][3];    // contact points used by the step (articulated per step when JOINTS)
+  S P0[PPL][3];   // rest configuration (cfg.robot_points): the terrain snap and the articulation start from it
+  S Iv[9];        // inverse inertia used by the step
   int part[PPL];
   bool act[PPL];
 #pragma unroll
@@ -78,11 +82,13 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
     int i = gl * PPL + j;       // blocked, as in the forward
     act[j] = i < a.N;
     int ii = act[j] ? i : 0;
-    P[j][0] = a.points[ii * 3 + 0];
-    P[j][1] = a.points[ii * 3 + 1];
-    P[j][2] = a.points[ii * 3 + 2];
+    P[j][0] = P0[j][0] = a.points[ii * 3 + 0];
+    P[j][1] = P0[j][1] = a.points[ii * 3 + 1];
+    P[j][2] = P0[j][2] = a.points[ii * 3 + 2];
     part[j] = act[j] ? a.part[ii] : -1;
   }
+#pragma unroll
+  for (int c = 0; c < 9; ++c) Iv[c] = a.Iinv[c];
 
   const size_t row_stride = (a.layout == MF_LAYOUT_TIME_MAJOR) ? (size_t)a.B : 1;
   const size_t row0 = (a.layout == MF_LAYOUT_TIME_MAJOR) ? (size_t)b : (size_t)b * a.T;
@@ -230,6 +236,8 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
 #pragma unroll
     for (int c = 0; c < 9; ++c) R[c] = cur.R[c];
     const S cv = cur.cv, cw = cur.cw;
+    // the articulated body of this step: a function of the joint angles only, constant w.r.t. everything differentiated
+    if (JOINTS) articulate_body<S, G, PPL>(a.joint_angles + ((size_t)b * a.T + n) * 4, a.joint_xyz, a.mass / (S)a.N, P0, part, act, P, Iv);
 
     // ---------------------------------------------------------------------------------------------------
     // forward recompute (identical arithmetic to rollout_fwd.hip)
@@ -324,7 +332,7 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
     S wraw[3], wd[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      wraw[c] = a.Iinv[c * 3 + 0] * sTau[0] + a.Iinv[c * 3 + 1] * sTau[1] + a.Iinv[c * 3 + 2] * sTau[2];
+      wraw[c] = Iv[c * 3 + 0] * sTau[0] + Iv[c * 3 + 1] * sTau[1] + Iv[c * 3 + 2] * sTau[2];
       wd[c] = mf_clamp(wraw[c], -a.omega_max, a.omega_max);
     }
 
@@ -437,7 +445,7 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
       S m1 = inside(wraw[1], -a.omega_max, a.omega_max) ? gwd[1] : zero;
       S m2 = inside(wraw[2], -a.omega_max, a.omega_max) ? gwd[2] : zero;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) gtau[c] = a.Iinv[0 * 3 + c] * m0 + a.Iinv[1 * 3 + c] * m1 + a.Iinv[2 * 3 + c] * m2;   // Iinv^T
+      for (int c = 0; c < 3; ++c) gtau[c] = Iv[0 * 3 + c] * m0 + Iv[1 * 3 + c] * m1 + Iv[2 * 3 + c] * m2;   // Iinv^T
     }
     const S gsum[3] = {FAST ? gxdd[0] * a.inv_mass : gxdd[0] / a.mass, FAST ? gxdd[1] * a.inv_mass : gxdd[1] / a.mass,
                        FAST ? gxdd[2] * a.inv_mass : gxdd[2] / a.mass};
@@ -614,8 +622,8 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
       if (act[j]) {
-        S px = P[j][0] * R0[0] + P[j][1] * R0[1] + P[j][2] * R0[2] + x0[0];
-        S py = P[j][0] * R0[3] + P[j][1] * R0[4] + P[j][2] * R0[5] + x0[1];
+        S px = P0[j][0] * R0[0] + P0[j][1] * R0[1] + P0[j][2] * R0[2] + x0[0];
+        S py = P0[j][0] * R0[3] + P0[j][1] * R0[4] + P0[j][2] * R0[5] + x0[1];
         Cell<S> c = locate_m<S, FAST>(px, py, a.d_max, a.res, a.inv_res, a.H, last);
         S v0 = ld32(zmap, moff + (unsigned)c.ic), v1 = ld32(zmap, moff + (unsigned)c.i_f), v2 = ld32(zmap, moff + (unsigned)c.il), v3 = ld32(zmap, moff + (unsigned)c.ifl);
         atomic_add(at32(gzmap, goff + (unsigned)c.ic), g * (one - c.fx) * (one - c.fy));
@@ -627,7 +635,7 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
         S gpx = M::div(g * dfx, a.res), gpy = M::div(g * dfy, a.res);
         sx += gpx; sy += gpy;
 #pragma unroll
-        for (int q = 0; q < 3; ++q) { sR[q] += gpx * P[j][q]; sR[3 + q] += gpy * P[j][q]; }
+        for (int q = 0; q < 3; ++q) { sR[q] += gpx * P0[j][q]; sR[3 + q] += gpy * P0[j][q]; }
       }
     }
     gx0[0] += group_sum<G>(sx);
@@ -648,21 +656,25 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
   }
 }
 
-template <typename S, bool FAST>
+template <typename S, bool FAST, bool JOINTS = false>
 int launch_rollout_bwd(const RolloutBwdArgs<S>& a, LaneMap m, int integ, int block, hipStream_t st) {
   const long long threads = (long long)a.B * m.G;
   const unsigned grid = (unsigned)((threads + block - 1) / block);
-#define MF_CASE(G_, P_)                                                                                                   \
-  if (m.G == G_ && m.PPL == P_) {                                                                                          \
-    if (integ == MF_INTEG_DYNAMICS)                                                                                        \
-      hipLaunchKernelGGL((rollout_bwd_kernel<S, G_, P_, MF_INTEG_DYNAMICS, FAST>), dim3(grid), dim3(block), 0, st, a);      \
-    else                                                                                                                   \
-      hipLaunchKernelGGL((rollout_bwd_kernel<S, G_, P_, MF_INTEG_ODEINT_EULER, FAST>), dim3(grid), dim3(block), 0, st, a);  \
-  } else
-  MF_CASE(4, 1) MF_CASE(8, 1) MF_CASE(16, 1) MF_CASE(32, 1) MF_CASE(64, 1) MF_CASE(64, 2)
-  MF_CASE(1, 4) MF_CASE(2, 4) MF_CASE(4, 4) MF_CASE(8, 4) MF_CASE(16, 4) MF_CASE(32, 4) MF_CASE(64, 4) MF_CASE(64, 8)
-  { set_error("rollout_bwd: no kernel for this lane mapping"); return MF_ERR_UNSUPPORTED; }
+  bool launched = false;
+#define MF_CASE(G_, P_)                                                                                                           \
+  if (!launched && m.G == G_ && m.PPL == P_) {                                                                                     \
+    launched = true;                                                                                                               \
+    if (integ == MF_INTEG_DYNAMICS)                                                                                                \
+      hipLaunchKernelGGL((rollout_bwd_kernel<S, G_, P_, MF_INTEG_DYNAMICS, FAST, JOINTS>), dim3(grid), dim3(block), 0, st, a);      \
+    else                                                                                                                           \
+      hipLaunchKernelGGL((rollout_bwd_kernel<S, G_, P_, MF_INTEG_ODEINT_EULER, FAST, JOINTS>), dim3(grid), dim3(block), 0, st, a);  \
+  }
+  MF_CASE(4, 1) MF_CASE(8, 1) MF_CASE(16, 1) MF_CASE(32, 1) MF_CASE(64, 1) MF_CASE(64, 2) MF_CASE(64, 4) MF_CASE(64, 8)
+  if constexpr (!JOINTS) {   // the 4-points-per-lane mappings are a tuning / test option of the rigid-body kernels
+    MF_CASE(1, 4) MF_CASE(2, 4) MF_CASE(4, 4) MF_CASE(8, 4) MF_CASE(16, 4) MF_CASE(32, 4)
+  }
 #undef MF_CASE
+  MF_REQUIRE(launched, MF_ERR_UNSUPPORTED, "rollout_bwd: no kernel for this lane mapping");
   hipError_t e = hipGetLastError();
   MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("rollout_bwd launch: ") + hipGetErrorString(e));
   return MF_OK;
@@ -670,5 +682,8 @@ int launch_rollout_bwd(const RolloutBwdArgs<S>& a, LaneMap m, int integ, int blo
 
 // defined in rollout_bwd_fast.hip
 int launch_rollout_bwd_fast_f32(const RolloutBwdArgs<float>& a, LaneMap m, int integ, int block, hipStream_t st);
+// defined in rollout_bwd_joints.hip (exact arithmetic, like the articulated forward)
+int launch_rollout_bwd_joints_f32(const RolloutBwdArgs<float>& a, LaneMap m, int integ, int block, hipStream_t st);
+int launch_rollout_bwd_joints_f64(const RolloutBwdArgs<double>& a, LaneMap m, int integ, int block, hipStream_t st);
 
 }  // namespace mf

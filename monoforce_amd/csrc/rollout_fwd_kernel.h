@@ -114,6 +114,44 @@ __device__ __forceinline__ S ld32(const S* base, unsigned elem) {
   return *reinterpret_cast<const S*>(reinterpret_cast<const char*>(base) + (size_t)(elem * (unsigned)sizeof(S)));
 }
 
+// update_joints (dphysics.py:326-358): rotate every driving part about the y-axis through its joint by the step's angle, then
+// the inertia of the articulated body about the body origin and its inverse (dphysics.py:196-197, 107-141) -- per step and per
+// rollout; `ja` = the 4 joint angles of this (rollout, step), P0 = rest configuration, P / Iv = articulated points / I^-1.
+template <typename S, int G, int PPL>
+__device__ __forceinline__ void articulate_body(const S* ja, const S* joint_xyz, S mp, const S (&P0)[PPL][3], const int (&part)[PPL],
+                                                const bool (&act)[PPL], S (&P)[PPL][3], S (&Iv)[9]) {
+  const S one = (S)1, zero = (S)0;
+  S sj[4], cj4[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) mf_sincos(ja[q], &sj[q], &cj4[q]);
+  S I6[6] = {zero, zero, zero, zero, zero, zero};   // xx, yy, zz, xy, xz, yz
+#pragma unroll
+  for (int j = 0; j < PPL; ++j) {
+    const int q = max(part[j], 0);
+    const S sn = sj[q], cs = cj4[q];
+    const S jx = joint_xyz[q * 3 + 0], jz = joint_xyz[q * 3 + 2];
+    const S dx = P0[j][0] - jx, dz = P0[j][2] - jz;
+    const S rx = (dx * cs + dz * sn) + jx, rz = (-(dx * sn) + dz * cs) + jz;   // (p - xyz) @ Ry^T + xyz
+    P[j][0] = part[j] >= 0 ? rx : P0[j][0];
+    P[j][1] = P0[j][1];
+    P[j][2] = part[j] >= 0 ? rz : P0[j][2];
+    const S px = P[j][0], py = P[j][1], pzz = P[j][2];
+    const S wgt = act[j] ? mp : zero;
+    I6[0] += wgt * (py * py + pzz * pzz); I6[1] += wgt * (px * px + pzz * pzz); I6[2] += wgt * (px * px + py * py);
+    I6[3] -= wgt * px * py; I6[4] -= wgt * px * pzz; I6[5] -= wgt * py * pzz;
+  }
+#pragma unroll
+  for (int c = 0; c < 6; ++c) I6[c] = group_sum<G>(I6[c]);
+  // inverse of the symmetric 3x3 by cofactors
+  const S a00 = I6[0], a11 = I6[1], a22 = I6[2], a01 = I6[3], a02 = I6[4], a12 = I6[5];
+  const S c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
+  const S c11 = a00 * a22 - a02 * a02, c12 = a01 * a02 - a00 * a12, c22 = a00 * a11 - a01 * a01;
+  const S idet = one / (a00 * c00 + a01 * c01 + a02 * c02);
+  Iv[0] = c00 * idet; Iv[1] = c01 * idet; Iv[2] = c02 * idet;
+  Iv[3] = c01 * idet; Iv[4] = c11 * idet; Iv[5] = c12 * idet;
+  Iv[6] = c02 * idet; Iv[7] = c12 * idet; Iv[8] = c22 * idet;
+}
+
 template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS = false, bool FORCES = true>
 __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a) {
   using M = Mth<S, FAST>;
@@ -240,41 +278,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
   // conservative in-loop wait is a wait for the previous step's stores
   __builtin_amdgcn_s_waitcnt(0);
   for (int n = 0; n < n_steps; ++n) {
-    if (JOINTS) {
-      // update_joints (dphysics.py:326-358): rotate every driving part about the y-axis through its joint, then the
-      // inertia of the articulated body and its inverse (dphysics.py:196-197), all per step and per rollout
-      const S* ja = a.joint_angles + ((size_t)b * a.T + n) * 4;
-      S sj[4], cj4[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) mf_sincos(ja[q], &sj[q], &cj4[q]);
-      S I6[6] = {zero, zero, zero, zero, zero, zero};   // xx, yy, zz, xy, xz, yz
-      const S mp = a.mass / (S)a.N;
-#pragma unroll
-      for (int j = 0; j < PPL; ++j) {
-        const int q = max(part[j], 0);
-        const S sn = sj[q], cs = cj4[q];
-        const S jx = a.joint_xyz[q * 3 + 0], jz = a.joint_xyz[q * 3 + 2];
-        const S dx = P0[j][0] - jx, dz = P0[j][2] - jz;
-        const S rx = (dx * cs + dz * sn) + jx, rz = (-(dx * sn) + dz * cs) + jz;   // (p - xyz) @ Ry^T + xyz
-        P[j][0] = part[j] >= 0 ? rx : P0[j][0];
-        P[j][1] = P0[j][1];
-        P[j][2] = part[j] >= 0 ? rz : P0[j][2];
-        const S px = P[j][0], py = P[j][1], pzz = P[j][2];
-        const S wgt = act[j] ? mp : zero;
-        I6[0] += wgt * (py * py + pzz * pzz); I6[1] += wgt * (px * px + pzz * pzz); I6[2] += wgt * (px * px + py * py);
-        I6[3] -= wgt * px * py; I6[4] -= wgt * px * pzz; I6[5] -= wgt * py * pzz;
-      }
-#pragma unroll
-      for (int c = 0; c < 6; ++c) I6[c] = group_sum<G>(I6[c]);
-      // inverse of the symmetric 3x3 by cofactors
-      const S a00 = I6[0], a11 = I6[1], a22 = I6[2], a01 = I6[3], a02 = I6[4], a12 = I6[5];
-      const S c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
-      const S c11 = a00 * a22 - a02 * a02, c12 = a01 * a02 - a00 * a12, c22 = a00 * a11 - a01 * a01;
-      const S idet = one / (a00 * c00 + a01 * c01 + a02 * c02);
-      Iv[0] = c00 * idet; Iv[1] = c01 * idet; Iv[2] = c02 * idet;
-      Iv[3] = c01 * idet; Iv[4] = c11 * idet; Iv[5] = c12 * idet;
-      Iv[6] = c02 * idet; Iv[7] = c12 * idet; Iv[8] = c22 * idet;
-    }
+    if (JOINTS) articulate_body<S, G, PPL>(a.joint_angles + ((size_t)b * a.T + n) * 4, a.joint_xyz, a.mass / (S)a.N, P0, part, act, P, Iv);
     // ---- geometry of the contact points and the gathers that depend only on it ----
     S r[PPL][3], pz[PPL];
     Cell<S> cell[PPL];

@@ -130,6 +130,7 @@ class _RolloutFn(torch.autograd.Function):
         if want_grad:
             ctx.mod, ctx.desc, ctx.keep = mod, desc, keep
             ctx.z_shape, ctx.mu_given = z.shape, mu is not None
+            ctx.joint_angles = joint_angles          # constants of the rollout (no gradient), kept for the backward
             ctx.save_for_backward(controls, x0.clone(), xd0, R0, w0, ts, Xraw, Xds, Rs, Om)
         return outs
 
@@ -281,9 +282,6 @@ class DPhysics(torch.nn.Module):
         xd0, R0, w0 = (s.to(device=dev, dtype=dtype).contiguous() for s in state[1:])
         want_grad = torch.is_grad_enabled() and any(
             t is not None and t.requires_grad for t in (z_grid, friction, controls, xd0, R0, w0))
-        if ja_dev is not None and want_grad:
-            raise NotImplementedError('backward through an articulated rollout (non-zero flipper joint angles) is not '
-                                      'implemented: run it under torch.no_grad()')
         want_forces = self.return_forces or self.precise or dtype != torch.float32 or ja_dev is not None
         outs = _RolloutFn.apply(self, z_grid, friction, controls.contiguous(), x0, xd0, R0, w0, ts, want_grad, ja_dev, want_forces)
         if not aliased:

@@ -432,8 +432,16 @@ def gen_joints(out):
                 cfg = make_ref_cfg(pts, masks, dtype, 0.1, 1.6, use_odeint=(integ == 1), robot='marv')
                 out['joint_positions'] = np.array(list(cfg.joint_positions.values()))
                 dp = ref_dp.DPhysics(cfg, device='cpu')
-                states, forces = dp(z_grid=z.to(dtype), controls=ctrl.to(dtype), joint_angles=ja.to(dtype), friction=mu.to(dtype))
-            for k, v in zip(['Xs', 'Xds', 'Rs', 'Om', 'Fs', 'Ff'], list(states) + list(forces)):
+                zg, cg, mg = (t.to(dtype).clone().requires_grad_(True) for t in (z, ctrl, mu))
+                states, forces = dp(z_grid=zg, controls=cg, joint_angles=ja.to(dtype), friction=mg)
+                outs = list(states) + list(forces)
+                loss = 0            # the probe loss of run_ref(): touches all six outputs
+                for i, (o, sc) in enumerate(zip(outs, [1.0, 1.0, 1.0, 1.0, 1e-3, 1e-3])):
+                    loss = loss + (o * syn.probe_weights(o.shape, phase=0.5 + i, dtype=dtype)).sum() * sc
+                loss.backward()
+            for k, v in zip(['Xs', 'Xds', 'Rs', 'Om', 'Fs', 'Ff'], outs):
+                out[f'{tag}/i{integ}/{k}'] = npy(v)
+            for k, v in dict(loss=loss, g_z=zg.grad, g_ctrl=cg.grad, g_mu=mg.grad).items():
                 out[f'{tag}/i{integ}/{k}'] = npy(v)
             print(f'joints {tag} integ={integ}: |Xs|max={float(states[0].abs().max()):.3f}')
 

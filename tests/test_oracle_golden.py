@@ -106,8 +106,17 @@ def test_flipper_joint_angles(tag, integ):
     spec = hp.spec_from(g['points'], g['masks'], integ, 0.1, 1.6)
     spec.joint_positions = g['joint_positions'].tolist()
     t = lambda k: torch.as_tensor(g[k]).to(dt)  # noqa: E731
-    with torch.no_grad():
-        st, fo = orc.rollout(spec, t('z'), t('ctrl'), friction=t('mu'), joint_angles=t('joint_angles'))
+    from monoforce_amd import synthetic as syn
+    zg, cg, mg = t('z').requires_grad_(True), t('ctrl').requires_grad_(True), t('mu').requires_grad_(True)
+    st, fo = orc.rollout(spec, zg, cg, friction=mg, joint_angles=t('joint_angles'))
     tol = 1e-10 if tag == 'f64' else 5e-5
     for k, o in zip(hp.OUT_KEYS, list(st) + list(fo)):
-        assert hp.rel_err(o, g[f'{tag}/i{integ}/{k}']) <= tol, (k, hp.rel_err(o, g[f'{tag}/i{integ}/{k}']))
+        assert hp.rel_err(o.detach(), g[f'{tag}/i{integ}/{k}']) <= tol, (k, hp.rel_err(o.detach(), g[f'{tag}/i{integ}/{k}']))
+    # gradients of the probe loss through the articulated rollout (the joint angles are constants)
+    loss = 0
+    for i, (o, sc) in enumerate(zip(list(st) + list(fo), [1.0, 1.0, 1.0, 1.0, 1e-3, 1e-3])):
+        loss = loss + (o * syn.probe_weights(o.shape, phase=0.5 + i, dtype=dt)).sum() * sc
+    loss.backward()
+    gtol = 1e-9 if tag == 'f64' else 2e-4
+    for k, v in (('g_z', zg.grad), ('g_ctrl', cg.grad), ('g_mu', mg.grad)):
+        assert hp.rel_err(v, g[f'{tag}/i{integ}/{k}']) <= gtol, (k, hp.rel_err(v, g[f'{tag}/i{integ}/{k}']))

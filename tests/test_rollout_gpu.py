@@ -240,9 +240,19 @@ def test_flipper_joint_angles_vs_reference(tag, integ):
     a = dp(t('z'), t('ctrl'), joint_angles=torch.zeros_like(t('joint_angles')), friction=t('mu'))
     b = dp(t('z'), t('ctrl'), friction=t('mu'))
     assert all(torch.equal(u, v) for u, v in zip(a[0] + a[1], b[0] + b[1]))
-    # gradients through an articulated rollout are refused, not silently wrong
-    with pytest.raises(NotImplementedError):
-        dp(t('z').requires_grad_(True), t('ctrl'), joint_angles=t('joint_angles'), friction=t('mu'))
+    # gradients through the articulated rollout (joint angles are constants) vs the reference's loss.backward()
+    from monoforce_amd import synthetic as syn
+    zg, cg, mg = t('z').requires_grad_(True), t('ctrl').requires_grad_(True), t('mu').requires_grad_(True)
+    states, forces = dp(zg, cg, joint_angles=t('joint_angles'), friction=mg)
+    loss = 0
+    for i, (o, sc) in enumerate(zip(list(states) + list(forces), [1.0, 1.0, 1.0, 1.0, 1e-3, 1e-3])):
+        loss = loss + (o * syn.probe_weights(o.shape, phase=0.5 + i, dtype=dt).to(DEV)).sum() * sc
+    loss.backward()
+    pre = f'{tag}/i{integ}/'
+    gtol = 1e-8 if tag == 'f64' else 2e-4
+    assert abs(float(loss) - float(g[pre + 'loss'])) <= gtol * abs(float(g[pre + 'loss'])) + gtol
+    for k, v in (('g_z', zg.grad), ('g_ctrl', cg.grad), ('g_mu', mg.grad)):
+        assert hp.rel_err(v.cpu(), g[pre + k]) <= gtol, (k, hp.rel_err(v.cpu(), g[pre + k]))
 
 
 def test_dtype_device_and_stride_handling():
