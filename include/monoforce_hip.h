@@ -77,6 +77,8 @@ typedef struct MfRolloutDesc {
                            copy b % grad_copies; the caller sums the copies).  Thousands of rollouts of one batch cross the
                            same cells, and same-address float atomics serialise in L2 at ~20 ns each; 0 or 1 = one copy. */
   int32_t has_joints;   /* 1: MfRolloutFwdBufs.joint_angles will be given (selects the articulated kernels / force stride) */
+  int32_t pose_stride;  /* path-cost mode (MfRolloutFwdBufs.cost_rows): Xs / Rs keep every pose_stride-th output row; else 0 */
+  int32_t reserved0;    /* 0 */
   double mass, gravity, stiffness, damping, omega_max;
   double grid_res, d_max;
   double dt;           /* cfg.dt: step of MF_INTEG_DYNAMICS (ODEINT takes its steps from ts[]) */
@@ -108,8 +110,15 @@ typedef struct MfRolloutFwdBufs {
   void* Xraw;           /* optional S[..][3]: unshifted positions saved for the backward pass; may be NULL */
   const void* joint_angles; /* optional S[B][T][4] flipper angles: each driving part is rotated about the y-axis through
                            its joint and the body inertia recomputed EVERY step (update_joints, dphysics.py:192-197,
-                           326-358; the reference does this for robot == 'marv' and non-zero angles).  Forward only,
-                           exact arithmetic.  NULL = rigid body. */
+                           326-358; the reference does this for robot == 'marv' and non-zero angles).  Exact
+                           arithmetic.  NULL = rigid body. */
+  void* cost_rows;      /* optional S[T][B][4], float32 MF_MATH_FAST + MF_LAYOUT_TIME_MAJOR rigid-body rollouts: PATH-COST mode
+                           for trajectory shooting.  Per output row the kernel writes (R[2][0], R[2][1], R[2][2], s) with
+                           s = unbiased std over the N contact points of |F_spring row| -- the inputs of the reference's
+                           path costs (monoforce_node.py:91 `norm(F_springs).std(points).std(time)`; diff_physics.py:263-266
+                           roll / pitch) -- instead of the full rows: Xds, Omegas, Fs, Ff, Xraw must be NULL, and Xs / Rs are
+                           DECIMATED to S[1 + ceil((T-1) / pose_stride)][B][3 | 3x3]: pose row r holds output row
+                           min(r * pose_stride, T - 1) (what the nodes publish: poses[::pose_step], plus the final pose). */
 } MfRolloutFwdBufs;
 
 /* Point slots per Fs/Ff row the kernels chosen for (B, N, points_per_lane) need (>= N; -1 on a bad descriptor). */

@@ -17,7 +17,7 @@ static int fill_args(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutA
   MF_REQUIRE(d->math_mode == MF_MATH_EXACT || d->math_mode == MF_MATH_FAST, MF_ERR_INVALID, "rollout_fwd: unknown math_mode");
   MF_REQUIRE(p->z && p->controls && p->ts && p->points && p->part && p->x0 && p->xd0 && p->R0 && p->w0, MF_ERR_INVALID,
              "rollout_fwd: null input buffer");
-  MF_REQUIRE(p->Xs && p->Xds && p->Rs && p->Omegas, MF_ERR_INVALID, "rollout_fwd: null output buffer");
+  MF_REQUIRE(p->Xs && p->Rs && (p->cost_rows || (p->Xds && p->Omegas)), MF_ERR_INVALID, "rollout_fwd: null output buffer");
   MF_REQUIRE((p->Fs != nullptr) == (p->Ff != nullptr), MF_ERR_INVALID, "rollout_fwd: pass both force buffers or neither");
   MF_REQUIRE((long long)d->H * d->W < (1ll << 30), MF_ERR_UNSUPPORTED, "rollout_fwd: grid too large");
   MF_REQUIRE(d->H < (1 << 23), MF_ERR_UNSUPPORTED, "rollout_fwd: grid too large (H must be below 2^23)");
@@ -28,7 +28,7 @@ static int fill_args(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutA
   MF_REQUIRE(*block == 64 || *block == 128 || *block == 256, MF_ERR_INVALID, "rollout_fwd: block must be 64, 128 or 256");
   *m = choose_lane_map(d->B, d->N, d->points_per_lane);
   const int fstride = d->force_stride ? d->force_stride : d->N;
-  MF_REQUIRE(fstride >= m->G * m->PPL, MF_ERR_INVALID,
+  MF_REQUIRE(!p->Fs || fstride >= m->G * m->PPL, MF_ERR_INVALID,
              "rollout_fwd: force_stride too small -- allocate Fs/Ff with mf_rollout_force_stride(desc) point slots per row");
 
   a->B = d->B; a->T = d->T; a->N = d->N; a->H = d->H; a->W = d->W;
@@ -46,6 +46,7 @@ static int fill_args(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutA
   a->Xs = (S*)p->Xs; a->Xds = (S*)p->Xds; a->Rs = (S*)p->Rs; a->Om = (S*)p->Omegas; a->Fs = (S*)p->Fs; a->Ff = (S*)p->Ff;
   a->Xraw = (S*)p->Xraw;
   a->joint_angles = (const S*)p->joint_angles;
+  a->cost_rows = (S*)p->cost_rows; a->pose_stride = d->pose_stride > 0 ? d->pose_stride : 1;
   for (int i = 0; i < 12; ++i) a->joint_xyz[i] = (S)d->joint_xyz[i];
   if (p->joint_angles) {
     MF_REQUIRE(d->n_tracks == 4, MF_ERR_UNSUPPORTED, "rollout_fwd: joint angles need 4 driving parts (fl, fr, rl, rr)");
@@ -71,6 +72,14 @@ extern "C" int mf_rollout_fwd_f32(const MfRolloutDesc* d, const MfRolloutFwdBufs
   int rc = mf::fill_args<float>(d, p, &a, &m, &block);
   if (rc != MF_OK) return rc;
   if (p->joint_angles) return mf::launch_rollout_fwd<float, false, true>(a, m, d->integrator, block, (hipStream_t)s);  // exact math
+  if (p->cost_rows) {   // path-cost mode: cost rows + decimated poses (see MfRolloutFwdBufs.cost_rows)
+    MF_REQUIRE(d->math_mode == MF_MATH_FAST && d->layout == MF_LAYOUT_TIME_MAJOR && d->pose_stride >= 1, MF_ERR_UNSUPPORTED,
+               "rollout_fwd: cost rows need float32 MF_MATH_FAST, MF_LAYOUT_TIME_MAJOR and pose_stride >= 1");
+    MF_REQUIRE(!p->Xds && !p->Omegas && !p->Fs && !p->Ff && !p->Xraw, MF_ERR_INVALID,
+               "rollout_fwd: with cost_rows only Xs and Rs (decimated) are written -- pass NULL for Xds, Omegas, Fs, Ff, Xraw");
+    if (m.PPL == 4 && m.G < 64) m = mf::choose_lane_map(d->B, d->N, 1);
+    return mf::launch_rollout_fwd_cost_f32(a, m, d->integrator, block, (hipStream_t)s);
+  }
   const bool forces = p->Fs != nullptr;
   if (!forces && (d->math_mode != MF_MATH_FAST || p->joint_angles)) {
     mf::set_error("rollout_fwd: the states-only kernels (Fs = Ff = NULL) exist for float32 MF_MATH_FAST rigid-body rollouts only");
@@ -90,6 +99,7 @@ extern "C" int mf_rollout_fwd_f64(const MfRolloutDesc* d, const MfRolloutFwdBufs
   int rc = mf::fill_args<double>(d, p, &a, &m, &block);
   if (rc != MF_OK) return rc;
   if (!p->Fs) { mf::set_error("rollout_fwd: float64 needs the force buffers"); return MF_ERR_UNSUPPORTED; }
+  if (p->cost_rows) { mf::set_error("rollout_fwd: cost rows exist for float32 only"); return MF_ERR_UNSUPPORTED; }
   if (p->joint_angles) return mf::launch_rollout_fwd<double, false, true>(a, m, d->integrator, block, (hipStream_t)s);
   return mf::launch_rollout_fwd<double, false>(a, m, d->integrator, block, (hipStream_t)s);   // float64 is always exact
 }

@@ -48,6 +48,8 @@ struct RolloutArgs {
   S* Xraw;
   const S* joint_angles;  // S[B][T][4] flipper angles (JOINTS kernels only)
   S joint_xyz[12];        // joint positions of the (up to 4) driving parts
+  S* cost_rows;           // COST kernels: S[T][B][4] = (R20, R21, R22, std over the points of |F_spring|) per output row
+  int pose_stride;        // COST kernels: Xs / Rs hold every pose_stride-th output row only
 };
 
 // Arithmetic policy.  Exact: IEEE divide / sqrt, libm exp and sincos, un-fused mul+add (the TU is built with
@@ -152,7 +154,7 @@ __device__ __forceinline__ void articulate_body(const S* ja, const S* joint_xyz,
   Iv[6] = c02 * idet; Iv[7] = c12 * idet; Iv[8] = c22 * idet;
 }
 
-template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS = false, bool FORCES = true>
+template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS = false, bool FORCES = true, bool COST = false>
 __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a) {
   using M = Mth<S, FAST>;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -239,10 +241,41 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
   // values to the same addresses (no exec-mask branch on the issue stream; the coalescer merges them) and its own forces.
   // (Splitting the 21 state floats over the lanes of the group -- 2 stores instead of 7 -- was measured: same store
   // bandwidth, more selects; tools/microbench/store_patterns.hip.)
+  // COST kernels (trajectory shooting): instead of the 84 + 24 N bytes of a full output row they write one
+  // 16-byte cost row -- what the reference's path costs read (monoforce_node.py:91: norm(F_springs).std(points);
+  // diff_physics.py:263-266: roll / pitch from the last row of R) -- and keep every pose_stride-th pose (the nodes publish
+  // poses[::pose_step]).  Pose row r holds output row m = min(r * pose_stride, T - 1).  A pose is stored by a wave-uniform
+  // branch at the very END of the step that produced it: the arithmetic of a step stays one basic block, so the FMA
+  // contraction -- and with it every bit of the trajectory -- is the one of the full-output kernels.
+  S* pC = COST ? a.cost_rows + row0 * 4 : nullptr;
+  int pose_wait = 0;   // output rows still to pass before the next pose is due
+  auto store_pose = [&]() {
+    pXs[0] = x[0] + R[2] * a.sink; pXs[1] = x[1] + R[5] * a.sink; pXs[2] = x[2] + R[8] * a.sink;
+#pragma unroll
+    for (int c = 0; c < 9; ++c) pRs[c] = R[c];
+  };
+  const S inv_N = one / (S)a.N, inv_Nm1 = one / (S)max(a.N - 1, 1);
   auto emit_row = [&](size_t adv) {
 #ifdef MF_DBG_NOSTORE   // A/B hook (tools/ab_rollout.py): time the kernel without its output stream
     if (a.B > 0) return;
 #endif
+    if (COST) {
+      auto stc = [](S* p, S v) { __builtin_nontemporal_store(v, p); };
+      S nrm_j[PPL], nsum = zero;
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        nrm_j[j] = M::sqrt(oFs[j][0] * oFs[j][0] + oFs[j][1] * oFs[j][1] + oFs[j][2] * oFs[j][2]);
+        nsum += act[j] ? nrm_j[j] : zero;
+      }
+      const S mean = group_sum<G>(nsum) * inv_N;
+      S dsum = zero;
+#pragma unroll
+      for (int j = 0; j < PPL; ++j) { const S dv = nrm_j[j] - mean; dsum += act[j] ? dv * dv : zero; }
+      const S sdev = M::sqrt(group_sum<G>(dsum) * inv_Nm1);   // unbiased, like torch.std
+      stc(pC + 0, R[6]); stc(pC + 1, R[7]); stc(pC + 2, R[8]); stc(pC + 3, sdev);
+      pC += adv * 4;
+      return;   // the decimated poses are written at the END of the step that produced them (store_pose below)
+    }
     // streaming (non-temporal) stores: the rows are never read again by this kernel and must not evict the map cells the
     // gathers keep hitting in L1 / L2
     auto st = [](S* p, S v) { __builtin_nontemporal_store(v, p); };
@@ -274,6 +307,11 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
   S cv = ctrl[0], cw = ctrl[1];
   S h_ode = (INTEG == MF_INTEG_ODEINT_EULER && a.T > 1) ? a.ts[1] - a.ts[0] : zero;   // step size of the current step
 
+  if (COST && INTEG == MF_INTEG_ODEINT_EULER) {   // output row 0 = the initial state (DYNAMICS: row 0 is produced by step 0)
+    store_pose();
+    pXs += row_stride * 3; pRs += row_stride * 9;
+    pose_wait = a.pose_stride - 1;
+  }
   // everything loaded so far is complete before the loop: otherwise the waits inside it also have to cover these loads, and a
   // conservative in-loop wait is a wait for the previous step's stores
   __builtin_amdgcn_s_waitcnt(0);
@@ -476,6 +514,12 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
     }
     cv = cv_next; cw = cw_next;
     h_ode = ts_b - ts_a;
+    if (COST) {   // the state is now output row m = n + 1 (ODEINT) / n (DYNAMICS)
+      const bool due = pose_wait == 0;
+      if (due || n == n_steps - 1) store_pose();
+      pXs += due ? row_stride * 3 : 0; pRs += due ? row_stride * 9 : 0;
+      pose_wait = due ? a.pose_stride - 1 : pose_wait - 1;
+    }
   }
   if (n_steps > 0 || INTEG == MF_INTEG_ODEINT_EULER) emit_row(row_stride);
 }
@@ -503,7 +547,7 @@ static inline LaneMap choose_lane_map(int B, int N, int points_per_lane) {
 
 // Instantiated mappings: one point per lane (G = 4..64) and (64, 2/4/8) always; the 4-points-per-lane mappings with G < 64
 // only for the full-output rigid-body kernels (they are a tuning / test option, see choose_lane_map).
-template <typename S, bool FAST, bool JOINTS = false, bool FORCES = true>
+template <typename S, bool FAST, bool JOINTS = false, bool FORCES = true, bool COST = false>
 int launch_rollout_fwd(const RolloutArgs<S>& a, LaneMap m, int integ, int block, hipStream_t st) {
   const long long threads = (long long)a.B * m.G;
   const unsigned grid = (unsigned)((threads + block - 1) / block);
@@ -512,9 +556,9 @@ int launch_rollout_fwd(const RolloutArgs<S>& a, LaneMap m, int integ, int block,
   if (!launched && m.G == G_ && m.PPL == P_) {                                                                                             \
     launched = true;                                                                                                                       \
     if (integ == MF_INTEG_DYNAMICS)                                                                                                        \
-      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_DYNAMICS, FAST, JOINTS, FORCES>), dim3(grid), dim3(block), 0, st, a);      \
+      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_DYNAMICS, FAST, JOINTS, FORCES, COST>), dim3(grid), dim3(block), 0, st, a);      \
     else                                                                                                                                   \
-      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_ODEINT_EULER, FAST, JOINTS, FORCES>), dim3(grid), dim3(block), 0, st, a);  \
+      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_ODEINT_EULER, FAST, JOINTS, FORCES, COST>), dim3(grid), dim3(block), 0, st, a);  \
   }
   if (!JOINTS) { MF_CASE(4, 1) MF_CASE(8, 1) MF_CASE(16, 1) MF_CASE(32, 1) MF_CASE(64, 1) MF_CASE(64, 2) }
   if (FORCES) { MF_CASE(1, 4) MF_CASE(2, 4) MF_CASE(4, 4) MF_CASE(8, 4) MF_CASE(16, 4) MF_CASE(32, 4) }
@@ -528,5 +572,7 @@ int launch_rollout_fwd(const RolloutArgs<S>& a, LaneMap m, int integ, int block,
 
 // defined in rollout_fwd_fast.hip
 int launch_rollout_fwd_fast_f32(const RolloutArgs<float>& a, LaneMap m, int integ, int block, bool forces, hipStream_t st);
+// defined in rollout_fwd_cost.hip
+int launch_rollout_fwd_cost_f32(const RolloutArgs<float>& a, LaneMap m, int integ, int block, hipStream_t st);
 
 }  // namespace mf

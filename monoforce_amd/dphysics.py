@@ -291,6 +291,59 @@ class DPhysics(torch.nn.Module):
         F_springs, F_frictions = outs[4:] if len(outs) == 6 else (None, None)
         return (Xs, Xds, Rs, Omegas), (F_springs, F_frictions)
 
+    @torch.no_grad()
+    def rollout_costs(self, z_grid, controls, state=None, friction=None, pose_stride=None):
+        """Trajectory-shooting forward: roll out and return only what the reference's planners consume.
+
+        The kernel's path-cost mode writes, per output row, `(R[2,0], R[2,1], R[2,2], std_points |F_spring|)` -- the inputs of
+        `norm(F_springs).std(points).std(time)` (monoforce_node.py:91) and of the roll / pitch cost
+        (monoforce_ros/nodes/diff_physics.py:263-266) -- and keeps every `pose_stride`-th pose (`poses[::pose_step]`,
+        monoforce_node.py:35,115; default 0.5 s like the node) plus the final one: 16 B per rollout-step instead of 180.
+        float32 fast-math rigid-body rollouts only; arguments as `forward` (a [1,H,W] map is shared by all rollouts).
+
+        Returns dict(cost_rows [B,T,4], Xs [B,Tp,3], Rs [B,Tp,3,3], pose_steps [Tp]) -- views of time-major buffers.
+        """
+        cfg = self.dphys_cfg
+        dev = torch.device(self.device)
+        if self.precise:
+            raise ValueError('rollout_costs uses the float32 fast-math kernels: construct DPhysics(precise=False)')
+        z_grid = z_grid.to(dev)
+        _lib.require_hip_tensor(z_grid, 'z_grid')
+        if z_grid.dtype != torch.float32:
+            raise TypeError('rollout_costs: float32 only')
+        controls = controls.to(device=dev, dtype=torch.float32)
+        B = z_grid.shape[0] if z_grid.shape[0] != 1 else controls.shape[0]
+        N_ts = min(int(cfg.traj_sim_time / cfg.dt), controls.shape[1])
+        assert controls.shape == (B, N_ts, 2), f'Controls shape {controls.shape} != {(B, N_ts, 2)}'
+        if state is None:                                                            # (dphysics.py:554-559)
+            x0 = torch.zeros(B, 3, device=dev)
+            xd0 = torch.zeros_like(x0); xd0[:, 0] = controls[:, 0, 0]
+            R0 = torch.eye(3, device=dev).repeat(B, 1, 1)
+            w0 = torch.zeros_like(x0); w0[:, 2] = controls[:, 0, 1]
+        else:
+            x0 = state[0].detach().to(device=dev, dtype=torch.float32).clone()       # the snap writes x0.z: keep the caller's
+            xd0, R0, w0 = (t.detach().to(device=dev, dtype=torch.float32).contiguous() for t in state[1:])
+        if friction is not None:
+            friction = friction.to(device=dev, dtype=torch.float32)
+        ps = int(pose_stride) if pose_stride else max(int(0.5 / cfg.dt), 1)
+        ts = self._time_grid(N_ts, torch.float32, dev)
+        controls = controls.contiguous()
+        desc, keep = self._make_desc(z_grid, friction, controls)
+        desc.layout, desc.pose_stride = _lib.MF_LAYOUT_TIME_MAJOR, ps
+        Tp = 1 + (N_ts - 1 + ps - 1) // ps
+        rows = torch.empty(N_ts, B, 4, device=dev)
+        Xs, Rs = torch.empty(Tp, B, 3, device=dev), torch.empty(Tp, B, 3, 3, device=dev)
+        bufs = _lib.MfRolloutFwdBufs(
+            z=_lib.ptr(keep['z']), mu=_lib.ptr(keep['mu']), controls=_lib.ptr(controls), ts=_lib.ptr(ts),
+            points=_lib.ptr(keep['points']), part=_lib.ptr(self._part_dev(dev)),
+            x0=_lib.ptr(x0), xd0=_lib.ptr(xd0), R0=_lib.ptr(R0), w0=_lib.ptr(w0),
+            Xs=_lib.ptr(Xs), Xds=None, Rs=_lib.ptr(Rs), Omegas=None, Fs=None, Ff=None, Xraw=None, joint_angles=None,
+            cost_rows=_lib.ptr(rows))
+        with torch.cuda.device(dev), _timing.timed('rollout_fwd_kernel', dev):
+            _lib.check(_lib.lib().mf_rollout_fwd_f32(C.byref(desc), C.byref(bufs), _stream_ptr(dev)), 'mf_rollout_fwd')
+        steps = torch.clamp(torch.arange(Tp, device=dev) * ps, max=N_ts - 1)
+        return dict(cost_rows=rows.transpose(0, 1), Xs=Xs.transpose(0, 1), Rs=Rs.transpose(0, 1), pose_steps=steps)
+
     def _time_grid(self, n, dtype, dev):
         key = ('ts', n, dtype, str(dev))
         if key not in self._cache:

@@ -10,11 +10,13 @@ paths, pick the cheapest -- the device-side part of the reference's planning nod
   * selection:    `argmin(path_costs)` (monoforce_node.py:126)
 
 All rollouts share ONE height/friction map (the rollout kernels' shared-map path), so thousands of samples cost one
-512 KiB map read; at B = 16 384 the states-only kernel runs ~12 G rollout-steps/s on one MI355X.
+512 KiB map read.  By default the rollout runs in the kernel's path-cost mode (`DPhysics.rollout_costs`): per step it writes
+one 16-byte cost row (the last row of R and the std over the contact points of |F_spring|) and keeps every
+`pose_stride`-th pose instead of the full 180-byte output row; `fused=False` uses the full outputs.
 """
 import torch
 
-__all__ = ['sample_controls', 'force_path_cost', 'inclination_path_cost', 'TrajectoryShooter']
+__all__ = ['sample_controls', 'force_path_cost', 'inclination_path_cost', 'costs_from_rows', 'TrajectoryShooter']
 
 
 def sample_controls(n_trajs, cfg, device, generator=None):
@@ -34,6 +36,15 @@ def force_path_cost(F_springs):
     return torch.norm(F_springs, dim=-1).std(dim=-1).std(dim=-1)
 
 
+def costs_from_rows(cost_rows, kind):
+    """[B,T,4] cost rows of the path-cost kernel -> [B] path costs (same formulas as the two functions above)."""
+    if kind == 'force':
+        return cost_rows[..., 3].std(dim=-1)
+    pitch = torch.asin(torch.clamp(-cost_rows[..., 0], -1.0, 1.0))
+    roll = torch.atan2(cost_rows[..., 1], cost_rows[..., 2])
+    return roll.abs().mean(dim=-1) + pitch.abs().mean(dim=-1)
+
+
 def inclination_path_cost(Rs):
     """[B,T,3,3] -> [B]: mean |roll| + mean |pitch| with roll/pitch of the extrinsic xyz Euler decomposition
     R = Rz(yaw) Ry(pitch) Rx(roll) (what scipy's `Rotation.as_euler('xyz')` returns; diff_physics.py:263-266)."""
@@ -43,17 +54,20 @@ def inclination_path_cost(Rs):
 
 
 class TrajectoryShooter:
-    def __init__(self, dphysics, n_trajs=None, cost='inclination'):
+    def __init__(self, dphysics, n_trajs=None, cost='inclination', fused=True, pose_stride=None):
         assert cost in ('inclination', 'force')
         self.dp = dphysics
         self.cfg = dphysics.dphys_cfg
         self.n_trajs = n_trajs or self.cfg.n_sim_trajs
         self.cost = cost
+        self.fused = fused and not dphysics.precise      # path-cost kernel: float32 fast math
+        self.pose_stride = pose_stride
 
     @torch.no_grad()
     def shoot(self, z_grid, friction=None, pose0=None, controls=None, generator=None):
         """z_grid [H,W] (or [1,H,W]); pose0 optional 4x4 start pose shared by all samples.
-        Returns dict(controls, Xs, Rs, costs, best) -- `best` is the index of the cheapest path."""
+        Returns dict(controls, Xs, Rs, costs, best) -- `best` is the index of the cheapest path; with the fused path-cost
+        kernel Xs / Rs hold every `pose_stride`-th pose (+ the final one) and `pose_steps` their step indices."""
         dev = z_grid.device
         if controls is None:
             controls = sample_controls(self.n_trajs, self.cfg, dev, generator)
@@ -64,6 +78,11 @@ class TrajectoryShooter:
         if pose0 is not None:
             x = pose0[:3, 3].to(dev).repeat(B, 1)
             state = (x, torch.zeros_like(x), pose0[:3, :3].to(dev).repeat(B, 1, 1).contiguous(), torch.zeros_like(x))   # monoforce_node.py:67-72
+        if self.fused and z.dtype == torch.float32:
+            out = self.dp.rollout_costs(z, controls, state=state, friction=mu, pose_stride=self.pose_stride)
+            costs = costs_from_rows(out['cost_rows'], self.cost)
+            return dict(controls=controls, Xs=out['Xs'], Rs=out['Rs'], pose_steps=out['pose_steps'], costs=costs,
+                        best=int(torch.argmin(costs)))
         need_forces = self.cost == 'force'
         old = self.dp.return_forces
         self.dp.return_forces = need_forces          # inclination cost only needs the states: states-only kernel

@@ -41,7 +41,48 @@ def test_shooter_selects_cheapest_path(cost):
     ref = (force_path_cost(Fs) if cost == 'force' else inclination_path_cost(Rs)).cpu()
     assert hp.rel_err(out['costs'].cpu(), ref) <= 1e-5
     assert out['best'] == int(torch.argmin(out['costs'])) and torch.isfinite(out['costs']).all()
+    # the fused path keeps poses[::pose_stride] (0.5 s like the node) plus the final pose, bit-identical to the full rollout's
+    steps = out['pose_steps'].cpu()
+    assert steps.tolist() == [0, 50, 100, 150, 199] and out['Xs'].shape == (512, 5, 3) and out['Rs'].shape == (512, 5, 3, 3)
+    assert torch.equal(out['Xs'].cpu(), Xs[:, steps].cpu()) and torch.equal(out['Rs'].cpu(), Rs[:, steps].cpu())
+    # ... and the un-fused shooter (full output rows) gives the same costs
+    out2 = TrajectoryShooter(dp, n_trajs=512, cost=cost, fused=False).shoot(z, controls=c)
+    assert hp.rel_err(out2['costs'].cpu(), ref) <= 1e-6 and out2['Xs'].shape == (512, 200, 3)
     # flat ground: inclination cost ~ 0 for everyone
     if cost == 'inclination':
         flat = sh.shoot(torch.zeros_like(z), controls=c)
         assert float(flat['costs'].max()) < 5e-3 and float(flat['costs'].max()) < 0.2 * float(out['costs'].max())
+
+
+def _start_state(B, seed=2):
+    from scipy.spatial.transform import Rotation
+    rng = np.random.RandomState(seed)
+    f = lambda a: torch.as_tensor(a, dtype=torch.float32)  # noqa: E731
+    R = Rotation.from_euler('xyz', rng.uniform(-0.1, 0.1, (B, 3)) * [1, 1, 10]).as_matrix()
+    return f(rng.uniform(-0.5, 0.5, (B, 3)) * [1, 1, 0.1]), f(rng.uniform(-0.3, 0.3, (B, 3))), f(R), f(rng.uniform(-0.2, 0.2, (B, 3)))
+
+
+@pytest.mark.parametrize('integ', [0, 1])
+@pytest.mark.parametrize('N,n_tracks,stride', [(4, 2, 1), (32, 4, 7), (175, 2, 50)])
+def test_cost_rows_match_full_outputs(integ, N, n_tracks, stride):
+    """Path-cost kernel vs the full-output kernel on the same inputs: cost rows, decimated poses, per-rollout maps, a start
+    state, all lane mappings (one point per lane ... 64 x 4)."""
+    from monoforce_amd import synthetic as syn
+    from tests.test_rollout_gpu import make_dphysics
+    pts, masks = syn.robot_points_box(N, seed=N, n_tracks=n_tracks) if N > 4 else syn.robot_points_4()
+    B, T = 37, 120
+    dp = make_dphysics(pts, masks, integ, 0.1, 3.2)
+    z = torch.stack([syn.bump_terrain(syn.bump_params(3 + k % 3), 3.2, 0.1) * 0.5 for k in range(B)]).to(DEV)
+    mu = torch.stack([syn.wave_friction(3.2, 0.1, 0.5, 1.0, 1.0 + 0.1 * k, 0.9) for k in range(B)]).to(DEV)
+    ctrl = syn.varying_controls(B, T, seed=5).to(DEV)
+    st = tuple(t.to(DEV) for t in _start_state(B))
+    (Xs, _, Rs, _), (Fs, _) = dp(z, ctrl, state=tuple(t.clone() for t in st), friction=mu)
+    out = dp.rollout_costs(z, ctrl, state=st, friction=mu, pose_stride=stride)
+    rows = out['cost_rows']
+    assert rows.shape == (B, T, 4) and torch.equal(rows[..., :3], Rs[:, :, 2, :])
+    s_ref = torch.norm(Fs, dim=-1).std(dim=-1)
+    assert hp.rel_err(rows[..., 3].cpu(), s_ref.cpu()) <= 2e-6, hp.rel_err(rows[..., 3].cpu(), s_ref.cpu())
+    steps = out['pose_steps']
+    assert steps[-1] == T - 1 and steps.numel() == 1 + -(-(T - 1) // stride)
+    assert torch.equal(out['Xs'], Xs[:, steps]) and torch.equal(out['Rs'], Rs[:, steps])
+    assert torch.equal(st[0].cpu(), _start_state(B)[0])      # the caller's start state is untouched (the snap works on a copy)
