@@ -22,7 +22,9 @@ Extra objects on the JSON line:
                 per launch from rocprofv3 PMC passes of this same command (profiles/hbm_traffic.json; null if absent).
   cpu_baseline  the CPU oracle (oracle/dphysics_oracle.py, a torch-CPU port of the reference algorithm) timed on this
                 box's host cores on a bounded sample of the same workload.  Reported, not the target.
-  other_workloads  (default run, 1 GPU only) short runs of c2 and c3, same accounting.
+  other_workloads  (default run, 1 GPU only) short runs of c2 and c3, same accounting, and `shoot`: trajectory shooting of
+                16384 sampled control sequences on the same terrain through the kernel's path-cost mode (rollout + path
+                costs + argmin, end to end; monoforce_amd/planner.py).
 """
 import argparse
 import json
@@ -220,6 +222,31 @@ class Runner:
         return res, (N, T)
 
 
+def shoot_workload(r, T, N, integ, B=16384, iters=8):
+    """Sampling-based planning (monoforce_node.py:41-126): B control samples, one shared map, force path cost, argmin."""
+    from monoforce_amd import _timing
+    from monoforce_amd.planner import TrajectoryShooter, sample_controls
+    dev = r.dev
+    cfg, dp, _, _, z, mu, _ = build_problem(B, T, N, dev, integ, seed=0)
+    zd, md = z.to(dev), mu.to(dev)
+    c = sample_controls(B, cfg, dev, torch.Generator(device=dev).manual_seed(0))
+    sh = TrajectoryShooter(dp, n_trajs=B, cost='force')
+    for _ in range(3):
+        sh.shoot(zd, friction=md, controls=c)
+    torch.cuda.synchronize(dev)
+    _timing.start()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        out = sh.shoot(zd, friction=md, controls=c)        # int(argmin) inside synchronises every iteration, like the node
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    kms = float(np.mean(_timing.stop()['rollout_fwd_kernel']))
+    return {'value': B * T / (ms * 1e-3), 'unit': 'rollout-steps/s', 'ms_per_step': ms,
+            'workload': f'shoot: {B} sampled control sequences x T={T} x N={N}, one shared map, path-cost kernel + force cost + argmin',
+            'per_kernel': {'rollout_fwd_kernel': {'ms': kms, 'bytes_per_rollout_step': 8 + 16 + 32 * N,
+                                                  'GB/s': (8 + 16 + 32 * N) * B * T / (kms * 1e-3) / 1e9}}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -243,6 +270,7 @@ def main():
             o, _ = r.run(name, max(args.steps // 3, 5), 3)
             others[name] = {'value': o['value'], 'unit': 'rollout-steps/s', 'ms_per_step': o['ms_per_step'],
                             'workload': o['config']['workload'], 'per_kernel': o['roofline']['per_kernel']}
+        others['shoot'] = shoot_workload(r, T, N, args.integrator)
     if r.rank == 0:
         out = {'metric': 'rollout-steps/sec (batch x horizon) on 256x256 terrain', 'value': res['value'], 'unit': 'rollout-steps/s',
                'n_gpus': r.world, 'steps': res['steps'], 'warmup': res['warmup'], 'ms_per_step': res['ms_per_step'],
