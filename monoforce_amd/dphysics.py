@@ -92,6 +92,18 @@ def _is_shared_map(t):
     return t.dim() == 3 and (t.shape[0] == 1 or t.stride(0) == 0)
 
 
+def _default_state(controls, B):
+    """x = 0, xd = (v_0, 0, 0), R = I, omega = (0, 0, w_0) (dphysics.py:554-559) in four small launches instead of nine.
+    xd and omega stay differentiable functions of the first control (as in the reference); x and R share one buffer."""
+    buf = torch.zeros(12 * B, dtype=controls.dtype, device=controls.device)
+    x, R = buf[:3 * B].view(B, 3), buf[3 * B:].view(B, 3, 3)
+    R.view(B, 9)[:, ::4] = 1.0
+    first = controls[:, 0]
+    xd = torch.nn.functional.pad(first[:, 0:1], (0, 2))
+    w = torch.nn.functional.pad(first[:, 1:2], (2, 0))
+    return x, xd, R, w
+
+
 class _RolloutFn(torch.autograd.Function):
     """forward = mf_rollout_fwd_*; backward = mf_rollout_bwd_* (reverse-time adjoint of the same scan)."""
 
@@ -131,7 +143,8 @@ class _RolloutFn(torch.autograd.Function):
             ctx.mod, ctx.desc, ctx.keep = mod, desc, keep
             ctx.z_shape, ctx.mu_given = z.shape, mu is not None
             ctx.joint_angles = joint_angles          # constants of the rollout (no gradient), kept for the backward
-            ctx.save_for_backward(controls, x0.clone(), xd0, R0, w0, ts, Xraw, Xds, Rs, Om)
+            # x0 now holds the snapped start position; a caller-visible buffer is copied, the module's own default is not
+            ctx.save_for_backward(controls, x0 if mod._own_state else x0.clone(), xd0, R0, w0, ts, Xraw, Xds, Rs, Om)
         return outs
 
     @staticmethod
@@ -246,14 +259,9 @@ class DPhysics(torch.nn.Module):
         _scalar_suffix(dtype)        # float32 / float64 only: anything else is refused here, loudly
         controls = controls.to(device=dev, dtype=dtype)
 
-        if state is None:                                                            # (:554-559)
-            x = torch.zeros(batch_size, 3, dtype=dtype, device=dev)
-            xd = torch.zeros_like(x)
-            xd[:, 0] = controls[:, 0, 0]
-            R = torch.eye(3, dtype=dtype, device=dev).repeat(batch_size, 1, 1)
-            omega = torch.zeros_like(x)
-            omega[:, 2] = controls[:, 0, 1]
-            state = (x, xd, R, omega)
+        own_state = state is None
+        if own_state:                                                                # (:554-559)
+            state = _default_state(controls, batch_size)
         if friction is not None:
             friction = friction.to(device=dev, dtype=dtype)
         self.z_grid = z_grid
@@ -283,6 +291,7 @@ class DPhysics(torch.nn.Module):
         want_grad = torch.is_grad_enabled() and any(
             t is not None and t.requires_grad for t in (z_grid, friction, controls, xd0, R0, w0))
         want_forces = self.return_forces or self.precise or dtype != torch.float32 or ja_dev is not None
+        self._own_state = own_state
         outs = _RolloutFn.apply(self, z_grid, friction, controls.contiguous(), x0, xd0, R0, w0, ts, want_grad, ja_dev, want_forces)
         if not aliased:
             with torch.no_grad():
@@ -316,10 +325,7 @@ class DPhysics(torch.nn.Module):
         N_ts = min(int(cfg.traj_sim_time / cfg.dt), controls.shape[1])
         assert controls.shape == (B, N_ts, 2), f'Controls shape {controls.shape} != {(B, N_ts, 2)}'
         if state is None:                                                            # (dphysics.py:554-559)
-            x0 = torch.zeros(B, 3, device=dev)
-            xd0 = torch.zeros_like(x0); xd0[:, 0] = controls[:, 0, 0]
-            R0 = torch.eye(3, device=dev).repeat(B, 1, 1)
-            w0 = torch.zeros_like(x0); w0[:, 2] = controls[:, 0, 1]
+            x0, xd0, R0, w0 = _default_state(controls, B)
         else:
             x0 = state[0].detach().to(device=dev, dtype=torch.float32).clone()       # the snap writes x0.z: keep the caller's
             xd0, R0, w0 = (t.detach().to(device=dev, dtype=torch.float32).contiguous() for t in state[1:])

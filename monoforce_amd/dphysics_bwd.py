@@ -37,11 +37,16 @@ def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf):
         # ~64 rollouts per copy (same-address atomics serialise), between GRAD_COPIES and 256 copies
         copies = max(1, min(max(GRAD_COPIES, B // 64), 256, B))
         desc.grad_copies = copies
-        gz = torch.zeros((copies,) + tuple(z.shape), dtype=dt, device=dev)
-        gmu = torch.zeros_like(gz) if want_gmu else None
+        # one zero fill for [gz copies | gmu copies | the zero row absent upstream gradients point at]
+        n_maps = 2 if want_gmu else 1
+        pool = torch.zeros(n_maps * copies * z.numel() + 16, dtype=dt, device=dev)
+        maps = pool[:n_maps * copies * z.numel()].view((n_maps, copies) + tuple(z.shape))
+        gz, gmu, zero_row = maps[0], (maps[1] if want_gmu else None), pool[-16:]
     else:
+        maps = None
         gz = torch.zeros_like(z)
         gmu = torch.zeros_like(mu) if want_gmu else None
+        zero_row = torch.zeros(16, dtype=dt, device=dev)
     gcontrols = torch.empty_like(controls)
     gxd0, gR0, gw0 = torch.empty_like(xd0), torch.empty_like(R0), torch.empty_like(w0)
     bufs = _lib.MfRolloutBwdBufs(
@@ -49,7 +54,7 @@ def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf):
         part=_lib.ptr(mod._part_dev(dev)), x_init=_lib.ptr(x_init), xd0=_lib.ptr(xd0), R0=_lib.ptr(R0), w0=_lib.ptr(w0),
         Xraw=_lib.ptr(Xraw), Xds=_lib.ptr(Xds), Rs=_lib.ptr(Rs), Omegas=_lib.ptr(Om),
         gXs=_lib.ptr(ups[0]), gXds=_lib.ptr(ups[1]), gRs=_lib.ptr(ups[2]), gOmegas=_lib.ptr(ups[3]),
-        gFs=_lib.ptr(ups[4]), gFf=_lib.ptr(ups[5]), zeros=_lib.ptr(torch.zeros(16, dtype=dt, device=dev)),
+        gFs=_lib.ptr(ups[4]), gFf=_lib.ptr(ups[5]), zeros=_lib.ptr(zero_row),
         gz=_lib.ptr(gz), gmu=_lib.ptr(gmu), gcontrols=_lib.ptr(gcontrols), gx0=None,
         gxd0=_lib.ptr(gxd0), gR0=_lib.ptr(gR0), gw0=_lib.ptr(gw0), joint_angles=_lib.ptr(getattr(ctx, 'joint_angles', None)))
     fn = getattr(_lib.lib(), 'mf_rollout_bwd_' + _scalar_suffix(dt))
@@ -57,8 +62,8 @@ def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf):
         _lib.check(fn(C.byref(desc), C.byref(bufs), _stream_ptr(dev)), 'mf_rollout_bwd')
 
     if desc.map_shared:
-        gz = gz.sum(0)
-        gmu = None if gmu is None else gmu.sum(0)
+        summed = maps.sum(1)                   # one reduction for both maps
+        gz, gmu = summed[0], (summed[1] if want_gmu else None)
 
     def to_input_shape(g, shape):
         """Gradient of a map input.  A shared map ([1,H,W], or one [H,W] map expanded over the batch) gets ONE [H,W]

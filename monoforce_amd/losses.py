@@ -88,7 +88,7 @@ class _FusedPhysicsLoss(torch.autograd.Function):
                                                                          _lib.ptr(near), _lib.ptr(partial), stream), 'mf_physics_loss_fwd')
         ctx.save_for_backward(X_pred, Xg, ts, near)
         ctx.desc, ctx.sfx = desc, sfx
-        return partial.sum() / (B * T2 * 3)
+        return partial.sum() * (1.0 / (B * T2 * 3))
 
     @staticmethod
     def backward(ctx, gloss):
