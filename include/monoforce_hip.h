@@ -8,11 +8,15 @@
  * Reference interfaces replaced (paths under /root/reference/monoforce/src/monoforce/models/):
  *   mf_rollout_fwd_*   traj_predictor/dphysics.py:530-594  DPhysics.dphysics()  = forward_kinematics (:172-272)
  *                      + dynamics (:467-497) / dynamics_odeint (:499-528) + interpolate_grid (:385-455)
+ *                      + update_joints (:326-358); in path-cost mode also the reductions the planning nodes apply to its
+ *                      outputs (monoforce_ros/nodes/monoforce_node.py:91, diff_physics.py:263-266)
  *   mf_rollout_bwd_*   the autograd graph the reference builds through the same functions (loss.backward(),
  *                      scripts/fit_terrain.py:53-62, scripts/train.py:399-406)
  *   mf_bev_splat_*     terrain_encoder/lss.py:238-280 LiftSplatShoot.voxel_pooling() + terrain_encoder/utils.py:144-181
  *                      (cumsum_trick / QuickCumsum forward and backward)
- *   mf_lss_geometry_*  terrain_encoder/lss.py:204-224 LiftSplatShoot.get_geometry()
+ *   mf_physics_loss_*  losses.py:102-127 physics_loss (position term) and its gradient, on the nearest-time-stamp
+ *                      subset of the predicted poses
+ * (LiftSplatShoot.get_geometry(), lss.py:204-224, is a 3x3 transform of 120 k points: it stays plain torch.)
  */
 #ifndef MONOFORCE_HIP_H
 #define MONOFORCE_HIP_H

@@ -74,7 +74,7 @@ def lib():
                 L.mf_version.restype = C.c_char_p
                 for name in SYMBOLS:
                     fn = getattr(L, name)   # AttributeError if the build is stale
-                    if name.startswith(('mf_rollout', 'mf_bev', 'mf_lss', 'mf_physics')):
+                    if name.startswith(('mf_rollout', 'mf_bev', 'mf_physics')):
                         fn.restype = C.c_int
                 L.mf_bev_splat_workspace_bytes.restype = C.c_size_t
                 _lib = L
