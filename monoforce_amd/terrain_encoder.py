@@ -139,14 +139,19 @@ class LiftSplatShoot(nn.Module):
 
     def get_geometry(self, rots, trans, intrins, post_rots, post_trans):
         """Ego-frame (x,y,z) of the frustum points, B x N x D x fH x fW x 3 (lss.py:204-224): undo the image augmentation,
-        un-project through the pinhole model, camera -> ego.  Tiny (3x3 algebra on ~1e5 points); plain torch ops in the
-        reference's order so the float32 coordinates -- and hence the voxel indices -- agree."""
+        un-project through the pinhole model, camera -> ego.  Tiny (3x3 algebra on ~1e5 points), the reference's steps in the
+        reference's order.  The two 3x3-times-point products are written as broadcast multiply + sum over the last axis: as
+        `matmul` they become a batched GEMM with 1e5 3x1 right-hand sides, which the GEMM library runs at 1.6 ms apiece
+        (3.2 ms of a 27 ms train step, measured) against ~10 us for the elementwise form."""
         B, N, _ = trans.shape
+
+        def apply(mats, p):        # [B,N,3,3] x [B,N,D,fH,fW,3] -> [B,N,D,fH,fW,3]:  out_i = sum_j M_ij p_j
+            return (mats.view(B, N, 1, 1, 1, 3, 3) * p.unsqueeze(-2)).sum(-1)
+
         pts = self.frustum - post_trans.view(B, N, 1, 1, 1, 3)
-        pts = torch.inverse(post_rots).view(B, N, 1, 1, 1, 3, 3).matmul(pts.unsqueeze(-1))
-        pts = torch.cat((pts[..., :2, :] * pts[..., 2:3, :], pts[..., 2:3, :]), 5)
-        combine = rots.matmul(torch.inverse(intrins))
-        pts = combine.view(B, N, 1, 1, 1, 3, 3).matmul(pts).squeeze(-1)
+        pts = apply(torch.inverse(post_rots), pts)
+        pts = torch.cat((pts[..., :2] * pts[..., 2:3], pts[..., 2:3]), 5)
+        pts = apply(rots.matmul(torch.inverse(intrins)), pts)
         pts += trans.view(B, N, 1, 1, 1, 3)
         return pts
 

@@ -61,7 +61,9 @@ class EncoderTrainStep:
         k = max(int(round(dphysics.dphys_cfg.grid_res / float(encoder.dx[0]))), 1)
         self.terrain_preproc = torch.nn.AvgPool2d(kernel_size=k, stride=k) if k > 1 else torch.nn.Identity()
         self.w = (geom_weight, terrain_weight, phys_weight)
-        self.opt = torch.optim.Adam(encoder.parameters(), lr=lr, betas=(0.8, 0.999), weight_decay=1e-7)   # train.py:374-375
+        # train.py:374-375; the fused (single multi-tensor kernel) implementation where the parameters live on the GPU
+        on_gpu = all(p.is_cuda for p in encoder.parameters())
+        self.opt = torch.optim.Adam(encoder.parameters(), lr=lr, betas=(0.8, 0.999), weight_decay=1e-7, fused=on_gpu)
         self.params = [p for p in encoder.parameters() if p.requires_grad]
         self.bucket = None
 
@@ -81,7 +83,7 @@ class EncoderTrainStep:
         return l_geom, l_terr, l_phys
 
     def step(self, batch):
-        self.opt.zero_grad(set_to_none=False)
+        self.opt.zero_grad(set_to_none=True)
         l_geom, l_terr, l_phys = self.losses(batch)
         loss = self.w[0] * l_geom + self.w[1] * l_terr + self.w[2] * l_phys
         loss.backward()
