@@ -130,6 +130,11 @@ int mf_rollout_force_stride(const MfRolloutDesc* desc);
 int mf_rollout_fwd_f32(const MfRolloutDesc* desc, const MfRolloutFwdBufs* bufs, void* hip_stream);
 int mf_rollout_fwd_f64(const MfRolloutDesc* desc, const MfRolloutFwdBufs* bufs, void* hip_stream);
 
+/* The start state DPhysics uses when the caller gives none (dphysics.py:554-559): x = 0, xd = (v_0, 0, 0), R = I,
+ * omega = (0, 0, w_0) with (v_0, w_0) = controls[b][0]; one launch.  controls S[B][T][2]; outputs S[B][3], [3], [3][3], [3]. */
+int mf_rollout_default_state_f32(int32_t B, int32_t T, const float* controls, float* x0, float* xd0, float* R0, float* w0, void* hip_stream);
+int mf_rollout_default_state_f64(int32_t B, int32_t T, const double* controls, double* x0, double* xd0, double* R0, double* w0, void* hip_stream);
+
 /* Device buffers of the backward rollout (reverse-time adjoint of the same scan; per-step intermediates are
  * recomputed from the saved per-step states, which are the forward's own outputs).  `desc` must be the forward's.
  * Upstream gradients use the outputs' layout and may each be NULL (= zeros).  Gradient outputs: gz/gmu are

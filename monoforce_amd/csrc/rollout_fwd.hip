@@ -103,3 +103,34 @@ extern "C" int mf_rollout_fwd_f64(const MfRolloutDesc* d, const MfRolloutFwdBufs
   if (p->joint_angles) return mf::launch_rollout_fwd<double, false, true>(a, m, d->integrator, block, (hipStream_t)s);
   return mf::launch_rollout_fwd<double, false>(a, m, d->integrator, block, (hipStream_t)s);   // float64 is always exact
 }
+
+namespace mf {
+template <typename S>
+__global__ void default_state_kernel(int B, int T, const S* __restrict__ controls, S* __restrict__ x0, S* __restrict__ xd0,
+                                     S* __restrict__ R0, S* __restrict__ w0) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const S v = controls[(size_t)b * T * 2 + 0], w = controls[(size_t)b * T * 2 + 1];
+  const S zero = (S)0, one = (S)1;
+  x0[b * 3 + 0] = zero; x0[b * 3 + 1] = zero; x0[b * 3 + 2] = zero;
+  xd0[b * 3 + 0] = v; xd0[b * 3 + 1] = zero; xd0[b * 3 + 2] = zero;
+  w0[b * 3 + 0] = zero; w0[b * 3 + 1] = zero; w0[b * 3 + 2] = w;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) R0[b * 9 + c] = (c % 4 == 0) ? one : zero;
+}
+template <typename S>
+static int default_state(int B, int T, const S* controls, S* x0, S* xd0, S* R0, S* w0, void* s) {
+  MF_REQUIRE(B > 0 && T > 0 && controls && x0 && xd0 && R0 && w0, MF_ERR_INVALID, "rollout_default_state: bad argument");
+  hipLaunchKernelGGL((default_state_kernel<S>), dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)s, B, T, controls, x0, xd0, R0, w0);
+  hipError_t e = hipGetLastError();
+  MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("rollout_default_state launch: ") + hipGetErrorString(e));
+  return MF_OK;
+}
+}  // namespace mf
+
+extern "C" int mf_rollout_default_state_f32(int32_t B, int32_t T, const float* controls, float* x0, float* xd0, float* R0, float* w0, void* s) {
+  return mf::default_state<float>(B, T, controls, x0, xd0, R0, w0, s);
+}
+extern "C" int mf_rollout_default_state_f64(int32_t B, int32_t T, const double* controls, double* x0, double* xd0, double* R0, double* w0, void* s) {
+  return mf::default_state<double>(B, T, controls, x0, xd0, R0, w0, s);
+}

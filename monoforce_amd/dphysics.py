@@ -95,6 +95,14 @@ def _is_shared_map(t):
 def _default_state(controls, B):
     """x = 0, xd = (v_0, 0, 0), R = I, omega = (0, 0, w_0) (dphysics.py:554-559) in four small launches instead of nine.
     xd and omega stay differentiable functions of the first control (as in the reference); x and R share one buffer."""
+    if not (controls.requires_grad and torch.is_grad_enabled()) and controls.is_cuda and controls.is_contiguous():
+        buf = torch.empty(18 * B, dtype=controls.dtype, device=controls.device)        # one launch (mf_rollout_default_state_*)
+        x, xd, R, w = buf[:3 * B].view(B, 3), buf[3 * B:6 * B].view(B, 3), buf[6 * B:15 * B].view(B, 3, 3), buf[15 * B:].view(B, 3)
+        fn = getattr(_lib.lib(), 'mf_rollout_default_state_' + _scalar_suffix(controls.dtype))
+        with torch.cuda.device(controls.device):
+            _lib.check(fn(C.c_int32(B), C.c_int32(controls.shape[1]), _lib.ptr(controls), _lib.ptr(x), _lib.ptr(xd), _lib.ptr(R), _lib.ptr(w),
+                          _stream_ptr(controls.device)), 'mf_rollout_default_state')
+        return x, xd, R, w
     buf = torch.zeros(12 * B, dtype=controls.dtype, device=controls.device)
     x, R = buf[:3 * B].view(B, 3), buf[3 * B:].view(B, 3, 3)
     R.view(B, 9)[:, ::4] = 1.0
