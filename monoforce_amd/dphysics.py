@@ -147,6 +147,8 @@ class _RolloutFn(torch.autograd.Function):
         if tm:
             outs = tuple(o.transpose(0, 1) for o in outs)
         ctx.n_force_outs = 2 if want_forces else 0
+        # outputs the loss does not touch arrive as None in backward (= NULL upstream pointers), not as zero-filled tensors
+        ctx.set_materialize_grads(False)
         if want_grad:
             ctx.mod, ctx.desc, ctx.keep = mod, desc, keep
             ctx.z_shape, ctx.mu_given = z.shape, mu is not None

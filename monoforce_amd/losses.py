@@ -89,6 +89,7 @@ class _FusedPhysicsLoss(torch.autograd.Function):
             _lib.check(getattr(_lib.lib(), 'mf_physics_loss_fwd_' + sfx)(C.byref(desc), _lib.ptr(X_pred), _lib.ptr(Xg), _lib.ptr(ts),
                                                                          _lib.ptr(near), _lib.ptr(partial), stream), 'mf_physics_loss_fwd')
         ctx.save_for_backward(X_pred, Xg, ts, near)
+        ctx.set_materialize_grads(False)
         ctx.desc, ctx.sfx = desc, sfx
         return partial.sum() * (1.0 / (B * T2 * 3))
 
@@ -96,6 +97,8 @@ class _FusedPhysicsLoss(torch.autograd.Function):
     def backward(ctx, gloss):
         import ctypes as C
         from . import _lib, _timing
+        if gloss is None:
+            return None, None, None, None, None
         X_pred, Xg, ts, near = ctx.saved_tensors
         gX = torch.zeros_like(X_pred)                     # preserve_format: same (dense) strides as X_pred
         if gX.stride() != X_pred.stride():
