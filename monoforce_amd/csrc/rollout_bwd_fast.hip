@@ -3,6 +3,6 @@
 
 namespace mf {
 int launch_rollout_bwd_fast_f32(const RolloutBwdArgs<float>& a, LaneMap m, int integ, int block, hipStream_t st) {
-  return launch_rollout_bwd<float, true>(a, m, integ, block, st);
+  return launch_rollout_bwd<float, true, false, false>(a, m, integ, block, st);   // plain flush: fewest instructions per step
 }
 }  // namespace mf

@@ -52,7 +52,7 @@ __device__ __forceinline__ S* at32(S* base, unsigned elem) {
     (o)[2] = (a)[0] * (b)[1] - (a)[1] * (b)[0]; \
   } while (0)
 
-template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS = false>
+template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS = false, bool CARRY = true>
 __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S> a) {
   using M = Mth<S, FAST>;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -192,13 +192,18 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
   // coherent): every one is a fabric transaction (PMC: WRITE_SIZE = 32 B per atomic, 0.5 GB per launch at B = 1024), and
   // same-address ones serialise.  A robot moves <= 0.2 cell per step, so consecutive steps of a point hit the SAME four
   // cells: their contributions are accumulated in registers (acc_*) and only written when the point changes cell
-  // (about every 5th step).  The write is deferred to the next iteration (st_*), after that step's loads were issued.
+  // (about every 5th step).  A move to an edge-adjacent cell keeps two of the four cells of the footprint: those two
+  // accumulators are carried over to their new slots and only the two cells left behind are written (half the atomics;
+  // measured 9.5 -> 5.5 ms at B = 65536).  The write is deferred to the next iteration (st_*), after that step's loads.
   unsigned acc_idx[PPL][4], st_idx[PPL][4];
   S acc_z[PPL][4], acc_m[PPL][4], st_z[PPL][4], st_m[PPL][4];
-  bool st_pending[PPL];
+  bool st_pending[PPL], st_all[PPL];      // slots 0, 1 of the stash are pending / all four are (the point jumped)
+  // The carry-over costs ~55 instructions per step: a loss while a launch is bound by the instruction stream of its few
+  // waves (B = 1024, N = 4: 0.91 -> 0.93 ms), a gain as soon as the atomics matter (B = 4096: 1.00 -> 0.94 ms).
+  constexpr bool carry_over = CARRY;      // compile-time: the float32 fast-math kernels exist in both forms, the host picks
 #pragma unroll
   for (int j = 0; j < PPL; ++j) {
-    st_pending[j] = false;
+    st_pending[j] = st_all[j] = false;
 #pragma unroll
     for (int q = 0; q < 4; ++q) { acc_idx[j][q] = st_idx[j][q] = 0u; acc_z[j][q] = acc_m[j][q] = st_z[j][q] = st_m[j][q] = zero; }
   }
@@ -207,13 +212,21 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
     for (int j = 0; j < PPL; ++j) {
       if (st_pending[j]) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) atomic_add(at32(gzmap, goff + st_idx[j][q]), st_z[j][q]);
+        for (int q = 0; q < 2; ++q) atomic_add(at32(gzmap, goff + st_idx[j][q]), st_z[j][q]);
         if (want_gmu) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) atomic_add(at32(gmumap, goff + st_idx[j][q]), st_m[j][q]);
+          for (int q = 0; q < 2; ++q) atomic_add(at32(gmumap, goff + st_idx[j][q]), st_m[j][q]);
+        }
+        if (st_all[j]) {
+#pragma unroll
+          for (int q = 2; q < 4; ++q) atomic_add(at32(gzmap, goff + st_idx[j][q]), st_z[j][q]);
+          if (want_gmu) {
+#pragma unroll
+            for (int q = 2; q < 4; ++q) atomic_add(at32(gmumap, goff + st_idx[j][q]), st_m[j][q]);
+          }
         }
       }
-      st_pending[j] = false;
+      st_pending[j] = st_all[j] = false;
     }
   };
 
@@ -533,14 +546,58 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
           const unsigned ni[4] = {(unsigned)c.ic, (unsigned)c.i_f, (unsigned)c.il, (unsigned)c.ifl};
           const S nz[4] = {gzq * w00 - ggx - ggy, gzq * w01 + ggx, gzq * w10 + ggy, gzq * w11};
           const S nm[4] = {gmuq[j] * w00, gmuq[j] * w01, gmuq[j] * w10, gmuq[j] * w11};
-          const bool same = !act[j] || (ni[0] == acc_idx[j][0] && ni[1] == acc_idx[j][1] && ni[2] == acc_idx[j][2] && ni[3] == acc_idx[j][3]);
-          st_pending[j] = !same;                 // the stash was flushed at the top of this iteration, so it is free
+          if (carry_over) {   // compile-time
+            // footprint slots: 0 = (ix, iy), 1 = (ix+1, iy), 2 = (ix, iy+1), 3 = (ix+1, iy+1).  Which old slots do the new ones
+            // coincide with?  (Index equality, so it also holds where the flat-index clamp folds cells onto each other.)
+            // (non-short-circuit & and | throughout: everything below must stay straight-line selects, no branches)
+            const unsigned o0 = acc_idx[j][0], o1 = acc_idx[j][1], o2 = acc_idx[j][2], o3 = acc_idx[j][3];
+            const bool same = !act[j] | ((ni[0] == o0) & (ni[1] == o1) & (ni[2] == o2) & (ni[3] == o3));
+            const bool cxp = (ni[0] == o1) & (ni[2] == o3), cxm = (ni[1] == o0) & (ni[3] == o2);
+            const bool cyp = (ni[0] == o2) & (ni[1] == o3), cym = (ni[2] == o0) & (ni[3] == o1);
+            const bool xp = !same & cxp;                          // moved one cell in +x: new 0,2 = old 1,3
+            const bool xm = !same & !cxp & cxm;                   // -x: new 1,3 = old 0,2
+            const bool yp = !same & !cxp & !cxm & cyp;            // +y: new 0,1 = old 2,3
+            const bool ym = !same & !cxp & !cxm & !cyp & cym;     // -y: new 2,3 = old 0,1
+            const bool jump = !same & !cxp & !cxm & !cyp & !cym;
+            st_pending[j] = !same;                 // the stash was flushed at the top of this iteration, so it is free
+            st_all[j] = jump;
+            // the cells left behind go to stash slots 0, 1 (a jump leaves all four: slots 2, 3 as well):
+            //   slot 0 <- old 1 (xm), old 2 (ym), else old 0 (xp, yp, jump);  slot 1 <- old 2 (xp), old 3 (xm, ym), else old 1 (yp, jump)
+            const bool e13 = xm | ym;
+            st_idx[j][0] = xm ? o1 : (ym ? o2 : o0);
+            st_z[j][0] = xm ? acc_z[j][1] : (ym ? acc_z[j][2] : acc_z[j][0]);
+            st_m[j][0] = xm ? acc_m[j][1] : (ym ? acc_m[j][2] : acc_m[j][0]);
+            st_idx[j][1] = xp ? o2 : (e13 ? o3 : o1);
+            st_z[j][1] = xp ? acc_z[j][2] : (e13 ? acc_z[j][3] : acc_z[j][1]);
+            st_m[j][1] = xp ? acc_m[j][2] : (e13 ? acc_m[j][3] : acc_m[j][1]);
+            st_idx[j][2] = o2; st_z[j][2] = acc_z[j][2]; st_m[j][2] = acc_m[j][2];
+            st_idx[j][3] = o3; st_z[j][3] = acc_z[j][3]; st_m[j][3] = acc_m[j][3];
+            // carried-over accumulators for the new slots
+            const S cz[4] = {same ? acc_z[j][0] : xp ? acc_z[j][1] : yp ? acc_z[j][2] : zero,
+                             same ? acc_z[j][1] : xm ? acc_z[j][0] : yp ? acc_z[j][3] : zero,
+                             same ? acc_z[j][2] : xp ? acc_z[j][3] : ym ? acc_z[j][0] : zero,
+                             same ? acc_z[j][3] : xm ? acc_z[j][2] : ym ? acc_z[j][1] : zero};
+            const S cm[4] = {same ? acc_m[j][0] : xp ? acc_m[j][1] : yp ? acc_m[j][2] : zero,
+                             same ? acc_m[j][1] : xm ? acc_m[j][0] : yp ? acc_m[j][3] : zero,
+                             same ? acc_m[j][2] : xp ? acc_m[j][3] : ym ? acc_m[j][0] : zero,
+                             same ? acc_m[j][3] : xm ? acc_m[j][2] : ym ? acc_m[j][1] : zero};
+  #pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              acc_idx[j][q] = act[j] ? ni[q] : acc_idx[j][q];
+              acc_z[j][q] = cz[q] + nz[q];
+              acc_m[j][q] = cm[q] + nm[q];
+            }
+          } else {            // plain form: any change of cell writes all four accumulators (fewest instructions per step)
+            const bool same = !act[j] | ((ni[0] == acc_idx[j][0]) & (ni[1] == acc_idx[j][1]) & (ni[2] == acc_idx[j][2]) & (ni[3] == acc_idx[j][3]));
+            st_pending[j] = !same;
+            st_all[j] = !same;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            st_idx[j][q] = acc_idx[j][q]; st_z[j][q] = acc_z[j][q]; st_m[j][q] = acc_m[j][q];
-            acc_idx[j][q] = same ? acc_idx[j][q] : ni[q];
-            acc_z[j][q] = same ? acc_z[j][q] + nz[q] : nz[q];
-            acc_m[j][q] = same ? acc_m[j][q] + nm[q] : nm[q];
+            for (int q = 0; q < 4; ++q) {
+              st_idx[j][q] = acc_idx[j][q]; st_z[j][q] = acc_z[j][q]; st_m[j][q] = acc_m[j][q];
+              acc_idx[j][q] = same ? acc_idx[j][q] : ni[q];
+              acc_z[j][q] = same ? acc_z[j][q] + nz[q] : nz[q];
+              acc_m[j][q] = same ? acc_m[j][q] + nm[q] : nm[q];
+            }
           }
         }
         S zfx, zfy, mfx, mfy;
@@ -656,7 +713,7 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
   }
 }
 
-template <typename S, bool FAST, bool JOINTS = false>
+template <typename S, bool FAST, bool JOINTS = false, bool CARRY = true>
 int launch_rollout_bwd(const RolloutBwdArgs<S>& a, LaneMap m, int integ, int block, hipStream_t st) {
   const long long threads = (long long)a.B * m.G;
   const unsigned grid = (unsigned)((threads + block - 1) / block);
@@ -665,9 +722,9 @@ int launch_rollout_bwd(const RolloutBwdArgs<S>& a, LaneMap m, int integ, int blo
   if (!launched && m.G == G_ && m.PPL == P_) {                                                                                     \
     launched = true;                                                                                                               \
     if (integ == MF_INTEG_DYNAMICS)                                                                                                \
-      hipLaunchKernelGGL((rollout_bwd_kernel<S, G_, P_, MF_INTEG_DYNAMICS, FAST, JOINTS>), dim3(grid), dim3(block), 0, st, a);      \
+      hipLaunchKernelGGL((rollout_bwd_kernel<S, G_, P_, MF_INTEG_DYNAMICS, FAST, JOINTS, CARRY>), dim3(grid), dim3(block), 0, st, a);      \
     else                                                                                                                           \
-      hipLaunchKernelGGL((rollout_bwd_kernel<S, G_, P_, MF_INTEG_ODEINT_EULER, FAST, JOINTS>), dim3(grid), dim3(block), 0, st, a);  \
+      hipLaunchKernelGGL((rollout_bwd_kernel<S, G_, P_, MF_INTEG_ODEINT_EULER, FAST, JOINTS, CARRY>), dim3(grid), dim3(block), 0, st, a);  \
   }
   MF_CASE(4, 1) MF_CASE(8, 1) MF_CASE(16, 1) MF_CASE(32, 1) MF_CASE(64, 1) MF_CASE(64, 2) MF_CASE(64, 4) MF_CASE(64, 8)
   if constexpr (!JOINTS) {   // the 4-points-per-lane mappings are a tuning / test option of the rigid-body kernels
@@ -680,8 +737,9 @@ int launch_rollout_bwd(const RolloutBwdArgs<S>& a, LaneMap m, int integ, int blo
   return MF_OK;
 }
 
-// defined in rollout_bwd_fast.hip
+// defined in rollout_bwd_fast.hip (plain flush) and rollout_bwd_carry_fast.hip (accumulator carry-over)
 int launch_rollout_bwd_fast_f32(const RolloutBwdArgs<float>& a, LaneMap m, int integ, int block, hipStream_t st);
+int launch_rollout_bwd_carry_fast_f32(const RolloutBwdArgs<float>& a, LaneMap m, int integ, int block, hipStream_t st);
 // defined in rollout_bwd_joints.hip (exact arithmetic, like the articulated forward)
 int launch_rollout_bwd_joints_f32(const RolloutBwdArgs<float>& a, LaneMap m, int integ, int block, hipStream_t st);
 int launch_rollout_bwd_joints_f64(const RolloutBwdArgs<double>& a, LaneMap m, int integ, int block, hipStream_t st);
