@@ -16,9 +16,10 @@
 //
 // Memory: map cells are gathered straight from global memory (both maps are read-only; 2 x 256 x 256 x 4 B = 512 KiB lives
 // in every XCD's L2, the handful of cells under a slowly moving robot in the CU's L1 -- DESIGN.md discusses why an LDS
-// tile does not pay).  Outputs are time-major by default: the rows a wave writes in one step are contiguous.  The stores
-// of step n-1 are issued right AFTER the gathers of step n: CDNA's vmcnt counts loads and stores in order, so a wait for
-// the gathers then never includes the previous step's stores.
+// tile does not pay).  Outputs are time-major by default: the rows a wave writes in one step are contiguous.  CDNA's vmcnt
+// retires loads and stores in order, so a wait for any load is a wait for every store issued before it: each step issues
+// ALL its loads first, then the (non-temporal) stores of the previous row, and the waits are vmcnt(k >= number of stores).
+// Variants: JOINTS (articulated body), FORCES = false (states only), COST (path-cost rows + decimated poses).
 #pragma once
 #include "rollout_common.h"
 
