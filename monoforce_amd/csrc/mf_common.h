@@ -53,6 +53,47 @@ __device__ __forceinline__ S group_sum(S v) {
   return v;
 }
 
+// Group reductions of a rollout kernel.  Up to 64 lanes per rollout this is group_sum<G> (DPP / lane permutes, stateless).
+// Larger bodies at small batch sizes spread ONE rollout over G / 64 waves of a workgroup (blockDim = G): every wave
+// all-reduces its 64 lanes, writes the partial to LDS, one s_barrier, and every lane adds the G / 64 partials in a fixed
+// order (deterministic).  Two LDS slots alternate: a wave can run at most one barrier ahead of the slowest one, so when it
+// writes slot p again every wave has finished reading it.  All threads of the workgroup must make the same calls.
+constexpr int kGroupSumMaxValues = 24;   // most values one sum_n() call reduces (the backward's 23 adjoint components)
+template <int G, typename S>
+struct GroupSum {
+  static constexpr int NW = G > 64 ? G / 64 : 1;
+  S* lds = nullptr;      // 2 * NW * kGroupSumMaxValues scalars of shared memory when G > 64
+  unsigned par = 0;
+  __device__ __forceinline__ S sum(S v) {
+    if (G <= 64) return group_sum<(G <= 64 ? G : 64)>(v);
+    S a[1] = {v};
+    sum_n<1>(a);
+    return a[0];
+  }
+  template <int K>
+  __device__ __forceinline__ void sum_n(S (&v)[K]) {
+    static_assert(K <= kGroupSumMaxValues, "raise kGroupSumMaxValues");
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = group_sum<(G <= 64 ? G : 64)>(v[k]);
+    if (G <= 64) return;
+    S* slot = lds + par * (NW * kGroupSumMaxValues);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) slot[wave * kGroupSumMaxValues + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      S t = slot[k];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) t += slot[w * kGroupSumMaxValues + k];
+      v[k] = t;
+    }
+    par ^= 1u;
+  }
+};
+
 // ---------------------------------------------------------------------------------------------------------
 // scalar helpers, overloaded on the arithmetic type
 // ---------------------------------------------------------------------------------------------------------

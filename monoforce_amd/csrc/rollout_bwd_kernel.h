@@ -61,6 +61,10 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
   if (b >= a.B) return;
   const S one = (S)1, zero = (S)0;
   const int HW = a.H * a.W, last = HW - 1;
+  // group reductions; a rollout spread over several waves (G > 64: one workgroup = one rollout) exchanges through LDS
+  __shared__ S gs_lds[G > 64 ? 2 * (G / 64) * kGroupSumMaxValues : 1];
+  GroupSum<G, S> gs;
+  gs.lds = gs_lds;
   // uniform base pointers + 32-bit element offsets (host guarantees < 4 GiB per array): scalar-base loads and atomics
   const unsigned moff = a.map_shared ? 0u : (unsigned)b * (unsigned)HW;
   const S* zmap = a.z;
@@ -250,7 +254,7 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
     for (int c = 0; c < 9; ++c) R[c] = cur.R[c];
     const S cv = cur.cv, cw = cur.cw;
     // the articulated body of this step: a function of the joint angles only, constant w.r.t. everything differentiated
-    if (JOINTS) articulate_body<S, G, PPL>(a.joint_angles + ((size_t)b * a.T + n) * 4, a.joint_xyz, a.mass / (S)a.N, P0, part, act, P, Iv);
+    if (JOINTS) articulate_body<S, G, PPL>(gs, a.joint_angles + ((size_t)b * a.T + n) * 4, a.joint_xyz, a.mass / (S)a.N, P0, part, act, P, Iv);
 
     // ---------------------------------------------------------------------------------------------------
     // forward recompute (identical arithmetic to rollout_fwd.hip)
@@ -303,7 +307,7 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
       Aj[j] = a.k * dh + a.damp * vn;
       F0[j][0] = -(Aj[j] * nrm[j][0]); F0[j][1] = -(Aj[j] * nrm[j][1]); F0[j][2] = -(Aj[j] * nrm[j][2]);
     }
-    csum = group_sum<G>(csum);
+    csum = gs.sum(csum);
 
     const S coln = M::sqrt(R[0] * R[0] + R[3] * R[3] + R[6] * R[6]);
     const S el = mf_max(coln, (S)1e-6);
@@ -340,8 +344,7 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
       sTau[1] += r[j][2] * f[0] - r[j][0] * f[2];
       sTau[2] += r[j][0] * f[1] - r[j][1] * f[0];
     }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) sTau[c] = group_sum<G>(sTau[c]);
+    gs.sum_n(sTau);
     S wraw[3], wd[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -525,7 +528,7 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
         gn[j][c] += gvn * vp[j][c];
       }
     }
-    gS = group_sum<G>(gS);
+    gS = gs.sum(gS);
 
     S gx_[3] = {zero, zero, zero}, gxd_[3] = {zero, zero, zero}, gw_[3] = {zero, zero, zero}, gR_[9];
 #pragma unroll
@@ -626,17 +629,18 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
         }
       }
     }
+    S red[23];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      lx[c] += group_sum<G>(gx_[c]);
-      lxd[c] += group_sum<G>(gxd_[c]);
-      lw[c] += group_sum<G>(gw_[c]);
-      ge[c] = group_sum<G>(ge[c]);
-    }
+    for (int c = 0; c < 3; ++c) { red[c] = gx_[c]; red[3 + c] = gxd_[c]; red[6 + c] = gw_[c]; red[9 + c] = ge[c]; }
 #pragma unroll
-    for (int c = 0; c < 9; ++c) lR[c] += group_sum<G>(gR_[c]);
-    gv = group_sum<G>(gv);
-    gwc = group_sum<G>(gwc);
+    for (int c = 0; c < 9; ++c) red[12 + c] = gR_[c];
+    red[21] = gv; red[22] = gwc;
+    gs.sum_n(red);       // the step's 23 adjoint sums in one batched reduction (multi-wave groups: one LDS exchange)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { lx[c] += red[c]; lxd[c] += red[3 + c]; lw[c] += red[6 + c]; ge[c] = red[9 + c]; }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) lR[c] += red[12 + c];
+    gv = red[21]; gwc = red[22];
     {   // e = col0(R) / max(|col0|, eps): through |col0| only when it is >= eps
       const S dote = (coln >= (S)1e-6) ? ge[0] * e[0] + ge[1] * e[1] + ge[2] * e[2] : zero;
       lR[0] += M::div(ge[0] - dote * e[0], el);
@@ -695,11 +699,11 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
         for (int q = 0; q < 3; ++q) { sR[q] += gpx * P0[j][q]; sR[3 + q] += gpy * P0[j][q]; }
       }
     }
-    gx0[0] += group_sum<G>(sx);
-    gx0[1] += group_sum<G>(sy);
+    gx0[0] += gs.sum(sx);
+    gx0[1] += gs.sum(sy);
     gx0[2] = zero;                          // the caller's x0.z is overwritten, so nothing flows to it
 #pragma unroll
-    for (int q = 0; q < 6; ++q) lR[q] += group_sum<G>(sR[q]);
+    for (int q = 0; q < 6; ++q) lR[q] += gs.sum(sR[q]);
   }
   if (gl == 0) {
 #pragma unroll

@@ -121,8 +121,8 @@ __device__ __forceinline__ S ld32(const S* base, unsigned elem) {
 // the inertia of the articulated body about the body origin and its inverse (dphysics.py:196-197, 107-141) -- per step and per
 // rollout; `ja` = the 4 joint angles of this (rollout, step), P0 = rest configuration, P / Iv = articulated points / I^-1.
 template <typename S, int G, int PPL>
-__device__ __forceinline__ void articulate_body(const S* ja, const S* joint_xyz, S mp, const S (&P0)[PPL][3], const int (&part)[PPL],
-                                                const bool (&act)[PPL], S (&P)[PPL][3], S (&Iv)[9]) {
+__device__ __forceinline__ void articulate_body(GroupSum<G, S>& gs, const S* ja, const S* joint_xyz, S mp, const S (&P0)[PPL][3],
+                                                const int (&part)[PPL], const bool (&act)[PPL], S (&P)[PPL][3], S (&Iv)[9]) {
   const S one = (S)1, zero = (S)0;
   S sj[4], cj4[4];
 #pragma unroll
@@ -143,8 +143,7 @@ __device__ __forceinline__ void articulate_body(const S* ja, const S* joint_xyz,
     I6[0] += wgt * (py * py + pzz * pzz); I6[1] += wgt * (px * px + pzz * pzz); I6[2] += wgt * (px * px + py * py);
     I6[3] -= wgt * px * py; I6[4] -= wgt * px * pzz; I6[5] -= wgt * py * pzz;
   }
-#pragma unroll
-  for (int c = 0; c < 6; ++c) I6[c] = group_sum<G>(I6[c]);
+  gs.sum_n(I6);
   // inverse of the symmetric 3x3 by cofactors
   const S a00 = I6[0], a11 = I6[1], a22 = I6[2], a01 = I6[3], a02 = I6[4], a12 = I6[5];
   const S c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
@@ -165,6 +164,10 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
   const S one = (S)1, zero = (S)0;
   const int HW = a.H * a.W, last = HW - 1;
   const bool has_mu = a.mu != nullptr;  // wave-uniform
+  // group reductions; a rollout spread over several waves (G > 64: one workgroup = one rollout) exchanges through LDS
+  __shared__ S gs_lds[G > 64 ? 2 * (G / 64) * kGroupSumMaxValues : 1];
+  GroupSum<G, S> gs;
+  gs.lds = gs_lds;
   // uniform base pointer + 32-bit element offset (the host guarantees B*H*W < 2^31 for per-rollout maps): scalar-base loads
   const unsigned moff = a.map_shared ? 0u : (unsigned)b * (unsigned)HW;
   const S* zmap = a.z;
@@ -213,7 +216,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
       S v = blend(c, ld32(zmap, moff + (unsigned)c.ic), ld32(zmap, moff + (unsigned)c.i_f), ld32(zmap, moff + (unsigned)c.il), ld32(zmap, moff + (unsigned)c.ifl));
       acc += act[j] ? v : zero;
     }
-    acc = group_sum<G>(acc);
+    acc = gs.sum(acc);
     x[2] = acc / (S)a.N;
     if (gl == 0) a.x0[b * 3 + 2] = x[2];
   }
@@ -268,11 +271,11 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
         nrm_j[j] = M::sqrt(oFs[j][0] * oFs[j][0] + oFs[j][1] * oFs[j][1] + oFs[j][2] * oFs[j][2]);
         nsum += act[j] ? nrm_j[j] : zero;
       }
-      const S mean = group_sum<G>(nsum) * inv_N;
+      const S mean = gs.sum(nsum) * inv_N;
       S dsum = zero;
 #pragma unroll
       for (int j = 0; j < PPL; ++j) { const S dv = nrm_j[j] - mean; dsum += act[j] ? dv * dv : zero; }
-      const S sdev = M::sqrt(group_sum<G>(dsum) * inv_Nm1);   // unbiased, like torch.std
+      const S sdev = M::sqrt(gs.sum(dsum) * inv_Nm1);   // unbiased, like torch.std
       stc(pC + 0, R[6]); stc(pC + 1, R[7]); stc(pC + 2, R[8]); stc(pC + 3, sdev);
       pC += adv * 4;
       return;   // the decimated poses are written at the END of the step that produced them (store_pose below)
@@ -317,7 +320,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
   // conservative in-loop wait is a wait for the previous step's stores
   __builtin_amdgcn_s_waitcnt(0);
   for (int n = 0; n < n_steps; ++n) {
-    if (JOINTS) articulate_body<S, G, PPL>(a.joint_angles + ((size_t)b * a.T + n) * 4, a.joint_xyz, a.mass / (S)a.N, P0, part, act, P, Iv);
+    if (JOINTS) articulate_body<S, G, PPL>(gs, a.joint_angles + ((size_t)b * a.T + n) * 4, a.joint_xyz, a.mass / (S)a.N, P0, part, act, P, Iv);
     // ---- geometry of the contact points and the gathers that depend only on it ----
     S r[PPL][3], pz[PPL];
     Cell<S> cell[PPL];
@@ -407,7 +410,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
       S A = a.k * dh + a.damp * vn;
       Fr[j][0] = -(A * nrm[j][0]); Fr[j][1] = -(A * nrm[j][1]); Fr[j][2] = -(A * nrm[j][2]);
     }
-    csum = group_sum<G>(csum);  // n_contact_pts (:231)
+    csum = gs.sum(csum);  // n_contact_pts (:231)
     const S inv_csum = FAST ? M::div(one, csum) : one;
 
     S sFr[3] = {zero, zero, zero}, sFf[3] = {zero, zero, zero}, sTau[3] = {zero, zero, zero};
@@ -442,11 +445,16 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
         for (int c = 0; c < 3; ++c) { sFr[c] += Fr[j][c]; sFf[c] += Ff[j][c]; }
       }
     }
+    if (FAST) {   // one batched reduction of the wrench (multi-wave groups: one LDS exchange)
+      S wr[6] = {sFr[0], sFr[1], sFr[2], sTau[0], sTau[1], sTau[2]};
+      gs.sum_n(wr);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      sFr[c] = group_sum<G>(sFr[c]);
-      if (!FAST) sFf[c] = group_sum<G>(sFf[c]);  // exact mode keeps the reference's two separate sums
-      sTau[c] = group_sum<G>(sTau[c]);
+      for (int c = 0; c < 3; ++c) { sFr[c] = wr[c]; sTau[c] = wr[3 + c]; }
+    } else {      // exact mode keeps the reference's two separate force sums
+      S wr[9] = {sFr[0], sFr[1], sFr[2], sFf[0], sFf[1], sFf[2], sTau[0], sTau[1], sTau[2]};
+      gs.sum_n(wr);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { sFr[c] = wr[c]; sFf[c] = wr[3 + c]; sTau[c] = wr[6 + c]; }
     }
     // omega_d = clamp(I^-1 tau) (body-frame I with world-frame torque, as the reference)   (:256-257)
     S wd[3];
