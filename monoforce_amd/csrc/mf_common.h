@@ -78,10 +78,10 @@ struct GroupSum {
     if (G <= 64) return;
     S* slot = lds + par * (NW * kGroupSumMaxValues);
     const int wave = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
+    // every lane of the wave holds the same total and writes it to the same word: no branch (a basic-block boundary here
+    // would change which multiply-add pairs around a call get contracted, i.e. the bits of the trajectory)
 #pragma unroll
-      for (int k = 0; k < K; ++k) slot[wave * kGroupSumMaxValues + k] = v[k];
-    }
+    for (int k = 0; k < K; ++k) slot[wave * kGroupSumMaxValues + k] = v[k];
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < K; ++k) {

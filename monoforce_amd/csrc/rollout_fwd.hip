@@ -50,7 +50,8 @@ static int fill_args(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutA
   for (int i = 0; i < 12; ++i) a->joint_xyz[i] = (S)d->joint_xyz[i];
   if (p->joint_angles) {
     MF_REQUIRE(d->n_tracks == 4, MF_ERR_UNSUPPORTED, "rollout_fwd: joint angles need 4 driving parts (fl, fr, rl, rr)");
-    *m = choose_lane_map(d->B, d->N, 4);     // the articulated kernels exist for the 4-points-per-lane mappings
+    *m = choose_lane_map(d->B, d->N, 0);     // the articulated kernels exist for the multi-wave mappings (small batches of
+    if (m->G <= 64) *m = choose_lane_map(d->B, d->N, 4);   // a large body) and the 4-points-per-lane ones
     MF_REQUIRE(fstride >= m->G * m->PPL, MF_ERR_INVALID, "rollout_fwd: force_stride too small for the articulated kernels");
   }
   return MF_OK;
@@ -60,7 +61,8 @@ static int fill_args(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutA
 
 extern "C" int mf_rollout_force_stride(const MfRolloutDesc* d) {
   if (!d || d->B <= 0 || d->N <= 0 || d->N > 512) return -1;
-  mf::LaneMap m = mf::choose_lane_map(d->B, d->N, d->has_joints ? 4 : d->points_per_lane);
+  mf::LaneMap m = mf::choose_lane_map(d->B, d->N, d->has_joints ? 0 : d->points_per_lane);
+  if (d->has_joints && m.G <= 64) m = mf::choose_lane_map(d->B, d->N, 4);
   const int lanes = m.G * m.PPL;
   return lanes > d->N ? lanes : d->N;
 }

@@ -106,3 +106,76 @@ def test_random_shape_forward_f32_vs_oracle_f64(seed, precise):
     for k, a, b in zip(hp.OUT_KEYS, list(sh) + list(fh), list(so) + list(fo)):
         tol = 1e-4 if k in ('Xs', 'Rs') else 1e-3
         assert hp.rel_err(a.cpu().double(), b) <= tol, (info, k, hp.rel_err(a.cpu().double(), b))
+
+
+@pytest.mark.parametrize('B,N,n_tracks', [(3, 100, 2), (5, 223, 4), (600, 100, 2), (300, 200, 4)])
+def test_large_body_lane_mappings_vs_oracle_f64(B, N, n_tracks):
+    """Bodies of more than 64 points: a small batch spreads ONE rollout over 2 / 4 waves (LDS exchange between them), a
+    large one keeps one wave per rollout with 2 / 4 points per lane -- forward and gradients of both against the oracle."""
+    from monoforce_amd import synthetic as syn
+    from oracle import dphysics_oracle as orc
+    pts, masks = syn.robot_points_box(N, seed=N + B, n_tracks=n_tracks)
+    T = 10 if B > 100 else 25
+    z1 = syn.bump_terrain(syn.bump_params(B), 3.2, 0.1, torch.float64) * 0.4
+    mu1 = syn.wave_friction(3.2, 0.1, 0.5, 1.0, 1.4, 0.8, torch.float64)
+    ctrl = syn.varying_controls(B, T, seed=B, dtype=torch.float64)
+    for integ in (0, 1):
+        spec = hp.spec_from(pts, masks, integ, 0.1, 3.2)
+
+        def run(fn, dev):
+            zl, ml, cl = (t.clone().to(dev).requires_grad_(True) for t in (z1, mu1, ctrl))
+            outs = fn(zl.unsqueeze(0).expand(B, -1, -1), cl, ml.unsqueeze(0).expand(B, -1, -1))
+            hp.probe_loss(outs, torch.float64).backward()
+            return [o.detach().cpu() for o in outs], [g.grad.cpu() for g in (zl, ml, cl)]
+
+        def f_oracle(zz, cc, mm):
+            so, fo = orc.rollout(spec, zz, cc, friction=mm)
+            return list(so) + list(fo)
+
+        dp = make_dphysics(pts, masks, integ, 0.1, 3.2)
+
+        def f_hip(zz, cc, mm):
+            s, f = dp(zz, cc, friction=mm)
+            return list(s) + list(f)
+
+        o_ref, g_ref = run(f_oracle, 'cpu')
+        o_hip, g_hip = run(f_hip, DEV)
+        for k, a, b in zip(hp.OUT_KEYS, o_hip, o_ref):
+            assert hp.rel_err(a, b) <= 1e-9, (B, N, integ, k, hp.rel_err(a, b))
+        for nm, a, b in zip(('z', 'mu', 'controls'), g_hip, g_ref):
+            assert hp.rel_err(a, b) <= 1e-7, (B, N, integ, nm, hp.rel_err(a, b))
+
+
+@pytest.mark.parametrize('tag', ['f32', 'f64'])
+def test_articulated_large_body_small_batch_vs_oracle(tag):
+    """robot 'marv' with moving flippers, 130 contact points, 2 rollouts: the articulated kernels on the multi-wave mapping."""
+    from monoforce_amd import synthetic as syn
+    from monoforce_amd.dphys_config import DPhysConfig
+    from monoforce_amd.dphysics import DPhysics
+    from oracle import dphysics_oracle as orc
+    dt = hp.DT[tag]
+    B, T, N = 2, 20, 130
+    pts, masks = syn.robot_points_box(N, seed=3, n_tracks=4)
+    cfg = DPhysConfig(robot='marv', grid_res=0.1, robot_points=pts, driving_parts=masks)
+    cfg.robot_mass = 40.0
+    cfg.damping = float(np.sqrt(4 * cfg.robot_mass * cfg.stiffness))
+    cfg.d_max = 1.6
+    z = torch.stack([syn.bump_terrain(np.array([[0.12, 0.5, 0.2, 0.6]]), 1.6, 0.1, torch.float64) + 0.01 * k for k in range(B)])
+    ctrl = syn.varying_controls(B, T, seed=6, dtype=torch.float64)
+    t = torch.linspace(0, 1, T, dtype=torch.float64).view(1, T, 1)
+    ja = 0.5 * torch.sin(2 * np.pi * (t * torch.tensor([1.0, 0.7, 1.3, 0.5]) + torch.arange(B).view(B, 1, 1) * 0.2))
+    for integ in (0, 1):
+        cfg.use_odeint = (integ == 1)
+        spec = hp.spec_from(pts, masks, integ, 0.1, 1.6)
+        spec.joint_positions = [list(v) for v in cfg.joint_positions.values()]
+        zo = z.clone().requires_grad_(True)
+        so, fo = orc.rollout(spec, zo, ctrl, joint_angles=ja)
+        hp.probe_loss(list(so) + list(fo), torch.float64).backward()
+        dp = DPhysics(cfg, device=DEV)
+        zh = z.to(dt).to(DEV).requires_grad_(True)
+        sh, fh = dp(zh, ctrl.to(dt).to(DEV), joint_angles=ja.to(dt).to(DEV))
+        hp.probe_loss(list(sh) + list(fh), dt).backward()
+        tol, gtol = (1e-9, 1e-7) if tag == 'f64' else (1e-4, 5e-4)
+        for k, a, b in zip(hp.OUT_KEYS, list(sh) + list(fh), list(so) + list(fo)):
+            assert hp.rel_err(a.detach().cpu().double(), b.detach()) <= tol, (integ, k, hp.rel_err(a.detach().cpu().double(), b.detach()))
+        assert hp.rel_err(zh.grad.cpu().double(), zo.grad) <= gtol, (integ, hp.rel_err(zh.grad.cpu().double(), zo.grad))
