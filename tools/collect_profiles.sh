@@ -1,5 +1,5 @@
 #!/bin/bash
-# Collect the measurement artefacts kept under profiles/ (run on the GPU box: `gpurun -- bash tools/collect_profiles.sh r1e`).
+# Collect the measurement artefacts kept under profiles/ (run on the GPU box: `gpurun -- bash tools/collect_profiles.sh <tag>`).
 # Every step has its own timeout; PMC passes are separate from the kernel-trace passes (and from each other).
 TAG=${1:-rX}
 OUT=gpurun_out/$TAG
