@@ -123,6 +123,8 @@ typedef struct MfRolloutFwdBufs {
                            roll / pitch) -- instead of the full rows: Xds, Omegas, Fs, Ff, Xraw must be NULL, and Xs / Rs are
                            DECIMATED to S[1 + ceil((T-1) / pose_stride)][B][3 | 3x3]: pose row r holds output row
                            min(r * pose_stride, T - 1) (what the nodes publish: poses[::pose_step], plus the final pose). */
+  void* path_cost;      /* optional S[B], with cost_rows: the force path cost itself, std over the T rows of s (unbiased, Welford
+                           in registers) = norm(F_springs, dim=-1).std(dim=-1).std(dim=-1) of monoforce_node.py:91 */
 } MfRolloutFwdBufs;
 
 /* Point slots per Fs/Ff row the kernels chosen for (B, N, points_per_lane) need (>= N; -1 on a bad descriptor). */

@@ -47,6 +47,7 @@ static int fill_args(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutA
   a->Xraw = (S*)p->Xraw;
   a->joint_angles = (const S*)p->joint_angles;
   a->cost_rows = (S*)p->cost_rows; a->pose_stride = d->pose_stride > 0 ? d->pose_stride : 1;
+  a->path_cost = (S*)p->path_cost;
   for (int i = 0; i < 12; ++i) a->joint_xyz[i] = (S)d->joint_xyz[i];
   if (p->joint_angles) {
     MF_REQUIRE(d->n_tracks == 4, MF_ERR_UNSUPPORTED, "rollout_fwd: joint angles need 4 driving parts (fl, fr, rl, rr)");

@@ -51,6 +51,7 @@ struct RolloutArgs {
   S joint_xyz[12];        // joint positions of the (up to 4) driving parts
   S* cost_rows;           // COST kernels: S[T][B][4] = (R20, R21, R22, std over the points of |F_spring|) per output row
   int pose_stride;        // COST kernels: Xs / Rs hold every pose_stride-th output row only
+  S* path_cost;           // COST kernels, optional: S[B] std over the T output rows of the 4th cost-row component
 };
 
 // Arithmetic policy.  Exact: IEEE divide / sqrt, libm exp and sincos, un-fused mul+add (the TU is built with
@@ -253,6 +254,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
   // contraction -- and with it every bit of the trajectory -- is the one of the full-output kernels.
   S* pC = COST ? a.cost_rows + row0 * 4 : nullptr;
   int pose_wait = 0;   // output rows still to pass before the next pose is due
+  S pc_n = zero, pc_mean = zero, pc_m2 = zero;   // path cost accumulators (COST)
   auto store_pose = [&]() {
     pXs[0] = x[0] + R[2] * a.sink; pXs[1] = x[1] + R[5] * a.sink; pXs[2] = x[2] + R[8] * a.sink;
 #pragma unroll
@@ -278,6 +280,13 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
       const S sdev = M::sqrt(gs.sum(dsum) * inv_Nm1);   // unbiased, like torch.std
       stc(pC + 0, R[6]); stc(pC + 1, R[7]); stc(pC + 2, R[8]); stc(pC + 3, sdev);
       pC += adv * 4;
+      // running mean / sum of squared deviations of sdev over the output rows (Welford); DYNAMICS' placeholder row (adv = 0)
+      // does not count
+      const S wgt = adv ? one : zero;
+      pc_n += wgt;
+      const S dlt = sdev - pc_mean;
+      pc_mean += wgt * M::div(dlt, mf_max(pc_n, one));
+      pc_m2 += wgt * dlt * (sdev - pc_mean);
       return;   // the decimated poses are written at the END of the step that produced them (store_pose below)
     }
     // streaming (non-temporal) stores: the rows are never read again by this kernel and must not evict the map cells the
@@ -531,6 +540,8 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
     }
   }
   if (n_steps > 0 || INTEG == MF_INTEG_ODEINT_EULER) emit_row(row_stride);
+  // the force path cost itself: norm(F_springs).std(points).std(time) (monoforce_node.py:91), unbiased like torch.std
+  if (COST && a.path_cost != nullptr && gl == 0) a.path_cost[b] = M::sqrt(pc_m2 / (pc_n - one));
 }
 
 // Lane mapping for (B, N): G lanes per rollout x PPL points per lane (see the header comment).

@@ -320,7 +320,8 @@ class DPhysics(torch.nn.Module):
         monoforce_node.py:35,115; default 0.5 s like the node) plus the final one: 16 B per rollout-step instead of 180.
         float32 fast-math rigid-body rollouts only; arguments as `forward` (a [1,H,W] map is shared by all rollouts).
 
-        Returns dict(cost_rows [B,T,4], Xs [B,Tp,3], Rs [B,Tp,3,3], pose_steps [Tp]) -- views of time-major buffers.
+        Returns dict(cost_rows [B,T,4], Xs [B,Tp,3], Rs [B,Tp,3,3], pose_steps [Tp], force_cost [B]) -- views of time-major
+        buffers; `force_cost` is the node's path cost itself (the std over time taken in the kernel's registers).
         """
         cfg = self.dphys_cfg
         dev = torch.device(self.device)
@@ -348,17 +349,18 @@ class DPhysics(torch.nn.Module):
         desc.layout, desc.pose_stride = _lib.MF_LAYOUT_TIME_MAJOR, ps
         Tp = 1 + (N_ts - 1 + ps - 1) // ps
         rows = torch.empty(N_ts, B, 4, device=dev)
+        force_cost = torch.empty(B, device=dev)
         Xs, Rs = torch.empty(Tp, B, 3, device=dev), torch.empty(Tp, B, 3, 3, device=dev)
         bufs = _lib.MfRolloutFwdBufs(
             z=_lib.ptr(keep['z']), mu=_lib.ptr(keep['mu']), controls=_lib.ptr(controls), ts=_lib.ptr(ts),
             points=_lib.ptr(keep['points']), part=_lib.ptr(self._part_dev(dev)),
             x0=_lib.ptr(x0), xd0=_lib.ptr(xd0), R0=_lib.ptr(R0), w0=_lib.ptr(w0),
             Xs=_lib.ptr(Xs), Xds=None, Rs=_lib.ptr(Rs), Omegas=None, Fs=None, Ff=None, Xraw=None, joint_angles=None,
-            cost_rows=_lib.ptr(rows))
+            cost_rows=_lib.ptr(rows), path_cost=_lib.ptr(force_cost))
         with torch.cuda.device(dev), _timing.timed('rollout_fwd_kernel', dev):
             _lib.check(_lib.lib().mf_rollout_fwd_f32(C.byref(desc), C.byref(bufs), _stream_ptr(dev)), 'mf_rollout_fwd')
         steps = torch.clamp(torch.arange(Tp, device=dev) * ps, max=N_ts - 1)
-        return dict(cost_rows=rows.transpose(0, 1), Xs=Xs.transpose(0, 1), Rs=Rs.transpose(0, 1), pose_steps=steps)
+        return dict(cost_rows=rows.transpose(0, 1), Xs=Xs.transpose(0, 1), Rs=Rs.transpose(0, 1), pose_steps=steps, force_cost=force_cost)
 
     def _time_grid(self, n, dtype, dev):
         key = ('ts', n, dtype, str(dev))

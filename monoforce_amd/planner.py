@@ -80,7 +80,7 @@ class TrajectoryShooter:
             state = (x, torch.zeros_like(x), pose0[:3, :3].to(dev).repeat(B, 1, 1).contiguous(), torch.zeros_like(x))   # monoforce_node.py:67-72
         if self.fused and z.dtype == torch.float32:
             out = self.dp.rollout_costs(z, controls, state=state, friction=mu, pose_stride=self.pose_stride)
-            costs = costs_from_rows(out['cost_rows'], self.cost)
+            costs = out['force_cost'] if self.cost == 'force' else costs_from_rows(out['cost_rows'], self.cost)
             return dict(controls=controls, Xs=out['Xs'], Rs=out['Rs'], pose_steps=out['pose_steps'], costs=costs,
                         best=int(torch.argmin(costs)))
         need_forces = self.cost == 'force'

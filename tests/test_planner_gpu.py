@@ -82,6 +82,7 @@ def test_cost_rows_match_full_outputs(integ, N, n_tracks, stride):
     assert rows.shape == (B, T, 4) and torch.equal(rows[..., :3], Rs[:, :, 2, :])
     s_ref = torch.norm(Fs, dim=-1).std(dim=-1)
     assert hp.rel_err(rows[..., 3].cpu(), s_ref.cpu()) <= 2e-6, hp.rel_err(rows[..., 3].cpu(), s_ref.cpu())
+    assert hp.rel_err(out['force_cost'].cpu(), s_ref.std(dim=-1).cpu()) <= 2e-5      # std over time, Welford in the kernel
     steps = out['pose_steps']
     assert steps[-1] == T - 1 and steps.numel() == 1 + -(-(T - 1) // stride)
     assert torch.equal(out['Xs'], Xs[:, steps]) and torch.equal(out['Rs'], Rs[:, steps])
