@@ -58,6 +58,8 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
   if (p->joint_angles) {   // articulated body: exact arithmetic, default lane mappings (the backward recomputes every step, so it
                            // need not mirror the forward's mapping)
     const LaneMap mj = choose_lane_map(d->B, d->N, 0);
+    if (sizeof(S) == 4 && d->math_mode == MF_MATH_FAST)
+      return launch_rollout_bwd_joints_fast_f32(*reinterpret_cast<const RolloutBwdArgs<float>*>(&a), mj, d->integrator, block, st);
     if (sizeof(S) == 4) return launch_rollout_bwd_joints_f32(*reinterpret_cast<const RolloutBwdArgs<float>*>(&a), mj, d->integrator, block, st);
     return launch_rollout_bwd_joints_f64(*reinterpret_cast<const RolloutBwdArgs<double>*>(&a), mj, d->integrator, block, st);
   }

@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S
     for (int c = 0; c < 9; ++c) R[c] = cur.R[c];
     const S cv = cur.cv, cw = cur.cw;
     // the articulated body of this step: a function of the joint angles only, constant w.r.t. everything differentiated
-    if (JOINTS) articulate_body<S, G, PPL>(gs, a.joint_angles + ((size_t)b * a.T + n) * 4, a.joint_xyz, a.mass / (S)a.N, P0, part, act, P, Iv);
+    if (JOINTS) articulate_body<S, G, PPL, FAST>(gs, a.joint_angles + ((size_t)b * a.T + n) * 4, a.joint_xyz, a.mass / (S)a.N, P0, part, act, P, Iv);
 
     // ---------------------------------------------------------------------------------------------------
     // forward recompute (identical arithmetic to rollout_fwd.hip)
@@ -749,5 +749,7 @@ int launch_rollout_bwd_carry_fast_f32(const RolloutBwdArgs<float>& a, LaneMap m,
 // defined in rollout_bwd_joints.hip (exact arithmetic, like the articulated forward)
 int launch_rollout_bwd_joints_f32(const RolloutBwdArgs<float>& a, LaneMap m, int integ, int block, hipStream_t st);
 int launch_rollout_bwd_joints_f64(const RolloutBwdArgs<double>& a, LaneMap m, int integ, int block, hipStream_t st);
+// defined in rollout_bwd_joints_fast.hip
+int launch_rollout_bwd_joints_fast_f32(const RolloutBwdArgs<float>& a, LaneMap m, int integ, int block, hipStream_t st);
 
 }  // namespace mf

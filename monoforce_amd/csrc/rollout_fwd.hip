@@ -74,7 +74,11 @@ extern "C" int mf_rollout_fwd_f32(const MfRolloutDesc* d, const MfRolloutFwdBufs
   int block;
   int rc = mf::fill_args<float>(d, p, &a, &m, &block);
   if (rc != MF_OK) return rc;
-  if (p->joint_angles) return mf::launch_rollout_fwd<float, false, true>(a, m, d->integrator, block, (hipStream_t)s);  // exact math
+  if (p->joint_angles) {
+    MF_REQUIRE(p->Fs && p->Ff && !p->cost_rows, MF_ERR_UNSUPPORTED, "rollout_fwd: articulated rollouts write all six outputs");
+    if (d->math_mode == MF_MATH_FAST) return mf::launch_rollout_fwd_joints_fast_f32(a, m, d->integrator, block, (hipStream_t)s);
+    return mf::launch_rollout_fwd<float, false, true>(a, m, d->integrator, block, (hipStream_t)s);
+  }
   if (p->cost_rows) {   // path-cost mode: cost rows + decimated poses (see MfRolloutFwdBufs.cost_rows)
     MF_REQUIRE(d->math_mode == MF_MATH_FAST && d->layout == MF_LAYOUT_TIME_MAJOR && d->pose_stride >= 1, MF_ERR_UNSUPPORTED,
                "rollout_fwd: cost rows need float32 MF_MATH_FAST, MF_LAYOUT_TIME_MAJOR and pose_stride >= 1");

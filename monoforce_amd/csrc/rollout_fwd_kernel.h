@@ -68,6 +68,7 @@ struct Mth {
   static constexpr bool kReciprocalNorm = false;
   static __device__ __forceinline__ void sincos_small(S v, S* s, S* omc) { S c; mf_sincos(v, s, &c); *omc = (S)1 - c; }
   static __device__ __forceinline__ S clamp(S v, S lo, S hi) { return mf_clamp(v, lo, hi); }   // torch.clamp, NaN propagates
+  static __device__ __forceinline__ void sincos(S v, S* sn, S* cs) { mf_sincos(v, sn, cs); }
 };
 template <>
 struct Mth<float, true> {
@@ -80,6 +81,8 @@ struct Mth<float, true> {
   static __device__ __forceinline__ float inv_len(float len2) { return __builtin_amdgcn_rsqf(fmaxf(len2, 1e-12f)); }
   static constexpr bool kReciprocalNorm = true;
   static __device__ __forceinline__ float clamp(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }  // 1 instr
+  // joint angles (|a| of a few radians at most): hardware sin / cos after the 1 / 2pi scaling, ~1e-6 absolute
+  static __device__ __forceinline__ void sincos(float v, float* sn, float* cs) { *sn = __sinf(v); *cs = __cosf(v); }
   static __device__ __forceinline__ void sincos_small(float v, float* s, float* omc) {
     if (fabsf(v) < 0.25f) {  // |w| dt is ~1e-2: short Taylor series, and 1 - cos without the cancellation
       const float v2 = v * v;
@@ -121,13 +124,13 @@ __device__ __forceinline__ S ld32(const S* base, unsigned elem) {
 // update_joints (dphysics.py:326-358): rotate every driving part about the y-axis through its joint by the step's angle, then
 // the inertia of the articulated body about the body origin and its inverse (dphysics.py:196-197, 107-141) -- per step and per
 // rollout; `ja` = the 4 joint angles of this (rollout, step), P0 = rest configuration, P / Iv = articulated points / I^-1.
-template <typename S, int G, int PPL>
+template <typename S, int G, int PPL, bool FAST = false>
 __device__ __forceinline__ void articulate_body(GroupSum<G, S>& gs, const S* ja, const S* joint_xyz, S mp, const S (&P0)[PPL][3],
                                                 const int (&part)[PPL], const bool (&act)[PPL], S (&P)[PPL][3], S (&Iv)[9]) {
   const S one = (S)1, zero = (S)0;
   S sj[4], cj4[4];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) mf_sincos(ja[q], &sj[q], &cj4[q]);
+  for (int q = 0; q < 4; ++q) Mth<S, FAST>::sincos(ja[q], &sj[q], &cj4[q]);
   S I6[6] = {zero, zero, zero, zero, zero, zero};   // xx, yy, zz, xy, xz, yz
 #pragma unroll
   for (int j = 0; j < PPL; ++j) {
@@ -149,7 +152,7 @@ __device__ __forceinline__ void articulate_body(GroupSum<G, S>& gs, const S* ja,
   const S a00 = I6[0], a11 = I6[1], a22 = I6[2], a01 = I6[3], a02 = I6[4], a12 = I6[5];
   const S c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
   const S c11 = a00 * a22 - a02 * a02, c12 = a01 * a02 - a00 * a12, c22 = a00 * a11 - a01 * a01;
-  const S idet = one / (a00 * c00 + a01 * c01 + a02 * c02);
+  const S idet = Mth<S, FAST>::div(one, a00 * c00 + a01 * c01 + a02 * c02);
   Iv[0] = c00 * idet; Iv[1] = c01 * idet; Iv[2] = c02 * idet;
   Iv[3] = c01 * idet; Iv[4] = c11 * idet; Iv[5] = c12 * idet;
   Iv[6] = c02 * idet; Iv[7] = c12 * idet; Iv[8] = c22 * idet;
@@ -329,7 +332,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
   // conservative in-loop wait is a wait for the previous step's stores
   __builtin_amdgcn_s_waitcnt(0);
   for (int n = 0; n < n_steps; ++n) {
-    if (JOINTS) articulate_body<S, G, PPL>(gs, a.joint_angles + ((size_t)b * a.T + n) * 4, a.joint_xyz, a.mass / (S)a.N, P0, part, act, P, Iv);
+    if (JOINTS) articulate_body<S, G, PPL, FAST>(gs, a.joint_angles + ((size_t)b * a.T + n) * 4, a.joint_xyz, a.mass / (S)a.N, P0, part, act, P, Iv);
     // ---- geometry of the contact points and the gathers that depend only on it ----
     S r[PPL][3], pz[PPL];
     Cell<S> cell[PPL];
@@ -604,5 +607,7 @@ int launch_rollout_fwd(const RolloutArgs<S>& a, LaneMap m, int integ, int block,
 int launch_rollout_fwd_fast_f32(const RolloutArgs<float>& a, LaneMap m, int integ, int block, bool forces, hipStream_t st);
 // defined in rollout_fwd_cost.hip
 int launch_rollout_fwd_cost_f32(const RolloutArgs<float>& a, LaneMap m, int integ, int block, hipStream_t st);
+// defined in rollout_fwd_joints_fast.hip
+int launch_rollout_fwd_joints_fast_f32(const RolloutArgs<float>& a, LaneMap m, int integ, int block, hipStream_t st);
 
 }  // namespace mf

@@ -216,9 +216,9 @@ def test_edge_cases_and_errors():
         assert torch.equal(u, v)
 
 
-@pytest.mark.parametrize('tag', ['f32', 'f64'])
+@pytest.mark.parametrize('tag,precise', [('f32', False), ('f32', True), ('f64', False)])
 @pytest.mark.parametrize('integ', [0, 1])
-def test_flipper_joint_angles_vs_reference(tag, integ):
+def test_flipper_joint_angles_vs_reference(tag, precise, integ):
     """robot == 'marv' with moving flippers (update_joints + per-step inertia, dphysics.py:192-197, 326-358) vs the reference."""
     from monoforce_amd.dphys_config import DPhysConfig
     from monoforce_amd.dphysics import DPhysics
@@ -229,7 +229,7 @@ def test_flipper_joint_angles_vs_reference(tag, integ):
     cfg.damping = float(np.sqrt(4 * cfg.robot_mass * cfg.stiffness))
     cfg.d_max, cfg.use_odeint = 1.6, (integ == 1)
     assert np.allclose(np.array(list(cfg.joint_positions.values())), g['joint_positions'])
-    dp = DPhysics(cfg, device=DEV)
+    dp = DPhysics(cfg, device=DEV, precise=precise)      # float32: fast-math and exact articulated kernels
     t = lambda k: torch.as_tensor(g[k]).to(dt).to(DEV)  # noqa: E731
     with torch.no_grad():
         states, forces = dp(t('z'), t('ctrl'), joint_angles=t('joint_angles'), friction=t('mu'))
