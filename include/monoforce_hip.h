@@ -114,8 +114,8 @@ typedef struct MfRolloutFwdBufs {
   void* Xraw;           /* optional S[..][3]: unshifted positions saved for the backward pass; may be NULL */
   const void* joint_angles; /* optional S[B][T][4] flipper angles: each driving part is rotated about the y-axis through
                            its joint and the body inertia recomputed EVERY step (update_joints, dphysics.py:192-197,
-                           326-358; the reference does this for robot == 'marv' and non-zero angles).  Exact
-                           arithmetic.  NULL = rigid body. */
+                           326-358; the reference does this for robot == 'marv' and non-zero angles).  All six
+                           outputs must be given.  NULL = rigid body. */
   void* cost_rows;      /* optional S[T][B][4], float32 MF_MATH_FAST + MF_LAYOUT_TIME_MAJOR rigid-body rollouts: PATH-COST mode
                            for trajectory shooting.  Per output row the kernel writes (R[2][0], R[2][1], R[2][2], s) with
                            s = unbiased std over the N contact points of |F_spring row| -- the inputs of the reference's
