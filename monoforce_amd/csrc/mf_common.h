@@ -34,6 +34,25 @@ __device__ __forceinline__ double dpp_mov(double v) {
   p.y = __builtin_amdgcn_update_dpp(0, p.y, CTRL, 0xF, 0xF, true);
   return __builtin_bit_cast(double, p);
 }
+// DPP move restricted to the rows of ROW_MASK (the other rows read 0): the row_bcast steps of a wave64 reduction
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov_rows(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov_rows(double v) {
+  int2 p = __builtin_bit_cast(int2, v);
+  p.x = __builtin_amdgcn_update_dpp(0, p.x, CTRL, ROW_MASK, 0xF, false);
+  p.y = __builtin_amdgcn_update_dpp(0, p.y, CTRL, ROW_MASK, 0xF, false);
+  return __builtin_bit_cast(double, p);
+}
+__device__ __forceinline__ float read_lane63(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); }
+__device__ __forceinline__ double read_lane63(double v) {
+  int2 p = __builtin_bit_cast(int2, v);
+  p.x = __builtin_amdgcn_readlane(p.x, 63);
+  p.y = __builtin_amdgcn_readlane(p.y, 63);
+  return __builtin_bit_cast(double, p);
+}
 __device__ __forceinline__ float lane_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 __device__ __forceinline__ double lane_xor(double v, int m) { return __shfl_xor(v, m, 64); }
 
@@ -48,8 +67,18 @@ __device__ __forceinline__ S group_sum(S v) {
   if (G >= 4) v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
   if (G >= 8) v += dpp_mov<0x141>(v);  // row_half_mirror
   if (G >= 16) v += dpp_mov<0x140>(v); // row_mirror
-  if (G >= 32) v += lane_xor(v, 16);
-  if (G >= 64) v += lane_xor(v, 32);
+  if (G == 32) v += lane_xor(v, 16);
+  if (G >= 64 && sizeof(S) == 8) {   // float64: the permute form (the scalar-register form below miscompiled in the largest
+    v += lane_xor(v, 16);            // float64 backward kernel, 64 lanes x 8 points, which spills heavily)
+    v += lane_xor(v, 32);
+  } else if (G >= 64) {
+    // whole wave: every lane of a 16-lane row now holds its row total.  row_bcast:15 adds row r-1's total into rows 1 and 3,
+    // row_bcast:31 adds lane 31's (= rows 0+1) into rows 2 and 3: lane 63 holds the wave total, which is wave-uniform and
+    // comes back through a scalar register -- no LDS-crossbar permutes (ds_bpermute) at all.
+    v += dpp_mov_rows<0x142, 0xA>(v);
+    v += dpp_mov_rows<0x143, 0xC>(v);
+    v = read_lane63(v);
+  }
   return v;
 }
 

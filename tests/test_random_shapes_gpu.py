@@ -179,3 +179,32 @@ def test_articulated_large_body_small_batch_vs_oracle(tag):
         for k, a, b in zip(hp.OUT_KEYS, list(sh) + list(fh), list(so) + list(fo)):
             assert hp.rel_err(a.detach().cpu().double(), b.detach()) <= tol, (integ, k, hp.rel_err(a.detach().cpu().double(), b.detach()))
         assert hp.rel_err(zh.grad.cpu().double(), zo.grad) <= gtol, (integ, hp.rel_err(zh.grad.cpu().double(), zo.grad))
+
+
+@pytest.mark.parametrize('B,N', [(3, 64), (3, 223), (2, 300), (2, 400)])
+def test_whole_wave_groups_f32_gradients_vs_oracle(B, N):
+    """float32 kernels whose rollout group is a whole wave (or several): the scalar-register form of the wave reduction
+    (row_bcast + readlane) in the forward and in the 23-component batched reduction of the backward.  The comparison is
+    with the oracle in float32 -- the reference's own precision; rounding the inputs to float32 alone moves these
+    contact-rich rollouts by 2e-4 relative to a float64 run."""
+    from monoforce_amd import synthetic as syn
+    from oracle import dphysics_oracle as orc
+    pts, masks = syn.robot_points_box(N, seed=N, n_tracks=2)
+    T = 30
+    z = (syn.bump_terrain(syn.bump_params(20), 3.2, 0.1, torch.float64) * 0.3).unsqueeze(0).float()
+    ctrl = syn.varying_controls(B, T, seed=N, dtype=torch.float64).float()
+    for integ in (0, 1):
+        spec = hp.spec_from(pts, masks, integ, 0.1, 3.2)
+        zo = z.clone().requires_grad_(True)
+        so, fo = orc.rollout(spec, zo.expand(B, -1, -1), ctrl)
+        hp.probe_loss(list(so) + list(fo), torch.float32).backward()
+        dp = make_dphysics(pts, masks, integ, 0.1, 3.2)
+        zh = z.to(DEV).requires_grad_(True)
+        sh, fh = dp(zh.expand(B, -1, -1), ctrl.to(DEV))
+        hp.probe_loss(list(sh) + list(fh), torch.float32).backward()
+        for k, a, b in zip(hp.OUT_KEYS, list(sh) + list(fh), list(so) + list(fo)):
+            # two float32 evaluation orders of these contact-rich rollouts sit up to 1-2e-4 apart themselves
+            # (per-point forces are k * penetration with k = 5e4: a float32 ulp of height is 1e-2 of a 2-newton force)
+            tol = 5e-4 if k in ('Xs', 'Rs') else (3e-2 if k in ('Fs', 'Ff') else 2e-3)
+            assert hp.rel_err(a.detach().cpu(), b.detach()) <= tol, (N, integ, k, hp.rel_err(a.detach().cpu(), b.detach()))
+        assert hp.rel_err(zh.grad.cpu(), zo.grad) <= 2e-3, (N, integ, hp.rel_err(zh.grad.cpu(), zo.grad))
