@@ -1,17 +1,19 @@
 """Multi-GPU plumbing: one process per GPU, `torch.distributed` (backend "nccl" == RCCL on ROCm; "gloo" in CPU tests).
 
 Rollouts never interact (every op of the step is per batch row), so the forward shards the batch with
-no communication at all.  The backward has exactly one exchange: the gradient of whatever is SHARED between ranks --
-a shared terrain/friction grid (2 x 256 x 256 x 4 B = 512 KiB) or the encoder parameters -- summed with one flat,
-bucketed all-reduce.  xGMI is point-to-point (7 links per GPU); payloads here are latency- not bandwidth-bound, so a
-single flat bucket (one collective launch) is the right shape.
+no communication at all.  The backward has exactly one exchange: the gradient of whatever is SHARED between ranks.
+  * a shared terrain/friction grid (2 x 256 x 256 x 4 B = 512 KiB): one flat bucket, one all-reduce (`allreduce_sum_`) --
+    latency-bound on xGMI, nothing to overlap with;
+  * the encoder parameters (~55 MB): `GradBuckets` -- two 32 MB buckets whose all-reduces start from autograd hooks while
+    the rest of the backward is still running.  xGMI is point-to-point (7 links per GPU, ring collectives are per-link
+    bound), so few large collectives, not many small ones.
 """
 import os
 
 import torch
 import torch.distributed as dist
 
-__all__ = ['init', 'world', 'rank', 'shard_range', 'shard', 'allreduce_sum_', 'FlatBucket']
+__all__ = ['init', 'world', 'rank', 'shard_range', 'shard', 'allreduce_sum_', 'FlatBucket', 'GradBuckets']
 
 
 def init(backend=None, device=None):
@@ -91,3 +93,93 @@ def allreduce_sum_(tensors, bucket=None, average=False):
         buf.div_(world())
     bucket.unpack_into(tensors)
     return bucket
+
+
+class GradBuckets:
+    """Data-parallel gradient exchange of a parameter list, overlapped with the backward pass (encoder weights, BASELINE
+    config 5: ~14 M parameters = 55 MB per step over RCCL).
+
+    The parameters are assigned, in reverse registration order (roughly the order their gradients become ready), to a few
+    flat buffers of about `bucket_mb` megabytes.  A post-accumulate hook counts the ready gradients of a bucket; when the
+    last one lands they are packed into the buffer with ONE multi-tensor copy and the bucket's all-reduce is launched
+    asynchronously (RCCL runs it on its own stream, concurrently with the rest of the backward).  `finish()` waits for the
+    collectives, averages, and points every `p.grad` at its slice of the reduced buffer (no copy back).  xGMI is point-to-point
+    and each collective pays its launch and ring latency, so few, large buckets (default 32 MB -> two for the encoder)
+    rather than many small ones.
+
+    `zero()` replaces `optimizer.zero_grad()`: it drops the gradients (`None`), so autograd hands each new gradient over
+    without an accumulation kernel.  Parameters that receive no gradient in a step are exchanged as zeros.
+    """
+
+    def __init__(self, params, bucket_mb=32.0, average=True):
+        self.params = [p for p in params if p.requires_grad]
+        self.average = average
+        self.buckets = []
+        cap = int(bucket_mb * (1 << 20))
+        group, nbytes = [], 0
+        for p in reversed(self.params):
+            group.append(p)
+            nbytes += p.numel() * p.element_size()
+            if nbytes >= cap:
+                self._make_bucket(group)
+                group, nbytes = [], 0
+        if group:
+            self._make_bucket(group)
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+
+    def _make_bucket(self, group):
+        p0 = group[0]
+        buf = torch.zeros(sum(p.numel() for p in group), dtype=p0.dtype, device=p0.device)
+        views, o = [], 0
+        for p in group:
+            views.append(buf[o:o + p.numel()].view_as(p))
+            p._mf_bucket = len(self.buckets)
+            o += p.numel()
+        self.buckets.append(dict(buf=buf, params=list(group), views=views, ready=0, work=None, launched=False))
+
+    def zero(self):
+        """Start of a step: forget the gradients and re-arm the ready counters."""
+        for b in self.buckets:
+            b['ready'], b['work'], b['launched'] = 0, None, False
+            for p in b['params']:
+                p.grad = None
+
+    def _launch(self, b):
+        b['launched'] = True
+        have = [(v, p.grad) for v, p in zip(b['views'], b['params']) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+        for v, p in zip(b['views'], b['params']):
+            if p.grad is None:
+                v.zero_()                                   # no gradient this step: contributes zeros
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])      # one multi-tensor pack
+        if world() > 1:
+            buf = b['buf']
+            if buf.is_cuda and dist.get_backend() == 'gloo':      # CPU-only test rigs: stage through the host, synchronously
+                host = buf.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                buf.copy_(host)
+            else:
+                b['work'] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+
+    def _on_grad(self, p):
+        b = self.buckets[p._mf_bucket]
+        b['ready'] += 1
+        if b['ready'] == len(b['params']) and not b['launched']:
+            self._launch(b)
+
+    def finish(self):
+        """After `loss.backward()`: launch what has not been launched, wait, average; `p.grad` then views the reduced buffers."""
+        for b in self.buckets:
+            if not b['launched']:
+                self._launch(b)
+        for b in self.buckets:
+            if b['work'] is not None:
+                b['work'].wait()
+            if self.average and world() > 1:
+                b['buf'].div_(world())
+            for v, p in zip(b['views'], b['params']):
+                p.grad = v
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()

@@ -65,7 +65,9 @@ class EncoderTrainStep:
         on_gpu = all(p.is_cuda for p in encoder.parameters())
         self.opt = torch.optim.Adam(encoder.parameters(), lr=lr, betas=(0.8, 0.999), weight_decay=1e-7, fused=on_gpu)
         self.params = [p for p in encoder.parameters() if p.requires_grad]
-        self.bucket = None
+        # gradients live in a few flat buckets whose all-reduce (RCCL) starts from autograd hooks while the backward is still
+        # running; one zero fill per bucket replaces the per-parameter zero_grad
+        self.buckets = mfdist.GradBuckets(self.params, bucket_mb=32.0, average=True)
 
     def losses(self, batch):
         from .losses import hm_loss
@@ -83,12 +85,11 @@ class EncoderTrainStep:
         return l_geom, l_terr, l_phys
 
     def step(self, batch):
-        self.opt.zero_grad(set_to_none=True)
+        self.buckets.zero()
         l_geom, l_terr, l_phys = self.losses(batch)
         loss = self.w[0] * l_geom + self.w[1] * l_terr + self.w[2] * l_phys
-        loss.backward()
-        grads = [p.grad for p in self.params]
-        self.bucket = mfdist.allreduce_sum_(grads, self.bucket, average=True)      # DDP-style, one flat bucket over RCCL
+        loss.backward()                      # bucket all-reduces are launched from the hooks as their gradients complete
+        self.buckets.finish()                # wait + average (no-op for one process)
         torch.nn.utils.clip_grad_norm_(self.params, max_norm=1.0)                   # train.py:167
         self.opt.step()
         return loss.detach(), (l_geom.detach(), l_terr.detach(), l_phys.detach())

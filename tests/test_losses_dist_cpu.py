@@ -80,3 +80,52 @@ def test_two_rank_gloo_gradient_allreduce(tmp_path):
     (Xs ** 2).sum().backward()
     assert hp.rel_err(got['gz'], z.grad) <= 1e-10
     assert hp.rel_err(got['gmu'], mu.grad) <= 1e-10
+
+
+def _ddp_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from monoforce_amd import dist as mfd
+    mfd.init(backend='gloo')
+    torch.manual_seed(0)                                   # identical initial weights on every rank
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(), torch.nn.Linear(16, 1))
+    unused = torch.nn.Parameter(torch.ones(3))             # a parameter no loss touches: exchanged as zeros
+    params = list(net.parameters()) + [unused]
+    gb = mfd.GradBuckets(params, bucket_mb=0.0001)          # ~100 bytes per bucket: several buckets, launched during backward
+    assert len(gb.buckets) >= 3
+    opt = torch.optim.SGD(params, lr=0.1)
+    g = torch.Generator().manual_seed(7)
+    X, Y = torch.randn(12, 8, generator=g), torch.randn(12, 1, generator=g)
+    lo, hi = mfd.shard_range(12)
+    for _ in range(3):
+        gb.zero()
+        ((net(X[lo:hi]) - Y[lo:hi]) ** 2).mean().backward()
+        gb.finish()
+        opt.step()
+    if rank == 0:
+        np.savez(out, **{f'p{i}': p.detach().numpy() for i, p in enumerate(params)}, g0=params[0].grad.numpy())
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gloo_bucketed_overlapped_gradient_exchange(tmp_path):
+    """GradBuckets (gradients as views of flat buckets, all-reduce launched from autograd hooks, averaged) == single-process
+    training on the whole batch."""
+    out = str(tmp_path / 'ddp.npz')
+    port = 31000 + os.getpid() % 2000
+    mp.spawn(_ddp_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(), torch.nn.Linear(16, 1))
+    unused = torch.nn.Parameter(torch.ones(3))
+    params = list(net.parameters()) + [unused]
+    opt = torch.optim.SGD(list(net.parameters()), lr=0.1)
+    g = torch.Generator().manual_seed(7)
+    X, Y = torch.randn(12, 8, generator=g), torch.randn(12, 1, generator=g)
+    for _ in range(3):
+        opt.zero_grad()
+        # mean over the two equally sized shards of per-shard means == mean over the batch
+        ((net(X) - Y) ** 2).mean().backward()
+        last = params[0].grad.clone()
+        opt.step()
+    for i, p in enumerate(params):
+        assert np.allclose(got[f'p{i}'], p.detach().numpy(), rtol=1e-5, atol=1e-6), i
+    assert np.allclose(got['g0'], last.numpy(), rtol=1e-5, atol=1e-7)
