@@ -82,7 +82,9 @@ typedef struct MfRolloutDesc {
                            same cells, and same-address float atomics serialise in L2 at ~20 ns each; 0 or 1 = one copy. */
   int32_t has_joints;   /* 1: MfRolloutFwdBufs.joint_angles will be given (selects the articulated kernels / force stride) */
   int32_t pose_stride;  /* path-cost mode (MfRolloutFwdBufs.cost_rows): Xs / Rs keep every pose_stride-th output row; else 0 */
-  int32_t reserved0;    /* 0 */
+  int32_t cost_project; /* path-cost mode, MF_INTEG_ODEINT_EULER: 1 = the cost rows carry the third row of the NEAREST ROTATION to
+                           the (drifting) R -- what scipy's Rotation.from_matrix(R).as_euler() reads roll / pitch from
+                           (diff_physics.py:263-266); 0 = the raw third row (enough for the force cost; ~20 % faster) */
   double mass, gravity, stiffness, damping, omega_max;
   double grid_res, d_max;
   double dt;           /* cfg.dt: step of MF_INTEG_DYNAMICS (ODEINT takes its steps from ts[]) */
@@ -117,7 +119,8 @@ typedef struct MfRolloutFwdBufs {
                            326-358; the reference does this for robot == 'marv' and non-zero angles).  All six
                            outputs must be given.  NULL = rigid body. */
   void* cost_rows;      /* optional S[T][B][4], float32 MF_MATH_FAST + MF_LAYOUT_TIME_MAJOR rigid-body rollouts: PATH-COST mode
-                           for trajectory shooting.  Per output row the kernel writes (R[2][0], R[2][1], R[2][2], s) with
+                           for trajectory shooting.  Per output row the kernel writes (R[2][0], R[2][1], R[2][2], s) (see
+                           desc->cost_project) with
                            s = unbiased std over the N contact points of |F_spring row| -- the inputs of the reference's
                            path costs (monoforce_node.py:91 `norm(F_springs).std(points).std(time)`; diff_physics.py:263-266
                            roll / pitch) -- instead of the full rows: Xds, Omegas, Fs, Ff, Xraw must be NULL, and Xs / Rs are

@@ -85,7 +85,7 @@ extern "C" int mf_rollout_fwd_f32(const MfRolloutDesc* d, const MfRolloutFwdBufs
     MF_REQUIRE(!p->Xds && !p->Omegas && !p->Fs && !p->Ff && !p->Xraw, MF_ERR_INVALID,
                "rollout_fwd: with cost_rows only Xs and Rs (decimated) are written -- pass NULL for Xds, Omegas, Fs, Ff, Xraw");
     if (m.PPL == 4 && m.G < 64) m = mf::choose_lane_map(d->B, d->N, 1);
-    return mf::launch_rollout_fwd_cost_f32(a, m, d->integrator, block, (hipStream_t)s);
+    return mf::launch_rollout_fwd_cost_f32(a, m, d->integrator, block, d->cost_project != 0, (hipStream_t)s);
   }
   const bool forces = p->Fs != nullptr;
   if (!forces && (d->math_mode != MF_MATH_FAST || p->joint_angles)) {

@@ -158,7 +158,7 @@ __device__ __forceinline__ void articulate_body(GroupSum<G, S>& gs, const S* ja,
   Iv[6] = c02 * idet; Iv[7] = c12 * idet; Iv[8] = c22 * idet;
 }
 
-template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS = false, bool FORCES = true, bool COST = false>
+template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS = false, bool FORCES = true, int COST = 0>
 __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a) {
   using M = Mth<S, FAST>;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -281,7 +281,25 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
 #pragma unroll
       for (int j = 0; j < PPL; ++j) { const S dv = nrm_j[j] - mean; dsum += act[j] ? dv * dv : zero; }
       const S sdev = M::sqrt(gs.sum(dsum) * inv_Nm1);   // unbiased, like torch.std
-      stc(pC + 0, R[6]); stc(pC + 1, R[7]); stc(pC + 2, R[8]); stc(pC + 3, sdev);
+      // Third row of the rotation the cost is read from.  The explicit Euler scheme lets R drift off SO(3) (|R R^T - I| up to
+      // 0.06 after 500 steps) and the reference takes roll / pitch through scipy's `Rotation.from_matrix`, which first
+      // projects onto the nearest rotation (polar factor U V^T): two Newton steps X <- (X + X^-T) / 2 reproduce it to ~1e-7
+      // (the second one only for the row that is stored).  dynamics() keeps R orthonormal by construction: stored as is.
+      S r20 = R[6], r21 = R[7], r22 = R[8];
+      if (INTEG == MF_INTEG_ODEINT_EULER && COST == 2) {   // COST = 2: the caller reads roll / pitch from the rows
+        const S half = (S)0.5;
+        const S c00 = R[4] * R[8] - R[5] * R[7], c01 = R[5] * R[6] - R[3] * R[8], c02 = R[3] * R[7] - R[4] * R[6];
+        const S c10 = R[2] * R[7] - R[1] * R[8], c11 = R[0] * R[8] - R[2] * R[6], c12 = R[1] * R[6] - R[0] * R[7];
+        const S c20 = R[1] * R[5] - R[2] * R[4], c21 = R[2] * R[3] - R[0] * R[5], c22 = R[0] * R[4] - R[1] * R[3];
+        const S hid = M::div(half, R[0] * c00 + R[1] * c01 + R[2] * c02);          // 1 / (2 det)
+        const S Y[9] = {half * R[0] + hid * c00, half * R[1] + hid * c01, half * R[2] + hid * c02,
+                        half * R[3] + hid * c10, half * R[4] + hid * c11, half * R[5] + hid * c12,
+                        half * R[6] + hid * c20, half * R[7] + hid * c21, half * R[8] + hid * c22};
+        const S d20 = Y[1] * Y[5] - Y[2] * Y[4], d21 = Y[2] * Y[3] - Y[0] * Y[5], d22 = Y[0] * Y[4] - Y[1] * Y[3];
+        const S hid2 = M::div(half, Y[6] * d20 + Y[7] * d21 + Y[8] * d22);
+        r20 = half * Y[6] + hid2 * d20; r21 = half * Y[7] + hid2 * d21; r22 = half * Y[8] + hid2 * d22;
+      }
+      stc(pC + 0, r20); stc(pC + 1, r21); stc(pC + 2, r22); stc(pC + 3, sdev);
       pC += adv * 4;
       // running mean / sum of squared deviations of sdev over the output rows (Welford); DYNAMICS' placeholder row (adv = 0)
       // does not count
@@ -578,7 +596,7 @@ static inline LaneMap choose_lane_map(int B, int N, int points_per_lane) {
 
 // Instantiated mappings: one point per lane (G = 4..64) and (64, 2/4/8) always; the 4-points-per-lane mappings with G < 64
 // only for the full-output rigid-body kernels (they are a tuning / test option, see choose_lane_map).
-template <typename S, bool FAST, bool JOINTS = false, bool FORCES = true, bool COST = false>
+template <typename S, bool FAST, bool JOINTS = false, bool FORCES = true, int COST = 0>
 int launch_rollout_fwd(const RolloutArgs<S>& a, LaneMap m, int integ, int block, hipStream_t st) {
   if (m.G > 64) block = m.G;   // a rollout spread over several waves: exactly one rollout per workgroup (LDS + barrier)
   const long long threads = (long long)a.B * m.G;
@@ -606,7 +624,7 @@ int launch_rollout_fwd(const RolloutArgs<S>& a, LaneMap m, int integ, int block,
 // defined in rollout_fwd_fast.hip
 int launch_rollout_fwd_fast_f32(const RolloutArgs<float>& a, LaneMap m, int integ, int block, bool forces, hipStream_t st);
 // defined in rollout_fwd_cost.hip
-int launch_rollout_fwd_cost_f32(const RolloutArgs<float>& a, LaneMap m, int integ, int block, hipStream_t st);
+int launch_rollout_fwd_cost_f32(const RolloutArgs<float>& a, LaneMap m, int integ, int block, bool project, hipStream_t st);
 // defined in rollout_fwd_joints_fast.hip
 int launch_rollout_fwd_joints_fast_f32(const RolloutArgs<float>& a, LaneMap m, int integ, int block, hipStream_t st);
 

@@ -311,7 +311,7 @@ class DPhysics(torch.nn.Module):
         return (Xs, Xds, Rs, Omegas), (F_springs, F_frictions)
 
     @torch.no_grad()
-    def rollout_costs(self, z_grid, controls, state=None, friction=None, pose_stride=None):
+    def rollout_costs(self, z_grid, controls, state=None, friction=None, pose_stride=None, project=True):
         """Trajectory-shooting forward: roll out and return only what the reference's planners consume.
 
         The kernel's path-cost mode writes, per output row, `(R[2,0], R[2,1], R[2,2], std_points |F_spring|)` -- the inputs of
@@ -319,6 +319,8 @@ class DPhysics(torch.nn.Module):
         (monoforce_ros/nodes/diff_physics.py:263-266) -- and keeps every `pose_stride`-th pose (`poses[::pose_step]`,
         monoforce_node.py:35,115; default 0.5 s like the node) plus the final one: 16 B per rollout-step instead of 180.
         float32 fast-math rigid-body rollouts only; arguments as `forward` (a [1,H,W] map is shared by all rollouts).
+        `project` (default integrator only): the rows carry the third row of the nearest rotation to the drifting R, which is
+        what scipy's `from_matrix(R).as_euler()` reads roll and pitch from; the force cost does not need it (`project=False`).
 
         Returns dict(cost_rows [B,T,4], Xs [B,Tp,3], Rs [B,Tp,3,3], pose_steps [Tp], force_cost [B]) -- views of time-major
         buffers; `force_cost` is the node's path cost itself (the std over time taken in the kernel's registers).
@@ -346,7 +348,7 @@ class DPhysics(torch.nn.Module):
         ts = self._time_grid(N_ts, torch.float32, dev)
         controls = controls.contiguous()
         desc, keep = self._make_desc(z_grid, friction, controls)
-        desc.layout, desc.pose_stride = _lib.MF_LAYOUT_TIME_MAJOR, ps
+        desc.layout, desc.pose_stride, desc.cost_project = _lib.MF_LAYOUT_TIME_MAJOR, ps, int(bool(project))
         Tp = 1 + (N_ts - 1 + ps - 1) // ps
         rows = torch.empty(N_ts, B, 4, device=dev)
         force_cost = torch.empty(B, device=dev)

@@ -50,7 +50,7 @@ class GraphedTerrainPlanner:
         bev = enc.bevencode(_Pool.apply(feats, self.plan))
         z = self.pool(bev['terrain']).squeeze(1)                 # [1, H, W]: one terrain shared by all sampled rollouts
         mu = self.pool(bev['friction']).squeeze(1)
-        r = self.dp.rollout_costs(z, self.controls, friction=mu, pose_stride=self.pose_stride)
+        r = self.dp.rollout_costs(z, self.controls, friction=mu, pose_stride=self.pose_stride, project=self.cost == 'inclination')
         costs = r['force_cost'] if self.cost == 'force' else costs_from_rows(r['cost_rows'], self.cost)
         best = torch.argmin(costs)
         return dict(terrain=bev['terrain'], friction=bev['friction'], costs=costs, best=best, Xs=r['Xs'], Rs=r['Rs'],

@@ -16,7 +16,7 @@ one 16-byte cost row (the last row of R and the std over the contact points of |
 """
 import torch
 
-__all__ = ['sample_controls', 'force_path_cost', 'inclination_path_cost', 'costs_from_rows', 'TrajectoryShooter']
+__all__ = ['sample_controls', 'force_path_cost', 'inclination_path_cost', 'nearest_rotation_row2', 'costs_from_rows', 'TrajectoryShooter']
 
 
 def sample_controls(n_trajs, cfg, device, generator=None):
@@ -48,9 +48,25 @@ def costs_from_rows(cost_rows, kind):
 def inclination_path_cost(Rs):
     """[B,T,3,3] -> [B]: mean |roll| + mean |pitch| with roll/pitch of the extrinsic xyz Euler decomposition
     R = Rz(yaw) Ry(pitch) Rx(roll) (what scipy's `Rotation.as_euler('xyz')` returns; diff_physics.py:263-266)."""
-    pitch = torch.asin(torch.clamp(-Rs[..., 2, 0], -1.0, 1.0))
-    roll = torch.atan2(Rs[..., 2, 1], Rs[..., 2, 2])
+    # scipy's `from_matrix` projects a non-orthonormal matrix onto the nearest rotation first (U V^T of its SVD); the default
+    # integrator's R drifts off SO(3), so the same projection is applied here (the path-cost kernel does it in registers)
+    r2 = nearest_rotation_row2(Rs)
+    pitch = torch.asin(torch.clamp(-r2[..., 0], -1.0, 1.0))
+    roll = torch.atan2(r2[..., 1], r2[..., 2])
     return roll.abs().mean(dim=-1) + pitch.abs().mean(dim=-1)
+
+
+def nearest_rotation_row2(Rs, iters=3):
+    """Third row of the polar factor U V^T of [..., 3, 3] near-rotations by Newton's iteration X <- (X + X^-T) / 2 with the
+    closed-form 3x3 inverse (rows of X^-T = cross products of the rows of X over det); a batched SVD of 3e7 matrices is not
+    an option.  Quadratic convergence: 3 steps from |R R^T - I| = 0.06 are exact to float32."""
+    X = Rs
+    for _ in range(iters):
+        r0, r1, r2 = X[..., 0, :], X[..., 1, :], X[..., 2, :]
+        c0, c1, c2 = torch.linalg.cross(r1, r2), torch.linalg.cross(r2, r0), torch.linalg.cross(r0, r1)
+        det = (r0 * c0).sum(-1, keepdim=True)
+        X = 0.5 * (X + torch.stack([c0, c1, c2], dim=-2) / det.unsqueeze(-1))
+    return X[..., 2, :]
 
 
 class TrajectoryShooter:
@@ -79,7 +95,8 @@ class TrajectoryShooter:
             x = pose0[:3, 3].to(dev).repeat(B, 1)
             state = (x, torch.zeros_like(x), pose0[:3, :3].to(dev).repeat(B, 1, 1).contiguous(), torch.zeros_like(x))   # monoforce_node.py:67-72
         if self.fused and z.dtype == torch.float32:
-            out = self.dp.rollout_costs(z, controls, state=state, friction=mu, pose_stride=self.pose_stride)
+            out = self.dp.rollout_costs(z, controls, state=state, friction=mu, pose_stride=self.pose_stride,
+                                        project=self.cost == 'inclination')
             costs = out['force_cost'] if self.cost == 'force' else costs_from_rows(out['cost_rows'], self.cost)
             return dict(controls=controls, Xs=out['Xs'], Rs=out['Rs'], pose_steps=out['pose_steps'], costs=costs,
                         best=int(torch.argmin(costs)))

@@ -79,7 +79,16 @@ def test_cost_rows_match_full_outputs(integ, N, n_tracks, stride):
     (Xs, _, Rs, _), (Fs, _) = dp(z, ctrl, state=tuple(t.clone() for t in st), friction=mu)
     out = dp.rollout_costs(z, ctrl, state=st, friction=mu, pose_stride=stride)
     rows = out['cost_rows']
-    assert rows.shape == (B, T, 4) and torch.equal(rows[..., :3], Rs[:, :, 2, :])
+    assert rows.shape == (B, T, 4)
+    if integ == 0:          # dynamics(): R stays orthonormal and its third row is stored as is
+        assert torch.equal(rows[..., :3], Rs[:, :, 2, :])
+    else:                   # odeint-euler: third row of the nearest rotation (two Newton steps in the kernel vs SVD here)
+        U, _, Vh = torch.linalg.svd(Rs.double().cpu())
+        assert float((rows[..., :3].double().cpu() - (U @ Vh)[:, :, 2, :]).abs().max()) <= 2e-6
+        raw = dp.rollout_costs(z, ctrl, state=st, friction=mu, pose_stride=stride, project=False)      # ... or the raw row
+        assert torch.equal(raw['cost_rows'][..., :3], Rs[:, :, 2, :]) and torch.equal(raw['force_cost'], out['force_cost'])
+        from monoforce_amd.planner import nearest_rotation_row2
+        assert float((nearest_rotation_row2(Rs).double().cpu() - (U @ Vh)[:, :, 2, :]).abs().max()) <= 2e-6
     s_ref = torch.norm(Fs, dim=-1).std(dim=-1)
     assert hp.rel_err(rows[..., 3].cpu(), s_ref.cpu()) <= 2e-6, hp.rel_err(rows[..., 3].cpu(), s_ref.cpu())
     assert hp.rel_err(out['force_cost'].cpu(), s_ref.std(dim=-1).cpu()) <= 2e-5      # std over time, Welford in the kernel
@@ -87,3 +96,30 @@ def test_cost_rows_match_full_outputs(integ, N, n_tracks, stride):
     assert steps[-1] == T - 1 and steps.numel() == 1 + -(-(T - 1) // stride)
     assert torch.equal(out['Xs'], Xs[:, steps]) and torch.equal(out['Rs'], Rs[:, steps])
     assert torch.equal(st[0].cpu(), _start_state(B)[0])      # the caller's start state is untouched (the snap works on a copy)
+
+
+@pytest.mark.parametrize('name', ['A', 'B', 'C'])
+@pytest.mark.parametrize('integ', [0, 1])
+def test_path_costs_vs_reference_rollouts(name, integ):
+    """The kernel's path costs against the reference nodes' formulas applied to the REFERENCE's own rollout outputs (golden
+    vectors): norm(F_springs).std(points).std(time) (monoforce_node.py:91) and mean|roll| + mean|pitch| of scipy's
+    `as_euler('xyz')` (diff_physics.py:263-266)."""
+    from scipy.spatial.transform import Rotation
+    from monoforce_amd.planner import costs_from_rows
+    from tests.test_rollout_gpu import make_dphysics
+    g = hp.load('rollout_small')
+    pts, masks, z, ctrl, state, mu = hp.small_case(g, name, torch.float32)
+    pre = f'{name}/f64/i{integ}/'
+    Fs, Rs = g[pre + 'Fs'], g[pre + 'Rs']
+    B, T = Fs.shape[:2]
+    ref_force = np.linalg.norm(Fs, axis=-1).std(axis=-1, ddof=1).std(axis=-1, ddof=1)            # torch.std is unbiased
+    rpy = Rotation.from_matrix(Rs.reshape(-1, 3, 3)).as_euler('xyz').reshape(B, T, 3)
+    ref_incl = np.abs(rpy[..., 0]).mean(-1) + np.abs(rpy[..., 1]).mean(-1)
+    dp = make_dphysics(pts, masks, integ, hp.SMALL['grid_res'], hp.SMALL['d_max'])
+    st = None if state is None else tuple(s.to(DEV) for s in state)
+    out = dp.rollout_costs(z.to(DEV), ctrl.to(DEV), state=st, friction=None if mu is None else mu.to(DEV), pose_stride=8)
+    assert hp.rel_err(out['force_cost'].cpu().double(), ref_force) <= 1e-3, hp.rel_err(out['force_cost'].cpu().double(), ref_force)
+    incl = costs_from_rows(out['cost_rows'], 'inclination').cpu().double()
+    assert hp.rel_err(incl, ref_incl) <= 1e-3, hp.rel_err(incl, ref_incl)
+    steps = out['pose_steps'].cpu().numpy()
+    assert hp.rel_err(out['Xs'].cpu().double(), g[pre + 'Xs'][:, steps]) <= 1e-4
