@@ -14,6 +14,7 @@
  *                      scripts/fit_terrain.py:53-62, scripts/train.py:399-406)
  *   mf_bev_splat_*     terrain_encoder/lss.py:238-280 LiftSplatShoot.voxel_pooling() + terrain_encoder/utils.py:144-181
  *                      (cumsum_trick / QuickCumsum forward and backward)
+ *   mf_bev_lift_splat_*  the same with the lift of lss.py:63-71 (depth distribution x context features) fused in
  *   mf_physics_loss_*  losses.py:102-127 physics_loss (position term) and its gradient, on the nearest-time-stamp
  *                      subset of the predicted poses
  * (LiftSplatShoot.get_geometry(), lss.py:204-224, is a 3x3 transform of 120 k points: it stays plain torch.)
@@ -194,6 +195,8 @@ typedef struct MfSplatDesc {
   int32_t nx, ny, nz;   /* BEV grid (gen_dx_bx, terrain_encoder/utils.py:136-141) */
   float off[3];         /* bx - dx/2, computed in float32 like the reference */
   float dx[3];          /* voxel size */
+  int32_t lift_D;       /* mf_bev_lift_splat_*: depth bins per pixel (D) ... */
+  int32_t lift_hw;      /* ... and pixels per camera feature map (fH * fW); n_per_sample = cameras * lift_D * lift_hw.  0 otherwise */
 } MfSplatDesc;
 
 size_t mf_bev_splat_workspace_bytes(const MfSplatDesc* desc); /* 0 on a bad descriptor */
@@ -204,6 +207,19 @@ int mf_bev_splat_fwd_f64(const MfSplatDesc* desc, const double* x, const void* w
 /* gx[B*n_per_sample][C] = gout at the point's voxel, 0 for dropped points (QuickCumsum.backward, utils.py:174-181) */
 int mf_bev_splat_bwd_f32(const MfSplatDesc* desc, const float* gout, const void* workspace, float* gx, void* hip_stream);
 int mf_bev_splat_bwd_f64(const MfSplatDesc* desc, const double* gout, const void* workspace, double* gx, void* hip_stream);
+
+/* The lift fused into the splat (lss.py:63-71 + :238-280): point p = ((cam * D + d) * fHW + pixel) carries
+ * depth[p] * ctx[cam * fHW + pixel][0..C) without the [points][C] tensor ever being materialised.
+ *   depth  S[B*cameras][D][fH][fW]   softmax depth distribution (= point order)
+ *   ctx    S[B*cameras][fH][fW][C]   context features, PIXEL-major
+ * fwd: out[B][nz*C][nx][ny] as mf_bev_splat_fwd.  bwd: g_depth (like depth), g_ctx (like ctx); rows_scratch = S[B*nz*nx*ny][C]
+ * (the BEV gradient re-laid voxel-major for the occupied tiles).  Same prepared workspace as the plain splat. */
+int mf_bev_lift_splat_fwd_f32(const MfSplatDesc* desc, const float* depth, const float* ctx, const void* workspace, float* out, void* hip_stream);
+int mf_bev_lift_splat_fwd_f64(const MfSplatDesc* desc, const double* depth, const double* ctx, const void* workspace, double* out, void* hip_stream);
+int mf_bev_lift_splat_bwd_f32(const MfSplatDesc* desc, const float* depth, const float* ctx, const void* workspace, const float* gout,
+                              float* rows_scratch, float* g_depth, float* g_ctx, void* hip_stream);
+int mf_bev_lift_splat_bwd_f64(const MfSplatDesc* desc, const double* depth, const double* ctx, const void* workspace, const double* gout,
+                              double* rows_scratch, double* g_depth, double* g_ctx, void* hip_stream);
 
 /* ---- fused physics loss (losses.py:102-127) -------------------------------------------------------------------
  * loss = mean_{b,j,c} ((Xs[b, nearest[b,j], c] - Xgt[b,j,c]) * w[b,j])^2,  w = 1 / (1 + gamma * gt_ts[b,j]).

@@ -44,12 +44,13 @@ class MfLossDesc(C.Structure):
 class MfSplatDesc(C.Structure):
     _fields_ = [('B', C.c_int32), ('n_per_sample', C.c_int32), ('C', C.c_int32),
                 ('nx', C.c_int32), ('ny', C.c_int32), ('nz', C.c_int32),
-                ('off', C.c_float * 3), ('dx', C.c_float * 3)]
+                ('off', C.c_float * 3), ('dx', C.c_float * 3), ('lift_D', C.c_int32), ('lift_hw', C.c_int32)]
 
 
 # every symbol include/monoforce_hip.h declares; tests check the library exports all of them
 SYMBOLS = ['mf_rollout_force_stride', 'mf_rollout_fwd_f32', 'mf_rollout_fwd_f64', 'mf_rollout_default_state_f32', 'mf_rollout_default_state_f64', 'mf_rollout_bwd_f32', 'mf_rollout_bwd_f64', 'mf_bev_splat_workspace_bytes', 'mf_bev_splat_prepare',
            'mf_bev_splat_fwd_f32', 'mf_bev_splat_fwd_f64', 'mf_bev_splat_bwd_f32', 'mf_bev_splat_bwd_f64',
+           'mf_bev_lift_splat_fwd_f32', 'mf_bev_lift_splat_fwd_f64', 'mf_bev_lift_splat_bwd_f32', 'mf_bev_lift_splat_bwd_f64',
            'mf_physics_loss_fwd_f32', 'mf_physics_loss_fwd_f64', 'mf_physics_loss_bwd_f32', 'mf_physics_loss_bwd_f64', 'mf_last_error', 'mf_version', 'mf_sizeof']
 
 _lib = None

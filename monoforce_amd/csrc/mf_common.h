@@ -53,6 +53,14 @@ __device__ __forceinline__ double read_lane63(double v) {
   p.y = __builtin_amdgcn_readlane(p.y, 63);
   return __builtin_bit_cast(double, p);
 }
+// value of lane `l` (wave-uniform index) as a scalar
+__device__ __forceinline__ float mf_readlane(float v, int l) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l)); }
+__device__ __forceinline__ double mf_readlane(double v, int l) {
+  int2 p = __builtin_bit_cast(int2, v);
+  p.x = __builtin_amdgcn_readlane(p.x, l);
+  p.y = __builtin_amdgcn_readlane(p.y, l);
+  return __builtin_bit_cast(double, p);
+}
 __device__ __forceinline__ float lane_xor(float v, int m) { return __shfl_xor(v, m, 64); }
 __device__ __forceinline__ double lane_xor(double v, int m) { return __shfl_xor(v, m, 64); }
 

@@ -16,7 +16,7 @@ only and are built once, outside the graph.
 import torch
 
 from .planner import costs_from_rows, sample_controls
-from .splat import SplatPlan, _Pool
+from .splat import SplatPlan, _LiftPool
 
 __all__ = ['GraphedTerrainPlanner']
 
@@ -46,8 +46,9 @@ class GraphedTerrainPlanner:
 
     def _pipeline(self):
         enc = self.enc
-        feats = enc.get_cam_feats(self.imgs)
-        bev = enc.bevencode(_Pool.apply(feats, self.plan))
+        B, N, C, imH, imW = self.imgs.shape
+        depth, context = enc.camencode.get_depth_and_context(self.imgs.view(B * N, C, imH, imW))
+        bev = enc.bevencode(_LiftPool.apply(depth, context, self.plan))
         z = self.pool(bev['terrain']).squeeze(1)                 # [1, H, W]: one terrain shared by all sampled rollouts
         mu = self.pool(bev['friction']).squeeze(1)
         r = self.dp.rollout_costs(z, self.controls, friction=mu, pose_stride=self.pose_stride, project=self.cost == 'inclination')

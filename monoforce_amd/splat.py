@@ -71,6 +71,51 @@ class _Pool(torch.autograd.Function):
         return gx.view(ctx.x_shape), None
 
 
+class _LiftPool(torch.autograd.Function):
+    """`mf_bev_lift_splat_*`: the lift `softmax(depth) (x) context` (lss.py:63-71) fused into the voxel pooling (lss.py:238-280);
+    the [B,N,D,fH,fW,C] tensor of lifted features (30.9 MB per sample at config-4 shapes) is never built."""
+
+    @staticmethod
+    def forward(ctx, depth, context, plan):
+        BN, D, fH, fW = depth.shape
+        Cc = context.shape[1]
+        assert context.shape == (BN, Cc, fH, fW) and BN * D * fH * fW == plan.B * plan.n_per_sample, \
+            'depth / context and the geometry disagree on the number of frustum points'
+        sfx = {torch.float32: 'f32', torch.float64: 'f64'}[depth.dtype]
+        dep = depth.contiguous()
+        ctxT = context.to(depth.dtype).permute(0, 2, 3, 1).contiguous()          # pixel-major rows [BN, fH, fW, C] (0.5 MB per sample)
+        d = plan.desc(Cc)
+        d.lift_D, d.lift_hw = D, fH * fW
+        out = torch.empty(plan.B, plan.nz * Cc, plan.nx, plan.ny, dtype=dep.dtype, device=dep.device)
+        with torch.cuda.device(dep.device), _timing.timed('lift_splat_fwd_kernel', dep.device):
+            _lib.check(getattr(_lib.lib(), 'mf_bev_lift_splat_fwd_' + sfx)(C.byref(d), _lib.ptr(dep), _lib.ptr(ctxT), _lib.ptr(plan.workspace),
+                                                                            _lib.ptr(out), _stream_ptr(dep.device)), 'mf_bev_lift_splat_fwd')
+        ctx.save_for_backward(dep, ctxT)
+        ctx.plan, ctx.d, ctx.sfx = plan, d, sfx
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        dep, ctxT = ctx.saved_tensors
+        plan, d = ctx.plan, ctx.d
+        g = gout.contiguous()
+        rows = torch.empty(plan.B * plan.nz * plan.nx * plan.ny, d.C, dtype=g.dtype, device=g.device)     # voxel-major gradient rows
+        g_dep, g_ctx = torch.empty_like(dep), torch.empty_like(ctxT)
+        with torch.cuda.device(g.device), _timing.timed('lift_splat_bwd_kernel', g.device):
+            _lib.check(getattr(_lib.lib(), 'mf_bev_lift_splat_bwd_' + ctx.sfx)(
+                C.byref(d), _lib.ptr(dep), _lib.ptr(ctxT), _lib.ptr(plan.workspace), _lib.ptr(g), _lib.ptr(rows), _lib.ptr(g_dep),
+                _lib.ptr(g_ctx), _stream_ptr(g.device)), 'mf_bev_lift_splat_bwd')
+        return g_dep, g_ctx.permute(0, 3, 1, 2), None
+
+
+def lift_voxel_pooling(geom, depth, context, dx, bx, nx, plan=None):
+    """geom [B,N,D,fH,fW,3], depth [B*N,D,fH,fW], context [B*N,C,fH,fW] -> [B, C*nz, nx, ny]: == voxel_pooling(geom, lift)."""
+    _lib.require_hip_tensor(depth, 'depth')
+    if plan is None:
+        plan = SplatPlan(geom, dx, bx, nx)
+    return _LiftPool.apply(depth, context, plan)
+
+
 def voxel_pooling(geom, x, dx, bx, nx, plan=None):
     """geom [B,N,D,H,W,3], x [B,N,D,H,W,C] -> [B, C*nz, nx, ny] (lss.py:238-280).  No gradient to geom, as in the reference."""
     _lib.require_hip_tensor(x, 'x')

@@ -71,10 +71,14 @@ class CamEncode(nn.Module):
         endpoints.append(x)
         return self.up1(endpoints[4], endpoints[3])
 
-    def get_depth_feat(self, x):
+    def get_depth_and_context(self, x):
+        """The two factors of the lift: depth distribution [BN,D,fH,fW] and context features [BN,C,fH,fW]."""
         x = self.depthnet(self.get_eff_depth(x))
-        depth = self.get_depth_dist(x[:, :self.D])
-        return depth, depth.unsqueeze(1) * x[:, self.D:self.D + self.C].unsqueeze(2)
+        return self.get_depth_dist(x[:, :self.D]), x[:, self.D:self.D + self.C]
+
+    def get_depth_feat(self, x):
+        depth, context = self.get_depth_and_context(x)
+        return depth, depth.unsqueeze(1) * context.unsqueeze(2)
 
     def forward(self, x):
         return self.get_depth_feat(x)[1]
@@ -126,6 +130,7 @@ class LiftSplatShoot(nn.Module):
             self.camencode = CamEncode(self.D, self.camC)
             self.bevencode = BevEncode(inC=self.camC, outC=outC)
         self.use_quickcumsum = True      # accepted for compatibility; both reference paths compute the same sums
+        self.fuse_lift = True            # lift (depth x context) inside the splat kernels; False: get_cam_feats + voxel_pooling
 
     def create_frustum(self):
         """(u, v, d) of every lifted point: pixel centres on the /16 feature grid x depth bins (lss.py:191-202)."""
@@ -167,6 +172,11 @@ class LiftSplatShoot(nn.Module):
 
     def get_voxels(self, x, rots, trans, intrins, post_rots, post_trans):
         geom = self.get_geometry(rots, trans, intrins, post_rots, post_trans)
+        if self.fuse_lift and x.is_cuda:
+            # lift fused into the splat: the [B,N,D,fH,fW,C] tensor of get_cam_feats() is never materialised
+            B, N, C, imH, imW = x.shape
+            depth, context = self.camencode.get_depth_and_context(x.view(B * N, C, imH, imW))
+            return splat.lift_voxel_pooling(geom, depth, context, self.dx, self.bx, self.nx)
         return self.voxel_pooling(geom, self.get_cam_feats(x))
 
     def forward(self, x, rots, trans, intrins, post_rots, post_trans):

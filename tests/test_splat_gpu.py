@@ -114,3 +114,34 @@ def test_plan_reuse():
     b = voxel_pooling(geom.to(DEV), torch.as_tensor(x).to(DEV), m.dx, m.bx, m.nx)
     c = voxel_pooling(None, torch.as_tensor(x[..., :16].copy()).to(DEV), None, None, None, plan=plan)   # other C, same plan
     assert torch.equal(a, b) and torch.equal(c, a[:, :16])
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+@pytest.mark.parametrize('shape', [dict(B=1, N=4, D=59, fH=16, fW=32, C=64, nx=256, nz=1), dict(B=2, N=3, D=7, fH=5, fW=9, C=80, nx=40, nz=2),
+                                   dict(B=1, N=1, D=70, fH=3, fW=4, C=5, nx=24, nz=1)])
+def test_fused_lift_splat_equals_lift_then_splat(dtype, shape):
+    """mf_bev_lift_splat_* (depth x context inside the splat) vs the materialised lift followed by the plain splat: forward,
+    and the gradients w.r.t. depth and context, incl. C not a multiple of 64, D > 64, nz > 1 and dropped points."""
+    from monoforce_amd import splat
+    B, N, D, fH, fW, C, nx, nz = (shape[k] for k in ('B', 'N', 'D', 'fH', 'fW', 'C', 'nx', 'nz'))
+    g = torch.Generator().manual_seed(5)
+    half = nx * 0.05 / 2
+    geom = (torch.rand(B, N, D, fH, fW, 3, generator=g) * 2 - 1) * torch.tensor([half * 1.3, half * 1.3, 3.0])   # ~40 % outside in x or y
+    dx = torch.tensor([0.05, 0.05, 6.4 / nz]); bx = torch.tensor([-half + 0.025, -half + 0.025, -3.2 + 3.2 / nz]); nxv = torch.tensor([nx, nx, nz])
+    depth0 = torch.rand(B * N, D, fH, fW, generator=g).softmax(dim=1).to(dtype)
+    ctx0 = torch.randn(B * N, C, fH, fW, generator=g).to(dtype)
+    w = torch.randn(B, C * nz, nx, nx, generator=g).to(dtype).to(DEV)
+    plan = splat.SplatPlan(geom.to(DEV), dx, bx, nxv)
+
+    d1, c1 = depth0.to(DEV).requires_grad_(True), ctx0.to(DEV).requires_grad_(True)
+    x = (d1.unsqueeze(1) * c1.unsqueeze(2)).view(B, N, C, D, fH, fW).permute(0, 1, 3, 4, 5, 2)          # lss.py:63-71, 226-236
+    ref = splat.voxel_pooling(geom.to(DEV), x, dx, bx, nxv, plan=plan)
+    (ref * w).sum().backward()
+
+    d2, c2 = depth0.to(DEV).requires_grad_(True), ctx0.to(DEV).requires_grad_(True)
+    out = splat.lift_voxel_pooling(geom.to(DEV), d2, c2, dx, bx, nxv, plan=plan)
+    (out * w).sum().backward()
+    tol = 1e-12 if dtype == torch.float64 else 2e-6
+    assert torch.equal(out, ref)                       # same products (rounded before the add), same summation order
+    assert hp.rel_err(d2.grad.cpu(), d1.grad.cpu()) <= tol, hp.rel_err(d2.grad.cpu(), d1.grad.cpu())
+    assert hp.rel_err(c2.grad.cpu(), c1.grad.cpu()) <= tol, hp.rel_err(c2.grad.cpu(), c1.grad.cpu())

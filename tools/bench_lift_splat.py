@@ -1,0 +1,36 @@
+"""Lift + splat at config-4 shapes: materialised lift followed by mf_bev_splat_* vs the fused mf_bev_lift_splat_*."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from monoforce_amd import splat, synthetic as syn
+from monoforce_amd.terrain_encoder import LiftSplatShoot
+DEV = 'cuda'
+gc = dict(xbound=[-6.4, 6.4, 0.05], ybound=[-6.4, 6.4, 0.05], zbound=[-3.2, 3.2, 6.4], dbound=[0.6, 6.4, 0.1])
+enc = LiftSplatShoot(gc, dict(final_dim=(256, 512))).to(DEV)
+for B in (1, 8):
+    calib = [t.to(DEV) for t in syn.lss_camera_rig(B)]
+    with torch.no_grad():
+        geom = enc.get_geometry(*calib)
+    _, N, D, fH, fW, _ = geom.shape
+    C = 64
+    plan = splat.SplatPlan(geom, enc.dx, enc.bx, enc.nx)
+    depth = torch.rand(B * N, D, fH, fW, device=DEV).softmax(dim=1).requires_grad_(True)
+    ctx = torch.randn(B * N, C, fH, fW, device=DEV, requires_grad=True)
+    w = torch.randn(B, C, 256, 256, device=DEV)
+    def unfused():
+        x = (depth.unsqueeze(1) * ctx.unsqueeze(2)).view(B, N, C, D, fH, fW).permute(0, 1, 3, 4, 5, 2)
+        return splat._Pool.apply(x, plan)
+    def fused():
+        return splat._LiftPool.apply(depth, ctx, plan)
+    for name, fn in (('lift + splat', unfused), ('fused lift-splat', fused)):
+        for _ in range(3):
+            out = fn(); (out * w).sum().backward()
+        torch.cuda.synchronize()
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        tf = tb = 0.0
+        for _ in range(10):
+            depth.grad = ctx.grad = None
+            e[0].record(); out = fn(); e[1].record(); out.backward(w); e[2].record()
+            torch.cuda.synchronize()
+            tf += e[0].elapsed_time(e[1]); tb += e[1].elapsed_time(e[2])
+        print(f'B={B} {name:18s} forward {tf / 10 * 1e3:7.1f} us   backward {tb / 10 * 1e3:7.1f} us', flush=True)
