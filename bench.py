@@ -185,7 +185,11 @@ class Runner:
         P4 = 4 * 59 * 16 * 32                                  # frustum points per sample at the config-4 shapes
         alg = {'rollout_fwd_kernel': fwd_bytes_per_rollout_step(N) * B * T, 'rollout_bwd_kernel': bwd_bytes_per_rollout_step(N) * B * T,
                'splat_fwd_kernel': 4 * 64 * P4 + 12 * P4 + 4 * 64 * 256 * 256, 'splat_bwd_kernel': 4 * 64 * 256 * 256 + 4 * 64 * P4,
-               'splat_prepare': 20 * P4}
+               'splat_prepare': 20 * P4,
+               # lift fused into the splat: depth 4 P + context 4*64*pixels + out / the reverse + the voxel-major rows
+               'lift_splat_fwd_kernel': 4 * P4 + 4 * 64 * (P4 // 59) + 4 * 64 * 256 * 256,
+               'lift_splat_bwd_kernel': 4 * 64 * 256 * 256 + 8 * P4 + 2 * 4 * 64 * (P4 // 59),
+               'physics_loss_fwd': 12 * 50 * B * 2, 'physics_loss_bwd': 12 * 50 * B * 2}
         kern = {k: v for k, v in kern.items() if k in alg}
         dom = max(kern, key=kern.get)                          # the dominant hand-written kernel of the step
         per_kernel = {k: {'ms': v, 'algorithmic_bytes': alg[k], 'GB/s': alg[k] / (v * 1e-3) / 1e9,
