@@ -117,6 +117,7 @@ class _RolloutFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, mod, z, mu, controls, x0, xd0, R0, w0, ts, want_grad, joint_angles=None, want_forces=True):
+        x0 = mod._x0_buf            # detached, contiguous, right dtype/device; receives the snapped height
         desc, keep = mod._make_desc(z, mu, controls)
         if joint_angles is not None:
             desc.has_joints = 1
@@ -299,13 +300,17 @@ class DPhysics(torch.nn.Module):
             x0 = x0.clone(); aliased = False
         xd0, R0, w0 = (s.to(device=dev, dtype=dtype).contiguous() for s in state[1:])
         want_grad = torch.is_grad_enabled() and any(
-            t is not None and t.requires_grad for t in (z_grid, friction, controls, xd0, R0, w0))
+            t is not None and t.requires_grad for t in (z_grid, friction, controls, x_in, xd0, R0, w0))
         want_forces = self.return_forces or self.precise or dtype != torch.float32 or ja_dev is not None
         self._own_state = own_state
-        outs = _RolloutFn.apply(self, z_grid, friction, controls.contiguous(), x0, xd0, R0, w0, ts, want_grad, ja_dev, want_forces)
+        # a start position that requires grad is the autograd input itself (its gradient: x and y through the contact geometry,
+        # z none -- the snap overwrites it); the kernel works on the detached buffer x0 either way
+        x_arg = x_in if (want_grad and x_in.requires_grad) else x0
+        self._x0_buf = x0
+        outs = _RolloutFn.apply(self, z_grid, friction, controls.contiguous(), x_arg, xd0, R0, w0, ts, want_grad, ja_dev, want_forces)
         if not aliased:
-            with torch.no_grad():
-                x_in[..., 2] = x0[..., 2].to(device=x_in.device, dtype=x_in.dtype)   # the reference's in-place write
+            with torch.no_grad():       # the reference's in-place write (through .data: no version bump on a tensor autograd saved)
+                x_in.data[..., 2] = x0[..., 2].to(device=x_in.device, dtype=x_in.dtype)
         Xs, Xds, Rs, Omegas = outs[:4]
         F_springs, F_frictions = outs[4:] if len(outs) == 6 else (None, None)
         return (Xs, Xds, Rs, Omegas), (F_springs, F_frictions)

@@ -196,3 +196,41 @@ def test_gradient_descent_recovers_terrain_offset():
         opt.step()
         losses.append(float(loss))
     assert np.isfinite(losses).all() and losses[-1] < 0.8 * losses[0], (losses[0], losses[-1])
+
+
+@pytest.mark.parametrize('integ', [0, 1])
+def test_gradient_wrt_start_position(integ):
+    """d loss / d x0: x and y through the contact geometry of every step, z none (the terrain snap overwrites it) -- vs the
+    oracle's autograd through the same in-place snap."""
+    from monoforce_amd import synthetic as syn
+    from oracle import dphysics_oracle as orc
+    from tests.golden_state import given_state
+    pts, masks = syn.robot_points_box(7, seed=2, n_tracks=2)
+    B, T = 3, 30
+    z = torch.stack([syn.bump_terrain(syn.bump_params(20 + b), 3.2, 0.1, torch.float64) * 0.3 for b in range(B)])
+    ctrl = syn.varying_controls(B, T, seed=4, dtype=torch.float64)
+    spec = hp.spec_from(pts, masks, integ, 0.1, 3.2)
+
+    def run(fn, dev):
+        st = [s.clone().to(dev) for s in given_state(B)]
+        leaf = st[0].clone().requires_grad_(True)
+        st[0] = leaf * 1.0                      # non-leaf: the in-place snap is legal on it
+        outs = fn(z.to(dev), ctrl.to(dev), tuple(st))
+        hp.probe_loss(outs, torch.float64).backward()
+        return leaf.grad.cpu(), st[0].detach().cpu()
+
+    def f_oracle(zz, cc, st):
+        so, fo = orc.rollout(spec, zz, cc, state=st)
+        return list(so) + list(fo)
+
+    dp = make_dphysics(pts, masks, integ, 0.1, 3.2)
+
+    def f_hip(zz, cc, st):
+        s, f = dp(zz, cc, state=st)
+        return list(s) + list(f)
+
+    g_ref, x_ref = run(f_oracle, 'cpu')
+    g_hip, x_hip = run(f_hip, DEV)
+    assert float(g_ref[:, :2].abs().max()) > 0 and float(g_hip[:, 2].abs().max()) == 0.0
+    assert hp.rel_err(g_hip, g_ref) <= 1e-8, hp.rel_err(g_hip, g_ref)
+    assert hp.rel_err(x_hip, x_ref) <= 1e-12          # both wrote the snapped height into the caller's tensor
