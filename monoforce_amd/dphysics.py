@@ -287,6 +287,9 @@ class DPhysics(torch.nn.Module):
             assert joint_angles.shape == (B, N_ts, 4), f'Joint angles shape {joint_angles.shape} != {(B, N_ts, 4)}'
             # the reference re-articulates the body only for robot == 'marv' and non-zero angles (dphysics.py:340)
             if cfg.robot == 'marv' and not torch.allclose(joint_angles, torch.zeros_like(joint_angles)):
+                if joint_angles.requires_grad and torch.is_grad_enabled():
+                    raise NotImplementedError('the HIP rollout treats joint angles as constants: no gradient w.r.t. joint_angles '
+                                              '(detach them, or use the CPU reference for that derivative)')
                 ja_dev = joint_angles.detach().to(device=dev, dtype=dtype).contiguous()
         self.joint_angles = joint_angles
         self.ts = self.ts[:N_ts]                                                     # permanent, like the reference (:581)

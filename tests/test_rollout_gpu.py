@@ -248,6 +248,8 @@ def test_flipper_joint_angles_vs_reference(tag, precise, integ):
     for i, (o, sc) in enumerate(zip(list(states) + list(forces), [1.0, 1.0, 1.0, 1.0, 1e-3, 1e-3])):
         loss = loss + (o * syn.probe_weights(o.shape, phase=0.5 + i, dtype=dt).to(DEV)).sum() * sc
     loss.backward()
+    with pytest.raises(NotImplementedError, match='joint angles as constants'):      # loud, not a silent zero gradient
+        dp(t('z'), t('ctrl'), joint_angles=t('joint_angles').requires_grad_(True), friction=t('mu'))
     pre = f'{tag}/i{integ}/'
     gtol = 1e-8 if tag == 'f64' else 2e-4
     assert abs(float(loss) - float(g[pre + 'loss'])) <= gtol * abs(float(g[pre + 'loss'])) + gtol
