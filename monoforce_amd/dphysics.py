@@ -116,8 +116,11 @@ class _RolloutFn(torch.autograd.Function):
     """forward = mf_rollout_fwd_*; backward = mf_rollout_bwd_* (reverse-time adjoint of the same scan)."""
 
     @staticmethod
-    def forward(ctx, mod, z, mu, controls, x0, xd0, R0, w0, ts, want_grad, joint_angles=None, want_forces=True):
-        x0 = mod._x0_buf            # detached, contiguous, right dtype/device; receives the snapped height
+    def forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_grad, joint_angles=None, want_forces=True,
+                x0_buf=None, x0_private=False):
+        # x_arg is the autograd input (the caller's start position when it requires grad); the kernel works on x0_buf, the
+        # detached contiguous buffer that receives the snapped height.  x0_private: nobody else sees that buffer.
+        x0 = x0_buf if x0_buf is not None else x_arg
         desc, keep = mod._make_desc(z, mu, controls)
         if joint_angles is not None:
             desc.has_joints = 1
@@ -155,13 +158,13 @@ class _RolloutFn(torch.autograd.Function):
             ctx.z_shape, ctx.mu_given = z.shape, mu is not None
             ctx.joint_angles = joint_angles          # constants of the rollout (no gradient), kept for the backward
             # x0 now holds the snapped start position; a caller-visible buffer is copied, the module's own default is not
-            ctx.save_for_backward(controls, x0 if mod._own_state else x0.clone(), xd0, R0, w0, ts, Xraw, Xds, Rs, Om)
+            ctx.save_for_backward(controls, x0 if x0_private else x0.clone(), xd0, R0, w0, ts, Xraw, Xds, Rs, Om)
         return outs
 
     @staticmethod
     def backward(ctx, gXs, gXds, gRs, gOm, gFs=None, gFf=None):
         from .dphysics_bwd import rollout_backward
-        return rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf) + (None, None)
+        return rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf) + (None, None, None, None)
 
 
 class DPhysics(torch.nn.Module):
@@ -305,12 +308,11 @@ class DPhysics(torch.nn.Module):
         want_grad = torch.is_grad_enabled() and any(
             t is not None and t.requires_grad for t in (z_grid, friction, controls, x_in, xd0, R0, w0))
         want_forces = self.return_forces or self.precise or dtype != torch.float32 or ja_dev is not None
-        self._own_state = own_state
         # a start position that requires grad is the autograd input itself (its gradient: x and y through the contact geometry,
         # z none -- the snap overwrites it); the kernel works on the detached buffer x0 either way
         x_arg = x_in if (want_grad and x_in.requires_grad) else x0
-        self._x0_buf = x0
-        outs = _RolloutFn.apply(self, z_grid, friction, controls.contiguous(), x_arg, xd0, R0, w0, ts, want_grad, ja_dev, want_forces)
+        outs = _RolloutFn.apply(self, z_grid, friction, controls.contiguous(), x_arg, xd0, R0, w0, ts, want_grad, ja_dev, want_forces,
+                                x0, own_state)
         if not aliased:
             with torch.no_grad():       # the reference's in-place write (through .data: no version bump on a tensor autograd saved)
                 x_in.data[..., 2] = x0[..., 2].to(device=x_in.device, dtype=x_in.dtype)
