@@ -94,6 +94,9 @@ extern "C" int mf_rollout_fwd_f32(const MfRolloutDesc* d, const MfRolloutFwdBufs
   }
   if (d->math_mode == MF_MATH_FAST) {
     if (!forces && m.PPL == 4 && m.G < 64) m = mf::choose_lane_map(d->B, d->N, 1);
+    // >= one wave per SIMD (1024) and a one-point-per-lane mapping within a wave: the split-store kernels (rollout_fwd_kernel.h)
+    if (m.PPL == 1 && m.G <= 64 && (long long)d->B * m.G >= 1024ll * 64)
+      return mf::launch_rollout_fwd_split_fast_f32(a, m, d->integrator, block, forces, (hipStream_t)s);
     return mf::launch_rollout_fwd_fast_f32(a, m, d->integrator, block, forces, (hipStream_t)s);
   }
   return mf::launch_rollout_fwd<float, false>(a, m, d->integrator, block, (hipStream_t)s);

@@ -158,7 +158,7 @@ __device__ __forceinline__ void articulate_body(GroupSum<G, S>& gs, const S* ja,
   Iv[6] = c02 * idet; Iv[7] = c12 * idet; Iv[8] = c22 * idet;
 }
 
-template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS = false, bool FORCES = true, int COST = 0>
+template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS = false, bool FORCES = true, int COST = 0, bool SPLIT = false>
 __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a) {
   using M = Mth<S, FAST>;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -247,8 +247,6 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
 
   // Stores of the pending output row (the state registers ARE that row).  Every lane of the group stores the same state
   // values to the same addresses (no exec-mask branch on the issue stream; the coalescer merges them) and its own forces.
-  // (Splitting the 21 state floats over the lanes of the group -- 2 stores instead of 7 -- was measured: same store
-  // bandwidth, more selects; tools/microbench/store_patterns.hip.)
   // COST kernels (trajectory shooting): instead of the 84 + 24 N bytes of a full output row they write one
   // 16-byte cost row -- what the reference's path costs read (monoforce_node.py:91: norm(F_springs).std(points);
   // diff_physics.py:263-266: roll / pitch from the last row of R) -- and keep every pose_stride-th pose (the nodes publish
@@ -256,6 +254,18 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
   // branch at the very END of the step that produced it: the arithmetic of a step stays one basic block, so the FMA
   // contraction -- and with it every bit of the trajectory -- is the one of the full-output kernels.
   S* pC = COST ? a.cost_rows + row0 * 4 : nullptr;
+  // SPLIT kernels: the replicated state of a group is written by its lanes in turn -- lane role (gl & 3) = 0..3 stores the
+  // vec3 of Xraw / Xs / Xds / Omegas and row min(role, 2) of R: 2 store instructions per step instead of 7 four-times-redundant
+  // ones (+2 for the forces).  Once every SIMD has a wave the CU's memory pipeline, which takes ~16 cycles per instruction
+  // whatever its payload, bounds the kernel (B = 16384: 0.67 -> 0.53 ms); below that the 15 selects it costs lose
+  // (B = 1024: 0.31 -> 0.34 ms), so the host picks by launch size.
+  const int role = gl & 3;
+  const bool role_b0 = (role & 1) != 0, role_b1 = (role & 2) != 0;
+  // roles 0 and 1 both store x + R[:, 2] * s: s = 0 is the unshifted Xraw row, s = sink the Xs row; without an Xraw buffer
+  // role 0 writes the Xs row as well (same address, same value as role 1)
+  const S sink_l = (role == 0 && a.Xraw) ? zero : a.sink;
+  S* pV3 = role == 0 ? pXraw : role == 1 ? pXs : role == 2 ? pXds : pOm;
+  S* pRrow = pRs + 3 * min(role, 2);
   int pose_wait = 0;   // output rows still to pass before the next pose is due
   S pc_n = zero, pc_mean = zero, pc_m2 = zero;   // path cost accumulators (COST)
   auto store_pose = [&]() {
@@ -313,6 +323,32 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
     // streaming (non-temporal) stores: the rows are never read again by this kernel and must not evict the map cells the
     // gathers keep hitting in L1 / L2
     auto st = [](S* p, S v) { __builtin_nontemporal_store(v, p); };
+    if (SPLIT && G >= 4) {
+      S v3[3], rr[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const S t0 = x[c] + R[3 * c + 2] * sink_l;
+        const S t1 = role_b0 ? w[c] : xd[c];
+        v3[c] = role_b1 ? t1 : t0;
+        const S r0 = role_b0 ? R[3 + c] : R[c];
+        rr[c] = role_b1 ? R[6 + c] : r0;
+      }
+      st(pV3 + 0, v3[0]); st(pV3 + 1, v3[1]); st(pV3 + 2, v3[2]);
+      st(pRrow + 0, rr[0]); st(pRrow + 1, rr[1]); st(pRrow + 2, rr[2]);
+      pV3 += adv * 3; pRrow += adv * 9;
+      if (FORCES) {
+#pragma unroll
+        for (int j = 0; j < PPL; ++j)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) st(pFs + j * 3 + c, oFs[j][c]);
+#pragma unroll
+        for (int j = 0; j < PPL; ++j)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) st(pFf + j * 3 + c, oFf[j][c]);
+        pFs += adv * frow; pFf += adv * frow;
+      }
+      return;
+    }
     st(pXraw + 0, x[0]); st(pXraw + 1, x[1]); st(pXraw + 2, x[2]);
     st(pXs + 0, x[0] + R[2] * a.sink);  // Xs += Rs[..., :, 2] * m g / (k + 1e-6)   (dphysics.py:587-589)
     st(pXs + 1, x[1] + R[5] * a.sink);
@@ -596,7 +632,7 @@ static inline LaneMap choose_lane_map(int B, int N, int points_per_lane) {
 
 // Instantiated mappings: one point per lane (G = 4..64) and (64, 2/4/8) always; the 4-points-per-lane mappings with G < 64
 // only for the full-output rigid-body kernels (they are a tuning / test option, see choose_lane_map).
-template <typename S, bool FAST, bool JOINTS = false, bool FORCES = true, int COST = 0>
+template <typename S, bool FAST, bool JOINTS = false, bool FORCES = true, int COST = 0, bool SPLIT = false>
 int launch_rollout_fwd(const RolloutArgs<S>& a, LaneMap m, int integ, int block, hipStream_t st) {
   if (m.G > 64) block = m.G;   // a rollout spread over several waves: exactly one rollout per workgroup (LDS + barrier)
   const long long threads = (long long)a.B * m.G;
@@ -606,14 +642,17 @@ int launch_rollout_fwd(const RolloutArgs<S>& a, LaneMap m, int integ, int block,
   if (!launched && m.G == G_ && m.PPL == P_) {                                                                                             \
     launched = true;                                                                                                                       \
     if (integ == MF_INTEG_DYNAMICS)                                                                                                        \
-      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_DYNAMICS, FAST, JOINTS, FORCES, COST>), dim3(grid), dim3(block), 0, st, a);      \
+      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_DYNAMICS, FAST, JOINTS, FORCES, COST, SPLIT>), dim3(grid), dim3(block), 0, st, a);      \
     else                                                                                                                                   \
-      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_ODEINT_EULER, FAST, JOINTS, FORCES, COST>), dim3(grid), dim3(block), 0, st, a);  \
+      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_ODEINT_EULER, FAST, JOINTS, FORCES, COST, SPLIT>), dim3(grid), dim3(block), 0, st, a);  \
   }
-  if (!JOINTS) { MF_CASE(4, 1) MF_CASE(8, 1) MF_CASE(16, 1) MF_CASE(32, 1) MF_CASE(64, 1) MF_CASE(64, 2) }
+  if (!JOINTS) { MF_CASE(4, 1) MF_CASE(8, 1) MF_CASE(16, 1) MF_CASE(32, 1) MF_CASE(64, 1) }
+  if constexpr (!SPLIT) {
+  if (!JOINTS) { MF_CASE(64, 2) }
   MF_CASE(128, 1) MF_CASE(256, 1)
   if (FORCES) { MF_CASE(1, 4) MF_CASE(2, 4) MF_CASE(4, 4) MF_CASE(8, 4) MF_CASE(16, 4) MF_CASE(32, 4) }
   MF_CASE(64, 4) MF_CASE(64, 8)
+  }
 #undef MF_CASE
   MF_REQUIRE(launched, MF_ERR_UNSUPPORTED, "rollout_fwd: no kernel for this lane mapping");
   hipError_t e = hipGetLastError();
@@ -623,6 +662,8 @@ int launch_rollout_fwd(const RolloutArgs<S>& a, LaneMap m, int integ, int block,
 
 // defined in rollout_fwd_fast.hip
 int launch_rollout_fwd_fast_f32(const RolloutArgs<float>& a, LaneMap m, int integ, int block, bool forces, hipStream_t st);
+// defined in rollout_fwd_split_fast.hip (state stores split over the lanes of a group; one-point-per-lane mappings up to a wave)
+int launch_rollout_fwd_split_fast_f32(const RolloutArgs<float>& a, LaneMap m, int integ, int block, bool forces, hipStream_t st);
 // defined in rollout_fwd_cost.hip
 int launch_rollout_fwd_cost_f32(const RolloutArgs<float>& a, LaneMap m, int integ, int block, bool project, hipStream_t st);
 // defined in rollout_fwd_joints_fast.hip

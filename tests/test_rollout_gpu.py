@@ -309,3 +309,33 @@ def test_states_only_kernels_match_full_output(integ):
     assert fo == (None, None) and torch.isfinite(st[0]).all()
     st, fo = make_dphysics(pts, masks, integ, 0.1, 3.2, return_forces=False, precise=True)(z.unsqueeze(0), ctrl)
     assert fo[0] is not None
+
+
+@pytest.mark.parametrize('integ', [0, 1])
+@pytest.mark.parametrize('N', [4, 40])
+def test_split_store_kernels_write_the_same_rows(integ, N):
+    """Launches with a wave for every SIMD use the kernels whose state stores are split over the lanes of a group: same
+    bits as the plain kernels (only the store instructions differ), with and without force outputs, with and without the
+    unshifted-position buffer the backward needs."""
+    from monoforce_amd import synthetic as syn
+    pts, masks = syn.robot_points_box(N, seed=N, n_tracks=2) if N > 4 else syn.robot_points_4()
+    G = 4 if N == 4 else 64
+    B_big = 1024 * 64 // G + 17                      # >= 1024 waves -> split-store kernels
+    T = 24
+    z = (syn.bump_terrain(syn.bump_params(5), 3.2, 0.1) * 0.3).to(DEV)
+    ctrl = syn.varying_controls(B_big, T, seed=1).to(DEV)
+    for forces in (True, False):
+        for grad in (False, True):
+            dp = make_dphysics(pts, masks, integ, 0.1, 3.2, return_forces=forces)
+            zb = z.clone().requires_grad_(grad)
+            big = dp(zb.unsqueeze(0), ctrl)
+            zs = z.clone().requires_grad_(grad)
+            small = dp(zs.unsqueeze(0), ctrl[:50].contiguous())
+            for u, v in zip(big[0] + big[1], small[0] + small[1]):
+                assert (u is None) == (v is None)
+                if u is not None:
+                    assert torch.equal(u[:50], v)
+            if grad:            # the backward reads the rows (incl. the unshifted positions) the split kernels wrote
+                big[0][0][:50].square().sum().backward()
+                small[0][0].square().sum().backward()
+                assert hp.rel_err(zb.grad.cpu(), zs.grad.cpu()) <= 1e-5
