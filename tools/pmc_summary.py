@@ -7,9 +7,10 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(collections.Counter)
 for r in rows:
-    k = r['Kernel_Name'].split('(')[0][-60:]
-    if len(sys.argv) > 2 and sys.argv[2] not in k:
+    full = r['Kernel_Name'].split('(')[0]
+    if len(sys.argv) > 2 and sys.argv[2] not in full:
         continue
+    k = full.replace('void ', '').replace('mf::', '')[:90]
     agg[k][r['Counter_Name']] += float(r['Counter_Value'])
     cnt[k][r['Counter_Name']] += 1
 for k, v in agg.items():
