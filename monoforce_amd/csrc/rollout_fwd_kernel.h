@@ -413,7 +413,12 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
     // ... and its step size h = ts[n+2] - ts[n+1] (torchdiffeq's fixed grid): loaded HERE, before the stores below -- a load
     // issued after them would make its wait (vmcnt is in-order) a wait for this step's stores as well
     S ts_a = zero, ts_b = zero;
-    if (INTEG == MF_INTEG_ODEINT_EULER) { ts_a = a.ts[nn]; ts_b = a.ts[min(n + 2, a.T - 1)]; }
+    if (INTEG == MF_INTEG_ODEINT_EULER) {
+      // one 8-byte load of the adjacent pair (ts[n+1], ts[n+2]); in the last iteration, whose h is never used, the pair is
+      // clamped into the grid
+      const int tp = max(min(n + 1, a.T - 2), 0);
+      ts_a = a.ts[tp]; ts_b = a.ts[tp + 1];        // T >= 2 inside the loop, so tp + 1 <= T - 1
+    }
 
     // ---- stores of the previous step's row: younger than the gathers above ----
     // DYNAMICS has nothing pending at n = 0: it writes the initial state into row 0 without advancing, and the real row 0
