@@ -34,6 +34,22 @@ __device__ __forceinline__ S blend(const Cell<S>& c, S vc, S vf, S vl, S vfl) {
   return w.w00 * vc + w.w01 * vf + w.w10 * vl + w.w11 * vfl;
 }
 
+// Two maps blended with the same weights in one pass of packed float32 arithmetic (v_pk_mul_f32 / v_pk_fma_f32: two
+// independent IEEE operations per instruction, so each half is bit-identical to blend() of that map).
+template <typename S>
+__device__ __forceinline__ void blend2(const Cell<S>& c, const S (&a)[4], const S (&b)[4], S* ra, S* rb) {
+  *ra = blend(c, a[0], a[1], a[2], a[3]);
+  *rb = blend(c, b[0], b[1], b[2], b[3]);
+}
+template <>
+__device__ __forceinline__ void blend2<float>(const Cell<float>& c, const float (&a)[4], const float (&b)[4], float* ra, float* rb) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const BlendW<float> w = blend_weights(c);
+  const f2 v0 = {a[0], b[0]}, v1 = {a[1], b[1]}, v2 = {a[2], b[2]}, v3 = {a[3], b[3]};
+  const f2 r = w.w00 * v0 + w.w01 * v1 + w.w10 * v2 + w.w11 * v3;      // same operation order as blend()
+  *ra = r.x; *rb = r.y;
+}
+
 // blend() of a map of ones (no friction map = cfg.friction = ones, dphysics.py:141,562): the sum of the weights in blend()'s
 // order, bit-identical to blend(c, 1, 1, 1, 1) with or without contraction.
 template <typename S>

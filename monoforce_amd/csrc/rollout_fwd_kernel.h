@@ -461,9 +461,10 @@ __global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
       const Cell<S>& c = cell[j];
-      S zq = blend(c, zc[j][0], zc[j][1], zc[j][2], zc[j][3]);  // height, normal, friction under the point (:211-216)
+      S zq, mub;                                                 // height, normal, friction under the point (:211-216)
+      blend2(c, zc[j], mc[j], &zq, &mub);
       // no friction map = a map of ones (dphysics.py:562): its blend is the (rounded) sum of the four weights, no loads involved
-      muq[j] = has_mu ? blend(c, mc[j][0], mc[j][1], mc[j][2], mc[j][3]) : blend_ones(c);
+      muq[j] = has_mu ? mub : blend_ones(c);
       S gx = M::div(zc[j][1] - zc[j][0], a.res), gy = M::div(zc[j][2] - zc[j][0], a.res);
       if (M::kReciprocalNorm) {
         const S inl = M::inv_len(gx * gx + gy * gy + one);
