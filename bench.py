@@ -223,6 +223,8 @@ class Runner:
                 sweep[str(Bs)] = {'kernel_ms': ms_, 'rollout_steps_per_s': Bs * T / (ms_ * 1e-3), 'GB/s': gbs, 'frac': gbs / HBM_PEAK_GBS}
                 del dps, cs
             res['batch_sweep'] = sweep
+            torch.cuda.empty_cache()      # return the sweep's multi-GB blocks now, not inside a later workload's timed region
+            torch.cuda.synchronize(dev)
         return res, (N, T)
 
 
