@@ -70,13 +70,13 @@ typedef struct MfRolloutDesc {
   int32_t layout;     /* MF_LAYOUT_* of all outputs */
   int32_t map_shared; /* 1: z/mu are one [H,W] map shared by all rollouts; 0: [B,H,W] */
   int32_t block;      /* threads per workgroup: 0 = default (64); otherwise 64, 128 or 256.  Ignored where one rollout
-                         spans a whole workgroup (bodies of 65..256 points at small batch sizes: 128 or 256 threads) */
+                         spans a whole workgroup (bodies of 65..512 points at small batch sizes: 128, 256 or 512 threads) */
   int32_t skip_snap;  /* 1: do NOT move x0.z onto the terrain first (dphysics.py:567-571) -- for continuing a rollout
                          from a mid-trajectory state (chunked horizons, teacher-forced single steps) */
   int32_t points_per_lane; /* lane mapping: 0 = choose from B and N; 1 = one contact point per lane (fewest instructions per
                          wave, best when the launch is latency-bound); 4 = four points per lane (least redundant work,
                          best when the chip is full).  Results differ only in float summation order.  With 0 or 1, bodies of
-                         65..256 points are spread over 2 or 4 waves per rollout while the launch has <= 2048 waves. */
+                         65..512 points are spread over 2, 4 or 8 waves per rollout while the launch has <= 2048 waves. */
   int32_t math_mode;    /* MF_MATH_* */
   int32_t force_stride; /* point slots per row of the Fs / Ff buffers, >= mf_rollout_force_stride(desc); 0 means N
                            (only valid when N is a multiple of the lane tile, e.g. N = 4).  Padding slots get zeros. */

@@ -53,7 +53,7 @@ __device__ __forceinline__ S* at32(S* base, unsigned elem) {
   } while (0)
 
 template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS = false, bool CARRY = true>
-__global__ void __launch_bounds__(256) rollout_bwd_kernel(const RolloutBwdArgs<S> a) {
+__global__ void __launch_bounds__(G > 256 ? G : 256) rollout_bwd_kernel(const RolloutBwdArgs<S> a) {
   using M = Mth<S, FAST>;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = tid / G;
@@ -732,7 +732,7 @@ int launch_rollout_bwd(const RolloutBwdArgs<S>& a, LaneMap m, int integ, int blo
       hipLaunchKernelGGL((rollout_bwd_kernel<S, G_, P_, MF_INTEG_ODEINT_EULER, FAST, JOINTS, CARRY>), dim3(grid), dim3(block), 0, st, a);  \
   }
   MF_CASE(4, 1) MF_CASE(8, 1) MF_CASE(16, 1) MF_CASE(32, 1) MF_CASE(64, 1) MF_CASE(64, 2) MF_CASE(64, 4) MF_CASE(64, 8)
-  MF_CASE(128, 1) MF_CASE(256, 1)
+  MF_CASE(128, 1) MF_CASE(256, 1) MF_CASE(512, 1)
   if constexpr (!JOINTS) {   // the 4-points-per-lane mappings are a tuning / test option of the rigid-body kernels
     MF_CASE(1, 4) MF_CASE(2, 4) MF_CASE(4, 4) MF_CASE(8, 4) MF_CASE(16, 4) MF_CASE(32, 4)
   }

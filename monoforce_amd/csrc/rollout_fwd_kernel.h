@@ -159,7 +159,7 @@ __device__ __forceinline__ void articulate_body(GroupSum<G, S>& gs, const S* ja,
 }
 
 template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS = false, bool FORCES = true, int COST = 0, bool SPLIT = false>
-__global__ void __launch_bounds__(256) rollout_fwd_kernel(const RolloutArgs<S> a) {
+__global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const RolloutArgs<S> a) {
   using M = Mth<S, FAST>;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = tid / G;
@@ -624,11 +624,11 @@ static inline LaneMap choose_lane_map(int B, int N, int points_per_lane) {
   if (N <= 64) return wide ? LaneMap{64, 1} : LaneMap{16, 4};
   // Larger bodies: one wave per rollout with 2 / 4 / 8 points per lane -- unless the batch is so small that this leaves
   // most of the chip idle (the reference's own use: 4 .. 64 rollouts of a 175- or 223-point robot).  Then ONE rollout is
-  // spread over 2 or 4 waves of a workgroup, one point per lane (GroupSum exchanges through LDS): ~2.3x fewer instructions
+  // spread over 2, 4 or 8 waves of a workgroup, one point per lane (GroupSum exchanges through LDS): ~2.3x fewer instructions
   // per wave and step.  Measured at N = 223: forward 0.79 vs 1.85 ms, backward 2.0 vs 5.6 ms for B <= 256; 0.98 / 2.9 vs
   // 1.38 / 4.4 ms at B = 512 (2 waves per SIMD); a tie at B = 1024 -- so up to 2048 waves per launch.
-  if (points_per_lane != 4 && N <= 256) {
-    const int g = N <= 128 ? 128 : 256;
+  if (points_per_lane != 4) {
+    const int g = N <= 128 ? 128 : (N <= 256 ? 256 : 512);
     if ((long long)B * (g / 64) <= 2048) return LaneMap{g, 1};
   }
   if (N <= 128) return points_per_lane != 4 ? LaneMap{64, 2} : LaneMap{32, 4};
@@ -655,7 +655,7 @@ int launch_rollout_fwd(const RolloutArgs<S>& a, LaneMap m, int integ, int block,
   if (!JOINTS) { MF_CASE(4, 1) MF_CASE(8, 1) MF_CASE(16, 1) MF_CASE(32, 1) MF_CASE(64, 1) }
   if constexpr (!SPLIT) {
   if (!JOINTS) { MF_CASE(64, 2) }
-  MF_CASE(128, 1) MF_CASE(256, 1)
+  MF_CASE(128, 1) MF_CASE(256, 1) MF_CASE(512, 1)
   if (FORCES) { MF_CASE(1, 4) MF_CASE(2, 4) MF_CASE(4, 4) MF_CASE(8, 4) MF_CASE(16, 4) MF_CASE(32, 4) }
   MF_CASE(64, 4) MF_CASE(64, 8)
   }

@@ -108,10 +108,10 @@ def test_random_shape_forward_f32_vs_oracle_f64(seed, precise):
         assert hp.rel_err(a.cpu().double(), b) <= tol, (info, k, hp.rel_err(a.cpu().double(), b))
 
 
-@pytest.mark.parametrize('B,N,n_tracks', [(3, 100, 2), (5, 223, 4), (600, 100, 2), (300, 200, 4)])
+@pytest.mark.parametrize('B,N,n_tracks', [(3, 100, 2), (5, 223, 4), (2, 400, 2), (600, 100, 2), (300, 200, 4), (260, 300, 2)])
 def test_large_body_lane_mappings_vs_oracle_f64(B, N, n_tracks):
-    """Bodies of more than 64 points: a small batch spreads ONE rollout over 2 / 4 waves (LDS exchange between them), a
-    large one keeps one wave per rollout with 2 / 4 points per lane -- forward and gradients of both against the oracle."""
+    """Bodies of more than 64 points: a small batch spreads ONE rollout over 2 / 4 / 8 waves (LDS exchange between them), a
+    large one keeps one wave per rollout with 2 / 4 / 8 points per lane -- forward and gradients of both against the oracle."""
     from monoforce_amd import synthetic as syn
     from oracle import dphysics_oracle as orc
     pts, masks = syn.robot_points_box(N, seed=N + B, n_tracks=n_tracks)
