@@ -17,7 +17,8 @@
  *   mf_bev_lift_splat_*  the same with the lift of lss.py:63-71 (depth distribution x context features) fused in
  *   mf_physics_loss_*  losses.py:102-127 physics_loss (position term) and its gradient, on the nearest-time-stamp
  *                      subset of the predicted poses
- * (LiftSplatShoot.get_geometry(), lss.py:204-224, is a 3x3 transform of 120 k points: it stays plain torch.)
+ *   mf_bev_splat_prepare_cameras  the voxel plan straight from the camera models: LiftSplatShoot.get_geometry()
+ *                      (lss.py:204-224) evaluated inside the key pass
  */
 #ifndef MONOFORCE_HIP_H
 #define MONOFORCE_HIP_H
@@ -203,6 +204,12 @@ typedef struct MfSplatDesc {
 
 size_t mf_bev_splat_workspace_bytes(const MfSplatDesc* desc); /* 0 on a bad descriptor */
 int mf_bev_splat_prepare(const MfSplatDesc* desc, const float* geom /* [B*n_per_sample][3] */, void* workspace, void* hip_stream);
+/* The same plan from the camera models instead of a geometry tensor: get_geometry (lss.py:204-224) evaluated per point
+ * inside the key pass, in the reference's order of float32 operations.  frustum[pts_per_cam][3] = (u, v, d) of
+ * create_frustum (lss.py:191-202), pts_per_cam = D*fH*fW, n_per_sample = cameras * pts_per_cam;
+ * cams[B*cameras][24] = post_trans[3], inverse(post_rots)[9], (rots x inverse(intrins))[9], trans[3], matrices row-major. */
+int mf_bev_splat_prepare_cameras(const MfSplatDesc* desc, const float* frustum, int32_t pts_per_cam, const float* cams,
+                                 void* workspace, void* hip_stream);
 /* out[B][nz*C][nx][ny] = per-voxel sums of x[B*n_per_sample][C]; every output element is written (zeros where empty) */
 int mf_bev_splat_fwd_f32(const MfSplatDesc* desc, const float* x, const void* workspace, float* out, void* hip_stream);
 int mf_bev_splat_fwd_f64(const MfSplatDesc* desc, const double* x, const void* workspace, double* out, void* hip_stream);

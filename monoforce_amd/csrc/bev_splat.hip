@@ -59,25 +59,58 @@ static size_t carve(const MfSplatDesc* d, void* base, SplatWs* ws) {
 // ---------------------------------------------------------------------------------------------------------
 // prepare
 // ---------------------------------------------------------------------------------------------------------
+// voxel of one point: idx = ((geom - (bx - dx/2)) / dx).long()   (lss.py:246): float32 subtract, IEEE divide, trunc toward zero;
+// -1 = dropped (lss.py:253-255).  NaN / +-inf / huge values fail the range tests and are dropped, as in the reference.
+__device__ __forceinline__ int voxel_key(float gx, float gy, float gz, int b, int nx, int ny, int nz, float ox, float oy, float oz,
+                                         float dx, float dy, float dz) {
+  const float vx = (gx - ox) / dx;
+  const float vy = (gy - oy) / dy;
+  const float vz = (gz - oz) / dz;
+  const float lim = 1073741824.0f;
+  if (!(vx > -lim && vx < lim && vy > -lim && vy < lim && vz > -lim && vz < lim)) return -1;
+  const int ix = (int)vx, iy = (int)vy, iz = (int)vz;
+  if (!(ix >= 0 && ix < nx && iy >= 0 && iy < ny && iz >= 0 && iz < nz)) return -1;
+  return ((b * nz + iz) * nx + ix) * ny + iy;
+}
+
 __global__ void __launch_bounds__(256) splat_keys_kernel(const float* __restrict__ geom, int P, int n_per_sample, int nx, int ny,
                                                         int nz, float ox, float oy, float oz, float dx, float dy, float dz,
                                                         int* __restrict__ keys, int* __restrict__ count) {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
-  // idx = ((geom - (bx - dx/2)) / dx).long()   (lss.py:246): float32 subtract, IEEE divide, trunc toward zero
-  const float vx = (geom[(size_t)p * 3 + 0] - ox) / dx;
-  const float vy = (geom[(size_t)p * 3 + 1] - oy) / dy;
-  const float vz = (geom[(size_t)p * 3 + 2] - oz) / dz;
-  const float lim = 1073741824.0f;  // NaN / +-inf / huge values fail these tests and are dropped, as in the reference
-  int key = -1;
-  if (vx > -lim && vx < lim && vy > -lim && vy < lim && vz > -lim && vz < lim) {
-    const int ix = (int)vx, iy = (int)vy, iz = (int)vz;
-    if (ix >= 0 && ix < nx && iy >= 0 && iy < ny && iz >= 0 && iz < nz) {   // (lss.py:253-255)
-      const int b = p / n_per_sample;
-      key = ((b * nz + iz) * nx + ix) * ny + iy;
-      atomicAdd(count + key, 1);
-    }
-  }
+  const int key = voxel_key(geom[(size_t)p * 3 + 0], geom[(size_t)p * 3 + 1], geom[(size_t)p * 3 + 2], p / n_per_sample, nx, ny, nz,
+                            ox, oy, oz, dx, dy, dz);
+  if (key >= 0) atomicAdd(count + key, 1);
+  keys[p] = key;
+}
+
+// get_geometry (lss.py:204-224) fused into the key pass: the ego-frame position of frustum point (u, v, d) of camera k is
+//   q = (u, v, d) - post_trans;  a = inv(post_rots) q;  b = (a.x a.z, a.y a.z, a.z);  g = (rots inv(intrins)) b + trans
+// evaluated in the reference's order with every product and sum rounded on its own (no FMA): the voxel index is a
+// truncation, so a last-bit difference in g could move a point on a voxel face to the neighbour.  `cams` holds per camera
+// post_trans[3], inv(post_rots)[9], (rots inv(intrins))[9], trans[3] (row-major, 24 floats; the two 3x3 products of
+// 3x3 matrices stay on the host side of the boundary).  The [B,N,D,fH,fW,3] geometry tensor is never materialised.
+__device__ __forceinline__ void mat_apply(const float* __restrict__ m, float p0, float p1, float p2, float* o) {
+#pragma clang fp contract(off)
+#pragma unroll
+  for (int i = 0; i < 3; ++i) o[i] = (m[i * 3 + 0] * p0 + m[i * 3 + 1] * p1) + m[i * 3 + 2] * p2;
+}
+
+__global__ void __launch_bounds__(256) splat_keys_frustum_kernel(const float* __restrict__ frustum, const float* __restrict__ cams,
+                                                                int P, int n_per_sample, int pts_per_cam, int nx, int ny, int nz,
+                                                                float ox, float oy, float oz, float dx, float dy, float dz,
+                                                                int* __restrict__ keys, int* __restrict__ count) {
+#pragma clang fp contract(off)
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int f = p % pts_per_cam;
+  const float* cam = cams + (size_t)(p / pts_per_cam) * 24;
+  const float q0 = frustum[(size_t)f * 3 + 0] - cam[0], q1 = frustum[(size_t)f * 3 + 1] - cam[1], q2 = frustum[(size_t)f * 3 + 2] - cam[2];
+  float a[3], g[3];
+  mat_apply(cam + 3, q0, q1, q2, a);
+  mat_apply(cam + 12, a[0] * a[2], a[1] * a[2], a[2], g);
+  const int key = voxel_key(g[0] + cam[21], g[1] + cam[22], g[2] + cam[23], p / n_per_sample, nx, ny, nz, ox, oy, oz, dx, dy, dz);
+  if (key >= 0) atomicAdd(count + key, 1);
   keys[p] = key;
 }
 
@@ -418,15 +451,21 @@ static int check_desc(const MfSplatDesc* d) {
     MF_REQUIRE(e_ == hipSuccess, MF_ERR_LAUNCH, std::string(what) + ": " + hipGetErrorString(e_));     \
   } while (0)
 
-static int splat_prepare(const MfSplatDesc* d, const float* geom, void* workspace, hipStream_t st) {
+static int splat_prepare(const MfSplatDesc* d, const float* geom, const float* frustum, const float* cams, int pts_per_cam,
+                         void* workspace, hipStream_t st) {
   SplatWs ws;
   carve(d, workspace, &ws);
   const int P = d->B * d->n_per_sample;
   const int V = d->B * d->nz * d->nx * d->ny;
   hipError_t e = hipMemsetAsync(ws.count, 0, (char*)ws.offsets - (char*)ws.count, st);   // count + cursor
   MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("bev_splat memset: ") + hipGetErrorString(e));
-  hipLaunchKernelGGL(splat_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, st, geom, P, d->n_per_sample, d->nx, d->ny, d->nz,
-                     d->off[0], d->off[1], d->off[2], d->dx[0], d->dx[1], d->dx[2], ws.keys, ws.count);
+  if (geom)
+    hipLaunchKernelGGL(splat_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, st, geom, P, d->n_per_sample, d->nx, d->ny, d->nz,
+                       d->off[0], d->off[1], d->off[2], d->dx[0], d->dx[1], d->dx[2], ws.keys, ws.count);
+  else
+    hipLaunchKernelGGL(splat_keys_frustum_kernel, dim3((P + 255) / 256), dim3(256), 0, st, frustum, cams, P, d->n_per_sample,
+                       pts_per_cam, d->nx, d->ny, d->nz, d->off[0], d->off[1], d->off[2], d->dx[0], d->dx[1], d->dx[2], ws.keys,
+                       ws.count);
   MF_LAUNCH_OK("splat_keys");
   const int nblk = (V + 2047) / 2048;
   hipLaunchKernelGGL(scan_block_kernel, dim3(nblk), dim3(256), 0, st, ws.count, V, ws.offsets, ws.block_sums);
@@ -529,7 +568,16 @@ extern "C" int mf_bev_splat_prepare(const MfSplatDesc* d, const float* geom, voi
   int rc = mf::check_desc(d);
   if (rc != MF_OK) return rc;
   MF_REQUIRE(geom && ws, MF_ERR_INVALID, "bev_splat_prepare: null buffer");
-  return mf::splat_prepare(d, geom, ws, (hipStream_t)s);
+  return mf::splat_prepare(d, geom, nullptr, nullptr, 0, ws, (hipStream_t)s);
+}
+extern "C" int mf_bev_splat_prepare_cameras(const MfSplatDesc* d, const float* frustum, int32_t pts_per_cam, const float* cams,
+                                            void* ws, void* s) {
+  int rc = mf::check_desc(d);
+  if (rc != MF_OK) return rc;
+  MF_REQUIRE(frustum && cams && ws, MF_ERR_INVALID, "bev_splat_prepare_cameras: null buffer");
+  MF_REQUIRE(pts_per_cam > 0 && d->n_per_sample % pts_per_cam == 0, MF_ERR_INVALID,
+             "bev_splat_prepare_cameras: n_per_sample must be cameras * pts_per_cam");
+  return mf::splat_prepare(d, nullptr, frustum, cams, pts_per_cam, ws, (hipStream_t)s);
 }
 #define MF_SPLAT_ENTRY(name, S, impl)                                                           \
   extern "C" int name(const MfSplatDesc* d, const S* in, const void* ws, S* out, void* s) {     \

@@ -37,8 +37,7 @@ class GraphedTerrainPlanner:
         k = max(int(round(cfg.grid_res / float(encoder.dx[0]))), 1)       # scripts/train.py:93-99: encoder grid -> physics grid
         self.pool = torch.nn.AvgPool2d(kernel_size=k, stride=k) if k > 1 else torch.nn.Identity()
         with torch.no_grad():
-            geom = encoder.get_geometry(*[t.to(dev) for t in calib])
-            self.plan = SplatPlan(geom, encoder.dx, encoder.bx, encoder.nx)
+            self.plan = encoder.splat_plan(*[t.to(dev) for t in calib])
         self.imgs = torch.zeros((1,) + tuple(img_shape), device=dev)
         self.graph = None
         self.out = None

@@ -15,29 +15,63 @@ def _stream_ptr(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def grid_host(dx, bx, nx):
+    """(off, dx, n) of the BEV grid as host values (a device -> host read: a stream sync, not capturable in a hipGraph --
+    callers that build plans per frame read it once and pass it as `grid=`)."""
+    dxc, bxc = dx.detach().float().cpu(), bx.detach().float().cpu()
+    off = bxc - dxc / 2.                                        # float32, like lss.py:246
+    return off.tolist(), dxc.tolist(), [int(v) for v in nx.detach().cpu().tolist()]
+
+
 class SplatPlan:
-    def __init__(self, geom, dx, bx, nx):
+    def __init__(self, geom, dx, bx, nx, _cameras=None, grid=None):
         """geom [B, ..., 3] float32 on the GPU; dx, bx (float32 tensors), nx (int64 tensor) as produced by gen_dx_bx."""
-        _lib.require_hip_tensor(geom, 'geom')
-        B = geom.shape[0]
-        g = geom.detach().to(torch.float32).contiguous().view(-1, 3)
-        dxc, bxc = dx.detach().float().cpu(), bx.detach().float().cpu()
-        off = bxc - dxc / 2.                                        # float32, like lss.py:246
-        n = [int(v) for v in nx.detach().cpu().tolist()]
-        self.B, self.n_per_sample = B, g.shape[0] // B
+        if _cameras is None:
+            _lib.require_hip_tensor(geom, 'geom')
+            B = geom.shape[0]
+            g = geom.detach().to(torch.float32).contiguous().view(-1, 3)
+            device, n_per_sample = geom.device, g.shape[0] // B
+        else:
+            frustum, cams, B = _cameras
+            _lib.require_hip_tensor(cams, 'camera models')
+            device, n_per_sample = cams.device, (cams.shape[0] // B) * frustum.shape[0]
+        off, dxl, n = grid if grid is not None else grid_host(dx, bx, nx)
+        self.B, self.n_per_sample = B, n_per_sample
         self.nx, self.ny, self.nz = n
-        self.device = geom.device
+        self.device = device
         self._desc_args = dict(B=B, n_per_sample=self.n_per_sample, nx=n[0], ny=n[1], nz=n[2],
-                               off=(C.c_float * 3)(*off.tolist()), dx=(C.c_float * 3)(*dxc.tolist()))
+                               off=(C.c_float * 3)(*off), dx=(C.c_float * 3)(*dxl))
         d = self.desc(1)
         nbytes = _lib.lib().mf_bev_splat_workspace_bytes(C.byref(d))
         if nbytes == 0:
             raise RuntimeError('mf_bev_splat_workspace_bytes: ' + _lib.lib().mf_last_error().decode())
-        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=geom.device)
-        with torch.cuda.device(geom.device), _timing.timed('splat_prepare', geom.device):
-            _lib.check(_lib.lib().mf_bev_splat_prepare(C.byref(d), _lib.ptr(g), _lib.ptr(self.workspace), _stream_ptr(geom.device)),
-                       'mf_bev_splat_prepare')
-        self._geom_keepalive = g
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        with torch.cuda.device(device), _timing.timed('splat_prepare', device):
+            if _cameras is None:
+                _lib.check(_lib.lib().mf_bev_splat_prepare(C.byref(d), _lib.ptr(g), _lib.ptr(self.workspace), _stream_ptr(device)),
+                           'mf_bev_splat_prepare')
+                self._keepalive = g
+            else:
+                _lib.check(_lib.lib().mf_bev_splat_prepare_cameras(C.byref(d), _lib.ptr(frustum), C.c_int32(frustum.shape[0]),
+                                                                   _lib.ptr(cams), _lib.ptr(self.workspace), _stream_ptr(device)),
+                           'mf_bev_splat_prepare_cameras')
+                self._keepalive = (frustum, cams)
+
+    @classmethod
+    def from_cameras(cls, frustum, rots, trans, intrins, post_rots, post_trans, dx, bx, nx, grid=None):
+        """The plan of `SplatPlan(get_geometry(rots, trans, intrins, post_rots, post_trans), ...)` without the geometry
+        tensor: frustum [D,fH,fW,3] (create_frustum), camera models [B,N,3(,3)] as LiftSplatShoot.forward takes them.  The two
+        3x3-by-3x3 products of get_geometry (lss.py:212, 218) stay here; the per-point part runs inside the key kernel."""
+        B, N = trans.shape[:2]
+        f32 = lambda t: t.detach().to(torch.float32)
+        cams = torch.cat((f32(post_trans).reshape(B * N, 3), torch.inverse(f32(post_rots)).reshape(B * N, 9),
+                          f32(rots).matmul(torch.inverse(f32(intrins))).reshape(B * N, 9), f32(trans).reshape(B * N, 3)), 1).contiguous()
+        fr = f32(frustum).contiguous().view(-1, 3)
+        return cls(None, dx, bx, nx, _cameras=(fr, cams, B), grid=grid)
+
+    def keys(self):
+        """Linear voxel id of every point ([B * n_per_sample] int32, -1 = dropped): the first array of the workspace."""
+        return self.workspace[:4 * self.B * self.n_per_sample].view(torch.int32)
 
     def desc(self, C_):
         return _lib.MfSplatDesc(C=C_, **self._desc_args)

@@ -131,6 +131,8 @@ class LiftSplatShoot(nn.Module):
             self.bevencode = BevEncode(inC=self.camC, outC=outC)
         self.use_quickcumsum = True      # accepted for compatibility; both reference paths compute the same sums
         self.fuse_lift = True            # lift (depth x context) inside the splat kernels; False: get_cam_feats + voxel_pooling
+        self.fuse_geometry = True        # with fuse_lift: get_geometry inside the splat's key pass (no [B,N,D,fH,fW,3] tensor)
+        self._grid_host = None
 
     def create_frustum(self):
         """(u, v, d) of every lifted point: pixel centres on the /16 feature grid x depth bins (lss.py:191-202)."""
@@ -170,14 +172,26 @@ class LiftSplatShoot(nn.Module):
     def voxel_pooling(self, geom_feats, x, plan=None):
         return splat.voxel_pooling(geom_feats, x, self.dx, self.bx, self.nx, plan=plan)
 
-    def get_voxels(self, x, rots, trans, intrins, post_rots, post_trans):
-        geom = self.get_geometry(rots, trans, intrins, post_rots, post_trans)
+    def splat_plan(self, rots, trans, intrins, post_rots, post_trans):
+        """Voxel plan of a camera rig without the geometry tensor (the reference's get_geometry + the index part of
+        voxel_pooling, lss.py:204-224, 246-262); reusable across frames while calibration and augmentation are unchanged."""
+        versions = (self.dx._version, self.bx._version, self.nx._version, self.dx.device)
+        if self._grid_host is None or self._grid_host[0] != versions:
+            self._grid_host = (versions, splat.grid_host(self.dx, self.bx, self.nx))
+        return splat.SplatPlan.from_cameras(self.frustum, rots, trans, intrins, post_rots, post_trans, self.dx, self.bx, self.nx,
+                                            grid=self._grid_host[1])
+
+    def get_voxels(self, x, rots, trans, intrins, post_rots, post_trans, plan=None):
         if self.fuse_lift and x.is_cuda:
             # lift fused into the splat: the [B,N,D,fH,fW,C] tensor of get_cam_feats() is never materialised
             B, N, C, imH, imW = x.shape
             depth, context = self.camencode.get_depth_and_context(x.view(B * N, C, imH, imW))
-            return splat.lift_voxel_pooling(geom, depth, context, self.dx, self.bx, self.nx)
-        return self.voxel_pooling(geom, self.get_cam_feats(x))
+            if plan is None and self.fuse_geometry:
+                plan = self.splat_plan(rots, trans, intrins, post_rots, post_trans)
+            geom = None if plan is not None else self.get_geometry(rots, trans, intrins, post_rots, post_trans)
+            return splat.lift_voxel_pooling(geom, depth, context, self.dx, self.bx, self.nx, plan=plan)
+        geom = self.get_geometry(rots, trans, intrins, post_rots, post_trans)
+        return self.voxel_pooling(geom, self.get_cam_feats(x), plan=plan)
 
     def forward(self, x, rots, trans, intrins, post_rots, post_trans):
         return self.bevencode(self.get_voxels(x, rots, trans, intrins, post_rots, post_trans))

@@ -145,3 +145,60 @@ def test_fused_lift_splat_equals_lift_then_splat(dtype, shape):
     assert torch.equal(out, ref)                       # same products (rounded before the add), same summation order
     assert hp.rel_err(d2.grad.cpu(), d1.grad.cpu()) <= tol, hp.rel_err(d2.grad.cpu(), d1.grad.cpu())
     assert hp.rel_err(c2.grad.cpu(), c1.grad.cpu()) <= tol, hp.rel_err(c2.grad.cpu(), c1.grad.cpu())
+
+
+def _voxel_keys(idx, kept, B, n_per_sample, nx, ny, nz):
+    b = np.arange(idx.shape[0]) // n_per_sample
+    key = ((b * nz + idx[:, 2]) * nx + idx[:, 0]) * ny + idx[:, 1]
+    return np.where(kept, key, -1)
+
+
+def test_camera_plan_reproduces_reference_indices():
+    """get_geometry fused into the key pass, pinned on the reference itself: the golden rig (with image augmentation) through
+    `SplatPlan.from_cameras` must give the voxel of every frustum point that the reference's get_geometry + voxel_pooling
+    index arithmetic gave (tests/golden/lss.npz: voxel_idx, kept).  The generator overwrote the geometry of points 0..3 with
+    hand-placed edge cases (gen_golden.py, fixture 5), so those four are not functions of the rig and are skipped."""
+    from monoforce_amd import splat
+    g = hp.load('lss')
+    t = lambda k: torch.from_numpy(g[k]).to(DEV)
+    plan = splat.SplatPlan.from_cameras(t('frustum'), t('rots'), t('trans'), t('intrins'), t('post_rots'), t('post_trans'),
+                                        torch.from_numpy(g['dx']), torch.from_numpy(g['bx']), torch.from_numpy(g['nx']))
+    B = g['rots'].shape[0]
+    nx, ny, nz = (int(v) for v in g['nx'])
+    want = _voxel_keys(g['voxel_idx'], g['kept'], B, plan.n_per_sample, nx, ny, nz)
+    assert 0.2 < g['kept'].mean() < 1.0
+    np.testing.assert_array_equal(plan.keys().cpu().numpy()[4:], want[4:])
+
+
+@pytest.mark.parametrize('shape', [dict(B=1, N=4, H=256, W=512, bound=6.4, res=0.05), dict(B=3, N=5, H=96, W=160, bound=3.2, res=0.1),
+                                   dict(B=2, N=1, H=64, W=96, bound=1.6, res=0.2)])
+def test_camera_plan_equals_geometry_plan(shape):
+    """Random augmented rigs: keys from the camera models == keys from the materialised get_geometry tensor, bit for bit, and
+    so is everything built from them (CSR lists -> pooled output)."""
+    from monoforce_amd import splat, synthetic as syn
+    from monoforce_amd.terrain_encoder import LiftSplatShoot
+    B, N, H, W, bound, res = (shape[k] for k in ('B', 'N', 'H', 'W', 'bound', 'res'))
+    gc = dict(xbound=[-bound, bound, res], ybound=[-bound, bound, res], zbound=[-1.0, 1.0, 1.0], dbound=[0.6, bound, 0.1])
+    m = LiftSplatShoot(gc, dict(final_dim=(H, W)), build_backbones=False).to(DEV)
+    gen = torch.Generator().manual_seed(11)
+    rots, trans, intrins, post_rots, post_trans = syn.lss_camera_rig(B, N, H, W, 0.6 * W)
+    # image-space augmentation as the reference's datasets produce it (resize + crop + flip + small rotation, utils.py:52-76)
+    for b in range(B):
+        for n in range(N):
+            s = 0.8 + 0.4 * float(torch.rand(1, generator=gen))
+            a = 0.2 * (float(torch.rand(1, generator=gen)) - 0.5)
+            flip = -1.0 if float(torch.rand(1, generator=gen)) < 0.5 else 1.0
+            A = torch.tensor([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]], dtype=torch.float32) * s
+            A[:, 0] *= flip
+            post_rots[b, n, :2, :2] = A
+            post_trans[b, n, :2] = (torch.rand(2, generator=gen) - 0.5) * 40
+            trans[b, n] += (torch.rand(3, generator=gen) - 0.5) * 0.2
+    rig = [t.to(DEV) for t in (rots, trans, intrins, post_rots, post_trans)]
+    geom = m.get_geometry(*rig)
+    p_geom = splat.SplatPlan(geom, m.dx, m.bx, m.nx)
+    p_cam = m.splat_plan(*rig)
+    k1, k2 = p_geom.keys(), p_cam.keys()
+    assert 0.05 < float((k1 >= 0).float().mean()) < 0.98
+    assert torch.equal(k1, k2)
+    x = torch.randn(B * p_cam.n_per_sample, 8, generator=gen).to(DEV).view(B, -1, 8)
+    assert torch.equal(splat.voxel_pooling(None, x, m.dx, m.bx, m.nx, plan=p_cam), splat.voxel_pooling(geom, x, m.dx, m.bx, m.nx, plan=p_geom))

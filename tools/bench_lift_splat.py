@@ -34,3 +34,18 @@ for B in (1, 8):
             torch.cuda.synchronize()
             tf += e[0].elapsed_time(e[1]); tb += e[1].elapsed_time(e[2])
         print(f'B={B} {name:18s} forward {tf / 10 * 1e3:7.1f} us   backward {tb / 10 * 1e3:7.1f} us', flush=True)
+    # the geometry side: get_geometry + key/CSR passes from the geometry tensor vs the plan straight from the camera models
+    def plan_geom():
+        return splat.SplatPlan(enc.get_geometry(*calib), enc.dx, enc.bx, enc.nx)
+    def plan_cams():
+        return enc.splat_plan(*calib)
+    for name, fn in (('get_geometry + plan', plan_geom), ('plan from cameras', plan_cams)):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter(); e0.record()
+        for _ in range(20):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        print(f'B={B} {name:20s} {e0.elapsed_time(e1) / 20 * 1e3:7.1f} us on the device, {(time.perf_counter() - t0) / 20 * 1e6:7.1f} us wall', flush=True)

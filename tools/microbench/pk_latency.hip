@@ -36,6 +36,16 @@ __global__ void k_pk_ind(float* out, long long* cyc, float a, float b) {
   long long t1 = clock64();
   out[threadIdx.x] = x0.x + x1.y + x2.x + x3.y; if (threadIdx.x == 0) cyc[0] = t1 - t0;
 }
+__global__ void k_scalar_ind_masked(float* out, long long* cyc, float a, float b, int lanes) {
+  // same chain with only `lanes` of the 64 lanes active: does the SIMD skip 16-lane passes whose EXEC bits are all zero?
+  if ((int)threadIdx.x >= lanes) return;
+  float x0 = threadIdx.x, x1 = 1, x2 = 2, x3 = 3;
+  long long t0 = clock64();
+#pragma unroll 16
+  for (int i = 0; i < REP / 4; ++i) { x0 = __builtin_fmaf(x0, a, b); x1 = __builtin_fmaf(x1, a, b); x2 = __builtin_fmaf(x2, a, b); x3 = __builtin_fmaf(x3, a, b); }
+  long long t1 = clock64();
+  out[threadIdx.x] = x0 + x1 + x2 + x3; if (threadIdx.x == 0) cyc[0] = t1 - t0;
+}
 int main() {
   float* out; long long* cyc; hipMalloc(&out, 256); hipMalloc(&cyc, 8);
   struct { const char* n; void (*k)(float*, long long*, float, float); } ks[] = {{"v_fma_f32 dependent", k_scalar_dep}, {"v_pk_fma_f32 dependent", k_pk_dep},
@@ -44,6 +54,11 @@ int main() {
     long long c = 0;
     for (int r = 0; r < 3; ++r) { hipLaunchKernelGGL(k.k, dim3(1), dim3(64), 0, 0, out, cyc, 0.999f, 0.001f); hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost); }
     printf("%-28s %lld clock64 ticks for %d instructions = %.2f ticks each\n", k.n, c, REP, (double)c / REP);
+  }
+  for (int lanes : {64, 32, 16, 1}) {
+    long long c = 0;
+    for (int r = 0; r < 3; ++r) { hipLaunchKernelGGL(k_scalar_ind_masked, dim3(1), dim3(64), 0, 0, out, cyc, 0.999f, 0.001f, lanes); hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost); }
+    printf("v_fma_f32 4 independent, %2d active lanes: %.2f ticks each\n", lanes, (double)c / REP);
   }
   return 0;
 }
