@@ -26,7 +26,8 @@ class MfRolloutDesc(C.Structure):
 
 class MfRolloutFwdBufs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('z', 'mu', 'controls', 'ts', 'points', 'part', 'x0', 'xd0', 'R0', 'w0',
-                                          'Xs', 'Xds', 'Rs', 'Omegas', 'Fs', 'Ff', 'Xraw', 'joint_angles', 'cost_rows', 'path_cost')]
+                                          'Xs', 'Xds', 'Rs', 'Omegas', 'Fs', 'Ff', 'Xraw', 'joint_angles', 'cost_rows', 'path_cost',
+                                          'zmu_scratch')]
 
 
 class MfRolloutBwdBufs(C.Structure):

@@ -21,6 +21,7 @@ static int fill_args(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutA
   MF_REQUIRE((p->Fs != nullptr) == (p->Ff != nullptr), MF_ERR_INVALID, "rollout_fwd: pass both force buffers or neither");
   MF_REQUIRE((long long)d->H * d->W < (1ll << 30), MF_ERR_UNSUPPORTED, "rollout_fwd: grid too large");
   MF_REQUIRE(d->H < (1 << 23), MF_ERR_UNSUPPORTED, "rollout_fwd: grid too large (H must be below 2^23)");
+  MF_REQUIRE(d->H >= 2, MF_ERR_INVALID, "rollout_fwd: the grid needs at least 2 x 2 cells");
   MF_REQUIRE(d->N <= 512, MF_ERR_UNSUPPORTED, "rollout_fwd: more than 512 contact points");
   MF_REQUIRE(d->map_shared || (long long)d->B * d->H * d->W * (long long)sizeof(S) < (1ll << 32), MF_ERR_UNSUPPORTED,
              "rollout_fwd: per-rollout maps of 4 GiB or more in total (use a shared map or split the batch)");
@@ -48,6 +49,7 @@ static int fill_args(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutA
   a->joint_angles = (const S*)p->joint_angles;
   a->cost_rows = (S*)p->cost_rows; a->pose_stride = d->pose_stride > 0 ? d->pose_stride : 1;
   a->path_cost = (S*)p->path_cost;
+  a->zmu = nullptr;
   for (int i = 0; i < 12; ++i) a->joint_xyz[i] = (S)d->joint_xyz[i];
   if (p->joint_angles) {
     MF_REQUIRE(d->n_tracks == 4, MF_ERR_UNSUPPORTED, "rollout_fwd: joint angles need 4 driving parts (fl, fr, rl, rr)");
@@ -68,12 +70,30 @@ extern "C" int mf_rollout_force_stride(const MfRolloutDesc* d) {
   return lanes > d->N ? lanes : d->N;
 }
 
+namespace mf {
+// (z, mu) of the shared maps interleaved for the ZMU kernels; without a friction map the second component is never used
+__global__ void __launch_bounds__(256) interleave_maps_kernel(const float* __restrict__ z, const float* __restrict__ mu, int n,
+                                                             float2* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = make_float2(z[i], mu ? mu[i] : 1.0f);
+}
+// true (and a.zmu set, the interleave pass launched) when this launch can read the interleaved copy
+static bool use_interleaved_maps(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutArgs<float>* a, const LaneMap& m, hipStream_t st) {
+  if (!p->zmu_scratch || !d->map_shared || d->math_mode != MF_MATH_FAST || p->joint_angles || m.PPL != 1 || m.G > 64) return false;
+  const int n = d->H * d->W;
+  hipLaunchKernelGGL(interleave_maps_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a->z, a->mu, n, (float2*)p->zmu_scratch);
+  a->zmu = (const float*)p->zmu_scratch;
+  return true;
+}
+}  // namespace mf
+
 extern "C" int mf_rollout_fwd_f32(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, void* s) {
   mf::RolloutArgs<float> a;
   mf::LaneMap m;
   int block;
   int rc = mf::fill_args<float>(d, p, &a, &m, &block);
   if (rc != MF_OK) return rc;
+  MF_REQUIRE(((uintptr_t)p->zmu_scratch & 7) == 0, MF_ERR_INVALID, "rollout_fwd: zmu_scratch must be 8-byte aligned");
   if (p->joint_angles) {
     MF_REQUIRE(p->Fs && p->Ff && !p->cost_rows, MF_ERR_UNSUPPORTED, "rollout_fwd: articulated rollouts write all six outputs");
     if (d->math_mode == MF_MATH_FAST) return mf::launch_rollout_fwd_joints_fast_f32(a, m, d->integrator, block, (hipStream_t)s);
@@ -85,6 +105,8 @@ extern "C" int mf_rollout_fwd_f32(const MfRolloutDesc* d, const MfRolloutFwdBufs
     MF_REQUIRE(!p->Xds && !p->Omegas && !p->Fs && !p->Ff && !p->Xraw, MF_ERR_INVALID,
                "rollout_fwd: with cost_rows only Xs and Rs (decimated) are written -- pass NULL for Xds, Omegas, Fs, Ff, Xraw");
     if (m.PPL == 4 && m.G < 64) m = mf::choose_lane_map(d->B, d->N, 1);
+    if (mf::use_interleaved_maps(d, p, &a, m, (hipStream_t)s))
+      return mf::launch_rollout_fwd_zmu_f32(a, m, d->integrator, block, false, false, d->cost_project != 0 ? 2 : 1, (hipStream_t)s);
     return mf::launch_rollout_fwd_cost_f32(a, m, d->integrator, block, d->cost_project != 0, (hipStream_t)s);
   }
   const bool forces = p->Fs != nullptr;
@@ -95,7 +117,10 @@ extern "C" int mf_rollout_fwd_f32(const MfRolloutDesc* d, const MfRolloutFwdBufs
   if (d->math_mode == MF_MATH_FAST) {
     if (!forces && m.PPL == 4 && m.G < 64) m = mf::choose_lane_map(d->B, d->N, 1);
     // >= one wave per SIMD (1024) and a one-point-per-lane mapping within a wave: the split-store kernels (rollout_fwd_kernel.h)
-    if (m.PPL == 1 && m.G <= 64 && (long long)d->B * m.G >= 1024ll * 64)
+    const bool split = m.PPL == 1 && m.G <= 64 && (long long)d->B * m.G >= 1024ll * 64;
+    if (mf::use_interleaved_maps(d, p, &a, m, (hipStream_t)s))
+      return mf::launch_rollout_fwd_zmu_f32(a, m, d->integrator, block, forces, split, 0, (hipStream_t)s);
+    if (split)
       return mf::launch_rollout_fwd_split_fast_f32(a, m, d->integrator, block, forces, (hipStream_t)s);
     return mf::launch_rollout_fwd_fast_f32(a, m, d->integrator, block, forces, (hipStream_t)s);
   }

@@ -52,6 +52,7 @@ struct RolloutArgs {
   S* cost_rows;           // COST kernels: S[T][B][4] = (R20, R21, R22, std over the points of |F_spring|) per output row
   int pose_stride;        // COST kernels: Xs / Rs hold every pose_stride-th output row only
   S* path_cost;           // COST kernels, optional: S[B] std over the T output rows of the 4th cost-row component
+  const S* zmu;           // ZMU kernels: the shared height and friction maps interleaved, S[H*W][2] = (z, mu) per cell
 };
 
 // Arithmetic policy.  Exact: IEEE divide / sqrt, libm exp and sincos, un-fused mul+add (the TU is built with
@@ -121,6 +122,42 @@ __device__ __forceinline__ S ld32(const S* base, unsigned elem) {
   return *reinterpret_cast<const S*>(reinterpret_cast<const char*>(base) + (size_t)(elem * (unsigned)sizeof(S)));
 }
 
+// The four cells of a bilinear footprint with TWO loads instead of four.  c/l and f/fl are neighbours in memory (flat index
+// base, base + 1 and base + H, base + H + 1) unless the reference's clamp of the FLAT index (dphysics.py:432-435) folds them
+// onto cell 0 or HW - 1, so each pair is one 2-element load at p = min(index, HW - 2) and the clamped cases pick the element
+// they name: bit-identical to four single loads for every index, in or out of the map.  The L1 (TCP) looks up one line per
+// lane and cycle for these divergent gathers -- at 16 waves per CU that, not VALU issue or HBM, bounds the saturated kernel
+// (PMC: TCP_TOTAL_CACHE_ACCESSES = 1 per cycle and CU), so halving the lane accesses is what counts.  v = (c, f, l, fl).
+template <typename S>
+struct CellPair { S a, b; };
+template <typename S>
+__device__ __forceinline__ void gather4(const S* map, unsigned moff, const Cell<S>& c, int last, S (&v)[4]) {
+  const int p1 = min(c.ic, last - 1), p2 = min(c.i_f, last - 1);   // last >= 1 (host-checked: H >= 2)
+  const CellPair<S> q1 = *reinterpret_cast<const CellPair<S>*>(reinterpret_cast<const char*>(map) + (size_t)((moff + (unsigned)p1) * (unsigned)sizeof(S)));
+  const CellPair<S> q2 = *reinterpret_cast<const CellPair<S>*>(reinterpret_cast<const char*>(map) + (size_t)((moff + (unsigned)p2) * (unsigned)sizeof(S)));
+  v[0] = c.ic != p1 ? q1.b : q1.a;
+  v[2] = c.il != p1 ? q1.b : q1.a;
+  v[1] = c.i_f != p2 ? q2.b : q2.a;
+  v[3] = c.ifl != p2 ? q2.b : q2.a;
+}
+
+// ZMU kernels (one map pair shared by all rollouts): height and friction interleaved cell by cell, so the footprint of a
+// point in BOTH maps is two 4-element loads: (z_c, mu_c, z_l, mu_l) and (z_f, mu_f, z_fl, mu_fl).  Same values, same
+// clamp handling as gather4 -- a quarter of the L1 lookups of eight single loads.
+template <typename S>
+struct CellQuad { S za, ma, zb, mb; };
+template <typename S>
+__device__ __forceinline__ void gather4x2(const S* zmu, const Cell<S>& c, int last, S (&z)[4], S (&m)[4]) {
+  const int p1 = min(c.ic, last - 1), p2 = min(c.i_f, last - 1);
+  const CellQuad<S> q1 = *reinterpret_cast<const CellQuad<S>*>(reinterpret_cast<const char*>(zmu) + (size_t)((unsigned)p1 * (unsigned)(2 * sizeof(S))));
+  const CellQuad<S> q2 = *reinterpret_cast<const CellQuad<S>*>(reinterpret_cast<const char*>(zmu) + (size_t)((unsigned)p2 * (unsigned)(2 * sizeof(S))));
+  const bool ec = c.ic != p1, el = c.il != p1, ef = c.i_f != p2, efl = c.ifl != p2;
+  z[0] = ec ? q1.zb : q1.za;   m[0] = ec ? q1.mb : q1.ma;
+  z[2] = el ? q1.zb : q1.za;   m[2] = el ? q1.mb : q1.ma;
+  z[1] = ef ? q2.zb : q2.za;   m[1] = ef ? q2.mb : q2.ma;
+  z[3] = efl ? q2.zb : q2.za;  m[3] = efl ? q2.mb : q2.ma;
+}
+
 // update_joints (dphysics.py:326-358): rotate every driving part about the y-axis through its joint by the step's angle, then
 // the inertia of the articulated body about the body origin and its inverse (dphysics.py:196-197, 107-141) -- per step and per
 // rollout; `ja` = the 4 joint angles of this (rollout, step), P0 = rest configuration, P / Iv = articulated points / I^-1.
@@ -158,7 +195,7 @@ __device__ __forceinline__ void articulate_body(GroupSum<G, S>& gs, const S* ja,
   Iv[6] = c02 * idet; Iv[7] = c12 * idet; Iv[8] = c22 * idet;
 }
 
-template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS = false, bool FORCES = true, int COST = 0, bool SPLIT = false>
+template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS = false, bool FORCES = true, int COST = 0, bool SPLIT = false, bool ZMU = false>
 __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const RolloutArgs<S> a) {
   using M = Mth<S, FAST>;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -217,7 +254,9 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
       S px = P[j][0] * R[0] + P[j][1] * R[1] + P[j][2] * R[2] + x[0];
       S py = P[j][0] * R[3] + P[j][1] * R[4] + P[j][2] * R[5] + x[1];
       Cell<S> c = locate_m<S, FAST>(px, py, a.d_max, a.res, a.inv_res, a.H, last);
-      S v = blend(c, ld32(zmap, moff + (unsigned)c.ic), ld32(zmap, moff + (unsigned)c.i_f), ld32(zmap, moff + (unsigned)c.il), ld32(zmap, moff + (unsigned)c.ifl));
+      S z4[4];
+      gather4(zmap, moff, c, last, z4);
+      S v = blend(c, z4[0], z4[1], z4[2], z4[3]);
       acc += act[j] ? v : zero;
     }
     acc = gs.sum(acc);
@@ -400,12 +439,13 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
       r[j][0] = px - x[0]; r[j][1] = py - x[1]; r[j][2] = pz[j] - x[2];
       cell[j] = locate_m<S, FAST>(px, py, a.d_max, a.res, a.inv_res, a.H, last);
       const Cell<S>& c = cell[j];
-      zc[j][0] = ld32(zmap, moff + (unsigned)c.ic); zc[j][1] = ld32(zmap, moff + (unsigned)c.i_f); zc[j][2] = ld32(zmap, moff + (unsigned)c.il); zc[j][3] = ld32(zmap, moff + (unsigned)c.ifl);
+      if constexpr (ZMU) gather4x2(a.zmu, c, last, zc[j], mc[j]);
+      else gather4(zmap, moff, c, last, zc[j]);
     }
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {   // unconditional (mumap aliases z without a friction map; selected after the blend): no branch
       const Cell<S>& c = cell[j];
-      mc[j][0] = ld32(mumap, moff + (unsigned)c.ic); mc[j][1] = ld32(mumap, moff + (unsigned)c.i_f); mc[j][2] = ld32(mumap, moff + (unsigned)c.il); mc[j][3] = ld32(mumap, moff + (unsigned)c.ifl);
+      if constexpr (!ZMU) gather4(mumap, moff, c, last, mc[j]);
     }
     // next step's controls (the lookup argmin|t - ts| is the step index on the grid, dphysics.py:183)
     const int nn = min(n + 1, a.T - 1);
@@ -638,7 +678,7 @@ static inline LaneMap choose_lane_map(int B, int N, int points_per_lane) {
 
 // Instantiated mappings: one point per lane (G = 4..64) and (64, 2/4/8) always; the 4-points-per-lane mappings with G < 64
 // only for the full-output rigid-body kernels (they are a tuning / test option, see choose_lane_map).
-template <typename S, bool FAST, bool JOINTS = false, bool FORCES = true, int COST = 0, bool SPLIT = false>
+template <typename S, bool FAST, bool JOINTS = false, bool FORCES = true, int COST = 0, bool SPLIT = false, bool ZMU = false>
 int launch_rollout_fwd(const RolloutArgs<S>& a, LaneMap m, int integ, int block, hipStream_t st) {
   if (m.G > 64) block = m.G;   // a rollout spread over several waves: exactly one rollout per workgroup (LDS + barrier)
   const long long threads = (long long)a.B * m.G;
@@ -648,12 +688,12 @@ int launch_rollout_fwd(const RolloutArgs<S>& a, LaneMap m, int integ, int block,
   if (!launched && m.G == G_ && m.PPL == P_) {                                                                                             \
     launched = true;                                                                                                                       \
     if (integ == MF_INTEG_DYNAMICS)                                                                                                        \
-      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_DYNAMICS, FAST, JOINTS, FORCES, COST, SPLIT>), dim3(grid), dim3(block), 0, st, a);      \
+      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_DYNAMICS, FAST, JOINTS, FORCES, COST, SPLIT, ZMU>), dim3(grid), dim3(block), 0, st, a);      \
     else                                                                                                                                   \
-      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_ODEINT_EULER, FAST, JOINTS, FORCES, COST, SPLIT>), dim3(grid), dim3(block), 0, st, a);  \
+      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_ODEINT_EULER, FAST, JOINTS, FORCES, COST, SPLIT, ZMU>), dim3(grid), dim3(block), 0, st, a);  \
   }
   if (!JOINTS) { MF_CASE(4, 1) MF_CASE(8, 1) MF_CASE(16, 1) MF_CASE(32, 1) MF_CASE(64, 1) }
-  if constexpr (!SPLIT) {
+  if constexpr (!SPLIT && !ZMU) {   // SPLIT / ZMU kernels: the one-point-per-lane mappings up to a wave only
   if (!JOINTS) { MF_CASE(64, 2) }
   MF_CASE(128, 1) MF_CASE(256, 1) MF_CASE(512, 1)
   if (FORCES) { MF_CASE(1, 4) MF_CASE(2, 4) MF_CASE(4, 4) MF_CASE(8, 4) MF_CASE(16, 4) MF_CASE(32, 4) }
@@ -672,6 +712,9 @@ int launch_rollout_fwd_fast_f32(const RolloutArgs<float>& a, LaneMap m, int inte
 int launch_rollout_fwd_split_fast_f32(const RolloutArgs<float>& a, LaneMap m, int integ, int block, bool forces, hipStream_t st);
 // defined in rollout_fwd_cost.hip
 int launch_rollout_fwd_cost_f32(const RolloutArgs<float>& a, LaneMap m, int integ, int block, bool project, hipStream_t st);
+// defined in rollout_fwd_zmu_fast.hip (shared maps interleaved as (z, mu); one-point-per-lane mappings up to a wave):
+// cost = 0 full outputs (split = state stores spread over the lanes of a group), 1 / 2 cost rows
+int launch_rollout_fwd_zmu_f32(const RolloutArgs<float>& a, LaneMap m, int integ, int block, bool forces, bool split, int cost, hipStream_t st);
 // defined in rollout_fwd_joints_fast.hip
 int launch_rollout_fwd_joints_fast_f32(const RolloutArgs<float>& a, LaneMap m, int integ, int block, hipStream_t st);
 

@@ -112,6 +112,14 @@ def _default_state(controls, B):
     return x, xd, R, w
 
 
+def _zmu_scratch(mod, desc, z):
+    """Scratch for the interleaved (z, mu) copy of a SHARED float32 map pair (MfRolloutFwdBufs.zmu_scratch): the library uses
+    it where its kernels gain from it and ignores it elsewhere; stream-ordered, so it may be freed right after the launch."""
+    if mod.interleave_maps and desc.map_shared and z.dtype == torch.float32:
+        return torch.empty(2 * desc.H * desc.W, dtype=torch.float32, device=z.device)
+    return None
+
+
 class _RolloutFn(torch.autograd.Function):
     """forward = mf_rollout_fwd_*; backward = mf_rollout_bwd_* (reverse-time adjoint of the same scan)."""
 
@@ -143,7 +151,8 @@ class _RolloutFn(torch.autograd.Function):
             points=_lib.ptr(keep['points']), part=_lib.ptr(mod._part_dev(dev)),
             x0=_lib.ptr(x0), xd0=_lib.ptr(xd0), R0=_lib.ptr(R0), w0=_lib.ptr(w0),
             Xs=_lib.ptr(Xs), Xds=_lib.ptr(Xds), Rs=_lib.ptr(Rs), Omegas=_lib.ptr(Om), Fs=_lib.ptr(Fs), Ff=_lib.ptr(Ff),
-            Xraw=_lib.ptr(Xraw), joint_angles=_lib.ptr(joint_angles))
+            Xraw=_lib.ptr(Xraw), joint_angles=_lib.ptr(joint_angles),
+            zmu_scratch=_lib.ptr(_zmu_scratch(mod, desc, keep['z'])))
         fn = getattr(_lib.lib(), 'mf_rollout_fwd_' + _scalar_suffix(dt))
         with torch.cuda.device(dev), _timing.timed('rollout_fwd_kernel', dev):
             _lib.check(fn(C.byref(desc), C.byref(bufs), _stream_ptr(dev)), 'mf_rollout_fwd')
@@ -196,6 +205,7 @@ class DPhysics(torch.nn.Module):
         # False: skip the force outputs (forward returns (states, (None, None))): training only consumes the states
         # (scripts/train.py:243 `states_pred, _ = self.dphysics(...)`); 57 % less output traffic.  float32 fast math only.
         self.return_forces = return_forces
+        self.interleave_maps = True      # shared float32 maps: let the library read an interleaved (z, mu) copy (same bits, fewer loads)
         self.precise = precise      # True: float32 kernels in the reference's exact op order (IEEE div/sqrt, no FMA); ~1.5x slower
         self._cache = {}
 
@@ -368,7 +378,7 @@ class DPhysics(torch.nn.Module):
             points=_lib.ptr(keep['points']), part=_lib.ptr(self._part_dev(dev)),
             x0=_lib.ptr(x0), xd0=_lib.ptr(xd0), R0=_lib.ptr(R0), w0=_lib.ptr(w0),
             Xs=_lib.ptr(Xs), Xds=None, Rs=_lib.ptr(Rs), Omegas=None, Fs=None, Ff=None, Xraw=None, joint_angles=None,
-            cost_rows=_lib.ptr(rows), path_cost=_lib.ptr(force_cost))
+            cost_rows=_lib.ptr(rows), path_cost=_lib.ptr(force_cost), zmu_scratch=_lib.ptr(_zmu_scratch(self, desc, keep['z'])))
         with torch.cuda.device(dev), _timing.timed('rollout_fwd_kernel', dev):
             _lib.check(_lib.lib().mf_rollout_fwd_f32(C.byref(desc), C.byref(bufs), _stream_ptr(dev)), 'mf_rollout_fwd')
         steps = torch.clamp(torch.arange(Tp, device=dev) * ps, max=N_ts - 1)

@@ -339,3 +339,44 @@ def test_split_store_kernels_write_the_same_rows(integ, N):
                 big[0][0][:50].square().sum().backward()
                 small[0][0].square().sum().backward()
                 assert hp.rel_err(zb.grad.cpu(), zs.grad.cpu()) <= 1e-5
+
+
+@pytest.mark.parametrize('integ', [0, 1])
+@pytest.mark.parametrize('N,d_max', [(4, 3.2), (4, 0.6), (23, 1.0), (64, 3.2)])
+def test_interleaved_map_kernels_read_the_same_cells(integ, N, d_max):
+    """With one map pair shared by all rollouts the library reads an interleaved (z, mu) copy -- two 16-byte loads per contact
+    point instead of eight 4-byte ones.  Same cells, same bits: full outputs (few waves and the split-store regime), states
+    only, cost rows (raw and projected), with and without a friction map -- including rollouts that leave a small map, where
+    the reference's clamp of the FLAT cell index folds neighbours onto cell 0 / HW-1 (d_max 0.6 and 1.0: 12 x 12 / 20 x 20 cells)."""
+    from monoforce_amd import synthetic as syn
+    pts, masks = syn.robot_points_box(N, seed=N, n_tracks=2) if N > 4 else syn.robot_points_4()
+    G = 4
+    while G < N:
+        G *= 2
+    T = 300 if d_max < 3 else 40
+    z = (syn.bump_terrain(syn.bump_params(7), d_max, 0.1) * 0.3).to(DEV)
+    mu = (0.5 + 0.5 * torch.rand(z.shape, generator=torch.Generator().manual_seed(3))).to(DEV)
+    for B in (37, 1024 * 64 // G + 5):
+        ctrl = syn.varying_controls(B, T, seed=2).to(DEV)
+        ctrl[:, :, 0] = ctrl[:, :, 0].abs() + 0.5                     # keep driving: on the small maps most rollouts leave the grid
+        for friction in (mu, None):
+            for forces in (True, False):
+                outs = []
+                for inter in (True, False):
+                    dp = make_dphysics(pts, masks, integ, 0.1, d_max, return_forces=forces)
+                    dp.interleave_maps = inter
+                    st, fo = dp(z.unsqueeze(0), ctrl, friction=None if friction is None else friction.unsqueeze(0))
+                    outs.append([o for o in list(st) + list(fo) if o is not None])
+                if d_max < 3:     # the test is about leaving the map: make sure contact points do
+                    assert float(outs[0][0][..., :2].abs().max()) > d_max - 0.1
+                for u, v in zip(*outs):
+                    assert torch.equal(u, v)
+            for project in (True, False):
+                rows = []
+                for inter in (True, False):
+                    dp = make_dphysics(pts, masks, integ, 0.1, d_max)
+                    dp.interleave_maps = inter
+                    r = dp.rollout_costs(z.unsqueeze(0), ctrl, friction=None if friction is None else friction.unsqueeze(0), pose_stride=10, project=project)
+                    rows.append(r)
+                for k in ('cost_rows', 'Xs', 'Rs', 'force_cost'):
+                    assert torch.equal(rows[0][k], rows[1][k]), k

@@ -1,0 +1,41 @@
+// Where does the dispatcher put the waves of a launch of one-wave workgroups?  Every wave records its (XCC, SE, CU, SIMD) from
+// the hardware-id registers while all waves of the launch are resident; the host prints the histogram of waves per SIMD / CU.
+//   hipcc --offload-arch=gfx950 -O3 wave_placement.hip -o wave_placement && ./wave_placement [block]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <vector>
+__global__ void k_place(unsigned* ids, float* sink, int spin) {
+  const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);     // HW_ID: wave[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13]
+  const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // XCC_ID
+  float x = threadIdx.x;
+  for (int i = 0; i < spin; ++i) x = __builtin_fmaf(x, 0.999f, 0.001f);   // stay resident until the whole grid is placed
+  if (threadIdx.x % 64 == 0) { const unsigned w = (blockIdx.x * blockDim.x + threadIdx.x) / 64; ids[2 * w] = hw; ids[2 * w + 1] = xcc; }
+  if (x == 12345.f) sink[0] = x;
+}
+int main(int argc, char** argv) {
+  const int block = argc > 1 ? atoi(argv[1]) : 64;
+  for (int waves : {256, 512, 1024, 2048, 4096}) {
+    unsigned* ids; float* sink; hipMalloc(&ids, 8 * waves); hipMalloc(&sink, 4);
+    hipLaunchKernelGGL(k_place, dim3(waves * 64 / block), dim3(block), 0, 0, ids, sink, 200000);
+    std::vector<unsigned> h(2 * waves); hipMemcpy(h.data(), ids, 8 * waves, hipMemcpyDeviceToHost);
+    std::map<unsigned, int> per_simd, per_cu, per_xcc;
+    for (int w = 0; w < waves; ++w) {
+      const unsigned hw = h[2 * w], xcc = h[2 * w + 1] & 0xf;
+      const unsigned simd = (hw >> 4) & 3, cu = (hw >> 8) & 0xf, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
+      const unsigned cu_key = (xcc << 12) | (se << 8) | (sh << 4) | cu;
+      per_cu[cu_key]++; per_simd[(cu_key << 2) | simd]++; per_xcc[xcc]++;
+    }
+    std::map<int, int> hs, hc;
+    for (auto& kv : per_simd) hs[kv.second]++;
+    for (auto& kv : per_cu) hc[kv.second]++;
+    printf("%5d waves (block %d): %zu XCCs, %zu CUs, %zu SIMDs used;  SIMDs by wave count:", waves, block, per_xcc.size(), per_cu.size(), per_simd.size());
+    for (auto& kv : hs) printf(" %dx%d", kv.second, kv.first);
+    printf(";  CUs by wave count:");
+    for (auto& kv : hc) printf(" %dx%d", kv.second, kv.first);
+    printf("\n");
+    hipFree(ids); hipFree(sink);
+  }
+  return 0;
+}
