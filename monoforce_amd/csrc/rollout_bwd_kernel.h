@@ -686,9 +686,7 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_bwd_kernel(const Ro
         S px = P0[j][0] * R0[0] + P0[j][1] * R0[1] + P0[j][2] * R0[2] + x0[0];
         S py = P0[j][0] * R0[3] + P0[j][1] * R0[4] + P0[j][2] * R0[5] + x0[1];
         Cell<S> c = locate_m<S, FAST>(px, py, a.d_max, a.res, a.inv_res, a.H, last);
-        S z4[4];
-        gather4(zmap, moff, c, last, z4);
-        S v0 = z4[0], v1 = z4[1], v2 = z4[2], v3 = z4[3];
+        S v0 = ld32(zmap, moff + (unsigned)c.ic), v1 = ld32(zmap, moff + (unsigned)c.i_f), v2 = ld32(zmap, moff + (unsigned)c.il), v3 = ld32(zmap, moff + (unsigned)c.ifl);
         atomic_add(at32(gzmap, goff + (unsigned)c.ic), g * (one - c.fx) * (one - c.fy));
         atomic_add(at32(gzmap, goff + (unsigned)c.i_f), g * (one - c.fx) * c.fy);
         atomic_add(at32(gzmap, goff + (unsigned)c.il), g * c.fx * (one - c.fy));

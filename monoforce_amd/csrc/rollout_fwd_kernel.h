@@ -457,6 +457,8 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
       // one 8-byte load of the adjacent pair (ts[n+1], ts[n+2]); in the last iteration, whose h is never used, the pair is
       // clamped into the grid
       const int tp = max(min(n + 1, a.T - 2), 0);
+      // (a vector load on purpose: as a scalar load through the constant address space it shares lgkmcnt with the LDS traffic
+      // of the split-store kernels and every LDS wait becomes a wait for it -- measured slower at 16 k rollouts)
       ts_a = a.ts[tp]; ts_b = a.ts[tp + 1];        // T >= 2 inside the loop, so tp + 1 <= T - 1
     }
 
