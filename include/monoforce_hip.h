@@ -133,7 +133,7 @@ typedef struct MfRolloutFwdBufs {
   void* path_cost;      /* optional S[B], with cost_rows: the force path cost itself, std over the T rows of s (unbiased, Welford
                            in registers) = norm(F_springs, dim=-1).std(dim=-1).std(dim=-1) of monoforce_node.py:91 */
   void* zmu_scratch;    /* optional scratch, 2*H*W floats (8-byte aligned): with a SHARED map (desc->map_shared), float32
-                           MF_MATH_FAST and a rigid body of <= 64 contact points the entry point first interleaves z and mu
+                           MF_MATH_FAST, a rigid body of <= 64 contact points and >= 512 waves of rollouts the entry point first interleaves z and mu
                            into it, cell by cell, and the rollout kernel reads a point's footprint in both maps with two
                            16-byte loads instead of eight 4-byte ones (the L1 looks up one line per lane and cycle: at
                            >= 16 k rollouts that bounds the kernel).  Same results, bit for bit.  Contents are undefined

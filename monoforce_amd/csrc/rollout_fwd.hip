@@ -80,6 +80,9 @@ __global__ void __launch_bounds__(256) interleave_maps_kernel(const float* __res
 // true (and a.zmu set, the interleave pass launched) when this launch can read the interleaved copy
 static bool use_interleaved_maps(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutArgs<float>* a, const LaneMap& m, hipStream_t st) {
   if (!p->zmu_scratch || !d->map_shared || d->math_mode != MF_MATH_FAST || p->joint_angles || m.PPL != 1 || m.G > 64) return false;
+  // Below ~half a wave per SIMD the launch is bound by the instruction stream of its waves; the extra pass (a second launch in
+  // front of the rollout, ~10 us) then costs what the two saved gathers bring (measured: B = 1024 path costs 0.306 -> 0.323 ms)
+  if ((long long)d->B * m.G < 512ll * 64) return false;
   const int n = d->H * d->W;
   hipLaunchKernelGGL(interleave_maps_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a->z, a->mu, n, (float2*)p->zmu_scratch);
   a->zmu = (const float*)p->zmu_scratch;

@@ -356,7 +356,7 @@ def test_interleaved_map_kernels_read_the_same_cells(integ, N, d_max):
     T = 300 if d_max < 3 else 40
     z = (syn.bump_terrain(syn.bump_params(7), d_max, 0.1) * 0.3).to(DEV)
     mu = (0.5 + 0.5 * torch.rand(z.shape, generator=torch.Generator().manual_seed(3))).to(DEV)
-    for B in (37, 1024 * 64 // G + 5):
+    for B in (37, 600 * 64 // G, 1024 * 64 // G + 5):    # no interleaving (few waves) | interleaved | interleaved + split stores
         ctrl = syn.varying_controls(B, T, seed=2).to(DEV)
         ctrl[:, :, 0] = ctrl[:, :, 0].abs() + 0.5                     # keep driving: on the small maps most rollouts leave the grid
         for friction in (mu, None):
