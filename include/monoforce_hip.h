@@ -89,6 +89,10 @@ typedef struct MfRolloutDesc {
   int32_t cost_project; /* path-cost mode, MF_INTEG_ODEINT_EULER: 1 = the cost rows carry the third row of the NEAREST ROTATION to
                            the (drifting) R -- what scipy's Rotation.from_matrix(R).as_euler() reads roll / pitch from
                            (diff_physics.py:263-266); 0 = the raw third row (enough for the force cost; ~20 % faster) */
+  int32_t default_state; /* forward only: 1 = start from the reference's default state (dphysics.py:554-559: x = 0,
+                           xd = (v_0, 0, 0), R = I, omega = (0, 0, w_0) with (v_0, w_0) = controls[b][0]); the kernel computes it
+                           and WRITES x0 / xd0 / R0 / w0 (for the caller and the backward pass) instead of reading them --
+                           saves the separate mf_rollout_default_state_* launch */
   double mass, gravity, stiffness, damping, omega_max;
   double grid_res, d_max;
   double dt;           /* cfg.dt: step of MF_INTEG_DYNAMICS (ODEINT takes its steps from ts[]) */

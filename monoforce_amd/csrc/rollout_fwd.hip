@@ -33,7 +33,7 @@ static int fill_args(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutA
              "rollout_fwd: force_stride too small -- allocate Fs/Ff with mf_rollout_force_stride(desc) point slots per row");
 
   a->B = d->B; a->T = d->T; a->N = d->N; a->H = d->H; a->W = d->W;
-  a->n_tracks = d->n_tracks; a->layout = d->layout; a->map_shared = d->map_shared; a->skip_snap = d->skip_snap;
+  a->n_tracks = d->n_tracks; a->layout = d->layout; a->map_shared = d->map_shared; a->skip_snap = d->skip_snap; a->default_state = d->default_state;
   a->fstride = fstride;
   a->mass = (S)d->mass; a->inv_mass = (S)(1.0 / d->mass); a->mg = (S)(d->mass * d->gravity); a->k = (S)d->stiffness;
   a->damp = (S)d->damping; a->omega_max = (S)d->omega_max; a->res = (S)d->grid_res; a->inv_res = (S)(1.0 / d->grid_res);

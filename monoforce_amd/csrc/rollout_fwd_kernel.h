@@ -27,7 +27,7 @@ namespace mf {
 
 template <typename S>
 struct RolloutArgs {
-  int B, T, N, H, W, n_tracks, layout, map_shared, skip_snap, fstride;
+  int B, T, N, H, W, n_tracks, layout, map_shared, skip_snap, fstride, default_state;
   S mass, inv_mass, mg, k, damp, omega_max, res, inv_res, d_max, dt, half_ly, sink;
   S Iinv[9];
   const S* z;
@@ -237,14 +237,29 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
 
   // state, replicated across the group
   S x[3], xd[3], R[9], w[3];
+  if (a.default_state) {   // the reference's default start (dphysics.py:554-559), written back for the caller / the backward
+    const S v0 = a.controls[(size_t)b * a.T * 2 + 0], w0 = a.controls[(size_t)b * a.T * 2 + 1];
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    x[c] = a.x0[b * 3 + c];
-    xd[c] = a.xd0[b * 3 + c];
-    w[c] = a.w0[b * 3 + c];
+    for (int c = 0; c < 3; ++c) { x[c] = zero; xd[c] = c == 0 ? v0 : zero; w[c] = c == 2 ? w0 : zero; }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) R[c] = (c % 4 == 0) ? one : zero;
+    if (gl == 0) {
+      S* oxd = const_cast<S*>(a.xd0); S* oR = const_cast<S*>(a.R0); S* ow = const_cast<S*>(a.w0);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { a.x0[b * 3 + c] = x[c]; oxd[b * 3 + c] = xd[c]; ow[b * 3 + c] = w[c]; }
+#pragma unroll
+      for (int c = 0; c < 9; ++c) oR[b * 9 + c] = R[c];
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      x[c] = a.x0[b * 3 + c];
+      xd[c] = a.xd0[b * 3 + c];
+      w[c] = a.w0[b * 3 + c];
+    }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) R[c] = a.R0[b * 9 + c];
   }
-#pragma unroll
-  for (int c = 0; c < 9; ++c) R[c] = a.R0[b * 9 + c];
 
   // start at the terrain height: x.z <- mean_i interp(z, (P R^T + x)_i)   (dphysics.py:567-571)
   if (!a.skip_snap) {

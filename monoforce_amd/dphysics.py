@@ -92,24 +92,28 @@ def _is_shared_map(t):
     return t.dim() == 3 and (t.shape[0] == 1 or t.stride(0) == 0)
 
 
-def _default_state(controls, B):
-    """x = 0, xd = (v_0, 0, 0), R = I, omega = (0, 0, w_0) (dphysics.py:554-559) in four small launches instead of nine.
-    xd and omega stay differentiable functions of the first control (as in the reference); x and R share one buffer."""
+def _default_state(controls, B, in_kernel=False):
+    """x = 0, xd = (v_0, 0, 0), R = I, omega = (0, 0, w_0) (dphysics.py:554-559).  xd and omega stay differentiable functions
+    of the first control when it requires grad (as in the reference); otherwise one launch (mf_rollout_default_state_*), or
+    none: with `in_kernel` the buffers come back UNINITIALISED and the rollout kernel fills them (MfRolloutDesc.default_state).
+    Returns (x, xd, R, w, filled_by_rollout_kernel)."""
     if not (controls.requires_grad and torch.is_grad_enabled()) and controls.is_cuda and controls.is_contiguous():
-        buf = torch.empty(18 * B, dtype=controls.dtype, device=controls.device)        # one launch (mf_rollout_default_state_*)
+        buf = torch.empty(18 * B, dtype=controls.dtype, device=controls.device)
         x, xd, R, w = buf[:3 * B].view(B, 3), buf[3 * B:6 * B].view(B, 3), buf[6 * B:15 * B].view(B, 3, 3), buf[15 * B:].view(B, 3)
+        if in_kernel:
+            return x, xd, R, w, True
         fn = getattr(_lib.lib(), 'mf_rollout_default_state_' + _scalar_suffix(controls.dtype))
         with torch.cuda.device(controls.device):
             _lib.check(fn(C.c_int32(B), C.c_int32(controls.shape[1]), _lib.ptr(controls), _lib.ptr(x), _lib.ptr(xd), _lib.ptr(R), _lib.ptr(w),
                           _stream_ptr(controls.device)), 'mf_rollout_default_state')
-        return x, xd, R, w
+        return x, xd, R, w, False
     buf = torch.zeros(12 * B, dtype=controls.dtype, device=controls.device)
     x, R = buf[:3 * B].view(B, 3), buf[3 * B:].view(B, 3, 3)
     R.view(B, 9)[:, ::4] = 1.0
     first = controls[:, 0]
     xd = torch.nn.functional.pad(first[:, 0:1], (0, 2))
     w = torch.nn.functional.pad(first[:, 1:2], (2, 0))
-    return x, xd, R, w
+    return x, xd, R, w, False
 
 
 def _zmu_scratch(mod, desc, z):
@@ -125,11 +129,12 @@ class _RolloutFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_grad, joint_angles=None, want_forces=True,
-                x0_buf=None, x0_private=False):
+                x0_buf=None, x0_private=False, default_state=False):
         # x_arg is the autograd input (the caller's start position when it requires grad); the kernel works on x0_buf, the
         # detached contiguous buffer that receives the snapped height.  x0_private: nobody else sees that buffer.
         x0 = x0_buf if x0_buf is not None else x_arg
         desc, keep = mod._make_desc(z, mu, controls)
+        desc.default_state = int(default_state)     # the kernel computes the start state and fills x0 / xd0 / R0 / w0
         if joint_angles is not None:
             desc.has_joints = 1
             for i, v in enumerate(sum((list(p) for p in mod.dphys_cfg.joint_positions.values()), [])[:12]):
@@ -173,7 +178,7 @@ class _RolloutFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gXs, gXds, gRs, gOm, gFs=None, gFf=None):
         from .dphysics_bwd import rollout_backward
-        return rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf) + (None, None, None, None)
+        return rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf) + (None, None, None, None, None)
 
 
 class DPhysics(torch.nn.Module):
@@ -284,8 +289,10 @@ class DPhysics(torch.nn.Module):
         controls = controls.to(device=dev, dtype=dtype)
 
         own_state = state is None
+        state_in_kernel = False
         if own_state:                                                                # (:554-559)
-            state = _default_state(controls, batch_size)
+            controls = controls.contiguous()
+            *state, state_in_kernel = _default_state(controls, batch_size, in_kernel=True)
         if friction is not None:
             friction = friction.to(device=dev, dtype=dtype)
         self.z_grid = z_grid
@@ -322,7 +329,7 @@ class DPhysics(torch.nn.Module):
         # z none -- the snap overwrites it); the kernel works on the detached buffer x0 either way
         x_arg = x_in if (want_grad and x_in.requires_grad) else x0
         outs = _RolloutFn.apply(self, z_grid, friction, controls.contiguous(), x_arg, xd0, R0, w0, ts, want_grad, ja_dev, want_forces,
-                                x0, own_state)
+                                x0, own_state, state_in_kernel)
         if not aliased:
             with torch.no_grad():       # the reference's in-place write (through .data: no version bump on a tensor autograd saved)
                 x_in.data[..., 2] = x0[..., 2].to(device=x_in.device, dtype=x_in.dtype)
@@ -357,8 +364,10 @@ class DPhysics(torch.nn.Module):
         B = z_grid.shape[0] if z_grid.shape[0] != 1 else controls.shape[0]
         N_ts = min(int(cfg.traj_sim_time / cfg.dt), controls.shape[1])
         assert controls.shape == (B, N_ts, 2), f'Controls shape {controls.shape} != {(B, N_ts, 2)}'
+        state_in_kernel = False
         if state is None:                                                            # (dphysics.py:554-559)
-            x0, xd0, R0, w0 = _default_state(controls, B)
+            controls = controls.contiguous()
+            x0, xd0, R0, w0, state_in_kernel = _default_state(controls.detach(), B, in_kernel=True)
         else:
             x0 = state[0].detach().to(device=dev, dtype=torch.float32).clone()       # the snap writes x0.z: keep the caller's
             xd0, R0, w0 = (t.detach().to(device=dev, dtype=torch.float32).contiguous() for t in state[1:])
@@ -369,6 +378,7 @@ class DPhysics(torch.nn.Module):
         controls = controls.contiguous()
         desc, keep = self._make_desc(z_grid, friction, controls)
         desc.layout, desc.pose_stride, desc.cost_project = _lib.MF_LAYOUT_TIME_MAJOR, ps, int(bool(project))
+        desc.default_state = int(state_in_kernel)
         Tp = 1 + (N_ts - 1 + ps - 1) // ps
         rows = torch.empty(N_ts, B, 4, device=dev)
         force_cost = torch.empty(B, device=dev)

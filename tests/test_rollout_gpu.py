@@ -380,3 +380,31 @@ def test_interleaved_map_kernels_read_the_same_cells(integ, N, d_max):
                     rows.append(r)
                 for k in ('cost_rows', 'Xs', 'Rs', 'force_cost'):
                     assert torch.equal(rows[0][k], rows[1][k]), k
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+def test_default_state_computed_in_the_kernel(dtype):
+    """state=None: the rollout kernel builds the reference's default start (dphysics.py:554-559) itself and writes it back --
+    same outputs as passing that state explicitly, the buffers it fills are what the backward pass then reads."""
+    from monoforce_amd import synthetic as syn
+    pts, masks = syn.robot_points_4()
+    B, T = 33, 60
+    z = (syn.bump_terrain(syn.bump_params(4), 3.2, 0.1) * 0.3).to(DEV).to(dtype)
+    ctrl = syn.varying_controls(B, T, seed=4).to(DEV).to(dtype)
+    for integ in (0, 1):
+        dp = make_dphysics(pts, masks, integ, 0.1, 3.2)
+        za = z.clone().requires_grad_(True)
+        a = dp(za.unsqueeze(0), ctrl)
+        state = (torch.zeros(B, 3, device=DEV, dtype=dtype), torch.nn.functional.pad(ctrl[:, 0, 0:1], (0, 2)),
+                 torch.eye(3, device=DEV, dtype=dtype).repeat(B, 1, 1), torch.nn.functional.pad(ctrl[:, 0, 1:2], (2, 0)))
+        zb = z.clone().requires_grad_(True)
+        b = dp(zb.unsqueeze(0), ctrl, state=state)
+        for u, v in zip(a[0] + a[1], b[0] + b[1]):
+            assert torch.equal(u, v)
+        a[0][0].square().sum().backward()
+        b[0][0].square().sum().backward()
+        assert hp.rel_err(za.grad.cpu(), zb.grad.cpu()) <= (1e-5 if dtype == torch.float32 else 1e-10)
+        ra = dp.rollout_costs(z.float().unsqueeze(0), ctrl.float(), pose_stride=10)
+        rb = dp.rollout_costs(z.float().unsqueeze(0), ctrl.float(), state=tuple(t.float() for t in state), pose_stride=10)
+        for k in ('cost_rows', 'Xs', 'Rs', 'force_cost'):
+            assert torch.equal(ra[k], rb[k]), k
