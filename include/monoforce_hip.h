@@ -93,6 +93,11 @@ typedef struct MfRolloutDesc {
                            xd = (v_0, 0, 0), R = I, omega = (0, 0, w_0) with (v_0, w_0) = controls[b][0]); the kernel computes it
                            and WRITES x0 / xd0 / R0 / w0 (for the caller and the backward pass) instead of reading them --
                            saves the separate mf_rollout_default_state_* launch */
+  int32_t controls_stride_b, controls_stride_t; /* forward only: element strides of `controls` over rollouts and over time
+                           ((v, w) stay adjacent); both 0 = contiguous [B][T][2].  controls_stride_t = 0 reads ONE (v, w) per
+                           rollout for the whole horizon -- the constant-in-time samples of trajectory shooting
+                           (generate_controls, dphysics.py:42-72; monoforce_node.py:41-52) as the [B,1,2] tensor they are,
+                           instead of a materialised [B,T,2] copy that every step of every rollout would fetch from HBM */
   double mass, gravity, stiffness, damping, omega_max;
   double grid_res, d_max;
   double dt;           /* cfg.dt: step of MF_INTEG_DYNAMICS (ODEINT takes its steps from ts[]) */

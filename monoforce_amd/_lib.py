@@ -18,7 +18,7 @@ MF_MATH_EXACT, MF_MATH_FAST = 0, 1
 class MfRolloutDesc(C.Structure):
     _fields_ = [('B', C.c_int32), ('T', C.c_int32), ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32),
                 ('n_tracks', C.c_int32), ('integrator', C.c_int32), ('layout', C.c_int32), ('map_shared', C.c_int32),
-                ('block', C.c_int32), ('skip_snap', C.c_int32), ('points_per_lane', C.c_int32), ('math_mode', C.c_int32), ('force_stride', C.c_int32), ('grad_copies', C.c_int32), ('has_joints', C.c_int32), ('pose_stride', C.c_int32), ('cost_project', C.c_int32), ('default_state', C.c_int32),
+                ('block', C.c_int32), ('skip_snap', C.c_int32), ('points_per_lane', C.c_int32), ('math_mode', C.c_int32), ('force_stride', C.c_int32), ('grad_copies', C.c_int32), ('has_joints', C.c_int32), ('pose_stride', C.c_int32), ('cost_project', C.c_int32), ('default_state', C.c_int32), ('controls_stride_b', C.c_int32), ('controls_stride_t', C.c_int32),
                 ('mass', C.c_double), ('gravity', C.c_double), ('stiffness', C.c_double), ('damping', C.c_double),
                 ('omega_max', C.c_double), ('grid_res', C.c_double), ('d_max', C.c_double), ('dt', C.c_double),
                 ('robot_size_y', C.c_double), ('Iinv', C.c_double * 9), ('joint_xyz', C.c_double * 12)]

@@ -18,6 +18,7 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
   MF_REQUIRE(d->N <= 512, MF_ERR_UNSUPPORTED, "rollout_bwd: more than 512 contact points");
   MF_REQUIRE(d->H < (1 << 23), MF_ERR_UNSUPPORTED, "rollout_bwd: grid too large (H must be below 2^23)");
   MF_REQUIRE(d->H >= 2, MF_ERR_INVALID, "rollout_bwd: the grid needs at least 2 x 2 cells");
+  MF_REQUIRE(d->controls_stride_b == 0 && d->controls_stride_t == 0, MF_ERR_UNSUPPORTED, "rollout_bwd: controls must be contiguous [B][T][2]");
   MF_REQUIRE(d->map_shared || (long long)d->B * d->H * d->W * (long long)sizeof(S) < (1ll << 32), MF_ERR_UNSUPPORTED,
              "rollout_bwd: per-rollout maps of 4 GiB or more in total (use a shared map or split the batch)");
   MF_REQUIRE((long long)(d->grad_copies > 1 ? d->grad_copies : 1) * d->H * d->W * (long long)sizeof(S) < (1ll << 32), MF_ERR_UNSUPPORTED,

@@ -34,6 +34,9 @@ static int fill_args(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutA
 
   a->B = d->B; a->T = d->T; a->N = d->N; a->H = d->H; a->W = d->W;
   a->n_tracks = d->n_tracks; a->layout = d->layout; a->map_shared = d->map_shared; a->skip_snap = d->skip_snap; a->default_state = d->default_state;
+  const bool strided = d->controls_stride_b != 0 || d->controls_stride_t != 0;
+  a->ctrl_sb = strided ? d->controls_stride_b : d->T * 2; a->ctrl_st = strided ? d->controls_stride_t : 2;
+  MF_REQUIRE(a->ctrl_sb >= 0 && a->ctrl_st >= 0, MF_ERR_INVALID, "rollout_fwd: negative controls stride");
   a->fstride = fstride;
   a->mass = (S)d->mass; a->inv_mass = (S)(1.0 / d->mass); a->mg = (S)(d->mass * d->gravity); a->k = (S)d->stiffness;
   a->damp = (S)d->damping; a->omega_max = (S)d->omega_max; a->res = (S)d->grid_res; a->inv_res = (S)(1.0 / d->grid_res);

@@ -27,7 +27,7 @@ namespace mf {
 
 template <typename S>
 struct RolloutArgs {
-  int B, T, N, H, W, n_tracks, layout, map_shared, skip_snap, fstride, default_state;
+  int B, T, N, H, W, n_tracks, layout, map_shared, skip_snap, fstride, default_state, ctrl_sb, ctrl_st;
   S mass, inv_mass, mg, k, damp, omega_max, res, inv_res, d_max, dt, half_ly, sink;
   S Iinv[9];
   const S* z;
@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
   // state, replicated across the group
   S x[3], xd[3], R[9], w[3];
   if (a.default_state) {   // the reference's default start (dphysics.py:554-559), written back for the caller / the backward
-    const S v0 = a.controls[(size_t)b * a.T * 2 + 0], w0 = a.controls[(size_t)b * a.T * 2 + 1];
+    const S v0 = a.controls[(size_t)b * a.ctrl_sb + 0], w0 = a.controls[(size_t)b * a.ctrl_sb + 1];
 #pragma unroll
     for (int c = 0; c < 3; ++c) { x[c] = zero; xd[c] = c == 0 ? v0 : zero; w[c] = c == 2 ? w0 : zero; }
 #pragma unroll
@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
 
   const int n_steps = (INTEG == MF_INTEG_ODEINT_EULER) ? a.T - 1 : a.T;
 
-  const S* ctrl = a.controls + (size_t)b * a.T * 2;
+  const S* ctrl = a.controls + (size_t)b * a.ctrl_sb;   // row of this rollout; ctrl_st = 0: one (v, w) for the whole horizon
   S cv = ctrl[0], cw = ctrl[1];
   S h_ode = (INTEG == MF_INTEG_ODEINT_EULER && a.T > 1) ? a.ts[1] - a.ts[0] : zero;   // step size of the current step
 
@@ -464,7 +464,7 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
     }
     // next step's controls (the lookup argmin|t - ts| is the step index on the grid, dphysics.py:183)
     const int nn = min(n + 1, a.T - 1);
-    const S cv_next = ctrl[nn * 2 + 0], cw_next = ctrl[nn * 2 + 1];
+    const S cv_next = ctrl[nn * a.ctrl_st + 0], cw_next = ctrl[nn * a.ctrl_st + 1];
     // ... and its step size h = ts[n+2] - ts[n+1] (torchdiffeq's fixed grid): loaded HERE, before the stores below -- a load
     // issued after them would make its wait (vmcnt is in-order) a wait for this step's stores as well
     S ts_a = zero, ts_b = zero;

@@ -97,7 +97,8 @@ def _default_state(controls, B, in_kernel=False):
     of the first control when it requires grad (as in the reference); otherwise one launch (mf_rollout_default_state_*), or
     none: with `in_kernel` the buffers come back UNINITIALISED and the rollout kernel fills them (MfRolloutDesc.default_state).
     Returns (x, xd, R, w, filled_by_rollout_kernel)."""
-    if not (controls.requires_grad and torch.is_grad_enabled()) and controls.is_cuda and controls.is_contiguous():
+    if not (controls.requires_grad and torch.is_grad_enabled()) and controls.is_cuda and (
+            controls.is_contiguous() or (in_kernel and _time_constant(controls))):
         buf = torch.empty(18 * B, dtype=controls.dtype, device=controls.device)
         x, xd, R, w = buf[:3 * B].view(B, 3), buf[3 * B:6 * B].view(B, 3), buf[6 * B:15 * B].view(B, 3, 3), buf[15 * B:].view(B, 3)
         if in_kernel:
@@ -114,6 +115,20 @@ def _default_state(controls, B, in_kernel=False):
     xd = torch.nn.functional.pad(first[:, 0:1], (0, 2))
     w = torch.nn.functional.pad(first[:, 1:2], (2, 0))
     return x, xd, R, w, False
+
+
+def _time_constant(controls):
+    """True for a [B,T,2] view of ONE (v, w) per rollout broadcast over time (`expand`, stride 0 along T): the kernels read it
+    as it is (MfRolloutDesc.controls_stride_t = 0) -- no [B,T,2] copy for every step of every rollout to fetch."""
+    return (controls.dim() == 3 and controls.shape[1] > 1 and controls.stride(1) == 0 and controls.stride(2) == 1
+            and controls.stride(0) >= 2)
+
+
+def _kernel_controls(controls, allow_view):
+    """(tensor whose memory the kernel reads, stride over rollouts, stride over time); (t, 0, 0) = contiguous."""
+    if allow_view and controls.is_cuda and _time_constant(controls):
+        return controls, controls.stride(0), 0
+    return controls.contiguous(), 0, 0
 
 
 def _zmu_scratch(mod, desc, z):
@@ -133,7 +148,10 @@ class _RolloutFn(torch.autograd.Function):
         # x_arg is the autograd input (the caller's start position when it requires grad); the kernel works on x0_buf, the
         # detached contiguous buffer that receives the snapped height.  x0_private: nobody else sees that buffer.
         x0 = x0_buf if x0_buf is not None else x_arg
+        # inference reads a time-constant (expanded) control tensor as it is; the backward kernel wants [B][T][2]
+        controls, sb, st = _kernel_controls(controls, allow_view=not want_grad)
         desc, keep = mod._make_desc(z, mu, controls)
+        desc.controls_stride_b, desc.controls_stride_t = sb, st
         desc.default_state = int(default_state)     # the kernel computes the start state and fills x0 / xd0 / R0 / w0
         if joint_angles is not None:
             desc.has_joints = 1
@@ -291,7 +309,8 @@ class DPhysics(torch.nn.Module):
         own_state = state is None
         state_in_kernel = False
         if own_state:                                                                # (:554-559)
-            controls = controls.contiguous()
+            if not _time_constant(controls):
+                controls = controls.contiguous()
             *state, state_in_kernel = _default_state(controls, batch_size, in_kernel=True)
         if friction is not None:
             friction = friction.to(device=dev, dtype=dtype)
@@ -328,7 +347,7 @@ class DPhysics(torch.nn.Module):
         # a start position that requires grad is the autograd input itself (its gradient: x and y through the contact geometry,
         # z none -- the snap overwrites it); the kernel works on the detached buffer x0 either way
         x_arg = x_in if (want_grad and x_in.requires_grad) else x0
-        outs = _RolloutFn.apply(self, z_grid, friction, controls.contiguous(), x_arg, xd0, R0, w0, ts, want_grad, ja_dev, want_forces,
+        outs = _RolloutFn.apply(self, z_grid, friction, controls, x_arg, xd0, R0, w0, ts, want_grad, ja_dev, want_forces,
                                 x0, own_state, state_in_kernel)
         if not aliased:
             with torch.no_grad():       # the reference's in-place write (through .data: no version bump on a tensor autograd saved)
@@ -365,9 +384,9 @@ class DPhysics(torch.nn.Module):
         N_ts = min(int(cfg.traj_sim_time / cfg.dt), controls.shape[1])
         assert controls.shape == (B, N_ts, 2), f'Controls shape {controls.shape} != {(B, N_ts, 2)}'
         state_in_kernel = False
+        controls, sb, st = _kernel_controls(controls.detach(), allow_view=True)
         if state is None:                                                            # (dphysics.py:554-559)
-            controls = controls.contiguous()
-            x0, xd0, R0, w0, state_in_kernel = _default_state(controls.detach(), B, in_kernel=True)
+            x0, xd0, R0, w0, state_in_kernel = _default_state(controls, B, in_kernel=True)
         else:
             x0 = state[0].detach().to(device=dev, dtype=torch.float32).clone()       # the snap writes x0.z: keep the caller's
             xd0, R0, w0 = (t.detach().to(device=dev, dtype=torch.float32).contiguous() for t in state[1:])
@@ -375,8 +394,8 @@ class DPhysics(torch.nn.Module):
             friction = friction.to(device=dev, dtype=torch.float32)
         ps = int(pose_stride) if pose_stride else max(int(0.5 / cfg.dt), 1)
         ts = self._time_grid(N_ts, torch.float32, dev)
-        controls = controls.contiguous()
         desc, keep = self._make_desc(z_grid, friction, controls)
+        desc.controls_stride_b, desc.controls_stride_t = sb, st
         desc.layout, desc.pose_stride, desc.cost_project = _lib.MF_LAYOUT_TIME_MAJOR, ps, int(bool(project))
         desc.default_state = int(state_in_kernel)
         Tp = 1 + (N_ts - 1 + ps - 1) // ps

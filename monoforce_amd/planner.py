@@ -20,7 +20,9 @@ __all__ = ['sample_controls', 'force_path_cost', 'inclination_path_cost', 'neare
 
 
 def sample_controls(n_trajs, cfg, device, generator=None):
-    """[n_trajs, T, 2] constant-in-time (v, w): first half forward, second half backward (monoforce_node.py:41-52)."""
+    """[n_trajs, T, 2] constant-in-time (v, w): first half forward, second half backward (monoforce_node.py:41-52).  Returned
+    as the [n_trajs, 1, 2] samples EXPANDED over time (stride 0): the rollout kernels read one (v, w) per trajectory instead of
+    a 2 T-float row; `.contiguous()` gives the reference's materialised tensor."""
     T = int(cfg.traj_sim_time / cfg.dt)
     n_f = n_trajs // 2
     u = torch.rand(n_trajs, 2, device=device, generator=generator)
@@ -28,7 +30,7 @@ def sample_controls(n_trajs, cfg, device, generator=None):
     v[:n_f] = cfg.vel_max / 2 + u[:n_f, 0] * (cfg.vel_max / 2)
     v[n_f:] = -cfg.vel_max + u[n_f:, 0] * (cfg.vel_max / 2)
     w = -cfg.omega_max + u[:, 1] * (2 * cfg.omega_max)
-    return torch.stack([v, w], -1).unsqueeze(1).expand(-1, T, -1).contiguous()
+    return torch.stack([v, w], -1).unsqueeze(1).expand(-1, T, -1)
 
 
 def force_path_cost(F_springs):

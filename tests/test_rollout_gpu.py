@@ -408,3 +408,41 @@ def test_default_state_computed_in_the_kernel(dtype):
         rb = dp.rollout_costs(z.float().unsqueeze(0), ctrl.float(), state=tuple(t.float() for t in state), pose_stride=10)
         for k in ('cost_rows', 'Xs', 'Rs', 'force_cost'):
             assert torch.equal(ra[k], rb[k]), k
+
+
+def test_time_constant_controls_are_read_in_place():
+    """One (v, w) per rollout expanded over the horizon (what generate_controls / the planning node sample) is handed to the
+    kernels as the [B,1,2] tensor it is (controls_stride_t = 0): same outputs as with the materialised [B,T,2] copy -- full
+    outputs, both integrators, float32 and float64, default and explicit start state, and the path-cost mode; with autograd on
+    the library gets a contiguous copy and gradients match."""
+    from monoforce_amd import synthetic as syn
+    from monoforce_amd.planner import sample_controls
+    pts, masks = syn.robot_points_4()
+    B, T = 41, 80
+    z = (syn.bump_terrain(syn.bump_params(2), 3.2, 0.1) * 0.3).to(DEV)
+    for integ in (0, 1):
+        dp = make_dphysics(pts, masks, integ, 0.1, 3.2)
+        dp.dphys_cfg.traj_sim_time = T * dp.dphys_cfg.dt + 1e-6
+        dp = make_dphysics(pts, masks, integ, 0.1, 3.2)
+        vw = torch.rand(B, 1, 2, generator=torch.Generator().manual_seed(integ)).to(DEV) * torch.tensor([1.0, 2.0], device=DEV) - torch.tensor([0.0, 1.0], device=DEV)
+        Tn = int(dp.dphys_cfg.traj_sim_time / dp.dphys_cfg.dt)
+        view = vw.expand(-1, Tn, -1)
+        assert view.stride(1) == 0
+        for dtype in (torch.float32, torch.float64):
+            a = dp(z.to(dtype).unsqueeze(0), view.to(dtype) if dtype == torch.float32 else vw.to(dtype).expand(-1, Tn, -1))
+            b = dp(z.to(dtype).unsqueeze(0), view.to(dtype).contiguous())
+            for u, v in zip(a[0] + a[1], b[0] + b[1]):
+                assert torch.equal(u, v)
+        state = (torch.zeros(B, 3, device=DEV), torch.zeros(B, 3, device=DEV), torch.eye(3, device=DEV).repeat(B, 1, 1), torch.zeros(B, 3, device=DEV))
+        ra = dp.rollout_costs(z.unsqueeze(0), view, state=tuple(t.clone() for t in state), pose_stride=10)
+        rb = dp.rollout_costs(z.unsqueeze(0), view.contiguous(), state=tuple(t.clone() for t in state), pose_stride=10)
+        rc = dp.rollout_costs(z.unsqueeze(0), view, pose_stride=10)
+        rd = dp.rollout_costs(z.unsqueeze(0), view.contiguous(), pose_stride=10)
+        for k in ('cost_rows', 'Xs', 'Rs', 'force_cost'):
+            assert torch.equal(ra[k], rb[k]) and torch.equal(rc[k], rd[k]), k
+        za, zb = z.clone().requires_grad_(True), z.clone().requires_grad_(True)
+        dp(za.unsqueeze(0), view)[0][0].square().sum().backward()
+        dp(zb.unsqueeze(0), view.contiguous())[0][0].square().sum().backward()
+        assert hp.rel_err(za.grad.cpu(), zb.grad.cpu()) <= 1e-5
+    c = sample_controls(64, dp.dphys_cfg, DEV)
+    assert c.shape == (64, Tn, 2) and c.stride(1) == 0
