@@ -210,7 +210,7 @@ class Runner:
         }
         if with_sweep and not wl['backward']:
             sweep = {}
-            for Bs in (256, 1024, 4096, 16384, 65536):
+            for Bs in (256, 1024, 4096, 8192, 16384, 32768, 65536):
                 _, dps, _, _, _, _, cs = build_problem(Bs, T, N, dev, args.integrator, seed=0)
                 cs = cs.to(dev)
                 with torch.no_grad():
