@@ -410,7 +410,10 @@ class DPhysics(torch.nn.Module):
             cost_rows=_lib.ptr(rows), path_cost=_lib.ptr(force_cost), zmu_scratch=_lib.ptr(_zmu_scratch(self, desc, keep['z'])))
         with torch.cuda.device(dev), _timing.timed('rollout_fwd_kernel', dev):
             _lib.check(_lib.lib().mf_rollout_fwd_f32(C.byref(desc), C.byref(bufs), _stream_ptr(dev)), 'mf_rollout_fwd')
-        steps = torch.clamp(torch.arange(Tp, device=dev) * ps, max=N_ts - 1)
+        key = ('pose_steps', Tp, ps, N_ts, str(dev))
+        if key not in self._cache:       # constant per configuration: no two extra launches per planning cycle
+            self._cache[key] = torch.clamp(torch.arange(Tp, device=dev) * ps, max=N_ts - 1)
+        steps = self._cache[key]
         return dict(cost_rows=rows.transpose(0, 1), Xs=Xs.transpose(0, 1), Rs=Rs.transpose(0, 1), pose_steps=steps, force_cost=force_cost)
 
     def _time_grid(self, n, dtype, dev):
