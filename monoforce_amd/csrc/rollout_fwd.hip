@@ -86,6 +86,7 @@ static bool use_interleaved_maps(const MfRolloutDesc* d, const MfRolloutFwdBufs*
   // Below ~half a wave per SIMD the launch is bound by the instruction stream of its waves; the extra pass (a second launch in
   // front of the rollout, ~10 us) then costs what the two saved gathers bring (measured: B = 1024 path costs 0.306 -> 0.323 ms)
   if ((long long)d->B * m.G < 512ll * 64) return false;
+  if ((long long)d->H * d->W >= (1ll << 29)) return false;   // 32-bit byte offsets into the 8-byte cells
   const int n = d->H * d->W;
   hipLaunchKernelGGL(interleave_maps_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a->z, a->mu, n, (float2*)p->zmu_scratch);
   a->zmu = (const float*)p->zmu_scratch;
