@@ -70,3 +70,26 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
     with pytest.raises(RuntimeError, match='no CPU fallback'):
         _lib.lib()
+
+
+def test_control_tensor_classification_on_the_host():
+    """Host logic of the controls hand-over: a [B,1,2] sample expanded over time is recognised (and read in place on the GPU);
+    everything else -- and every CPU tensor -- is handed over as a contiguous [B,T,2] copy."""
+    import torch
+    from monoforce_amd.dphys_config import DPhysConfig
+    from monoforce_amd.dphysics import _kernel_controls, _time_constant
+    from monoforce_amd.planner import sample_controls
+    from monoforce_amd import synthetic as syn
+    pts, masks = syn.robot_points_4()
+    cfg = DPhysConfig(robot='tradr', grid_res=0.1, robot_points=pts, driving_parts=masks)
+    c = sample_controls(6, cfg, 'cpu', torch.Generator().manual_seed(0))
+    T = int(cfg.traj_sim_time / cfg.dt)
+    assert c.shape == (6, T, 2) and c.stride(1) == 0 and _time_constant(c)
+    assert float(c[:3, 0, 0].min()) > 0 > float(c[3:, 0, 0].max())            # first half forward, second half backward
+    assert torch.equal(c[:, 0], c[:, T - 1])
+    dense = c.contiguous()
+    assert not _time_constant(dense) and not _time_constant(c[:, :1]) and not _time_constant(dense.transpose(0, 1))
+    t, sb, st = _kernel_controls(c, allow_view=True)                          # CPU tensor: never handed over as a view
+    assert t.is_contiguous() and (sb, st) == (0, 0) and torch.equal(t, dense)
+    t, sb, st = _kernel_controls(c, allow_view=False)
+    assert t.is_contiguous() and (sb, st) == (0, 0)
