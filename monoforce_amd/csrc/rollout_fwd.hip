@@ -33,7 +33,7 @@ static int fill_args(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutA
              "rollout_fwd: force_stride too small -- allocate Fs/Ff with mf_rollout_force_stride(desc) point slots per row");
 
   a->B = d->B; a->T = d->T; a->N = d->N; a->H = d->H; a->W = d->W;
-  a->n_tracks = d->n_tracks; a->layout = d->layout; a->map_shared = d->map_shared; a->skip_snap = d->skip_snap; a->default_state = d->default_state;
+  a->n_tracks = d->n_tracks; a->layout = d->layout; a->map_shared = d->map_shared; a->skip_snap = d->skip_snap; a->default_state = d->default_state; a->b0 = 0;
   const bool strided = d->controls_stride_b != 0 || d->controls_stride_t != 0;
   a->ctrl_sb = strided ? d->controls_stride_b : d->T * 2; a->ctrl_st = strided ? d->controls_stride_t : 2;
   MF_REQUIRE(a->ctrl_sb >= 0 && a->ctrl_st >= 0, MF_ERR_INVALID, "rollout_fwd: negative controls stride");

@@ -21,13 +21,14 @@
 // ALL its loads first, then the (non-temporal) stores of the previous row, and the waits are vmcnt(k >= number of stores).
 // Variants: JOINTS (articulated body), FORCES = false (states only), COST (path-cost rows + decimated poses).
 #pragma once
+#include <cstdlib>
 #include "rollout_common.h"
 
 namespace mf {
 
 template <typename S>
 struct RolloutArgs {
-  int B, T, N, H, W, n_tracks, layout, map_shared, skip_snap, fstride, default_state, ctrl_sb, ctrl_st;
+  int B, T, N, H, W, n_tracks, layout, map_shared, skip_snap, fstride, default_state, ctrl_sb, ctrl_st, b0;
   S mass, inv_mass, mg, k, damp, omega_max, res, inv_res, d_max, dt, half_ly, sink;
   S Iinv[9];
   const S* z;
@@ -199,7 +200,7 @@ template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS = false,
 __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const RolloutArgs<S> a) {
   using M = Mth<S, FAST>;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-  const int b = tid / G;
+  const int b = tid / G + a.b0;   // b0: first rollout of this launch (very large batches go out in several launches)
   const int gl = tid % G;
   if (b >= a.B) return;  // whole groups leave together; live groups never read dead lanes
   const S one = (S)1, zero = (S)0;
@@ -698,16 +699,26 @@ static inline LaneMap choose_lane_map(int B, int N, int points_per_lane) {
 template <typename S, bool FAST, bool JOINTS = false, bool FORCES = true, int COST = 0, bool SPLIT = false, bool ZMU = false>
 int launch_rollout_fwd(const RolloutArgs<S>& a, LaneMap m, int integ, int block, hipStream_t st) {
   if (m.G > 64) block = m.G;   // a rollout spread over several waves: exactly one rollout per workgroup (LDS + barrier)
-  const long long threads = (long long)a.B * m.G;
-  const unsigned grid = (unsigned)((threads + block - 1) / block);
+  // More than two waves per SIMD do not help these kernels -- their gathers then miss the CU's L1 more often -- so a very
+  // large batch goes out as consecutive launches of <= kChunkWaves waves on the same stream (measured: B = 65536 1.81 -> 1.73 ms,
+  // B = 131072 4.23 -> 3.90 ms; MF_CHUNK_WAVES=0 disables).  The chunk is a whole number of workgroups; results do not depend on it.
+  static const long long kChunkWaves = getenv("MF_CHUNK_WAVES") ? atoll(getenv("MF_CHUNK_WAVES")) : 2048;
+  int chunk_B = a.B;
+  if (m.G <= 64 && kChunkWaves > 0 && (long long)a.B * m.G > kChunkWaves * 64) chunk_B = (int)(kChunkWaves * 64 / m.G);
   bool launched = false;
+  for (int b0 = 0; b0 < a.B; b0 += chunk_B) {
+  RolloutArgs<S> ac = a;
+  ac.b0 = b0;
+  const long long threads = (long long)((a.B - b0 < chunk_B) ? a.B - b0 : chunk_B) * m.G;
+  const unsigned grid = (unsigned)((threads + block - 1) / block);
+  launched = false;
 #define MF_CASE(G_, P_)                                                                                                                   \
   if (!launched && m.G == G_ && m.PPL == P_) {                                                                                             \
     launched = true;                                                                                                                       \
     if (integ == MF_INTEG_DYNAMICS)                                                                                                        \
-      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_DYNAMICS, FAST, JOINTS, FORCES, COST, SPLIT, ZMU>), dim3(grid), dim3(block), 0, st, a);      \
+      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_DYNAMICS, FAST, JOINTS, FORCES, COST, SPLIT, ZMU>), dim3(grid), dim3(block), 0, st, ac);     \
     else                                                                                                                                   \
-      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_ODEINT_EULER, FAST, JOINTS, FORCES, COST, SPLIT, ZMU>), dim3(grid), dim3(block), 0, st, a);  \
+      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_ODEINT_EULER, FAST, JOINTS, FORCES, COST, SPLIT, ZMU>), dim3(grid), dim3(block), 0, st, ac); \
   }
   if (!JOINTS) { MF_CASE(4, 1) MF_CASE(8, 1) MF_CASE(16, 1) MF_CASE(32, 1) MF_CASE(64, 1) }
   if constexpr (!SPLIT && !ZMU) {   // SPLIT / ZMU kernels: the one-point-per-lane mappings up to a wave only
@@ -718,6 +729,7 @@ int launch_rollout_fwd(const RolloutArgs<S>& a, LaneMap m, int integ, int block,
   }
 #undef MF_CASE
   MF_REQUIRE(launched, MF_ERR_UNSUPPORTED, "rollout_fwd: no kernel for this lane mapping");
+  }
   hipError_t e = hipGetLastError();
   MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("rollout_fwd launch: ") + hipGetErrorString(e));
   return MF_OK;

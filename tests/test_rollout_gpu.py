@@ -446,3 +446,28 @@ def test_time_constant_controls_are_read_in_place():
         assert hp.rel_err(za.grad.cpu(), zb.grad.cpu()) <= 1e-5
     c = sample_controls(64, dp.dphys_cfg, DEV)
     assert c.shape == (64, Tn, 2) and c.stride(1) == 0
+
+
+def test_very_large_batches_go_out_in_several_launches():
+    """More than 2048 waves of rollouts are launched in chunks (two waves per SIMD is where these kernels peak): every rollout
+    computes what it computes alone, whatever chunk it lands in -- full outputs, states only and cost rows, across a chunk edge."""
+    from monoforce_amd import synthetic as syn
+    pts, masks = syn.robot_points_box(40, seed=40, n_tracks=2)       # 64 lanes per rollout: 2100 rollouts = 2100 waves, 2 launches
+    B, T = 2100, 10
+    z = (syn.bump_terrain(syn.bump_params(6), 3.2, 0.1) * 0.3).to(DEV)
+    ctrl = syn.varying_controls(B, T, seed=3).to(DEV)
+    tail = ctrl[2030:2100].contiguous()                               # rollouts on both sides of the edge at 2048
+    for integ in (0, 1):
+        for forces in (True, False):
+            dp = make_dphysics(pts, masks, integ, 0.1, 3.2, return_forces=forces)
+            big = dp(z.unsqueeze(0), ctrl)
+            small = dp(z.unsqueeze(0), tail)
+            for u, v in zip(big[0] + big[1], small[0] + small[1]):
+                assert (u is None) == (v is None)
+                if u is not None:
+                    assert torch.equal(u[2030:2100], v)
+        dp = make_dphysics(pts, masks, integ, 0.1, 3.2)
+        rb = dp.rollout_costs(z.unsqueeze(0), ctrl, pose_stride=5)
+        rs = dp.rollout_costs(z.unsqueeze(0), tail, pose_stride=5)
+        for k in ('cost_rows', 'Xs', 'Rs', 'force_cost'):
+            assert torch.equal(rb[k][2030:2100], rs[k]), k
