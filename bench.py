@@ -1,34 +1,46 @@
 #!/usr/bin/env python3
 """bench.py -- rollout-steps/s of the DPhysics hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
 
-A "step" is one pass of the hot path over one batch of synthetic input: B rollouts x T Euler steps x N contact points on
-a 256x256 terrain.  `value` = (B * T * world_size * K) / wall time of the K timed steps (barrier + synchronize on both
-sides, max over ranks), inputs resident in HBM, outputs allocated inside the timed region (the API returns fresh
-tensors).  Rollouts are independent, so ranks shard the batch with no data-path collective (weak scaling: B rollouts per
-GPU); the backward workloads all-reduce the gradient of what the ranks share (terrain grids / encoder weights) over RCCL.
+N > 1: one rank per GPU over RCCL.  Either the caller launches the ranks (`python -m torch.distributed.run --nproc-per-node N
+... bench.py --gpus N`, RANK / LOCAL_RANK / WORLD_SIZE in the env) or, when WORLD_SIZE is absent, bench.py re-executes itself
+under torch.distributed.run with N ranks.  It never runs fewer ranks than asked for: WORLD_SIZE != N, or fewer than N
+visible GPUs, is an error (exit code 2).
 
-Workloads (`--workload`, default c3f = the shape the metric is quoted on):
+A "step" is one pass of the hot path over one batch of synthetic input: B rollouts x T Euler steps x N contact points on a
+256x256 terrain.  `value` = (B * T * world_size * K) / wall time of the K timed steps (barrier + synchronize on both sides,
+max over ranks), inputs resident in HBM, outputs allocated inside the timed region (the API returns fresh tensors).
+Rollouts are independent: ranks shard the batch with no data-path collective (weak scaling: B rollouts per GPU); the
+backward all-reduces the gradient of what the ranks SHARE -- one terrain / friction map pair, the same on every rank
+(same seed), fitted to every rank's rollouts -- over RCCL.
+
+Workloads (`--workload`; the default, c3, is BASELINE configs[2], the shape north_star quotes the metric on):
+  c1   BASELINE configs[0]   1 rollout x 200 steps, 128x128 terrain (res 0.1), forward + backward
   c2   BASELINE configs[1]   256 rollouts x 500 steps, forward
-  c3f  north_star shape      1024 rollouts x 500 steps x 4 contact points, forward
-  c3   BASELINE configs[2]   same + physics-loss backward to the (shared) terrain and friction grids
-  c4   BASELINE configs[3/4] TerrainEncoder (4 cams 3x256x512 -> 256x256 BEV) + 1024 rollouts, end-to-end train step
+  c3   BASELINE configs[2]   1024 rollouts x 500 steps x 4 contact points, forward + physics loss + backward to terrain
+  c3f  the same batch, forward only (all six outputs written)
+  c4   BASELINE configs[3]   TerrainEncoder (4 cams 3x256x512 -> 256x256 BEV) + 1024 rollouts, end-to-end train step
+  c5   BASELINE configs[4]   8192 rollouts in total + encoder, sharded over the ranks (STRONG scaling: 8192 / N per GPU)
 
-Extra objects on the JSON line:
-  roofline      dominant hand-written kernel of the step: algorithmic bytes per launch (80 + 56 N bytes per
-                rollout-step forward, 160 + 120 N backward) / its average launch duration, measured live with HIP events
-                on the launch stream (monoforce_amd/_timing.py), against the 8 TB/s HBM peak.  `traffic` = HBM bytes
-                per launch from rocprofv3 PMC passes of this same command (profiles/hbm_traffic.json; null if absent).
-  cpu_baseline  the CPU oracle (oracle/dphysics_oracle.py, a torch-CPU port of the reference algorithm) timed on this
-                box's host cores on a bounded sample of the same workload.  Reported, not the target.
-  other_workloads  (default run, 1 GPU only) short runs of c2 and c3, same accounting, and `shoot`: trajectory shooting of
-                16384 sampled control sequences on the same terrain through the kernel's path-cost mode (rollout + path
-                costs + argmin, end to end; monoforce_amd/planner.py).
+The JSON line (rank 0) carries, besides the contract's keys:
+  roofline      dominant hand-written kernel of the headline step -- algorithmic bytes per launch (80 + 56 N
+                bytes per rollout-step forward, 160 + 120 N backward) / its average launch duration, measured live with HIP
+                events on the launch stream, against the 8 TB/s HBM peak -- plus `per_kernel` (forward AND backward
+                fractions) and `batch_sweep` (forward / backward kernel at 1024, 8192, 16384 rollouts; `first_B_at_40pct`).
+                `traffic` = HBM bytes per launch from rocprofv3 PMC passes of this command, read from
+                profiles/hbm_traffic.json (`traffic_source` says so: it is not re-measured inside the run).
+  forward_only  the c3f workload, same accounting (top level: both the forward-only and the forward+backward rate count)
+  cpu_baseline  the CPU oracle (oracle/dphysics_oracle.py, a torch-CPU port of the reference algorithm) timed on this box's
+                host cores on bounded samples: forward (no_grad), the autograd forward+backward of config 3, and config 1.
+  other_workloads  (default run) short runs of c1, c2, c4 and `shoot` (trajectory shooting of 16384 sampled control
+                sequences through the kernel's path-cost mode); N > 1: `strong_c3` (8192 rollouts in total) and c5.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -42,11 +54,14 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s HBM3E peak (~6.3 TB/s achievable)
 
 WORKLOADS = {
+    'c1': dict(B=1, T=200, N=4, backward=True, grid_res=0.1, desc='BASELINE configs[0]: 1 rollout x 200 steps, 128x128 terrain, forward + backward'),
     'c2': dict(B=256, T=500, N=4, backward=False, desc='BASELINE configs[1]: 256 rollouts x 500 steps, forward'),
-    'c3f': dict(B=1024, T=500, N=4, backward=False, desc='north_star shape: 1024 rollouts x 500 steps x 4 points, forward'),
-    'c3': dict(B=1024, T=500, N=4, backward=True, desc='BASELINE configs[2]: 1024 rollouts x 500 steps, forward + backward to terrain'),
+    'c3f': dict(B=1024, T=500, N=4, backward=False, desc='north_star shape: 1024 rollouts x 500 steps x 4 points, forward only'),
+    'c3': dict(B=1024, T=500, N=4, backward=True, desc='BASELINE configs[2]: 1024 rollouts x 500 steps, forward + physics loss + backward to terrain'),
     'c4': dict(B=1024, T=500, N=4, backward=True, encoder=True,
-               desc='BASELINE configs[3]/[4]: TerrainEncoder (4 cams 3x256x512 -> 256x256 BEV) + 1024 rollouts per GPU, end-to-end train step'),
+               desc='BASELINE configs[3]: TerrainEncoder (4 cams 3x256x512 -> 256x256 BEV) + 1024 rollouts per GPU, end-to-end train step'),
+    'c5': dict(B=8192, T=500, N=4, backward=True, encoder=True, strong=True,
+               desc='BASELINE configs[4]: 8192 rollouts in total + encoder (one 4-camera sample per GPU), data-parallel with RCCL gradient all-reduce'),
 }
 
 
@@ -60,7 +75,8 @@ def bwd_bytes_per_rollout_step(N):
     return 160 + 120 * N
 
 
-def build_problem(B, T, N, device, integ, seed=0):
+def build_problem(B, T, N, device, integ, seed=0, grid_res=0.05, terrain_seed=0):
+    """Synthetic inputs: terrain / friction from `terrain_seed`, controls from `seed`."""
     from monoforce_amd import synthetic as syn
     from monoforce_amd.dphys_config import DPhysConfig
     from monoforce_amd.dphysics import DPhysics
@@ -68,35 +84,76 @@ def build_problem(B, T, N, device, integ, seed=0):
         pts, masks = syn.robot_points_4()
     else:
         pts, masks = syn.robot_points_box(N, seed=1, n_tracks=2)
-    cfg = DPhysConfig(robot='tradr', grid_res=0.05, robot_points=pts, driving_parts=masks)
+    cfg = DPhysConfig(robot='tradr', grid_res=grid_res, robot_points=pts, driving_parts=masks)
     cfg.use_odeint = (integ == 1)
-    z = syn.bump_terrain(syn.bump_params(seed), 6.4, 0.05)
-    mu = syn.wave_friction(6.4, 0.05)
+    z = syn.bump_terrain(syn.bump_params(terrain_seed), 6.4, grid_res)
+    mu = syn.wave_friction(6.4, grid_res)
     ctrl = syn.const_controls(B, T, seed=seed)
     dp = DPhysics(cfg, device=device) if device is not None else None
     return cfg, dp, pts, masks, z, mu, ctrl
 
 
-def cpu_baseline(N, integ, T, budget_s=20.0):
-    """Time the CPU oracle on a bounded sample (forward, no_grad), host threads as torch sees them."""
+def _oracle_spec(cfg, pts, masks, integ, grid_res):
     from oracle import dphysics_oracle as orc      # checker / baseline only -- never on the product path
+    return orc.RolloutSpec(points=torch.as_tensor(pts), driving_parts=[torch.as_tensor(m) for m in masks],
+                           robot_size_y=float(cfg.robot_size[1]), mass=cfg.robot_mass, grid_res=grid_res, d_max=6.4,
+                           integrator=integ)
+
+
+def _time_cpu(fn, budget_s, max_runs=12):
+    times, t_start = [], time.perf_counter()
+    while len(times) < 2 or (time.perf_counter() - t_start < budget_s and len(times) < max_runs):
+        t0 = time.perf_counter()
+        fn()
+        times.append(time.perf_counter() - t0)
+    return float(np.median(times[1:])), len(times) - 1
+
+
+def cpu_baseline(N, integ, T, budget_s=12.0):
+    """Time the CPU oracle on bounded samples, host threads as torch sees them: the forward (no_grad) at B=256, the autograd
+    forward + backward of config 3 at B=128, and config 1 (one rollout, 200 steps, 128x128)."""
+    from oracle import dphysics_oracle as orc      # checker / baseline only -- never on the product path
+    from monoforce_amd import synthetic as syn
+    cores = torch.get_num_threads()
+    legs = {}
+    # forward, no_grad (SURVEY 8d: C2)
     Bs = 256
     cfg, _, pts, masks, z, mu, ctrl = build_problem(Bs, T, N, None, integ, seed=0)
-    spec = orc.RolloutSpec(points=torch.as_tensor(pts), driving_parts=[torch.as_tensor(m) for m in masks],
-                           robot_size_y=float(cfg.robot_size[1]), mass=cfg.robot_mass, grid_res=0.05, d_max=6.4,
-                           integrator=integ)
+    spec = _oracle_spec(cfg, pts, masks, integ, 0.05)
     zb, mb = z.unsqueeze(0).expand(Bs, -1, -1), mu.unsqueeze(0).expand(Bs, -1, -1)
-    times = []
-    t_start = time.perf_counter()
-    with torch.no_grad():
-        while len(times) < 2 or (time.perf_counter() - t_start < budget_s and len(times) < 12):
-            t0 = time.perf_counter()
+
+    def fwd():
+        with torch.no_grad():
             orc.rollout(spec, zb, ctrl, friction=mb)
-            times.append(time.perf_counter() - t0)
-    best = float(np.median(times[1:])) if len(times) > 1 else times[0]
-    return dict(value=Bs * T / best, unit='rollout-steps/s', cores=torch.get_num_threads(), kind='port',
+    t, n = _time_cpu(fwd, budget_s)
+    head = dict(value=Bs * T / t, unit='rollout-steps/s', cores=cores, kind='port',
                 sample=f'oracle/dphysics_oracle.py (torch-CPU port), B={Bs} x T={T} x N={N}, 256x256 shared map, forward '
-                       f'no_grad, median of {max(len(times) - 1, 1)} runs after 1 warm-up; os.cpu_count()={os.cpu_count()}')
+                       f'no_grad, median of {n} runs after 1 warm-up; os.cpu_count()={os.cpu_count()}')
+    # forward + autograd backward to the terrain (SURVEY 8d: C3), loss on every 10th pose like physics_loss
+    Ba = 128
+    ctrl_a = syn.const_controls(Ba, T, seed=0)
+
+    def fwd_bwd():
+        zl = z.clone().requires_grad_(True)
+        ml = mu.clone().requires_grad_(True)
+        (Xs, _, _, _), _ = orc.rollout(spec, zl.unsqueeze(0).expand(Ba, -1, -1), ctrl_a, friction=ml.unsqueeze(0).expand(Ba, -1, -1))
+        (Xs[:, 9::10] ** 2).mean().backward()
+    t, n = _time_cpu(fwd_bwd, budget_s, max_runs=6)
+    legs['c3_autograd'] = dict(value=Ba * T / t, unit='rollout-steps/s', cores=cores, kind='port',
+                               sample=f'B={Ba} x T={T} x N={N}, 256x256 shared map, forward + torch autograd backward to '
+                                      f'terrain and friction, median of {n} runs after 1 warm-up')
+    # config 1: ONE rollout, 200 steps, 128x128 map (the reference's own CPU-runnable case)
+    cfg1, _, pts1, masks1, z1, mu1, ctrl1 = build_problem(1, 200, N, None, integ, seed=0, grid_res=0.1)
+    spec1 = _oracle_spec(cfg1, pts1, masks1, integ, 0.1)
+
+    def c1():
+        with torch.no_grad():
+            orc.rollout(spec1, z1.unsqueeze(0), ctrl1, friction=mu1.unsqueeze(0))
+    t, n = _time_cpu(c1, 4.0, max_runs=8)
+    legs['c1_forward'] = dict(value=200 / t, unit='rollout-steps/s', cores=cores, kind='port',
+                              sample=f'B=1 x T=200 x N={N}, 128x128 map (res 0.1), forward no_grad, median of {n} runs')
+    head['legs'] = legs
+    return head
 
 
 class Runner:
@@ -111,6 +168,7 @@ class Runner:
         torch.cuda.set_device(local_rank)
         self.dev = torch.device('cuda', local_rank)
         self.backend = os.environ.get('MF_BENCH_BACKEND', 'nccl')      # "nccl" is RCCL on ROCm
+        self.dist_world = 1
         if self.world > 1:
             import torch.distributed as dist
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -118,7 +176,7 @@ class Runner:
                 dist.init_process_group('nccl', device_id=self.dev)
             else:
                 dist.init_process_group(self.backend)
-        assert self.world == args.gpus or self.world == 1, f'--gpus {args.gpus} but WORLD_SIZE={self.world}'
+            self.dist_world = dist.get_world_size()        # what the collective library itself sees
         traffic_file = os.path.join(REPO, 'profiles', 'hbm_traffic.json')
         self.traffic = json.load(open(traffic_file)) if os.path.exists(traffic_file) else {}
 
@@ -128,18 +186,32 @@ class Runner:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run(self, name, steps, warmup, with_sweep=False):
+    def max_over_ranks(self, v):
+        if self.world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([v], device=self.dev if self.backend == 'nccl' else 'cpu', dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            v = float(tt.item())
+        return v
+
+    def run(self, name, steps, warmup, batch=0):
         from monoforce_amd import _timing
         args, dev, world, rank = self.args, self.dev, self.world, self.rank
         wl = dict(WORKLOADS[name])
-        if args.batch:
-            wl['B'] = args.batch
+        if batch:
+            wl['B'] = batch
         if args.points:
             wl['N'] = args.points
-        B, T, N = wl['B'], wl['T'], wl['N']
-        cfg, dp, pts, masks, z, mu, ctrl = build_problem(B, T, N, dev, args.integrator, seed=rank)
+        strong = bool(wl.get('strong'))
+        B_total = wl['B'] if strong else wl['B'] * world
+        B = wl['B'] // world if strong else wl['B']           # rollouts of THIS rank
+        assert B >= 1 and (not strong or B * world == wl['B']), f'{wl["B"]} rollouts do not split over {world} ranks'
+        T, N = wl['T'], wl['N']
+        res = wl.get('grid_res', 0.05)
+        # ONE terrain / friction pair, the same on every rank (terrain_seed 0); every rank rolls out its OWN controls (seed = rank)
+        cfg, dp, pts, masks, z, mu, ctrl = build_problem(B, T, N, dev, args.integrator, seed=rank, grid_res=res, terrain_seed=0)
         dp.block = args.block
-        zd = z.to(dev).unsqueeze(0)       # ONE terrain shared by the rollouts ([1,H,W] map + [B,T,2] controls)
+        zd = z.to(dev).unsqueeze(0)       # [1,H,W] map shared by the rollouts + [B,T,2] controls
         md = mu.to(dev).unsqueeze(0)
         cd = ctrl.to(dev)
         if wl.get('encoder'):
@@ -148,12 +220,12 @@ class Runner:
             torch.manual_seed(0)        # identical initial weights on every rank (DDP convention)
             gc = dict(xbound=[-6.4, 6.4, 0.05], ybound=[-6.4, 6.4, 0.05], zbound=[-3.2, 3.2, 6.4], dbound=[0.6, 6.4, 0.1])
             enc = LiftSplatShoot(gc, dict(final_dim=(256, 512))).to(dev).train()
-            ebatch = synthetic_encoder_batch(enc, dp, n_rollouts=B, device=dev, seed=rank)
+            ebatch = synthetic_encoder_batch(enc, dp, n_rollouts=B, device=dev, seed=rank)    # the encoder batch is sharded too
             estep = EncoderTrainStep(enc, dp, lr=1e-4)
         elif wl['backward']:
             from monoforce_amd.train import TerrainFitProblem
             from monoforce_amd import synthetic as syn
-            z_true = syn.bump_terrain(syn.bump_params(100), 6.4, 0.05).to(dev)       # GT trajectories come from another terrain
+            z_true = syn.bump_terrain(syn.bump_params(100), 6.4, res).to(dev)       # GT trajectories come from another terrain
             prob = TerrainFitProblem(dp, z_true, mu.to(dev), cd)
             zleaf = z.to(dev).clone().requires_grad_(True)
             mleaf = mu.to(dev).clone().requires_grad_(True)
@@ -176,11 +248,7 @@ class Runner:
         self.barrier()
         elapsed = time.perf_counter() - t0
         kern = {k: float(np.mean(v)) for k, v in _timing.stop().items()}       # average launch duration per kernel, ms
-        if world > 1:
-            import torch.distributed as dist
-            tt = torch.tensor([elapsed], device=dev if self.backend == 'nccl' else 'cpu', dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
+        elapsed = self.max_over_ranks(elapsed)
 
         P4 = 4 * 59 * 16 * 32                                  # frustum points per sample at the config-4 shapes
         alg = {'rollout_fwd_kernel': fwd_bytes_per_rollout_step(N) * B * T, 'rollout_bwd_kernel': bwd_bytes_per_rollout_step(N) * B * T,
@@ -197,35 +265,59 @@ class Runner:
         achieved = per_kernel[dom]['GB/s']
         mode = 'encoder train step (fwd+bwd+Adam)' if wl.get('encoder') else 'forward+backward' if wl['backward'] else 'forward'
         integ = 'odeint-euler (reference default)' if args.integrator == 1 else 'dynamics()'
-        res = {
-            'value': B * T * world * steps / elapsed, 'steps': steps, 'warmup': warmup, 'ms_per_step': elapsed / steps * 1e3,
-            'config': {'workload': f'{name}: B={B}/GPU x T={T} x N={N} contact points, 256x256 grid (res 0.05 m), one shared '
-                                   f'terrain+friction map, integrator={integ}, {mode}; {wl["desc"]}',
-                       'rollouts_per_gpu': B, 'horizon': T, 'contact_points': N, 'grid': [256, 256],
+        H = int(round(12.8 / res))
+        traffic = self.traffic.get(name, {}).get(dom)
+        out = {
+            'value': B_total * T * steps / elapsed, 'steps': steps, 'warmup': warmup, 'ms_per_step': elapsed / steps * 1e3,
+            'scaling': 'strong' if strong else 'weak',
+            'config': {'workload': f'{name}: B={B}/GPU x T={T} x N={N} contact points, {H}x{H} grid (res {res} m), one shared '
+                                   f'terrain+friction map (the same on every rank), integrator={integ}, {mode}; {wl["desc"]}',
+                       'rollouts_per_gpu': B, 'rollouts_total': B_total, 'horizon': T, 'contact_points': N, 'grid': [H, H],
                        'parallelism': f'rollout-sharded x{world}'},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
-                         'traffic': self.traffic.get(name, {}).get(dom), 'kernel': dom, 'kernel_ms': kern[dom],
+                         'traffic': traffic,
+                         'traffic_source': 'profiles/hbm_traffic.json (rocprofv3 PMC passes of this command, static -- not re-measured in this run)' if traffic else None,
+                         'kernel': dom, 'kernel_ms': kern[dom],
                          'algorithmic_bytes_per_launch': alg[dom], 'bytes_per_rollout_step': alg[dom] // (B * T),
                          'per_kernel': per_kernel},
         }
-        if with_sweep and not wl['backward']:
-            sweep = {}
-            for Bs in (256, 1024, 4096, 8192, 16384, 32768, 65536):
-                _, dps, _, _, _, _, cs = build_problem(Bs, T, N, dev, args.integrator, seed=0)
-                cs = cs.to(dev)
-                with torch.no_grad():
-                    dps(zd, cs, friction=md); dps(zd, cs, friction=md)
-                    _timing.start()
-                    for _ in range(3):
-                        dps(zd, cs, friction=md)
-                    ms_ = float(np.mean(_timing.stop()['rollout_fwd_kernel']))
-                gbs = fwd_bytes_per_rollout_step(N) * Bs * T / (ms_ * 1e-3) / 1e9
-                sweep[str(Bs)] = {'kernel_ms': ms_, 'rollout_steps_per_s': Bs * T / (ms_ * 1e-3), 'GB/s': gbs, 'frac': gbs / HBM_PEAK_GBS}
-                del dps, cs
-            res['batch_sweep'] = sweep
+        del dp
+        return out, (N, T)
+
+    def batch_sweep(self, N, T, batches=(1024, 8192, 16384)):
+        """Forward and backward rollout kernels at a few batch sizes (kernel time from HIP events; not part of `value`)."""
+        from monoforce_amd import _timing
+        from monoforce_amd.train import TerrainFitProblem
+        from monoforce_amd import synthetic as syn
+        dev = self.dev
+        sweep = {}
+        for Bs in batches:
+            _, dps, _, _, z, mu, cs = build_problem(Bs, T, N, dev, self.args.integrator, seed=0)
+            cs = cs.to(dev)
+            prob = TerrainFitProblem(dps, syn.bump_terrain(syn.bump_params(100), 6.4, 0.05).to(dev), mu.to(dev), cs)
+            zl, ml = z.to(dev).clone().requires_grad_(True), mu.to(dev).clone().requires_grad_(True)
+            zd, md = z.to(dev).unsqueeze(0), mu.to(dev).unsqueeze(0)
+            for _ in range(2):
+                prob.step(zl, ml)
+            _timing.start()
+            for _ in range(3):
+                prob.step(zl, ml)
+            k = _timing.stop()
+            with torch.no_grad():       # the plain forward (all six outputs, no saved rows for a backward)
+                dps(zd, cs, friction=md)
+                _timing.start()
+                for _ in range(3):
+                    dps(zd, cs, friction=md)
+                kf = _timing.stop()
+            f_ms, b_ms = float(np.mean(kf['rollout_fwd_kernel'])), float(np.mean(k['rollout_bwd_kernel']))
+            fg = fwd_bytes_per_rollout_step(N) * Bs * T / (f_ms * 1e-3) / 1e9
+            bg = bwd_bytes_per_rollout_step(N) * Bs * T / (b_ms * 1e-3) / 1e9
+            sweep[str(Bs)] = {'fwd_ms': f_ms, 'fwd_frac': fg / HBM_PEAK_GBS, 'fwd_rollout_steps_per_s': Bs * T / (f_ms * 1e-3),
+                              'bwd_ms': b_ms, 'bwd_frac': bg / HBM_PEAK_GBS}
+            del dps, prob, cs, zl, ml
             torch.cuda.empty_cache()      # return the sweep's multi-GB blocks now, not inside a later workload's timed region
-            torch.cuda.synchronize(dev)
-        return res, (N, T)
+        first = {leg: next((int(b) for b in sweep if sweep[b][leg + '_frac'] >= 0.4), None) for leg in ('fwd', 'bwd')}
+        return {'batches': sweep, 'first_B_at_40pct': first}
 
 
 def shoot_workload(r, T, N, integ, B=16384, iters=8):
@@ -243,7 +335,7 @@ def shoot_workload(r, T, N, integ, B=16384, iters=8):
     _timing.start()
     t0 = time.perf_counter()
     for _ in range(iters):
-        out = sh.shoot(zd, friction=md, controls=c)        # int(argmin) inside synchronises every iteration, like the node
+        sh.shoot(zd, friction=md, controls=c)        # int(argmin) inside synchronises every iteration, like the node
     torch.cuda.synchronize(dev)
     ms = (time.perf_counter() - t0) / iters * 1e3
     kms = float(np.mean(_timing.stop()['rollout_fwd_kernel']))
@@ -253,37 +345,81 @@ def shoot_workload(r, T, N, integ, B=16384, iters=8):
                                                   'GB/s': (8 + 16 + 32 * N) * B * T / (kms * 1e-3) / 1e9}}}
 
 
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def spawn_ranks(n):
+    """`--gpus n` without a launcher: re-execute this script under torch.distributed.run with n ranks on this node."""
+    if not os.environ.get('MF_BENCH_SINGLE_DEVICE'):
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f'bench.py: --gpus {n} but only {have} GPU(s) are visible; refusing to run fewer ranks than asked for', file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # RCCL / IPC across processes needs dmabuf IPC on this driver
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--workload', default='c3f', choices=sorted(WORKLOADS))
-    ap.add_argument('--batch', type=int, default=0, help='override rollouts per GPU')
+    ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
+    ap.add_argument('--batch', type=int, default=0, help='override rollouts per GPU (total for c5)')
     ap.add_argument('--points', type=int, default=0, help='override contact points')
     ap.add_argument('--integrator', type=int, default=1, help='1 = odeint-euler (reference default), 0 = dynamics()')
     ap.add_argument('--block', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-others', action='store_true', help='skip the short c2 / c3 side runs of the default command')
-    ap.add_argument('--sweep', action='store_true', help='also report a forward batch sweep (not part of the timed value)')
+    ap.add_argument('--no-others', action='store_true', help='headline workload only (no forward_only / sweep / side workloads)')
     args = ap.parse_args()
 
+    world_env = os.environ.get('WORLD_SIZE')
+    if args.gpus > 1 and world_env is None:
+        sys.exit(spawn_ranks(args.gpus))
+    if int(world_env or '1') != args.gpus:
+        print(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world_env}: refusing to run a different number of ranks', file=sys.stderr)
+        sys.exit(2)
+
     r = Runner(args)
-    res, (N, T) = r.run(args.workload, args.steps, args.warmup, with_sweep=args.sweep)
-    others = {}
-    if args.workload == 'c3f' and r.world == 1 and not args.no_others and not args.batch and not args.points:
-        for name in ('c2', 'c3'):
-            o, _ = r.run(name, max(args.steps // 3, 5), 3)
-            others[name] = {'value': o['value'], 'unit': 'rollout-steps/s', 'ms_per_step': o['ms_per_step'],
-                            'workload': o['config']['workload'], 'per_kernel': o['roofline']['per_kernel']}
-        others['shoot'] = shoot_workload(r, T, N, args.integrator)
+    if r.world > 1 and r.dist_world != args.gpus:
+        print(f'bench.py: the process group has {r.dist_world} ranks, --gpus {args.gpus}', file=sys.stderr)
+        sys.exit(2)
+    res, (N, T) = r.run(args.workload, args.steps, args.warmup, batch=args.batch)
+    extras, others = {}, {}
+    full = args.workload == 'c3' and not args.no_others and not args.batch and not args.points
+    if full:
+        short = max(args.steps // 3, 5)
+        f, _ = r.run('c3f', args.steps, args.warmup)
+        extras['forward_only'] = {'value': f['value'], 'unit': 'rollout-steps/s', 'ms_per_step': f['ms_per_step'],
+                                  'workload': f['config']['workload'], 'roofline': {k: f['roofline'][k] for k in ('achieved', 'frac', 'kernel', 'kernel_ms', 'traffic', 'traffic_source')}}
+        res['roofline']['per_kernel']['rollout_fwd_kernel_all_outputs'] = f['roofline']['per_kernel']['rollout_fwd_kernel']
+
+        def brief(o):
+            return {'value': o['value'], 'unit': 'rollout-steps/s', 'ms_per_step': o['ms_per_step'], 'scaling': o['scaling'],
+                    'workload': o['config']['workload'], 'per_kernel': o['roofline']['per_kernel']}
+        if r.world == 1:
+            res['roofline']['batch_sweep'] = r.batch_sweep(N, T)
+            for name in ('c1', 'c2'):
+                others[name] = brief(r.run(name, short, 3)[0])
+            others['shoot'] = shoot_workload(r, T, N, args.integrator)
+            others['c4'] = brief(r.run('c4', 5, 4)[0])
+        else:
+            others['strong_c3'] = brief(r.run('c3', short, 3, batch=max(8192 // r.world, 1))[0])
+            others['strong_c3']['scaling'] = 'strong (8192 rollouts in total)'
+            others['c5'] = brief(r.run('c5', 5, 4)[0])
     if r.rank == 0:
         out = {'metric': 'rollout-steps/sec (batch x horizon) on 256x256 terrain', 'value': res['value'], 'unit': 'rollout-steps/s',
-               'n_gpus': r.world, 'steps': res['steps'], 'warmup': res['warmup'], 'ms_per_step': res['ms_per_step'],
-               'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+               'n_gpus': r.world, 'world_size': r.dist_world, 'backend': ('rccl' if r.backend == 'nccl' else r.backend) if r.world > 1 else None,
+               'steps': res['steps'], 'warmup': res['warmup'], 'ms_per_step': res['ms_per_step'],
+               'higher_is_better': True, 'scaling': res['scaling'], 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                'config': res['config'], 'roofline': res['roofline']}
-        if 'batch_sweep' in res:
-            out['batch_sweep'] = res['batch_sweep']
+        out.update(extras)
         if others:
             out['other_workloads'] = others
         if not args.no_cpu_baseline:

@@ -108,7 +108,8 @@ class GradBuckets:
     rather than many small ones.
 
     `zero()` replaces `optimizer.zero_grad()`: it drops the gradients (`None`), so autograd hands each new gradient over
-    without an accumulation kernel.  Parameters that receive no gradient in a step are exchanged as zeros.
+    without an accumulation kernel.  Parameters that receive no gradient in a step are exchanged as zeros and keep
+    `grad = None`.
     """
 
     def __init__(self, params, bucket_mb=32.0, average=True):
@@ -147,9 +148,13 @@ class GradBuckets:
     def _launch(self, b):
         b['launched'] = True
         have = [(v, p.grad) for v, p in zip(b['views'], b['params']) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+        # parameters the forward did not use (the same ones on every rank: same model, same code path) are exchanged as zeros
+        # and keep `grad = None` afterwards, like in the reference, so the optimizer skips them (Adam's weight decay would
+        # otherwise move them on a zero gradient)
+        b['got'] = [p.grad is not None for p in b['params']]
         for v, p in zip(b['views'], b['params']):
             if p.grad is None:
-                v.zero_()                                   # no gradient this step: contributes zeros
+                v.zero_()
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])      # one multi-tensor pack
         if world() > 1:
@@ -177,8 +182,8 @@ class GradBuckets:
                 b['work'].wait()
             if self.average and world() > 1:
                 b['buf'].div_(world())
-            for v, p in zip(b['views'], b['params']):
-                p.grad = v
+            for v, p, got in zip(b['views'], b['params'], b['got']):
+                p.grad = v if got else None
 
     def remove(self):
         for h in self._hooks:

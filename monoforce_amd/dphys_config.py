@@ -69,7 +69,14 @@ def find_mesh(robot):
 def get_points_from_robot_mesh(robot, voxel_size=0.1):
     """Body points of `robot` (dphys_config.py:8-35), from its mesh if one is found, else the stand-in body."""
     path = find_mesh(robot)
-    return points_from_obj(path, voxel_size) if path else standin_points(robot)
+    if path:
+        return points_from_obj(path, voxel_size)
+    import warnings
+    warnings.warn(f"no mesh '{_robot_family(robot)}.obj' found (searched $MONOFORCE_MESH_DIR and monoforce_amd/config/meshes): "
+                  f"DPhysConfig('{robot}') simulates a box-shaped STAND-IN body -- different point count, inertia and driving "
+                  'masks than the reference robot.  Point MONOFORCE_MESH_DIR at the reference\'s config/meshes, or pass '
+                  'robot_points= / driving_parts=.', stacklevel=3)
+    return standin_points(robot)
 
 
 def robot_geometry(robot, x_points=None):

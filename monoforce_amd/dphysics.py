@@ -187,7 +187,9 @@ class _RolloutFn(torch.autograd.Function):
         ctx.set_materialize_grads(False)
         if want_grad:
             ctx.mod, ctx.desc, ctx.keep = mod, desc, keep
-            ctx.z_shape, ctx.mu_given = z.shape, mu is not None
+            ctx.z_shape, ctx.mu_shape, ctx.mu_given = z.shape, (mu.shape if mu is not None else None), mu is not None
+            ctx.z_expanded = z.stride(0) == 0 and z.shape[0] > 1
+            ctx.mu_expanded = mu is not None and mu.stride(0) == 0 and mu.shape[0] > 1
             ctx.joint_angles = joint_angles          # constants of the rollout (no gradient), kept for the backward
             # x0 now holds the snapped start position; a caller-visible buffer is copied, the module's own default is not
             ctx.save_for_backward(controls, x0 if x0_private else x0.clone(), xd0, R0, w0, ts, Xraw, Xds, Rs, Om)
@@ -260,14 +262,23 @@ class DPhysics(torch.nn.Module):
 
     def _make_desc(self, z, mu, controls):
         cfg = self.dphys_cfg
+        B = controls.shape[0]
+        assert z.dim() == 3, f'z_grid must be [B,H,W] (or [1,H,W] = one map shared by all rollouts), got {tuple(z.shape)}'
+        _, H, W = z.shape
+        for name, m in (('z_grid', z), ('friction', mu)):
+            if m is None:
+                continue
+            assert m.dim() == 3 and tuple(m.shape[-2:]) == (H, W), \
+                f'{name} shape {tuple(m.shape)} does not match the {H}x{W} height grid'
+            assert m.shape[0] in (1, B), f'{name} batch {m.shape[0]} is neither 1 (shared map) nor the {B} rollouts of controls'
         shared = _is_shared_map(z) and (mu is None or _is_shared_map(mu))
         if shared:
             zc = z[0].contiguous()
             muc = None if mu is None else mu[0].contiguous()
         else:
-            zc = z.contiguous()
-            muc = None if mu is None else mu.contiguous()
-        _, H, W = z.shape
+            # one map shared, the other per rollout: the kernels index both at b*H*W, so the shared one is expanded for real
+            zc = z.expand(B, H, W).contiguous()
+            muc = None if mu is None else mu.expand(B, H, W).contiguous()
         integ = _lib.MF_INTEG_ODEINT_EULER if cfg.use_odeint else _lib.MF_INTEG_DYNAMICS
         if cfg.integration_mode != 'euler':
             # the reference's 'rk4' is a degenerate formula on the custom loop and an adaptive-free torchdiffeq solver on

@@ -66,17 +66,32 @@ def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf):
         summed = maps.sum(1)                   # one reduction for both maps
         gz, gmu = summed[0], (summed[1] if want_gmu else None)
 
-    def to_input_shape(g, shape):
-        """Gradient of a map input.  A shared map ([1,H,W], or one [H,W] map expanded over the batch) gets ONE [H,W]
-        gradient; for the expanded case it is handed back as a stride-0 expand of g/B, which autograd's ExpandBackward
-        sums over the batch back to g (exact for power-of-two B) without materialising B copies."""
+    def to_input_shape(g, shape, expanded):
+        """Gradient of a map input in that input's own shape.  A per-rollout map given where the kernels ran shared maps
+        cannot happen (`_make_desc` expands); what can: a shared run ([H,W] gradient g) whose input was [1,H,W] -> g[None],
+        or ONE map expanded over the batch (stride 0) -> autograd's ExpandBackward sums whatever [B,H,W] gradient it is
+        handed, so it gets g/B as a stride-0 expand when B is a power of two (the division and the B-fold sum are then
+        exact), and otherwise g in row 0 and zeros elsewhere (exact for every B, costs the B x H x W buffer).  A per-rollout
+        run whose input was one shared map (the other map was per-rollout) gets the sum over the rollouts."""
         if g is None:
             return None
-        if g.dim() == 3:
-            return g
-        return g.unsqueeze(0) if shape[0] == 1 else (g / shape[0]).unsqueeze(0).expand(shape)
+        Bm = shape[0]
+        if g.dim() == 3:                         # per-rollout gradient [B,H,W]
+            if Bm == g.shape[0] and not expanded:
+                return g
+            gs_ = g.sum(0)                       # the input was ONE map ([1,H,W] or an expand of it)
+            if Bm == 1:
+                return gs_.unsqueeze(0)
+            g = gs_
+        if Bm == 1:
+            return g.unsqueeze(0)
+        if Bm & (Bm - 1) == 0:
+            return (g / Bm).unsqueeze(0).expand(shape)
+        full = torch.zeros(shape, dtype=g.dtype, device=g.device)
+        full[0] = g
+        return full
 
-    return (None, to_input_shape(gz, ctx.z_shape) if ctx.needs_input_grad[1] else None,
-            to_input_shape(gmu, ctx.z_shape), gcontrols if ctx.needs_input_grad[3] else None, gx0,
+    return (None, to_input_shape(gz, ctx.z_shape, ctx.z_expanded) if ctx.needs_input_grad[1] else None,
+            to_input_shape(gmu, ctx.mu_shape, ctx.mu_expanded), gcontrols if ctx.needs_input_grad[3] else None, gx0,
             gxd0 if ctx.needs_input_grad[5] else None, gR0 if ctx.needs_input_grad[6] else None,
             gw0 if ctx.needs_input_grad[7] else None, None, None)

@@ -31,7 +31,7 @@ class TerrainFitProblem:
         self.bucket = None
 
     def step(self, z, mu):
-        """One forward + backward: returns the loss; leaves d loss / d z, d mu (summed over ALL ranks' rollouts) in .grad."""
+        """One forward + backward: returns the loss averaged over ALL ranks' rollouts; leaves its gradient w.r.t. z, mu in .grad."""
         z.grad = None
         mu.grad = None
         states, _ = self.dp(z.unsqueeze(0), self.controls, friction=mu.unsqueeze(0))
@@ -39,9 +39,12 @@ class TerrainFitProblem:
         loss = loss_fn(states, self.states_gt, self.pred_ts, self.gt_ts,
                        nearest=self.nearest if self.fused_loss else self.nearest.long())
         loss.backward()
-        # the one exchange step of the backward: 2 x H x W floats over RCCL
-        self.bucket = mfdist.allreduce_sum_([z.grad, mu.grad], self.bucket)
-        return loss
+        # the one exchange step of the backward: 2 x H x W floats (+ the loss scalar) over RCCL.  Every rank's loss is the MEAN
+        # over its own rollouts (equal shares), so the mean over ranks is the gradient of the global-mean loss: the step does
+        # not depend on the number of GPUs.
+        lbuf = loss.detach().reshape(1).clone()
+        self.bucket = mfdist.allreduce_sum_([z.grad, mu.grad, lbuf], self.bucket, average=True)
+        return lbuf[0]
 
 
 class EncoderTrainStep:
