@@ -59,6 +59,13 @@ enum {
   MF_MATH_FAST = 1   /* hardware rcp/rsq/exp2 (1 ulp) + FMA: ~1.5x faster per step; same parity tolerances hold */
 };
 
+/* MfRolloutDesc.points_per_lane, besides 0 / 1 / 4: the component-parallel mapping -- a rollout over a 16-lane row, four lanes
+ * per contact point (lane = vector component / footprint cell).  float32 MF_MATH_FAST rigid bodies of <= 4 points, full or
+ * states-only outputs; with points_per_lane = 0 it is chosen by itself while the launch has at most one wave per SIMD
+ * (B <= 4096), where a step costs ~2x fewer instructions per wave than one point per lane.  Other configurations fall
+ * back to the automatic choice. */
+enum { MF_LANES_COMPONENT = 16 };
+
 /* Shapes and physical constants of one rollout launch.  Scalars are double here and are rounded ONCE to the
  * kernel's arithmetic type, like the Python floats of DPhysConfig are when they meet a tensor. */
 typedef struct MfRolloutDesc {
@@ -260,6 +267,21 @@ int mf_physics_loss_fwd_f32(const MfLossDesc* desc, const float* Xs, const float
 int mf_physics_loss_fwd_f64(const MfLossDesc* desc, const double* Xs, const double* Xgt, const double* gt_ts, const int32_t* nearest, double* partial, void* hip_stream);
 int mf_physics_loss_bwd_f32(const MfLossDesc* desc, const float* Xs, const float* Xgt, const float* gt_ts, const int32_t* nearest, const float* gloss, float* gXs, void* hip_stream);
 int mf_physics_loss_bwd_f64(const MfLossDesc* desc, const double* Xs, const double* Xgt, const double* gt_ts, const int32_t* nearest, const double* gloss, double* gXs, void* hip_stream);
+
+/* ---- estimate_heightmap (cloudproc.py:88-148): per-cell maximum height of a point cloud + measurement mask ------------
+ * points[n][3] float32 (rows with NaNs, points within r_min of the origin in xy, and points outside the open box
+ * (-d_max, d_max)^2 x (h_min, h_max) are dropped); x_bins[nx] / y_bins[ny] are the bin edges the reference builds with
+ * torch.arange(-d_max, d_max, grid_res) -- a point falls into bin torch.bucketize(x, bins) - 1; scratch = nx*ny int32;
+ * hm[2][nx][ny]: hm[0][ix][iy] = max z of the cell (0 where empty), hm[1][ix][iy] = 1.0 where measured (the reference's
+ * transposed output layout: first axis = x). */
+typedef struct MfHeightmapDesc {
+  int32_t n_points, nx, ny;
+  float d_max, h_min, h_max;
+  float r_min;   /* < 0: no inner radius filter */
+  float inv_res; /* 1 / grid_res: first guess of the bin (the edges decide) */
+} MfHeightmapDesc;
+int mf_estimate_heightmap_f32(const MfHeightmapDesc* desc, const float* points, const float* x_bins, const float* y_bins,
+                              int32_t* scratch, float* hm, void* hip_stream);
 
 /* Text of the calling thread's last error ("" if none). */
 const char* mf_last_error(void);

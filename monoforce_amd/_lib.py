@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libmonoforce_hip.so')
 MF_INTEG_DYNAMICS, MF_INTEG_ODEINT_EULER = 0, 1
 MF_LAYOUT_BATCH_MAJOR, MF_LAYOUT_TIME_MAJOR = 0, 1
 MF_MATH_EXACT, MF_MATH_FAST = 0, 1
+MF_LANES_COMPONENT = 16
 
 
 class MfRolloutDesc(C.Structure):
@@ -48,11 +49,16 @@ class MfSplatDesc(C.Structure):
                 ('off', C.c_float * 3), ('dx', C.c_float * 3), ('lift_D', C.c_int32), ('lift_hw', C.c_int32)]
 
 
+class MfHeightmapDesc(C.Structure):
+    _fields_ = [('n_points', C.c_int32), ('nx', C.c_int32), ('ny', C.c_int32), ('d_max', C.c_float), ('h_min', C.c_float),
+                ('h_max', C.c_float), ('r_min', C.c_float), ('inv_res', C.c_float)]
+
+
 # every symbol include/monoforce_hip.h declares; tests check the library exports all of them
 SYMBOLS = ['mf_rollout_force_stride', 'mf_rollout_fwd_f32', 'mf_rollout_fwd_f64', 'mf_rollout_default_state_f32', 'mf_rollout_default_state_f64', 'mf_rollout_bwd_f32', 'mf_rollout_bwd_f64', 'mf_bev_splat_workspace_bytes', 'mf_bev_splat_prepare', 'mf_bev_splat_prepare_cameras',
            'mf_bev_splat_fwd_f32', 'mf_bev_splat_fwd_f64', 'mf_bev_splat_bwd_f32', 'mf_bev_splat_bwd_f64',
            'mf_bev_lift_splat_fwd_f32', 'mf_bev_lift_splat_fwd_f64', 'mf_bev_lift_splat_bwd_f32', 'mf_bev_lift_splat_bwd_f64',
-           'mf_physics_loss_fwd_f32', 'mf_physics_loss_fwd_f64', 'mf_physics_loss_bwd_f32', 'mf_physics_loss_bwd_f64', 'mf_last_error', 'mf_version', 'mf_sizeof']
+           'mf_physics_loss_fwd_f32', 'mf_physics_loss_fwd_f64', 'mf_physics_loss_bwd_f32', 'mf_physics_loss_bwd_f64', 'mf_estimate_heightmap_f32', 'mf_last_error', 'mf_version', 'mf_sizeof']
 
 _lib = None
 _lock = threading.Lock()
@@ -76,7 +82,7 @@ def lib():
                 L.mf_version.restype = C.c_char_p
                 for name in SYMBOLS:
                     fn = getattr(L, name)   # AttributeError if the build is stale
-                    if name.startswith(('mf_rollout', 'mf_bev', 'mf_physics')):
+                    if name.startswith(('mf_rollout', 'mf_bev', 'mf_physics', 'mf_estimate')):
                         fn.restype = C.c_int
                 L.mf_bev_splat_workspace_bytes.restype = C.c_size_t
                 _lib = L

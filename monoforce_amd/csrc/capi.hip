@@ -17,5 +17,6 @@ extern "C" int mf_sizeof(const char* name) {
   if (!strcmp(name, "MfRolloutBwdBufs")) return (int)sizeof(MfRolloutBwdBufs);
   if (!strcmp(name, "MfSplatDesc")) return (int)sizeof(MfSplatDesc);
   if (!strcmp(name, "MfLossDesc")) return (int)sizeof(MfLossDesc);
+  if (!strcmp(name, "MfHeightmapDesc")) return (int)sizeof(MfHeightmapDesc);
   return -1;
 }

@@ -1,6 +1,6 @@
 // Backward rollout: host side of mf_rollout_bwd_* and the reference-order (exact) kernel instantiations.
 // Compiled with -ffp-contract=off; the FMA-contracted float32 kernels live in rollout_bwd_fast.hip.
-#include "rollout_bwd_kernel.h"
+#include "rollout_bwd_cp_kernel.h"
 
 namespace mf {
 
@@ -65,7 +65,9 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
     if (sizeof(S) == 4) return launch_rollout_bwd_joints_f32(*reinterpret_cast<const RolloutBwdArgs<float>*>(&a), mj, d->integrator, block, st);
     return launch_rollout_bwd_joints_f64(*reinterpret_cast<const RolloutBwdArgs<double>*>(&a), mj, d->integrator, block, st);
   }
-  const LaneMap m = choose_lane_map(d->B, d->N, d->points_per_lane);   // the forward's mapping (same rule, same descriptor)
+  if (sizeof(S) == 4 && use_component_parallel_bwd(d, p))   // few rollouts of a small body: a rollout over 16 lanes
+    return launch_rollout_bwd_cp_f32(*reinterpret_cast<const RolloutBwdArgs<float>*>(&a), d->integrator, st);
+  const LaneMap m = choose_lane_map(d->B, d->N, d->points_per_lane == MF_LANES_COMPONENT ? 0 : d->points_per_lane);
   if (sizeof(S) == 4 && d->math_mode == MF_MATH_FAST) {
     // accumulator carry-over between adjacent cells (rollout_bwd_kernel.h): ~55 more instructions per step, half the atomics --
     // a gain from ~3 waves per 4 CUs upwards (B = 4096 at N = 4: 1.00 -> 0.94 ms; B = 65536: 9.5 -> 5.5 ms), a loss below

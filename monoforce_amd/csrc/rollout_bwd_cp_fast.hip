@@ -1,0 +1,35 @@
+// Backward rollout, component-parallel lane mapping (rollout_bwd_cp_kernel.h): float32 fast-math instantiation and the
+// host-side choice between it and the one-point-per-lane kernels.
+#include "rollout_bwd_cp_kernel.h"
+
+namespace mf {
+
+// as the forward (rollout_fwd_cp_fast.hip): up to one wave per SIMD; MF_CP_BWD_MAX_WAVES overrides (0 disables)
+static long long cp_bwd_max_waves() {
+  static const long long v = getenv("MF_CP_BWD_MAX_WAVES") ? atoll(getenv("MF_CP_BWD_MAX_WAVES")) : 1024;
+  return v;
+}
+
+bool use_component_parallel_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p) {
+  if (d->math_mode != MF_MATH_FAST || d->N > 4 || p->joint_angles || d->integrator != MF_INTEG_ODEINT_EULER) return false;
+  if (d->points_per_lane != 0 && d->points_per_lane != MF_LANES_COMPONENT) return false;
+  const long long waves = ((long long)d->B + 3) / 4;
+  if (d->points_per_lane == 0 && waves > cp_bwd_max_waves()) return false;
+  // 32-bit byte offsets into the saved rows and the upstream gradients
+  const long long row = (long long)d->N * 3 > 9 ? (long long)d->N * 3 : 9;
+  if ((long long)d->T * d->B * row * 4 >= (1ll << 32)) return false;
+  return true;
+}
+
+int launch_rollout_bwd_cp_f32(const RolloutBwdArgs<float>& a, int integ, hipStream_t st) {
+  MF_REQUIRE(integ == MF_INTEG_ODEINT_EULER, MF_ERR_UNSUPPORTED, "rollout_bwd (component-parallel): default integrator only");
+  const int block = 64;
+  const long long threads = (long long)a.B * 16;
+  const unsigned grid = (unsigned)((threads + block - 1) / block);
+  hipLaunchKernelGGL((rollout_bwd_cp_kernel<MF_INTEG_ODEINT_EULER>), dim3(grid), dim3(block), 0, st, a);
+  hipError_t e = hipGetLastError();
+  MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("rollout_bwd (component-parallel) launch: ") + hipGetErrorString(e));
+  return MF_OK;
+}
+
+}  // namespace mf

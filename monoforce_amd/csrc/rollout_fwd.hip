@@ -1,6 +1,6 @@
 // Forward rollout: host side of mf_rollout_fwd_* and the reference-order (exact) kernel instantiations.
 // This TU is compiled with -ffp-contract=off; the FMA-contracted float32 kernels live in rollout_fwd_fast.hip.
-#include "rollout_fwd_kernel.h"
+#include "rollout_fwd_cp_kernel.h"
 
 namespace mf {
 
@@ -27,7 +27,7 @@ static int fill_args(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutA
              "rollout_fwd: per-rollout maps of 4 GiB or more in total (use a shared map or split the batch)");
   *block = d->block ? d->block : 64;
   MF_REQUIRE(*block == 64 || *block == 128 || *block == 256, MF_ERR_INVALID, "rollout_fwd: block must be 64, 128 or 256");
-  *m = choose_lane_map(d->B, d->N, d->points_per_lane);
+  *m = choose_lane_map(d->B, d->N, d->points_per_lane == MF_LANES_COMPONENT ? 0 : d->points_per_lane);
   const int fstride = d->force_stride ? d->force_stride : d->N;
   MF_REQUIRE(!p->Fs || fstride >= m->G * m->PPL, MF_ERR_INVALID,
              "rollout_fwd: force_stride too small -- allocate Fs/Ff with mf_rollout_force_stride(desc) point slots per row");
@@ -67,7 +67,7 @@ static int fill_args(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutA
 
 extern "C" int mf_rollout_force_stride(const MfRolloutDesc* d) {
   if (!d || d->B <= 0 || d->N <= 0 || d->N > 512) return -1;
-  mf::LaneMap m = mf::choose_lane_map(d->B, d->N, d->has_joints ? 0 : d->points_per_lane);
+  mf::LaneMap m = mf::choose_lane_map(d->B, d->N, (d->has_joints || d->points_per_lane == MF_LANES_COMPONENT) ? 0 : d->points_per_lane);
   if (d->has_joints && m.G <= 64) m = mf::choose_lane_map(d->B, d->N, 4);
   const int lanes = m.G * m.PPL;
   return lanes > d->N ? lanes : d->N;
@@ -122,6 +122,10 @@ extern "C" int mf_rollout_fwd_f32(const MfRolloutDesc* d, const MfRolloutFwdBufs
     return MF_ERR_UNSUPPORTED;
   }
   if (d->math_mode == MF_MATH_FAST) {
+    if (mf::use_component_parallel(d, p)) {   // few rollouts of a small body: a rollout over 16 lanes (rollout_fwd_cp_kernel.h)
+      const bool zmu = mf::use_interleaved_maps(d, p, &a, mf::LaneMap{16, 1}, (hipStream_t)s);
+      return mf::launch_rollout_fwd_cp_f32(a, d->integrator, forces, zmu, (hipStream_t)s);
+    }
     if (!forces && m.PPL == 4 && m.G < 64) m = mf::choose_lane_map(d->B, d->N, 1);
     // >= one wave per SIMD (1024) and a one-point-per-lane mapping within a wave: the split-store kernels (rollout_fwd_kernel.h)
     const bool split = m.PPL == 1 && m.G <= 64 && (long long)d->B * m.G >= 1024ll * 64;

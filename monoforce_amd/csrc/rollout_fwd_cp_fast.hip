@@ -1,0 +1,47 @@
+// Forward rollout, component-parallel lane mapping (rollout_fwd_cp_kernel.h): float32 fast-math instantiations and the
+// host-side choice between this mapping and the one-point-per-lane kernels.  Built with FMA contraction like the other
+// *_fast units.
+#include "rollout_fwd_cp_kernel.h"
+
+namespace mf {
+
+// Waves of a component-parallel launch up to which it beats the one-point-per-lane mapping: one wave per SIMD (1024 on the
+// 256 CUs).  Above, both mappings keep every SIMD busy and the 4x fewer lanes per rollout of the G = 4 kernels win.
+// MF_CP_MAX_WAVES overrides (tuning / A-B runs; 0 disables the mapping).
+static long long cp_max_waves() {
+  static const long long v = getenv("MF_CP_MAX_WAVES") ? atoll(getenv("MF_CP_MAX_WAVES")) : 1024;
+  return v;
+}
+
+bool use_component_parallel(const MfRolloutDesc* d, const MfRolloutFwdBufs* p) {
+  if (d->math_mode != MF_MATH_FAST || d->N > 4 || p->joint_angles || p->cost_rows) return false;
+  if (d->points_per_lane != 0 && d->points_per_lane != MF_LANES_COMPONENT) return false;   // an explicit other mapping
+  const long long waves = ((long long)d->B + 3) / 4;
+  if (d->points_per_lane == 0 && waves > cp_max_waves()) return false;
+  // 32-bit byte offsets into every output and into the controls
+  const long long fs = d->force_stride ? d->force_stride : d->N;
+  const long long row = fs * 3 > 9 ? fs * 3 : 9;
+  if ((long long)d->T * d->B * row * 4 >= (1ll << 32)) return false;
+  if (fs < 4) return false;   // quads of absent points write their (zero) slots
+  return true;
+}
+
+int launch_rollout_fwd_cp_f32(const RolloutArgs<float>& a, int integ, bool forces, bool zmu, hipStream_t st) {
+  const int block = 64;   // one wave = 4 rollouts per workgroup: B = 1024 puts one wave on each of the 256 CUs
+  const long long threads = (long long)a.B * 16;
+  const unsigned grid = (unsigned)((threads + block - 1) / block);
+#define MF_CP(INTEG_, FORCES_, ZMU_) hipLaunchKernelGGL((rollout_fwd_cp_kernel<INTEG_, FORCES_, ZMU_>), dim3(grid), dim3(block), 0, st, a)
+#define MF_CP_F(INTEG_)                                          \
+  do {                                                           \
+    if (forces) { if (zmu) MF_CP(INTEG_, true, true); else MF_CP(INTEG_, true, false); }    \
+    else        { if (zmu) MF_CP(INTEG_, false, true); else MF_CP(INTEG_, false, false); }  \
+  } while (0)
+  if (integ == MF_INTEG_DYNAMICS) MF_CP_F(MF_INTEG_DYNAMICS); else MF_CP_F(MF_INTEG_ODEINT_EULER);
+#undef MF_CP_F
+#undef MF_CP
+  hipError_t e = hipGetLastError();
+  MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("rollout_fwd (component-parallel) launch: ") + hipGetErrorString(e));
+  return MF_OK;
+}
+
+}  // namespace mf

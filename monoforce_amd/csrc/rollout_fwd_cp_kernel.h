@@ -1,0 +1,250 @@
+// Fused DPhysics rollout, forward pass, COMPONENT-PARALLEL lane mapping (see rollout_cp_common.h): float32 fast math, rigid
+// bodies of up to 4 contact points, the mapping for launches that leave most SIMDs without a wave (B <= ~4096 at N = 4).
+// Same physics, same outputs as rollout_fwd_kernel.h (dphysics.py:172-272, 385-455, 467-594 of the reference); sums run in a
+// different order (butterflies over lanes), so results agree with the other mappings to rounding, not bit for bit.
+#pragma once
+#include "rollout_cp_common.h"
+#include "rollout_fwd_kernel.h"
+
+namespace mf {
+
+// store / load through a wave-uniform base and a 32-bit BYTE offset (the host keeps every array of a CP launch below 4 GiB)
+__device__ __forceinline__ void st_nt(float* base, unsigned off, float v) {
+  __builtin_nontemporal_store(v, reinterpret_cast<float*>(reinterpret_cast<char*>(base) + (size_t)off));
+}
+__device__ __forceinline__ void st_nt3(float* base, unsigned off, float v0, float v1, float v2) {
+  typedef float f3v __attribute__((ext_vector_type(3)));
+  typedef f3v __attribute__((aligned(4))) f3u;
+  f3v v = {v0, v1, v2};
+  __builtin_nontemporal_store(v, reinterpret_cast<f3u*>(reinterpret_cast<char*>(base) + (size_t)off));
+}
+
+template <int INTEG, bool FORCES, bool ZMU>
+__global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<float> a) {
+  using namespace cp;
+  using M = Mth<float, true>;
+  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = (tid >> 4) + a.b0;      // one 16-lane row per rollout
+  if (b >= a.B) return;                  // whole rows leave together; DPP never crosses a row
+  const int p = (tid >> 2) & 3;          // quad = contact point
+  const int q = tid & 3;                 // lane of the quad: cell role q, component role cc
+  const int cc = q < 3 ? q : 2;
+  const float one = 1.0f, zero = 0.0f;
+  const int HW = a.H * a.W, last = HW - 1;
+  const bool has_mu = a.mu != nullptr;   // wave-uniform
+  const unsigned moff = a.map_shared ? 0u : (unsigned)b * (unsigned)HW;
+  const float* zmap = a.z;
+  const float* mumap = has_mu ? a.mu : a.z;
+
+  // ---- per-lane constants ----
+  const bool act = p < a.N;
+  const int pi = act ? p : 0;
+  const float P0 = a.points[pi * 3 + 0], P1 = a.points[pi * 3 + 1], P2 = a.points[pi * 3 + 2];
+  const int part = act ? a.part[pi] : -1;
+  // track speed of this point = tv_v * v + tv_w * w (dphysics.py:75-104, 242-246); 0 for non-driving points
+  const float tv_v = part < 0 ? zero : one;
+  const float tv_w = part < 0 ? zero : ((part & 1) ? a.half_ly : -a.half_ly);
+  const float I0 = a.Iinv[cc * 3 + 0], I1 = a.Iinv[cc * 3 + 1], I2 = a.Iinv[cc * 3 + 2];   // row cc of I^-1
+  const float grav_c = cc == 2 ? a.mg * a.inv_mass : zero;
+  const int cell_off = ((q & 1) ? a.H : 0) + ((q & 2) ? 1 : 0);     // c, f (+x neighbour: +H), l (+y: +1), fl
+  // weight of cell q = (q & 2 ? fx : 1 - fx) * (q & 1 ? fy : 1 - fy)   (dphysics.py:442-445: fx pairs with the +y neighbour)
+  const float wa_s = (q & 2) ? one : -one, wa_o = (q & 2) ? zero : one;
+  const float wb_s = (q & 1) ? one : -one, wb_o = (q & 1) ? zero : one;
+  const float n_mul = q < 2 ? -a.inv_res : zero, n_add = q < 2 ? zero : one;   // u = (-gx, -gy, 1)
+
+  // ---- state: component cc / row cc in this lane, replicated over the four quads ----
+  float x, xd, w, R0, R1, R2;
+  if (a.default_state) {   // the reference's default start (dphysics.py:554-559), written back for the caller / the backward
+    const float v0 = a.controls[(size_t)b * a.ctrl_sb + 0], w0 = a.controls[(size_t)b * a.ctrl_sb + 1];
+    x = zero; xd = cc == 0 ? v0 : zero; w = cc == 2 ? w0 : zero;
+    R0 = cc == 0 ? one : zero; R1 = cc == 1 ? one : zero; R2 = cc == 2 ? one : zero;
+    if (p == 0) {
+      float* oxd = const_cast<float*>(a.xd0); float* oR = const_cast<float*>(a.R0); float* ow = const_cast<float*>(a.w0);
+      a.x0[b * 3 + cc] = x; oxd[b * 3 + cc] = xd; ow[b * 3 + cc] = w;
+      oR[b * 9 + cc * 3 + 0] = R0; oR[b * 9 + cc * 3 + 1] = R1; oR[b * 9 + cc * 3 + 2] = R2;
+    }
+  } else {
+    x = a.x0[b * 3 + cc]; xd = a.xd0[b * 3 + cc]; w = a.w0[b * 3 + cc];
+    R0 = a.R0[b * 9 + cc * 3 + 0]; R1 = a.R0[b * 9 + cc * 3 + 1]; R2 = a.R0[b * 9 + cc * 3 + 2];
+  }
+
+  // footprint of the point under position component pc: this lane's cell index and weight
+  auto footprint = [&](float pc, int* idx, float* wq) {
+    const float lim = 262144.0f;
+    const float u = M::cell_coord(pc, a.d_max, a.res, a.inv_res);      // lanes 0, 1: ux, uy
+    const int ui = (int)M::clamp(u, -lim, lim);                         // trunc toward zero, like .long()
+    const float fr = u - (float)ui;
+    const int base = dppi<kB1>(ui) + __mul24(a.H, dppi<kB0>(ui));       // iy + H * ix
+    *idx = min(max(base + cell_off, 0), last);                          // the reference clamps the FLAT index (:432-435)
+    const float wa = fmaf(wa_s, dpp<kB0>(fr), wa_o), wb = fmaf(wb_s, dpp<kB1>(fr), wb_o);   // exact: 1 - f or f
+    *wq = wa * wb;
+  };
+
+  // start at the terrain height: x.z <- mean_i interp(z, (P R^T + x)_i)   (dphysics.py:567-571)
+  if (!a.skip_snap) {
+    const float pc = (P0 * R0 + P1 * R1 + P2 * R2) + x;
+    int idx; float wq;
+    footprint(pc, &idx, &wq);
+    const float zq = sum4(wq * ld32(zmap, moff + (unsigned)idx));
+    const float acc = sum_points(act ? zq : zero);
+    const float xz = acc / (float)a.N;
+    x = cc == 2 ? xz : x;
+    if (p == 0 && q == 2) a.x0[b * 3 + 2] = xz;
+  }
+
+  // ---- running output offsets (bytes) off wave-uniform bases ----
+  const unsigned row_stride = (a.layout == MF_LAYOUT_TIME_MAJOR) ? (unsigned)a.B : 1u;   // rows between consecutive t
+  const unsigned row0 = (a.layout == MF_LAYOUT_TIME_MAJOR) ? (unsigned)b : (unsigned)b * (unsigned)a.T;
+  // vec3 rows: quad 0 writes Xs, quad 1 Xds, quad 2 Omegas, quad 3 the unshifted positions (or Xs again when nobody wants them)
+  float* v3base = p == 0 ? a.Xs : p == 1 ? a.Xds : p == 2 ? a.Om : (a.Xraw ? a.Xraw : a.Xs);
+  const float sink_l = (p == 3 && a.Xraw) ? zero : a.sink;
+  const unsigned m_xd = p == 1 ? ~0u : 0u, m_w = p == 2 ? ~0u : 0u, m_x = ~(m_xd | m_w);
+  unsigned o3 = (row0 * 3u + (unsigned)cc) * 4u;
+  unsigned o9 = (row0 * 9u + (unsigned)cc * 3u) * 4u;
+  const unsigned frow = (unsigned)a.fstride * 3u;
+  unsigned of = (row0 * frow + (unsigned)p * 3u + (unsigned)cc) * 4u;
+  const unsigned d3 = row_stride * 12u, d9 = row_stride * 36u, df = row_stride * frow * 4u;
+
+  float oFs = zero, oFf = zero;   // forces of the pending output row (ODEINT: running impulses, dphysics.py:506-509)
+
+  auto emit_row = [&](unsigned adv) {
+    // the state registers ARE the pending row.  v3base differs per quad, so the store takes a per-lane 64-bit address.
+    const float vx = fmaf(R2, sink_l, x);           // Xs += Rs[..., :, 2] * m g / (k + 1e-6)   (dphysics.py:587-589)
+    const float v3 = mask_or(mask_or(mask_or(zero, vx, m_x), xd, m_xd), w, m_w);
+    __builtin_nontemporal_store(v3, reinterpret_cast<float*>(reinterpret_cast<char*>(v3base) + (size_t)o3));
+    st_nt3(a.Rs, o9, R0, R1, R2);                   // row cc of R: one 12-byte store (all quads, same address, same value)
+    if (FORCES) { st_nt(a.Fs, of, oFs); st_nt(a.Ff, of, oFf); }
+    const unsigned m = adv ? 0xFFFFFFFFu : 0u;
+    o3 += d3 & m; o9 += d9 & m; of += df & m;
+  };
+
+  const int n_steps = (INTEG == MF_INTEG_ODEINT_EULER) ? a.T - 1 : a.T;
+  const float* ctrl = a.controls + (size_t)b * a.ctrl_sb;
+  float cv = ctrl[0], cw = ctrl[1];
+  float h_ode = (INTEG == MF_INTEG_ODEINT_EULER && a.T > 1) ? a.ts[1] - a.ts[0] : zero;
+  // Everything of a step that depends on the pose (x, R) only: r = R P (component cc), p = r + x, this lane's footprint cell
+  // and weight, the gathers, the thrust direction.  The explicit scheme knows the NEXT pose as soon as a step starts
+  // (x' = x + h xd, R' = R + h [w]x R use the old xd, w), so its kernels compute the geometry of step n + 1 -- and issue its
+  // gathers -- while the contact chain of step n runs: two independent instruction streams in one basic block fill each
+  // other's dependency stalls, and a gather has a whole step to arrive.
+  struct Geo { float r, pc, wq, zc, mc, e; };
+  auto geometry = [&](float gx, float g0, float g1, float g2) {
+    Geo g;
+    g.r = P0 * g0 + P1 * g1 + P2 * g2;               // (:200)
+    g.pc = g.r + gx;
+    int idx;
+    footprint(g.pc, &idx, &g.wq);
+    if constexpr (ZMU) {
+      const float2 zm = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(a.zmu) + (size_t)((unsigned)idx * 8u));
+      g.zc = zm.x; g.mc = zm.y;
+    } else {
+      g.zc = ld32(zmap, moff + (unsigned)idx);
+      g.mc = ld32(mumap, moff + (unsigned)idx);       // aliases z without a friction map; selected after the blend
+    }
+    g.e = g0 * M::inv_len(dot3(g0, g0));              // thrust direction = normalized first column of R (:237)
+    return g;
+  };
+  // contact model + wrench of one step from its geometry and the state's velocities: (xdd, wd, F_spring, F_friction)
+  auto contact = [&](const Geo& g, float vxd, float vw, float tv, float* xdd, float* wd, float* oFr, float* oFf) {
+    const float r1 = dpp<kRot1>(g.r), r2 = dpp<kRot2>(g.r);
+    const float vp = vxd + (dpp<kRot1>(vw) * r2 - dpp<kRot2>(vw) * r1);   // v_p = xd + w x r   (:204)
+    const float zq = sum4(g.wq * g.zc);                               // height under the point (:211)
+    const float mub = sum4(g.wq * (has_mu ? g.mc : one));             // friction (:216); no map = a map of ones (:562)
+    const float dz = g.zc - dpp<kB0>(g.zc);                           // lane 1: z_f - z_c, lane 2: z_l - z_c
+    const float u = fmaf(dpp<kN12>(dz), n_mul, n_add);                // (-gx, -gy, 1)
+    const float nrm = u * M::inv_len(dot3(u, u));
+    const float dh = dpp<kB2>(g.pc) - zq;                             // soft contact + spring-damper along the normal (:220-230)
+    float cj = M::sigmoid_m10(dh);
+    cj = act ? cj : zero;
+    const float csum = sum_points(cj);                                // n_contact_pts (:231)
+    const float cjn = cj * M::div(one, csum);
+    const float vn = dot3(vp, nrm);
+    const float A = a.k * dh + a.damp * vn;
+    const float Fr = M::clamp(-(A * nrm) * cjn, -a.mg, a.mg);         // (:232-233)
+    const float Nn = M::sqrt(dot3(Fr, Fr));                           // (:238)
+    const float s = mub * (tv * g.e - vp);                            // slip (:247)
+    const float sn = dot3(s, nrm);
+    const float Ff = M::clamp(Nn * (s - sn * nrm), -a.mg, a.mg);      // (:248-251); absent points: cj = 0 -> Fr = Nn = Ff = 0
+    const float f = Fr + Ff;
+    const float tau = r1 * dpp<kRot2>(f) - r2 * dpp<kRot1>(f);        // r x (Fs + Ff)   (:255)
+    const float Fsum = sum_points(f), Tsum = sum_points(tau);
+    // omega_d = clamp(I^-1 tau)   (:256-257); xdd = (m g ghat + sum F) / m   (:264-266)
+    *wd = M::clamp(I0 * dpp<kB0>(Tsum) + I1 * dpp<kB1>(Tsum) + I2 * dpp<kB2>(Tsum), -a.omega_max, a.omega_max);
+    *xdd = Fsum * a.inv_mass - grav_c;
+    *oFr = Fr; *oFf = Ff;
+  };
+
+  Geo geo;
+  if (INTEG == MF_INTEG_ODEINT_EULER && n_steps > 0) geo = geometry(x, R0, R1, R2);
+  __builtin_amdgcn_s_waitcnt(0);
+  for (int n = 0; n < n_steps; ++n) {
+    // next step's controls and step size: loaded before the stores below (vmcnt retires in order)
+    const int nn = min(n + 1, a.T - 1);
+    const float cv_next = ctrl[nn * a.ctrl_st + 0], cw_next = ctrl[nn * a.ctrl_st + 1];
+    float ts_a = zero, ts_b = zero;
+    if (INTEG == MF_INTEG_ODEINT_EULER) {
+      const int tp = max(min(n + 1, a.T - 2), 0);
+      ts_a = a.ts[tp]; ts_b = a.ts[tp + 1];
+    }
+    const float tv = tv_v * cv + tv_w * cw;
+    float xdd, wd, Fr, Ff;
+    if (INTEG == MF_INTEG_ODEINT_EULER) {
+      // ---- row n: the state registers are that row ----
+      emit_row(1u);
+      // ---- stream B: pose and geometry of step n + 1 (torchdiffeq fixed-grid euler: y_{n+1} = y_n + h f(t_n, y_n)) ----
+      // dR[c][j] = w_{c+1} R[c+2][j] - w_{c+2} R[c+1][j]
+      const float w1 = dpp<kRot1>(w), w2 = dpp<kRot2>(w);
+      const float d0 = w1 * dpp<kRot2>(R0) - w2 * dpp<kRot1>(R0);
+      const float d1 = w1 * dpp<kRot2>(R1) - w2 * dpp<kRot1>(R1);
+      const float d2 = w1 * dpp<kRot2>(R2) - w2 * dpp<kRot1>(R2);
+      x = fmaf(h_ode, xd, x);
+      R0 = fmaf(h_ode, d0, R0); R1 = fmaf(h_ode, d1, R1); R2 = fmaf(h_ode, d2, R2);
+      const Geo geo_next = geometry(x, R0, R1, R2);     // (after the last step: the final pose -- unused, in range)
+      // ---- stream A: contact chain of step n ----
+      contact(geo, xd, w, tv, &xdd, &wd, &Fr, &Ff);
+      xd = fmaf(h_ode, xdd, xd);
+      w = fmaf(h_ode, wd, w);
+      oFs = fmaf(h_ode, Fr, oFs);
+      oFf = fmaf(h_ode, Ff, oFf);
+      geo = geo_next;
+    } else {
+      // dynamics(): the next pose needs this step's forces (x += xd_new h, R <- R M(w_new)): one stream
+      const Geo g = geometry(x, R0, R1, R2);
+      emit_row(n > 0 ? 1u : 0u);      // n = 0: the initial state as a placeholder in row 0, overwritten one iteration later
+      contact(g, xd, w, tv, &xdd, &wd, &Fr, &Ff);
+      // update_state (:274-288): xd += xdd h ; x += xd_new h ; w += wd h ; R <- R (I + K sin + K^2 (1 - cos))
+      const float h = a.dt;
+      xd = fmaf(xdd, h, xd);
+      x = fmaf(xd, h, x);
+      w = fmaf(wd, h, w);
+      const float th2 = dot3(w, w);
+      const float kc = w * M::inv_len(th2);                            // K = [w]x / max(|w|, eps)
+      const float k1 = dpp<kRot1>(kc), k2 = dpp<kRot2>(kc);
+      float sn_, oc;
+      M::sincos_small(M::sqrt(th2) * h, &sn_, &oc);
+      const float kk = dot3(kc, kc);
+      // row c of M = I + K sin + K^2 (1 - cos), stored relative to the diagonal: m0 = M[c][c], m1 = M[c][c+1], m2 = M[c][c+2]
+      // (K[c][c+1] = -k_{c+2}, K[c][c+2] = k_{c+1}, K^2 = k k^T - |k|^2 I)
+      const float ock = oc * kc;
+      const float m0 = one + oc * (kc * kc - kk);
+      const float m1 = fmaf(ock, k1, -(sn_ * k2));
+      const float m2 = fmaf(ock, k2, sn_ * k1);
+      // R'[c][j] = sum_m R[c][m] M[m][j]; M[m][j] lives in lane m as m_{(j - m) mod 3}
+      const float n0 = R0 * dpp<kB0>(m0) + R1 * dpp<kB1>(m2) + R2 * dpp<kB2>(m1);
+      const float n1 = R0 * dpp<kB0>(m1) + R1 * dpp<kB1>(m0) + R2 * dpp<kB2>(m2);
+      const float n2 = R0 * dpp<kB0>(m2) + R1 * dpp<kB1>(m1) + R2 * dpp<kB2>(m0);
+      R0 = n0; R1 = n1; R2 = n2;
+      oFs = Fr; oFf = Ff;                                               // true forces of this step
+    }
+    cv = cv_next; cw = cw_next;
+    h_ode = ts_b - ts_a;
+  }
+  if (n_steps > 0 || INTEG == MF_INTEG_ODEINT_EULER) emit_row(1u);
+}
+
+// true when the component-parallel kernels cover this launch: float32 fast math, a rigid body of <= 4 points, full outputs
+// (or states only), and few enough rollouts that the launch is bound by the instruction stream of its waves
+bool use_component_parallel(const MfRolloutDesc* d, const MfRolloutFwdBufs* p);
+int launch_rollout_fwd_cp_f32(const RolloutArgs<float>& a, int integ, bool forces, bool zmu, hipStream_t st);
+
+}  // namespace mf

@@ -446,9 +446,78 @@ def gen_joints(out):
             print(f'joints {tag} integ={integ}: |Xs|max={float(states[0].abs().max()):.3f}')
 
 
+# ----------------------------------------------------------------------------------------------------------
+# fixture 8: host-side image / camera helpers (terrain_encoder/utils.py:13-133) and estimate_heightmap (cloudproc.py:88-148)
+# ----------------------------------------------------------------------------------------------------------
+def _test_image(w, h):
+    """Deterministic RGB test image (gradients + a checker), regenerated identically by the tests."""
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([(xx * 255 // max(w - 1, 1)), (yy * 255 // max(h - 1, 1)), (((xx // 16) + (yy // 16)) % 2) * 200], -1)
+    return img.astype(np.uint8)
+
+
+def gen_img_utils(out):
+    from PIL import Image
+    U = ref_lss_utils
+    rng = np.random.RandomState(5)
+    # camera projection helpers
+    pts = torch.as_tensor(rng.randn(3, 40) * 3.0 + np.array([[4.0], [0.0], [0.5]]), dtype=torch.float32)
+    yaw = 0.3
+    rot = torch.as_tensor(np.array([[np.cos(yaw), -np.sin(yaw), 0], [np.sin(yaw), np.cos(yaw), 0], [0, 0, 1]]) @
+                          np.array([[0, 0, 1], [-1, 0, 0], [0, -1, 0]], np.float64), dtype=torch.float32)
+    trans = torch.tensor([0.3, -0.1, 0.5])
+    K = torch.tensor([[300., 0., 256.], [0., 300., 128.], [0., 0., 1.]])
+    cam = U.ego_to_cam(pts.clone(), rot, trans, K)
+    out['proj/pts'] = npy(pts); out['proj/rot'] = npy(rot); out['proj/trans'] = npy(trans); out['proj/K'] = npy(K)
+    out['proj/cam'] = npy(cam)
+    out['proj/mask'] = npy(U.get_only_in_img_mask(cam, 256, 512))
+    out['proj/back'] = npy(U.cam_to_ego(cam.clone(), rot, trans, K))
+    out['get_rot'] = np.stack([npy(U.get_rot(h)) for h in (0.0, 0.1, -0.7, np.pi / 2)])
+    # sample_augmentation: the deterministic variant and seeded random draws
+    cfg = dict(data_aug_conf=dict(H=1200, W=1920, final_dim=(256, 512), resize_lim=(0.25, 0.35), bot_pct_lim=(0.0, 0.1),
+                                  rot_lim=(-5.4, 5.4), rand_flip=True))
+    def pack(t):
+        resize, dims, crop, flip, rotate = t
+        return np.array([resize, dims[0], dims[1], crop[0], crop[1], crop[2], crop[3], float(flip), rotate], np.float64)
+    out['aug/eval'] = pack(U.sample_augmentation(cfg, is_train=False))
+    np.random.seed(11)
+    out['aug/train'] = np.stack([pack(U.sample_augmentation(cfg, is_train=True)) for _ in range(8)])
+    # img_transform on a synthetic image: flipped + rotated, and the plain variant
+    src = _test_image(320, 200)
+    cases = [(0.6, (192, 120), (20, 10, 148, 74), True, 7.5), (0.5, (160, 100), (16, 18, 144, 82), False, 0.0),
+             (0.7, (224, 140), (40, 30, 168, 94), False, -12.0)]
+    for i, (resize, dims, crop, flip, rotate) in enumerate(cases):
+        img, pr, pt = U.img_transform(Image.fromarray(src), torch.eye(2), torch.zeros(2), resize=resize, resize_dims=dims,
+                                      crop=crop, flip=flip, rotate=rotate)
+        out[f'tf{i}/args'] = np.array([resize, dims[0], dims[1], *crop, float(flip), rotate], np.float64)
+        out[f'tf{i}/img'] = np.asarray(img)
+        out[f'tf{i}/post_rot'] = npy(pr); out[f'tf{i}/post_tran'] = npy(pt)
+
+
+def gen_heightmap(out):
+    from monoforce.cloudproc import estimate_heightmap
+    rng = np.random.RandomState(9)
+    n = 20000
+    pts = np.concatenate([rng.uniform(-7.5, 7.5, (n, 2)), rng.normal(0.0, 0.6, (n, 1))], 1).astype(np.float32)
+    pts[::97, 2] = np.nan                              # rows with NaNs are dropped
+    pts[5::211, 0] = 6.4                               # on the (exclusive) bounds
+    pts[7::199, 1] = -6.4
+    # points exactly on bin edges of the float32 arange
+    edges = torch.arange(-6.4, 6.4, 0.1).numpy()
+    pts[11:11 + 60, 0] = edges[1:121:2]
+    pts[100:160, 1] = edges[2:122:2]
+    P = torch.as_tensor(pts)
+    for tag, kw in (('a', dict(grid_res=0.1, d_max=6.4, h_max=1.0)), ('b', dict(grid_res=0.1, d_max=6.4, h_max=1.0, r_min=1.0)),
+                    ('c', dict(grid_res=0.4, d_max=6.4, h_max=2.0, h_min=-0.5)), ('d', dict(grid_res=0.05, d_max=3.2, h_max=1.5, r_min=0.3))):
+        hm = estimate_heightmap(P.clone(), **kw)
+        out[f'{tag}/hm'] = npy(hm).astype(np.float32)
+        out[f'{tag}/kw'] = np.array([kw['grid_res'], kw['d_max'], kw['h_max'], kw.get('r_min', -1.0), kw.get('h_min', np.nan)], np.float64)
+    out['points'] = pts
+
+
 def main():
     jobs = dict(interp=gen_interp, rollout_small=gen_small, step=gen_step, rollout_full=gen_full, lss=gen_lss,
-                physics_loss=gen_loss, rollout_joints=gen_joints)
+                physics_loss=gen_loss, rollout_joints=gen_joints, img_utils=gen_img_utils, heightmap=gen_heightmap)
     only = sys.argv[1:]
     for name, fn in jobs.items():
         if only and name not in only:

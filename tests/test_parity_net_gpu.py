@@ -1,0 +1,258 @@
+"""Parity cases the first round left thin: `interpolate_grid` fed directly, the BASELINE configurations at
+their own shapes, float32 `dynamics()` over the full horizon, component-wise error metrics, and the large-batch shared-map
+backward (private gradient copies, accumulator carry-over) against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dphysics_oracle as orc
+from tests import helpers as hp
+from tests.test_rollout_gpu import make_dphysics, run_hip
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def comp_rel_err(a, b, comp_axes=1):
+    """Component-wise companion of helpers.rel_err: every component index of the trailing `comp_axes` axes (x / y / z of a
+    vec3, each of the 9 entries of R) is judged against ITS OWN largest reference magnitude over the whole tensor --
+    the small ones (z of Xs, the off-axis entries of Rs) no longer hide behind the largest entry.  Returns the worst ratio."""
+    a, b = (np.asarray(v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else v, np.float64) for v in (a, b))
+    nc = int(np.prod(a.shape[a.ndim - comp_axes:]))
+    a2, b2 = a.reshape(-1, nc), b.reshape(-1, nc)
+    scale = np.maximum(np.abs(b2).max(0), 1e-30)
+    return float((np.abs(a2 - b2).max(0) / scale).max())
+
+
+def probe_body(dp, dtype):
+    """Turn `dp` into a ONE-point body at the body origin (test-only): with R = I the terrain snap of `DPhysics.dphysics`
+    (dphysics.py:567-571) then IS interpolate_grid at the start position.  A single point mass has a singular inertia, so
+    the body inertia handed to the kernel is set to the identity (no torque arises: r = 0)."""
+    cfg = dp.dphys_cfg
+    cfg.robot_points = torch.zeros(1, 3)
+    cfg.driving_parts = [torch.ones(1, dtype=torch.bool), torch.zeros(1, dtype=torch.bool)]
+    dp.x_points = cfg.robot_points.unsqueeze(0).to(dp.device)
+    dp._cache = {('iinv', dtype): [1.0, 0, 0, 0, 1.0, 0, 0, 0, 1.0]}
+    return dp
+
+
+@pytest.mark.parametrize('tag', ['f32', 'f64'])
+@pytest.mark.parametrize('ppl', [0, 1, 4])
+@pytest.mark.parametrize('precise', [False, True])
+def test_interpolate_grid_golden_through_the_snap(tag, ppl, precise):
+    """SURVEY 8 row a5, directly: the 16 edge / out-of-range queries of tests/golden/interp.npz (values of the reference's
+    own interpolate_grid) through the HIP kernels: heights via the snap of a one-point body, normals via the direction of
+    the spring force of dynamics()' first step (dh = 0 after the snap, so F_spring = -damping (xd . n) n)."""
+    g = hp.load('interp')
+    dt = hp.DT[tag]
+    res, d_max = float(g['grid_res']), float(g['d_max'])
+    grid = torch.as_tensor(g[f'{tag}/grid'])                     # [2, 8, 8]
+    qx, qy = g[f'{tag}/qx'][0], g[f'{tag}/qy'][0]                # the same 16 queries for both grids
+    nq = qx.shape[0]
+    pts, masks = __import__('monoforce_amd.synthetic', fromlist=['x']).robot_points_4()
+    dp = probe_body(make_dphysics(pts, masks, 0, res, d_max, points_per_lane=ppl, precise=precise), dt)
+    dp.dphys_cfg.robot_mass = 1e6                                # force clamps at +-m g: far away
+    for gi in range(2):
+        x0 = torch.zeros(nq, 3, dtype=dt)
+        x0[:, 0], x0[:, 1] = torch.as_tensor(qx), torch.as_tensor(qy)
+        xd = torch.zeros(nq, 3, dtype=dt); xd[:, 2] = -1.0
+        st = (x0, xd, torch.eye(3, dtype=dt).repeat(nq, 1, 1), torch.zeros(nq, 3, dtype=dt))
+        ctrl = torch.zeros(nq, 1, 2, dtype=dt)
+        outs, st_dev = run_hip(dp, grid[gi:gi + 1].to(dt), ctrl, st, None)       # ONE shared 8x8 map
+        z_hip = st_dev[0][:, 2].cpu().numpy().astype(np.float64)
+        F = outs[4][:, 0, 0].numpy().astype(np.float64)
+        n_hip = F / np.linalg.norm(F, axis=-1, keepdims=True)
+        z_ref, n_ref = g[f'{tag}/z'][gi].astype(np.float64), g[f'{tag}/n'][gi].astype(np.float64)
+        # queries sitting ON a cell boundary: the fast-math kernels scale by 1/res instead of dividing by res, which may
+        # land the truncation in the neighbouring cell (the reference's own fp32 and fp64 disagree there too)
+        u = np.stack([(qx.astype(np.float64) + d_max) / res, (qy.astype(np.float64) + d_max) / res])
+        clear = (np.abs(u - np.round(u)) > 1e-4).all(0)
+        tol = 1e-12 if tag == 'f64' else 2e-6
+        ok = (np.abs(z_hip - z_ref) <= tol * np.abs(z_ref).max()) & (np.abs(n_hip - n_ref).max(-1) <= (1e-10 if tag == 'f64' else 2e-6))
+        if precise or tag == 'f64':
+            assert ok.all(), (gi, np.nonzero(~ok)[0])
+        else:      # fast math: every query clear of a boundary, and most of the ten that sit on one
+            assert clear.sum() == 6 and ok[clear].all() and ok.sum() >= 12, (gi, np.nonzero(~ok)[0])
+
+
+def _c1_problem(dtype):
+    from monoforce_amd import synthetic as syn
+    pts, masks = syn.robot_points_4()
+    z = syn.bump_terrain(syn.bump_params(0, smooth=True), 6.4, 0.1, torch.float64).to(dtype).unsqueeze(0)      # [1,128,128]
+    mu = syn.wave_friction(6.4, 0.1, dtype=torch.float64).to(dtype).unsqueeze(0)
+    ctrl = syn.const_controls(1, 200, seed=3, dtype=torch.float64).to(dtype)
+    return pts, masks, z, mu, ctrl
+
+
+@pytest.mark.parametrize('tag', ['f32', 'f64'])
+@pytest.mark.parametrize('integ', [0, 1])
+@pytest.mark.parametrize('ppl', [0, 1])
+def test_config1_single_rollout_forward_backward_vs_oracle(tag, integ, ppl):
+    """BASELINE configs[0] at its own shape: ONE rollout, 4 contact points, 200 Euler steps, 128x128 map at 0.1 m --
+    all six outputs and the gradients to terrain, friction and controls vs the oracle."""
+    dt = hp.DT[tag]
+    pts, masks, z, mu, ctrl = _c1_problem(dt)
+    assert z.shape == (1, 128, 128) and ctrl.shape == (1, 200, 2)
+    dp = make_dphysics(pts, masks, integ, 0.1, 6.4, points_per_lane=ppl)
+    zd, md, cd = z.to(DEV).requires_grad_(True), mu.to(DEV).requires_grad_(True), ctrl.to(DEV).requires_grad_(True)
+    states, forces = dp(zd, cd, friction=md)
+    outs = list(states) + list(forces)
+    hp.probe_loss(outs, dt).backward()
+    spec = hp.spec_from(pts, masks, integ, 0.1, 6.4)
+    zc, mc, cc = z.clone().requires_grad_(True), mu.clone().requires_grad_(True), ctrl.clone().requires_grad_(True)
+    rs, rf = orc.rollout(spec, zc, cc, friction=mc)
+    refs = list(rs) + list(rf)
+    hp.probe_loss(refs, dt).backward()
+    tol = 1e-9 if tag == 'f64' else 1e-4
+    for k, o, r in zip(hp.OUT_KEYS, outs, refs):
+        assert hp.rel_err(o, r) <= tol, (k, hp.rel_err(o, r))
+        # ... and component by component (z of Xs, every entry of R on its own scale); the y components of this nearly straight
+        # drive are ~1e-2 of the x ones, so float32 gets a 10x wider bar here
+        ce = comp_rel_err(o, r, 2 if k == 'Rs' else 1)
+        assert ce <= (1e-8 if tag == 'f64' else 1e-3), (k, ce)
+    gtol = 1e-7 if tag == 'f64' else 2e-3          # 200-step BPTT in float32: the reference's own fp32-vs-fp64 is ~1e-4 here
+    assert hp.rel_err(zd.grad, zc.grad) <= gtol, hp.rel_err(zd.grad, zc.grad)
+    assert hp.rel_err(md.grad, mc.grad) <= gtol, hp.rel_err(md.grad, mc.grad)
+    assert hp.rel_err(cd.grad, cc.grad) <= gtol, hp.rel_err(cd.grad, cc.grad)
+
+
+@pytest.mark.parametrize('ppl', [0, 1, 4])
+@pytest.mark.parametrize('precise', [False, True])
+def test_dynamics_integrator_f32_full_horizon_on_smooth_terrain(ppl, precise):
+    """float32 `dynamics()` (use_odeint=False) over all 500 steps on the smooth and the flat terrain of the full-horizon
+    fixture, vs the reference's own float32 outputs.  The reference's float32 run is itself only reproducible to its
+    fp32-vs-fp64 envelope (~1e-3 on the positions here: the semi-implicit scheme with re-normalised rotations amplifies
+    rounding more than the default integrator), so the bar is max(1e-4, 4 x that envelope) per output."""
+    g = hp.load('rollout_full')
+    pts, masks, z, mu, ctrl = hp.full_inputs(torch.float32)
+    dp = make_dphysics(pts, masks, 0, hp.FULL['grid_res'], hp.FULL['d_max'], points_per_lane=ppl, precise=precise)
+    outs, _ = run_hip(dp, z, ctrl, None, mu)
+    for k, o in zip(hp.OUT_KEYS[:4], outs[:4]):
+        r32, r64 = g[f'f32/i0/{k}'][2:], g[f'f64/i0/{k}'][2:]
+        env = hp.rel_err(r32, r64)
+        err = hp.rel_err(o[2:], r32)
+        assert err <= max(1e-4, 4 * env), (k, err, env)
+        assert env <= 5e-3, (k, env)      # (measured: ~1.2e-3 on Xs -- dynamics() is not a 1e-4 float32 path even in the reference)
+
+
+def test_full_horizon_f32_calm_floor():
+    """The reproducible-prefix test of test_rollout_gpu.py demands `n_calm > 960`; pin what the fixture actually offers so a
+    regression cannot hide behind the low floor: with the default integrator the reference is reproducible (envelope
+    <= 1e-6) on at least 3000 state-rows, and every one of them is checked at 1e-4 here for the default lane mapping."""
+    g = hp.load('rollout_full')
+    pts, masks, z, mu, ctrl = hp.full_inputs(torch.float32)
+    for integ, floor in ((1, 3000), (0, 1200)):
+        dp = make_dphysics(pts, masks, integ, hp.FULL['grid_res'], hp.FULL['d_max'])
+        outs, _ = run_hip(dp, z, ctrl, None, mu)
+        n_calm = 0
+        for k, o in zip(hp.OUT_KEYS[:4], outs[:4]):
+            r32, r64 = g[f'f32/i{integ}/{k}'].astype(np.float64), g[f'f64/i{integ}/{k}']
+            o = o.numpy().astype(np.float64)
+            B, T = r32.shape[:2]
+            scale = np.abs(r64).reshape(B, -1).max(1).clip(1e-30)[:, None]
+            env = np.maximum.accumulate(np.abs(r32 - r64).reshape(B, T, -1).max(2) / scale, axis=1)
+            err = np.abs(o - r32).reshape(B, T, -1).max(2) / scale
+            calm = env <= 1e-6
+            n_calm += int(calm.sum())
+            assert (err[calm] <= 1e-4).all(), (integ, k, float(err[calm].max()))
+        assert n_calm >= floor, (integ, n_calm)
+
+
+@pytest.mark.parametrize('B,ppl', [(1024, 1), (4096, 1), (1024, 0)])
+def test_large_batch_shared_map_backward_vs_oracle(B, ppl):
+    """The shared-map backward at BASELINE batch sizes -- private gradient copies (rollout b -> copy b % copies) and, from
+    192 waves up, the accumulator carry-over kernels -- against the ORACLE: the loss touches 32 rollouts spread over the
+    batch (every 32nd or 128th; the others run with zero upstream gradients), so the oracle only has to differentiate those."""
+    from monoforce_amd import synthetic as syn
+    T, sub = 100, 32
+    pts, masks = syn.robot_points_4()
+    z = syn.bump_terrain(syn.bump_params(5), 6.4, 0.05)
+    mu = syn.wave_friction(6.4, 0.05)
+    ctrl = syn.const_controls(B, T, seed=2)
+    sel = torch.arange(0, B, B // sub)[:sub]
+    wts = syn.probe_weights((sub, T, 3), phase=0.3)
+    dp = make_dphysics(pts, masks, 1, 0.05, 6.4, points_per_lane=ppl)
+    dp.dphys_cfg.traj_sim_time = 5.0
+    zd, md = z.to(DEV).requires_grad_(True), mu.to(DEV).requires_grad_(True)
+    cd = ctrl.to(DEV).requires_grad_(True)
+    (Xs, Xds, Rs, Om), _ = dp(zd.unsqueeze(0), cd, friction=md.unsqueeze(0))
+    ((Xs[sel.to(DEV)] * wts.to(DEV)).sum() + (Om[sel.to(DEV)] * wts.to(DEV)).sum() * 0.1).backward()
+    spec = hp.spec_from(pts, masks, 1, 0.05, 6.4)
+    zc, mc = z.clone().requires_grad_(True), mu.clone().requires_grad_(True)
+    cc = ctrl[sel].clone().requires_grad_(True)
+    (rX, _, _, rO), _ = orc.rollout(spec, zc.unsqueeze(0).expand(sub, -1, -1), cc, friction=mc.unsqueeze(0).expand(sub, -1, -1))
+    ((rX * wts).sum() + (rO * wts).sum() * 0.1).backward()
+    assert hp.rel_err(zd.grad, zc.grad) <= 2e-4, hp.rel_err(zd.grad, zc.grad)
+    assert hp.rel_err(md.grad, mc.grad) <= 2e-4, hp.rel_err(md.grad, mc.grad)
+    assert hp.rel_err(cd.grad[sel.to(DEV)], cc.grad) <= 2e-4
+    rest = torch.ones(B, dtype=torch.bool); rest[sel] = False
+    assert float(cd.grad[rest.to(DEV)].abs().max()) == 0.0          # rollouts the loss does not touch get exactly nothing
+
+
+def test_config4_full_size_step_vs_oracles():
+    """BASELINE configs[3] at full size, one step: 4 cameras x 3x256x512 -> 256x256 BEV, 1024 rollouts x 500 steps on the
+    predicted terrain.  BEV vs the splat oracle on the lifted features; rollout states vs the rollout oracle on the
+    PREDICTED maps (a 128-rollout subset, float32 calm prefix + full-horizon boundedness); finite, non-zero gradients."""
+    from oracle import splat_oracle as so
+    from monoforce_amd import synthetic as syn
+    from monoforce_amd.dphys_config import DPhysConfig
+    from monoforce_amd.dphysics import DPhysics
+    from monoforce_amd.terrain_encoder import LiftSplatShoot
+    from monoforce_amd.train import EncoderTrainStep, synthetic_encoder_batch
+    torch.manual_seed(0)
+    gc = dict(xbound=[-6.4, 6.4, 0.05], ybound=[-6.4, 6.4, 0.05], zbound=[-3.2, 3.2, 6.4], dbound=[0.6, 6.4, 0.1])
+    enc = LiftSplatShoot(gc, dict(final_dim=(256, 512))).to(DEV).eval()       # eval for (1), (2): no drop-connect between two calls
+    pts, masks = syn.robot_points_4()
+    cfg = DPhysConfig(robot='tradr', grid_res=0.05, robot_points=pts, driving_parts=masks)
+    dp = DPhysics(cfg, device=DEV)
+    batch = synthetic_encoder_batch(enc, dp, n_rollouts=1024, device=DEV)
+    inputs = batch[0]
+    assert inputs[0].shape == (1, 4, 3, 256, 512)
+    # (1) BEV of the fused lift-splat vs the oracle's voxel pooling of the lifted features
+    with torch.no_grad():
+        geom = enc.get_geometry(*inputs[1:])
+        feats = enc.get_cam_feats(inputs[0])
+        bev = enc.get_voxels(*inputs)
+    assert bev.shape == (1, 64, 256, 256)
+    ref, kept = so.voxel_pooling(geom.cpu().numpy(), feats.cpu().numpy(), enc.dx.cpu().numpy(), enc.bx.cpu().numpy(), enc.nx.cpu().numpy())
+    assert hp.rel_err(bev.cpu(), ref) <= 1e-6
+    # (2) the rollout of the step, on the maps the encoder predicts
+    step = EncoderTrainStep(enc, dp, lr=1e-4)
+    with torch.no_grad():
+        terrain = enc(*inputs)
+        zp = step.terrain_preproc(terrain['terrain']).squeeze(1)
+        mp = step.terrain_preproc(terrain['friction']).squeeze(1)
+        controls, pose0 = batch[3], batch[4]
+        x0 = pose0[:, :3, 3].clone()
+        st = (x0, torch.zeros_like(x0), pose0[:, :3, :3].contiguous(), torch.zeros_like(x0))
+        (Xs, Xds, Rs, Om), _ = dp(z_grid=zp, controls=controls, state=st, friction=mp)
+    assert Xs.shape == (1024, 500, 3) and zp.shape == (1, 256, 256)
+    sub = torch.arange(0, 1024, 8)
+    spec = hp.spec_from(pts, masks, 1, 0.05, 6.4)
+    def ref_run(dtype):
+        sr = tuple(t[sub].cpu().to(dtype) for t in (pose0[:, :3, 3], torch.zeros_like(x0), pose0[:, :3, :3], torch.zeros_like(x0)))
+        with torch.no_grad():
+            (a, b, c, d), _ = orc.rollout(spec, zp.cpu().to(dtype).expand(len(sub), -1, -1), controls[sub].cpu().to(dtype),
+                                          friction=mp.cpu().to(dtype).expand(len(sub), -1, -1), state=sr)
+        return [a, b, c, d]
+    r32, r64 = ref_run(torch.float32), ref_run(torch.float64)
+    n_calm = 0
+    for o, a32, a64 in zip((Xs, Xds, Rs, Om), r32, r64):
+        o = o[sub.to(DEV)].cpu().numpy().astype(np.float64)
+        a32, a64 = a32.numpy().astype(np.float64), a64.numpy()
+        Bq, T = a32.shape[:2]
+        scale = np.abs(a64).reshape(Bq, -1).max(1).clip(1e-30)[:, None]
+        env = np.maximum.accumulate(np.abs(a32 - a64).reshape(Bq, T, -1).max(2) / scale, axis=1)
+        err = np.abs(o - a32).reshape(Bq, T, -1).max(2) / scale
+        calm = env <= 1e-6
+        n_calm += int(calm.sum())
+        assert (err[calm] <= 1e-4).all(), float(err[calm].max())
+        assert np.isfinite(o).all() and float(err.max()) < 0.5
+    assert n_calm >= 4 * 128 * 50
+    # (3) the whole step: finite loss, finite non-zero gradients through rollout backward + lift-splat backward
+    enc.train()
+    loss, parts = step.step(batch)
+    assert all(np.isfinite(float(v)) for v in (loss,) + tuple(parts))
+    grads = [p.grad for p in enc.parameters() if p.requires_grad and p.grad is not None]
+    assert len(grads) > 100 and all(torch.isfinite(t).all() for t in grads)
+    assert any(float(p.grad.abs().max()) > 0 for n, p in enc.named_parameters() if n.startswith('camencode.depthnet') and p.grad is not None)

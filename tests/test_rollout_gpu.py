@@ -326,7 +326,8 @@ def test_split_store_kernels_write_the_same_rows(integ, N):
     ctrl = syn.varying_controls(B_big, T, seed=1).to(DEV)
     for forces in (True, False):
         for grad in (False, True):
-            dp = make_dphysics(pts, masks, integ, 0.1, 3.2, return_forces=forces)
+            # (one point per lane in both launches: a small batch would otherwise take the component-parallel kernels)
+            dp = make_dphysics(pts, masks, integ, 0.1, 3.2, return_forces=forces, points_per_lane=1 if N <= 4 else 0)
             zb = z.clone().requires_grad_(grad)
             big = dp(zb.unsqueeze(0), ctrl)
             zs = z.clone().requires_grad_(grad)
