@@ -4,7 +4,8 @@
 
 namespace mf {
 
-// as the forward (rollout_fwd_cp_fast.hip): up to one wave per SIMD; MF_CP_BWD_MAX_WAVES overrides (0 disables)
+// Measured, backward, N = 4 (tools/ab_cp.py; ms component-parallel vs one point per lane): B = 256 0.46 / 0.88, 1024 0.47 / 0.89,
+// 2048 0.53 / 0.90, 4096 0.74 / 0.95 -- up to one wave per SIMD; MF_CP_BWD_MAX_WAVES overrides (0 disables)
 static long long cp_bwd_max_waves() {
   static const long long v = getenv("MF_CP_BWD_MAX_WAVES") ? atoll(getenv("MF_CP_BWD_MAX_WAVES")) : 1024;
   return v;

@@ -24,7 +24,7 @@ __device__ __forceinline__ float ld1(const float* base, unsigned off) {
 }
 
 template <int INTEG>
-__global__ void __launch_bounds__(256) rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
+__global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
   static_assert(INTEG == MF_INTEG_ODEINT_EULER, "the component-parallel backward covers the default integrator");
   using namespace cp;
   using M = Mth<float, true>;
@@ -57,8 +57,8 @@ __global__ void __launch_bounds__(256) rollout_bwd_cp_kernel(const RolloutBwdArg
   const float wb_s = (q & 1) ? one : -one, wb_o = (q & 1) ? zero : one;
   const float n_mul = q < 2 ? -a.inv_res : zero, n_add = q < 2 ? zero : one;
   // cell gradient of the normal's finite differences: cells (c, f, l, fl) get (-ggx - ggy, +ggx, +ggy, 0); ggx sits in lane 0,
-  // ggy in lane 1, t = quad_perm[1,0,1,1](gg) brings the partner over: nz += sA * gg + sB * t
-  const float sA = q == 0 ? -one : zero, sB = q == 0 ? -one : (q == 3 ? zero : one);
+  // ggy in lane 1, t = quad_perm[1,0,1,1](gg) brings the partner over: nz += cgA * gg + cgB * t
+  const float cgA = q == 0 ? -one : zero, cgB = q == 0 ? -one : (q == 3 ? zero : one);
   const float sel_xy = q < 2 ? one : zero;       // components that receive d(sample)/d(position) through the fractions
   const float mg = a.mg;
 
@@ -76,27 +76,30 @@ __global__ void __launch_bounds__(256) rollout_bwd_cp_kernel(const RolloutBwdArg
   const unsigned u_om = (row0 * (unsigned)a.sOm + (unsigned)cc) * 4u, u_r = (row0 * (unsigned)a.sRs + (unsigned)cc * 3u) * 4u;
   const unsigned u_fs = ((row0 * (unsigned)a.N + pcl) * (unsigned)a.sFs + (unsigned)cc) * 4u;
   const unsigned u_ff = ((row0 * (unsigned)a.N + pcl) * (unsigned)a.sFf + (unsigned)cc) * 4u;
-  const float* ctrl = a.controls + (size_t)b * a.T * 2;
-  float* gctrl = a.gcontrols + (size_t)b * a.T * 2;
 
   struct StateIn { float x, xd, w, R0, R1, R2, cv, cw, t0, t1; };
   struct UpIn { float gXs, gXds, gOm, gR0, gR1, gR2, gFs, gFf; };
   const int n_steps = a.T - 1;
+  const Rsrc rXraw = make_rsrc(a.Xraw), rXds = make_rsrc(a.Xds), rOm = make_rsrc(a.Om), rRs = make_rsrc(a.Rs);
+  const Rsrc rgXs = make_rsrc(a.gXs), rgXds = make_rsrc(a.gXds), rgOm = make_rsrc(a.gOm), rgRs = make_rsrc(a.gRs);
+  const Rsrc rgFs = make_rsrc(a.gFs), rgFf = make_rsrc(a.gFf), rCtrl = make_rsrc(a.controls), rGctrl = make_rsrc(a.gcontrols);
+  const unsigned v_ctrl = (unsigned)b * (unsigned)a.T * 8u;      // this rollout's control rows (bytes)
+  const unsigned s3 = row_stride * 12u, s9 = row_stride * 36u;   // bytes between consecutive time steps
+  const unsigned sg_xs = row_stride * (unsigned)a.sXs * 4u, sg_xds = row_stride * (unsigned)a.sXds * 4u, sg_om = row_stride * (unsigned)a.sOm * 4u;
+  const unsigned sg_r = row_stride * (unsigned)a.sRs * 4u;
+  const unsigned sg_fs = row_stride * (unsigned)a.N * (unsigned)a.sFs * 4u, sg_ff = row_stride * (unsigned)a.N * (unsigned)a.sFf * 4u;
   auto load_state = [&](int m, StateIn& s) {            // the state step m started from = saved output row m
-    const size_t ro = (size_t)m * row_stride;            // wave-uniform
-    const float* bx = a.Xraw + ro * 3; const float* bxd = a.Xds + ro * 3; const float* bw = a.Om + ro * 3; const float* bR = a.Rs + ro * 9;
-    s.x = ld1(bx, v3); s.xd = ld1(bxd, v3); s.w = ld1(bw, v3);
-    const CpF3 r = ld3(bR, v9);
-    s.R0 = r.a; s.R1 = r.b; s.R2 = r.c;
-    s.cv = ctrl[m * 2 + 0]; s.cw = ctrl[m * 2 + 1];
+    const unsigned um = __builtin_amdgcn_readfirstlane((unsigned)m);    // wave-uniform, and provably so (scalar offsets)
+    s.x = bload1(rXraw, v3, um * s3); s.xd = bload1(rXds, v3, um * s3); s.w = bload1(rOm, v3, um * s3);
+    bload3(rRs, v9, um * s9, &s.R0, &s.R1, &s.R2);
+    bload2(rCtrl, v_ctrl, um * 8u, &s.cv, &s.cw);
     s.t0 = a.ts[m]; s.t1 = a.ts[m + 1 < a.T ? m + 1 : m];
   };
   auto load_upstream = [&](int orow, UpIn& u) {         // upstream gradients of output row `orow`
-    const size_t ro = (size_t)orow * row_stride;
-    u.gXs = ld1(a.gXs + ro * a.sXs, u_xs); u.gXds = ld1(a.gXds + ro * a.sXds, u_xds); u.gOm = ld1(a.gOm + ro * a.sOm, u_om);
-    const CpF3 r = ld3(a.gRs + ro * a.sRs, u_r);
-    u.gR0 = r.a; u.gR1 = r.b; u.gR2 = r.c;
-    u.gFs = ld1(a.gFs + ro * a.N * a.sFs, u_fs); u.gFf = ld1(a.gFf + ro * a.N * a.sFf, u_ff);
+    const unsigned uo = __builtin_amdgcn_readfirstlane((unsigned)orow);
+    u.gXs = bload1(rgXs, u_xs, uo * sg_xs); u.gXds = bload1(rgXds, u_xds, uo * sg_xds); u.gOm = bload1(rgOm, u_om, uo * sg_om);
+    bload3(rgRs, u_r, uo * sg_r, &u.gR0, &u.gR1, &u.gR2);
+    u.gFs = bload1(rgFs, u_fs, uo * sg_fs); u.gFf = bload1(rgFf, u_ff, uo * sg_ff);
   };
   auto add_upstream_state = [&](const UpIn& u) {
     lx += u.gXs;
@@ -106,7 +109,7 @@ __global__ void __launch_bounds__(256) rollout_bwd_cp_kernel(const RolloutBwdArg
     lw += u.gOm;
   };
 
-  gctrl[(a.T - 1) * 2 + 0] = zero; gctrl[(a.T - 1) * 2 + 1] = zero;   // the last control is never used by the explicit scheme
+  bstore2(rGctrl, v_ctrl, (unsigned)(a.T - 1) * 8u, zero, zero);   // the last control is never used by the explicit scheme
 
   // Cell-gradient accumulator of this lane's footprint cell: contributions of consecutive steps to the SAME cell (a robot
   // moves <= 0.2 cell per step) add up in registers; when the lane's cell changes, the old pair goes to a stash that is
@@ -122,84 +125,75 @@ __global__ void __launch_bounds__(256) rollout_bwd_cp_kernel(const RolloutBwdArg
     st_pending = false;
   };
 
-  float* gctrl_pending = gctrl + (size_t)(a.T - 1) * 2;
+  unsigned gctrl_pending = (unsigned)(a.T - 1) * 8u;      // wave-uniform byte offset of the control row written next
   float gv_pending = zero, gwc_pending = zero;
-  StateIn cur;
-  UpIn up;
-  load_state(max(n_steps - 1, 0), cur);
-  load_upstream(max(n_steps - 1, 0) + 1 < a.T ? max(n_steps - 1, 0) + 1 : 0, up);
-  __builtin_amdgcn_s_waitcnt(0);
-  for (int n = n_steps - 1; n >= 0; --n) {
-    add_upstream_state(up);
-    const float x = cur.x, xd = cur.xd, w = cur.w, R0 = cur.R0, R1 = cur.R1, R2 = cur.R2;
-    const float cv = cur.cv, cw = cur.cw;
 
-    // ------------------------------------------------------------------------------------------------
-    // forward recompute (the arithmetic of rollout_fwd_cp_kernel.h)
-    // ------------------------------------------------------------------------------------------------
-    const float r = P0 * R0 + P1 * R1 + P2 * R2;
+  // Everything of a step that does not depend on the adjoint: the forward recompute (the arithmetic of
+  // rollout_fwd_cp_kernel.h) from the saved state the step started from.  The adjoint recurrence is the only serial part of
+  // the backward, so the loop is a two-stage software pipeline: while the vector-Jacobian chain of step n runs, the
+  // recompute of step n - 1 (its gathers included) runs beside it in the same basic block -- two independent instruction
+  // streams that fill each other's dependency stalls -- and the saved rows are loaded two steps ahead.
+  struct Rec {
+    float R0, R1, R2, r1, r2, w1, w2, vp, e, il, coln2, tv, h;
+    float wq, wa, wb, zc, mcv, mub, nrm, inl, cj, inv_csum, A, F0, F1, Fr, Nn, cmdv, s, sn, stv, Gf, f1, f2, wraw;
+    int idx;
+  };
+  auto recompute = [&](const StateIn& st, Rec& k) {
+    const float x = st.x, xd = st.xd, w = st.w;
+    k.R0 = st.R0; k.R1 = st.R1; k.R2 = st.R2;
+    k.h = st.t1 - st.t0;
+    const float r = P0 * st.R0 + P1 * st.R1 + P2 * st.R2;
     const float pc = r + x;
     const float lim = 262144.0f;
     const float uq = M::cell_coord(pc, a.d_max, a.res, a.inv_res);
     const int ui = (int)M::clamp(uq, -lim, lim);
     const float fr = uq - (float)ui;
     const int base = dppi<kB1>(ui) + __mul24(a.H, dppi<kB0>(ui));
-    const int idx = min(max(base + cell_off, 0), last);
-    const float zc = ld32(zmap, moff + (unsigned)idx);
-    const float mc = ld32(mumap, moff + (unsigned)idx);
-    // issue order (vmcnt is one in-order counter): gathers | atomics + control-gradient store deferred from the previous
-    // step | prefetch of the next step's rows
-    flush_stash();
-    gctrl_pending[0] = gv_pending; gctrl_pending[1] = gwc_pending;      // every lane of the row: same address, same value
-    StateIn nxt;
-    UpIn up_next;
-    load_state(max(n - 1, 0), nxt);
-    load_upstream(n, up_next);          // output row n = the row step n - 1 produced (row 0 after the loop)
-
-    const float wa = fmaf(wa_s, dpp<kB0>(fr), wa_o), wb = fmaf(wb_s, dpp<kB1>(fr), wb_o);
-    const float wq = wa * wb;
-    const float r1 = dpp<kRot1>(r), r2 = dpp<kRot2>(r);
-    const float w1 = dpp<kRot1>(w), w2 = dpp<kRot2>(w);
-    const float vp = xd + (w1 * r2 - w2 * r1);
-    const float coln2 = dot3(R0, R0);
-    const float il = M::inv_len(coln2);
-    const float e = R0 * il;
-    const float tv = tv_v * cv + tv_w * cw;
-
-    const float zq = sum4(wq * zc);
-    const float mcv = has_mu ? mc : one;
-    const float mub = sum4(wq * mcv);
-    const float dz = zc - dpp<kB0>(zc);
+    k.idx = min(max(base + cell_off, 0), last);
+    k.zc = ld32(zmap, moff + (unsigned)k.idx);
+    const float mc = ld32(mumap, moff + (unsigned)k.idx);
+    k.wa = fmaf(wa_s, dpp<kB0>(fr), wa_o); k.wb = fmaf(wb_s, dpp<kB1>(fr), wb_o);
+    k.wq = k.wa * k.wb;
+    k.r1 = dpp<kRot1>(r); k.r2 = dpp<kRot2>(r);
+    k.w1 = dpp<kRot1>(w); k.w2 = dpp<kRot2>(w);
+    k.vp = xd + (k.w1 * k.r2 - k.w2 * k.r1);
+    k.coln2 = dot3(st.R0, st.R0);
+    k.il = M::inv_len(k.coln2);
+    k.e = st.R0 * k.il;
+    k.tv = tv_v * st.cv + tv_w * st.cw;
+    const float zq = dot4(k.wq, k.zc);
+    k.mcv = has_mu ? mc : one;
+    k.mub = dot4(k.wq, k.mcv);
+    const float dz = k.zc - dpp<kB0>(k.zc);
     const float u = fmaf(dpp<kN12>(dz), n_mul, n_add);
-    const float inl = M::inv_len(dot3(u, u));
-    const float nrm = u * inl;
+    k.inl = M::inv_len(dot3(u, u));
+    k.nrm = u * k.inl;
     const float dh = dpp<kB2>(pc) - zq;
     float cj = M::sigmoid_m10(dh);
-    cj = act ? cj : zero;
-    const float csum = sum_points(cj);
-    const float inv_csum = M::div(one, csum);
-    const float vn = dot3(vp, nrm);
-    const float A = a.k * dh + a.damp * vn;
-    const float F0 = -(A * nrm);
-    const float F1 = F0 * cj * inv_csum;
-    const float Fr = M::clamp(F1, -mg, mg);
-    const float Nn = M::sqrt(dot3(Fr, Fr));
-    const float cmdv = tv * e - vp;
-    const float s = mub * cmdv;
-    const float sn = dot3(s, nrm);
-    const float stv = s - sn * nrm;
-    const float Gf = Nn * stv;
-    const float Ff = M::clamp(Gf, -mg, mg);
-    const float f = Fr + Ff;
-    const float f1 = dpp<kRot1>(f), f2 = dpp<kRot2>(f);
-    const float tau = r1 * f2 - r2 * f1;
-    const float Tsum = sum_points(tau);
-    const float wraw = I0 * dpp<kB0>(Tsum) + I1 * dpp<kB1>(Tsum) + I2 * dpp<kB2>(Tsum);
+    k.cj = act ? cj : zero;
+    k.inv_csum = M::div(one, sum_points(k.cj));
+    const float vn = dot3(k.vp, k.nrm);
+    k.A = a.k * dh + a.damp * vn;
+    k.F0 = -(k.A * k.nrm);
+    k.F1 = k.F0 * k.cj * k.inv_csum;
+    k.Fr = M::clamp(k.F1, -mg, mg);
+    k.Nn = M::sqrt(dot3(k.Fr, k.Fr));
+    k.cmdv = k.tv * k.e - k.vp;
+    k.s = k.mub * k.cmdv;
+    k.sn = dot3(k.s, k.nrm);
+    k.stv = k.s - k.sn * k.nrm;
+    k.Gf = k.Nn * k.stv;
+    const float Ff = M::clamp(k.Gf, -mg, mg);
+    const float f = k.Fr + Ff;
+    k.f1 = dpp<kRot1>(f); k.f2 = dpp<kRot2>(f);
+    const float Tsum = sum_points(k.r1 * k.f2 - k.r2 * k.f1);
+    k.wraw = I0 * dpp<kB0>(Tsum) + I1 * dpp<kB1>(Tsum) + I2 * dpp<kB2>(Tsum);
+  };
 
-    // ------------------------------------------------------------------------------------------------
-    // integrator backward (torchdiffeq fixed-grid Euler): adjoint of the step's outputs -> (g_xdd, g_wd, g_Fs, g_Ff)
-    // ------------------------------------------------------------------------------------------------
-    const float h = cur.t1 - cur.t0;
+  // vector-Jacobian product of step n given its recomputed intermediates and the upstream gradient of the forces it fed
+  auto vjp = [&](int n, const Rec& k, const UpIn& up) {
+    const float h = k.h, w1 = k.w1, w2 = k.w2, r1 = k.r1, r2 = k.r2, nrm = k.nrm, cj = k.cj, inv_csum = k.inv_csum;
+    // ---- integrator backward (torchdiffeq fixed-grid Euler): adjoint of the step's outputs -> (g_xdd, g_wd, g_Fs, g_Ff) ----
     laFs += act ? up.gFs : zero;
     laFf += act ? up.gFf : zero;
     const float gxdd = h * lxd, gwd = h * lw;
@@ -208,58 +202,55 @@ __global__ void __launch_bounds__(256) rollout_bwd_cp_kernel(const RolloutBwdArg
     {   // R' = R + h [w]x R, column by column: d/dw of (w x R_j) . g_j = R_j x g_j ; d/dR_j = g_j x w   (g_j = h lR[:, j])
       const float g0 = h * lR0, g1 = h * lR1, g2 = h * lR2;
       const float g01 = dpp<kRot1>(g0), g02 = dpp<kRot2>(g0), g11 = dpp<kRot1>(g1), g12 = dpp<kRot2>(g1), g21 = dpp<kRot1>(g2), g22 = dpp<kRot2>(g2);
-      lw += (dpp<kRot1>(R0) * g02 - dpp<kRot2>(R0) * g01) + (dpp<kRot1>(R1) * g12 - dpp<kRot2>(R1) * g11) + (dpp<kRot1>(R2) * g22 - dpp<kRot2>(R2) * g21);
+      lw += (dpp<kRot1>(k.R0) * g02 - dpp<kRot2>(k.R0) * g01) + (dpp<kRot1>(k.R1) * g12 - dpp<kRot2>(k.R1) * g11) + (dpp<kRot1>(k.R2) * g22 - dpp<kRot2>(k.R2) * g21);
       lR0 += g01 * w2 - g02 * w1;
       lR1 += g11 * w2 - g12 * w1;
       lR2 += g21 * w2 - g22 * w1;
     }
-
-    // ------------------------------------------------------------------------------------------------
-    // RHS backward
-    // ------------------------------------------------------------------------------------------------
-    const float mwd = inside(wraw, -a.omega_max, a.omega_max) ? gwd : zero;
+    // ---- RHS backward ----
+    const float mwd = inside(k.wraw, -a.omega_max, a.omega_max) ? gwd : zero;
     const float gtau = J0 * dpp<kB0>(mwd) + J1 * dpp<kB1>(mwd) + J2 * dpp<kB2>(mwd);      // I^-T m
     const float gsum = gxdd * a.inv_mass;
     const float gt1 = dpp<kRot1>(gtau), gt2 = dpp<kRot2>(gtau);
     const float gf = gt1 * r2 - gt2 * r1;                 // tau += r x f : df = gtau x r
-    float gr = f1 * gt2 - f2 * gt1;                       //                dr = f x gtau
+    float gr = k.f1 * gt2 - k.f2 * gt1;                   //                dr = f x gtau
     float gFr = gFr_up + gsum + gf;
     const float gFf_ = gFf_up + gsum + gf;
-    const float gG = inside(Gf, -mg, mg) ? gFf_ : zero;
-    const float gNn = dot3(gG, stv);
-    const float gst = Nn * gG;
+    const float gG = inside(k.Gf, -mg, mg) ? gFf_ : zero;
+    const float gNn = dot3(gG, k.stv);
+    const float gst = k.Nn * gG;
     const float gsn = -dot3(gst, nrm);
-    float gn = gsn * s - sn * gst;
+    float gn = gsn * k.s - k.sn * gst;
     const float gslip = gst + gsn * nrm;
-    const float gmuq = dot3(gslip, cmdv);
-    const float gcmd = mub * gslip;
+    const float gmuq = dot3(gslip, k.cmdv);
+    const float gcmd = k.mub * gslip;
     float gvp = -gcmd;
-    const float gtv = dot3(gcmd, e);                       // tv_v = tv_w = 0 for non-driving points
-    const float ge_p = tv * gcmd;
+    const float gtv = dot3(gcmd, k.e);                     // tv_v = tv_w = 0 for non-driving points
+    const float ge_p = k.tv * gcmd;
     const float gv_p = tv_v * gtv, gwc_p = tv_w * gtv;
-    gFr = fmaf(Nn > zero ? gNn * M::div(one, Nn) : zero, Fr, gFr);
-    const float gF1 = inside(F1, -mg, mg) ? gFr : zero;
-    const float dF = dot3(gF1, F0);
+    gFr = fmaf(k.Nn > zero ? gNn * M::div(one, k.Nn) : zero, k.Fr, gFr);
+    const float gF1 = inside(k.F1, -mg, mg) ? gFr : zero;
+    const float dF = dot3(gF1, k.F0);
     const float gc_p = dF * inv_csum;
     const float gS = sum_points(-(dF * cj) * inv_csum * inv_csum);
     const float gF0 = gF1 * cj * inv_csum;
     const float gA = -dot3(gF0, nrm);
-    gn = fmaf(-A, gF0, gn);
+    gn = fmaf(-k.A, gF0, gn);
     const float gdh_p = a.k * gA;
     const float gvn = a.damp * gA;
     gvp = fmaf(gvn, nrm, gvp);
-    gn = fmaf(gvn, vp, gn);
+    gn = fmaf(gvn, k.vp, gn);
     const float gcw = gc_p + gS;
     const float gdh = gdh_p + gcw * (-10.0f) * cj * (one - cj);
     const float gzq = -gdh;
     // n = u / |u|, u = (-gx, -gy, 1): components 0, 1 carry the finite differences
     const float dotn = dot3(gn, nrm);
-    const float gg = -((gn - dotn * nrm) * inl) * a.inv_res;      // lane 0: ggx, lane 1: ggy
-    const float ggp = dpp<0x51>(gg);                                // quad_perm [1,0,1,1]
-    const float nz = fmaf(gzq, wq, sA * gg + sB * ggp);
-    const float nm = gmuq * wq;
+    const float gg = -((gn - dotn * nrm) * k.inl) * a.inv_res;      // lane 0: ggx, lane 1: ggy
+    const float ggp = dpp<0x51>(gg);                                  // quad_perm [1,0,1,1]
+    const float nz = fmaf(gzq, k.wq, cgA * gg + cgB * ggp);
+    const float nm = gmuq * k.wq;
     {   // this lane's cell accumulator
-      const unsigned ni = (unsigned)idx;
+      const unsigned ni = (unsigned)k.idx;
       const bool same = !act | (ni == acc_idx);          // absent points contribute exact zeros: never flushed
       st_pending = !same;
       st_idx = acc_idx; st_z = acc_z; st_m = acc_m;
@@ -268,8 +259,8 @@ __global__ void __launch_bounds__(256) rollout_bwd_cp_kernel(const RolloutBwdArg
       acc_m = same ? acc_m + nm : nm;
     }
     // d(sample)/d(position) through the fractions only: d wq / d fx = wa_s * wb, d wq / d fy = wb_s * wa
-    const float vq = gzq * zc + gmuq * mcv;
-    const float gpx = sum4(vq * (wa_s * wb)), gpy = sum4(vq * (wb_s * wa));
+    const float vq = gzq * k.zc + gmuq * k.mcv;
+    const float gpx = dot4(vq, wa_s * k.wb), gpy = dot4(vq, wb_s * k.wa);
     const float gp = q == 0 ? gpx * a.inv_res : (q == 1 ? gpy * a.inv_res : gdh);
     // v_p = xd + w x r
     const float gvp1 = dpp<kRot1>(gvp), gvp2 = dpp<kRot2>(gvp);
@@ -284,21 +275,49 @@ __global__ void __launch_bounds__(256) rollout_bwd_cp_kernel(const RolloutBwdArg
     const float ge = sum_points(ge_p);
     const float gv = sum_points(gv_p), gwc = sum_points(gwc_p);
     {   // e = col0(R) / max(|col0|, eps): through |col0| only when it is >= eps
-      const float dote = coln2 >= 1e-12f ? dot3(ge, e) : zero;
-      lR0 = fmaf(ge - dote * e, il, lR0);
+      const float dote = k.coln2 >= 1e-12f ? dot3(ge, k.e) : zero;
+      lR0 = fmaf(ge - dote * k.e, k.il, lR0);
     }
-    gctrl_pending = gctrl + n * 2; gv_pending = gv; gwc_pending = gwc;
-    cur = nxt;
-    up = up_next;
+    gctrl_pending = __builtin_amdgcn_readfirstlane((unsigned)n * 8u); gv_pending = gv; gwc_pending = gwc;      // stored by the next iteration (or after the loop)
+  };
+
+  // One iteration.  Memory operations in program order (vmcnt is one in-order counter over loads, stores and atomics):
+  // prefetch of the rows of step n - 2 and of output row n | gathers of step n - 1 (inside recompute) | the atomics and the
+  // control-gradient store deferred from step n + 1 -- so no wait of this or the next iteration covers a younger store.
+  auto body = [&](int n, const Rec& rec, Rec& rec_next, const StateIn& s_prev, StateIn& s_pp, const UpIn& up, UpIn& up_next) {
+    add_upstream_state(up);
+    load_state(max(n - 2, 0), s_pp);
+    load_upstream(n, up_next);            // output row n = the row step n - 1 produced (row 0: added after the loop)
+    recompute(s_prev, rec_next);          // step n - 1 (after step 0: a harmless repeat of step 0)
+    flush_stash();
+    bstore2(rGctrl, v_ctrl, gctrl_pending, gv_pending, gwc_pending);      // every lane of the row: same address, same value
+    vjp(n, rec, up);
+  };
+
+  StateIn sA, sB;
+  UpIn uA, uB;
+  Rec recA, recB;
+  int n = n_steps - 1;
+  load_state(max(n, 0), sA);
+  load_upstream(min(max(n, 0) + 1, a.T - 1), uA);
+  load_state(max(n - 1, 0), sB);
+  recompute(sA, recA);
+  __builtin_amdgcn_s_waitcnt(0);
+  for (; n >= 1; n -= 2) {
+    body(n, recA, recB, sB, sA, uA, uB);
+    body(n - 1, recB, recA, sA, sB, uB, uA);
   }
+  if (n == 0) body(0, recA, recB, sB, sA, uA, uB);
+  // the upstream gradient of output row 0 sits in the buffer the last iteration prefetched into
+  UpIn up = (n_steps & 1) ? uB : uA;
   flush_stash();
-  gctrl_pending[0] = gv_pending; gctrl_pending[1] = gwc_pending;
+  bstore2(rGctrl, v_ctrl, gctrl_pending, gv_pending, gwc_pending);
   if (act) {                               // what is still accumulated in registers
     atomic_add(at32(gzmap, goff + acc_idx), acc_z);
     if (want_gmu) atomic_add(at32(gmumap, goff + acc_idx), acc_m);
   }
   // output 0 is the initial state itself (its forces are constant zeros)
-  if (n_steps == 0) load_upstream(0, up);      // T == 1: the loop never prefetched row 0
+  if (n_steps == 0) load_upstream(0, up);      // T == 1: the loop never ran
   add_upstream_state(up);
 
   // terrain snap of the initial height: x.z = mean_i blend(z; cell((R0 P_i + x0).xy))   (dphysics.py:567-571)
@@ -317,7 +336,7 @@ __global__ void __launch_bounds__(256) rollout_bwd_cp_kernel(const RolloutBwdArg
     const float wa = fmaf(wa_s, dpp<kB0>(fr), wa_o), wb = fmaf(wb_s, dpp<kB1>(fr), wb_o);
     const float zc = ld32(zmap, moff + (unsigned)idx);
     if (act) atomic_add(at32(gzmap, goff + (unsigned)idx), g * (wa * wb));
-    const float gpx = sum4(zc * (wa_s * wb)) * g * a.inv_res, gpy = sum4(zc * (wb_s * wa)) * g * a.inv_res;
+    const float gpx = dot4(zc, wa_s * wb) * g * a.inv_res, gpy = dot4(zc, wb_s * wa) * g * a.inv_res;
     float gpxy = q == 0 ? gpx : (q == 1 ? gpy : zero);
     gpxy = act ? gpxy : zero;
     gx0 = (q < 2 ? lx : zero) + sum_points(gpxy);        // the caller's x0.z is overwritten, so nothing flows to it

@@ -45,10 +45,79 @@ __device__ __forceinline__ float mask_or(float acc, float v, unsigned m) {
 }
 // sum over the four lanes of a quad (cell roles)
 __device__ __forceinline__ float sum4(float v) { v += dpp<kXor1>(v); return v + dpp<kXor2>(v); }
+// sum_q a_q b_q over the four lanes of a quad, THE SAME BITS in all four: the products are rounded before the butterfly (a
+// contracted first add would make lane 0 hold fma(a0, b0, round(a1 b1)) and lane 1 fma(a1, b1, round(a0 b0)) -- one ulp apart;
+// on the sampled height that ulp is multiplied by the contact stiffness, 5e4 N/m), and (p0 + p1) + (p2 + p3) commutes
+__device__ __forceinline__ float dot4(float a, float b) {
+#pragma clang fp contract(off)
+  float v = a * b;
+  v += dpp<kXor1>(v);
+  return v + dpp<kXor2>(v);
+}
 // sum over the four quads of a row, lane position by lane position (contact points of one rollout)
 __device__ __forceinline__ float sum_points(float v) { v += dpp<kRor8>(v); return v + dpp<kRor4>(v); }
 // (a x b)_c given the components of a and b in the lanes: a_{c+1} b_{c+2} - a_{c+2} b_{c+1}
 __device__ __forceinline__ float cross_c(float a, float b) { return dpp<kRot1>(a) * dpp<kRot2>(b) - dpp<kRot2>(a) * dpp<kRot1>(b); }
+
+// ---- rows through buffer descriptors -------------------------------------------------------------------------------------
+// A row of a [T][B][...] array is addressed as descriptor base (SGPRs, built once from the kernel argument) + a per-lane byte
+// offset that never changes (VGPR) + a wave-uniform byte offset of the time step (SGPR, scalar arithmetic): no vector
+// instruction is spent on addresses inside the loop (64-bit per-lane pointer bumps were ~17 of the backward's ~420).
+// The host keeps every array of a component-parallel launch below 4 GiB; num_records = 2^32 - 1 = no bounds clamp.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+constexpr int kAuxNT = 2;   // streaming access: do not keep the line (the map cells the gathers re-use stay in L1 / L2)
+#ifndef MF_CP_NO_BUFFER
+using Rsrc = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ Rsrc make_rsrc(const void* p) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xFFFFFFFFu, 0x00020000);
+}
+__device__ __forceinline__ float bload1(Rsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, kAuxNT));
+}
+// (the whole vector is bit-cast, THEN its elements are taken: __builtin_bit_cast applied to an element expression `v.y` of an
+// ext_vector reads element 0 with this compiler -- tools/microbench/buffer_ops.hip checks the accessors on the device)
+__device__ __forceinline__ void bload2(Rsrc r, unsigned voff, unsigned soff, float* a, float* b) {
+  const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, kAuxNT));
+  *a = v.x; *b = v.y;
+}
+__device__ __forceinline__ void bload3(Rsrc r, unsigned voff, unsigned soff, float* a, float* b, float* c) {
+  const f32x3 v = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(r, voff, soff, kAuxNT));
+  *a = v.x; *b = v.y; *c = v.z;
+}
+__device__ __forceinline__ void bstore1(Rsrc r, unsigned voff, unsigned soff, float a) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, a), r, voff, soff, kAuxNT);
+}
+__device__ __forceinline__ void bstore2(Rsrc r, unsigned voff, unsigned soff, float a, float b) {
+  const f32x2 v = {a, b};
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
+}
+__device__ __forceinline__ void bstore3(Rsrc r, unsigned voff, unsigned soff, float a, float b, float c) {
+  const f32x3 v = {a, b, c};
+  __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u32x3, v), r, voff, soff, kAuxNT);
+}
+#else   // A/B and debugging: the same accessors on plain global addresses
+using Rsrc = const char*;
+__device__ __forceinline__ Rsrc make_rsrc(const void* p) { return reinterpret_cast<const char*>(p); }
+struct __attribute__((aligned(4))) Pk2 { float a, b; };
+struct __attribute__((aligned(4))) Pk3 { float a, b, c; };
+__device__ __forceinline__ float bload1(Rsrc r, unsigned voff, unsigned soff) { return *reinterpret_cast<const float*>(r + (size_t)soff + (size_t)voff); }
+__device__ __forceinline__ void bload2(Rsrc r, unsigned voff, unsigned soff, float* a, float* b) {
+  const Pk2 v = *reinterpret_cast<const Pk2*>(r + (size_t)soff + (size_t)voff); *a = v.a; *b = v.b;
+}
+__device__ __forceinline__ void bload3(Rsrc r, unsigned voff, unsigned soff, float* a, float* b, float* c) {
+  const Pk3 v = *reinterpret_cast<const Pk3*>(r + (size_t)soff + (size_t)voff); *a = v.a; *b = v.b; *c = v.c;
+}
+__device__ __forceinline__ void bstore1(Rsrc r, unsigned voff, unsigned soff, float a) { *reinterpret_cast<float*>(const_cast<char*>(r) + (size_t)soff + (size_t)voff) = a; }
+__device__ __forceinline__ void bstore2(Rsrc r, unsigned voff, unsigned soff, float a, float b) {
+  *reinterpret_cast<Pk2*>(const_cast<char*>(r) + (size_t)soff + (size_t)voff) = Pk2{a, b};
+}
+__device__ __forceinline__ void bstore3(Rsrc r, unsigned voff, unsigned soff, float a, float b, float c) {
+  *reinterpret_cast<Pk3*>(const_cast<char*>(r) + (size_t)soff + (size_t)voff) = Pk3{a, b, c};
+}
+#endif
 
 }  // namespace cp
 }  // namespace mf

@@ -5,11 +5,12 @@
 
 namespace mf {
 
-// Waves of a component-parallel launch up to which it beats the one-point-per-lane mapping: one wave per SIMD (1024 on the
-// 256 CUs).  Above, both mappings keep every SIMD busy and the 4x fewer lanes per rollout of the G = 4 kernels win.
-// MF_CP_MAX_WAVES overrides (tuning / A-B runs; 0 disables the mapping).
+// Waves of a component-parallel launch up to which it beats the one-point-per-lane mapping (4 rollouts per wave here, 16 there).
+// Measured, forward, N = 4 (tools/ab_cp.py; ms component-parallel vs one point per lane): B = 256 0.17 / 0.29, 1024 0.18 / 0.30,
+// 2048 0.22 / 0.30, 4096 0.32 / 0.30 -- so up to 512 waves, one per two SIMDs.  MF_CP_MAX_WAVES overrides (tuning / A-B runs;
+// 0 disables the mapping).
 static long long cp_max_waves() {
-  static const long long v = getenv("MF_CP_MAX_WAVES") ? atoll(getenv("MF_CP_MAX_WAVES")) : 1024;
+  static const long long v = getenv("MF_CP_MAX_WAVES") ? atoll(getenv("MF_CP_MAX_WAVES")) : 512;
   return v;
 }
 

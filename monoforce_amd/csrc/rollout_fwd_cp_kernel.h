@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
     const float pc = (P0 * R0 + P1 * R1 + P2 * R2) + x;
     int idx; float wq;
     footprint(pc, &idx, &wq);
-    const float zq = sum4(wq * ld32(zmap, moff + (unsigned)idx));
+    const float zq = dot4(wq, ld32(zmap, moff + (unsigned)idx));
     const float acc = sum_points(act ? zq : zero);
     const float xz = acc / (float)a.N;
     x = cc == 2 ? xz : x;
@@ -148,8 +148,8 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
   auto contact = [&](const Geo& g, float vxd, float vw, float tv, float* xdd, float* wd, float* oFr, float* oFf) {
     const float r1 = dpp<kRot1>(g.r), r2 = dpp<kRot2>(g.r);
     const float vp = vxd + (dpp<kRot1>(vw) * r2 - dpp<kRot2>(vw) * r1);   // v_p = xd + w x r   (:204)
-    const float zq = sum4(g.wq * g.zc);                               // height under the point (:211)
-    const float mub = sum4(g.wq * (has_mu ? g.mc : one));             // friction (:216); no map = a map of ones (:562)
+    const float zq = dot4(g.wq, g.zc);                               // height under the point (:211)
+    const float mub = dot4(g.wq, has_mu ? g.mc : one);             // friction (:216); no map = a map of ones (:562)
     const float dz = g.zc - dpp<kB0>(g.zc);                           // lane 1: z_f - z_c, lane 2: z_l - z_c
     const float u = fmaf(dpp<kN12>(dz), n_mul, n_add);                // (-gx, -gy, 1)
     const float nrm = u * M::inv_len(dot3(u, u));
