@@ -265,3 +265,82 @@ def test_config4_full_size_step_vs_oracles():
     assert not any(bool(torch.isnan(t).any()) for t in grads)
     loss, parts2 = step.step(batch)          # and the full step (clip + Adam) runs
     assert np.isfinite(float(loss))
+
+
+@pytest.mark.parametrize('integ', [0, 1])
+@pytest.mark.parametrize('friction', [False, True])
+@pytest.mark.parametrize('given_state', [False, True])
+def test_component_parallel_mapping_vs_reference_golden(integ, friction, given_state):
+    """The 16-lanes-per-rollout kernels (MF_LANES_COMPONENT; what small batches of a 4-point body run on by default) against
+    the reference's own outputs and autograd gradients: case A of rollout_small.npz (N = 4, T = 48), plus oracle-checked
+    variants with a friction map and a given start state (per-rollout maps, start poses off the origin)."""
+    from tests.golden_state import given_state as make_state
+    g = hp.load('rollout_small')
+    pts, masks, z, ctrl, _, _ = hp.small_case(g, 'A', torch.float32)
+    B = z.shape[0]
+    mu = None
+    if friction:
+        from monoforce_amd import synthetic as syn
+        mu = torch.stack([syn.wave_friction(hp.SMALL['d_max'], hp.SMALL['grid_res'], 0.5, 1.0, 1.1 + 0.2 * k, 0.8) for k in range(B)])
+    state = tuple(t.float() for t in make_state(B)) if given_state else None
+    dp = make_dphysics(pts, masks, integ, hp.SMALL['grid_res'], hp.SMALL['d_max'], points_per_lane=16)
+    zd = z.to(DEV).requires_grad_(True)
+    cd = ctrl.to(DEV).requires_grad_(True)
+    md = None if mu is None else mu.to(DEV).requires_grad_(True)
+    st = None if state is None else tuple(s.clone().to(DEV) for s in state)
+    states, forces = dp(z_grid=zd, controls=cd, state=st, friction=md)
+    outs = list(states) + list(forces)
+    loss = hp.probe_loss(outs, torch.float32)
+    loss.backward()
+    if not friction and not given_state:       # the reference itself
+        pre = f'A/f32/i{integ}/'
+        for k, o in zip(hp.OUT_KEYS, outs):
+            assert hp.rel_err(o, g[pre + k]) <= 1e-4, (k, hp.rel_err(o, g[pre + k]))
+        assert abs(float(loss) - float(g[pre + 'loss'])) <= 2e-4 * abs(float(g[pre + 'loss'])) + 2e-4
+        assert hp.rel_err(zd.grad, g[pre + 'g_z']) <= 2e-4, hp.rel_err(zd.grad, g[pre + 'g_z'])
+        assert hp.rel_err(cd.grad, g[pre + 'g_ctrl']) <= 2e-4, hp.rel_err(cd.grad, g[pre + 'g_ctrl'])
+    # ... and the oracle on the same inputs (float64 oracle: the float32 kernels are judged against exact arithmetic)
+    spec = hp.spec_from(pts, masks, integ, hp.SMALL['grid_res'], hp.SMALL['d_max'])
+    zc, cc = z.double().requires_grad_(True), ctrl.double().requires_grad_(True)
+    mc = None if mu is None else mu.double().requires_grad_(True)
+    sc = None if state is None else tuple(s.double().clone() for s in state)
+    rs, rf = orc.rollout(spec, zc, cc, state=sc, friction=mc)
+    refs = list(rs) + list(rf)
+    hp.probe_loss(refs, torch.float64).backward()
+    for k, o, r in zip(hp.OUT_KEYS, outs, refs):
+        assert hp.rel_err(o, r) <= 1e-4, (k, hp.rel_err(o, r))
+    assert hp.rel_err(zd.grad, zc.grad) <= 2e-4, hp.rel_err(zd.grad, zc.grad)
+    assert hp.rel_err(cd.grad, cc.grad) <= 2e-4, hp.rel_err(cd.grad, cc.grad)
+    if friction:
+        assert hp.rel_err(md.grad, mc.grad) <= 2e-4, hp.rel_err(md.grad, mc.grad)
+    if st is not None:
+        assert hp.rel_err(st[0].cpu(), sc[0]) <= 1e-5       # the in-place terrain snap of the caller's start position
+
+
+@pytest.mark.parametrize('N', [1, 2, 3])
+def test_component_parallel_mapping_with_fewer_points(N):
+    """Bodies of fewer than 4 contact points leave quads of the 16-lane row without a point: they must contribute nothing."""
+    from monoforce_amd import synthetic as syn
+    pts4, _ = syn.robot_points_4()
+    pts = pts4[:N].copy()
+    if N < 3:
+        pts[:, 2] += np.array([0.0, 0.05])[:N]        # (inertia of 1 or 2 points is singular: the test supplies its own)
+    masks = [pts[:, 1] > 0, pts[:, 1] <= 0]
+    B, T = 5, 40
+    z = torch.stack([syn.bump_terrain(syn.bump_params(20 + k), 1.6, 0.1) * 0.3 for k in range(B)])
+    ctrl = syn.varying_controls(B, T, seed=3)
+    base = make_dphysics(pts4, [pts4[:, 1] > 0, pts4[:, 1] <= 0], 1, 0.1, 1.6)
+    outs = {}
+    for ppl in (16, 1):
+        dp = make_dphysics(pts4, [pts4[:, 1] > 0, pts4[:, 1] <= 0], 1, 0.1, 1.6, points_per_lane=ppl)
+        dp.dphys_cfg.robot_points = torch.as_tensor(pts)
+        dp.dphys_cfg.driving_parts = [torch.as_tensor(m) for m in masks]
+        dp.x_points = dp.dphys_cfg.robot_points.unsqueeze(0).to(dp.device)
+        dp._cache = {('iinv', torch.float32): base._iinv(torch.float32)}      # the 4-point body's inertia for both mappings
+        zd = z.to(DEV).requires_grad_(True)
+        st, fo = dp(zd, ctrl.to(DEV))
+        (st[0].square().sum() + 1e-3 * fo[0].square().sum()).backward()
+        outs[ppl] = [o.detach().cpu() for o in list(st) + list(fo)] + [zd.grad.cpu()]
+    for k, a_, b_ in zip(hp.OUT_KEYS + ('g_z',), outs[16], outs[1]):
+        assert a_.shape == b_.shape and torch.isfinite(a_).all()
+        assert hp.rel_err(a_, b_) <= (2e-4 if k == 'g_z' else 1e-4), (k, hp.rel_err(a_, b_))
