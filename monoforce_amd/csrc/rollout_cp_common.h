@@ -59,46 +59,14 @@ __device__ __forceinline__ float sum_points(float v) { v += dpp<kRor8>(v); retur
 // (a x b)_c given the components of a and b in the lanes: a_{c+1} b_{c+2} - a_{c+2} b_{c+1}
 __device__ __forceinline__ float cross_c(float a, float b) { return dpp<kRot1>(a) * dpp<kRot2>(b) - dpp<kRot2>(a) * dpp<kRot1>(b); }
 
-// ---- rows through buffer descriptors -------------------------------------------------------------------------------------
-// A row of a [T][B][...] array is addressed as descriptor base (SGPRs, built once from the kernel argument) + a per-lane byte
-// offset that never changes (VGPR) + a wave-uniform byte offset of the time step (SGPR, scalar arithmetic): no vector
-// instruction is spent on addresses inside the loop (64-bit per-lane pointer bumps were ~17 of the backward's ~420).
-// The host keeps every array of a component-parallel launch below 4 GiB; num_records = 2^32 - 1 = no bounds clamp.
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x3 __attribute__((ext_vector_type(3)));
-constexpr int kAuxNT = 2;   // streaming access: do not keep the line (the map cells the gathers re-use stay in L1 / L2)
-#ifndef MF_CP_NO_BUFFER
-using Rsrc = __amdgpu_buffer_rsrc_t;
-__device__ __forceinline__ Rsrc make_rsrc(const void* p) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0xFFFFFFFFu, 0x00020000);
-}
-__device__ __forceinline__ float bload1(Rsrc r, unsigned voff, unsigned soff) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, kAuxNT));
-}
-// (the whole vector is bit-cast, THEN its elements are taken: __builtin_bit_cast applied to an element expression `v.y` of an
-// ext_vector reads element 0 with this compiler -- tools/microbench/buffer_ops.hip checks the accessors on the device)
-__device__ __forceinline__ void bload2(Rsrc r, unsigned voff, unsigned soff, float* a, float* b) {
-  const f32x2 v = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, kAuxNT));
-  *a = v.x; *b = v.y;
-}
-__device__ __forceinline__ void bload3(Rsrc r, unsigned voff, unsigned soff, float* a, float* b, float* c) {
-  const f32x3 v = __builtin_bit_cast(f32x3, __builtin_amdgcn_raw_buffer_load_b96(r, voff, soff, kAuxNT));
-  *a = v.x; *b = v.y; *c = v.z;
-}
-__device__ __forceinline__ void bstore1(Rsrc r, unsigned voff, unsigned soff, float a) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, a), r, voff, soff, kAuxNT);
-}
-__device__ __forceinline__ void bstore2(Rsrc r, unsigned voff, unsigned soff, float a, float b) {
-  const f32x2 v = {a, b};
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, voff, soff, 0);
-}
-__device__ __forceinline__ void bstore3(Rsrc r, unsigned voff, unsigned soff, float a, float b, float c) {
-  const f32x3 v = {a, b, c};
-  __builtin_amdgcn_raw_buffer_store_b96(__builtin_bit_cast(u32x3, v), r, voff, soff, kAuxNT);
-}
-#else   // A/B and debugging: the same accessors on plain global addresses
+// ---- rows of the [T][B][...] arrays -----------------------------------------------------------------------------------------
+// A row is addressed as wave-uniform base pointer + wave-uniform byte offset of the time step + a per-lane byte offset that
+// never changes (32 bits: the host keeps every array of a component-parallel launch below 4 GiB).
+// Measured alternative, NOT kept: the same accesses through buffer descriptors (raw_buffer_load / _store with the step offset
+// in the scalar soffset operand) spend no vector instruction on addresses at all, but ran slower at every batch size --
+// forward 0.207 vs 0.184 ms, backward 0.473 vs 0.439 ms at B = 1024 (twelve descriptors do not fit the scalar registers next
+// to everything else, so words of them are re-assembled with s_mov before most accesses).  tools/microbench/buffer_ops.hip
+// keeps the device check of that variant (it found that __builtin_bit_cast applied to an ext_vector ELEMENT reads element 0).
 using Rsrc = const char*;
 __device__ __forceinline__ Rsrc make_rsrc(const void* p) { return reinterpret_cast<const char*>(p); }
 struct __attribute__((aligned(4))) Pk2 { float a, b; };
@@ -110,14 +78,20 @@ __device__ __forceinline__ void bload2(Rsrc r, unsigned voff, unsigned soff, flo
 __device__ __forceinline__ void bload3(Rsrc r, unsigned voff, unsigned soff, float* a, float* b, float* c) {
   const Pk3 v = *reinterpret_cast<const Pk3*>(r + (size_t)soff + (size_t)voff); *a = v.a; *b = v.b; *c = v.c;
 }
-__device__ __forceinline__ void bstore1(Rsrc r, unsigned voff, unsigned soff, float a) { *reinterpret_cast<float*>(const_cast<char*>(r) + (size_t)soff + (size_t)voff) = a; }
+// output rows are written once and never re-read by the kernel: streaming (non-temporal) stores, so they do not evict the map
+// cells the gathers keep hitting in L1 / L2
+__device__ __forceinline__ void bstore1(Rsrc r, unsigned voff, unsigned soff, float a) {
+  __builtin_nontemporal_store(a, reinterpret_cast<float*>(const_cast<char*>(r) + (size_t)soff + (size_t)voff));
+}
 __device__ __forceinline__ void bstore2(Rsrc r, unsigned voff, unsigned soff, float a, float b) {
   *reinterpret_cast<Pk2*>(const_cast<char*>(r) + (size_t)soff + (size_t)voff) = Pk2{a, b};
 }
 __device__ __forceinline__ void bstore3(Rsrc r, unsigned voff, unsigned soff, float a, float b, float c) {
-  *reinterpret_cast<Pk3*>(const_cast<char*>(r) + (size_t)soff + (size_t)voff) = Pk3{a, b, c};
+  typedef float f3v __attribute__((ext_vector_type(3)));
+  typedef f3v __attribute__((aligned(4))) f3u;
+  const f3v v = {a, b, c};
+  __builtin_nontemporal_store(v, reinterpret_cast<f3u*>(const_cast<char*>(r) + (size_t)soff + (size_t)voff));
 }
-#endif
 
 }  // namespace cp
 }  // namespace mf

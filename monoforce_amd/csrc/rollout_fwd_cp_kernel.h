@@ -8,17 +8,6 @@
 
 namespace mf {
 
-// store / load through a wave-uniform base and a 32-bit BYTE offset (the host keeps every array of a CP launch below 4 GiB)
-__device__ __forceinline__ void st_nt(float* base, unsigned off, float v) {
-  __builtin_nontemporal_store(v, reinterpret_cast<float*>(reinterpret_cast<char*>(base) + (size_t)off));
-}
-__device__ __forceinline__ void st_nt3(float* base, unsigned off, float v0, float v1, float v2) {
-  typedef float f3v __attribute__((ext_vector_type(3)));
-  typedef f3v __attribute__((aligned(4))) f3u;
-  f3v v = {v0, v1, v2};
-  __builtin_nontemporal_store(v, reinterpret_cast<f3u*>(reinterpret_cast<char*>(base) + (size_t)off));
-}
-
 template <int INTEG, bool FORCES, bool ZMU>
 __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<float> a) {
   using namespace cp;
@@ -92,35 +81,38 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
     if (p == 0 && q == 2) a.x0[b * 3 + 2] = xz;
   }
 
-  // ---- running output offsets (bytes) off wave-uniform bases ----
+  // ---- output rows: base + per-lane byte offset (fixed) + wave-uniform byte offset of the time step (rollout_cp_common.h) ----
   const unsigned row_stride = (a.layout == MF_LAYOUT_TIME_MAJOR) ? (unsigned)a.B : 1u;   // rows between consecutive t
   const unsigned row0 = (a.layout == MF_LAYOUT_TIME_MAJOR) ? (unsigned)b : (unsigned)b * (unsigned)a.T;
-  // vec3 rows: quad 0 writes Xs, quad 1 Xds, quad 2 Omegas, quad 3 the unshifted positions (or Xs again when nobody wants them)
+  // vec3 rows: quad 0 writes Xs, quad 1 Xds, quad 2 Omegas, quad 3 the unshifted positions (or Xs again when nobody wants them):
+  // four different arrays in one store instruction, so this one takes per-lane 64-bit addresses
   float* v3base = p == 0 ? a.Xs : p == 1 ? a.Xds : p == 2 ? a.Om : (a.Xraw ? a.Xraw : a.Xs);
   const float sink_l = (p == 3 && a.Xraw) ? zero : a.sink;
   const unsigned m_xd = p == 1 ? ~0u : 0u, m_w = p == 2 ? ~0u : 0u, m_x = ~(m_xd | m_w);
-  unsigned o3 = (row0 * 3u + (unsigned)cc) * 4u;
-  unsigned o9 = (row0 * 9u + (unsigned)cc * 3u) * 4u;
+  char* p3 = reinterpret_cast<char*>(v3base) + (size_t)(row0 * 3u + (unsigned)cc) * 4u;
+  const Rsrc rRs = make_rsrc(a.Rs), rFs = make_rsrc(a.Fs), rFf = make_rsrc(a.Ff), rCtrl = make_rsrc(a.controls);
+  const unsigned o9 = (row0 * 9u + (unsigned)cc * 3u) * 4u;
   const unsigned frow = (unsigned)a.fstride * 3u;
-  unsigned of = (row0 * frow + (unsigned)p * 3u + (unsigned)cc) * 4u;
+  const unsigned of = (row0 * frow + (unsigned)p * 3u + (unsigned)cc) * 4u;
   const unsigned d3 = row_stride * 12u, d9 = row_stride * 36u, df = row_stride * frow * 4u;
+  unsigned s9 = 0u, sf = 0u;       // wave-uniform: scalar registers, scalar adds
 
   float oFs = zero, oFf = zero;   // forces of the pending output row (ODEINT: running impulses, dphysics.py:506-509)
 
-  auto emit_row = [&](unsigned adv) {
-    // the state registers ARE the pending row.  v3base differs per quad, so the store takes a per-lane 64-bit address.
-    const float vx = fmaf(R2, sink_l, x);           // Xs += Rs[..., :, 2] * m g / (k + 1e-6)   (dphysics.py:587-589)
-    const float v3 = mask_or(mask_or(mask_or(zero, vx, m_x), xd, m_xd), w, m_w);
-    __builtin_nontemporal_store(v3, reinterpret_cast<float*>(reinterpret_cast<char*>(v3base) + (size_t)o3));
-    st_nt3(a.Rs, o9, R0, R1, R2);                   // row cc of R: one 12-byte store (all quads, same address, same value)
-    if (FORCES) { st_nt(a.Fs, of, oFs); st_nt(a.Ff, of, oFf); }
-    const unsigned m = adv ? 0xFFFFFFFFu : 0u;
-    o3 += d3 & m; o9 += d9 & m; of += df & m;
+  // the pending row from explicit values (the pipelined loop has already advanced x and R when it stores the row)
+  auto emit_row = [&](float ex, float exd, float ew, float e0, float e1, float e2, unsigned adv) {
+    const float vx = fmaf(e2, sink_l, ex);          // Xs += Rs[..., :, 2] * m g / (k + 1e-6)   (dphysics.py:587-589)
+    const float v3 = mask_or(mask_or(mask_or(zero, vx, m_x), exd, m_xd), ew, m_w);
+    __builtin_nontemporal_store(v3, reinterpret_cast<float*>(p3));
+    bstore3(rRs, o9, s9, e0, e1, e2);               // row cc of R: one 12-byte store (all quads, same address, same value)
+    if (FORCES) { bstore1(rFs, of, sf, oFs); bstore1(rFf, of, sf, oFf); }
+    if (adv) { p3 += d3; s9 += d9; sf += df; }
   };
 
   const int n_steps = (INTEG == MF_INTEG_ODEINT_EULER) ? a.T - 1 : a.T;
-  const float* ctrl = a.controls + (size_t)b * a.ctrl_sb;
-  float cv = ctrl[0], cw = ctrl[1];
+  const unsigned v_ctrl = (unsigned)b * (unsigned)a.ctrl_sb * 4u;      // this rollout's control rows (bytes)
+  float cv, cw;
+  bload2(rCtrl, v_ctrl, 0u, &cv, &cw);
   float h_ode = (INTEG == MF_INTEG_ODEINT_EULER && a.T > 1) ? a.ts[1] - a.ts[0] : zero;
   // Everything of a step that depends on the pose (x, R) only: r = R P (component cc), p = r + x, this lane's footprint cell
   // and weight, the gathers, the thrust direction.  The explicit scheme knows the NEXT pose as soon as a step starts
@@ -180,7 +172,8 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
   for (int n = 0; n < n_steps; ++n) {
     // next step's controls and step size: loaded before the stores below (vmcnt retires in order)
     const int nn = min(n + 1, a.T - 1);
-    const float cv_next = ctrl[nn * a.ctrl_st + 0], cw_next = ctrl[nn * a.ctrl_st + 1];
+    float cv_next, cw_next;
+    bload2(rCtrl, v_ctrl, __builtin_amdgcn_readfirstlane((unsigned)(nn * a.ctrl_st) * 4u), &cv_next, &cw_next);
     float ts_a = zero, ts_b = zero;
     if (INTEG == MF_INTEG_ODEINT_EULER) {
       const int tp = max(min(n + 1, a.T - 2), 0);
@@ -189,17 +182,18 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
     const float tv = tv_v * cv + tv_w * cw;
     float xdd, wd, Fr, Ff;
     if (INTEG == MF_INTEG_ODEINT_EULER) {
-      // ---- row n: the state registers are that row ----
-      emit_row(1u);
       // ---- stream B: pose and geometry of step n + 1 (torchdiffeq fixed-grid euler: y_{n+1} = y_n + h f(t_n, y_n)) ----
       // dR[c][j] = w_{c+1} R[c+2][j] - w_{c+2} R[c+1][j]
       const float w1 = dpp<kRot1>(w), w2 = dpp<kRot2>(w);
       const float d0 = w1 * dpp<kRot2>(R0) - w2 * dpp<kRot1>(R0);
       const float d1 = w1 * dpp<kRot2>(R1) - w2 * dpp<kRot1>(R1);
       const float d2 = w1 * dpp<kRot2>(R2) - w2 * dpp<kRot1>(R2);
-      x = fmaf(h_ode, xd, x);
-      R0 = fmaf(h_ode, d0, R0); R1 = fmaf(h_ode, d1, R1); R2 = fmaf(h_ode, d2, R2);
-      const Geo geo_next = geometry(x, R0, R1, R2);     // (after the last step: the final pose -- unused, in range)
+      const float xn = fmaf(h_ode, xd, x);
+      const float Rn0 = fmaf(h_ode, d0, R0), Rn1 = fmaf(h_ode, d1, R1), Rn2 = fmaf(h_ode, d2, R2);
+      const Geo geo_next = geometry(xn, Rn0, Rn1, Rn2);     // (after the last step: the final pose -- unused, in range)
+      // ---- row n, AFTER the gathers in program order: their wait a step later then covers no store of this step ----
+      emit_row(x, xd, w, R0, R1, R2, 1u);
+      x = xn; R0 = Rn0; R1 = Rn1; R2 = Rn2;
       // ---- stream A: contact chain of step n ----
       contact(geo, xd, w, tv, &xdd, &wd, &Fr, &Ff);
       xd = fmaf(h_ode, xdd, xd);
@@ -210,7 +204,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
     } else {
       // dynamics(): the next pose needs this step's forces (x += xd_new h, R <- R M(w_new)): one stream
       const Geo g = geometry(x, R0, R1, R2);
-      emit_row(n > 0 ? 1u : 0u);      // n = 0: the initial state as a placeholder in row 0, overwritten one iteration later
+      emit_row(x, xd, w, R0, R1, R2, n > 0 ? 1u : 0u);      // n = 0: the initial state as a placeholder in row 0, overwritten one iteration later
       contact(g, xd, w, tv, &xdd, &wd, &Fr, &Ff);
       // update_state (:274-288): xd += xdd h ; x += xd_new h ; w += wd h ; R <- R (I + K sin + K^2 (1 - cos))
       const float h = a.dt;
@@ -239,7 +233,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
     cv = cv_next; cw = cw_next;
     h_ode = ts_b - ts_a;
   }
-  if (n_steps > 0 || INTEG == MF_INTEG_ODEINT_EULER) emit_row(1u);
+  if (n_steps > 0 || INTEG == MF_INTEG_ODEINT_EULER) emit_row(x, xd, w, R0, R1, R2, 1u);
 }
 
 // true when the component-parallel kernels cover this launch: float32 fast math, a rigid body of <= 4 points, full outputs
