@@ -154,6 +154,10 @@ typedef struct MfRolloutFwdBufs {
                            16-byte loads instead of eight 4-byte ones (the L1 looks up one line per lane and cycle: at
                            >= 16 k rollouts that bounds the kernel).  Same results, bit for bit.  Contents are undefined
                            afterwards; NULL (or any other configuration) = the maps are read where they are. */
+  const void* zmu;      /* optional, float32: the SHARED maps already interleaved, S[H][W][2] = (z, mu) per cell, holding the same
+                           values as z / mu (mf_terrain_stage_fwd_f32 writes all three in one pass).  Kernels that gather from an
+                           interleaved pair (float32 MF_MATH_FAST, rigid body of <= 64 points, one point per lane or component-
+                           parallel) read it whatever the batch size and skip their own interleave pass; the others read z / mu. */
 } MfRolloutFwdBufs;
 
 /* Point slots per Fs/Ff row the kernels chosen for (B, N, points_per_lane) need (>= N; -1 on a bad descriptor). */
@@ -267,6 +271,21 @@ int mf_physics_loss_fwd_f32(const MfLossDesc* desc, const float* Xs, const float
 int mf_physics_loss_fwd_f64(const MfLossDesc* desc, const double* Xs, const double* Xgt, const double* gt_ts, const int32_t* nearest, double* partial, void* hip_stream);
 int mf_physics_loss_bwd_f32(const MfLossDesc* desc, const float* Xs, const float* Xgt, const float* gt_ts, const int32_t* nearest, const float* gloss, float* gXs, void* hip_stream);
 int mf_physics_loss_bwd_f64(const MfLossDesc* desc, const double* Xs, const double* Xgt, const double* gt_ts, const int32_t* nearest, const double* gloss, double* gXs, void* hip_stream);
+
+/* ---- terrain staging between the BEV heads and the rollout (scripts/train.py:93-99, 233-235; lss.py:158) ------------------
+ * One pass over the head outputs geom, diff, friction (each float32 [B][H][W]):
+ *   terrain[B][H][W] = geom - diff (may be NULL);  z / mu [B][h][w] = k x k average pooling (stride k, h = H / k, w = W / k,
+ *   overhanging cells dropped like torch.nn.AvgPool2d) of terrain / friction;  zmu[B][h][w][2] = (z, mu) interleaved -- what
+ *   MfRolloutFwdBufs.zmu takes (may be NULL).
+ * _bwd: g_geom = g_terrain + upsample(gz) / k^2, g_diff = -g_geom, g_friction = upsample(gmu) / k^2; g_terrain, gz, gmu may
+ * each be NULL (= zeros); every element of the three outputs is written. */
+typedef struct MfStageDesc {
+  int32_t B, H, W, k;
+} MfStageDesc;
+int mf_terrain_stage_fwd_f32(const MfStageDesc* desc, const float* geom, const float* diff, const float* friction, float* terrain,
+                             float* z, float* mu, float* zmu, void* hip_stream);
+int mf_terrain_stage_bwd_f32(const MfStageDesc* desc, const float* g_terrain, const float* gz, const float* gmu, float* g_geom,
+                             float* g_diff, float* g_friction, void* hip_stream);
 
 /* ---- estimate_heightmap (cloudproc.py:88-148): per-cell maximum height of a point cloud + measurement mask ------------
  * points[n][3] float32 (rows with NaNs, points within r_min of the origin in xy, and points outside the open box

@@ -28,7 +28,7 @@ class MfRolloutDesc(C.Structure):
 class MfRolloutFwdBufs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('z', 'mu', 'controls', 'ts', 'points', 'part', 'x0', 'xd0', 'R0', 'w0',
                                           'Xs', 'Xds', 'Rs', 'Omegas', 'Fs', 'Ff', 'Xraw', 'joint_angles', 'cost_rows', 'path_cost',
-                                          'zmu_scratch')]
+                                          'zmu_scratch', 'zmu')]
 
 
 class MfRolloutBwdBufs(C.Structure):
@@ -49,6 +49,10 @@ class MfSplatDesc(C.Structure):
                 ('off', C.c_float * 3), ('dx', C.c_float * 3), ('lift_D', C.c_int32), ('lift_hw', C.c_int32)]
 
 
+class MfStageDesc(C.Structure):
+    _fields_ = [('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('k', C.c_int32)]
+
+
 class MfHeightmapDesc(C.Structure):
     _fields_ = [('n_points', C.c_int32), ('nx', C.c_int32), ('ny', C.c_int32), ('d_max', C.c_float), ('h_min', C.c_float),
                 ('h_max', C.c_float), ('r_min', C.c_float), ('inv_res', C.c_float)]
@@ -58,7 +62,7 @@ class MfHeightmapDesc(C.Structure):
 SYMBOLS = ['mf_rollout_force_stride', 'mf_rollout_fwd_f32', 'mf_rollout_fwd_f64', 'mf_rollout_default_state_f32', 'mf_rollout_default_state_f64', 'mf_rollout_bwd_f32', 'mf_rollout_bwd_f64', 'mf_bev_splat_workspace_bytes', 'mf_bev_splat_prepare', 'mf_bev_splat_prepare_cameras',
            'mf_bev_splat_fwd_f32', 'mf_bev_splat_fwd_f64', 'mf_bev_splat_bwd_f32', 'mf_bev_splat_bwd_f64',
            'mf_bev_lift_splat_fwd_f32', 'mf_bev_lift_splat_fwd_f64', 'mf_bev_lift_splat_bwd_f32', 'mf_bev_lift_splat_bwd_f64',
-           'mf_physics_loss_fwd_f32', 'mf_physics_loss_fwd_f64', 'mf_physics_loss_bwd_f32', 'mf_physics_loss_bwd_f64', 'mf_estimate_heightmap_f32', 'mf_last_error', 'mf_version', 'mf_sizeof']
+           'mf_physics_loss_fwd_f32', 'mf_physics_loss_fwd_f64', 'mf_physics_loss_bwd_f32', 'mf_physics_loss_bwd_f64', 'mf_estimate_heightmap_f32', 'mf_terrain_stage_fwd_f32', 'mf_terrain_stage_bwd_f32', 'mf_last_error', 'mf_version', 'mf_sizeof']
 
 _lib = None
 _lock = threading.Lock()
@@ -82,7 +86,7 @@ def lib():
                 L.mf_version.restype = C.c_char_p
                 for name in SYMBOLS:
                     fn = getattr(L, name)   # AttributeError if the build is stale
-                    if name.startswith(('mf_rollout', 'mf_bev', 'mf_physics', 'mf_estimate')):
+                    if name.startswith(('mf_rollout', 'mf_bev', 'mf_physics', 'mf_estimate', 'mf_terrain')):
                         fn.restype = C.c_int
                 L.mf_bev_splat_workspace_bytes.restype = C.c_size_t
                 _lib = L

@@ -18,5 +18,6 @@ extern "C" int mf_sizeof(const char* name) {
   if (!strcmp(name, "MfSplatDesc")) return (int)sizeof(MfSplatDesc);
   if (!strcmp(name, "MfLossDesc")) return (int)sizeof(MfLossDesc);
   if (!strcmp(name, "MfHeightmapDesc")) return (int)sizeof(MfHeightmapDesc);
+  if (!strcmp(name, "MfStageDesc")) return (int)sizeof(MfStageDesc);
   return -1;
 }

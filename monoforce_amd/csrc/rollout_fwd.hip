@@ -82,11 +82,16 @@ __global__ void __launch_bounds__(256) interleave_maps_kernel(const float* __res
 }
 // true (and a.zmu set, the interleave pass launched) when this launch can read the interleaved copy
 static bool use_interleaved_maps(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutArgs<float>* a, const LaneMap& m, hipStream_t st) {
-  if (!p->zmu_scratch || !d->map_shared || d->math_mode != MF_MATH_FAST || p->joint_angles || m.PPL != 1 || m.G > 64) return false;
+  if ((!p->zmu_scratch && !p->zmu) || !d->map_shared || d->math_mode != MF_MATH_FAST || p->joint_angles || m.PPL != 1 || m.G > 64) return false;
+  if ((long long)d->H * d->W >= (1ll << 29)) return false;   // 32-bit byte offsets into the 8-byte cells
+  if (p->zmu && p->mu) {   // the caller staged the interleaved pair itself (mf_terrain_stage_fwd_f32): no pass, no batch-size condition
+    a->zmu = (const float*)p->zmu;
+    return true;
+  }
+  if (!p->zmu_scratch) return false;
   // Below ~half a wave per SIMD the launch is bound by the instruction stream of its waves; the extra pass (a second launch in
   // front of the rollout, ~10 us) then costs what the two saved gathers bring (measured: B = 1024 path costs 0.306 -> 0.323 ms)
   if ((long long)d->B * m.G < 512ll * 64) return false;
-  if ((long long)d->H * d->W >= (1ll << 29)) return false;   // 32-bit byte offsets into the 8-byte cells
   const int n = d->H * d->W;
   hipLaunchKernelGGL(interleave_maps_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a->z, a->mu, n, (float2*)p->zmu_scratch);
   a->zmu = (const float*)p->zmu_scratch;
@@ -100,7 +105,7 @@ extern "C" int mf_rollout_fwd_f32(const MfRolloutDesc* d, const MfRolloutFwdBufs
   int block;
   int rc = mf::fill_args<float>(d, p, &a, &m, &block);
   if (rc != MF_OK) return rc;
-  MF_REQUIRE(((uintptr_t)p->zmu_scratch & 7) == 0, MF_ERR_INVALID, "rollout_fwd: zmu_scratch must be 8-byte aligned");
+  MF_REQUIRE((((uintptr_t)p->zmu_scratch | (uintptr_t)p->zmu) & 7) == 0, MF_ERR_INVALID, "rollout_fwd: zmu_scratch / zmu must be 8-byte aligned");
   if (p->joint_angles) {
     MF_REQUIRE(p->Fs && p->Ff && !p->cost_rows, MF_ERR_UNSUPPORTED, "rollout_fwd: articulated rollouts write all six outputs");
     if (d->math_mode == MF_MATH_FAST) return mf::launch_rollout_fwd_joints_fast_f32(a, m, d->integrator, block, (hipStream_t)s);

@@ -175,7 +175,7 @@ class _RolloutFn(torch.autograd.Function):
             x0=_lib.ptr(x0), xd0=_lib.ptr(xd0), R0=_lib.ptr(R0), w0=_lib.ptr(w0),
             Xs=_lib.ptr(Xs), Xds=_lib.ptr(Xds), Rs=_lib.ptr(Rs), Omegas=_lib.ptr(Om), Fs=_lib.ptr(Fs), Ff=_lib.ptr(Ff),
             Xraw=_lib.ptr(Xraw), joint_angles=_lib.ptr(joint_angles),
-            zmu_scratch=_lib.ptr(_zmu_scratch(mod, desc, keep['z'])))
+            zmu_scratch=_lib.ptr(_zmu_scratch(mod, desc, keep['z'])), zmu=_lib.ptr(mod._staged_zmu(desc, z, mu)))
         fn = getattr(_lib.lib(), 'mf_rollout_fwd_' + _scalar_suffix(dt))
         with torch.cuda.device(dev), _timing.timed('rollout_fwd_kernel', dev):
             _lib.check(fn(C.byref(desc), C.byref(bufs), _stream_ptr(dev)), 'mf_rollout_fwd')
@@ -232,6 +232,7 @@ class DPhysics(torch.nn.Module):
         self.return_forces = return_forces
         self.interleave_maps = True      # shared float32 maps: let the library read an interleaved (z, mu) copy (same bits, fewer loads)
         self.precise = precise      # True: float32 kernels in the reference's exact op order (IEEE div/sqrt, no FMA); ~1.5x slower
+        self.staged_handoffs = 0    # rollouts that read an interleaved map pair staged by terrain_stage.stage_terrain
         self._cache = {}
 
     # -- constants marshalled for the C ABI ---------------------------------------------------------------
@@ -259,6 +260,18 @@ class DPhysics(torch.nn.Module):
             P = self.dphys_cfg.robot_points.detach().cpu().to(dtype).unsqueeze(0)
             self._cache[key] = torch.linalg.inv(inertia_tensor(self.dphys_cfg.robot_mass, P))[0].double().flatten().tolist()
         return self._cache[key]
+
+    def _staged_zmu(self, desc, z, mu):
+        """The interleaved (z, mu) pair `terrain_stage.stage_terrain` produced together with exactly these two maps (ONE shared
+        map pair, float32), for MfRolloutFwdBufs.zmu; None otherwise."""
+        if not (self.interleave_maps and desc.map_shared and z.dtype == torch.float32 and z.shape[0] == 1):
+            return None
+        from .terrain_stage import staged_pair
+        zmu = staged_pair(z, mu)
+        if zmu is None or zmu.shape[0] != 1:
+            return None
+        self.staged_handoffs += 1
+        return zmu
 
     def _make_desc(self, z, mu, controls):
         cfg = self.dphys_cfg

@@ -108,10 +108,17 @@ class BevEncode(nn.Module):
         x1 = self.layer1(self.relu(self.bn1(self.conv1(x))))
         return self.up1(self.layer3(self.layer2(x1)), x1)
 
-    def forward(self, x):
+    def forward(self, x, stage_k=None):
         x = self.backbone(x)
         geom, diff = self.up_geom(x), self.up_diff(x)
-        return {'geom': geom, 'terrain': geom - diff, 'diff': diff, 'friction': self.up_friction(x)}
+        friction = self.up_friction(x)
+        if stage_k is None:
+            return {'geom': geom, 'terrain': geom - diff, 'diff': diff, 'friction': friction}
+        # staged for the physics: terrain, its pooling onto the physics grid (factor stage_k), the pooled
+        # friction and their interleaved pair from ONE kernel; `terrain_phys` / `friction_phys` go straight into DPhysics
+        from .terrain_stage import stage_terrain
+        terrain, z, mu = stage_terrain(geom, diff, friction, stage_k)
+        return {'geom': geom, 'terrain': terrain, 'diff': diff, 'friction': friction, 'terrain_phys': z, 'friction_phys': mu}
 
 
 class LiftSplatShoot(nn.Module):
@@ -193,8 +200,11 @@ class LiftSplatShoot(nn.Module):
         geom = self.get_geometry(rots, trans, intrins, post_rots, post_trans)
         return self.voxel_pooling(geom, self.get_cam_feats(x), plan=plan)
 
-    def forward(self, x, rots, trans, intrins, post_rots, post_trans):
-        return self.bevencode(self.get_voxels(x, rots, trans, intrins, post_rots, post_trans))
+    def forward(self, x, rots, trans, intrins, post_rots, post_trans, stage_k=None):
+        """The reference's forward (lss.py:282-296).  `stage_k` (extension): also return the maps on the physics grid
+        ('terrain_phys', 'friction_phys': average pooling by that factor, scripts/train.py:93-99) from the fused staging kernel."""
+        bev = self.get_voxels(x, rots, trans, intrins, post_rots, post_trans)
+        return self.bevencode(bev) if stage_k is None else self.bevencode(bev, stage_k=stage_k)
 
     def from_pretrained(self, modelf):
         if not modelf:

@@ -63,6 +63,8 @@ class EncoderTrainStep:
         # coarser grid for the physics than for the encoder: average pooling (scripts/train.py:93-99, 233-235)
         k = max(int(round(dphysics.dphys_cfg.grid_res / float(encoder.dx[0]))), 1)
         self.terrain_preproc = torch.nn.AvgPool2d(kernel_size=k, stride=k) if k > 1 else torch.nn.Identity()
+        self.pool_k = k
+        self.fused_stage = True        # terrain = geom - diff, both poolings and the (z, mu) interleave as one kernel
         self.w = (geom_weight, terrain_weight, phys_weight)
         # train.py:374-375; the fused (single multi-tensor kernel) implementation where the parameters live on the GPU
         on_gpu = all(p.is_cuda for p in encoder.parameters())
@@ -75,12 +77,17 @@ class EncoderTrainStep:
     def losses(self, batch):
         from .losses import hm_loss
         (inputs, hm_geom, hm_terrain, controls, pose0, states_gt, pred_ts, gt_ts, nearest) = batch
-        terrain = self.enc(*inputs)
+        if self.fused_stage and inputs[0].is_cuda:
+            # heads -> (terrain, pooled z, pooled mu, interleaved (z, mu)) in one kernel (terrain_stage.py); same values
+            terrain = self.enc(*inputs, stage_k=self.pool_k)
+            z, mu = terrain['terrain_phys'], terrain['friction_phys']
+        else:
+            terrain = self.enc(*inputs)
+            # one predicted map per sample; B controls per sample share it ([1,H,W] map + [B,T,2] controls)
+            z = self.terrain_preproc(terrain['terrain']).squeeze(1)
+            mu = self.terrain_preproc(terrain['friction']).squeeze(1)
         l_geom = hm_loss(terrain['geom'], hm_geom[:, 0:1], hm_geom[:, 1:2])                  # train.py:388-392
         l_terr = hm_loss(terrain['terrain'], hm_terrain[:, 0:1], hm_terrain[:, 1:2])         # train.py:395-398
-        # one predicted map per sample; B controls per sample share it ([1,H,W] map + [B,T,2] controls)
-        z = self.terrain_preproc(terrain['terrain']).squeeze(1)
-        mu = self.terrain_preproc(terrain['friction']).squeeze(1)
         x0 = pose0[:, :3, 3].clone()
         state0 = (x0, torch.zeros_like(x0), pose0[:, :3, :3].contiguous(), torch.zeros_like(x0))   # train.py:237-241
         states, _ = self.dp(z_grid=z, controls=controls, state=state0, friction=mu)
