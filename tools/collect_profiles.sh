@@ -6,23 +6,50 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 B="--no-cpu-baseline --no-others"
-timeout 600 python bench.py --sweep > $OUT/${TAG}_bench_default_with_sweep.json 2> $OUT/bench_default.err
+timeout 900 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err
 for w in c3f c3 c4; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$w -o $w -- python bench.py --steps 20 --warmup 3 --workload $w $B > $OUT/${TAG}_${w}_bench_under_rocprof.json 2> $OUT/prof_$w.err
   f=$(find $OUT/prof_$w -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && head -40 "$f" > $OUT/${TAG}_${w}_kernel_stats.csv
 done
 for c in FETCH_SIZE WRITE_SIZE; do
-  for w in c3f c3; do
+  for w in c3f c3 c4; do
     timeout 240 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_${c}_$w -o $w -- python bench.py --steps 4 --warmup 1 --workload $w $B > /dev/null 2> $OUT/pmc_${c}_$w.err
     f=$(find $OUT/pmc_${c}_$w -name "*counter_collection.csv" | head -1)
-    [ -n "$f" ] && python tools/pmc_summary.py "$f" rollout > $OUT/${TAG}_pmc_${c}_$w.txt
+    [ -n "$f" ] && python tools/pmc_summary.py "$f" > $OUT/${TAG}_pmc_${c}_$w.txt
   done
 done
+# HBM bytes per launch of the hand-written kernels for bench.py's `roofline.traffic`: WRITE_SIZE + 2 x FETCH_SIZE (KiB; on
+# gfx950 rocprofv3 tallies a 128-byte read request as 64 bytes -- MI355X_MICROARCH.md, "HBM")
+python - "$OUT" "$TAG" <<'PY'
+import ast, json, re, sys
+out, tag = sys.argv[1], sys.argv[2]
+names = {'rollout_fwd': 'rollout_fwd_kernel', 'rollout_bwd': 'rollout_bwd_kernel', 'lift_splat_fwd': 'lift_splat_fwd_kernel',
+         'lift_splat_bwd': 'lift_splat_bwd_kernel'}
+res = {}
+for w in ('c3f', 'c3', 'c4'):
+    per = {}
+    for c, mult in (('FETCH_SIZE', 2), ('WRITE_SIZE', 1)):
+        try:
+            for line in open(f'{out}/{tag}_pmc_{c}_{w}.txt'):
+                m = re.match(r'(.*?) (\{.*\})\s*$', line)
+                if not m:
+                    continue
+                key = next((v for k, v in names.items() if k in m.group(1)), None)
+                if key:
+                    per[key] = per.get(key, 0) + mult * ast.literal_eval(m.group(2))[c] * 1024
+        except FileNotFoundError:
+            pass
+    if per:
+        res[w] = per
+json.dump(res, open(f'{out}/hbm_traffic.json', 'w'), indent=1)
+print(json.dumps(res))
+PY
 timeout 600 python tools/bench_kernels.py > $OUT/${TAG}_bench_kernels.jsonl 2> $OUT/bench_kernels.err
+AB_BWD=1 AB_B=256,1024,2048,4096,8192 timeout 300 python tools/ab_cp.py 2> /dev/null | grep "^B " > $OUT/${TAG}_ab_lane_mappings.txt
 AB_B=1024,16384,65536 timeout 300 python tools/bench_planner.py > $OUT/${TAG}_bench_planner.jsonl 2> $OUT/bench_planner.err
 timeout 300 python tools/bench_lift_splat.py 2> $OUT/bench_lift_splat.err | grep '^B=' > $OUT/${TAG}_bench_lift_splat.txt
 timeout 300 python tools/bench_graphed.py 2> $OUT/bench_graphed.err | grep n_trajs > $OUT/${TAG}_bench_graphed.txt
 AB_B=4 AB_N=100,175,223,400 timeout 300 python tools/ab_points.py 2> /dev/null | grep forces > $OUT/${TAG}_large_body_small_batch.txt
 AB_B=64 AB_N=100,175,223,400 timeout 300 python tools/ab_points.py 2> /dev/null | grep forces >> $OUT/${TAG}_large_body_small_batch.txt
-ls -la $OUT | head -40
+ls -la $OUT | head -60
