@@ -219,6 +219,8 @@ class Runner:
         md = mu.to(dev).unsqueeze(0)
         cd = ctrl.to(dev)
         if wl.get('encoder'):
+            if os.environ.get('MF_MIOPEN_BENCHMARK'):      # let MIOpen time its solvers per convolution shape (first steps slower)
+                torch.backends.cudnn.benchmark = True
             from monoforce_amd.terrain_encoder import LiftSplatShoot
             from monoforce_amd.train import EncoderTrainStep, synthetic_encoder_batch
             torch.manual_seed(0)        # identical initial weights on every rank (DDP convention)

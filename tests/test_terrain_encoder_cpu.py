@@ -78,3 +78,33 @@ def test_encoder_runs_on_cpu_and_head_ranges():
     assert set(out) == {'geom', 'terrain', 'diff', 'friction'} and tuple(out['geom'].shape) == (1, 1, 32, 32)
     assert float(out['geom'].abs().max()) <= 1.0 and float(out['diff'].min()) >= 0.0 and float(out['friction'].min()) >= 0.0
     assert torch.equal(out['terrain'], out['geom'] - out['diff'])
+
+
+def test_points_from_obj_voxel_average(tmp_path):
+    """`points_from_obj` (the stand-in for open3d's voxel_down_sample, dphys_config.py:26-31) on a hand-computed case: vertices
+    are averaged per 0.1 m cube of the grid anchored at (min - voxel/2); faces / normals / comments are ignored."""
+    from monoforce_amd.dphys_config import points_from_obj
+    obj = tmp_path / 'body.obj'
+    obj.write_text('\n'.join([
+        '# test body', 'o body',
+        'v 0.00 0.00 0.00', 'v 0.02 0.01 0.03',          # same cube (anchor -0.05): average (0.01, 0.005, 0.015)
+        'v 0.30 0.00 0.00',                               # alone
+        'v 0.30 0.26 0.00', 'v 0.34 0.28 0.04', 'v 0.32 0.27 0.02',   # same cube: average (0.32, 0.27, 0.02)
+        'v 0.06 0.00 0.00',                               # next cube along x (boundary at 0.05)
+        'vn 0 0 1', 'f 1 2 3', '']))
+    pts = points_from_obj(str(obj), voxel_size=0.1)
+    got = sorted(tuple(round(float(v), 6) for v in p) for p in pts)
+    want = sorted([(0.01, 0.005, 0.015), (0.3, 0.0, 0.0), (0.32, 0.27, 0.02), (0.06, 0.0, 0.0)])
+    assert len(got) == 4 and all(max(abs(a - b) for a, b in zip(g, w)) < 1e-6 for g, w in zip(got, want)), got
+    raw = points_from_obj(str(obj), voxel_size=0)
+    assert tuple(raw.shape) == (7, 3)
+
+
+def test_missing_mesh_warns_about_the_standin(monkeypatch):
+    import warnings
+    from monoforce_amd.dphys_config import DPhysConfig
+    monkeypatch.delenv('MONOFORCE_MESH_DIR', raising=False)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter('always')
+        cfg = DPhysConfig(robot='tradr')
+    assert any('STAND-IN' in str(w.message) for w in rec) and cfg.robot_points.shape[1] == 3
