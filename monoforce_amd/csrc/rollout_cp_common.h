@@ -56,8 +56,15 @@ __device__ __forceinline__ float dot4(float a, float b) {
 }
 // sum over the four quads of a row, lane position by lane position (contact points of one rollout)
 __device__ __forceinline__ float sum_points(float v) { v += dpp<kRor8>(v); return v + dpp<kRor4>(v); }
-// (a x b)_c given the components of a and b in the lanes: a_{c+1} b_{c+2} - a_{c+2} b_{c+1}
-__device__ __forceinline__ float cross_c(float a, float b) { return dpp<kRot1>(a) * dpp<kRot2>(b) - dpp<kRot2>(a) * dpp<kRot1>(b); }
+// Cross products with the components in the lanes.  d = cross_pre(a, b) holds (a x b)_{c+2} in lane c:
+//   d_c = a_c b_{c+1} - a_{c+1} b_c  -- two multiplies that take their rotated operand as a DPP operand, one subtract, no
+// register spent on rotated copies; unrot() brings component c home to lane c (one more DPP operand of whatever consumes it,
+// or one move).  Sums of cross products are un-rotated once: unrot(d1 + d2 + d3).
+__device__ __forceinline__ float cross_pre(float a, float b) {
+#pragma clang fp contract(off)
+  return a * dpp<kRot1>(b) - dpp<kRot1>(a) * b;
+}
+__device__ __forceinline__ float unrot(float d) { return dpp<kRot1>(d); }
 
 // ---- rows of the [T][B][...] arrays -----------------------------------------------------------------------------------------
 // A row is addressed as wave-uniform base pointer + wave-uniform byte offset of the time step + a per-lane byte offset that

@@ -138,8 +138,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
   };
   // contact model + wrench of one step from its geometry and the state's velocities: (xdd, wd, F_spring, F_friction)
   auto contact = [&](const Geo& g, float vxd, float vw, float tv, float* xdd, float* wd, float* oFr, float* oFf) {
-    const float r1 = dpp<kRot1>(g.r), r2 = dpp<kRot2>(g.r);
-    const float vp = vxd + (dpp<kRot1>(vw) * r2 - dpp<kRot2>(vw) * r1);   // v_p = xd + w x r   (:204)
+    const float vp = vxd + unrot(cross_pre(vw, g.r));                  // v_p = xd + w x r   (:204)
     const float zq = dot4(g.wq, g.zc);                               // height under the point (:211)
     const float mub = dot4(g.wq, has_mu ? g.mc : one);             // friction (:216); no map = a map of ones (:562)
     const float dz = g.zc - dpp<kB0>(g.zc);                           // lane 1: z_f - z_c, lane 2: z_l - z_c
@@ -158,7 +157,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
     const float sn = dot3(s, nrm);
     const float Ff = M::clamp(Nn * (s - sn * nrm), -a.mg, a.mg);      // (:248-251); absent points: cj = 0 -> Fr = Nn = Ff = 0
     const float f = Fr + Ff;
-    const float tau = r1 * dpp<kRot2>(f) - r2 * dpp<kRot1>(f);        // r x (Fs + Ff)   (:255)
+    const float tau = unrot(cross_pre(g.r, f));                        // r x (Fs + Ff)   (:255)
     const float Fsum = sum_points(f), Tsum = sum_points(tau);
     // omega_d = clamp(I^-1 tau)   (:256-257); xdd = (m g ghat + sum F) / m   (:264-266)
     *wd = M::clamp(I0 * dpp<kB0>(Tsum) + I1 * dpp<kB1>(Tsum) + I2 * dpp<kB2>(Tsum), -a.omega_max, a.omega_max);
@@ -184,12 +183,10 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
     if (INTEG == MF_INTEG_ODEINT_EULER) {
       // ---- stream B: pose and geometry of step n + 1 (torchdiffeq fixed-grid euler: y_{n+1} = y_n + h f(t_n, y_n)) ----
       // dR[c][j] = w_{c+1} R[c+2][j] - w_{c+2} R[c+1][j]
-      const float w1 = dpp<kRot1>(w), w2 = dpp<kRot2>(w);
-      const float d0 = w1 * dpp<kRot2>(R0) - w2 * dpp<kRot1>(R0);
-      const float d1 = w1 * dpp<kRot2>(R1) - w2 * dpp<kRot1>(R1);
-      const float d2 = w1 * dpp<kRot2>(R2) - w2 * dpp<kRot1>(R2);
+      // (column j of R is a 3-vector over the lanes: dR_j = w x R_j)
+      const float d0 = h_ode * cross_pre(w, R0), d1 = h_ode * cross_pre(w, R1), d2 = h_ode * cross_pre(w, R2);
       const float xn = fmaf(h_ode, xd, x);
-      const float Rn0 = fmaf(h_ode, d0, R0), Rn1 = fmaf(h_ode, d1, R1), Rn2 = fmaf(h_ode, d2, R2);
+      const float Rn0 = R0 + unrot(d0), Rn1 = R1 + unrot(d1), Rn2 = R2 + unrot(d2);
       const Geo geo_next = geometry(xn, Rn0, Rn1, Rn2);     // (after the last step: the final pose -- unused, in range)
       // ---- row n, AFTER the gathers in program order: their wait a step later then covers no store of this step ----
       emit_row(x, xd, w, R0, R1, R2, 1u);
