@@ -66,7 +66,8 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
     return launch_rollout_bwd_joints_f64(*reinterpret_cast<const RolloutBwdArgs<double>*>(&a), mj, d->integrator, block, st);
   }
   if (sizeof(S) == 4 && use_component_parallel_bwd(d, p))   // few rollouts of a small body: a rollout over 16 lanes
-    return launch_rollout_bwd_cp_f32(*reinterpret_cast<const RolloutBwdArgs<float>*>(&a), d->integrator, st);
+    return launch_rollout_bwd_cp_f32(*reinterpret_cast<const RolloutBwdArgs<float>*>(&a), d->integrator,
+                                     p->gXs && !p->gXds && !p->gRs && !p->gOmegas && !p->gFs && !p->gFf, st);
   const LaneMap m = choose_lane_map(d->B, d->N, d->points_per_lane == MF_LANES_COMPONENT ? 0 : d->points_per_lane);
   if (sizeof(S) == 4 && d->math_mode == MF_MATH_FAST) {
     // accumulator carry-over between adjacent cells (rollout_bwd_kernel.h): ~55 more instructions per step, half the atomics --

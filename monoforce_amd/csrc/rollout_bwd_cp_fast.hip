@@ -22,12 +22,13 @@ bool use_component_parallel_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* 
   return true;
 }
 
-int launch_rollout_bwd_cp_f32(const RolloutBwdArgs<float>& a, int integ, hipStream_t st) {
+int launch_rollout_bwd_cp_f32(const RolloutBwdArgs<float>& a, int integ, bool xs_only, hipStream_t st) {
   MF_REQUIRE(integ == MF_INTEG_ODEINT_EULER, MF_ERR_UNSUPPORTED, "rollout_bwd (component-parallel): default integrator only");
   const int block = 64;
   const long long threads = (long long)a.B * 16;
   const unsigned grid = (unsigned)((threads + block - 1) / block);
-  hipLaunchKernelGGL((rollout_bwd_cp_kernel<MF_INTEG_ODEINT_EULER>), dim3(grid), dim3(block), 0, st, a);
+  if (xs_only) hipLaunchKernelGGL((rollout_bwd_cp_kernel<MF_INTEG_ODEINT_EULER, true>), dim3(grid), dim3(block), 0, st, a);
+  else hipLaunchKernelGGL((rollout_bwd_cp_kernel<MF_INTEG_ODEINT_EULER, false>), dim3(grid), dim3(block), 0, st, a);
   hipError_t e = hipGetLastError();
   MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("rollout_bwd (component-parallel) launch: ") + hipGetErrorString(e));
   return MF_OK;

@@ -23,7 +23,10 @@ __device__ __forceinline__ float ld1(const float* base, unsigned off) {
   return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)off);
 }
 
-template <int INTEG>
+// XS_ONLY: the loss reads the positions only (physics_loss, losses.py:102-127 -- every training caller): the other five upstream
+// gradients are absent, so their loads, their additions and the adjoint of the impulse accumulators are compiled out
+// (~19 of ~410 instructions per step).
+template <int INTEG, bool XS_ONLY>
 __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
   static_assert(INTEG == MF_INTEG_ODEINT_EULER, "the component-parallel backward covers the default integrator");
   using namespace cp;
@@ -97,16 +100,21 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
   };
   auto load_upstream = [&](int orow, UpIn& u) {         // upstream gradients of output row `orow`
     const unsigned uo = __builtin_amdgcn_readfirstlane((unsigned)orow);
-    u.gXs = bload1(rgXs, u_xs, uo * sg_xs); u.gXds = bload1(rgXds, u_xds, uo * sg_xds); u.gOm = bload1(rgOm, u_om, uo * sg_om);
-    bload3(rgRs, u_r, uo * sg_r, &u.gR0, &u.gR1, &u.gR2);
-    u.gFs = bload1(rgFs, u_fs, uo * sg_fs); u.gFf = bload1(rgFf, u_ff, uo * sg_ff);
+    u.gXs = bload1(rgXs, u_xs, uo * sg_xs);
+    if constexpr (!XS_ONLY) {
+      u.gXds = bload1(rgXds, u_xds, uo * sg_xds); u.gOm = bload1(rgOm, u_om, uo * sg_om);
+      bload3(rgRs, u_r, uo * sg_r, &u.gR0, &u.gR1, &u.gR2);
+      u.gFs = bload1(rgFs, u_fs, uo * sg_fs); u.gFf = bload1(rgFf, u_ff, uo * sg_ff);
+    }
   };
   auto add_upstream_state = [&](const UpIn& u) {
     lx += u.gXs;
     lR2 = fmaf(u.gXs, a.sink, lR2);                     // Xs = x + R[:, 2] * sink
-    lxd += u.gXds;
-    lR0 += u.gR0; lR1 += u.gR1; lR2 += u.gR2;
-    lw += u.gOm;
+    if constexpr (!XS_ONLY) {
+      lxd += u.gXds;
+      lR0 += u.gR0; lR1 += u.gR1; lR2 += u.gR2;
+      lw += u.gOm;
+    }
   };
 
   bstore2(rGctrl, v_ctrl, (unsigned)(a.T - 1) * 8u, zero, zero);   // the last control is never used by the explicit scheme
@@ -194,11 +202,14 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
   auto vjp = [&](int n, const Rec& k, const UpIn& up) {
     const float h = k.h, w1 = k.w1, w2 = k.w2, r1 = k.r1, r2 = k.r2, nrm = k.nrm, cj = k.cj, inv_csum = k.inv_csum;
     // ---- integrator backward (torchdiffeq fixed-grid Euler): adjoint of the step's outputs -> (g_xdd, g_wd, g_Fs, g_Ff) ----
-    laFs += act ? up.gFs : zero;
-    laFf += act ? up.gFf : zero;
+    float gFr_up = zero, gFf_up = zero;
+    if constexpr (!XS_ONLY) {
+      laFs += act ? up.gFs : zero;
+      laFf += act ? up.gFf : zero;
+      gFr_up = h * laFs; gFf_up = h * laFf;
+    }
     const float gxdd = h * lxd, gwd = h * lw;
     lxd = fmaf(h, lx, lxd);                               // x' = x + h xd
-    const float gFr_up = h * laFs, gFf_up = h * laFf;
     {   // R' = R + h [w]x R, column by column: d/dw of (w x R_j) . g_j = R_j x g_j ; d/dR_j = g_j x w   (g_j = h lR[:, j])
       const float g0 = h * lR0, g1 = h * lR1, g2 = h * lR2;
       const float g01 = dpp<kRot1>(g0), g02 = dpp<kRot2>(g0), g11 = dpp<kRot1>(g1), g12 = dpp<kRot2>(g1), g21 = dpp<kRot1>(g2), g22 = dpp<kRot2>(g2);
@@ -351,6 +362,6 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
 }
 
 bool use_component_parallel_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p);
-int launch_rollout_bwd_cp_f32(const RolloutBwdArgs<float>& a, int integ, hipStream_t st);
+int launch_rollout_bwd_cp_f32(const RolloutBwdArgs<float>& a, int integ, bool xs_only, hipStream_t st);
 
 }  // namespace mf

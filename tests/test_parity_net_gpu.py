@@ -344,3 +344,34 @@ def test_component_parallel_mapping_with_fewer_points(N):
     for k, a_, b_ in zip(hp.OUT_KEYS + ('g_z',), outs[16], outs[1]):
         assert a_.shape == b_.shape and torch.isfinite(a_).all()
         assert hp.rel_err(a_, b_) <= (2e-4 if k == 'g_z' else 1e-4), (k, hp.rel_err(a_, b_))
+
+
+@pytest.mark.parametrize('B', [5, 1024])
+def test_component_parallel_backward_positions_only_loss(B):
+    """A loss that reads the positions only (what `physics_loss` does, losses.py:102-127) takes the backward kernel with the
+    other five upstream gradients compiled out: its gradients vs the oracle (B = 5 per-rollout maps, every rollout in the loss;
+    B = 1024 on one shared map, 32 rollouts in the loss)."""
+    from monoforce_amd import synthetic as syn
+    pts, masks = syn.robot_points_4()
+    T = 80
+    shared = B > 16
+    nz = 1 if shared else B
+    z = torch.stack([syn.bump_terrain(syn.bump_params(50 + k), 6.4, 0.05) * 0.7 for k in range(nz)])
+    mu = torch.stack([syn.wave_friction(6.4, 0.05, 0.5, 1.0, 1.2 + 0.1 * k, 0.9) for k in range(nz)])
+    ctrl = syn.varying_controls(B, T, seed=6)
+    sel = torch.arange(0, B, max(B // 32, 1))[:32]
+    wts = syn.probe_weights((len(sel), T, 3), phase=0.7)
+    dp = make_dphysics(pts, masks, 1, 0.05, 6.4, points_per_lane=16)
+    zd, md, cd = z.to(DEV).requires_grad_(True), mu.to(DEV).requires_grad_(True), ctrl.to(DEV).requires_grad_(True)
+    (Xs, _, _, _), _ = dp(zd, cd, friction=md)
+    (Xs[sel.to(DEV)] * wts.to(DEV)).sum().backward()
+    spec = hp.spec_from(pts, masks, 1, 0.05, 6.4)
+    zc, mc = z.double().requires_grad_(True), mu.double().requires_grad_(True)
+    cc = ctrl[sel].double().requires_grad_(True)
+    zin = zc.expand(len(sel), -1, -1) if shared else zc[sel]
+    min_ = mc.expand(len(sel), -1, -1) if shared else mc[sel]
+    (rX, _, _, _), _ = orc.rollout(spec, zin, cc, friction=min_)
+    (rX * wts.double()).sum().backward()
+    assert hp.rel_err(zd.grad, zc.grad) <= 2e-4, hp.rel_err(zd.grad, zc.grad)
+    assert hp.rel_err(md.grad, mc.grad) <= 2e-4, hp.rel_err(md.grad, mc.grad)
+    assert hp.rel_err(cd.grad[sel.to(DEV)], cc.grad) <= 2e-4, hp.rel_err(cd.grad[sel.to(DEV)], cc.grad)
