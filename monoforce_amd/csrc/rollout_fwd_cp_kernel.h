@@ -90,12 +90,15 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
   const float sink_l = (p == 3 && a.Xraw) ? zero : a.sink;
   const unsigned m_xd = p == 1 ? ~0u : 0u, m_w = p == 2 ? ~0u : 0u, m_x = ~(m_xd | m_w);
   char* p3 = reinterpret_cast<char*>(v3base) + (size_t)(row0 * 3u + (unsigned)cc) * 4u;
-  const Rsrc rRs = make_rsrc(a.Rs), rFs = make_rsrc(a.Fs), rFf = make_rsrc(a.Ff), rCtrl = make_rsrc(a.controls);
-  const unsigned o9 = (row0 * 9u + (unsigned)cc * 3u) * 4u;
+  const Rsrc rCtrl = make_rsrc(a.controls);
+  unsigned o9 = (row0 * 9u + (unsigned)cc * 3u) * 4u;
   const unsigned frow = (unsigned)a.fstride * 3u;
-  const unsigned of = (row0 * frow + (unsigned)p * 3u + (unsigned)cc) * 4u;
+  unsigned ofs = (row0 * frow + (unsigned)p * 3u + (unsigned)cc) * 4u, off = ofs;
   const unsigned d3 = row_stride * 12u, d9 = row_stride * 36u, df = row_stride * frow * 4u;
-  unsigned s9 = 0u, sf = 0u;       // wave-uniform: scalar registers, scalar adds
+  // wave-uniform running row pointers (scalar registers, scalar adds); the per-lane part is the fixed 32-bit offset
+  const char* pRs = reinterpret_cast<const char*>(a.Rs);
+  const char* pFs = reinterpret_cast<const char*>(a.Fs);
+  const char* pFf = reinterpret_cast<const char*>(a.Ff);
 
   float oFs = zero, oFf = zero;   // forces of the pending output row (ODEINT: running impulses, dphysics.py:506-509)
 
@@ -104,13 +107,16 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
     const float vx = fmaf(e2, sink_l, ex);          // Xs += Rs[..., :, 2] * m g / (k + 1e-6)   (dphysics.py:587-589)
     const float v3 = mask_or(mask_or(mask_or(zero, vx, m_x), exd, m_xd), ew, m_w);
     __builtin_nontemporal_store(v3, reinterpret_cast<float*>(p3));
-    bstore3(rRs, o9, s9, e0, e1, e2);               // row cc of R: one 12-byte store (all quads, same address, same value)
-    if (FORCES) { bstore1(rFs, of, sf, oFs); bstore1(rFf, of, sf, oFf); }
-    if (adv) { p3 += d3; s9 += d9; sf += df; }
+    // (the per-lane offsets are laundered through an empty asm: a loop-invariant zero-extension would be hoisted out of the
+    // loop and the address then formed by a 64-bit vector add per store instead of the scalar-base + 32-bit-offset mode)
+    asm volatile("" : "+v"(o9), "+v"(ofs), "+v"(off));      // in place: no copies, the registers just look loop-variant
+    bstore3(pRs, o9, 0u, e0, e1, e2);               // row cc of R: one 12-byte store (all quads, same address, same value)
+    if (FORCES) { bstore1(pFs, ofs, 0u, oFs); bstore1(pFf, off, 0u, oFf); }
+    if (adv) { p3 += d3; pRs += d9; pFs += df; pFf += df; }
   };
 
   const int n_steps = (INTEG == MF_INTEG_ODEINT_EULER) ? a.T - 1 : a.T;
-  const unsigned v_ctrl = (unsigned)b * (unsigned)a.ctrl_sb * 4u;      // this rollout's control rows (bytes)
+  unsigned v_ctrl = (unsigned)b * (unsigned)a.ctrl_sb * 4u;      // this rollout's control rows (bytes)
   float cv, cw;
   bload2(rCtrl, v_ctrl, 0u, &cv, &cw);
   float h_ode = (INTEG == MF_INTEG_ODEINT_EULER && a.T > 1) ? a.ts[1] - a.ts[0] : zero;
@@ -165,40 +171,54 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
     *oFr = Fr; *oFf = Ff;
   };
 
-  Geo geo;
-  if (INTEG == MF_INTEG_ODEINT_EULER && n_steps > 0) geo = geometry(x, R0, R1, R2);
-  __builtin_amdgcn_s_waitcnt(0);
-  for (int n = 0; n < n_steps; ++n) {
-    // next step's controls and step size: loaded before the stores below (vmcnt retires in order)
-    const int nn = min(n + 1, a.T - 1);
-    float cv_next, cw_next;
-    bload2(rCtrl, v_ctrl, __builtin_amdgcn_readfirstlane((unsigned)(nn * a.ctrl_st) * 4u), &cv_next, &cw_next);
-    float ts_a = zero, ts_b = zero;
-    if (INTEG == MF_INTEG_ODEINT_EULER) {
+  if constexpr (INTEG == MF_INTEG_ODEINT_EULER) {
+    // One step of the two-stream pipeline: geometry `g` / controls (cv, cw) / step size h of step n come in, those of step
+    // n + 1 go out into the OTHER buffer set -- the loop below alternates two sets, so nothing is moved between iterations.
+    auto ode_step = [&](int n, const Geo& g, Geo& g_next, float cv_n, float cw_n, float h, float& cv_next, float& cw_next, float& h_next) {
+      // next step's controls and step size: loaded before the stores below (vmcnt retires in order)
+      const int nn = min(n + 1, a.T - 1);
+      asm volatile("" : "+v"(v_ctrl));
+      bload2(rCtrl + (size_t)((unsigned)(nn * a.ctrl_st) * 4u), v_ctrl, 0u, &cv_next, &cw_next);
       const int tp = max(min(n + 1, a.T - 2), 0);
-      ts_a = a.ts[tp]; ts_b = a.ts[tp + 1];
-    }
-    const float tv = tv_v * cv + tv_w * cw;
-    float xdd, wd, Fr, Ff;
-    if (INTEG == MF_INTEG_ODEINT_EULER) {
+      const float ts_a = a.ts[tp], ts_b = a.ts[tp + 1];
+      const float tv = tv_v * cv_n + tv_w * cw_n;
       // ---- stream B: pose and geometry of step n + 1 (torchdiffeq fixed-grid euler: y_{n+1} = y_n + h f(t_n, y_n)) ----
-      // dR[c][j] = w_{c+1} R[c+2][j] - w_{c+2} R[c+1][j]
       // (column j of R is a 3-vector over the lanes: dR_j = w x R_j)
-      const float d0 = h_ode * cross_pre(w, R0), d1 = h_ode * cross_pre(w, R1), d2 = h_ode * cross_pre(w, R2);
-      const float xn = fmaf(h_ode, xd, x);
+      const float d0 = h * cross_pre(w, R0), d1 = h * cross_pre(w, R1), d2 = h * cross_pre(w, R2);
+      const float xn = fmaf(h, xd, x);
       const float Rn0 = R0 + unrot(d0), Rn1 = R1 + unrot(d1), Rn2 = R2 + unrot(d2);
-      const Geo geo_next = geometry(xn, Rn0, Rn1, Rn2);     // (after the last step: the final pose -- unused, in range)
+      g_next = geometry(xn, Rn0, Rn1, Rn2);           // (after the last step: the final pose -- unused, in range)
       // ---- row n, AFTER the gathers in program order: their wait a step later then covers no store of this step ----
       emit_row(x, xd, w, R0, R1, R2, 1u);
       x = xn; R0 = Rn0; R1 = Rn1; R2 = Rn2;
       // ---- stream A: contact chain of step n ----
-      contact(geo, xd, w, tv, &xdd, &wd, &Fr, &Ff);
-      xd = fmaf(h_ode, xdd, xd);
-      w = fmaf(h_ode, wd, w);
-      oFs = fmaf(h_ode, Fr, oFs);
-      oFf = fmaf(h_ode, Ff, oFf);
-      geo = geo_next;
-    } else {
+      float xdd, wd, Fr, Ff;
+      contact(g, xd, w, tv, &xdd, &wd, &Fr, &Ff);
+      xd = fmaf(h, xdd, xd);
+      w = fmaf(h, wd, w);
+      oFs = fmaf(h, Fr, oFs);
+      oFf = fmaf(h, Ff, oFf);
+      h_next = ts_b - ts_a;
+    };
+    Geo gA, gB;
+    float cvA = cv, cwA = cw, hA = h_ode, cvB = zero, cwB = zero, hB = zero;
+    if (n_steps > 0) gA = geometry(x, R0, R1, R2);
+    __builtin_amdgcn_s_waitcnt(0);
+    int n = 0;
+    for (; n + 1 < n_steps; n += 2) {
+      ode_step(n, gA, gB, cvA, cwA, hA, cvB, cwB, hB);
+      ode_step(n + 1, gB, gA, cvB, cwB, hB, cvA, cwA, hA);
+    }
+    if (n < n_steps) ode_step(n, gA, gB, cvA, cwA, hA, cvB, cwB, hB);
+  } else {
+    __builtin_amdgcn_s_waitcnt(0);
+    for (int n = 0; n < n_steps; ++n) {
+      // next step's controls: loaded before the stores below (vmcnt retires in order)
+      const int nn = min(n + 1, a.T - 1);
+      float cv_next, cw_next;
+      bload2(rCtrl, v_ctrl, __builtin_amdgcn_readfirstlane((unsigned)(nn * a.ctrl_st) * 4u), &cv_next, &cw_next);
+      const float tv = tv_v * cv + tv_w * cw;
+      float xdd, wd, Fr, Ff;
       // dynamics(): the next pose needs this step's forces (x += xd_new h, R <- R M(w_new)): one stream
       const Geo g = geometry(x, R0, R1, R2);
       emit_row(x, xd, w, R0, R1, R2, n > 0 ? 1u : 0u);      // n = 0: the initial state as a placeholder in row 0, overwritten one iteration later
@@ -226,9 +246,8 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
       const float n2 = R0 * dpp<kB0>(m2) + R1 * dpp<kB1>(m1) + R2 * dpp<kB2>(m0);
       R0 = n0; R1 = n1; R2 = n2;
       oFs = Fr; oFf = Ff;                                               // true forces of this step
+      cv = cv_next; cw = cw_next;
     }
-    cv = cv_next; cw = cw_next;
-    h_ode = ts_b - ts_a;
   }
   if (n_steps > 0 || INTEG == MF_INTEG_ODEINT_EULER) emit_row(x, xd, w, R0, R1, R2, 1u);
 }
