@@ -198,7 +198,7 @@ typedef struct MfRolloutBwdBufs {
   const void* zeros;    /* >= 9 zero scalars of type S; required when any of the six upstream pointers is NULL */
   void* gz;             /* out (atomic accumulate): dL/dz, S[map_shared ? max(grad_copies,1) : B][H][W] */
   void* gmu;            /* out (atomic accumulate): dL/dmu, same shape; NULL to skip */
-  void* gcontrols;      /* out: S[B][T][2] */
+  void* gcontrols;      /* out: S[B][T][2]; may be NULL (gradient not wanted) where mf_rollout_bwd_wants_gcontrols(desc) returns 0 */
   void* gx0;            /* out: S[B][3] (z component is 0 unless skip_snap); NULL to skip */
   void* gxd0;           /* out: S[B][3] */
   void* gR0;            /* out: S[B][3][3] */
@@ -207,6 +207,9 @@ typedef struct MfRolloutBwdBufs {
                            rollout: no gradient is produced for them (the reference's datasets feed measured angles) */
 } MfRolloutBwdBufs;
 
+/* 1 if the backward kernels chosen for this descriptor always write the control gradient (gcontrols must then be a buffer), 0 if
+ * they can skip it (gcontrols may be NULL: saves its dot product, sums and stores per step). */
+int mf_rollout_bwd_wants_gcontrols(const MfRolloutDesc* desc);
 int mf_rollout_bwd_f32(const MfRolloutDesc* desc, const MfRolloutBwdBufs* bufs, void* hip_stream);
 int mf_rollout_bwd_f64(const MfRolloutDesc* desc, const MfRolloutBwdBufs* bufs, void* hip_stream);
 

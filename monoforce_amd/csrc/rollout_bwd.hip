@@ -14,7 +14,7 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
   MF_REQUIRE(p->z && p->controls && p->ts && p->points && p->part && p->x_init && p->xd0 && p->R0 && p->w0, MF_ERR_INVALID,
              "rollout_bwd: null input buffer");
   MF_REQUIRE(p->Xraw && p->Xds && p->Rs && p->Omegas, MF_ERR_INVALID, "rollout_bwd: null saved-state buffer");
-  MF_REQUIRE(p->gz && p->gcontrols && p->gxd0 && p->gR0 && p->gw0, MF_ERR_INVALID, "rollout_bwd: null gradient output buffer");
+  MF_REQUIRE(p->gz && p->gxd0 && p->gR0 && p->gw0, MF_ERR_INVALID, "rollout_bwd: null gradient output buffer");
   MF_REQUIRE(d->N <= 512, MF_ERR_UNSUPPORTED, "rollout_bwd: more than 512 contact points");
   MF_REQUIRE(d->H < (1 << 23), MF_ERR_UNSUPPORTED, "rollout_bwd: grid too large (H must be below 2^23)");
   MF_REQUIRE(d->H >= 2, MF_ERR_INVALID, "rollout_bwd: the grid needs at least 2 x 2 cells");
@@ -65,7 +65,10 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
     if (sizeof(S) == 4) return launch_rollout_bwd_joints_f32(*reinterpret_cast<const RolloutBwdArgs<float>*>(&a), mj, d->integrator, block, st);
     return launch_rollout_bwd_joints_f64(*reinterpret_cast<const RolloutBwdArgs<double>*>(&a), mj, d->integrator, block, st);
   }
-  if (sizeof(S) == 4 && use_component_parallel_bwd(d, p))   // few rollouts of a small body: a rollout over 16 lanes
+  const bool cp = sizeof(S) == 4 && use_component_parallel_bwd(d, p);
+  MF_REQUIRE(p->gcontrols || cp, MF_ERR_INVALID, "rollout_bwd: gcontrols may be NULL only where the component-parallel kernels run "
+             "(float32 MF_MATH_FAST, N <= 4, default integrator, small batch)");
+  if (cp)   // few rollouts of a small body: a rollout over 16 lanes
     return launch_rollout_bwd_cp_f32(*reinterpret_cast<const RolloutBwdArgs<float>*>(&a), d->integrator,
                                      p->gXs && !p->gXds && !p->gRs && !p->gOmegas && !p->gFs && !p->gFf, st);
   const LaneMap m = choose_lane_map(d->B, d->N, d->points_per_lane == MF_LANES_COMPONENT ? 0 : d->points_per_lane);

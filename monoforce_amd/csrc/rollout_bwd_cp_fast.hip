@@ -11,8 +11,8 @@ static long long cp_bwd_max_waves() {
   return v;
 }
 
-bool use_component_parallel_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p) {
-  if (d->math_mode != MF_MATH_FAST || d->N > 4 || p->joint_angles || d->integrator != MF_INTEG_ODEINT_EULER) return false;
+static bool cp_bwd_covers(const MfRolloutDesc* d, bool joints) {
+  if (d->math_mode != MF_MATH_FAST || d->N > 4 || joints || d->integrator != MF_INTEG_ODEINT_EULER) return false;
   if (d->points_per_lane != 0 && d->points_per_lane != MF_LANES_COMPONENT) return false;
   const long long waves = ((long long)d->B + 3) / 4;
   if (d->points_per_lane == 0 && waves > cp_bwd_max_waves()) return false;
@@ -21,14 +21,22 @@ bool use_component_parallel_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* 
   if ((long long)d->T * d->B * row * 4 >= (1ll << 32)) return false;
   return true;
 }
+bool use_component_parallel_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p) { return cp_bwd_covers(d, p->joint_angles != nullptr); }
+
+}  // namespace mf
+extern "C" int mf_rollout_bwd_wants_gcontrols(const MfRolloutDesc* d) { return (d && mf::cp_bwd_covers(d, d->has_joints != 0)) ? 0 : 1; }
+namespace mf {
 
 int launch_rollout_bwd_cp_f32(const RolloutBwdArgs<float>& a, int integ, bool xs_only, hipStream_t st) {
   MF_REQUIRE(integ == MF_INTEG_ODEINT_EULER, MF_ERR_UNSUPPORTED, "rollout_bwd (component-parallel): default integrator only");
   const int block = 64;
   const long long threads = (long long)a.B * 16;
   const unsigned grid = (unsigned)((threads + block - 1) / block);
-  if (xs_only) hipLaunchKernelGGL((rollout_bwd_cp_kernel<MF_INTEG_ODEINT_EULER, true>), dim3(grid), dim3(block), 0, st, a);
-  else hipLaunchKernelGGL((rollout_bwd_cp_kernel<MF_INTEG_ODEINT_EULER, false>), dim3(grid), dim3(block), 0, st, a);
+  const bool gc = a.gcontrols != nullptr;
+#define MF_BCP(XS_, GC_) hipLaunchKernelGGL((rollout_bwd_cp_kernel<MF_INTEG_ODEINT_EULER, XS_, GC_>), dim3(grid), dim3(block), 0, st, a)
+  if (xs_only) { if (gc) MF_BCP(true, true); else MF_BCP(true, false); }
+  else         { if (gc) MF_BCP(false, true); else MF_BCP(false, false); }
+#undef MF_BCP
   hipError_t e = hipGetLastError();
   MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("rollout_bwd (component-parallel) launch: ") + hipGetErrorString(e));
   return MF_OK;

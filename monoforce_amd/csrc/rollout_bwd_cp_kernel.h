@@ -26,7 +26,9 @@ __device__ __forceinline__ float ld1(const float* base, unsigned off) {
 // XS_ONLY: the loss reads the positions only (physics_loss, losses.py:102-127 -- every training caller): the other five upstream
 // gradients are absent, so their loads, their additions and the adjoint of the impulse accumulators are compiled out
 // (~19 of ~410 instructions per step).
-template <int INTEG, bool XS_ONLY>
+// GCTRL = false: nobody asked for the gradient of the controls (a terrain fit, an encoder train step): its dot product, two
+// sums over the contact points and the store are compiled out.
+template <int INTEG, bool XS_ONLY, bool GCTRL>
 __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
   static_assert(INTEG == MF_INTEG_ODEINT_EULER, "the component-parallel backward covers the default integrator");
   using namespace cp;
@@ -117,7 +119,7 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
     }
   };
 
-  bstore2(rGctrl, v_ctrl, (unsigned)(a.T - 1) * 8u, zero, zero);   // the last control is never used by the explicit scheme
+  if constexpr (GCTRL) bstore2(rGctrl, v_ctrl, (unsigned)(a.T - 1) * 8u, zero, zero);   // the last control is never used by the explicit scheme
 
   // Cell-gradient accumulator of this lane's footprint cell: contributions of consecutive steps to the SAME cell (a robot
   // moves <= 0.2 cell per step) add up in registers; when the lane's cell changes, the old pair goes to a stash that is
@@ -236,9 +238,12 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
     const float gmuq = dot3(gslip, k.cmdv);
     const float gcmd = k.mub * gslip;
     float gvp = -gcmd;
-    const float gtv = dot3(gcmd, k.e);                     // tv_v = tv_w = 0 for non-driving points
     const float ge_p = k.tv * gcmd;
-    const float gv_p = tv_v * gtv, gwc_p = tv_w * gtv;
+    float gv_p = zero, gwc_p = zero;
+    if constexpr (GCTRL) {
+      const float gtv = dot3(gcmd, k.e);                   // tv_v = tv_w = 0 for non-driving points
+      gv_p = tv_v * gtv; gwc_p = tv_w * gtv;
+    }
     gFr = fmaf(k.Nn > zero ? gNn * M::div(one, k.Nn) : zero, k.Fr, gFr);
     const float gF1 = inside(k.F1, -mg, mg) ? gFr : zero;
     const float dF = dot3(gF1, k.F0);
@@ -284,7 +289,8 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
     lw += sum_points(gw_p);
     lR0 += sum_points(qa * P0); lR1 += sum_points(qa * P1); lR2 += sum_points(qa * P2);
     const float ge = sum_points(ge_p);
-    const float gv = sum_points(gv_p), gwc = sum_points(gwc_p);
+    float gv = zero, gwc = zero;
+    if constexpr (GCTRL) { gv = sum_points(gv_p); gwc = sum_points(gwc_p); }
     {   // e = col0(R) / max(|col0|, eps): through |col0| only when it is >= eps
       const float dote = k.coln2 >= 1e-12f ? dot3(ge, k.e) : zero;
       lR0 = fmaf(ge - dote * k.e, k.il, lR0);
@@ -301,7 +307,7 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
     load_upstream(n, up_next);            // output row n = the row step n - 1 produced (row 0: added after the loop)
     recompute(s_prev, rec_next);          // step n - 1 (after step 0: a harmless repeat of step 0)
     flush_stash();
-    bstore2(rGctrl, v_ctrl, gctrl_pending, gv_pending, gwc_pending);      // every lane of the row: same address, same value
+    if constexpr (GCTRL) bstore2(rGctrl, v_ctrl, gctrl_pending, gv_pending, gwc_pending);      // every lane of the row: same address, same value
     vjp(n, rec, up);
   };
 
@@ -322,7 +328,7 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
   // the upstream gradient of output row 0 sits in the buffer the last iteration prefetched into
   UpIn up = (n_steps & 1) ? uB : uA;
   flush_stash();
-  bstore2(rGctrl, v_ctrl, gctrl_pending, gv_pending, gwc_pending);
+  if constexpr (GCTRL) bstore2(rGctrl, v_ctrl, gctrl_pending, gv_pending, gwc_pending);
   if (act) {                               // what is still accumulated in registers
     atomic_add(at32(gzmap, goff + acc_idx), acc_z);
     if (want_gmu) atomic_add(at32(gmumap, goff + acc_idx), acc_m);
@@ -362,6 +368,6 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
 }
 
 bool use_component_parallel_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p);
-int launch_rollout_bwd_cp_f32(const RolloutBwdArgs<float>& a, int integ, bool xs_only, hipStream_t st);
+int launch_rollout_bwd_cp_f32(const RolloutBwdArgs<float>& a, int integ, bool xs_only, hipStream_t st);   // a.gcontrols may be NULL
 
 }  // namespace mf

@@ -47,7 +47,9 @@ def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf):
         gz = torch.zeros_like(z)
         gmu = torch.zeros_like(mu) if want_gmu else None
         zero_row = torch.zeros(16, dtype=dt, device=dev)
-    gcontrols = torch.empty_like(controls)
+    # the control gradient is skipped where nobody wants it and the chosen kernels can leave it out (mf_rollout_bwd_wants_gcontrols)
+    need_gc = ctx.needs_input_grad[3] or bool(_lib.lib().mf_rollout_bwd_wants_gcontrols(C.byref(desc))) or dt != torch.float32
+    gcontrols = torch.empty_like(controls) if need_gc else None
     gxd0, gR0, gw0 = torch.empty_like(xd0), torch.empty_like(R0), torch.empty_like(w0)
     gx0 = torch.empty_like(xd0) if ctx.needs_input_grad[4] else None
     bufs = _lib.MfRolloutBwdBufs(
