@@ -25,6 +25,9 @@
 namespace mf {
 
 constexpr int kTileVox = 64;
+// row loads in flight per wave: the forward kernels keep 4 (hand-unrolled; a generic 8-deep loop measured slower: 70 -> 92 us
+// at B = 1), the fused backward's gather over a pixel's depth bins 8 (unpipelined before: 152 -> 143 us at B = 8)
+constexpr int kPipeBwd = 8;
 
 struct SplatWs {        // carve-up of the caller's workspace (all int32)
   int* keys;            // [P]      linear voxel id of each point, -1 = dropped
@@ -414,17 +417,30 @@ __global__ void __launch_bounds__(256) lift_splat_bwd_gather_kernel(const S* __r
       const int md = min(64, D - d0);
       const int key_l = (lane < md) ? keys[p0 + (size_t)(d0 + lane) * hw] : -1;
       const S dep_l = (lane < md) ? depth[p0 + (size_t)(d0 + lane) * hw] : (S)0;
-      for (int d = 0; d < md; ++d) {
-        const int key = __builtin_amdgcn_readlane(key_l, d);    // wave-uniform
-        S dot = (S)0;
-        if (key >= 0) {
-          const S g = on ? gT[(size_t)key * C + c] : (S)0;
-          acc += mf_readlane(dep_l, d) * g;
-          dot = group_sum<64>(f * g);
-        }
-        if (lane == 0) {
-          const size_t p = p0 + (size_t)(d0 + d) * hw;
-          g_depth[p] = (c0 == 0) ? dot : g_depth[p] + dot;      // channel chunks beyond the first accumulate (same lane, in order)
+      // the gradient rows of the bins' voxels through a kPipeBwd-deep pipeline (one L2 round trip each; unpipelined, the 59
+      // dependent round trips of a pixel were the kernel); dropped points read row 0 and are masked
+      const int cl = on ? c : 0;
+      S buf[kPipeBwd];
+#pragma unroll
+      for (int i = 0; i < kPipeBwd; ++i) buf[i] = (i < md) ? gT[(size_t)max(__builtin_amdgcn_readlane(key_l, min(i, 63)), 0) * C + cl] : (S)0;
+      for (int dd = 0; dd < md; dd += kPipeBwd) {
+#pragma unroll
+        for (int i = 0; i < kPipeBwd; ++i) {
+          const int d = dd + i;
+          if (d < md) {
+            const int key = __builtin_amdgcn_readlane(key_l, d);    // wave-uniform
+            const S g = (key >= 0 && on) ? buf[i] : (S)0;
+            if (d + kPipeBwd < md) buf[i] = gT[(size_t)max(__builtin_amdgcn_readlane(key_l, d + kPipeBwd), 0) * C + cl];
+            S dot = (S)0;
+            if (key >= 0) {
+              acc += mf_readlane(dep_l, d) * g;
+              dot = group_sum<64>(f * g);
+            }
+            if (lane == 0) {
+              const size_t p = p0 + (size_t)(d0 + d) * hw;
+              g_depth[p] = (c0 == 0) ? dot : g_depth[p] + dot;      // channel chunks beyond the first accumulate (same lane, in order)
+            }
+          }
         }
       }
     }

@@ -64,8 +64,11 @@ class SplatPlan:
         3x3-by-3x3 products of get_geometry (lss.py:212, 218) stay here; the per-point part runs inside the key kernel."""
         B, N = trans.shape[:2]
         f32 = lambda t: t.detach().to(torch.float32)
-        cams = torch.cat((f32(post_trans).reshape(B * N, 3), torch.inverse(f32(post_rots)).reshape(B * N, 9),
-                          f32(rots).matmul(torch.inverse(f32(intrins))).reshape(B * N, 9), f32(trans).reshape(B * N, 3)), 1).contiguous()
+        # both 3x3 inverses of get_geometry (lss.py:212, 218) in ONE batched call: the batched LU treats every matrix on its own, so
+        # the results are the reference's, bit for bit, at half the launches
+        inv = torch.inverse(torch.cat((f32(post_rots).reshape(B * N, 3, 3), f32(intrins).reshape(B * N, 3, 3))))
+        cams = torch.cat((f32(post_trans).reshape(B * N, 3), inv[:B * N].reshape(B * N, 9),
+                          f32(rots).reshape(B * N, 3, 3).matmul(inv[B * N:]).reshape(B * N, 9), f32(trans).reshape(B * N, 3)), 1).contiguous()
         fr = f32(frustum).contiguous().view(-1, 3)
         return cls(None, dx, bx, nx, _cameras=(fr, cams, B), grid=grid)
 
