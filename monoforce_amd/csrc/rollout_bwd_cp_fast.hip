@@ -4,10 +4,12 @@
 
 namespace mf {
 
-// Measured, backward, N = 4 (tools/ab_cp.py; ms component-parallel vs one point per lane): B = 256 0.46 / 0.88, 1024 0.47 / 0.89,
-// 2048 0.53 / 0.90, 4096 0.74 / 0.95 -- up to one wave per SIMD; MF_CP_BWD_MAX_WAVES overrides (0 disables)
+// Measured, backward, N = 4 (tools/ab_cp.py; ms component-parallel vs one point per lane): B = 256 0.38 / 0.88, 1024 0.39 / 0.89,
+// 2048 0.45 / 0.90, 4096 0.63 / 0.95, 8192 0.81 / 0.99, 16384 1.63 / 1.62, 32768 3.19 / 2.89 -- up to two waves per SIMD (a lane
+// owns one footprint cell here: its gradient accumulator flushes with one atomic per map, which is what bounds the one-point-
+// per-lane kernel once the chip is full); MF_CP_BWD_MAX_WAVES overrides (0 disables)
 static long long cp_bwd_max_waves() {
-  static const long long v = getenv("MF_CP_BWD_MAX_WAVES") ? atoll(getenv("MF_CP_BWD_MAX_WAVES")) : 1024;
+  static const long long v = getenv("MF_CP_BWD_MAX_WAVES") ? atoll(getenv("MF_CP_BWD_MAX_WAVES")) : 2048;
   return v;
 }
 
