@@ -158,7 +158,7 @@ def test_full_horizon_f32_calm_floor():
         assert n_calm >= floor, (integ, n_calm)
 
 
-@pytest.mark.parametrize('B,ppl', [(1024, 1), (4096, 1), (1024, 0)])
+@pytest.mark.parametrize('B,ppl', [(1024, 1), (4096, 1), (1024, 0), (8192, 0)])
 def test_large_batch_shared_map_backward_vs_oracle(B, ppl):
     """The shared-map backward at BASELINE batch sizes -- private gradient copies (rollout b -> copy b % copies) and, from
     192 waves up, the accumulator carry-over kernels -- against the ORACLE: the loss touches 32 rollouts spread over the
