@@ -27,7 +27,7 @@ The JSON line (rank 0) carries, besides the contract's keys:
   roofline      dominant hand-written kernel of the headline step -- algorithmic bytes per launch (80 + 56 N
                 bytes per rollout-step forward, 160 + 120 N backward) / its average launch duration, measured live with HIP
                 events on the launch stream, against the 8 TB/s HBM peak -- plus `per_kernel` (forward AND backward
-                fractions) and `batch_sweep` (forward / backward kernel at 1024 ... 32768 rollouts; `first_B_at_40pct`).
+                fractions) and `batch_sweep` (forward / backward kernel at 1024, 4096, 8192, 16384 rollouts; `first_B_at_40pct`).
                 `traffic` = HBM bytes per launch from rocprofv3 PMC passes of this command, read from
                 profiles/hbm_traffic.json (`traffic_source` says so: it is not re-measured inside the run).
   forward_only  the c3f workload, same accounting (top level: both the forward-only and the forward+backward rate count)
@@ -290,7 +290,7 @@ class Runner:
         del dp
         return out, (N, T)
 
-    def batch_sweep(self, N, T, batches=(1024, 8192, 16384, 32768)):
+    def batch_sweep(self, N, T, batches=(1024, 4096, 8192, 16384)):
         """Forward and backward rollout kernels at a few batch sizes (kernel time from HIP events; not part of `value`)."""
         from monoforce_amd import _timing
         from monoforce_amd.train import TerrainFitProblem

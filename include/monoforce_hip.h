@@ -61,7 +61,7 @@ enum {
 
 /* MfRolloutDesc.points_per_lane, besides 0 / 1 / 4: the component-parallel mapping -- a rollout over a 16-lane row, four lanes
  * per contact point (lane = vector component / footprint cell).  float32 MF_MATH_FAST rigid bodies of <= 4 points, full or
- * states-only outputs; with points_per_lane = 0 it is chosen by itself for small launches (forward: B <= 2048, backward --
+ * states-only outputs; with points_per_lane = 0 it is chosen by itself for small launches (forward: B <= 4096, backward --
  * default integrator only -- B <= 8192), where a step costs ~2x fewer instructions per wave than one point per lane.  Other configurations fall
  * back to the automatic choice. */
 enum { MF_LANES_COMPONENT = 16 };

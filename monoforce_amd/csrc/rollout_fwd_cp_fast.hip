@@ -6,11 +6,11 @@
 namespace mf {
 
 // Waves of a component-parallel launch up to which it beats the one-point-per-lane mapping (4 rollouts per wave here, 16 there).
-// Measured, forward, N = 4 (tools/ab_cp.py; ms component-parallel vs one point per lane): B = 256 0.17 / 0.29, 1024 0.18 / 0.30,
-// 2048 0.22 / 0.30, 4096 0.32 / 0.30 -- so up to 512 waves, one per two SIMDs.  MF_CP_MAX_WAVES overrides (tuning / A-B runs;
-// 0 disables the mapping).
+// Measured, forward with all six outputs, N = 4 (tools/ab_cp.py; ms component-parallel vs one point per lane): B = 256 0.16 / 0.29,
+// 1024 0.16 / 0.29, 2048 0.17 / 0.29, 4096 0.18 / 0.30 (43 % of the HBM roofline), 8192 0.41 / 0.32 -- so up to 1024 waves, one per
+// SIMD.  MF_CP_MAX_WAVES overrides (tuning / A-B runs; 0 disables the mapping).
 static long long cp_max_waves() {
-  static const long long v = getenv("MF_CP_MAX_WAVES") ? atoll(getenv("MF_CP_MAX_WAVES")) : 512;
+  static const long long v = getenv("MF_CP_MAX_WAVES") ? atoll(getenv("MF_CP_MAX_WAVES")) : 1024;
   return v;
 }
 

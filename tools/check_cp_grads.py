@@ -1,4 +1,5 @@
-"""Debug aid: gradients of the component-parallel backward vs the one-point-per-lane backward over short horizons."""
+"""Quick device check: gradients of the component-parallel backward vs the one-point-per-lane backward over short horizons
+(T = 1 .. 48; a bug in the loop structure shows at T = 2, one in the unroll parity at T = 3 / 4)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
