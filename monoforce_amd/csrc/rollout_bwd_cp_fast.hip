@@ -14,7 +14,7 @@ static long long cp_bwd_max_waves() {
 }
 
 static bool cp_bwd_covers(const MfRolloutDesc* d, bool joints) {
-  if (d->math_mode != MF_MATH_FAST || d->N > 4 || joints || d->integrator != MF_INTEG_ODEINT_EULER) return false;
+  if (d->math_mode != MF_MATH_FAST || d->N > 4 || joints) return false;
   if (d->points_per_lane != 0 && d->points_per_lane != MF_LANES_COMPONENT) return false;
   const long long waves = ((long long)d->B + 3) / 4;
   if (d->points_per_lane == 0 && waves > cp_bwd_max_waves()) return false;
@@ -30,18 +30,8 @@ extern "C" int mf_rollout_bwd_wants_gcontrols(const MfRolloutDesc* d) { return (
 namespace mf {
 
 int launch_rollout_bwd_cp_f32(const RolloutBwdArgs<float>& a, int integ, bool xs_only, hipStream_t st) {
-  MF_REQUIRE(integ == MF_INTEG_ODEINT_EULER, MF_ERR_UNSUPPORTED, "rollout_bwd (component-parallel): default integrator only");
-  const int block = 64;
-  const long long threads = (long long)a.B * 16;
-  const unsigned grid = (unsigned)((threads + block - 1) / block);
-  const bool gc = a.gcontrols != nullptr;
-#define MF_BCP(XS_, GC_) hipLaunchKernelGGL((rollout_bwd_cp_kernel<MF_INTEG_ODEINT_EULER, XS_, GC_>), dim3(grid), dim3(block), 0, st, a)
-  if (xs_only) { if (gc) MF_BCP(true, true); else MF_BCP(true, false); }
-  else         { if (gc) MF_BCP(false, true); else MF_BCP(false, false); }
-#undef MF_BCP
-  hipError_t e = hipGetLastError();
-  MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("rollout_bwd (component-parallel) launch: ") + hipGetErrorString(e));
-  return MF_OK;
+  if (integ == MF_INTEG_DYNAMICS) return launch_rollout_bwd_cp_dynamics_f32(a, xs_only, st);
+  return launch_rollout_bwd_cp_variant<MF_INTEG_ODEINT_EULER>(a, xs_only, st);
 }
 
 }  // namespace mf

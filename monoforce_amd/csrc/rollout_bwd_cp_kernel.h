@@ -1,8 +1,8 @@
 // Fused DPhysics rollout, backward pass, COMPONENT-PARALLEL lane mapping (rollout_cp_common.h): the reverse-time adjoint of
 // rollout_bwd_kernel.h with a rollout spread over a 16-lane row -- quad = contact point, lane c = component c of every vector /
 // row c of R and of its adjoint, lane q = cell q of the bilinear footprint.  float32 fast math, rigid bodies of <= 4 contact
-// points, the reference's default integrator (torchdiffeq fixed-grid Euler, dphysics.py:499-528); everything else runs on
-// the one-point-per-lane kernels.  Same derivation, same autograd conventions (clamp passes gradient iff
+// points, both integrators (torchdiffeq fixed-grid Euler, dphysics.py:499-528; the semi-implicit Euler + Rodrigues step of
+// `dynamics`, dphysics.py:428-466); everything else runs on the one-point-per-lane kernels.  Same derivation, same autograd conventions (clamp passes gradient iff
 // inside, `.long()` indices are constants, |v| has zero gradient at 0); sums run in a different order.
 //
 // Why: at the BASELINE shape (1024 rollouts x 4 points) the G = 4 kernel is 64 waves issuing ~840 instructions per step --
@@ -28,9 +28,13 @@ __device__ __forceinline__ float ld1(const float* base, unsigned off) {
 // (~19 of ~410 instructions per step).
 // GCTRL = false: nobody asked for the gradient of the controls (a terrain fit, an encoder train step): its dot product, two
 // sums over the contact points and the store are compiled out.
-template <int INTEG, bool XS_ONLY, bool GCTRL>
+// LATE: the second half of a step's recompute (everything behind its two gathers) is placed after the vector-Jacobian chain of
+// the step before it instead of beside it.  With at most one wave per SIMD nothing else hides the round trip of the gathers
+// (B = 1024: 0.395 -> 0.368 ms, B = 4096: 0.63 -> 0.59 ms; dynamics(): 0.65 -> 0.47 ms); with two waves per SIMD the other
+// wave does, and the early form is the faster one (B = 8192: 0.82 vs 0.93 ms).
+template <int INTEG, bool XS_ONLY, bool GCTRL, bool LATE>
 __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
-  static_assert(INTEG == MF_INTEG_ODEINT_EULER, "the component-parallel backward covers the default integrator");
+  constexpr bool ODE = INTEG == MF_INTEG_ODEINT_EULER;
   using namespace cp;
   using M = Mth<float, true>;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -66,6 +70,9 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
   const float cgA = q == 0 ? -one : zero, cgB = q == 0 ? -one : (q == 3 ? zero : one);
   const float sel_xy = q < 2 ? one : zero;       // components that receive d(sample)/d(position) through the fractions
   const float mg = a.mg;
+  // bit masks of the lane role for mask_or: a ternary on the role around lane sums becomes an exec-masked branch, and a
+  // branch splits the basic block the two instruction streams of the loop are interleaved in
+  const unsigned lane0 = q == 0 ? ~0u : 0u, lane1 = q == 1 ? ~0u : 0u, lane2 = q >= 2 ? ~0u : 0u;
 
   // ---- adjoint of the state: component cc / row cc ----
   float lx = zero, lxd = zero, lw = zero, lR0 = zero, lR1 = zero, lR2 = zero;
@@ -84,7 +91,9 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
 
   struct StateIn { float x, xd, w, R0, R1, R2, cv, cw, t0, t1; };
   struct UpIn { float gXs, gXds, gOm, gR0, gR1, gR2, gFs, gFf; };
-  const int n_steps = a.T - 1;
+  // ODEINT: output row 0 is the initial state and step m maps row m -> row m + 1 (the last control is unused); DYNAMICS: step m
+  // maps row m - 1 (the initial state for m = 0) -> row m
+  const int n_steps = ODE ? a.T - 1 : a.T;
   const Rsrc rXraw = make_rsrc(a.Xraw), rXds = make_rsrc(a.Xds), rOm = make_rsrc(a.Om), rRs = make_rsrc(a.Rs);
   const Rsrc rgXs = make_rsrc(a.gXs), rgXds = make_rsrc(a.gXds), rgOm = make_rsrc(a.gOm), rgRs = make_rsrc(a.gRs);
   const Rsrc rgFs = make_rsrc(a.gFs), rgFf = make_rsrc(a.gFf), rCtrl = make_rsrc(a.controls), rGctrl = make_rsrc(a.gcontrols);
@@ -93,12 +102,27 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
   const unsigned sg_xs = row_stride * (unsigned)a.sXs * 4u, sg_xds = row_stride * (unsigned)a.sXds * 4u, sg_om = row_stride * (unsigned)a.sOm * 4u;
   const unsigned sg_r = row_stride * (unsigned)a.sRs * 4u;
   const unsigned sg_fs = row_stride * (unsigned)a.N * (unsigned)a.sFs * 4u, sg_ff = row_stride * (unsigned)a.N * (unsigned)a.sFf * 4u;
-  auto load_state = [&](int m, StateIn& s) {            // the state step m started from = saved output row m
+  struct { float x, xd, w, R0, R1, R2; } ini = {zero, zero, zero, zero, zero, zero};
+  if constexpr (!ODE) {
+    ini.x = a.x_init[b * 3 + cc]; ini.xd = a.xd0[b * 3 + cc]; ini.w = a.w0[b * 3 + cc];
+    ini.R0 = a.R0[b * 9 + cc * 3 + 0]; ini.R1 = a.R0[b * 9 + cc * 3 + 1]; ini.R2 = a.R0[b * 9 + cc * 3 + 2];
+  }
+  auto load_state = [&](int m, StateIn& s) {            // the state step m started from
     const unsigned um = __builtin_amdgcn_readfirstlane((unsigned)m);    // wave-uniform, and provably so (scalar offsets)
-    s.x = bload1(rXraw, v3, um * s3); s.xd = bload1(rXds, v3, um * s3); s.w = bload1(rOm, v3, um * s3);
-    bload3(rRs, v9, um * s9, &s.R0, &s.R1, &s.R2);
+    if constexpr (ODE) {                                // = saved output row m
+      s.x = bload1(rXraw, v3, um * s3); s.xd = bload1(rXds, v3, um * s3); s.w = bload1(rOm, v3, um * s3);
+      bload3(rRs, v9, um * s9, &s.R0, &s.R1, &s.R2);
+      s.t0 = a.ts[m]; s.t1 = a.ts[m + 1 < a.T ? m + 1 : m];
+    } else {                                            // = saved output row m - 1; step 0: the initial state, held in registers
+      const bool init = um == 0u;                       // (a select between two base pointers becomes a branch around scalar loads)
+      const unsigned ur = init ? 0u : um - 1u;
+      float R0, R1, R2;
+      const float x = bload1(rXraw, v3, ur * s3), xd = bload1(rXds, v3, ur * s3), w = bload1(rOm, v3, ur * s3);
+      bload3(rRs, v9, ur * s9, &R0, &R1, &R2);
+      s.x = init ? ini.x : x; s.xd = init ? ini.xd : xd; s.w = init ? ini.w : w;
+      s.R0 = init ? ini.R0 : R0; s.R1 = init ? ini.R1 : R1; s.R2 = init ? ini.R2 : R2;
+    }
     bload2(rCtrl, v_ctrl, um * 8u, &s.cv, &s.cw);
-    s.t0 = a.ts[m]; s.t1 = a.ts[m + 1 < a.T ? m + 1 : m];
   };
   auto load_upstream = [&](int orow, UpIn& u) {         // upstream gradients of output row `orow`
     const unsigned uo = __builtin_amdgcn_readfirstlane((unsigned)orow);
@@ -119,7 +143,9 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
     }
   };
 
-  if constexpr (GCTRL) bstore2(rGctrl, v_ctrl, (unsigned)(a.T - 1) * 8u, zero, zero);   // the last control is never used by the explicit scheme
+  // ODEINT: the last control is never used by the explicit scheme.  DYNAMICS uses all T of them: the deferred store below
+  // writes these zeros to the last row first, then that step's own result over them (same lanes, program order).
+  if constexpr (GCTRL && ODE) bstore2(rGctrl, v_ctrl, (unsigned)(a.T - 1) * 8u, zero, zero);
 
   // Cell-gradient accumulator of this lane's footprint cell: contributions of consecutive steps to the SAME cell (a robot
   // moves <= 0.2 cell per step) add up in registers; when the lane's cell changes, the old pair goes to a stash that is
@@ -144,35 +170,41 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
   // recompute of step n - 1 (its gathers included) runs beside it in the same basic block -- two independent instruction
   // streams that fill each other's dependency stalls -- and the saved rows are loaded two steps ahead.
   struct Rec {
-    float R0, R1, R2, r1, r2, w1, w2, vp, e, il, coln2, tv, h;
+    float x, xd, cv, cw, r, pc, fr, mc;                  // between the two halves of the recompute
+    float R0, R1, R2, w, r1, r2, w1, w2, vp, e, il, coln2, tv, h;
     float wq, wa, wb, zc, mcv, mub, nrm, inl, cj, inv_csum, A, F0, F1, Fr, Nn, cmdv, s, sn, stv, Gf, f1, f2, wraw;
     int idx;
   };
-  auto recompute = [&](const StateIn& st, Rec& k) {
-    const float x = st.x, xd = st.xd, w = st.w;
+  // first half: the footprint cell of this lane and its two gathers -- issued a whole vector-Jacobian chain (~1000 cycles)
+  // before the second half consumes them
+  auto recompute_gather = [&](const StateIn& st, Rec& k) {
+    k.x = st.x; k.xd = st.xd; k.w = st.w; k.cv = st.cv; k.cw = st.cw;
     k.R0 = st.R0; k.R1 = st.R1; k.R2 = st.R2;
-    k.h = st.t1 - st.t0;
-    const float r = P0 * st.R0 + P1 * st.R1 + P2 * st.R2;
-    const float pc = r + x;
+    k.h = ODE ? st.t1 - st.t0 : a.dt;
+    k.r = P0 * st.R0 + P1 * st.R1 + P2 * st.R2;
+    k.pc = k.r + st.x;
     const float lim = 262144.0f;
-    const float uq = M::cell_coord(pc, a.d_max, a.res, a.inv_res);
+    const float uq = M::cell_coord(k.pc, a.d_max, a.res, a.inv_res);
     const int ui = (int)M::clamp(uq, -lim, lim);
-    const float fr = uq - (float)ui;
+    k.fr = uq - (float)ui;
     const int base = dppi<kB1>(ui) + __mul24(a.H, dppi<kB0>(ui));
     k.idx = min(max(base + cell_off, 0), last);
     k.zc = ld32(zmap, moff + (unsigned)k.idx);
-    const float mc = ld32(mumap, moff + (unsigned)k.idx);
+    k.mc = ld32(mumap, moff + (unsigned)k.idx);
+  };
+  auto recompute = [&](Rec& k) {
+    const float xd = k.xd, w = k.w, r = k.r, pc = k.pc, fr = k.fr;
     k.wa = fmaf(wa_s, dpp<kB0>(fr), wa_o); k.wb = fmaf(wb_s, dpp<kB1>(fr), wb_o);
     k.wq = k.wa * k.wb;
     k.r1 = dpp<kRot1>(r); k.r2 = dpp<kRot2>(r);
     k.w1 = dpp<kRot1>(w); k.w2 = dpp<kRot2>(w);
     k.vp = xd + (k.w1 * k.r2 - k.w2 * k.r1);
-    k.coln2 = dot3(st.R0, st.R0);
+    k.coln2 = dot3(k.R0, k.R0);
     k.il = M::inv_len(k.coln2);
-    k.e = st.R0 * k.il;
-    k.tv = tv_v * st.cv + tv_w * st.cw;
+    k.e = k.R0 * k.il;
+    k.tv = tv_v * k.cv + tv_w * k.cw;
     const float zq = dot4(k.wq, k.zc);
-    k.mcv = has_mu ? mc : one;
+    k.mcv = has_mu ? k.mc : one;
     k.mub = dot4(k.wq, k.mcv);
     const float dz = k.zc - dpp<kB0>(k.zc);
     const float u = fmaf(dpp<kN12>(dz), n_mul, n_add);
@@ -203,22 +235,69 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
   // vector-Jacobian product of step n given its recomputed intermediates and the upstream gradient of the forces it fed
   auto vjp = [&](int n, const Rec& k, const UpIn& up) {
     const float h = k.h, w1 = k.w1, w2 = k.w2, r1 = k.r1, r2 = k.r2, nrm = k.nrm, cj = k.cj, inv_csum = k.inv_csum;
-    // ---- integrator backward (torchdiffeq fixed-grid Euler): adjoint of the step's outputs -> (g_xdd, g_wd, g_Fs, g_Ff) ----
-    float gFr_up = zero, gFf_up = zero;
-    if constexpr (!XS_ONLY) {
-      laFs += act ? up.gFs : zero;
-      laFf += act ? up.gFf : zero;
-      gFr_up = h * laFs; gFf_up = h * laFf;
-    }
-    const float gxdd = h * lxd, gwd = h * lw;
-    lxd = fmaf(h, lx, lxd);                               // x' = x + h xd
-    {   // R' = R + h [w]x R, column by column: d/dw of (w x R_j) . g_j = R_j x g_j ; d/dR_j = g_j x w   (g_j = h lR[:, j])
+    // ---- integrator backward: adjoint of the step's outputs -> (g_xdd, g_wd, g_Fs, g_Ff) ----
+    float gFr_up = zero, gFf_up = zero, gxdd, gwd;
+    if constexpr (ODE) {   // torchdiffeq fixed-grid Euler
+      if constexpr (!XS_ONLY) {
+        laFs += act ? up.gFs : zero;
+        laFf += act ? up.gFf : zero;
+        gFr_up = h * laFs; gFf_up = h * laFf;
+      }
+      gxdd = h * lxd; gwd = h * lw;
+      lxd = fmaf(h, lx, lxd);                               // x' = x + h xd
+      // R' = R + h [w]x R, column by column: d/dw of (w x R_j) . g_j = R_j x g_j ; d/dR_j = g_j x w   (g_j = h lR[:, j])
       const float g0 = h * lR0, g1 = h * lR1, g2 = h * lR2;
       const float g01 = dpp<kRot1>(g0), g02 = dpp<kRot2>(g0), g11 = dpp<kRot1>(g1), g12 = dpp<kRot2>(g1), g21 = dpp<kRot1>(g2), g22 = dpp<kRot2>(g2);
       lw += (dpp<kRot1>(k.R0) * g02 - dpp<kRot2>(k.R0) * g01) + (dpp<kRot1>(k.R1) * g12 - dpp<kRot2>(k.R1) * g11) + (dpp<kRot1>(k.R2) * g22 - dpp<kRot2>(k.R2) * g21);
       lR0 += g01 * w2 - g02 * w1;
       lR1 += g11 * w2 - g12 * w1;
       lR2 += g21 * w2 - g22 * w1;
+    } else {
+      // xd' = xd + xdd h, x' = x + xd' h, w' = w + wd h, R' = R M(w'),  M = I + K sin(th h) + K^2 (1 - cos(th h)),
+      // K = [kv]x, kv = w' / max(|w'|, eps), th = |w'|.  The forces of this step are outputs themselves.
+      // With G = R^T lR (the gradient of M):  <G, K> = -kv . ax(G),  <G, K^2> = kv^T G kv - |kv|^2 tr G,
+      // d/dkv = -sin ax(G) - (1 - cos) (2 tr(G) kv - (G + G^T) kv),  ax(G)_l = G[l+1][l+2] - G[l+2][l+1]
+      // -- no 3x3 product is ever formed: a lane holds row c of R and lR, so  (G kv)_m = R[:, m] . (lR kv),
+      // (G^T kv)_j = (R kv) . lR[:, j],  ax(G) = sum over the rows of (row of R) x (row of lR),  tr G = sum of their dots.
+      if constexpr (!XS_ONLY) { gFr_up = act ? up.gFs : zero; gFf_up = act ? up.gFf : zero; }
+      const float wd = M::clamp(k.wraw, -a.omega_max, a.omega_max);
+      const float wn = fmaf(wd, h, k.w);
+      const float th2 = dot3(wn, wn);
+      const float idn = M::inv_len(th2);                    // 1 / max(th, 1e-6)
+      const float kv = wn * idn;
+      const float th = M::sqrt(th2);
+      float sn_, oc;
+      M::sincos_small(th * h, &sn_, &oc);
+      const float kk = dot3(kv, kv);
+      const float kv1 = dpp<kRot1>(kv), kv2 = dpp<kRot2>(kv);
+      const float ok = oc * kv;
+      const float m0 = fmaf(ok, kv, fmaf(-oc, kk, one)), m1 = fmaf(ok, kv1, -(sn_ * kv2)), m2 = fmaf(ok, kv2, sn_ * kv1);   // M[c][c], M[c][c+1], M[c][c+2]
+      const float q0 = dpp<kB0>(kv), q1 = dpp<kB1>(kv), q2 = dpp<kB2>(kv);
+      const float Lk = lR0 * q0 + lR1 * q1 + lR2 * q2, Rk = k.R0 * q0 + k.R1 * q1 + k.R2 * q2;
+      const float Gk0 = dot3(k.R0, Lk), Gk1 = dot3(k.R1, Lk), Gk2 = dot3(k.R2, Lk);
+      const float Gt0 = dot3(Rk, lR0), Gt1 = dot3(Rk, lR1), Gt2 = dot3(Rk, lR2);
+      const float trG = sum3(k.R0 * lR0 + k.R1 * lR1 + k.R2 * lR2);
+      const float a0 = sum3(k.R1 * lR2 - k.R2 * lR1), a1 = sum3(k.R2 * lR0 - k.R0 * lR2), a2 = sum3(k.R0 * lR1 - k.R1 * lR0);
+      const float ga = -(q0 * a0 + q1 * a1 + q2 * a2);
+      const float gb = (q0 * Gk0 + q1 * Gk1 + q2 * Gk2) - kk * trG;
+      float gth = ga * h * (one - oc) + gb * h * sn_;
+      // component c of a replicated triple: bit masks on the lane role (a ternary on it turns into branches)
+      const float ac = mask_or(mask_or(mask_or(zero, a0, lane0), a1, lane1), a2, lane2);
+      const float sc = mask_or(mask_or(mask_or(zero, Gk0 + Gt0, lane0), Gk1 + Gt1, lane1), Gk2 + Gt2, lane2);
+      const float gk = -(sn_ * ac) - oc * (2.0f * trG * kv - sc);
+      const float gkw = dot3(gk, wn);
+      const float idn2 = th2 >= 1e-12f ? idn * idn : zero;      // through max(th, eps) only when th >= eps
+      gth = fmaf(-gkw, idn2, gth);
+      const float ith = th2 > zero ? M::div(one, th) : zero;    // d|w'|/dw' = w' / |w'|, 0 at 0
+      lw += fmaf(gth * ith, wn, gk * idn);
+      gwd = h * lw;
+      lxd = fmaf(h, lx, lxd);
+      gxdd = h * lxd;
+      // lR <- lR M^T: column m of the result = sum_j lR[:, j] M[m][j], M[m][j] sits in lane m as m_{(j - m) % 3}
+      const float n0 = lR0 * dpp<kB0>(m0) + lR1 * dpp<kB0>(m1) + lR2 * dpp<kB0>(m2);
+      const float n1 = lR0 * dpp<kB1>(m2) + lR1 * dpp<kB1>(m0) + lR2 * dpp<kB1>(m1);
+      const float n2 = lR0 * dpp<kB2>(m1) + lR1 * dpp<kB2>(m2) + lR2 * dpp<kB2>(m0);
+      lR0 = n0; lR1 = n1; lR2 = n2;
     }
     // ---- RHS backward ----
     const float mwd = inside(k.wraw, -a.omega_max, a.omega_max) ? gwd : zero;
@@ -277,7 +356,7 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
     // d(sample)/d(position) through the fractions only: d wq / d fx = wa_s * wb, d wq / d fy = wb_s * wa
     const float vq = gzq * k.zc + gmuq * k.mcv;
     const float gpx = dot4(vq, wa_s * k.wb), gpy = dot4(vq, wb_s * k.wa);
-    const float gp = q == 0 ? gpx * a.inv_res : (q == 1 ? gpy * a.inv_res : gdh);
+    const float gp = mask_or(mask_or(mask_or(zero, gpx * a.inv_res, lane0), gpy * a.inv_res, lane1), gdh, lane2);
     // v_p = xd + w x r
     const float gvp1 = dpp<kRot1>(gvp), gvp2 = dpp<kRot2>(gvp);
     gr += gvp1 * w2 - gvp2 * w1;                           // dr += gvp x w
@@ -292,23 +371,31 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
     float gv = zero, gwc = zero;
     if constexpr (GCTRL) { gv = sum_points(gv_p); gwc = sum_points(gwc_p); }
     {   // e = col0(R) / max(|col0|, eps): through |col0| only when it is >= eps
-      const float dote = k.coln2 >= 1e-12f ? dot3(ge, k.e) : zero;
+      const float dote = dot3(ge, k.e) * (k.coln2 >= 1e-12f ? one : zero);   // (a ternary around the lane sum becomes a branch)
       lR0 = fmaf(ge - dote * k.e, k.il, lR0);
     }
     gctrl_pending = __builtin_amdgcn_readfirstlane((unsigned)n * 8u); gv_pending = gv; gwc_pending = gwc;      // stored by the next iteration (or after the loop)
   };
 
   // One iteration.  Memory operations in program order (vmcnt is one in-order counter over loads, stores and atomics):
-  // prefetch of the rows of step n - 2 and of output row n | gathers of step n - 1 (inside recompute) | the atomics and the
-  // control-gradient store deferred from step n + 1 -- so no wait of this or the next iteration covers a younger store.
+  // prefetch of the rows of step n - 2 and of output row n | gathers of step n - 1 | the atomics and the control-gradient
+  // store deferred from step n + 1 -- so no wait of this or the next iteration covers a younger store.  The gathers are
+  // consumed beside the vector-Jacobian chain of step n or (LATE) after it.
   auto body = [&](int n, const Rec& rec, Rec& rec_next, const StateIn& s_prev, StateIn& s_pp, const UpIn& up, UpIn& up_next) {
     add_upstream_state(up);
     load_state(max(n - 2, 0), s_pp);
-    load_upstream(n, up_next);            // output row n = the row step n - 1 produced (row 0: added after the loop)
-    recompute(s_prev, rec_next);          // step n - 1 (after step 0: a harmless repeat of step 0)
+    load_upstream(ODE ? n : max(n - 1, 0), up_next);      // the row step n - 1 produced (ODEINT's row 0: added after the loop)
+    recompute_gather(s_prev, rec_next);   // step n - 1 (after step 0: a harmless repeat of step 0)
+    if constexpr (!LATE) recompute(rec_next);
     flush_stash();
     if constexpr (GCTRL) bstore2(rGctrl, v_ctrl, gctrl_pending, gv_pending, gwc_pending);      // every lane of the row: same address, same value
     vjp(n, rec, up);
+    if constexpr (LATE) {
+      // the gathered values pass through an empty asm that also reads the adjoint the chain ends in: their consumers cannot
+      // be scheduled ahead of it (left alone, the compiler puts them a few instructions behind the gathers)
+      asm("" : "+v"(rec_next.zc), "+v"(rec_next.mc) : "v"(lR0));
+      recompute(rec_next);
+    }
   };
 
   StateIn sA, sB;
@@ -316,9 +403,10 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
   Rec recA, recB;
   int n = n_steps - 1;
   load_state(max(n, 0), sA);
-  load_upstream(min(max(n, 0) + 1, a.T - 1), uA);
+  load_upstream(min(max(n, 0) + (ODE ? 1 : 0), a.T - 1), uA);
   load_state(max(n - 1, 0), sB);
-  recompute(sA, recA);
+  recompute_gather(sA, recA);
+  recompute(recA);
   __builtin_amdgcn_s_waitcnt(0);
   for (; n >= 1; n -= 2) {
     body(n, recA, recB, sB, sA, uA, uB);
@@ -333,9 +421,10 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
     atomic_add(at32(gzmap, goff + acc_idx), acc_z);
     if (want_gmu) atomic_add(at32(gmumap, goff + acc_idx), acc_m);
   }
-  // output 0 is the initial state itself (its forces are constant zeros)
-  if (n_steps == 0) load_upstream(0, up);      // T == 1: the loop never ran
-  add_upstream_state(up);
+  if constexpr (ODE) {                         // output 0 is the initial state itself (its forces are constant zeros)
+    if (n_steps == 0) load_upstream(0, up);    // T == 1: the loop never ran
+    add_upstream_state(up);
+  }
 
   // terrain snap of the initial height: x.z = mean_i blend(z; cell((R0 P_i + x0).xy))   (dphysics.py:567-571)
   float gx0 = lx;
@@ -369,5 +458,25 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
 
 bool use_component_parallel_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p);
 int launch_rollout_bwd_cp_f32(const RolloutBwdArgs<float>& a, int integ, bool xs_only, hipStream_t st);   // a.gcontrols may be NULL
+int launch_rollout_bwd_cp_dynamics_f32(const RolloutBwdArgs<float>& a, bool xs_only, hipStream_t st);      // rollout_bwd_cp_dyn_fast.hip
+
+// one launch of the variant (positions-only loss?, control gradient?, late recompute?) the arguments call for
+template <int INTEG>
+int launch_rollout_bwd_cp_variant(const RolloutBwdArgs<float>& a, bool xs_only, hipStream_t st) {
+  const int block = 64;
+  const long long threads = (long long)a.B * 16;
+  const unsigned grid = (unsigned)((threads + block - 1) / block);
+  const bool gc = a.gcontrols != nullptr;
+  const bool late = grid <= 1024u;       // at most one wave per SIMD (256 CUs x 4)
+#define MF_BCP(XS_, GC_, L_) hipLaunchKernelGGL((rollout_bwd_cp_kernel<INTEG, XS_, GC_, L_>), dim3(grid), dim3(block), 0, st, a)
+#define MF_BCP_L(XS_, GC_) do { if (late) MF_BCP(XS_, GC_, true); else MF_BCP(XS_, GC_, false); } while (0)
+  if (xs_only) { if (gc) MF_BCP_L(true, true); else MF_BCP_L(true, false); }
+  else         { if (gc) MF_BCP_L(false, true); else MF_BCP_L(false, false); }
+#undef MF_BCP_L
+#undef MF_BCP
+  hipError_t e = hipGetLastError();
+  MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("rollout_bwd (component-parallel) launch: ") + hipGetErrorString(e));
+  return MF_OK;
+}
 
 }  // namespace mf

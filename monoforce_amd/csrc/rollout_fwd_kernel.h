@@ -85,16 +85,18 @@ struct Mth<float, true> {
   static __device__ __forceinline__ float clamp(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }  // 1 instr
   // joint angles (|a| of a few radians at most): hardware sin / cos after the 1 / 2pi scaling, ~1e-6 absolute
   static __device__ __forceinline__ void sincos(float v, float* sn, float* cs) { *sn = __sinf(v); *cs = __cosf(v); }
+  // sin(v), 1 - cos(v) of the Rodrigues step, v = |w| dt ~ 1e-2.  Branch-free (a branch here splits the basic block the
+  // backward's two instruction streams are interleaved in): |v| < 1 -- Taylor series to v^11 / v^12 (< 2e-10), and 1 - cos
+  // without the cancellation; a body spinning faster than 1 rad per step gets the hardware sin / cos (~1e-6 absolute on
+  // values of order 1).
   static __device__ __forceinline__ void sincos_small(float v, float* s, float* omc) {
-    if (fabsf(v) < 0.25f) {  // |w| dt is ~1e-2: short Taylor series, and 1 - cos without the cancellation
-      const float v2 = v * v;
-      *s = v * (1.0f + v2 * (-1.0f / 6 + v2 * (1.0f / 120 - v2 * (1.0f / 5040))));
-      *omc = v2 * (0.5f + v2 * (-1.0f / 24 + v2 * (1.0f / 720 - v2 * (1.0f / 40320))));
-    } else {
-      float c;
-      sincosf(v, s, &c);
-      *omc = 1.0f - c;
-    }
+    const float v2 = v * v;
+    const float ts = v * (1.0f + v2 * (-1.0f / 6 + v2 * (1.0f / 120 + v2 * (-1.0f / 5040 + v2 * (1.0f / 362880 - v2 * (1.0f / 39916800))))));
+    const float tc = v2 * (0.5f + v2 * (-1.0f / 24 + v2 * (1.0f / 720 + v2 * (-1.0f / 40320 + v2 * (1.0f / 3628800 - v2 * (1.0f / 479001600))))));
+    const float rev = __builtin_amdgcn_fractf(v * 0.15915494309189535f);
+    const bool small = fabsf(v) < 1.0f;
+    *s = small ? ts : __builtin_amdgcn_sinf(rev);
+    *omc = small ? tc : 1.0f - __builtin_amdgcn_cosf(rev);
   }
 };
 

@@ -317,8 +317,9 @@ def test_component_parallel_mapping_vs_reference_golden(integ, friction, given_s
         assert hp.rel_err(st[0].cpu(), sc[0]) <= 1e-5       # the in-place terrain snap of the caller's start position
 
 
+@pytest.mark.parametrize('integ', [0, 1])
 @pytest.mark.parametrize('N', [1, 2, 3])
-def test_component_parallel_mapping_with_fewer_points(N):
+def test_component_parallel_mapping_with_fewer_points(N, integ):
     """Bodies of fewer than 4 contact points leave quads of the 16-lane row without a point: they must contribute nothing."""
     from monoforce_amd import synthetic as syn
     pts4, _ = syn.robot_points_4()
@@ -329,10 +330,10 @@ def test_component_parallel_mapping_with_fewer_points(N):
     B, T = 5, 40
     z = torch.stack([syn.bump_terrain(syn.bump_params(20 + k), 1.6, 0.1) * 0.3 for k in range(B)])
     ctrl = syn.varying_controls(B, T, seed=3)
-    base = make_dphysics(pts4, [pts4[:, 1] > 0, pts4[:, 1] <= 0], 1, 0.1, 1.6)
+    base = make_dphysics(pts4, [pts4[:, 1] > 0, pts4[:, 1] <= 0], integ, 0.1, 1.6)
     outs = {}
     for ppl in (16, 1):
-        dp = make_dphysics(pts4, [pts4[:, 1] > 0, pts4[:, 1] <= 0], 1, 0.1, 1.6, points_per_lane=ppl)
+        dp = make_dphysics(pts4, [pts4[:, 1] > 0, pts4[:, 1] <= 0], integ, 0.1, 1.6, points_per_lane=ppl)
         dp.dphys_cfg.robot_points = torch.as_tensor(pts)
         dp.dphys_cfg.driving_parts = [torch.as_tensor(m) for m in masks]
         dp.x_points = dp.dphys_cfg.robot_points.unsqueeze(0).to(dp.device)
@@ -346,8 +347,9 @@ def test_component_parallel_mapping_with_fewer_points(N):
         assert hp.rel_err(a_, b_) <= (2e-4 if k == 'g_z' else 1e-4), (k, hp.rel_err(a_, b_))
 
 
+@pytest.mark.parametrize('integ', [0, 1])
 @pytest.mark.parametrize('B', [5, 1024])
-def test_component_parallel_backward_positions_only_loss(B):
+def test_component_parallel_backward_positions_only_loss(B, integ):
     """A loss that reads the positions only (what `physics_loss` does, losses.py:102-127) takes the backward kernel with the
     other five upstream gradients compiled out: its gradients vs the oracle (B = 5 per-rollout maps, every rollout in the loss;
     B = 1024 on one shared map, 32 rollouts in the loss)."""
@@ -361,11 +363,11 @@ def test_component_parallel_backward_positions_only_loss(B):
     ctrl = syn.varying_controls(B, T, seed=6)
     sel = torch.arange(0, B, max(B // 32, 1))[:32]
     wts = syn.probe_weights((len(sel), T, 3), phase=0.7)
-    dp = make_dphysics(pts, masks, 1, 0.05, 6.4, points_per_lane=16)
+    dp = make_dphysics(pts, masks, integ, 0.05, 6.4, points_per_lane=16)
     zd, md, cd = z.to(DEV).requires_grad_(True), mu.to(DEV).requires_grad_(True), ctrl.to(DEV).requires_grad_(True)
     (Xs, _, _, _), _ = dp(zd, cd, friction=md)
     (Xs[sel.to(DEV)] * wts.to(DEV)).sum().backward()
-    spec = hp.spec_from(pts, masks, 1, 0.05, 6.4)
+    spec = hp.spec_from(pts, masks, integ, 0.05, 6.4)
     zc, mc = z.double().requires_grad_(True), mu.double().requires_grad_(True)
     cc = ctrl[sel].double().requires_grad_(True)
     zin = zc.expand(len(sel), -1, -1) if shared else zc[sel]
@@ -375,3 +377,34 @@ def test_component_parallel_backward_positions_only_loss(B):
     assert hp.rel_err(zd.grad, zc.grad) <= 2e-4, hp.rel_err(zd.grad, zc.grad)
     assert hp.rel_err(md.grad, mc.grad) <= 2e-4, hp.rel_err(md.grad, mc.grad)
     assert hp.rel_err(cd.grad[sel.to(DEV)], cc.grad) <= 2e-4, hp.rel_err(cd.grad[sel.to(DEV)], cc.grad)
+
+
+@pytest.mark.parametrize('ppl', [0, 1, 16])
+def test_dynamics_rodrigues_step_of_a_fast_spinning_body(ppl):
+    """`dynamics()`'s rotation update, R <- R (I + K sin(|w| dt) + K^2 (1 - cos(|w| dt))) (dphysics.py:274-288), away from the
+    |w| dt ~ 1e-2 of a driving robot: start spins of 20 .. 400 rad/s cover the series (|w| dt < 1) and the hardware sin / cos of
+    the fast-math kernels beyond it, forward and backward, against the float64 oracle."""
+    from tests.golden_state import given_state as make_state
+    from monoforce_amd import synthetic as syn
+    pts, masks = syn.robot_points_4()
+    B, T = 6, 6
+    z = torch.stack([syn.bump_terrain(syn.bump_params(70 + k), 1.6, 0.1) * 0.2 for k in range(B)])
+    ctrl = syn.varying_controls(B, T, seed=11)
+    x, xd, R, w = make_state(B)
+    spin = torch.tensor([20.0, 60.0, 99.0, 101.0, 250.0, 400.0], dtype=torch.float64)
+    w = torch.stack([0.3 * spin, -0.2 * spin, 0.93 * spin], 1)
+    state = (x, xd, R, w)
+    dp = make_dphysics(pts, masks, 0, 0.1, 1.6, points_per_lane=ppl)
+    zd = z.to(DEV).requires_grad_(True)
+    st = tuple(s.float().clone().to(DEV) for s in state)
+    (Xs, Xds, Rs, Om), _ = dp(z_grid=zd, controls=ctrl.to(DEV), state=st)
+    wts = syn.probe_weights((B, T, 3, 3), phase=0.3)
+    ((Rs * wts.to(DEV)).sum() + Xs.square().sum()).backward()
+    spec = hp.spec_from(pts, masks, 0, 0.1, 1.6)
+    zc = z.double().requires_grad_(True)
+    (rX, rXd, rR, rOm), _ = orc.rollout(spec, zc, ctrl.double(), state=tuple(s.clone() for s in state))
+    ((rR * wts.double()).sum() + rX.square().sum()).backward()
+    for b in range(B):
+        assert hp.rel_err(Rs[b], rR[b]) <= 2e-5, (b, hp.rel_err(Rs[b], rR[b]))
+        assert hp.rel_err(Xs[b], rX[b]) <= 1e-4, (b, hp.rel_err(Xs[b], rX[b]))
+    assert hp.rel_err(zd.grad, zc.grad) <= 2e-4, hp.rel_err(zd.grad, zc.grad)
