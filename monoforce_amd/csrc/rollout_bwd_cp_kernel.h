@@ -2,8 +2,9 @@
 // rollout_bwd_kernel.h with a rollout spread over a 16-lane row -- quad = contact point, lane c = component c of every vector /
 // row c of R and of its adjoint, lane q = cell q of the bilinear footprint.  float32 fast math, rigid bodies of <= 4 contact
 // points, both integrators (torchdiffeq fixed-grid Euler, dphysics.py:499-528; the semi-implicit Euler + Rodrigues step of
-// `dynamics`, dphysics.py:428-466); everything else runs on the one-point-per-lane kernels.  Same derivation, same autograd conventions (clamp passes gradient iff
-// inside, `.long()` indices are constants, |v| has zero gradient at 0); sums run in a different order.
+// `dynamics`, dphysics.py:428-466); everything else runs on the one-point-per-lane kernels.  Same derivation, same autograd
+// conventions (clamp passes gradient iff inside, `.long()` indices are constants, |v| has zero gradient at 0);
+// sums run in a different order.
 //
 // Why: at the BASELINE shape (1024 rollouts x 4 points) the G = 4 kernel is 64 waves issuing ~840 instructions per step --
 // the launch is bound by the instruction stream of one wave.  Here a step is ~1/3 of that per wave (3-vector algebra is
@@ -32,9 +33,17 @@ __device__ __forceinline__ float ld1(const float* base, unsigned off) {
 // the step before it instead of beside it.  With at most one wave per SIMD nothing else hides the round trip of the gathers
 // (B = 1024: 0.395 -> 0.368 ms, B = 4096: 0.63 -> 0.59 ms; dynamics(): 0.65 -> 0.47 ms); with two waves per SIMD the other
 // wave does, and the early form is the faster one (B = 8192: 0.82 vs 0.93 ms).
-template <int INTEG, bool XS_ONLY, bool GCTRL, bool LATE>
+//
+// Tried and not kept -- producer / consumer waves (the recompute on a second SIMD of the CU, each step's 38 intermediates handed
+// over through an LDS ring, counters instead of barriers; B <= 1024 leaves half of the SIMDs idle): the consumer's ~250
+// instructions are one dependent chain, and a dependent VALU instruction issues every ~6.3 cycles against ~4.3 for an
+// independent one (profiles/r1g_microbench_valu_issue.txt) -- the single wave fills exactly those bubbles with the recompute.
+// Measured at B = 1024: 0.388 ms split vs 0.365 ms single wave (dynamics(): 0.478 vs 0.443).
+enum { kCpEarly = 0, kCpLate = 1 };
+template <int INTEG, bool XS_ONLY, bool GCTRL, int MODE>
 __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
   constexpr bool ODE = INTEG == MF_INTEG_ODEINT_EULER;
+  constexpr bool LATE = MODE == kCpLate;
   using namespace cp;
   using M = Mth<float, true>;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -458,7 +467,7 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
 
 bool use_component_parallel_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p);
 int launch_rollout_bwd_cp_f32(const RolloutBwdArgs<float>& a, int integ, bool xs_only, hipStream_t st);   // a.gcontrols may be NULL
-int launch_rollout_bwd_cp_dynamics_f32(const RolloutBwdArgs<float>& a, bool xs_only, hipStream_t st);      // rollout_bwd_cp_dyn_fast.hip
+int launch_rollout_bwd_cp_dynamics_f32(const RolloutBwdArgs<float>& a, bool xs_only, hipStream_t st);      // rollout_bwd_dyn_cp_fast.hip
 
 // one launch of the variant (positions-only loss?, control gradient?, late recompute?) the arguments call for
 template <int INTEG>
@@ -467,9 +476,9 @@ int launch_rollout_bwd_cp_variant(const RolloutBwdArgs<float>& a, bool xs_only, 
   const long long threads = (long long)a.B * 16;
   const unsigned grid = (unsigned)((threads + block - 1) / block);
   const bool gc = a.gcontrols != nullptr;
-  const bool late = grid <= 1024u;       // at most one wave per SIMD (256 CUs x 4)
-#define MF_BCP(XS_, GC_, L_) hipLaunchKernelGGL((rollout_bwd_cp_kernel<INTEG, XS_, GC_, L_>), dim3(grid), dim3(block), 0, st, a)
-#define MF_BCP_L(XS_, GC_) do { if (late) MF_BCP(XS_, GC_, true); else MF_BCP(XS_, GC_, false); } while (0)
+  const int mode = grid <= 1024u ? kCpLate : kCpEarly;        // at most one wave per SIMD: late recompute
+#define MF_BCP(XS_, GC_, M_) hipLaunchKernelGGL((rollout_bwd_cp_kernel<INTEG, XS_, GC_, M_>), dim3(grid), dim3(block), 0, st, a)
+#define MF_BCP_L(XS_, GC_) do { if (mode == kCpLate) MF_BCP(XS_, GC_, kCpLate); else MF_BCP(XS_, GC_, kCpEarly); } while (0)
   if (xs_only) { if (gc) MF_BCP_L(true, true); else MF_BCP_L(true, false); }
   else         { if (gc) MF_BCP_L(false, true); else MF_BCP_L(false, false); }
 #undef MF_BCP_L

@@ -158,11 +158,13 @@ def test_full_horizon_f32_calm_floor():
         assert n_calm >= floor, (integ, n_calm)
 
 
-@pytest.mark.parametrize('B,ppl', [(1024, 1), (4096, 1), (1024, 0), (8192, 0)])
-def test_large_batch_shared_map_backward_vs_oracle(B, ppl):
+@pytest.mark.parametrize('B,ppl,integ', [(1024, 1, 1), (4096, 1, 1), (1024, 0, 1), (2048, 0, 1), (8192, 0, 1), (1024, 0, 0), (4096, 0, 0), (8192, 0, 0)])
+def test_large_batch_shared_map_backward_vs_oracle(B, ppl, integ):
     """The shared-map backward at BASELINE batch sizes -- private gradient copies (rollout b -> copy b % copies) and, from
     192 waves up, the accumulator carry-over kernels -- against the ORACLE: the loss touches 32 rollouts spread over the
-    batch (every 32nd or 128th; the others run with zero upstream gradients), so the oracle only has to differentiate those."""
+    batch (every 32nd or 128th; the others run with zero upstream gradients), so the oracle only has to differentiate those.
+    ppl = 0 is the library's own choice: the component-parallel kernels in their three forms (producer / consumer waves up
+    to B = 1024, late recompute up to 4096, early up to 8192), both integrators."""
     from monoforce_amd import synthetic as syn
     T, sub = 100, 32
     pts, masks = syn.robot_points_4()
@@ -171,20 +173,35 @@ def test_large_batch_shared_map_backward_vs_oracle(B, ppl):
     ctrl = syn.const_controls(B, T, seed=2)
     sel = torch.arange(0, B, B // sub)[:sub]
     wts = syn.probe_weights((sub, T, 3), phase=0.3)
-    dp = make_dphysics(pts, masks, 1, 0.05, 6.4, points_per_lane=ppl)
+    dp = make_dphysics(pts, masks, integ, 0.05, 6.4, points_per_lane=ppl)
     dp.dphys_cfg.traj_sim_time = 5.0
     zd, md = z.to(DEV).requires_grad_(True), mu.to(DEV).requires_grad_(True)
     cd = ctrl.to(DEV).requires_grad_(True)
     (Xs, Xds, Rs, Om), _ = dp(zd.unsqueeze(0), cd, friction=md.unsqueeze(0))
     ((Xs[sel.to(DEV)] * wts.to(DEV)).sum() + (Om[sel.to(DEV)] * wts.to(DEV)).sum() * 0.1).backward()
-    spec = hp.spec_from(pts, masks, 1, 0.05, 6.4)
-    zc, mc = z.clone().requires_grad_(True), mu.clone().requires_grad_(True)
-    cc = ctrl[sel].clone().requires_grad_(True)
-    (rX, _, _, rO), _ = orc.rollout(spec, zc.unsqueeze(0).expand(sub, -1, -1), cc, friction=mc.unsqueeze(0).expand(sub, -1, -1))
-    ((rX * wts).sum() + (rO * wts).sum() * 0.1).backward()
-    assert hp.rel_err(zd.grad, zc.grad) <= 2e-4, hp.rel_err(zd.grad, zc.grad)
-    assert hp.rel_err(md.grad, mc.grad) <= 2e-4, hp.rel_err(md.grad, mc.grad)
-    assert hp.rel_err(cd.grad[sel.to(DEV)], cc.grad) <= 2e-4
+    if integ == 1:
+        spec = hp.spec_from(pts, masks, integ, 0.05, 6.4)
+        zc, mc = z.clone().requires_grad_(True), mu.clone().requires_grad_(True)
+        cc = ctrl[sel].clone().requires_grad_(True)
+        (rX, _, _, rO), _ = orc.rollout(spec, zc.unsqueeze(0).expand(sub, -1, -1), cc, friction=mc.unsqueeze(0).expand(sub, -1, -1))
+        ((rX * wts).sum() + (rO * wts).sum() * 0.1).backward()
+        ref_z, ref_m, ref_c = zc.grad, mc.grad, cc.grad
+    else:
+        # float32 `dynamics()` on this terrain and horizon is not a 1e-4 path (some of the 32 rollouts sit on a contact switch:
+        # dL/dz of every lane mapping differs from the float32 oracle's by the same 9.4 %, while the mappings agree with each
+        # other to 1e-6): the component-parallel forms are held to the one-point-per-lane kernel, which
+        # test_rollout_bwd_gpu.py holds to the reference's autograd on the golden cases
+        d1 = make_dphysics(pts, masks, integ, 0.05, 6.4, points_per_lane=1)
+        d1.dphys_cfg.traj_sim_time = 5.0
+        z1, m1 = z.to(DEV).requires_grad_(True), mu.to(DEV).requires_grad_(True)
+        c1 = ctrl.to(DEV).requires_grad_(True)
+        (X1, _, _, O1), _ = d1(z1.unsqueeze(0), c1, friction=m1.unsqueeze(0))
+        ((X1[sel.to(DEV)] * wts.to(DEV)).sum() + (O1[sel.to(DEV)] * wts.to(DEV)).sum() * 0.1).backward()
+        assert hp.rel_err(Xs, X1) <= 1e-4
+        ref_z, ref_m, ref_c = z1.grad, m1.grad, c1.grad[sel.to(DEV)]
+    assert hp.rel_err(zd.grad, ref_z) <= 2e-4, hp.rel_err(zd.grad, ref_z)
+    assert hp.rel_err(md.grad, ref_m) <= 2e-4, hp.rel_err(md.grad, ref_m)
+    assert hp.rel_err(cd.grad[sel.to(DEV)], ref_c) <= 2e-4
     rest = torch.ones(B, dtype=torch.bool); rest[sel] = False
     assert float(cd.grad[rest.to(DEV)].abs().max()) == 0.0          # rollouts the loss does not touch get exactly nothing
 
