@@ -274,6 +274,16 @@ int mf_physics_loss_fwd_f32(const MfLossDesc* desc, const float* Xs, const float
 int mf_physics_loss_fwd_f64(const MfLossDesc* desc, const double* Xs, const double* Xgt, const double* gt_ts, const int32_t* nearest, double* partial, void* hip_stream);
 int mf_physics_loss_bwd_f32(const MfLossDesc* desc, const float* Xs, const float* Xgt, const float* gt_ts, const int32_t* nearest, const float* gloss, float* gXs, void* hip_stream);
 int mf_physics_loss_bwd_f64(const MfLossDesc* desc, const double* Xs, const double* Xgt, const double* gt_ts, const int32_t* nearest, const double* gloss, double* gXs, void* hip_stream);
+/* The same loss, finished inside the launch: `loss[0]` receives the mean (what `partial.sum() / (3 B T2)` gives, summed in block
+ * order).  `partial` holds ceil(B*T2/256) scalars of scratch; `ticket` is ONE zero-initialised uint32 the library resets itself --
+ * reusable launch after launch by calls ordered on one stream (two streams need two tickets). */
+int mf_physics_loss_value_f32(const MfLossDesc* desc, const float* Xs, const float* Xgt, const float* gt_ts, const int32_t* nearest, float* partial, uint32_t* ticket, float* loss, void* hip_stream);
+int mf_physics_loss_value_f64(const MfLossDesc* desc, const double* Xs, const double* Xgt, const double* gt_ts, const int32_t* nearest, double* partial, uint32_t* ticket, double* loss, void* hip_stream);
+/* The reduction that follows a shared-map mf_rollout_bwd_* (MfRolloutDesc.grad_copies private copies of each map gradient,
+ * pool = [n_maps][copies][n]):  out[m][i] = sum_c pool[m][c][i], and pool is left ZEROED -- a caller that keeps the pool across
+ * steps never fills it again (replaces a zero fill + `maps.sum(1)`, scripts/train.py's optimizer step reads `out`). */
+int mf_reduce_grad_copies_f32(float* pool, int n_maps, int copies, long long n, float* out, void* hip_stream);
+int mf_reduce_grad_copies_f64(double* pool, int n_maps, int copies, long long n, double* out, void* hip_stream);
 
 /* ---- terrain staging between the BEV heads and the rollout (scripts/train.py:93-99, 233-235; lss.py:158) ------------------
  * One pass over the head outputs geom, diff, friction (each float32 [B][H][W]):

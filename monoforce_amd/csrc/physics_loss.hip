@@ -3,6 +3,10 @@
 // ~25 small ATen kernels (gather, broadcasts, pow, mean, and an index_put backward that sorts).  The backward writes
 // d loss / d Xs directly in the rollout's own (time-major) layout, so the rollout backward consumes it without a copy.
 //   loss = mean_{b,j,c} ( (Xs[b, nearest[b,j], c] - Xgt[b,j,c]) * w[b,j] )^2,   w = 1 / (1 + gamma * gt_ts[b,j])
+// mf_physics_loss_value_* finishes the mean inside the same launch (the block that takes the last ticket adds the per-block
+// partial sums in index order), and mf_reduce_grad_copies_* sums the rollout backward's private gradient copies and clears them
+// for the next step: a train step at the BASELINE shape is two ~0.2-0.4 ms kernels, and every ~4 us ATen launch between them
+// costs ~10 us of dependent-launch latency (four of them went here, one more in train.py: 0.62 -> 0.59 ms per step).
 #include "mf_common.h"
 
 namespace mf {
@@ -34,6 +38,62 @@ __global__ void __launch_bounds__(256) physics_loss_fwd_kernel(const S* __restri
   if (threadIdx.x == 0) partial[blockIdx.x] = (wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3]);
 }
 
+// the same, and the block that finishes last turns the partial sums into the mean (fixed order: deterministic); `ticket` is a
+// zero-initialised counter the last block resets, so the buffer is reusable launch after launch on one stream
+template <typename S>
+__global__ void __launch_bounds__(256) physics_loss_value_kernel(const S* __restrict__ Xs, long long sb, long long st,
+                                                                const S* __restrict__ Xgt, const S* __restrict__ gt_ts,
+                                                                const int* __restrict__ nearest, int B, int T2, S gamma,
+                                                                S* __restrict__ partial, unsigned* __restrict__ ticket, S inv_count,
+                                                                S* __restrict__ loss) {
+  __shared__ S wave_sum[4];
+  __shared__ bool last;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;        // = b * T2 + j
+  S acc = (S)0;
+  if (i < B * T2) {
+    const int b = i / T2;
+    const S w = (S)1 / ((S)1 + gamma * gt_ts[i]);
+    const S* x = Xs + b * sb + (long long)nearest[i] * st;
+    const S* g = Xgt + (size_t)i * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { const S d = x[c] * w - g[c] * w; acc += d * d; }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = (wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3]);
+    __threadfence();
+    last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  // 256 threads stride over the partial sums in index order, then the same butterfly
+  S tot = (S)0;
+  for (unsigned k = threadIdx.x; k < gridDim.x; k += 256) tot += __builtin_nontemporal_load(partial + k);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d, 64);
+  if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    loss[0] = ((wave_sum[0] + wave_sum[1]) + (wave_sum[2] + wave_sum[3])) * inv_count;
+    *ticket = 0u;
+  }
+}
+
+// out[m][i] = sum_c pool[m][c][i];  pool <- 0   (the rollout backward scatters into `copies` private copies of each map)
+template <typename S>
+__global__ void __launch_bounds__(256) reduce_grad_copies_kernel(S* __restrict__ pool, int copies, long long n, S* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  S* p = pool + (long long)blockIdx.y * copies * n + i;
+  S acc = (S)0;
+  for (int c = 0; c < copies; ++c) { acc += p[(long long)c * n]; p[(long long)c * n] = (S)0; }
+  out[(long long)blockIdx.y * n + i] = acc;
+}
+
 template <typename S>
 __global__ void __launch_bounds__(256) physics_loss_bwd_kernel(const S* __restrict__ Xs, long long sb, long long st,
                                                               const S* __restrict__ Xgt, const S* __restrict__ gt_ts,
@@ -62,6 +122,29 @@ static int loss_fwd(const MfLossDesc* d, const S* Xs, const S* Xgt, const S* gt_
 }
 
 template <typename S>
+static int loss_value(const MfLossDesc* d, const S* Xs, const S* Xgt, const S* gt_ts, const int* nearest, S* partial, unsigned* ticket,
+                      S* loss, hipStream_t st) {
+  MF_REQUIRE(d && Xs && Xgt && gt_ts && nearest && partial && ticket && loss, MF_ERR_INVALID, "physics_loss_value: null argument");
+  MF_REQUIRE(d->B > 0 && d->T1 > 0 && d->T2 > 0, MF_ERR_INVALID, "physics_loss_value: B, T1, T2 must be positive");
+  const double count = (double)d->B * d->T2 * 3;
+  hipLaunchKernelGGL((physics_loss_value_kernel<S>), dim3((d->B * d->T2 + 255) / 256), dim3(256), 0, st, Xs, (long long)d->x_stride_b,
+                     (long long)d->x_stride_t, Xgt, gt_ts, nearest, d->B, d->T2, (S)d->gamma, partial, ticket, (S)(1.0 / count), loss);
+  hipError_t e = hipGetLastError();
+  MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("physics_loss_value launch: ") + hipGetErrorString(e));
+  return MF_OK;
+}
+
+template <typename S>
+static int reduce_copies(S* pool, int n_maps, int copies, long long n, S* out, hipStream_t st) {
+  MF_REQUIRE(pool && out, MF_ERR_INVALID, "reduce_grad_copies: null argument");
+  MF_REQUIRE(n_maps > 0 && n_maps < 65536 && copies > 0 && n > 0, MF_ERR_INVALID, "reduce_grad_copies: n_maps, copies, n must be positive");
+  hipLaunchKernelGGL((reduce_grad_copies_kernel<S>), dim3((unsigned)((n + 255) / 256), (unsigned)n_maps), dim3(256), 0, st, pool, copies, n, out);
+  hipError_t e = hipGetLastError();
+  MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("reduce_grad_copies launch: ") + hipGetErrorString(e));
+  return MF_OK;
+}
+
+template <typename S>
 static int loss_bwd(const MfLossDesc* d, const S* Xs, const S* Xgt, const S* gt_ts, const int* nearest, const S* gloss, S* gXs,
                     hipStream_t st) {
   MF_REQUIRE(d && Xs && Xgt && gt_ts && nearest && gloss && gXs, MF_ERR_INVALID, "physics_loss_bwd: null argument");
@@ -84,3 +167,9 @@ extern "C" int mf_physics_loss_bwd_f32(const MfLossDesc* d, const float* Xs, con
                                        const float* gloss, float* gXs, void* s) { return mf::loss_bwd<float>(d, Xs, Xgt, gt_ts, nearest, gloss, gXs, (hipStream_t)s); }
 extern "C" int mf_physics_loss_bwd_f64(const MfLossDesc* d, const double* Xs, const double* Xgt, const double* gt_ts, const int32_t* nearest,
                                        const double* gloss, double* gXs, void* s) { return mf::loss_bwd<double>(d, Xs, Xgt, gt_ts, nearest, gloss, gXs, (hipStream_t)s); }
+extern "C" int mf_physics_loss_value_f32(const MfLossDesc* d, const float* Xs, const float* Xgt, const float* gt_ts, const int32_t* nearest,
+                                         float* partial, uint32_t* ticket, float* loss, void* s) { return mf::loss_value<float>(d, Xs, Xgt, gt_ts, nearest, partial, ticket, loss, (hipStream_t)s); }
+extern "C" int mf_physics_loss_value_f64(const MfLossDesc* d, const double* Xs, const double* Xgt, const double* gt_ts, const int32_t* nearest,
+                                         double* partial, uint32_t* ticket, double* loss, void* s) { return mf::loss_value<double>(d, Xs, Xgt, gt_ts, nearest, partial, ticket, loss, (hipStream_t)s); }
+extern "C" int mf_reduce_grad_copies_f32(float* pool, int n_maps, int copies, long long n, float* out, void* s) { return mf::reduce_copies<float>(pool, n_maps, copies, n, out, (hipStream_t)s); }
+extern "C" int mf_reduce_grad_copies_f64(double* pool, int n_maps, int copies, long long n, double* out, void* s) { return mf::reduce_copies<double>(pool, n_maps, copies, n, out, (hipStream_t)s); }

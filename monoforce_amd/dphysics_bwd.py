@@ -15,6 +15,48 @@ import os
 GRAD_COPIES = int(os.environ.get('MF_GRAD_COPIES', '16'))     # 16 and 64 measure the same kernel time; 16 zero-fills 4x less
 
 
+class GradPool:
+    """The private gradient copies of a shared-map backward, [n_maps][copies][H*W] + 16 zeros (the row absent upstream
+    gradients point at), kept ZEROED between steps: `mf_reduce_grad_copies_*` sums the copies and clears them in one launch, so a
+    step pays neither the zero fill nor a separate reduction (~10 us of dependent-launch latency each at the BASELINE shape).
+    `busy` is set while a backward is between its kernel launch and the reduction; a pool found busy (an exception in between,
+    or two streams at once) is not trusted and gets refilled."""
+
+    def __init__(self, n_maps, copies, n, dt, dev):
+        self.n_maps, self.copies, self.n = n_maps, copies, n
+        self.buf = torch.zeros(n_maps * copies * n + 16, dtype=dt, device=dev)
+        self.busy = False
+        self.stream = None
+
+    def acquire(self):
+        cur = torch.cuda.current_stream(self.buf.device).cuda_stream
+        if self.busy or (self.stream is not None and self.stream != cur):
+            self.buf.zero_()
+        self.busy, self.stream = True, cur
+
+    def reduce(self, map_shape):
+        from .dphysics import _scalar_suffix
+        out = torch.empty((self.n_maps,) + tuple(map_shape), dtype=self.buf.dtype, device=self.buf.device)
+        fn = getattr(_lib.lib(), 'mf_reduce_grad_copies_' + _scalar_suffix(self.buf.dtype))
+        with torch.cuda.device(self.buf.device):
+            _lib.check(fn(_lib.ptr(self.buf), self.n_maps, self.copies, C.c_longlong(self.n), _lib.ptr(out),
+                          C.c_void_p(self.stream)), 'mf_reduce_grad_copies')
+        self.busy = False
+        return out
+
+
+def grad_pool(owner, n_maps, copies, n, dt, dev):
+    """The owner's (a DPhysics module's) pool for this shape, acquired for one backward."""
+    pools = owner.__dict__.setdefault('_grad_pools', {})
+    key = (n_maps, copies, n, dt, dev)
+    p = pools.get(key)
+    if p is None:
+        if len(pools) >= 4:                    # shapes come and go (tests, sweeps): keep the memory bounded
+            pools.clear()
+        p = pools[key] = GradPool(n_maps, copies, n, dt, dev)
+    p.acquire()
+    return p
+
 def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf):
     from .dphysics import _scalar_suffix, _stream_ptr
     controls, x_init, xd0, R0, w0, ts, Xraw, Xds, Rs, Om = ctx.saved_tensors
@@ -39,9 +81,9 @@ def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf):
         desc.grad_copies = copies
         # one zero fill for [gz copies | gmu copies | the zero row absent upstream gradients point at]
         n_maps = 2 if want_gmu else 1
-        pool = torch.zeros(n_maps * copies * z.numel() + 16, dtype=dt, device=dev)
-        maps = pool[:n_maps * copies * z.numel()].view((n_maps, copies) + tuple(z.shape))
-        gz, gmu, zero_row = maps[0], (maps[1] if want_gmu else None), pool[-16:]
+        pool = grad_pool(mod, n_maps, copies, z.numel(), dt, dev)
+        maps = pool.buf[:n_maps * copies * z.numel()].view((n_maps, copies) + tuple(z.shape))
+        gz, gmu, zero_row = maps[0], (maps[1] if want_gmu else None), pool.buf[-16:]
     else:
         maps = None
         gz = torch.zeros_like(z)
@@ -65,7 +107,7 @@ def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf):
         _lib.check(fn(C.byref(desc), C.byref(bufs), _stream_ptr(dev)), 'mf_rollout_bwd')
 
     if desc.map_shared:
-        summed = maps.sum(1)                   # one reduction for both maps
+        summed = pool.reduce(z.shape)          # one launch: both maps summed over their copies, the pool left zeroed
         gz, gmu = summed[0], (summed[1] if want_gmu else None)
 
     def to_input_shape(g, shape, expanded):

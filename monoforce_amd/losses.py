@@ -65,6 +65,19 @@ def rotation_difference(R1, R2, reduction='mean'):
     return theta2
 
 
+_TICKETS = {}
+
+
+def _ticket(device, stream):
+    """The zero-initialised counter `mf_physics_loss_value_*` needs, one per (device, stream): launches ordered on one stream
+    share it (the kernel resets it)."""
+    key = (device.index, stream.cuda_stream)
+    t = _TICKETS.get(key)
+    if t is None:
+        t = _TICKETS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return t
+
+
 class _FusedPhysicsLoss(torch.autograd.Function):
     """`mf_physics_loss_fwd/bwd_*`: one gather-reduce kernel forward, one scatter kernel backward; the gradient comes back
     with the SAME strides as `X_pred` (for the rollout's time-major outputs: ready for `mf_rollout_bwd_*` without a copy)."""
@@ -84,14 +97,18 @@ class _FusedPhysicsLoss(torch.autograd.Function):
         near = near.contiguous()
         desc = _lib.MfLossDesc(B=B, T1=T1, T2=T2, x_stride_b=X_pred.stride(0), x_stride_t=X_pred.stride(1), gamma=float(gamma))
         partial = torch.empty((B * T2 + 255) // 256, dtype=X_pred.dtype, device=X_pred.device)
-        stream = C.c_void_p(torch.cuda.current_stream(X_pred.device).cuda_stream)
+        loss = torch.empty((), dtype=X_pred.dtype, device=X_pred.device)
+        cur = torch.cuda.current_stream(X_pred.device)
+        stream = C.c_void_p(cur.cuda_stream)
+        # the mean is finished inside the launch (no `partial.sum() * c`: two launches fewer forward, two fewer backward)
         with torch.cuda.device(X_pred.device), _timing.timed('physics_loss_fwd', X_pred.device):
-            _lib.check(getattr(_lib.lib(), 'mf_physics_loss_fwd_' + sfx)(C.byref(desc), _lib.ptr(X_pred), _lib.ptr(Xg), _lib.ptr(ts),
-                                                                         _lib.ptr(near), _lib.ptr(partial), stream), 'mf_physics_loss_fwd')
+            _lib.check(getattr(_lib.lib(), 'mf_physics_loss_value_' + sfx)(C.byref(desc), _lib.ptr(X_pred), _lib.ptr(Xg), _lib.ptr(ts),
+                                                                           _lib.ptr(near), _lib.ptr(partial), _lib.ptr(_ticket(X_pred.device, cur)),
+                                                                           _lib.ptr(loss), stream), 'mf_physics_loss_value')
         ctx.save_for_backward(X_pred, Xg, ts, near)
         ctx.set_materialize_grads(False)
         ctx.desc, ctx.sfx = desc, sfx
-        return partial.sum() * (1.0 / (B * T2 * 3))
+        return loss
 
     @staticmethod
     def backward(ctx, gloss):

@@ -31,6 +31,14 @@ import ctypes as C
 import torch
 
 from . import _lib, _timing
+from .dphysics_bwd import grad_pool
+
+
+class _PoolOwner:       # the registered ops have no module to hang the persistent gradient-copy pools on
+    pass
+
+
+_POOL_OWNER = _PoolOwner()
 
 __all__ = ['rollout', 'splat', 'CONST_NAMES']
 
@@ -132,9 +140,9 @@ def _rollout_bwd(z, mu, controls, x_init, xd0, R0, w0, pts, part_id, Iinv, const
         copies = max(1, min(max(16, B // 64), 256, B))
         d.grad_copies = copies
         n_maps = 2 if muc is not None else 1
-        pool = torch.zeros(n_maps * copies * zc[0].numel() + 16, dtype=dt, device=dev)
-        maps = pool[:n_maps * copies * zc[0].numel()].view((n_maps, copies) + tuple(zc.shape[1:]))
-        gz, gmu, zero_row = maps[0], (maps[1] if muc is not None else None), pool[-16:]
+        pool = grad_pool(_POOL_OWNER, n_maps, copies, zc[0].numel(), dt, dev)
+        maps = pool.buf[:n_maps * copies * zc[0].numel()].view((n_maps, copies) + tuple(zc.shape[1:]))
+        gz, gmu, zero_row = maps[0], (maps[1] if muc is not None else None), pool.buf[-16:]
     else:
         gz, gmu = torch.zeros_like(zc), (torch.zeros_like(muc) if muc is not None else None)
         zero_row = torch.zeros(16, dtype=dt, device=dev)
@@ -152,7 +160,7 @@ def _rollout_bwd(z, mu, controls, x_init, xd0, R0, w0, pts, part_id, Iinv, const
     with torch.cuda.device(dev), _timing.timed('rollout_bwd_kernel', dev):
         _lib.check(getattr(_lib.lib(), 'mf_rollout_bwd_' + _sfx(dt))(C.byref(d), C.byref(bufs), _stream(dev)), 'mf_rollout_bwd')
     if d.map_shared:
-        summed = maps.sum(1)
+        summed = pool.reduce(zc.shape[1:])
         gz = summed[0].unsqueeze(0)
         gmu = summed[1].unsqueeze(0) if muc is not None else None
     if gmu is None:

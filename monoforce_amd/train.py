@@ -29,6 +29,7 @@ class TerrainFitProblem:
         self.states_gt = [Xs[:, sel].contiguous(), Xds[:, sel].contiguous(), Rs[:, sel].contiguous(), Om[:, sel].contiguous()]
         self.nearest = nearest_steps(self.pred_ts, self.gt_ts).to(torch.int32)      # time stamps are fixed: computed once
         self.bucket = None
+        self._one = None
 
     def step(self, z, mu):
         """One forward + backward: returns the loss averaged over ALL ranks' rollouts; leaves its gradient w.r.t. z, mu in .grad."""
@@ -38,7 +39,11 @@ class TerrainFitProblem:
         loss_fn = physics_loss_fused if self.fused_loss else physics_loss
         loss = loss_fn(states, self.states_gt, self.pred_ts, self.gt_ts,
                        nearest=self.nearest if self.fused_loss else self.nearest.long())
-        loss.backward()
+        if self._one is None or self._one.dtype != loss.dtype or self._one.device != loss.device:
+            self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
+        loss.backward(self._one)          # (the default seed is a fresh ones_like: one more launch in front of the backward)
+        if mfdist.world() == 1:
+            return loss.detach()
         # the one exchange step of the backward: 2 x H x W floats (+ the loss scalar) over RCCL.  Every rank's loss is the MEAN
         # over its own rollouts (equal shares), so the mean over ranks is the gradient of the global-mean loss: the step does
         # not depend on the number of GPUs.

@@ -59,3 +59,45 @@ def test_terrain_fit_step_same_gradients_with_fused_loss():
         out.append((float(loss), z.grad.clone(), m.grad.clone()))
     assert abs(out[0][0] - out[1][0]) <= 1e-5 * abs(out[0][0])
     assert hp.rel_err(out[1][1].cpu(), out[0][1].cpu()) <= 1e-4 and hp.rel_err(out[1][2].cpu(), out[0][2].cpu()) <= 1e-4
+
+
+@pytest.mark.parametrize('B,T2', [(1, 1), (5, 50), (1024, 50), (3000, 7)])
+def test_loss_value_is_finished_inside_the_launch_and_reusable(B, T2):
+    """`mf_physics_loss_value_*`: the block taking the last ticket turns the per-block partial sums into the mean and resets the
+    ticket -- the same value launch after launch (1 .. 587 blocks), equal to the plain-torch restatement of losses.py:102-127."""
+    from monoforce_amd.losses import physics_loss, physics_loss_fused
+    T1 = 10 * T2
+    gen = torch.Generator().manual_seed(B)
+    X = torch.randn(B, T1, 3, generator=gen).to(DEV)
+    Xgt = torch.randn(B, T2, 3, generator=gen).to(DEV)
+    pred_ts = (torch.arange(T1, dtype=torch.float32) * 0.01).unsqueeze(0).expand(B, -1).to(DEV)
+    gt_ts = pred_ts[:, 9::10].contiguous()
+    ref = physics_loss([X], [Xgt], pred_ts, gt_ts)
+    vals = [float(physics_loss_fused([X], [Xgt], pred_ts, gt_ts)) for _ in range(4)]
+    assert len(set(vals)) == 1, vals                      # deterministic, and the ticket came back to zero every time
+    assert abs(vals[0] - float(ref)) <= 2e-6 * abs(float(ref))
+
+
+def test_gradient_copy_pool_is_reused_clean():
+    """The shared-map backward keeps its private gradient copies zeroed across steps (`mf_reduce_grad_copies_*` sums and clears in
+    one launch): backward passes in a row through one module give the same gradients (to the rounding of the atomics' arrival
+    order) -- also after a pass whose reduction never ran (the pool is found busy and refilled)."""
+    from bench import build_problem
+    from monoforce_amd import dphysics_bwd
+    cfg, dp, pts, masks, z, mu, ctrl = build_problem(256, 120, 4, torch.device(DEV), 1, seed=0)
+    zl, ml = z.to(DEV).clone().requires_grad_(True), mu.to(DEV).clone().requires_grad_(True)
+    cd = ctrl.to(DEV)
+    grads = []
+    for it in range(4):
+        zl.grad = None; ml.grad = None
+        (Xs, _, _, _), _ = dp(zl.unsqueeze(0), cd, friction=ml.unsqueeze(0))
+        Xs[:, 9::10].square().mean().backward()
+        grads.append((zl.grad.clone(), ml.grad.clone()))
+        if it == 1:                                        # leave dirt behind, as an exception between kernel and reduction would
+            for p in dp._grad_pools.values():
+                p.buf[:-16].fill_(7.0); p.busy = True
+    assert float(grads[0][0].abs().max()) > 0
+    for gz, gm in grads[1:]:
+        assert hp.rel_err(gz, grads[0][0]) <= 1e-5 and hp.rel_err(gm, grads[0][1]) <= 1e-5
+    pool = next(iter(dp._grad_pools.values()))
+    assert float(pool.buf.abs().max()) == 0.0 and not pool.busy
