@@ -276,9 +276,10 @@ int mf_physics_loss_bwd_f32(const MfLossDesc* desc, const float* Xs, const float
 int mf_physics_loss_bwd_f64(const MfLossDesc* desc, const double* Xs, const double* Xgt, const double* gt_ts, const int32_t* nearest, const double* gloss, double* gXs, void* hip_stream);
 /* The same loss, finished inside the launch: `loss[0]` receives the mean (what `partial.sum() / (3 B T2)` gives, summed in block
  * order).  `partial` holds ceil(B*T2/256) scalars of scratch; `ticket` is ONE zero-initialised uint32 the library resets itself --
- * reusable launch after launch by calls ordered on one stream (two streams need two tickets). */
-int mf_physics_loss_value_f32(const MfLossDesc* desc, const float* Xs, const float* Xgt, const float* gt_ts, const int32_t* nearest, float* partial, uint32_t* ticket, float* loss, void* hip_stream);
-int mf_physics_loss_value_f64(const MfLossDesc* desc, const double* Xs, const double* Xgt, const double* gt_ts, const int32_t* nearest, double* partial, uint32_t* ticket, double* loss, void* hip_stream);
+ * reusable launch after launch by calls ordered on one stream (two streams need two tickets).  `zero_fill` (may be NULL): a buffer
+ * of `zero_count` scalars cleared by the same launch -- the gXs a later mf_physics_loss_bwd_* scatters into. */
+int mf_physics_loss_value_f32(const MfLossDesc* desc, const float* Xs, const float* Xgt, const float* gt_ts, const int32_t* nearest, float* partial, uint32_t* ticket, float* loss, float* zero_fill, long long zero_count, void* hip_stream);
+int mf_physics_loss_value_f64(const MfLossDesc* desc, const double* Xs, const double* Xgt, const double* gt_ts, const int32_t* nearest, double* partial, uint32_t* ticket, double* loss, double* zero_fill, long long zero_count, void* hip_stream);
 /* The reduction that follows a shared-map mf_rollout_bwd_* (MfRolloutDesc.grad_copies private copies of each map gradient,
  * pool = [n_maps][copies][n]):  out[m][i] = sum_c pool[m][c][i], and pool is left ZEROED -- a caller that keeps the pool across
  * steps never fills it again (replaces a zero fill + `maps.sum(1)`, scripts/train.py's optimizer step reads `out`). */

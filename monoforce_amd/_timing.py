@@ -5,13 +5,23 @@ import torch
 
 _records = None     # None = off; else list of (name, start_event, end_event)
 _pool = []          # pre-created events (creating them inside a timed region costs host time)
+_every, _step = 1, 0
 
 
-def start(capacity=4096):
-    global _records
+def start(capacity=4096, every=1):
+    """Record HIP events around the C-ABI launches from now on.  `every` > 1 samples: only the launches of every `every`-th
+    step (the caller marks steps with `next_step()`) are bracketed -- an event record is a packet of its own on the stream, and
+    eight of them around the four kernels of a 0.55 ms train step cost 33 us (6 %) of it."""
+    global _records, _every, _step
     while len(_pool) < 2 * capacity:
         _pool.append(torch.cuda.Event(enable_timing=True))
     _records = []
+    _every, _step = max(int(every), 1), -1
+
+
+def next_step():
+    global _step
+    _step += 1
 
 
 def stop():
@@ -27,7 +37,7 @@ def stop():
 
 @contextlib.contextmanager
 def timed(name, device):
-    if _records is None:
+    if _records is None or (_every > 1 and _step % _every != 0):
         yield
         return
     i = 2 * len(_records)

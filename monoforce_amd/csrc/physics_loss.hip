@@ -45,10 +45,12 @@ __global__ void __launch_bounds__(256) physics_loss_value_kernel(const S* __rest
                                                                 const S* __restrict__ Xgt, const S* __restrict__ gt_ts,
                                                                 const int* __restrict__ nearest, int B, int T2, S gamma,
                                                                 S* __restrict__ partial, unsigned* __restrict__ ticket, S inv_count,
-                                                                S* __restrict__ loss) {
+                                                                S* __restrict__ loss, S* __restrict__ zero_fill, long long zero_count) {
   __shared__ S wave_sum[4];
   __shared__ bool last;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;        // = b * T2 + j
+  // the buffer the backward will scatter d loss / d Xs into is cleared here (one launch fewer in front of the rollout backward)
+  for (long long k = i; k < zero_count; k += (long long)gridDim.x * blockDim.x) zero_fill[k] = (S)0;
   S acc = (S)0;
   if (i < B * T2) {
     const int b = i / T2;
@@ -123,12 +125,13 @@ static int loss_fwd(const MfLossDesc* d, const S* Xs, const S* Xgt, const S* gt_
 
 template <typename S>
 static int loss_value(const MfLossDesc* d, const S* Xs, const S* Xgt, const S* gt_ts, const int* nearest, S* partial, unsigned* ticket,
-                      S* loss, hipStream_t st) {
+                      S* loss, S* zero_fill, long long zero_count, hipStream_t st) {
   MF_REQUIRE(d && Xs && Xgt && gt_ts && nearest && partial && ticket && loss, MF_ERR_INVALID, "physics_loss_value: null argument");
   MF_REQUIRE(d->B > 0 && d->T1 > 0 && d->T2 > 0, MF_ERR_INVALID, "physics_loss_value: B, T1, T2 must be positive");
+  MF_REQUIRE(zero_count >= 0 && (zero_fill || zero_count == 0), MF_ERR_INVALID, "physics_loss_value: zero_count without zero_fill");
   const double count = (double)d->B * d->T2 * 3;
   hipLaunchKernelGGL((physics_loss_value_kernel<S>), dim3((d->B * d->T2 + 255) / 256), dim3(256), 0, st, Xs, (long long)d->x_stride_b,
-                     (long long)d->x_stride_t, Xgt, gt_ts, nearest, d->B, d->T2, (S)d->gamma, partial, ticket, (S)(1.0 / count), loss);
+                     (long long)d->x_stride_t, Xgt, gt_ts, nearest, d->B, d->T2, (S)d->gamma, partial, ticket, (S)(1.0 / count), loss, zero_fill, zero_count);
   hipError_t e = hipGetLastError();
   MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("physics_loss_value launch: ") + hipGetErrorString(e));
   return MF_OK;
@@ -168,8 +171,8 @@ extern "C" int mf_physics_loss_bwd_f32(const MfLossDesc* d, const float* Xs, con
 extern "C" int mf_physics_loss_bwd_f64(const MfLossDesc* d, const double* Xs, const double* Xgt, const double* gt_ts, const int32_t* nearest,
                                        const double* gloss, double* gXs, void* s) { return mf::loss_bwd<double>(d, Xs, Xgt, gt_ts, nearest, gloss, gXs, (hipStream_t)s); }
 extern "C" int mf_physics_loss_value_f32(const MfLossDesc* d, const float* Xs, const float* Xgt, const float* gt_ts, const int32_t* nearest,
-                                         float* partial, uint32_t* ticket, float* loss, void* s) { return mf::loss_value<float>(d, Xs, Xgt, gt_ts, nearest, partial, ticket, loss, (hipStream_t)s); }
+                                         float* partial, uint32_t* ticket, float* loss, float* zero_fill, long long zero_count, void* s) { return mf::loss_value<float>(d, Xs, Xgt, gt_ts, nearest, partial, ticket, loss, zero_fill, zero_count, (hipStream_t)s); }
 extern "C" int mf_physics_loss_value_f64(const MfLossDesc* d, const double* Xs, const double* Xgt, const double* gt_ts, const int32_t* nearest,
-                                         double* partial, uint32_t* ticket, double* loss, void* s) { return mf::loss_value<double>(d, Xs, Xgt, gt_ts, nearest, partial, ticket, loss, (hipStream_t)s); }
+                                         double* partial, uint32_t* ticket, double* loss, double* zero_fill, long long zero_count, void* s) { return mf::loss_value<double>(d, Xs, Xgt, gt_ts, nearest, partial, ticket, loss, zero_fill, zero_count, (hipStream_t)s); }
 extern "C" int mf_reduce_grad_copies_f32(float* pool, int n_maps, int copies, long long n, float* out, void* s) { return mf::reduce_copies<float>(pool, n_maps, copies, n, out, (hipStream_t)s); }
 extern "C" int mf_reduce_grad_copies_f64(double* pool, int n_maps, int copies, long long n, double* out, void* s) { return mf::reduce_copies<double>(pool, n_maps, copies, n, out, (hipStream_t)s); }

@@ -101,11 +101,20 @@ class _FusedPhysicsLoss(torch.autograd.Function):
         cur = torch.cuda.current_stream(X_pred.device)
         stream = C.c_void_p(cur.cuda_stream)
         # the mean is finished inside the launch (no `partial.sum() * c`: two launches fewer forward, two fewer backward)
+        # when a backward will follow and X_pred is a dense view (the rollout's outputs are), its gradient buffer is allocated now
+        # and cleared by the same launch
+        gX = None
+        if ctx.needs_input_grad[0] and X_pred.numel() > 0:
+            gX = torch.empty_like(X_pred)                  # preserve_format: the strides of X_pred
+            if gX.stride() != X_pred.stride():
+                gX = None
         with torch.cuda.device(X_pred.device), _timing.timed('physics_loss_fwd', X_pred.device):
             _lib.check(getattr(_lib.lib(), 'mf_physics_loss_value_' + sfx)(C.byref(desc), _lib.ptr(X_pred), _lib.ptr(Xg), _lib.ptr(ts),
                                                                            _lib.ptr(near), _lib.ptr(partial), _lib.ptr(_ticket(X_pred.device, cur)),
-                                                                           _lib.ptr(loss), stream), 'mf_physics_loss_value')
+                                                                           _lib.ptr(loss), _lib.ptr(gX), C.c_longlong(0 if gX is None else gX.numel()),
+                                                                           stream), 'mf_physics_loss_value')
         ctx.save_for_backward(X_pred, Xg, ts, near)
+        ctx.gX = gX
         ctx.set_materialize_grads(False)
         ctx.desc, ctx.sfx = desc, sfx
         return loss
@@ -117,9 +126,11 @@ class _FusedPhysicsLoss(torch.autograd.Function):
         if gloss is None:
             return None, None, None, None, None
         X_pred, Xg, ts, near = ctx.saved_tensors
-        gX = torch.zeros_like(X_pred)                     # preserve_format: same (dense) strides as X_pred
-        if gX.stride() != X_pred.stride():
-            gX = torch.empty_strided(X_pred.shape, X_pred.stride(), dtype=X_pred.dtype, device=X_pred.device).zero_()
+        gX, ctx.gX = ctx.gX, None                         # cleared by the forward launch; a second backward (retain_graph) refills
+        if gX is None:
+            gX = torch.zeros_like(X_pred)                 # preserve_format: same (dense) strides as X_pred
+            if gX.stride() != X_pred.stride():
+                gX = torch.empty_strided(X_pred.shape, X_pred.stride(), dtype=X_pred.dtype, device=X_pred.device).zero_()
         gl = gloss.to(X_pred.dtype).reshape(1).contiguous()
         stream = C.c_void_p(torch.cuda.current_stream(X_pred.device).cuda_stream)
         with torch.cuda.device(X_pred.device), _timing.timed('physics_loss_bwd', X_pred.device):
