@@ -47,6 +47,7 @@ print(json.dumps(res))
 PY
 timeout 600 python tools/bench_kernels.py > $OUT/${TAG}_bench_kernels.jsonl 2> $OUT/bench_kernels.err
 AB_BWD=1 AB_B=256,1024,2048,4096,8192 timeout 300 python tools/ab_cp.py 2> /dev/null | grep "^B " > $OUT/${TAG}_ab_lane_mappings.txt
+AB_INTEG=0 AB_BWD=1 AB_B=1024,4096,8192 timeout 300 python tools/ab_cp.py 2> /dev/null | grep "^B " | sed 's/^B /dynamics() B /' >> $OUT/${TAG}_ab_lane_mappings.txt
 AB_B=1024,16384,65536 timeout 300 python tools/bench_planner.py > $OUT/${TAG}_bench_planner.jsonl 2> $OUT/bench_planner.err
 timeout 300 python tools/bench_lift_splat.py 2> $OUT/bench_lift_splat.err | grep '^B=' > $OUT/${TAG}_bench_lift_splat.txt
 timeout 300 python tools/bench_graphed.py 2> $OUT/bench_graphed.err | grep n_trajs > $OUT/${TAG}_bench_graphed.txt
