@@ -203,8 +203,10 @@ typedef struct MfRolloutBwdBufs {
   void* gxd0;           /* out: S[B][3] */
   void* gR0;            /* out: S[B][3][3] */
   void* gw0;            /* out: S[B][3] */
-  const void* joint_angles; /* the forward's S[B][T][4] flipper angles (desc->has_joints), else NULL.  They are constants of the
-                           rollout: no gradient is produced for them (the reference's datasets feed measured angles) */
+  const void* joint_angles; /* the forward's S[B][T][4] flipper angles (desc->has_joints), else NULL */
+  void* gjoint_angles;      /* out: dL/d(joint_angles), S[B][T][4], through update_joints AND the per-step inertia
+                               (dphysics.py:191-197, 326-358); NULL to skip.  Rows the scheme never reads (the last one of the
+                               default integrator) are not written: hand in zeros. */
 } MfRolloutBwdBufs;
 
 /* 1 if the backward kernels chosen for this descriptor always write the control gradient (gcontrols must then be a buffer), 0 if

@@ -35,7 +35,7 @@ class MfRolloutBwdBufs(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ('z', 'mu', 'controls', 'ts', 'points', 'part', 'x_init', 'xd0', 'R0', 'w0',
                                           'Xraw', 'Xds', 'Rs', 'Omegas',
                                           'gXs', 'gXds', 'gRs', 'gOmegas', 'gFs', 'gFf', 'zeros',
-                                          'gz', 'gmu', 'gcontrols', 'gx0', 'gxd0', 'gR0', 'gw0', 'joint_angles')]
+                                          'gz', 'gmu', 'gcontrols', 'gx0', 'gxd0', 'gR0', 'gw0', 'joint_angles', 'gjoint_angles')]
 
 
 class MfLossDesc(C.Structure):

@@ -95,7 +95,7 @@ __device__ __forceinline__ S group_sum(S v) {
 // all-reduces its 64 lanes, writes the partial to LDS, one s_barrier, and every lane adds the G / 64 partials in a fixed
 // order (deterministic).  Two LDS slots alternate: a wave can run at most one barrier ahead of the slowest one, so when it
 // writes slot p again every wave has finished reading it.  All threads of the workgroup must make the same calls.
-constexpr int kGroupSumMaxValues = 24;   // most values one sum_n() call reduces (the backward's 23 adjoint components)
+constexpr int kGroupSumMaxValues = 28;   // most values one sum_n() call reduces (the backward's 23 adjoint components + 4 joint-angle gradients)
 template <int G, typename S>
 struct GroupSum {
   static constexpr int NW = G > 64 ? G / 64 : 1;

@@ -37,6 +37,8 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
   for (int i = 0; i < 9; ++i) a.Iinv[i] = (S)d->Iinv[i];
   for (int i = 0; i < 12; ++i) a.joint_xyz[i] = (S)d->joint_xyz[i];
   a.joint_angles = (const S*)p->joint_angles;
+  a.gjoint = (S*)p->gjoint_angles;
+  MF_REQUIRE(!p->gjoint_angles || p->joint_angles, MF_ERR_INVALID, "rollout_bwd: gjoint_angles without joint_angles");
   MF_REQUIRE(!d->has_joints == !p->joint_angles, MF_ERR_INVALID, "rollout_bwd: joint_angles must be given exactly when desc->has_joints is set");
   MF_REQUIRE(!p->joint_angles || d->n_tracks == 4, MF_ERR_INVALID, "rollout_bwd: joint angles need the 4 driving parts of robot 'marv'");
   a.z = (const S*)p->z; a.mu = (const S*)p->mu; a.controls = (const S*)p->controls; a.ts = (const S*)p->ts;

@@ -27,8 +27,9 @@ struct RolloutBwdArgs {
   const S *gXs, *gXds, *gRs, *gOm, *gFs, *gFf;   // never NULL here: the host substitutes `zeros` with a zero stride
   int sXs, sXds, sRs, sOm, sFs, sFf;              // floats per row element group: 3 / 9 (present) or 0 (absent -> zeros)
   S *gz, *gmu, *gcontrols, *gx0, *gxd0, *gR0, *gw0;
-  const S* joint_angles;   // [B,T,4] flipper angles (constants of the rollout: no gradient), or NULL
+  const S* joint_angles;   // [B,T,4] flipper angles, or NULL
   S joint_xyz[12];
+  S* gjoint;               // [B,T,4] out: gradient of the flipper angles, or NULL
 };
 
 #ifdef MF_NO_ATOMICS
@@ -531,6 +532,7 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_bwd_kernel(const Ro
     gS = gs.sum(gS);
 
     S gx_[3] = {zero, zero, zero}, gxd_[3] = {zero, zero, zero}, gw_[3] = {zero, zero, zero}, gR_[9];
+    S gja_[4] = {zero, zero, zero, zero};
 #pragma unroll
     for (int c = 0; c < 9; ++c) gR_[c] = zero;
 #pragma unroll
@@ -614,6 +616,7 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_bwd_kernel(const Ro
         S gp[3] = {M::div(gzq * zfx + gmuq[j] * mfx, a.res), M::div(gzq * zfy + gmuq[j] * mfy, a.res), gdh};
         // v_p = xd + w x r
         S t1[3], t2[3];
+        S gP[3] = {zero, zero, zero};      // adjoint of the body-frame point (articulated bodies: feeds the joint angles)
         MF_CROSS(t1, gvp[j], w);           // dr += gvp x w
         MF_CROSS(t2, r[j], gvp[j]);        // dw += r x gvp
 #pragma unroll
@@ -626,16 +629,40 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_bwd_kernel(const Ro
           gR_[q * 3 + 0] += qa * P[j][0];
           gR_[q * 3 + 1] += qa * P[j][1];
           gR_[q * 3 + 2] += qa * P[j][2];
+          if constexpr (JOINTS) { gP[0] += qa * R[q * 3 + 0]; gP[1] += qa * R[q * 3 + 1]; gP[2] += qa * R[q * 3 + 2]; }   // R^T qa
+        }
+        if constexpr (JOINTS) {
+          // ... and through the inertia of the articulated body (dphysics.py:196-197): wd = I^-1 tau, I = sum_j m (|P_j|^2 E -
+          // P_j P_j^T).  With a = I^-T g_wd (= gtau) and b = I^-1 tau (= wraw) the gradient of I is -a b^T, and
+          // dL/dP_j = m (2 tr(gI) P_j - (gI + gI^T) P_j) = m (-2 (a.b) P_j + a (b.P_j) + b (a.P_j))
+          const S mp = act[j] ? a.mass / (S)a.N : zero;
+          const S ab = gtau[0] * wraw[0] + gtau[1] * wraw[1] + gtau[2] * wraw[2];
+          const S bP = wraw[0] * P[j][0] + wraw[1] * P[j][1] + wraw[2] * P[j][2];
+          const S aP = gtau[0] * P[j][0] + gtau[1] * P[j][1] + gtau[2] * P[j][2];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) gP[c] += mp * (((S)-2 * ab) * P[j][c] + gtau[c] * bP + wraw[c] * aP);
+          // P_j = J + Ry(theta) (P0_j - J) for the points of flipper q: dP/dtheta = (P_z - J_z, 0, -(P_x - J_x))
+          const int qj = max(part[j], 0);
+          const S dth = gP[0] * (P[j][2] - a.joint_xyz[qj * 3 + 2]) - gP[2] * (P[j][0] - a.joint_xyz[qj * 3 + 0]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) gja_[q] += (part[j] == q) ? dth : zero;
         }
       }
     }
-    S red[23];
+    S red[JOINTS ? 27 : 23];
 #pragma unroll
     for (int c = 0; c < 3; ++c) { red[c] = gx_[c]; red[3 + c] = gxd_[c]; red[6 + c] = gw_[c]; red[9 + c] = ge[c]; }
 #pragma unroll
     for (int c = 0; c < 9; ++c) red[12 + c] = gR_[c];
     red[21] = gv; red[22] = gwc;
+    if constexpr (JOINTS) { red[23] = gja_[0]; red[24] = gja_[1]; red[25] = gja_[2]; red[26] = gja_[3]; }
     gs.sum_n(red);       // the step's 23 adjoint sums in one batched reduction (multi-wave groups: one LDS exchange)
+    if constexpr (JOINTS) {
+      if (a.gjoint != nullptr && gl == 0) {
+        S* o = a.gjoint + ((size_t)b * a.T + n) * 4;
+        o[0] = red[23]; o[1] = red[24]; o[2] = red[25]; o[3] = red[26];
+      }
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) { lx[c] += red[c]; lxd[c] += red[3 + c]; lw[c] += red[6 + c]; ge[c] = red[9 + c]; }
 #pragma unroll

@@ -190,7 +190,7 @@ class _RolloutFn(torch.autograd.Function):
             ctx.z_shape, ctx.mu_shape, ctx.mu_given = z.shape, (mu.shape if mu is not None else None), mu is not None
             ctx.z_expanded = z.stride(0) == 0 and z.shape[0] > 1
             ctx.mu_expanded = mu is not None and mu.stride(0) == 0 and mu.shape[0] > 1
-            ctx.joint_angles = joint_angles          # constants of the rollout (no gradient), kept for the backward
+            ctx.joint_angles = joint_angles.detach() if joint_angles is not None else None
             # x0 now holds the snapped start position; a caller-visible buffer is copied, the module's own default is not
             ctx.save_for_backward(controls, x0 if x0_private else x0.clone(), xd0, R0, w0, ts, Xraw, Xds, Rs, Om)
         return outs
@@ -198,7 +198,7 @@ class _RolloutFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gXs, gXds, gRs, gOm, gFs=None, gFf=None):
         from .dphysics_bwd import rollout_backward
-        return rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf) + (None, None, None, None, None)
+        return rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf) + (None, None, None, None)
 
 
 class DPhysics(torch.nn.Module):
@@ -350,10 +350,8 @@ class DPhysics(torch.nn.Module):
             assert joint_angles.shape == (B, N_ts, 4), f'Joint angles shape {joint_angles.shape} != {(B, N_ts, 4)}'
             # the reference re-articulates the body only for robot == 'marv' and non-zero angles (dphysics.py:340)
             if cfg.robot == 'marv' and not torch.allclose(joint_angles, torch.zeros_like(joint_angles)):
-                if joint_angles.requires_grad and torch.is_grad_enabled():
-                    raise NotImplementedError('the HIP rollout treats joint angles as constants: no gradient w.r.t. joint_angles '
-                                              '(detach them, or use the CPU reference for that derivative)')
-                ja_dev = joint_angles.detach().to(device=dev, dtype=dtype).contiguous()
+                # (differentiable: the gradient flows through update_joints and the per-step inertia, dphysics.py:191-197)
+                ja_dev = joint_angles.to(device=dev, dtype=dtype).contiguous()
         self.joint_angles = joint_angles
         self.ts = self.ts[:N_ts]                                                     # permanent, like the reference (:581)
         ts = self._time_grid(N_ts, dtype, dev)
@@ -366,7 +364,7 @@ class DPhysics(torch.nn.Module):
             x0 = x0.clone(); aliased = False
         xd0, R0, w0 = (s.to(device=dev, dtype=dtype).contiguous() for s in state[1:])
         want_grad = torch.is_grad_enabled() and any(
-            t is not None and t.requires_grad for t in (z_grid, friction, controls, x_in, xd0, R0, w0))
+            t is not None and t.requires_grad for t in (z_grid, friction, controls, x_in, xd0, R0, w0, ja_dev))
         want_forces = self.return_forces or self.precise or dtype != torch.float32 or ja_dev is not None
         # a start position that requires grad is the autograd input itself (its gradient: x and y through the contact geometry,
         # z none -- the snap overwrites it); the kernel works on the detached buffer x0 either way

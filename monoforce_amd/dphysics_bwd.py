@@ -94,6 +94,9 @@ def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf):
     gcontrols = torch.empty_like(controls) if need_gc else None
     gxd0, gR0, gw0 = torch.empty_like(xd0), torch.empty_like(R0), torch.empty_like(w0)
     gx0 = torch.empty_like(xd0) if ctx.needs_input_grad[4] else None
+    ja = getattr(ctx, 'joint_angles', None)
+    # (zeros: the default integrator never reads its last row of angles, and the kernel does not write that gradient row)
+    gja = torch.zeros_like(ja) if ja is not None and ctx.needs_input_grad[10] else None
     bufs = _lib.MfRolloutBwdBufs(
         z=_lib.ptr(z), mu=_lib.ptr(mu), controls=_lib.ptr(controls), ts=_lib.ptr(ts), points=_lib.ptr(keep['points']),
         part=_lib.ptr(mod._part_dev(dev)), x_init=_lib.ptr(x_init), xd0=_lib.ptr(xd0), R0=_lib.ptr(R0), w0=_lib.ptr(w0),
@@ -101,7 +104,7 @@ def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf):
         gXs=_lib.ptr(ups[0]), gXds=_lib.ptr(ups[1]), gRs=_lib.ptr(ups[2]), gOmegas=_lib.ptr(ups[3]),
         gFs=_lib.ptr(ups[4]), gFf=_lib.ptr(ups[5]), zeros=_lib.ptr(zero_row),
         gz=_lib.ptr(gz), gmu=_lib.ptr(gmu), gcontrols=_lib.ptr(gcontrols), gx0=_lib.ptr(gx0),
-        gxd0=_lib.ptr(gxd0), gR0=_lib.ptr(gR0), gw0=_lib.ptr(gw0), joint_angles=_lib.ptr(getattr(ctx, 'joint_angles', None)))
+        gxd0=_lib.ptr(gxd0), gR0=_lib.ptr(gR0), gw0=_lib.ptr(gw0), joint_angles=_lib.ptr(ja), gjoint_angles=_lib.ptr(gja))
     fn = getattr(_lib.lib(), 'mf_rollout_bwd_' + _scalar_suffix(dt))
     with torch.cuda.device(dev), _timing.timed('rollout_bwd_kernel', dev):
         _lib.check(fn(C.byref(desc), C.byref(bufs), _stream_ptr(dev)), 'mf_rollout_bwd')
@@ -138,4 +141,4 @@ def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf):
     return (None, to_input_shape(gz, ctx.z_shape, ctx.z_expanded) if ctx.needs_input_grad[1] else None,
             to_input_shape(gmu, ctx.mu_shape, ctx.mu_expanded), gcontrols if ctx.needs_input_grad[3] else None, gx0,
             gxd0 if ctx.needs_input_grad[5] else None, gR0 if ctx.needs_input_grad[6] else None,
-            gw0 if ctx.needs_input_grad[7] else None, None, None)
+            gw0 if ctx.needs_input_grad[7] else None, None, None, gja)

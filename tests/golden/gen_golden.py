@@ -432,8 +432,8 @@ def gen_joints(out):
                 cfg = make_ref_cfg(pts, masks, dtype, 0.1, 1.6, use_odeint=(integ == 1), robot='marv')
                 out['joint_positions'] = np.array(list(cfg.joint_positions.values()))
                 dp = ref_dp.DPhysics(cfg, device='cpu')
-                zg, cg, mg = (t.to(dtype).clone().requires_grad_(True) for t in (z, ctrl, mu))
-                states, forces = dp(z_grid=zg, controls=cg, joint_angles=ja.to(dtype), friction=mg)
+                zg, cg, mg, jg = (t.to(dtype).clone().requires_grad_(True) for t in (z, ctrl, mu, ja))
+                states, forces = dp(z_grid=zg, controls=cg, joint_angles=jg, friction=mg)
                 outs = list(states) + list(forces)
                 loss = 0            # the probe loss of run_ref(): touches all six outputs
                 for i, (o, sc) in enumerate(zip(outs, [1.0, 1.0, 1.0, 1.0, 1e-3, 1e-3])):
@@ -441,7 +441,7 @@ def gen_joints(out):
                 loss.backward()
             for k, v in zip(['Xs', 'Xds', 'Rs', 'Om', 'Fs', 'Ff'], outs):
                 out[f'{tag}/i{integ}/{k}'] = npy(v)
-            for k, v in dict(loss=loss, g_z=zg.grad, g_ctrl=cg.grad, g_mu=mg.grad).items():
+            for k, v in dict(loss=loss, g_z=zg.grad, g_ctrl=cg.grad, g_mu=mg.grad, g_ja=jg.grad).items():
                 out[f'{tag}/i{integ}/{k}'] = npy(v)
             print(f'joints {tag} integ={integ}: |Xs|max={float(states[0].abs().max()):.3f}')
 

@@ -237,3 +237,45 @@ def test_gradient_wrt_start_position(integ):
     assert float(g_ref[:, :2].abs().max()) > 0 and float(g_hip[:, 2].abs().max()) == 0.0
     assert hp.rel_err(g_hip, g_ref) <= 1e-8, hp.rel_err(g_hip, g_ref)
     assert hp.rel_err(x_hip, x_ref) <= 1e-12          # both wrote the snapped height into the caller's tensor
+
+
+@pytest.mark.parametrize('tag', ['f32', 'f64'])
+@pytest.mark.parametrize('integ', [0, 1])
+def test_gradient_wrt_joint_angles_all_four_flippers(tag, integ):
+    """dL/d(joint_angles) through `update_joints` and the per-step inertia (dphysics.py:191-197, 326-358) vs the oracle's
+    autograd, with points on ALL four flippers (the reference fixture rollout_joints.npz has points on two), a friction map and
+    a loss on every output; also dL/dz next to it (the articulated body feeds both)."""
+    from monoforce_amd import synthetic as syn
+    from monoforce_amd.dphys_config import DPhysConfig
+    from monoforce_amd.dphysics import DPhysics
+    from oracle import dphysics_oracle as orc
+    dt = hp.DT[tag]
+    pts, masks = syn.robot_points_box(96, seed=3, n_tracks=4)
+    assert all(int(m.sum()) >= 2 for m in masks)
+    B, T = 4, 36
+    z = torch.stack([syn.bump_terrain(syn.bump_params(30 + k), 1.6, 0.1, torch.float64) * 0.4 for k in range(B)])
+    mu = torch.stack([syn.wave_friction(1.6, 0.1, 0.5, 1.0, 1.3 + 0.2 * k, 0.9, torch.float64) for k in range(B)])
+    ctrl = syn.varying_controls(B, T, seed=12, dtype=torch.float64)
+    tt = torch.linspace(0, 1, T, dtype=torch.float64).view(1, T, 1)
+    ja = 0.5 * torch.sin(2 * np.pi * (tt * torch.tensor([0.9, 1.2, 0.6, 1.5]) + torch.arange(B).view(B, 1, 1) * 0.15)) + 0.1
+    cfg = DPhysConfig(robot='marv', grid_res=0.1, robot_points=pts, driving_parts=np.stack(masks))
+    cfg.robot_mass = 40.0
+    cfg.damping = float(np.sqrt(4 * cfg.robot_mass * cfg.stiffness))
+    cfg.d_max, cfg.use_odeint = 1.6, (integ == 1)
+    dp = DPhysics(cfg, device=DEV)
+    zg, mg, jg = (t.to(dt).to(DEV).requires_grad_(True) for t in (z, mu, ja))
+    states, forces = dp(zg, ctrl.to(dt).to(DEV), joint_angles=jg, friction=mg)
+    hp.probe_loss(list(states) + list(forces), dt).backward()
+    spec = hp.spec_from(pts, masks, integ, 0.1, 1.6)
+    spec.joint_positions = [list(v) for v in cfg.joint_positions.values()]
+    zc, mc, jc = (t.clone().requires_grad_(True) for t in (z, mu, ja))
+    rs, rf = orc.rollout(spec, zc, ctrl, friction=mc, joint_angles=jc)
+    hp.probe_loss(list(rs) + list(rf), torch.float64).backward()
+    tol = 1e-8 if tag == 'f64' else 3e-4
+    for k, o, r in zip(hp.OUT_KEYS, list(states) + list(forces), list(rs) + list(rf)):
+        assert hp.rel_err(o, r) <= (1e-9 if tag == 'f64' else 1e-4), (k, hp.rel_err(o, r))
+    assert float(jc.grad.abs().amax(dim=(0, 1)).min()) > 0          # every flipper's angle matters in the oracle
+    assert hp.rel_err(jg.grad, jc.grad) <= tol, hp.rel_err(jg.grad, jc.grad)
+    for q in range(4):                                               # per flipper, not only against the largest one
+        assert hp.rel_err(jg.grad[..., q], jc.grad[..., q]) <= tol, (q, hp.rel_err(jg.grad[..., q], jc.grad[..., q]))
+    assert hp.rel_err(zg.grad, zc.grad) <= tol, hp.rel_err(zg.grad, zc.grad)

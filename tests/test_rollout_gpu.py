@@ -243,17 +243,16 @@ def test_flipper_joint_angles_vs_reference(tag, precise, integ):
     # gradients through the articulated rollout (joint angles are constants) vs the reference's loss.backward()
     from monoforce_amd import synthetic as syn
     zg, cg, mg = t('z').requires_grad_(True), t('ctrl').requires_grad_(True), t('mu').requires_grad_(True)
-    states, forces = dp(zg, cg, joint_angles=t('joint_angles'), friction=mg)
+    jg = t('joint_angles').requires_grad_(True)          # ... and w.r.t. the angles: update_joints + the per-step inertia
+    states, forces = dp(zg, cg, joint_angles=jg, friction=mg)
     loss = 0
     for i, (o, sc) in enumerate(zip(list(states) + list(forces), [1.0, 1.0, 1.0, 1.0, 1e-3, 1e-3])):
         loss = loss + (o * syn.probe_weights(o.shape, phase=0.5 + i, dtype=dt).to(DEV)).sum() * sc
     loss.backward()
-    with pytest.raises(NotImplementedError, match='joint angles as constants'):      # loud, not a silent zero gradient
-        dp(t('z'), t('ctrl'), joint_angles=t('joint_angles').requires_grad_(True), friction=t('mu'))
     pre = f'{tag}/i{integ}/'
     gtol = 1e-8 if tag == 'f64' else 2e-4
     assert abs(float(loss) - float(g[pre + 'loss'])) <= gtol * abs(float(g[pre + 'loss'])) + gtol
-    for k, v in (('g_z', zg.grad), ('g_ctrl', cg.grad), ('g_mu', mg.grad)):
+    for k, v in (('g_z', zg.grad), ('g_ctrl', cg.grad), ('g_mu', mg.grad), ('g_ja', jg.grad)):
         assert hp.rel_err(v.cpu(), g[pre + k]) <= gtol, (k, hp.rel_err(v.cpu(), g[pre + k]))
 
 
