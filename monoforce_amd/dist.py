@@ -75,6 +75,40 @@ class FlatBucket:
             o += n
 
 
+def shared_flat_buffer(tensors):
+    """A 1-D view over the storage `tensors` are consecutive slices of, when that storage holds exactly them plus ONE spare
+    element behind the last -- or None.  (The shared-map rollout backward hands its map gradients out that way,
+    dphysics_bwd.GradPool.reduce; autograd detaches them on the way into `.grad`, so this goes by storage, not by `_base`.)"""
+    tensors = [t for t in tensors if t is not None]
+    if not tensors:
+        return None
+    st, isz, off = tensors[0].untyped_storage(), tensors[0].element_size(), 0
+    for t in tensors:
+        if (t.untyped_storage().data_ptr() != st.data_ptr() or not t.is_contiguous() or t.dtype != tensors[0].dtype
+                or t.storage_offset() != off):
+            return None
+        off += t.numel()
+    if st.nbytes() != (off + 1) * isz:
+        return None
+    return torch.as_strided(tensors[0], (off + 1,), (1,), 0)
+
+
+def allreduce_mean_inplace_(flat):
+    """Mean of one buffer across ranks, in place, as ONE collective (RCCL computes the average itself: no divide launch)."""
+    if world() == 1:
+        return flat
+    if flat.is_cuda and dist.get_backend() == 'gloo':      # CPU-only test rigs: stage through the host
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        flat.copy_(host / world())
+    elif dist.get_backend() == 'gloo':
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(world())
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG)        # RCCL over xGMI
+    return flat
+
+
 def allreduce_sum_(tensors, bucket=None, average=False):
     """In-place sum (or mean) of `tensors` across ranks through one flat bucket; returns the bucket for reuse."""
     tensors = [t for t in tensors if t is not None]

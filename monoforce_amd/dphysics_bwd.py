@@ -36,7 +36,10 @@ class GradPool:
 
     def reduce(self, map_shape):
         from .dphysics import _scalar_suffix
-        out = torch.empty((self.n_maps,) + tuple(map_shape), dtype=self.buf.dtype, device=self.buf.device)
+        # one spare scalar behind the maps: a data-parallel caller puts its loss there and exchanges gradients and loss with
+        # ONE collective on this buffer, no pack / unpack (train.py::TerrainFitProblem)
+        flat = torch.empty(self.n_maps * self.n + 1, dtype=self.buf.dtype, device=self.buf.device)
+        out = flat[:-1].view((self.n_maps,) + tuple(map_shape))
         fn = getattr(_lib.lib(), 'mf_reduce_grad_copies_' + _scalar_suffix(self.buf.dtype))
         with torch.cuda.device(self.buf.device):
             _lib.check(fn(_lib.ptr(self.buf), self.n_maps, self.copies, C.c_longlong(self.n), _lib.ptr(out),

@@ -30,6 +30,7 @@ class TerrainFitProblem:
         self.nearest = nearest_steps(self.pred_ts, self.gt_ts).to(torch.int32)      # time stamps are fixed: computed once
         self.bucket = None
         self._one = None
+        self.fast_exchange = None         # True once a step exchanged gradients and loss in place (one collective, no copies)
 
     def step(self, z, mu):
         """One forward + backward: returns the loss averaged over ALL ranks' rollouts; leaves its gradient w.r.t. z, mu in .grad."""
@@ -47,6 +48,15 @@ class TerrainFitProblem:
         # the one exchange step of the backward: 2 x H x W floats (+ the loss scalar) over RCCL.  Every rank's loss is the MEAN
         # over its own rollouts (equal shares), so the mean over ranks is the gradient of the global-mean loss: the step does
         # not depend on the number of GPUs.
+        # The shared-map backward hands both gradients out as views of one buffer with a spare scalar behind them: the loss goes
+        # there and the buffer is averaged in place by one collective -- no pack, divide or unpack launches around it (eight
+        # ~10 us launches on a 0.56 ms step).
+        flat = mfdist.shared_flat_buffer([z.grad, mu.grad])
+        self.fast_exchange = flat is not None
+        if flat is not None:
+            flat[-1:].copy_(loss.detach().reshape(1))
+            mfdist.allreduce_mean_inplace_(flat)
+            return flat[-1]
         lbuf = loss.detach().reshape(1).clone()
         self.bucket = mfdist.allreduce_sum_([z.grad, mu.grad, lbuf], self.bucket, average=True)
         return lbuf[0]

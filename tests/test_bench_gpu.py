@@ -61,7 +61,7 @@ def _fit_worker(rank, world, store, B, T, out_path):
     zl, ml = z.to(dev).clone().requires_grad_(True), mu.to(dev).clone().requires_grad_(True)
     loss = prob.step(zl, ml)
     if rank == 0:
-        torch.save({'loss': loss.detach().cpu(), 'gz': zl.grad.cpu(), 'gmu': ml.grad.cpu()}, out_path)
+        torch.save({'loss': loss.detach().cpu(), 'gz': zl.grad.cpu(), 'gmu': ml.grad.cpu(), 'fast': prob.fast_exchange}, out_path)
     if world > 1:
         dist.destroy_process_group()
 
@@ -75,6 +75,7 @@ def test_two_rank_terrain_gradient_equals_single_process():
         mp.spawn(_fit_worker, args=(2, os.path.join(td, 'store'), B, T, os.path.join(td, 'two.pt')), nprocs=2, join=True)
         _fit_worker(0, 1, None, B, T, os.path.join(td, 'one.pt'))
         two, one = torch.load(os.path.join(td, 'two.pt')), torch.load(os.path.join(td, 'one.pt'))
+    assert two['fast'] is True            # gradients and loss went through ONE in-place collective (no pack / unpack copies)
     assert abs(float(two['loss']) - float(one['loss'])) <= 1e-5 * abs(float(one['loss']))
     for k in ('gz', 'gmu'):
         scale = float(one[k].abs().max())
