@@ -52,7 +52,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s HBM3E peak (~6.3 TB/s achievable)
-EVENT_EVERY = 4              # kernel durations: HIP events around the launches of every 4th step of the timed region
+EVENT_EVERY = 8              # kernel durations: HIP events around the launches of every 8th step of the timed region
 
 WORKLOADS = {
     'c1': dict(B=1, T=200, N=4, backward=True, grid_res=0.1, desc='BASELINE configs[0]: 1 rollout x 200 steps, 128x128 terrain, forward + backward'),
@@ -233,22 +233,63 @@ class Runner:
             from monoforce_amd.train import TerrainFitProblem
             from monoforce_amd import synthetic as syn
             z_true = syn.bump_terrain(syn.bump_params(100), 6.4, res).to(dev)       # GT trajectories come from another terrain
-            prob = TerrainFitProblem(dp, z_true, mu.to(dev), cd)
+            # (graph=True: `prob.step(eager=False)` replays forward + loss + backward as one hipGraph, captured at its first use)
+            prob = TerrainFitProblem(dp, z_true, mu.to(dev), cd, graph=True)
             zleaf = z.to(dev).clone().requires_grad_(True)
             mleaf = mu.to(dev).clone().requires_grad_(True)
+
+        use_graph = not os.environ.get('MF_BENCH_NO_GRAPH') and not wl.get('encoder')
+        mode = {'graph': False}
+        fwd_graph = None
+
+        def forward_eager():
+            with torch.no_grad():
+                return dp(zd, cd, friction=md)
 
         def step():
             if wl.get('encoder'):
                 return estep.step(ebatch)
+            eager = _timing.sampled() or not mode['graph']       # steps bracketed with HIP events run launch by launch
             if wl['backward']:
-                return prob.step(zleaf, mleaf)
-            with torch.no_grad():
-                return dp(zd, cd, friction=md)
+                return prob.step(zleaf, mleaf, eager=eager)
+            if eager:
+                return forward_eager()
+            fwd_graph.replay()
 
         for _ in range(warmup):
             step()
+        launch = None
+        if use_graph:
+            # Launch mode of the timed region, chosen by measurement on THIS host (untimed, after the warm-up): the step replayed
+            # as one hipGraph (~20 us of host work, but every graph node pays a few us more on the device) against the step
+            # launched call by call (0.15 ms of Python and launch calls forward, 0.3 ms forward + backward: faster while the host
+            # keeps ahead of the kernels, host-bound on a loaded or slower box and at the small configs).  Same kernels, same
+            # work either way.
+            if not wl['backward']:
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    forward_eager()
+                torch.cuda.current_stream(dev).wait_stream(side)
+                fwd_graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(fwd_graph, stream=side):
+                    forward_eager()
+
+            def timed(graph, n=32):
+                mode['graph'] = graph
+                step()
+                torch.cuda.synchronize(dev)
+                t = time.perf_counter()
+                for _ in range(n):
+                    step()
+                torch.cuda.synchronize(dev)
+                return (time.perf_counter() - t) / n * 1e3
+            t_graph, t_eager = self.max_over_ranks(timed(True)), self.max_over_ranks(timed(False))
+            mode['graph'] = t_graph < t_eager
+            launch = {'mode': 'one hipGraph replay per step' if mode['graph'] else 'launch by launch',
+                      'calibration_ms_per_step': {'graph': t_graph, 'eager': t_eager}}
         self.barrier()
-        # HIP events around the C-ABI launches of every 4th step of the timed region, on the stream the kernel is launched on
+        # HIP events around the C-ABI launches of every 8th step of the timed region, on the stream the kernel is launched on
         # (around all of them they cost 33 us of a 0.55 ms step: each record is a packet of its own between two kernels)
         _timing.start(every=EVENT_EVERY)
         t0 = time.perf_counter()
@@ -283,7 +324,7 @@ class Runner:
             'config': {'workload': f'{name}: B={B}/GPU x T={T} x N={N} contact points, {H}x{H} grid (res {res} m), one shared '
                                    f'terrain+friction map (the same on every rank), integrator={integ}, {mode}; {wl["desc"]}',
                        'rollouts_per_gpu': B, 'rollouts_total': B_total, 'horizon': T, 'contact_points': N, 'grid': [H, H],
-                       'parallelism': f'rollout-sharded x{world}'},
+                       'parallelism': f'rollout-sharded x{world}', **({'launch': launch} if launch else {})},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic,
                          'traffic_source': 'profiles/hbm_traffic.json (rocprofv3 PMC passes of this command, static -- not re-measured in this run)' if traffic else None,
@@ -378,7 +419,7 @@ def spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--steps', type=int, default=48)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='c3', choices=sorted(WORKLOADS))
     ap.add_argument('--batch', type=int, default=0, help='override rollouts per GPU (total for c5)')

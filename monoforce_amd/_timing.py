@@ -24,6 +24,12 @@ def next_step():
     _step += 1
 
 
+def sampled():
+    """True while the launches of the current step are being bracketed with events (callers that replay a captured graph run
+    such a step launch by launch instead)."""
+    return _records is not None and (_every <= 1 or _step % _every == 0)
+
+
 def stop():
     """Stop recording and return {name: [ms, ...]} (synchronises)."""
     global _records

@@ -338,13 +338,17 @@ class DPhysics(torch.nn.Module):
             *state, state_in_kernel = _default_state(controls, batch_size, in_kernel=True)
         if friction is not None:
             friction = friction.to(device=dev, dtype=dtype)
-        self.z_grid = z_grid
-        self.friction = friction if friction is not None else cfg.friction      # all-ones default (:562), never expanded
+        # The attributes the reference keeps (:561-580) hold DETACHED tensors here: a view of a leaf that requires grad, kept
+        # alive on the module, keeps that leaf's gradient accumulator -- and the stream it was created on -- alive too, and a
+        # later hipGraph capture of a backward to the same leaf on another stream then dies in hipStreamEndCapture
+        # (tools/try_graph_step.py; round 1's "core dump when capturing a train step").
+        self.z_grid = z_grid.detach()
+        self.friction = friction.detach() if friction is not None else cfg.friction      # all-ones default (:562), never expanded
 
         N_ts = min(int(T_ / dt_), controls.shape[1])                                 # (:573)
         B = state[0].shape[0]
         assert controls.shape == (B, N_ts, 2), f'Controls shape {controls.shape} != {(B, N_ts, 2)}'
-        self.controls = controls
+        self.controls = controls.detach()
         ja_dev = None
         if joint_angles is not None:
             assert joint_angles.shape == (B, N_ts, 4), f'Joint angles shape {joint_angles.shape} != {(B, N_ts, 4)}'
@@ -352,7 +356,7 @@ class DPhysics(torch.nn.Module):
             if cfg.robot == 'marv' and not torch.allclose(joint_angles, torch.zeros_like(joint_angles)):
                 # (differentiable: the gradient flows through update_joints and the per-step inertia, dphysics.py:191-197)
                 ja_dev = joint_angles.to(device=dev, dtype=dtype).contiguous()
-        self.joint_angles = joint_angles
+        self.joint_angles = joint_angles.detach() if joint_angles is not None else None
         self.ts = self.ts[:N_ts]                                                     # permanent, like the reference (:581)
         ts = self._time_grid(N_ts, dtype, dev)
 

@@ -14,7 +14,7 @@ class TerrainFitProblem:
     The ground truth is a rollout of the same controls on a "true" terrain, generated once with the HIP forward.
     """
 
-    def __init__(self, dphysics, z_true, mu_true, controls, gt_every=10, fused_loss=True):
+    def __init__(self, dphysics, z_true, mu_true, controls, gt_every=10, fused_loss=True, graph=False):
         self.dp = dphysics
         self.fused_loss = fused_loss      # mf_physics_loss_* instead of ~25 small ATen kernels (same value and gradient)
         self.controls = controls
@@ -31,23 +31,23 @@ class TerrainFitProblem:
         self.bucket = None
         self._one = None
         self.fast_exchange = None         # True once a step exchanged gradients and loss in place (one collective, no copies)
+        # graph = True: forward + loss + backward are captured once and replayed as ONE hipGraph launch per step -- the host side
+        # of a step is ~0.3 ms of Python and launch calls against ~0.55 ms of kernels at the BASELINE shape (a loaded or slower
+        # host makes the step host-bound) and against ~0.15 ms at 256 rollouts x 100 steps (0.38 -> 0.15 ms per step replayed).
+        self.graph = bool(graph) and fused_loss and controls.is_cuda
+        self._captured = None
 
-    def step(self, z, mu):
-        """One forward + backward: returns the loss averaged over ALL ranks' rollouts; leaves its gradient w.r.t. z, mu in .grad."""
-        z.grad = None
-        mu.grad = None
-        states, _ = self.dp(z.unsqueeze(0), self.controls, friction=mu.unsqueeze(0))
-        loss_fn = physics_loss_fused if self.fused_loss else physics_loss
-        loss = loss_fn(states, self.states_gt, self.pred_ts, self.gt_ts,
-                       nearest=self.nearest if self.fused_loss else self.nearest.long())
+    def _seed(self, loss):
         if self._one is None or self._one.dtype != loss.dtype or self._one.device != loss.device:
             self._one = torch.ones((), dtype=loss.dtype, device=loss.device)
-        loss.backward(self._one)          # (the default seed is a fresh ones_like: one more launch in front of the backward)
+        return self._one
+
+    def _exchange(self, z, mu, loss):
+        """The one exchange step of the backward: 2 x H x W floats (+ the loss scalar) over RCCL.  Every rank's loss is the MEAN
+        over its own rollouts (equal shares), so the mean over ranks is the gradient of the global-mean loss: the step does
+        not depend on the number of GPUs."""
         if mfdist.world() == 1:
             return loss.detach()
-        # the one exchange step of the backward: 2 x H x W floats (+ the loss scalar) over RCCL.  Every rank's loss is the MEAN
-        # over its own rollouts (equal shares), so the mean over ranks is the gradient of the global-mean loss: the step does
-        # not depend on the number of GPUs.
         # The shared-map backward hands both gradients out as views of one buffer with a spare scalar behind them: the loss goes
         # there and the buffer is averaged in place by one collective -- no pack, divide or unpack launches around it (eight
         # ~10 us launches on a 0.56 ms step).
@@ -60,6 +60,49 @@ class TerrainFitProblem:
         lbuf = loss.detach().reshape(1).clone()
         self.bucket = mfdist.allreduce_sum_([z.grad, mu.grad, lbuf], self.bucket, average=True)
         return lbuf[0]
+
+    def step(self, z, mu, eager=False):
+        """One forward + backward: returns the loss averaged over ALL ranks' rollouts; leaves its gradient w.r.t. z, mu in .grad.
+        `eager=True` runs this one step launch by launch even in graph mode (bench.py brackets the kernels of such steps with
+        HIP events)."""
+        if self.graph and not eager:
+            return self._step_graph(z, mu)
+        z.grad = None
+        mu.grad = None
+        states, _ = self.dp(z.unsqueeze(0), self.controls, friction=mu.unsqueeze(0))
+        loss_fn = physics_loss_fused if self.fused_loss else physics_loss
+        loss = loss_fn(states, self.states_gt, self.pred_ts, self.gt_ts,
+                       nearest=self.nearest if self.fused_loss else self.nearest.long())
+        loss.backward(self._seed(loss))   # (the default seed is a fresh ones_like: one more launch in front of the backward)
+        return self._exchange(z, mu, loss)
+
+    def _step_graph(self, z, mu):
+        cap = self._captured
+        if cap is None or cap['z'] is not z or cap['mu'] is not mu:
+            cap = self._captured = self._capture(z, mu)
+        cap['graph'].replay()
+        z.grad, mu.grad = cap['gz'], cap['gmu']
+        return self._exchange(z, mu, cap['loss'])
+
+    def _capture(self, z, mu):
+        dev = z.device
+
+        def fwd_bwd():
+            states, _ = self.dp(z.unsqueeze(0), self.controls, friction=mu.unsqueeze(0))
+            loss = physics_loss_fused(states, self.states_gt, self.pred_ts, self.gt_ts, nearest=self.nearest)
+            gz, gmu = torch.autograd.grad(loss, [z, mu], grad_outputs=self._seed(loss))
+            return loss.detach(), gz, gmu
+
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(s):          # warm-up on the capture stream: per-stream workspaces (tickets, gradient pool) exist
+            for _ in range(2):
+                fwd_bwd()
+        torch.cuda.current_stream(dev).wait_stream(s)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            loss, gz, gmu = fwd_bwd()
+        return dict(graph=g, z=z, mu=mu, loss=loss, gz=gz, gmu=gmu)
 
 
 class EncoderTrainStep:

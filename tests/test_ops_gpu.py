@@ -103,3 +103,39 @@ def test_train_step_through_the_ops_can_be_graph_captured():
     captured train step dumped core in hipStreamEndCapture).  Run in a child process: a crash there must not take pytest down."""
     r = subprocess.run([sys.executable, '-c', _CAPTURE % REPO], capture_output=True, text=True, timeout=600)
     assert 'CAPTURE_OK' in r.stdout, (r.returncode, r.stdout[-500:], r.stderr[-3000:])
+
+
+_FIT_GRAPH = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from bench import build_problem
+from monoforce_amd import synthetic as syn
+from monoforce_amd.train import TerrainFitProblem
+dev = torch.device('cuda', 0)
+cfg, dp, pts, masks, z, mu, ctrl = build_problem(512, 200, 4, dev, 1, seed=0)
+z_true = syn.bump_terrain(syn.bump_params(100), 6.4, 0.05).to(dev)
+prob = TerrainFitProblem(dp, z_true, mu.to(dev), ctrl.to(dev), graph=True)
+zl, ml = z.to(dev).clone().requires_grad_(True), mu.to(dev).clone().requires_grad_(True)
+res = []
+for eager in (True, False, False, True, False):       # launch by launch, captured + replayed, replayed, eager again, replayed
+    loss = prob.step(zl, ml, eager=eager)
+    torch.cuda.synchronize()
+    res.append((float(loss), zl.grad.clone(), ml.grad.clone()))
+with torch.no_grad():                                   # a changed terrain is seen by the replay (same tensors, new values)
+    zl.add_(0.01 * torch.sin(torch.arange(zl.numel(), device=dev, dtype=zl.dtype) * 0.01).view_as(zl))
+a = prob.step(zl, ml, eager=True); ga = zl.grad.clone()
+b = prob.step(zl, ml); gb = zl.grad.clone()
+torch.cuda.synchronize()
+rel = lambda u, v: float((u - v).abs().max()) / max(float(v.abs().max()), 1e-30)
+ok = all(abs(l - res[0][0]) <= 1e-5 * abs(res[0][0]) and rel(gz, res[0][1]) <= 2e-4 and rel(gm, res[0][2]) <= 2e-4 for l, gz, gm in res[1:])
+ok = ok and abs(float(a) - float(b)) <= 1e-5 * abs(float(a)) and rel(gb, ga) <= 2e-4 and abs(float(a) - res[0][0]) > 1e-7 * abs(res[0][0])
+print('FIT_GRAPH_OK' if ok else 'FIT_GRAPH_MISMATCH', [r[0] for r in res], float(a), float(b))
+'''
+
+
+def test_terrain_fit_step_replayed_as_one_graph_equals_the_eager_step():
+    """`TerrainFitProblem(graph=True)`: forward + fused loss + backward captured once and replayed as one hipGraph per step give
+    the loss and gradients of the launch-by-launch step, steps of both kinds can be mixed, and a replay sees new terrain
+    values.  (Child process: a crash inside a capture must not take pytest down.)"""
+    r = subprocess.run([sys.executable, '-c', _FIT_GRAPH % REPO], capture_output=True, text=True, timeout=600)
+    assert 'FIT_GRAPH_OK' in r.stdout, (r.returncode, r.stdout[-800:], r.stderr[-3000:])

@@ -1,7 +1,10 @@
 """Which route of a train step survives hipGraph capture?  Each variant runs in a child process (a crash must not stop the
-others).  Finding (round 2): forward + backward through the registered ops (`monoforce_amd.ops.rollout`, variants ops_*) captures
-and replays at every size; the same step through `DPhysics.forward` (a torch.autograd.Function around the same library calls,
-variants module_*) segfaults inside hipStreamEndCapture, whatever the loss, batch size or start state."""
+others).  History: the variants through `DPhysics.forward` (module_*, full) used to segfault inside hipStreamEndCapture while the
+ones through the registered ops (ops_*) captured.  Cause (found by clearing module attributes one by one before the capture):
+the module kept `self.z_grid / self.friction` as the caller's tensors -- views of leaves that require grad, whose gradient
+accumulators (created on the default stream by the eager warm-up steps) stayed alive with them; the backward captured on the
+side stream then had to be synchronised with the default stream.  With detached attributes every variant captures; the tool
+stays as the regression check and prints eager vs replayed step times."""
 import subprocess, sys, os
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BODY = r'''
