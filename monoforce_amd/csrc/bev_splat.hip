@@ -13,7 +13,7 @@
 //     rank      order each voxel's CSR segment by point id (thread per point: rank inside its short segment)
 //   forward   one workgroup per tile of 64 consecutive voxels of one BEV plane, 16 voxels per wave, lane = channel:
 //             the wave's points are one contiguous sorted range of the CSR list; their feature rows (C contiguous floats
-//             = one coalesced 256 B access per point) stream through a 4-deep load pipeline and are accumulated in
+//             = one coalesced 256 B access per point) stream through a 16-deep, branch-free load pipeline and are accumulated in
 //             ascending point order (deterministic, bit-reproducible); the
 //             [channel][voxel] tile is transposed through LDS so every output row segment (64 voxels of one channel
 //             plane) is written as one contiguous 256 B store.  Empty voxels cost one offsets read.
@@ -25,8 +25,8 @@
 namespace mf {
 
 constexpr int kTileVox = 64;
-// row loads in flight per wave: the forward kernels keep 4 (hand-unrolled; a generic 8-deep loop measured slower: 70 -> 92 us
-// at B = 1), the fused backward's gather over a pixel's depth bins 8 (unpipelined before: 152 -> 143 us at B = 8)
+// row loads in flight per wave in the fused backward's gather over a pixel's depth bins (unpipelined before: 152 -> 143 us at
+// B = 8); the forward kernels: kFwdPipe below
 constexpr int kPipeBwd = 8;
 
 struct SplatWs {        // carve-up of the caller's workspace (all int32)
@@ -196,13 +196,72 @@ __global__ void __launch_bounds__(256) splat_rank_kernel(const int* __restrict__
   sorted[s + rank] = p;
 }
 
+template <typename S>
+__device__ __forceinline__ S mul_rounded(S a, S b) {
+#pragma clang fp contract(off)
+  return a * b;          // rounded on its own, like the reference's materialised product, whatever the TU's contraction mode
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// segmented accumulation of a wave's points into its voxels of the LDS tile (both forward kernels)
+// ---------------------------------------------------------------------------------------------------------
+// The points of a wave's kFwdVox consecutive voxels are ONE contiguous, (voxel, point)-sorted range of `list`.  They are taken 64
+// at a time; lane l of a chunk learns the voxel of point l by counting the CSR bounds at or below its index, and the rows are
+// then streamed through a kFwdPipe-deep register pipeline in which EVERYTHING is unconditional: the prefetch index is clamped
+// instead of guarded, a slot past the end contributes a selected zero to the last voxel, and "voxel finished" is not a branch --
+// the running sum is written to the tile after every point (the last write of a voxel is its sum; empty voxels keep the zeros
+// the tile was cleared with).  That is what lets the compiler count its loads: with guards and a voxel-closing `while` in the
+// loop it waited `vmcnt(0)` before every use (23 of 26 waits), i.e. one L2 round trip per POINT, and the densest waves of the
+// config-4 rig hold 256 points (46 -> 27 us fused, 75 -> 41 us plain at B = 1).  Sums run in ascending point order as before.
+constexpr int kFwdVox = 16;      // voxels per wave (4 waves per 64-voxel tile)
+constexpr int kFwdPipe = 16;     // row loads in flight per wave
+
+template <typename S, bool WEIGHTED, typename RowIndex>
+__device__ __forceinline__ void accumulate_tile_rows(const S* __restrict__ xc, int C, const int* __restrict__ list, const S* __restrict__ weight,
+                                                     RowIndex row_of, int my_off, int start, int n, int v_lo, int v_hi, int lane,
+                                                     S (*tile)[kTileVox + 1]) {
+  for (int v = v_lo; v < v_lo + kFwdVox; ++v) tile[lane][v] = (S)0;
+  const int bound_l = (lane <= v_hi - v_lo) ? my_off : 0x3fffffff;     // lanes past a ragged wave's last voxel: no bound
+  S acc = (S)0;
+  int prev_v = -1;
+  for (int k0 = 0; k0 < n; k0 += 64) {
+    const int m = min(64, n - k0);
+    const int pid = (lane < m) ? list[start + k0 + lane] : 0;
+    const int row = row_of(pid);
+    S wl = (S)1;
+    if constexpr (WEIGHTED) wl = (lane < m) ? weight[pid] : (S)0;
+    // voxel of this lane's point = v_lo + number of CSR bounds <= its index; lanes past the end take the last point's voxel
+    int vox = v_lo;
+#pragma unroll
+    for (int j = 1; j < kFwdVox; ++j) vox += (k0 + lane >= __builtin_amdgcn_readlane(bound_l, j) - start) ? 1 : 0;
+    vox = (lane < m) ? vox : __builtin_amdgcn_readlane(vox, m - 1);
+    S buf[kFwdPipe];
+#pragma unroll
+    for (int i = 0; i < kFwdPipe; ++i) buf[i] = xc[(size_t)__builtin_amdgcn_readlane(row, i) * C];
+    for (int k = 0; k < m; k += kFwdPipe) {
+#pragma unroll
+      for (int i = 0; i < kFwdPipe; ++i) {
+        const int p = min(k + i, 63);                       // wave-uniform slot
+        S val = buf[i];
+        buf[i] = xc[(size_t)__builtin_amdgcn_readlane(row, min(p + kFwdPipe, 63)) * C];
+        if constexpr (WEIGHTED) val = mul_rounded(mf_readlane(wl, p), val);
+        const int vi = __builtin_amdgcn_readlane(vox, p);
+        const bool valid = k + i < m;
+        acc = (vi != prev_v ? (S)0 : acc) + (valid ? val : (S)0);
+        tile[lane][vi] = acc;
+        prev_v = vi;
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // forward / backward tiles
 // ---------------------------------------------------------------------------------------------------------
 // A workgroup owns a tile of 64 consecutive voxels of one BEV plane, each of its 4 waves 16 of them.  The CSR segments of
 // consecutive voxels are contiguous, so a wave's points are ONE contiguous, (voxel, point)-sorted range of `list`: it is
 // fetched 64 ids at a time with one coalesced load, and the feature rows (lane = channel: one 256 B row per point) are
-// streamed through a 4-deep register pipeline so that four row loads are always in flight -- no per-voxel latency chain.
+// streamed through the register pipeline of accumulate_tile_rows() above -- no per-voxel latency chain.
 template <typename S>
 __global__ void __launch_bounds__(256) splat_fwd_kernel(const S* __restrict__ x, const int* __restrict__ offsets,
                                                        const int* __restrict__ list, int C, int plane, int tiles_per_plane,
@@ -220,35 +279,7 @@ __global__ void __launch_bounds__(256) splat_fwd_kernel(const S* __restrict__ x,
   const int n = (v_hi > v_lo) ? __builtin_amdgcn_readlane(my_off, v_hi - v_lo) - start : 0;
   for (int c0 = 0; c0 < C; c0 += 64) {
     const int c = min(c0 + lane, C - 1);                       // lanes beyond C read a valid channel and are not stored
-    const S* xc = x + c;
-    S acc = (S)0;
-    int v = v_lo;                                              // voxel being accumulated
-    int bound = (v_hi > v_lo) ? __builtin_amdgcn_readlane(my_off, 1) - start : 0;   // first point index NOT in voxel v
-    for (int k0 = 0; k0 < n; k0 += 64) {
-      const int m = min(64, n - k0);
-      const int pid = (lane < m) ? list[start + k0 + lane] : 0;
-      // 4-deep pipeline over the m points of this chunk
-      S b0 = (S)0, b1 = (S)0, b2 = (S)0, b3 = (S)0;
-      if (0 < m) b0 = xc[(size_t)__builtin_amdgcn_readlane(pid, 0) * C];
-      if (1 < m) b1 = xc[(size_t)__builtin_amdgcn_readlane(pid, 1) * C];
-      if (2 < m) b2 = xc[(size_t)__builtin_amdgcn_readlane(pid, 2) * C];
-      if (3 < m) b3 = xc[(size_t)__builtin_amdgcn_readlane(pid, 3) * C];
-      for (int k = 0; k < m; k += 4) {
-#define MF_STEP(BUF, I)                                                                             \
-        if (k + I < m) {                                                                            \
-          const S val = BUF;                                                                        \
-          if (k + I + 4 < m) BUF = xc[(size_t)__builtin_amdgcn_readlane(pid, k + I + 4) * C];       \
-          while (k0 + k + I >= bound) {          /* wave-uniform: close voxel v (possibly empty) */ \
-            tile[lane][v] = acc; acc = (S)0; ++v;                                                   \
-            bound = __builtin_amdgcn_readlane(my_off, v - v_lo + 1) - start;                        \
-          }                                                                                         \
-          acc += val;                                                                               \
-        }
-        MF_STEP(b0, 0) MF_STEP(b1, 1) MF_STEP(b2, 2) MF_STEP(b3, 3)
-#undef MF_STEP
-      }
-    }
-    for (; v < v_hi; ++v) { tile[lane][v] = acc; acc = (S)0; }   // last voxel with points + trailing empty ones
+    accumulate_tile_rows<S, false>(x + c, C, list, (const S*)nullptr, [](int pid) { return pid; }, my_off, start, n, v_lo, v_hi, lane, tile);
     __syncthreads();
     // out[(bz*C + c) * plane + vid]: 64 consecutive voxels of one channel plane per store
     const int nch = min(64, C - c0);
@@ -313,11 +344,6 @@ __global__ void __launch_bounds__(256) splat_bwd_zero_kernel(const int* __restri
 // point's depth probability depth[p] and the pixel's context row ctx[cam * fHW + pixel][C] (pixel-major, 0.5 MB per sample,
 // cache-resident) and accumulates depth * ctx; 17.8 MB of traffic per sample instead of 49.2 MB.
 // ---------------------------------------------------------------------------------------------------------
-template <typename S>
-__device__ __forceinline__ S mul_rounded(S a, S b) {
-#pragma clang fp contract(off)
-  return a * b;          // rounded on its own, like the reference's materialised product, whatever the TU's contraction mode
-}
 
 template <typename S>
 __global__ void __launch_bounds__(256) lift_splat_fwd_kernel(const S* __restrict__ depth, const S* __restrict__ ctx,
@@ -335,36 +361,9 @@ __global__ void __launch_bounds__(256) lift_splat_fwd_kernel(const S* __restrict
   const int n = (v_hi > v_lo) ? __builtin_amdgcn_readlane(my_off, v_hi - v_lo) - start : 0;
   for (int c0 = 0; c0 < C; c0 += 64) {
     const int c = min(c0 + lane, C - 1);
-    const S* xc = ctx + c;
-    S acc = (S)0;
-    int v = v_lo;
-    int bound = (v_hi > v_lo) ? __builtin_amdgcn_readlane(my_off, 1) - start : 0;
-    for (int k0 = 0; k0 < n; k0 += 64) {
-      const int m = min(64, n - k0);
-      const int pid = (lane < m) ? list[start + k0 + lane] : 0;
-      const int row = (pid / d_hw) * hw + pid % hw;               // the point's pixel row of ctx
-      const S wl = (lane < m) ? depth[pid] : (S)0;                // ... and its depth probability (one lane per point)
-      S b0 = (S)0, b1 = (S)0, b2 = (S)0, b3 = (S)0;
-      if (0 < m) b0 = xc[(size_t)__builtin_amdgcn_readlane(row, 0) * C];
-      if (1 < m) b1 = xc[(size_t)__builtin_amdgcn_readlane(row, 1) * C];
-      if (2 < m) b2 = xc[(size_t)__builtin_amdgcn_readlane(row, 2) * C];
-      if (3 < m) b3 = xc[(size_t)__builtin_amdgcn_readlane(row, 3) * C];
-      for (int k = 0; k < m; k += 4) {
-#define MF_STEP(BUF, I)                                                                             \
-        if (k + I < m) {                                                                            \
-          const S val = mul_rounded(mf_readlane(wl, k + I), BUF);                                   \
-          if (k + I + 4 < m) BUF = xc[(size_t)__builtin_amdgcn_readlane(row, k + I + 4) * C];       \
-          while (k0 + k + I >= bound) {                                                             \
-            tile[lane][v] = acc; acc = (S)0; ++v;                                                   \
-            bound = __builtin_amdgcn_readlane(my_off, v - v_lo + 1) - start;                        \
-          }                                                                                         \
-          acc += val;                                                                               \
-        }
-        MF_STEP(b0, 0) MF_STEP(b1, 1) MF_STEP(b2, 2) MF_STEP(b3, 3)
-#undef MF_STEP
-      }
-    }
-    for (; v < v_hi; ++v) { tile[lane][v] = acc; acc = (S)0; }
+    // a point's row is its pixel's context row, its weight its depth probability
+    accumulate_tile_rows<S, true>(ctx + c, C, list, depth, [=](int pid) { return (pid / d_hw) * hw + pid % hw; }, my_off, start, n, v_lo,
+                                  v_hi, lane, tile);
     __syncthreads();
     const int nch = min(64, C - c0);
     for (int cc = wave; cc < nch; cc += 4)
@@ -422,24 +421,22 @@ __global__ void __launch_bounds__(256) lift_splat_bwd_gather_kernel(const S* __r
       const int cl = on ? c : 0;
       S buf[kPipeBwd];
 #pragma unroll
-      for (int i = 0; i < kPipeBwd; ++i) buf[i] = (i < md) ? gT[(size_t)max(__builtin_amdgcn_readlane(key_l, min(i, 63)), 0) * C + cl] : (S)0;
+      for (int i = 0; i < kPipeBwd; ++i) buf[i] = gT[(size_t)max(__builtin_amdgcn_readlane(key_l, i), 0) * C + cl];
+      // (everything in the loop is unconditional -- clamped prefetch index, masked contributions -- so that the compiler can count
+      // its loads; with guards around them it waited for ALL outstanding loads before every use)
       for (int dd = 0; dd < md; dd += kPipeBwd) {
 #pragma unroll
         for (int i = 0; i < kPipeBwd; ++i) {
-          const int d = dd + i;
-          if (d < md) {
-            const int key = __builtin_amdgcn_readlane(key_l, d);    // wave-uniform
-            const S g = (key >= 0 && on) ? buf[i] : (S)0;
-            if (d + kPipeBwd < md) buf[i] = gT[(size_t)max(__builtin_amdgcn_readlane(key_l, d + kPipeBwd), 0) * C + cl];
-            S dot = (S)0;
-            if (key >= 0) {
-              acc += mf_readlane(dep_l, d) * g;
-              dot = group_sum<64>(f * g);
-            }
-            if (lane == 0) {
-              const size_t p = p0 + (size_t)(d0 + d) * hw;
-              g_depth[p] = (c0 == 0) ? dot : g_depth[p] + dot;      // channel chunks beyond the first accumulate (same lane, in order)
-            }
+          const int d = min(dd + i, 63);
+          const bool valid = dd + i < md;
+          const int key = __builtin_amdgcn_readlane(key_l, d);    // wave-uniform; -1 for dropped points and slots past the end
+          const S g = (key >= 0 && on) ? buf[i] : (S)0;
+          buf[i] = gT[(size_t)max(__builtin_amdgcn_readlane(key_l, min(d + kPipeBwd, 63)), 0) * C + cl];
+          acc += mf_readlane(dep_l, d) * g;
+          const S dot = group_sum<64>(f * g);
+          if (valid && lane == 0) {
+            const size_t p = p0 + (size_t)(d0 + d) * hw;
+            g_depth[p] = (c0 == 0) ? dot : g_depth[p] + dot;      // channel chunks beyond the first accumulate (same lane, in order)
           }
         }
       }

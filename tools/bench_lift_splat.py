@@ -2,7 +2,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from monoforce_amd import splat, synthetic as syn
+from monoforce_amd import _timing, splat, synthetic as syn
 from monoforce_amd.terrain_encoder import LiftSplatShoot
 DEV = 'cuda'
 gc = dict(xbound=[-6.4, 6.4, 0.05], ybound=[-6.4, 6.4, 0.05], zbound=[-3.2, 3.2, 6.4], dbound=[0.6, 6.4, 0.1])
@@ -26,6 +26,8 @@ for B in (1, 8):
         for _ in range(3):
             out = fn(); (out * w).sum().backward()
         torch.cuda.synchronize()
+        # (a) what the caller sees: events around the Python calls with the GPU drained before each (host launch path included);
+        # (b) the hand-written kernels alone: HIP events around the C-ABI launches, 10 iterations queued back to back
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         tf = tb = 0.0
         for _ in range(10):
@@ -33,7 +35,13 @@ for B in (1, 8):
             e[0].record(); out = fn(); e[1].record(); out.backward(w); e[2].record()
             torch.cuda.synchronize()
             tf += e[0].elapsed_time(e[1]); tb += e[1].elapsed_time(e[2])
-        print(f'B={B} {name:18s} forward {tf / 10 * 1e3:7.1f} us   backward {tb / 10 * 1e3:7.1f} us', flush=True)
+        _timing.start()
+        for _ in range(10):
+            depth.grad = ctx.grad = None
+            fn().backward(w)
+        k = {n: sum(v) / len(v) * 1e3 for n, v in _timing.stop().items()}
+        kern = '  kernels: ' + ', '.join(f'{n} {v:.1f} us' for n, v in k.items())
+        print(f'B={B} {name:18s} forward {tf / 10 * 1e3:7.1f} us   backward {tb / 10 * 1e3:7.1f} us (call to call, drained GPU){kern}', flush=True)
     # the geometry side: get_geometry + key/CSR passes from the geometry tensor vs the plan straight from the camera models
     def plan_geom():
         return splat.SplatPlan(enc.get_geometry(*calib), enc.dx, enc.bx, enc.nx)
