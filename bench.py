@@ -272,7 +272,7 @@ class Runner:
                     forward_eager()
                 torch.cuda.current_stream(dev).wait_stream(side)
                 fwd_graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(fwd_graph, stream=side):
+                with torch.cuda.graph(fwd_graph, stream=side, capture_error_mode='thread_local'):
                     forward_eager()
 
             def timed(graph, n=32):

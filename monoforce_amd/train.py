@@ -79,7 +79,14 @@ class TerrainFitProblem:
     def _step_graph(self, z, mu):
         cap = self._captured
         if cap is None or cap['z'] is not z or cap['mu'] is not mu:
-            cap = self._captured = self._capture(z, mu)
+            try:
+                cap = self._captured = self._capture(z, mu)
+            except RuntimeError as e:       # a capture the runtime refuses (e.g. another thread's call landed in it): launch by launch
+                import warnings
+                warnings.warn(f'TerrainFitProblem: hipGraph capture failed ({str(e).splitlines()[0][:120]}); running launch by launch')
+                self.graph, self._captured = False, None
+                torch.cuda.synchronize(z.device)
+                return self.step(z, mu, eager=True)
         cap['graph'].replay()
         z.grad, mu.grad = cap['gz'], cap['gmu']
         return self._exchange(z, mu, cap['loss'])
@@ -100,7 +107,10 @@ class TerrainFitProblem:
                 fwd_bwd()
         torch.cuda.current_stream(dev).wait_stream(s)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=s):
+        # thread_local: only this thread's calls are policed during the capture (a process-group watchdog polling its events
+        # from another thread must not abort it); the backward's launches come from the autograd thread and are captured with
+        # the stream they run on either way
+        with torch.cuda.graph(g, stream=s, capture_error_mode='thread_local'):
             loss, gz, gmu = fwd_bwd()
         return dict(graph=g, z=z, mu=mu, loss=loss, gz=gz, gmu=gmu)
 
