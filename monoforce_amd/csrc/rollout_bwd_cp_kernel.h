@@ -39,6 +39,9 @@ __device__ __forceinline__ float ld1(const float* base, unsigned off) {
 // instructions are one dependent chain, and a dependent VALU instruction issues every ~6.3 cycles against ~4.3 for an
 // independent one (profiles/r1g_microbench_valu_issue.txt) -- the single wave fills exactly those bubbles with the recompute.
 // Measured at B = 1024: 0.388 ms split vs 0.365 ms single wave (dynamics(): 0.478 vs 0.443).
+// Also tried and not kept -- a three-stage single-wave pipeline (gathers of step n - 2, the rest of the recompute of step n - 1
+// BESIDE the chain of step n, three register sets, unrolled by three): the same ~350 instructions per step, interleaved by
+// the compiler instead of run one stream after the other, and slower: 0.399 vs 0.367 ms (dynamics(): 0.548 vs 0.448).
 enum { kCpEarly = 0, kCpLate = 1 };
 template <int INTEG, bool XS_ONLY, bool GCTRL, int MODE>
 __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
@@ -476,7 +479,8 @@ int launch_rollout_bwd_cp_variant(const RolloutBwdArgs<float>& a, bool xs_only, 
   const long long threads = (long long)a.B * 16;
   const unsigned grid = (unsigned)((threads + block - 1) / block);
   const bool gc = a.gcontrols != nullptr;
-  const int mode = grid <= 1024u ? kCpLate : kCpEarly;        // at most one wave per SIMD: late recompute
+  static const int forced = getenv("MF_CP_BWD_MODE") ? atoi(getenv("MF_CP_BWD_MODE")) : -1;      // A/B (tools/ab_cp.py)
+  const int mode = forced >= 0 ? forced : (grid <= 1024u ? kCpLate : kCpEarly);        // at most one wave per SIMD: late recompute
 #define MF_BCP(XS_, GC_, M_) hipLaunchKernelGGL((rollout_bwd_cp_kernel<INTEG, XS_, GC_, M_>), dim3(grid), dim3(block), 0, st, a)
 #define MF_BCP_L(XS_, GC_) do { if (mode == kCpLate) MF_BCP(XS_, GC_, kCpLate); else MF_BCP(XS_, GC_, kCpEarly); } while (0)
   if (xs_only) { if (gc) MF_BCP_L(true, true); else MF_BCP_L(true, false); }
