@@ -10,7 +10,12 @@ visible GPUs, is an error (exit code 2).
 
 A "step" is one pass of the hot path over one batch of synthetic input: B rollouts x T Euler steps x N contact points on a
 256x256 terrain.  `value` = (B * T * world_size * K) / wall time of the K timed steps (barrier + synchronize on both sides,
-max over ranks), inputs resident in HBM, outputs allocated inside the timed region (the API returns fresh tensors).
+max over ranks), inputs resident in HBM, outputs allocated inside the timed region (the API returns fresh tensors) or, when
+the step is replayed as a hipGraph, owned by the captured graph.  Launch mode (`config.launch`): after the warm-up the step is
+timed both ways on the host at hand -- launched call by call, and captured once and replayed as ONE hipGraph launch per step
+(same kernels, same work) -- and the timed region runs in the faster mode; MF_BENCH_NO_GRAPH=1 keeps it launch by launch.
+Kernel durations for `roofline` come from HIP events around the C-ABI launches of every 8th timed step (those steps run
+launch by launch in either mode).
 Rollouts are independent: ranks shard the batch with no data-path collective (weak scaling: B rollouts per GPU); the
 backward all-reduces the gradient of what the ranks SHARE -- one terrain / friction map pair, the same on every rank
 (same seed), fitted to every rank's rollouts -- over RCCL.
@@ -448,12 +453,13 @@ def main():
         short = max(args.steps // 3, 5)
         f, _ = r.run('c3f', args.steps, args.warmup)
         extras['forward_only'] = {'value': f['value'], 'unit': 'rollout-steps/s', 'ms_per_step': f['ms_per_step'],
-                                  'workload': f['config']['workload'], 'roofline': {k: f['roofline'][k] for k in ('achieved', 'frac', 'kernel', 'kernel_ms', 'traffic', 'traffic_source')}}
+                                  'workload': f['config']['workload'], 'launch': f['config'].get('launch'),
+                                  'roofline': {k: f['roofline'][k] for k in ('achieved', 'frac', 'kernel', 'kernel_ms', 'traffic', 'traffic_source')}}
         res['roofline']['per_kernel']['rollout_fwd_kernel_all_outputs'] = f['roofline']['per_kernel']['rollout_fwd_kernel']
 
         def brief(o):
             return {'value': o['value'], 'unit': 'rollout-steps/s', 'ms_per_step': o['ms_per_step'], 'scaling': o['scaling'],
-                    'workload': o['config']['workload'], 'per_kernel': o['roofline']['per_kernel']}
+                    'workload': o['config']['workload'], 'launch': o['config'].get('launch'), 'per_kernel': o['roofline']['per_kernel']}
         if r.world == 1:
             res['roofline']['batch_sweep'] = r.batch_sweep(N, T)
             for name in ('c1', 'c2'):
