@@ -208,3 +208,96 @@ def test_whole_wave_groups_f32_gradients_vs_oracle(B, N):
             tol = 5e-4 if k in ('Xs', 'Rs') else (3e-2 if k in ('Fs', 'Ff') else 2e-3)
             assert hp.rel_err(a.detach().cpu(), b.detach()) <= tol, (N, integ, k, hp.rel_err(a.detach().cpu(), b.detach()))
         assert hp.rel_err(zh.grad.cpu(), zo.grad) <= 2e-3, (N, integ, hp.rel_err(zh.grad.cpu(), zo.grad))
+
+
+def _cp_case(seed):
+    """Random small-body problems for the component-parallel kernels (float32 fast math, N <= 4 contact points)."""
+    from monoforce_amd import synthetic as syn
+    rng = np.random.RandomState(5000 + seed)
+    N = int(rng.randint(1, 5))
+    pts4, _ = syn.robot_points_4()
+    pts = pts4[:N].copy()
+    if N < 3:
+        pts[:, 2] += np.array([0.0, 0.05])[:N]
+    masks = [pts[:, 1] > 0, pts[:, 1] <= 0]
+    B = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 13, 33, 64, 130]))
+    T = int(rng.randint(1, 70))
+    H = int(rng.randint(12, 49))
+    res = float(rng.choice([0.05, 0.1, 0.2]))
+    d_max = H * res / 2
+    integ = int(rng.randint(0, 2))
+    shared = bool(rng.randint(0, 2))
+    with_mu = bool(rng.randint(0, 3))
+    with_state = bool(rng.randint(0, 2))
+    loss_kind = int(rng.randint(0, 3))          # all outputs / positions only / positions + forces
+    nb = 1 if shared else B
+    amp = float(rng.choice([0.0, 0.2, 0.5]))
+    z = torch.stack([syn.bump_terrain(syn.bump_params(seed * 5 + b), d_max, res)[:H, :H] * amp for b in range(nb)])
+    mu = torch.stack([syn.wave_friction(d_max, res, 0.4, 1.0, 1.0 + 0.3 * b, 0.7)[:H, :H] for b in range(nb)]) if with_mu else None
+    ctrl = syn.varying_controls(B, T, seed=seed)
+    state = None
+    if with_state:
+        from scipy.spatial.transform import Rotation
+        f = lambda a: torch.as_tensor(a, dtype=torch.float32)  # noqa: E731
+        span = d_max * float(rng.choice([0.3, 1.2]))
+        state = (f(rng.uniform(-span, span, (B, 3)) * [1, 1, 0.05]), f(rng.uniform(-0.5, 0.5, (B, 3))),
+                 f(Rotation.from_euler('xyz', rng.uniform(-0.2, 0.2, (B, 3)) * [1, 1, 15]).as_matrix()), f(rng.uniform(-0.3, 0.3, (B, 3))))
+    return dict(N=N, B=B, T=T, H=H, res=res, integ=integ, shared=shared, mu=with_mu, state=with_state, loss=loss_kind), pts, masks, z, mu, ctrl, state, d_max
+
+
+def _cp_vs_lanes(seed):
+    from monoforce_amd import synthetic as syn
+    info, pts, masks, z, mu, ctrl, state, d_max = _cp_case(seed)
+    B = info['B']
+    pts4, _ = syn.robot_points_4()
+    base = make_dphysics(pts4, [pts4[:, 1] > 0, pts4[:, 1] <= 0], info['integ'], info['res'], d_max)
+    res = {}
+    for ppl in (16, 1):
+        dp = make_dphysics(pts4, [pts4[:, 1] > 0, pts4[:, 1] <= 0], info['integ'], info['res'], d_max, points_per_lane=ppl)
+        dp.dphys_cfg.robot_points = torch.as_tensor(pts)
+        dp.dphys_cfg.driving_parts = [torch.as_tensor(m) for m in masks]
+        dp.x_points = dp.dphys_cfg.robot_points.unsqueeze(0).to(dp.device)
+        dp._cache = {('iinv', torch.float32): base._iinv(torch.float32)}      # the 4-point body's inertia for both mappings
+        zl = z.clone().to(DEV).requires_grad_(True)
+        cl = ctrl.clone().to(DEV).requires_grad_(True)
+        ml = None if mu is None else mu.clone().to(DEV).requires_grad_(True)
+        st = None
+        if state is not None:
+            st = [s.clone().to(DEV) for s in state]
+            for s in st[1:]:
+                s.requires_grad_(True)
+        ex = lambda m: None if m is None else (m.expand(B, -1, -1) if info['shared'] and B > 1 else m)  # noqa: E731
+        so, fo = dp(ex(zl), cl, state=None if st is None else tuple(st), friction=ex(ml))
+        outs = list(so) + list(fo)
+        if info['loss'] == 0:
+            loss = hp.probe_loss(outs, torch.float32)
+        elif info['loss'] == 1:
+            loss = (outs[0] * syn.probe_weights(outs[0].shape, phase=0.4).to(DEV)).sum()
+        else:
+            loss = (outs[0] * syn.probe_weights(outs[0].shape, phase=0.4).to(DEV)).sum() + 1e-3 * (outs[4] * syn.probe_weights(outs[4].shape, phase=1.4).to(DEV)).sum()
+        loss.backward()
+        grads = [zl.grad, cl.grad] + ([] if ml is None else [ml.grad]) + ([] if st is None else [s.grad for s in st[1:]])
+        res[ppl] = ([o.detach().cpu() for o in outs], [g.cpu() for g in grads])
+    worst = 0.0
+    for k, a_, b_ in zip(hp.OUT_KEYS, res[16][0], res[1][0]):
+        assert a_.shape == b_.shape and torch.isfinite(a_).all(), (info, k)
+        worst = max(worst, hp.rel_err(a_, b_))
+        assert hp.rel_err(a_, b_) <= 2e-4, (info, k, hp.rel_err(a_, b_))
+    for i, (a_, b_) in enumerate(zip(res[16][1], res[1][1])):
+        scale = float(b_.abs().max())
+        if scale == 0.0:
+            assert float(a_.abs().max()) == 0.0, (info, 'grad', i)
+            continue
+        worst = max(worst, hp.rel_err(a_, b_))
+        assert hp.rel_err(a_, b_) <= 5e-4, (info, 'grad', i, hp.rel_err(a_, b_))
+    return worst
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_random_shape_component_parallel_vs_one_point_per_lane_f32(seed):
+    """The 16-lanes-per-rollout kernels against the one-point-per-lane kernels (themselves held to the oracle above) on random
+    small problems: 1..4 contact points, 1..130 rollouts (partial waves), 1..69 steps (every remainder of the unrolled loops),
+    both integrators, shared or per-rollout maps, friction map or none, given (also off-map) or default start state, and the
+    three kinds of loss the backward is specialised for -- outputs <= 2e-4, every gradient <= 5e-4 (float32 fast math, two
+    summation orders)."""
+    _cp_vs_lanes(seed)
