@@ -202,3 +202,40 @@ def test_camera_plan_equals_geometry_plan(shape):
     assert torch.equal(k1, k2)
     x = torch.randn(B * p_cam.n_per_sample, 8, generator=gen).to(DEV).view(B, -1, 8)
     assert torch.equal(splat.voxel_pooling(None, x, m.dx, m.bx, m.nx, plan=p_cam), splat.voxel_pooling(geom, x, m.dx, m.bx, m.nx, plan=p_geom))
+
+
+def _random_pool_case(seed):
+    """Random pooling problem with points clustered into few voxels (long per-wave point lists, voxel changes anywhere inside the
+    64-point chunks, chunk counts on and off multiples of 64)."""
+    rng = np.random.RandomState(9000 + seed)
+    B = int(rng.randint(1, 4))
+    C = int(rng.choice([1, 3, 16, 63, 64, 65, 100, 130]))
+    nxy, nz = int(rng.randint(5, 71)), int(rng.randint(1, 4))
+    P = int(rng.choice([1, 63, 64, 65, 128, 500, 1500, 4000]))
+    dx = np.array([0.5, 0.5, 1.0], np.float32)
+    bx = np.array([-nxy * 0.25 + 0.25, -nxy * 0.25 + 0.25, -nz * 0.5 + 0.5], np.float32)
+    nx = np.array([nxy, nxy, nz])
+    spread = float(rng.choice([0.02, 0.1, 0.6]))                       # fraction of the plane the points fall into
+    centre = (rng.rand(1, 1, 3).astype(np.float32) - 0.5) * np.array([nxy * 0.3, nxy * 0.3, nz * 0.5], np.float32)
+    geom = centre + (rng.rand(B, P, 3).astype(np.float32) - 0.5) * np.array([nxy * 0.5 * spread, nxy * 0.5 * spread, nz * 1.2], np.float32)
+    if P >= 128:
+        geom[0, :P // 2] = geom[0, 0]                                  # half of sample 0 piled into ONE voxel
+    x = rng.randn(B, P, C)
+    return geom, x, dx, bx, nx, C
+
+
+def _check_random_pool(seed):
+    geom, x, dx, bx, nx, C = _random_pool_case(seed)
+    out, xg = pool(geom, x, dx, bx, nx, requires_grad=True)
+    ref, kept = so.voxel_pooling(geom, x, dx, bx, nx)
+    assert hp.rel_err(out, ref) <= 1e-12, (seed, hp.rel_err(out, ref))
+    gout = np.random.RandomState(seed).randn(*out.shape)
+    out.backward(torch.as_tensor(gout).to(DEV))
+    assert np.array_equal(xg.grad.cpu().numpy(), so.voxel_pooling_grad(geom, gout, dx, bx, nx, C)), seed
+
+
+@pytest.mark.parametrize('seed', range(16))
+def test_random_clustered_pooling_vs_oracle(seed):
+    """float64 pooling of random, clustered point sets vs the exact sums of the oracle (forward <= 1e-12, backward bit-exact):
+    piles of up to 2000 points in one voxel, channel counts around 64, planes that are no multiple of the tile, 1..3 slabs."""
+    _check_random_pool(seed)
