@@ -38,6 +38,7 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
   for (int i = 0; i < 12; ++i) a.joint_xyz[i] = (S)d->joint_xyz[i];
   a.joint_angles = (const S*)p->joint_angles;
   a.gjoint = (S*)p->gjoint_angles;
+  a.rec = nullptr;
   MF_REQUIRE(!p->gjoint_angles || p->joint_angles, MF_ERR_INVALID, "rollout_bwd: gjoint_angles without joint_angles");
   MF_REQUIRE(!d->has_joints == !p->joint_angles, MF_ERR_INVALID, "rollout_bwd: joint_angles must be given exactly when desc->has_joints is set");
   MF_REQUIRE(!p->joint_angles || d->n_tracks == 4, MF_ERR_INVALID, "rollout_bwd: joint angles need the 4 driving parts of robot 'marv'");
@@ -70,9 +71,14 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
   const bool cp = sizeof(S) == 4 && use_component_parallel_bwd(d, p);
   MF_REQUIRE(p->gcontrols || cp, MF_ERR_INVALID, "rollout_bwd: gcontrols may be NULL only where the component-parallel kernels run "
              "(float32 MF_MATH_FAST, N <= 4, default integrator, small batch)");
-  if (cp)   // few rollouts of a small body: a rollout over 16 lanes
+  if (cp) {   // few rollouts of a small body: a rollout over 16 lanes
+    if (p->rec && cp_record_bytes(d) > 0) {      // the forward kept its per-step record: read it instead of recomputing
+      MF_REQUIRE(((uintptr_t)p->rec & 15) == 0, MF_ERR_INVALID, "rollout_bwd: rec must be 16-byte aligned");
+      a.rec = (const S*)p->rec;
+    }
     return launch_rollout_bwd_cp_f32(*reinterpret_cast<const RolloutBwdArgs<float>*>(&a), d->integrator,
                                      p->gXs && !p->gXds && !p->gRs && !p->gOmegas && !p->gFs && !p->gFf, st);
+  }
   const LaneMap m = choose_lane_map(d->B, d->N, d->points_per_lane == MF_LANES_COMPONENT ? 0 : d->points_per_lane);
   if (sizeof(S) == 4 && d->math_mode == MF_MATH_FAST) {
     // accumulator carry-over between adjacent cells (rollout_bwd_kernel.h): ~55 more instructions per step, half the atomics --

@@ -42,11 +42,11 @@ __device__ __forceinline__ float ld1(const float* base, unsigned off) {
 // Also tried and not kept -- a three-stage single-wave pipeline (gathers of step n - 2, the rest of the recompute of step n - 1
 // BESIDE the chain of step n, three register sets, unrolled by three): the same ~350 instructions per step, interleaved by
 // the compiler instead of run one stream after the other, and slower: 0.399 vs 0.367 ms (dynamics(): 0.548 vs 0.448).
-enum { kCpEarly = 0, kCpLate = 1 };
+enum { kCpEarly = 0, kCpLate = 1, kCpSaved = 2 };
 template <int INTEG, bool XS_ONLY, bool GCTRL, int MODE>
 __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
   constexpr bool ODE = INTEG == MF_INTEG_ODEINT_EULER;
-  constexpr bool LATE = MODE == kCpLate;
+  constexpr bool LATE = MODE == kCpLate, SAVED = MODE == kCpSaved;
   using namespace cp;
   using M = Mth<float, true>;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -414,6 +414,70 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
   UpIn uA, uB;
   Rec recA, recB;
   int n = n_steps - 1;
+  if constexpr (SAVED) {
+    // The forward kept its per-step record (rollout_fwd_cp_kernel.h REC): 16 floats per lane and step -- cell index, the gathered
+    // height and friction, footprint weights, normal and 1 / |u|, blended friction, contact weight, 1 / sum of the weights,
+    // A = k dh + d v_n, |F_n|, s . n, the unclamped angular acceleration, 1 / |R[:, 0]| and its square.  What is left of the
+    // recompute is ~35 instructions of 3-vector algebra: no gathers, no cell arithmetic, no transcendentals.
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    struct Saved { f4v q0, q1, q2, q3; };
+    // (a step's slab: four planes of one 16-byte quad per lane -- every load of a wave is one contiguous kilobyte)
+    const char* prec = reinterpret_cast<const char*>(a.rec) + (size_t)tid * 16u;
+    const size_t rec_plane = (size_t)a.B * 16u * 16u, rec_step = 4u * rec_plane;
+    auto load_saved = [&](int m, Saved& v) {
+      const char* o = prec + (size_t)__builtin_amdgcn_readfirstlane((unsigned)m) * rec_step;
+      v.q0 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(o));
+      v.q1 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(o + rec_plane));
+      v.q2 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(o + 2 * rec_plane));
+      v.q3 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(o + 3 * rec_plane));
+    };
+    auto rebuild = [&](const StateIn& st, const Saved& v, Rec& k) {
+      k.R0 = st.R0; k.R1 = st.R1; k.R2 = st.R2; k.w = st.w;
+      k.h = ODE ? st.t1 - st.t0 : a.dt;
+      const float r = P0 * st.R0 + P1 * st.R1 + P2 * st.R2;
+      k.r1 = dpp<kRot1>(r); k.r2 = dpp<kRot2>(r);
+      k.w1 = dpp<kRot1>(st.w); k.w2 = dpp<kRot2>(st.w);
+      k.vp = st.xd + (k.w1 * k.r2 - k.w2 * k.r1);
+      k.idx = __builtin_bit_cast(int, v.q0.x); k.zc = v.q0.y; k.mcv = v.q0.z; k.wa = v.q0.w;
+      k.wb = v.q1.x; k.nrm = v.q1.y; k.inl = v.q1.z; k.mub = v.q1.w;
+      k.cj = v.q2.x; k.inv_csum = v.q2.y; k.A = v.q2.z; k.Nn = v.q2.w;
+      k.sn = v.q3.x; k.wraw = v.q3.y; k.il = v.q3.z; k.coln2 = v.q3.w;
+      k.wq = k.wa * k.wb;
+      k.e = st.R0 * k.il;
+      k.tv = tv_v * st.cv + tv_w * st.cw;
+      k.F0 = -(k.A * k.nrm);
+      k.F1 = k.F0 * k.cj * k.inv_csum;
+      k.Fr = M::clamp(k.F1, -mg, mg);
+      k.cmdv = k.tv * k.e - k.vp;
+      k.s = k.mub * k.cmdv;
+      k.stv = k.s - k.sn * k.nrm;
+      k.Gf = k.Nn * k.stv;
+      const float f = k.Fr + M::clamp(k.Gf, -mg, mg);
+      k.f1 = dpp<kRot1>(f); k.f2 = dpp<kRot2>(f);
+    };
+    Saved vA, vB;
+    // one iteration: the rows, the record and the upstream gradient of step n - 1 are loaded while step n runs
+    auto saved_body = [&](int n, const StateIn& st, const Saved& sv, const UpIn& up, StateIn& st_next, Saved& sv_next, UpIn& up_next) {
+      add_upstream_state(up);
+      load_state(max(n - 1, 0), st_next);
+      load_saved(max(n - 1, 0), sv_next);
+      load_upstream(ODE ? n : max(n - 1, 0), up_next);
+      flush_stash();
+      if constexpr (GCTRL) bstore2(rGctrl, v_ctrl, gctrl_pending, gv_pending, gwc_pending);
+      Rec k;
+      rebuild(st, sv, k);
+      vjp(n, k, up);
+    };
+    load_state(max(n, 0), sA);
+    load_saved(max(n, 0), vA);
+    load_upstream(min(max(n, 0) + (ODE ? 1 : 0), a.T - 1), uA);
+    __builtin_amdgcn_s_waitcnt(0);
+    for (; n >= 1; n -= 2) {
+      saved_body(n, sA, vA, uA, sB, vB, uB);
+      saved_body(n - 1, sB, vB, uB, sA, vA, uA);
+    }
+    if (n == 0) saved_body(0, sA, vA, uA, sB, vB, uB);
+  } else {
   load_state(max(n, 0), sA);
   load_upstream(min(max(n, 0) + (ODE ? 1 : 0), a.T - 1), uA);
   load_state(max(n - 1, 0), sB);
@@ -425,6 +489,7 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
     body(n - 1, recB, recA, sA, sB, uB, uA);
   }
   if (n == 0) body(0, recA, recB, sB, sA, uA, uB);
+  }
   // the upstream gradient of output row 0 sits in the buffer the last iteration prefetched into
   UpIn up = (n_steps & 1) ? uB : uA;
   flush_stash();
@@ -469,6 +534,7 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
 }
 
 bool use_component_parallel_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p);
+long long cp_record_bytes(const MfRolloutDesc* d);      // bytes of the forward's per-step record for this launch shape (0: none)
 int launch_rollout_bwd_cp_f32(const RolloutBwdArgs<float>& a, int integ, bool xs_only, hipStream_t st);   // a.gcontrols may be NULL
 int launch_rollout_bwd_cp_dynamics_f32(const RolloutBwdArgs<float>& a, bool xs_only, hipStream_t st);      // rollout_bwd_dyn_cp_fast.hip
 
@@ -479,10 +545,11 @@ int launch_rollout_bwd_cp_variant(const RolloutBwdArgs<float>& a, bool xs_only, 
   const long long threads = (long long)a.B * 16;
   const unsigned grid = (unsigned)((threads + block - 1) / block);
   const bool gc = a.gcontrols != nullptr;
-  static const int forced = getenv("MF_CP_BWD_MODE") ? atoi(getenv("MF_CP_BWD_MODE")) : -1;      // A/B (tools/ab_cp.py)
-  const int mode = forced >= 0 ? forced : (grid <= 1024u ? kCpLate : kCpEarly);        // at most one wave per SIMD: late recompute
+  static const int forced = getenv("MF_CP_BWD_MODE") ? atoi(getenv("MF_CP_BWD_MODE")) : -1;      // A/B (tools/ab_cp.py): 0 early, 1 late
+  // the forward's record when there is one; else at most one wave per SIMD: late recompute
+  const int mode = a.rec ? kCpSaved : (forced >= 0 && forced != kCpSaved ? forced : (grid <= 1024u ? kCpLate : kCpEarly));
 #define MF_BCP(XS_, GC_, M_) hipLaunchKernelGGL((rollout_bwd_cp_kernel<INTEG, XS_, GC_, M_>), dim3(grid), dim3(block), 0, st, a)
-#define MF_BCP_L(XS_, GC_) do { if (mode == kCpLate) MF_BCP(XS_, GC_, kCpLate); else MF_BCP(XS_, GC_, kCpEarly); } while (0)
+#define MF_BCP_L(XS_, GC_) do { if (mode == kCpSaved) MF_BCP(XS_, GC_, kCpSaved); else if (mode == kCpLate) MF_BCP(XS_, GC_, kCpLate); else MF_BCP(XS_, GC_, kCpEarly); } while (0)
   if (xs_only) { if (gc) MF_BCP_L(true, true); else MF_BCP_L(true, false); }
   else         { if (gc) MF_BCP_L(false, true); else MF_BCP_L(false, false); }
 #undef MF_BCP_L

@@ -30,6 +30,7 @@ struct RolloutBwdArgs {
   const S* joint_angles;   // [B,T,4] flipper angles, or NULL
   S joint_xyz[12];
   S* gjoint;               // [B,T,4] out: gradient of the flipper angles, or NULL
+  const S* rec;            // component-parallel kernels: the forward's per-step record (rollout_fwd_cp_kernel.h), or NULL
 };
 
 #ifdef MF_NO_ATOMICS

@@ -53,6 +53,7 @@ static int fill_args(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutA
   a->cost_rows = (S*)p->cost_rows; a->pose_stride = d->pose_stride > 0 ? d->pose_stride : 1;
   a->path_cost = (S*)p->path_cost;
   a->zmu = nullptr;
+  a->rec = nullptr;
   for (int i = 0; i < 12; ++i) a->joint_xyz[i] = (S)d->joint_xyz[i];
   if (p->joint_angles) {
     MF_REQUIRE(d->n_tracks == 4, MF_ERR_UNSUPPORTED, "rollout_fwd: joint angles need 4 driving parts (fl, fr, rl, rr)");
@@ -129,6 +130,10 @@ extern "C" int mf_rollout_fwd_f32(const MfRolloutDesc* d, const MfRolloutFwdBufs
   if (d->math_mode == MF_MATH_FAST) {
     if (mf::use_component_parallel(d, p)) {   // few rollouts of a small body: a rollout over 16 lanes (rollout_fwd_cp_kernel.h)
       const bool zmu = mf::use_interleaved_maps(d, p, &a, mf::LaneMap{16, 1}, (hipStream_t)s);
+      if (p->rec && mf::cp_record_bytes(d) > 0) {      // the per-step record for the backward (MfRolloutFwdBufs.rec)
+        MF_REQUIRE(((uintptr_t)p->rec & 15) == 0, MF_ERR_INVALID, "rollout_fwd: rec must be 16-byte aligned");
+        a.rec = (float*)p->rec;
+      }
       return mf::launch_rollout_fwd_cp_f32(a, d->integrator, forces, zmu, (hipStream_t)s);
     }
     if (!forces && m.PPL == 4 && m.G < 64) m = mf::choose_lane_map(d->B, d->N, 1);

@@ -31,7 +31,9 @@ int launch_rollout_fwd_cp_f32(const RolloutArgs<float>& a, int integ, bool force
   const int block = 64;   // one wave = 4 rollouts per workgroup: B = 1024 puts one wave on each of the 256 CUs
   const long long threads = (long long)a.B * 16;
   const unsigned grid = (unsigned)((threads + block - 1) / block);
-#define MF_CP(INTEG_, FORCES_, ZMU_) hipLaunchKernelGGL((rollout_fwd_cp_kernel<INTEG_, FORCES_, ZMU_>), dim3(grid), dim3(block), 0, st, a)
+  const bool rec = a.rec != nullptr;
+#define MF_CP(INTEG_, FORCES_, ZMU_) do { if (rec) hipLaunchKernelGGL((rollout_fwd_cp_kernel<INTEG_, FORCES_, ZMU_, true>), dim3(grid), dim3(block), 0, st, a); \
+                                          else hipLaunchKernelGGL((rollout_fwd_cp_kernel<INTEG_, FORCES_, ZMU_, false>), dim3(grid), dim3(block), 0, st, a); } while (0)
 #define MF_CP_F(INTEG_)                                          \
   do {                                                           \
     if (forces) { if (zmu) MF_CP(INTEG_, true, true); else MF_CP(INTEG_, true, false); }    \

@@ -8,7 +8,7 @@
 
 namespace mf {
 
-template <int INTEG, bool FORCES, bool ZMU>
+template <int INTEG, bool FORCES, bool ZMU, bool REC>
 __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<float> a) {
   using namespace cp;
   using M = Mth<float, true>;
@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
   }
 
   // footprint of the point under position component pc: this lane's cell index and weight
-  auto footprint = [&](float pc, int* idx, float* wq) {
+  auto footprint = [&](float pc, int* idx, float* wq, float* owa = nullptr, float* owb = nullptr) {
     const float lim = 262144.0f;
     const float u = M::cell_coord(pc, a.d_max, a.res, a.inv_res);      // lanes 0, 1: ux, uy
     const int ui = (int)M::clamp(u, -lim, lim);                         // trunc toward zero, like .long()
@@ -67,6 +67,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
     *idx = min(max(base + cell_off, 0), last);                          // the reference clamps the FLAT index (:432-435)
     const float wa = fmaf(wa_s, dpp<kB0>(fr), wa_o), wb = fmaf(wb_s, dpp<kB1>(fr), wb_o);   // exact: 1 - f or f
     *wq = wa * wb;
+    if (owa) { *owa = wa; *owb = wb; }
   };
 
   // start at the terrain height: x.z <- mean_i interp(z, (P R^T + x)_i)   (dphysics.py:567-571)
@@ -125,13 +126,13 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
   // (x' = x + h xd, R' = R + h [w]x R use the old xd, w), so its kernels compute the geometry of step n + 1 -- and issue its
   // gathers -- while the contact chain of step n runs: two independent instruction streams in one basic block fill each
   // other's dependency stalls, and a gather has a whole step to arrive.
-  struct Geo { float r, pc, wq, zc, mc, e; };
+  struct Geo { float r, pc, wq, zc, mc, e, wa, wb, il, coln2; int idx; };
   auto geometry = [&](float gx, float g0, float g1, float g2) {
     Geo g;
     g.r = P0 * g0 + P1 * g1 + P2 * g2;               // (:200)
     g.pc = g.r + gx;
-    int idx;
-    footprint(g.pc, &idx, &g.wq);
+    footprint(g.pc, &g.idx, &g.wq, &g.wa, &g.wb);
+    const int idx = g.idx;
     if constexpr (ZMU) {
       const float2 zm = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(a.zmu) + (size_t)((unsigned)idx * 8u));
       g.zc = zm.x; g.mc = zm.y;
@@ -139,22 +140,35 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
       g.zc = ld32(zmap, moff + (unsigned)idx);
       g.mc = ld32(mumap, moff + (unsigned)idx);       // aliases z without a friction map; selected after the blend
     }
-    g.e = g0 * M::inv_len(dot3(g0, g0));              // thrust direction = normalized first column of R (:237)
+    g.coln2 = dot3(g0, g0);
+    g.il = M::inv_len(g.coln2);
+    g.e = g0 * g.il;                                  // thrust direction = normalized first column of R (:237)
     return g;
   };
   // contact model + wrench of one step from its geometry and the state's velocities: (xdd, wd, F_spring, F_friction)
+  // REC: what the backward would otherwise recompute from the saved state -- the two gathered cells and their footprint weights,
+  // the normal, the contact weight, the normal-force and slip scalars, the unclamped angular acceleration: 16 floats per lane
+  // and step, four 16-byte stores here, four 16-byte loads there, against ~100 instructions, 7 transcendentals and the two
+  // gathers of the recompute (rollout_bwd_cp_kernel.h).  A step's slab is four planes of one 16-byte quad per lane,
+  // [4][B * 16 lanes][4 floats]: each of the four stores of a wave is one contiguous kilobyte (with the 16 floats of a lane
+  // side by side a store touched 64 separate 64-byte segments and the forward went from 0.17 to 0.48 ms at B = 1024).
+  char* pRec = reinterpret_cast<char*>(a.rec);
+  const unsigned rec_lane = (unsigned)tid * 16u;
+  const size_t rec_plane = (size_t)a.B * 16u * 16u, rec_step = 4u * rec_plane;
   auto contact = [&](const Geo& g, float vxd, float vw, float tv, float* xdd, float* wd, float* oFr, float* oFf) {
     const float vp = vxd + unrot(cross_pre(vw, g.r));                  // v_p = xd + w x r   (:204)
     const float zq = dot4(g.wq, g.zc);                               // height under the point (:211)
     const float mub = dot4(g.wq, has_mu ? g.mc : one);             // friction (:216); no map = a map of ones (:562)
     const float dz = g.zc - dpp<kB0>(g.zc);                           // lane 1: z_f - z_c, lane 2: z_l - z_c
     const float u = fmaf(dpp<kN12>(dz), n_mul, n_add);                // (-gx, -gy, 1)
-    const float nrm = u * M::inv_len(dot3(u, u));
+    const float inl = M::inv_len(dot3(u, u));
+    const float nrm = u * inl;
     const float dh = dpp<kB2>(g.pc) - zq;                             // soft contact + spring-damper along the normal (:220-230)
     float cj = M::sigmoid_m10(dh);
     cj = act ? cj : zero;
     const float csum = sum_points(cj);                                // n_contact_pts (:231)
-    const float cjn = cj * M::div(one, csum);
+    const float inv_csum = M::div(one, csum);
+    const float cjn = cj * inv_csum;
     const float vn = dot3(vp, nrm);
     const float A = a.k * dh + a.damp * vn;
     const float Fr = M::clamp(-(A * nrm) * cjn, -a.mg, a.mg);         // (:232-233)
@@ -166,9 +180,19 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
     const float tau = unrot(cross_pre(g.r, f));                        // r x (Fs + Ff)   (:255)
     const float Fsum = sum_points(f), Tsum = sum_points(tau);
     // omega_d = clamp(I^-1 tau)   (:256-257); xdd = (m g ghat + sum F) / m   (:264-266)
-    *wd = M::clamp(I0 * dpp<kB0>(Tsum) + I1 * dpp<kB1>(Tsum) + I2 * dpp<kB2>(Tsum), -a.omega_max, a.omega_max);
+    const float wraw = I0 * dpp<kB0>(Tsum) + I1 * dpp<kB1>(Tsum) + I2 * dpp<kB2>(Tsum);
+    *wd = M::clamp(wraw, -a.omega_max, a.omega_max);
     *xdd = Fsum * a.inv_mass - grav_c;
     *oFr = Fr; *oFf = Ff;
+    if constexpr (REC) {
+      typedef float f4v __attribute__((ext_vector_type(4)));
+      char* o = pRec + rec_lane;
+      __builtin_nontemporal_store(f4v{__builtin_bit_cast(float, g.idx), g.zc, has_mu ? g.mc : one, g.wa}, reinterpret_cast<f4v*>(o));
+      __builtin_nontemporal_store(f4v{g.wb, nrm, inl, mub}, reinterpret_cast<f4v*>(o + rec_plane));
+      __builtin_nontemporal_store(f4v{cj, inv_csum, A, Nn}, reinterpret_cast<f4v*>(o + 2 * rec_plane));
+      __builtin_nontemporal_store(f4v{sn, wraw, g.il, g.coln2}, reinterpret_cast<f4v*>(o + 3 * rec_plane));
+      pRec += rec_step;
+    }
   };
 
   if constexpr (INTEG == MF_INTEG_ODEINT_EULER) {
@@ -255,6 +279,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
 // true when the component-parallel kernels cover this launch: float32 fast math, a rigid body of <= 4 points, full outputs
 // (or states only), and few enough rollouts that the launch is bound by the instruction stream of its waves
 bool use_component_parallel(const MfRolloutDesc* d, const MfRolloutFwdBufs* p);
-int launch_rollout_fwd_cp_f32(const RolloutArgs<float>& a, int integ, bool forces, bool zmu, hipStream_t st);
+int launch_rollout_fwd_cp_f32(const RolloutArgs<float>& a, int integ, bool forces, bool zmu, hipStream_t st);   // a.rec: record wanted
+long long cp_record_bytes(const MfRolloutDesc* d);      // bytes of the per-step record a launch of this shape writes (0: none)
 
 }  // namespace mf

@@ -169,13 +169,20 @@ class _RolloutFn(torch.autograd.Function):
         Xs, Xds, Rs, Om = new(3), new(3), new(3, 3), new(3)
         Fs, Ff = (new(Np, 3), new(Np, 3)) if want_forces else (None, None)
         Xraw = new(3) if want_grad else None
+        # the per-step record of the component-parallel kernels (MfRolloutFwdBufs.rec): kept for the backward where the library
+        # says it pays (few rollouts of a small body), 1 KiB per rollout and step
+        rec = None
+        if want_grad and dt == torch.float32 and joint_angles is None:
+            nbytes = int(_lib.lib().mf_rollout_record_bytes(C.byref(desc)))
+            if nbytes > 0:
+                rec = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
         bufs = _lib.MfRolloutFwdBufs(
             z=_lib.ptr(keep['z']), mu=_lib.ptr(keep['mu']), controls=_lib.ptr(controls), ts=_lib.ptr(ts),
             points=_lib.ptr(keep['points']), part=_lib.ptr(mod._part_dev(dev)),
             x0=_lib.ptr(x0), xd0=_lib.ptr(xd0), R0=_lib.ptr(R0), w0=_lib.ptr(w0),
             Xs=_lib.ptr(Xs), Xds=_lib.ptr(Xds), Rs=_lib.ptr(Rs), Omegas=_lib.ptr(Om), Fs=_lib.ptr(Fs), Ff=_lib.ptr(Ff),
             Xraw=_lib.ptr(Xraw), joint_angles=_lib.ptr(joint_angles),
-            zmu_scratch=_lib.ptr(_zmu_scratch(mod, desc, keep['z'])), zmu=_lib.ptr(mod._staged_zmu(desc, z, mu)))
+            zmu_scratch=_lib.ptr(_zmu_scratch(mod, desc, keep['z'])), zmu=_lib.ptr(mod._staged_zmu(desc, z, mu)), rec=_lib.ptr(rec))
         fn = getattr(_lib.lib(), 'mf_rollout_fwd_' + _scalar_suffix(dt))
         with torch.cuda.device(dev), _timing.timed('rollout_fwd_kernel', dev):
             _lib.check(fn(C.byref(desc), C.byref(bufs), _stream_ptr(dev)), 'mf_rollout_fwd')
@@ -191,6 +198,7 @@ class _RolloutFn(torch.autograd.Function):
             ctx.z_expanded = z.stride(0) == 0 and z.shape[0] > 1
             ctx.mu_expanded = mu is not None and mu.stride(0) == 0 and mu.shape[0] > 1
             ctx.joint_angles = joint_angles.detach() if joint_angles is not None else None
+            ctx.rec = rec
             # x0 now holds the snapped start position; a caller-visible buffer is copied, the module's own default is not
             ctx.save_for_backward(controls, x0 if x0_private else x0.clone(), xd0, R0, w0, ts, Xraw, Xds, Rs, Om)
         return outs

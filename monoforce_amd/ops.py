@@ -4,10 +4,11 @@ Schemas (tensors on the GPU, float32 or float64; `Bz` in {1, B}: a [1,H,W] map i
 
     monoforce::dphys_rollout_fwd(Tensor z, Tensor? mu, Tensor controls, Tensor x0, Tensor xd0, Tensor R0, Tensor w0,
                                  Tensor pts, Tensor part_id, Tensor Iinv, float[] consts, int integrator, bool save_for_bwd)
-                                 -> (Tensor Xs, Tensor Xds, Tensor Rs, Tensor Om, Tensor Fs, Tensor Ff, Tensor Xraw, Tensor x0_snapped)
+                                 -> (Tensor Xs, Tensor Xds, Tensor Rs, Tensor Om, Tensor Fs, Tensor Ff, Tensor Xraw, Tensor x0_snapped,
+                                     Tensor rec)
     monoforce::dphys_rollout_bwd(Tensor z, Tensor? mu, Tensor controls, Tensor x_init, Tensor xd0, Tensor R0, Tensor w0,
                                  Tensor pts, Tensor part_id, Tensor Iinv, float[] consts, int integrator,
-                                 Tensor Xraw, Tensor Xds, Tensor Rs, Tensor Om,
+                                 Tensor Xraw, Tensor Xds, Tensor Rs, Tensor Om, Tensor rec,
                                  Tensor? gXs, Tensor? gXds, Tensor? gRs, Tensor? gOm, Tensor? gFs, Tensor? gFf)
                                  -> (Tensor gz, Tensor gmu, Tensor gcontrols, Tensor gx0, Tensor gxd0, Tensor gR0, Tensor gw0)
     monoforce::bev_splat_plan(Tensor geom, float[] dx, float[] bx, int[] nx) -> Tensor plan
@@ -21,7 +22,8 @@ its z component moved onto the terrain (dphysics.py:567-571, an in-place write i
 and `rollout()` below copies it into the caller's tensor.  Outputs are `[B,T,...]` views of time-major buffers, like
 `DPhysics.forward`.  Every op is one or two launches of the C ABI (include/monoforce_hip.h) on
 the current stream; no synchronisation, no host round trip, so they can be captured into a hipGraph.  Autograd formulas are
-registered (`rollout_fwd` -> `rollout_bwd`, `bev_splat_fwd` -> `bev_splat_bwd`), as are shape functions for tracing.
+registered (`rollout_fwd` -> `rollout_bwd`, `bev_splat_fwd` -> `bev_splat_bwd`), as are shape functions for tracing.  `rec` is
+the per-step record small launches keep for the backward (MfRolloutFwdBufs.rec; empty otherwise).
 
 `DPhysics` itself keeps calling the C ABI through its own autograd function (monoforce_amd/dphysics.py) -- same library calls,
 more options (articulated bodies, path costs, strided controls); `rollout()` / `splat()` below are the functional entries.
@@ -46,9 +48,9 @@ CONST_NAMES = ('mass', 'gravity', 'stiffness', 'damping', 'grid_res', 'd_max', '
 
 _L = torch.library.Library('monoforce', 'DEF')
 _L.define('dphys_rollout_fwd(Tensor z, Tensor? mu, Tensor controls, Tensor x0, Tensor xd0, Tensor R0, Tensor w0, Tensor pts, '
-          'Tensor part_id, Tensor Iinv, float[] consts, int integrator, bool save_for_bwd) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)')
+          'Tensor part_id, Tensor Iinv, float[] consts, int integrator, bool save_for_bwd) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)')
 _L.define('dphys_rollout_bwd(Tensor z, Tensor? mu, Tensor controls, Tensor x_init, Tensor xd0, Tensor R0, Tensor w0, Tensor pts, '
-          'Tensor part_id, Tensor Iinv, float[] consts, int integrator, Tensor Xraw, Tensor Xds, Tensor Rs, Tensor Om, '
+          'Tensor part_id, Tensor Iinv, float[] consts, int integrator, Tensor Xraw, Tensor Xds, Tensor Rs, Tensor Om, Tensor rec, '
           'Tensor? gXs, Tensor? gXds, Tensor? gRs, Tensor? gOm, Tensor? gFs, Tensor? gFf) -> (Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)')
 _L.define('bev_splat_plan(Tensor geom, float[] dx, float[] bx, int[] nx) -> Tensor')
 _L.define('bev_splat_fwd(Tensor x, Tensor plan, int B, int n_per_sample, float[] dx, float[] bx, int[] nx) -> Tensor')
@@ -114,19 +116,23 @@ def _rollout_fwd(z, mu, controls, x0, xd0, R0, w0, pts, part_id, Iinv, consts, i
     new = lambda *tail: torch.empty(T, B, *tail, dtype=dt, device=dev)  # noqa: E731
     Xs, Xds, Rs, Om, Fs, Ff = new(3), new(3), new(3, 3), new(3), new(Np, 3), new(Np, 3)
     Xraw = new(3) if save_for_bwd else torch.empty(0, dtype=dt, device=dev)
+    # the component-parallel kernels' per-step record for the backward (MfRolloutFwdBufs.rec), where the library keeps one
+    nrec = int(_lib.lib().mf_rollout_record_bytes(C.byref(d))) // 4 if (save_for_bwd and dt == torch.float32) else 0
+    rec = torch.empty(nrec, dtype=dt, device=dev)
     ts = _time_grid(consts, T, dt, dev)
     bufs = _lib.MfRolloutFwdBufs(z=_lib.ptr(zc), mu=_lib.ptr(muc), controls=_lib.ptr(cc), ts=_lib.ptr(ts), points=_lib.ptr(pc),
                                  part=_lib.ptr(part), x0=_lib.ptr(x0), xd0=_lib.ptr(xd0.to(dt).contiguous()), R0=_lib.ptr(R0.to(dt).contiguous()),
                                  w0=_lib.ptr(w0.to(dt).contiguous()), Xs=_lib.ptr(Xs), Xds=_lib.ptr(Xds), Rs=_lib.ptr(Rs), Omegas=_lib.ptr(Om),
-                                 Fs=_lib.ptr(Fs), Ff=_lib.ptr(Ff), Xraw=_lib.ptr(Xraw) if save_for_bwd else None)
+                                 Fs=_lib.ptr(Fs), Ff=_lib.ptr(Ff), Xraw=_lib.ptr(Xraw) if save_for_bwd else None,
+                                 rec=_lib.ptr(rec) if nrec else None)
     with torch.cuda.device(dev), _timing.timed('rollout_fwd_kernel', dev):
         _lib.check(getattr(_lib.lib(), 'mf_rollout_fwd_' + _sfx(dt))(C.byref(d), C.byref(bufs), _stream(dev)), 'mf_rollout_fwd')
     tr = lambda t: t.transpose(0, 1)  # noqa: E731
-    return tr(Xs), tr(Xds), tr(Rs), tr(Om), tr(Fs[:, :, :N]), tr(Ff[:, :, :N]), (tr(Xraw) if save_for_bwd else Xraw), x0
+    return tr(Xs), tr(Xds), tr(Rs), tr(Om), tr(Fs[:, :, :N]), tr(Ff[:, :, :N]), (tr(Xraw) if save_for_bwd else Xraw), x0, rec
 
 
 @torch.library.impl(_L, 'dphys_rollout_bwd', 'CUDA')
-def _rollout_bwd(z, mu, controls, x_init, xd0, R0, w0, pts, part_id, Iinv, consts, integrator, Xraw, Xds, Rs, Om, gXs, gXds, gRs, gOm, gFs, gFf):
+def _rollout_bwd(z, mu, controls, x_init, xd0, R0, w0, pts, part_id, Iinv, consts, integrator, Xraw, Xds, Rs, Om, rec, gXs, gXds, gRs, gOm, gFs, gFf):
     dev, dt = z.device, z.dtype
     zc, muc, cc, pc, part = _prep(z, mu, controls, pts, part_id)
     d = _rollout_desc(zc, cc, pc, Iinv, consts, integrator)
@@ -156,7 +162,7 @@ def _rollout_bwd(z, mu, controls, x_init, xd0, R0, w0, pts, part_id, Iinv, const
         w0=_lib.ptr(w0.to(dt).contiguous()), Xraw=_lib.ptr(saved[0]), Xds=_lib.ptr(saved[1]), Rs=_lib.ptr(saved[2]), Omegas=_lib.ptr(saved[3]),
         gXs=_lib.ptr(ups[0]), gXds=_lib.ptr(ups[1]), gRs=_lib.ptr(ups[2]), gOmegas=_lib.ptr(ups[3]), gFs=_lib.ptr(ups[4]), gFf=_lib.ptr(ups[5]),
         zeros=_lib.ptr(zero_row), gz=_lib.ptr(gz), gmu=_lib.ptr(gmu), gcontrols=_lib.ptr(gcontrols), gx0=_lib.ptr(gx0), gxd0=_lib.ptr(gxd0),
-        gR0=_lib.ptr(gR0), gw0=_lib.ptr(gw0))
+        gR0=_lib.ptr(gR0), gw0=_lib.ptr(gw0), rec=_lib.ptr(rec) if rec.numel() else None)
     with torch.cuda.device(dev), _timing.timed('rollout_bwd_kernel', dev):
         _lib.check(getattr(_lib.lib(), 'mf_rollout_bwd_' + _sfx(dt))(C.byref(d), C.byref(bufs), _stream(dev)), 'mf_rollout_bwd')
     if d.map_shared:
@@ -175,17 +181,17 @@ def _rollout_setup(ctx, inputs, output):
         ctx.ok = False
         return
     ctx.ok = True
-    Xs, Xds, Rs, Om, Fs, Ff, Xraw, x0s = output
-    ctx.save_for_backward(z, mu, controls, x0s, xd0, R0, w0, pts, part_id, Iinv, Xraw, Xds, Rs, Om)
+    Xs, Xds, Rs, Om, Fs, Ff, Xraw, x0s, rec = output
+    ctx.save_for_backward(z, mu, controls, x0s, xd0, R0, w0, pts, part_id, Iinv, Xraw, Xds, Rs, Om, rec)
     ctx.set_materialize_grads(False)
 
 
-def _rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf, _gXraw, _gx0s):
+def _rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf, _gXraw, _gx0s, _grec):
     if not ctx.ok:
         raise RuntimeError('monoforce::dphys_rollout_fwd was called with save_for_bwd=False: no gradient available')
-    z, mu, controls, x_init, xd0, R0, w0, pts, part_id, Iinv, Xraw, Xds, Rs, Om = ctx.saved_tensors
+    z, mu, controls, x_init, xd0, R0, w0, pts, part_id, Iinv, Xraw, Xds, Rs, Om, rec = ctx.saved_tensors
     gz, gmu, gc, gx0, gxd0, gR0, gw0 = torch.ops.monoforce.dphys_rollout_bwd(
-        z, mu, controls, x_init, xd0, R0, w0, pts, part_id, Iinv, ctx.consts, ctx.integrator, Xraw, Xds, Rs, Om, gXs, gXds, gRs, gOm, gFs, gFf)
+        z, mu, controls, x_init, xd0, R0, w0, pts, part_id, Iinv, ctx.consts, ctx.integrator, Xraw, Xds, Rs, Om, rec, gXs, gXds, gRs, gOm, gFs, gFf)
     return gz, (gmu if ctx.has_mu else None), gc, gx0, gxd0, gR0, gw0, None, None, None, None, None, None
 
 
@@ -197,11 +203,11 @@ def _rollout_fwd_fake(z, mu, controls, x0, xd0, R0, w0, pts, part_id, Iinv, cons
     B, T = controls.shape[:2]
     N = pts.shape[0]
     e = lambda *s: z.new_empty(s)  # noqa: E731
-    return e(B, T, 3), e(B, T, 3), e(B, T, 3, 3), e(B, T, 3), e(B, T, N, 3), e(B, T, N, 3), (e(B, T, 3) if save_for_bwd else e(0)), e(B, 3)
+    return e(B, T, 3), e(B, T, 3), e(B, T, 3, 3), e(B, T, 3), e(B, T, N, 3), e(B, T, N, 3), (e(B, T, 3) if save_for_bwd else e(0)), e(B, 3), e(0)
 
 
 @torch.library.register_fake('monoforce::dphys_rollout_bwd', lib=_L)
-def _rollout_bwd_fake(z, mu, controls, x_init, xd0, R0, w0, pts, part_id, Iinv, consts, integrator, Xraw, Xds, Rs, Om, gXs, gXds, gRs, gOm, gFs, gFf):
+def _rollout_bwd_fake(z, mu, controls, x_init, xd0, R0, w0, pts, part_id, Iinv, consts, integrator, Xraw, Xds, Rs, Om, rec, gXs, gXds, gRs, gOm, gFs, gFf):
     B = controls.shape[0]
     return (torch.empty_like(z), torch.empty_like(mu) if mu is not None else z.new_empty(0), torch.empty_like(controls), z.new_empty(B, 3),
             z.new_empty(B, 3), z.new_empty(B, 3, 3), z.new_empty(B, 3))

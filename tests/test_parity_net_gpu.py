@@ -425,3 +425,58 @@ def test_dynamics_rodrigues_step_of_a_fast_spinning_body(ppl):
         assert hp.rel_err(Rs[b], rR[b]) <= 2e-5, (b, hp.rel_err(Rs[b], rR[b]))
         assert hp.rel_err(Xs[b], rX[b]) <= 1e-4, (b, hp.rel_err(Xs[b], rX[b]))
     assert hp.rel_err(zd.grad, zc.grad) <= 2e-4, hp.rel_err(zd.grad, zc.grad)
+
+
+_NO_RECORD = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from tests.test_parity_net_gpu import _record_case
+torch.save(_record_case(), %r)
+'''
+
+
+def _record_case():
+    from monoforce_amd import synthetic as syn
+    pts, masks = syn.robot_points_4()
+    B, T = 37, 90
+    z = syn.bump_terrain(syn.bump_params(61), 6.4, 0.05) * 0.8
+    mu = syn.wave_friction(6.4, 0.05, 0.5, 1.0, 1.3, 0.9)
+    ctrl = syn.varying_controls(B, T, seed=9)
+    dp = make_dphysics(pts, masks, 1, 0.05, 6.4)
+    zd, md, cd = z.to(DEV).requires_grad_(True), mu.to(DEV).requires_grad_(True), ctrl.to(DEV).requires_grad_(True)
+    st, fo = dp(zd.unsqueeze(0), cd, friction=md.unsqueeze(0))
+    outs = list(st) + list(fo)
+    hp.probe_loss(outs, torch.float32).backward()
+    return dict(outs=[o.detach().cpu() for o in outs], gz=zd.grad.cpu(), gmu=md.grad.cpu(), gc=cd.grad.cpu())
+
+
+def test_backward_from_the_forward_record_equals_the_recomputing_backward():
+    """Small launches of the default integrator keep a per-step record in the forward (MfRolloutFwdBufs.rec) and the backward
+    reads it instead of recomputing (the default here); a child process with MF_CP_RECORD_MAX_WAVES=0 runs the same problem
+    through the recomputing backward: same outputs bit for bit (the record changes no arithmetic of the forward), gradients to
+    float32 rounding, and both within the usual bar of the float64 oracle."""
+    import os, subprocess, sys, tempfile
+    from oracle import dphysics_oracle as orc  # noqa: F401
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with_rec = _record_case()
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, 'norec.pt')
+        env = dict(os.environ, MF_CP_RECORD_MAX_WAVES='0')
+        r = subprocess.run([sys.executable, '-c', _NO_RECORD % (repo, path)], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        without = torch.load(path)
+    for a_, b_ in zip(with_rec['outs'], without['outs']):
+        assert torch.equal(a_, b_)
+    for k in ('gz', 'gmu', 'gc'):
+        assert hp.rel_err(with_rec[k], without[k]) <= 2e-5, (k, hp.rel_err(with_rec[k], without[k]))
+    # ... and the recorded route against the oracle
+    from monoforce_amd import synthetic as syn
+    pts, masks = syn.robot_points_4()
+    B, T = 37, 90
+    z = (syn.bump_terrain(syn.bump_params(61), 6.4, 0.05) * 0.8).double().requires_grad_(True)
+    mu = syn.wave_friction(6.4, 0.05, 0.5, 1.0, 1.3, 0.9).double().requires_grad_(True)
+    ctrl = syn.varying_controls(B, T, seed=9).double().requires_grad_(True)
+    spec = hp.spec_from(pts, masks, 1, 0.05, 6.4)
+    rs, rf = orc.rollout(spec, z.unsqueeze(0).expand(B, -1, -1), ctrl, friction=mu.unsqueeze(0).expand(B, -1, -1))
+    hp.probe_loss(list(rs) + list(rf), torch.float64).backward()
+    assert hp.rel_err(with_rec['gz'], z.grad) <= 2e-4 and hp.rel_err(with_rec['gmu'], mu.grad) <= 2e-4 and hp.rel_err(with_rec['gc'], ctrl.grad) <= 2e-4
