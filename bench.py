@@ -323,6 +323,15 @@ class Runner:
         integ = 'odeint-euler (reference default)' if args.integrator == 1 else 'dynamics()'
         H = int(round(12.8 / res))
         traffic = self.traffic.get(name, {}).get(dom)
+        # the per-step record small default-integrator launches keep in the forward for the backward (MfRolloutFwdBufs.rec): real
+        # bytes on top of the algorithmic ones -- a recompute-for-storage trade, reported so that `traffic` reads right
+        rec_bytes = 0
+        if wl['backward'] and not wl.get('encoder'):
+            import ctypes as C
+            from monoforce_amd import _lib
+            d = _lib.MfRolloutDesc(B=B, T=T, N=N, H=int(round(12.8 / res)), W=int(round(12.8 / res)), integrator=args.integrator,
+                                   math_mode=_lib.MF_MATH_FAST, force_stride=max(N, 4), map_shared=1, layout=_lib.MF_LAYOUT_TIME_MAJOR)
+            rec_bytes = int(_lib.lib().mf_rollout_record_bytes(C.byref(d)))
         out = {
             'value': B_total * T * steps / elapsed, 'steps': steps, 'warmup': warmup, 'ms_per_step': elapsed / steps * 1e3,
             'scaling': 'strong' if strong else 'weak',
@@ -332,6 +341,9 @@ class Runner:
                        'parallelism': f'rollout-sharded x{world}', **({'launch': launch} if launch else {})},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic,
+                         **({'record_bytes_per_launch': rec_bytes,
+                             'traffic_note': 'traffic includes the per-step record the forward writes and the backward reads instead of '
+                                             'recomputing it (record_bytes_per_launch; DESIGN.md 4.2b) -- not re-reads'} if rec_bytes else {}),
                          'traffic_source': 'profiles/hbm_traffic.json (rocprofv3 PMC passes of this command, static -- not re-measured in this run)' if traffic else None,
                          'kernel': dom, 'kernel_ms': kern[dom], 'kernel_ms_from': f'HIP events around the launches of every {EVENT_EVERY}th timed step',
                          'algorithmic_bytes_per_launch': alg[dom], 'bytes_per_rollout_step': alg[dom] // (B * T),
