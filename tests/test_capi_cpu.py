@@ -64,6 +64,28 @@ def test_force_stride_query(built_lib):
     assert q(B=8, N=300) == 512 and q(B=0, N=4) == -1 and q(B=1, N=513) == -1
 
 
+def test_record_bytes_query(built_lib):
+    """`mf_rollout_record_bytes` is a host-side policy: 1 KiB per rollout and step where both directions run component-parallel
+    with the default integrator and at most 256 waves; 0 everywhere else (the caller then passes rec = NULL)."""
+    import ctypes as C
+    from monoforce_amd import _lib
+    built_lib.mf_rollout_record_bytes.restype = C.c_longlong
+
+    def q(**kw):
+        d = dict(B=1024, T=500, N=4, H=256, W=256, integrator=1, math_mode=_lib.MF_MATH_FAST, force_stride=4, map_shared=1,
+                 layout=_lib.MF_LAYOUT_TIME_MAJOR)
+        d.update(kw)
+        return int(built_lib.mf_rollout_record_bytes(C.byref(_lib.MfRolloutDesc(**d))))
+    assert q() == 1024 * 500 * 1024
+    assert q(B=1, T=200) == 200 * 1024
+    assert q(B=3, T=7, N=2) == 3 * 7 * 1024                  # per-lane slabs: absent contact points included
+    assert q(B=1025) == 0 and q(B=2048) == 0                 # more than 256 waves: the forward would be bound by the record's stores
+    assert q(integrator=0) == 0                              # dynamics(): measured, no gain
+    assert q(N=5, force_stride=5) == 0 and q(math_mode=_lib.MF_MATH_EXACT) == 0 and q(has_joints=1) == 0
+    assert q(points_per_lane=1) == 0                         # an explicit other lane mapping
+    assert int(built_lib.mf_rollout_record_bytes(None)) == 0
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from monoforce_amd import _lib
     monkeypatch.setattr(_lib, '_lib', None)
