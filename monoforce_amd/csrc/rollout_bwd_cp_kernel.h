@@ -13,6 +13,7 @@
 #pragma once
 #include "rollout_bwd_kernel.h"
 #include "rollout_cp_common.h"
+#include <type_traits>
 
 namespace mf {
 
@@ -456,6 +457,71 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
       k.f1 = dpp<kRot1>(f); k.f2 = dpp<kRot2>(f);
     };
     Saved vA, vB;
+    if constexpr (ODE) {
+      // Addresses: constant scalar bases + RUNNING 32-bit per-lane byte offsets, one vector subtract per array and step.  (With
+      // a wave-uniform step offset added to a scalar base the compiler formed 64-bit addresses with ~10 vector adds and ~25
+      // scalar multiplies / adds per step -- scalar instructions take a full issue slot when a SIMD holds one wave.)  The offsets
+      // point at the rows of the step being REQUESTED; the last iteration requests nothing but the upstream row 0.
+      const unsigned un = (unsigned)max(n, 0);
+      unsigned o3 = v3 + un * s3, o9 = v9 + un * s9, oc = v_ctrl + un * 8u, orc = un * (unsigned)rec_step;
+      unsigned og_xs = u_xs + (un + 1u) * sg_xs, og_xds = u_xds + (un + 1u) * sg_xds, og_om = u_om + (un + 1u) * sg_om;
+      unsigned og_r = u_r + (un + 1u) * sg_r, og_fs = u_fs + (un + 1u) * sg_fs, og_ff = u_ff + (un + 1u) * sg_ff;
+      const char* const prec1 = prec + rec_plane;
+      const char* const prec2 = prec + 2 * rec_plane;
+      const char* const prec3 = prec + 3 * rec_plane;
+      int ti = max(n, 0);                        // index of the lower time stamp of the requested step
+      float t_hi = a.ts[min(ti + 1, a.T - 1)];
+      auto request_state = [&](StateIn& d, Saved& v) {      // rows + record of the step the offsets point at
+        d.x = zero;                                            // (positions are not needed: the record replaces what used them)
+        d.xd = bload1(rXds, o3, 0u); d.w = bload1(rOm, o3, 0u);
+        bload3(rRs, o9, 0u, &d.R0, &d.R1, &d.R2);
+        bload2(rCtrl, oc, 0u, &d.cv, &d.cw);
+        d.t1 = t_hi; d.t0 = a.ts[ti]; t_hi = d.t0;
+        v.q0 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(prec + (size_t)orc));
+        v.q1 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(prec1 + (size_t)orc));
+        v.q2 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(prec2 + (size_t)orc));
+        v.q3 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(prec3 + (size_t)orc));
+      };
+      auto request_up = [&](UpIn& u) {                       // upstream gradients of the row that step produced
+        u.gXs = bload1(rgXs, og_xs, 0u);
+        if constexpr (!XS_ONLY) {
+          u.gXds = bload1(rgXds, og_xds, 0u); u.gOm = bload1(rgOm, og_om, 0u);
+          bload3(rgRs, og_r, 0u, &u.gR0, &u.gR1, &u.gR2);
+          u.gFs = bload1(rgFs, og_fs, 0u); u.gFf = bload1(rgFf, og_ff, 0u);
+        }
+      };
+      auto step_back_up = [&]() {
+        og_xs -= sg_xs;
+        if constexpr (!XS_ONLY) { og_xds -= sg_xds; og_om -= sg_om; og_r -= sg_r; og_fs -= sg_fs; og_ff -= sg_ff; }
+      };
+      auto run = [&](int n, const StateIn& st, const Saved& sv, const UpIn& up, StateIn& st_next, Saved& sv_next, UpIn& up_next, auto more) {
+        add_upstream_state(up);
+        step_back_up();
+        if constexpr (decltype(more)::value) {          // n >= 1: the rows and the record of step n - 1 ...
+          o3 -= s3; o9 -= s9; oc -= 8u; orc -= (unsigned)rec_step; --ti;
+          request_state(st_next, sv_next);
+        }
+        request_up(up_next);                            // ... and the upstream gradient of the row it produced (n = 0: row 0 itself)
+        flush_stash();
+        if constexpr (GCTRL) bstore2(rGctrl, v_ctrl, gctrl_pending, gv_pending, gwc_pending);
+        Rec k;
+        rebuild(st, sv, k);
+        vjp(n, k, up);
+      };
+      using std::true_type;
+      using std::false_type;
+      if (n_steps > 0) {
+        request_state(sA, vA);
+        request_up(uA);
+        __builtin_amdgcn_s_waitcnt(0);
+        for (; n >= 2; n -= 2) {
+          run(n, sA, vA, uA, sB, vB, uB, true_type{});
+          run(n - 1, sB, vB, uB, sA, vA, uA, true_type{});
+        }
+        if (n == 1) { run(1, sA, vA, uA, sB, vB, uB, true_type{}); run(0, sB, vB, uB, sA, vA, uA, false_type{}); }
+        else run(0, sA, vA, uA, sB, vB, uB, false_type{});
+      }
+    } else {
     // one iteration: the rows, the record and the upstream gradient of step n - 1 are loaded while step n runs
     auto saved_body = [&](int n, const StateIn& st, const Saved& sv, const UpIn& up, StateIn& st_next, Saved& sv_next, UpIn& up_next) {
       add_upstream_state(up);
@@ -477,6 +543,7 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
       saved_body(n - 1, sB, vB, uB, sA, vA, uA);
     }
     if (n == 0) saved_body(0, sA, vA, uA, sB, vB, uB);
+    }
   } else {
   load_state(max(n, 0), sA);
   load_upstream(min(max(n, 0) + (ODE ? 1 : 0), a.T - 1), uA);

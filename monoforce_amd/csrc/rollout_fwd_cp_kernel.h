@@ -108,12 +108,12 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
     const float vx = fmaf(e2, sink_l, ex);          // Xs += Rs[..., :, 2] * m g / (k + 1e-6)   (dphysics.py:587-589)
     const float v3 = mask_or(mask_or(mask_or(zero, vx, m_x), exd, m_xd), ew, m_w);
     __builtin_nontemporal_store(v3, reinterpret_cast<float*>(p3));
-    // (the per-lane offsets are laundered through an empty asm: a loop-invariant zero-extension would be hoisted out of the
-    // loop and the address then formed by a 64-bit vector add per store instead of the scalar-base + 32-bit-offset mode)
-    asm volatile("" : "+v"(o9), "+v"(ofs), "+v"(off));      // in place: no copies, the registers just look loop-variant
+    // (scalar base + RUNNING 32-bit per-lane offset: the step's advance is one vector add per array.  A scalar running pointer
+    // costs s_add + s_addc, and scalar instructions take a full issue slot when a SIMD holds one wave: 22 of them per step were
+    // 11 % of the forward, tools/pmc_groups.sh)
     bstore3(pRs, o9, 0u, e0, e1, e2);               // row cc of R: one 12-byte store (all quads, same address, same value)
     if (FORCES) { bstore1(pFs, ofs, 0u, oFs); bstore1(pFf, off, 0u, oFf); }
-    if (adv) { p3 += d3; pRs += d9; pFs += df; pFf += df; }
+    if (adv) { p3 += d3; o9 += d9; ofs += df; off += df; }
   };
 
   const int n_steps = (INTEG == MF_INTEG_ODEINT_EULER) ? a.T - 1 : a.T;
@@ -152,9 +152,14 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
   // gathers of the recompute (rollout_bwd_cp_kernel.h).  A step's slab is four planes of one 16-byte quad per lane,
   // [4][B * 16 lanes][4 floats]: each of the four stores of a wave is one contiguous kilobyte (with the 16 floats of a lane
   // side by side a store touched 64 separate 64-byte segments and the forward went from 0.17 to 0.48 ms at B = 1024).
-  char* pRec = reinterpret_cast<char*>(a.rec);
-  const unsigned rec_lane = (unsigned)tid * 16u;
-  const size_t rec_plane = (size_t)a.B * 16u * 16u, rec_step = 4u * rec_plane;
+  // (four loop-invariant scalar plane bases + one running 32-bit per-lane offset: mf_rollout_record_bytes keeps the record < 4 GiB)
+  const size_t rec_plane = (size_t)a.B * 16u * 16u;
+  char* const pRec0 = reinterpret_cast<char*>(a.rec);
+  char* const pRec1 = pRec0 + rec_plane;
+  char* const pRec2 = pRec0 + 2 * rec_plane;
+  char* const pRec3 = pRec0 + 3 * rec_plane;
+  unsigned rec_off = (unsigned)tid * 16u;
+  const unsigned rec_step = (unsigned)(4u * rec_plane);
   auto contact = [&](const Geo& g, float vxd, float vw, float tv, float* xdd, float* wd, float* oFr, float* oFf) {
     const float vp = vxd + unrot(cross_pre(vw, g.r));                  // v_p = xd + w x r   (:204)
     const float zq = dot4(g.wq, g.zc);                               // height under the point (:211)
@@ -186,25 +191,26 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
     *oFr = Fr; *oFf = Ff;
     if constexpr (REC) {
       typedef float f4v __attribute__((ext_vector_type(4)));
-      char* o = pRec + rec_lane;
-      __builtin_nontemporal_store(f4v{__builtin_bit_cast(float, g.idx), g.zc, has_mu ? g.mc : one, g.wa}, reinterpret_cast<f4v*>(o));
-      __builtin_nontemporal_store(f4v{g.wb, nrm, inl, mub}, reinterpret_cast<f4v*>(o + rec_plane));
-      __builtin_nontemporal_store(f4v{cj, inv_csum, A, Nn}, reinterpret_cast<f4v*>(o + 2 * rec_plane));
-      __builtin_nontemporal_store(f4v{sn, wraw, g.il, g.coln2}, reinterpret_cast<f4v*>(o + 3 * rec_plane));
-      pRec += rec_step;
+      __builtin_nontemporal_store(f4v{__builtin_bit_cast(float, g.idx), g.zc, has_mu ? g.mc : one, g.wa}, reinterpret_cast<f4v*>(pRec0 + (size_t)rec_off));
+      __builtin_nontemporal_store(f4v{g.wb, nrm, inl, mub}, reinterpret_cast<f4v*>(pRec1 + (size_t)rec_off));
+      __builtin_nontemporal_store(f4v{cj, inv_csum, A, Nn}, reinterpret_cast<f4v*>(pRec2 + (size_t)rec_off));
+      __builtin_nontemporal_store(f4v{sn, wraw, g.il, g.coln2}, reinterpret_cast<f4v*>(pRec3 + (size_t)rec_off));
+      rec_off += rec_step;
     }
   };
 
   if constexpr (INTEG == MF_INTEG_ODEINT_EULER) {
     // One step of the two-stream pipeline: geometry `g` / controls (cv, cw) / step size h of step n come in, those of step
     // n + 1 go out into the OTHER buffer set -- the loop below alternates two sets, so nothing is moved between iterations.
+    float t_cur = a.T > 1 ? a.ts[1] : zero;
+    const unsigned ctrl_step = (unsigned)a.ctrl_st * 4u, v_ctrl_last = v_ctrl + (unsigned)(a.T - 1) * ctrl_step;
     auto ode_step = [&](int n, const Geo& g, Geo& g_next, float cv_n, float cw_n, float h, float& cv_next, float& cw_next, float& h_next) {
       // next step's controls and step size: loaded before the stores below (vmcnt retires in order)
-      const int nn = min(n + 1, a.T - 1);
-      asm volatile("" : "+v"(v_ctrl));
-      bload2(rCtrl + (size_t)((unsigned)(nn * a.ctrl_st) * 4u), v_ctrl, 0u, &cv_next, &cw_next);
-      const int tp = max(min(n + 1, a.T - 2), 0);
-      const float ts_a = a.ts[tp], ts_b = a.ts[tp + 1];
+      // (vector arithmetic on purpose -- a running per-lane offset clamped at the last row, the previous time stamp carried over:
+      // the scalar index / address chains they replace were 10 scalar instructions per step, each a full issue slot here)
+      v_ctrl = min(v_ctrl + ctrl_step, v_ctrl_last);
+      bload2(rCtrl, v_ctrl, 0u, &cv_next, &cw_next);
+      const float t_next = a.ts[min(n + 2, a.T - 1)];
       const float tv = tv_v * cv_n + tv_w * cw_n;
       // ---- stream B: pose and geometry of step n + 1 (torchdiffeq fixed-grid euler: y_{n+1} = y_n + h f(t_n, y_n)) ----
       // (column j of R is a 3-vector over the lanes: dR_j = w x R_j)
@@ -222,7 +228,8 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
       w = fmaf(h, wd, w);
       oFs = fmaf(h, Fr, oFs);
       oFf = fmaf(h, Ff, oFf);
-      h_next = ts_b - ts_a;
+      h_next = t_next - t_cur;          // (after the last step: 0, unused)
+      t_cur = t_next;
     };
     Geo gA, gB;
     float cvA = cv, cwA = cw, hA = h_ode, cvB = zero, cwB = zero, hB = zero;
