@@ -290,7 +290,7 @@ class Runner:
                 torch.cuda.synchronize(dev)
                 return (time.perf_counter() - t) / n * 1e3
             t_graph, t_eager = self.max_over_ranks(timed(True)), self.max_over_ranks(timed(False))
-            mode['graph'] = t_graph < t_eager
+            mode['graph'] = t_graph < 1.03 * t_eager       # near a tie the replay wins: its timed region does not depend on the host keeping ahead
             launch = {'mode': 'one hipGraph replay per step' if mode['graph'] else 'launch by launch',
                       'calibration_ms_per_step': {'graph': t_graph, 'eager': t_eager}}
         self.barrier()
