@@ -43,14 +43,15 @@ __device__ __forceinline__ float ld1(const float* base, unsigned off) {
 // Also tried and not kept -- a three-stage single-wave pipeline (gathers of step n - 2, the rest of the recompute of step n - 1
 // BESIDE the chain of step n, three register sets, unrolled by three): the same ~350 instructions per step, interleaved by
 // the compiler instead of run one stream after the other, and slower: 0.399 vs 0.367 ms (dynamics(): 0.548 vs 0.448).
-enum { kCpEarly = 0, kCpLate = 1, kCpSaved = 2 };
+enum { kCpEarly = 0, kCpLate = 1, kCpSaved = 2, kCpStream = 3 };
 template <int INTEG, bool XS_ONLY, bool GCTRL, int MODE>
-__global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
+__global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
   constexpr bool ODE = INTEG == MF_INTEG_ODEINT_EULER;
-  constexpr bool LATE = MODE == kCpLate, SAVED = MODE == kCpSaved;
+  constexpr bool LATE = MODE == kCpLate, STREAM = MODE == kCpStream, SAVED = MODE == kCpSaved || STREAM;
   using namespace cp;
   using M = Mth<float, true>;
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int tid = STREAM ? blockIdx.x * 64 + lane : blockIdx.x * blockDim.x + threadIdx.x;
   const int b = tid >> 4;
   if (b >= a.B) return;
   const int p = (tid >> 2) & 3, q = tid & 3, cc = q < 3 ? q : 2;
@@ -494,6 +495,111 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
         og_xs -= sg_xs;
         if constexpr (!XS_ONLY) { og_xds -= sg_xds; og_om -= sg_om; og_r -= sg_r; og_fs -= sg_fs; og_ff -= sg_ff; }
       };
+      if constexpr (STREAM) {
+        // MODE = kCpStream: the record-reading kernel waits for HBM -- SQ_WAIT_ANY 22 % with the record and the rows requested one
+        // step (0.6 us) ahead, and a single wave cannot request further ahead (the values crossing the loop's back edge get copied
+        // there, which drains them).  A SECOND wave of the workgroup (B <= 1024 leaves three SIMDs of every CU idle) therefore
+        // does nothing but fetch: four steps per trip straight into registers -- thirty-odd loads in flight -- then into an LDS
+        // ring of eight slots; the first wave reads a step's planes from LDS and runs the same rebuild + chain as before.  Two
+        // LDS counters (records written / records read) instead of barriers; LDS executes a wave's operations in order, so a
+        // counter written after a slot is seen after it.
+        constexpr int kSlots = 8, kPlanes = 6 + (XS_ONLY ? 1 : 2);
+        __shared__ f4v ring[kSlots * kPlanes * 64];
+        __shared__ int flags[2];
+        typedef __attribute__((address_space(3))) volatile int LdsCounter;      // (a generic volatile pointer would make FLAT accesses)
+        LdsCounter* vflags = (LdsCounter*)flags;
+        if (threadIdx.x == 0) { flags[0] = 0; flags[1] = 0; }
+        __syncthreads();
+        if (threadIdx.x >= 64) {
+          // ---------------- the fetching wave ----------------
+          struct Raw { StateIn st; Saved sv; UpIn up; };
+          int produced = 0, m = n;                    // m: the step the offsets point at
+          auto fetch = [&](Raw& r) {                  // everything of step m; then the offsets move to step m - 1
+            request_state(r.st, r.sv);
+            request_up(r.up);
+            o3 -= s3; o9 -= s9; oc -= 8u; orc -= (unsigned)rec_step; --ti;
+            step_back_up();
+            --m;
+          };
+          auto put = [&](const Raw& r) {
+            f4v* o = ring + (produced & (kSlots - 1)) * (kPlanes * 64) + lane;
+            o[0] = r.sv.q0; o[64] = r.sv.q1; o[128] = r.sv.q2; o[192] = r.sv.q3;
+            o[256] = f4v{r.st.xd, r.st.w, r.st.R0, r.st.R1};
+            o[320] = f4v{r.st.R2, r.st.cv, r.st.cw, r.st.t1 - r.st.t0};
+            if constexpr (XS_ONLY) o[384] = f4v{r.up.gXs, zero, zero, zero};
+            else { o[384] = f4v{r.up.gXs, r.up.gXds, r.up.gOm, r.up.gFs}; o[448] = f4v{r.up.gFf, r.up.gR0, r.up.gR1, r.up.gR2}; }
+            ++produced;
+          };
+          auto room = [&](int want) {                 // wait until `want` more slots may be overwritten
+            while (produced + want - __builtin_amdgcn_readfirstlane(vflags[1]) > kSlots) __builtin_amdgcn_s_sleep(2);
+            asm volatile("" ::: "memory");
+          };
+          while (m >= 3) {                            // four steps per trip: their ~36 loads are in flight together
+            Raw r0, r1, r2, r3;
+            fetch(r0); fetch(r1); fetch(r2); fetch(r3);
+            room(4);
+            put(r0); put(r1); put(r2); put(r3);
+            asm volatile("" ::: "memory");
+            vflags[0] = produced;
+          }
+          while (m >= 0) {
+            Raw r0;
+            fetch(r0);                                // (after step 0 the offsets wrap around; nothing reads them again)
+            room(1);
+            put(r0);
+            asm volatile("" ::: "memory");
+            vflags[0] = produced;
+          }
+          return;
+        }
+        // ---------------- the computing wave ----------------
+        int consumed = 0, seen = 0;                   // records read so far; the fetching wave's counter as last read
+        UpIn uZ;                                      // the upstream gradient of output row 0 (the initial state): not in the ring
+        load_upstream(0, uZ);
+        auto take = [&](StateIn& st, Saved& sv, UpIn& up) {      // the next record out of the ring
+          int have = __builtin_amdgcn_readfirstlane(seen);
+          while (have <= consumed) have = __builtin_amdgcn_readfirstlane(vflags[0]);
+          asm volatile("" ::: "memory");
+          const f4v* o = ring + (consumed & (kSlots - 1)) * (kPlanes * 64) + lane;
+          sv.q0 = o[0]; sv.q1 = o[64]; sv.q2 = o[128]; sv.q3 = o[192];
+          const f4v s0 = o[256], s1 = o[320];
+          st.x = zero; st.xd = s0.x; st.w = s0.y; st.R0 = s0.z; st.R1 = s0.w;
+          st.R2 = s1.x; st.cv = s1.y; st.cw = s1.z; st.t0 = zero; st.t1 = s1.w;
+          // (positions-only: one float of the quad is read -- the unused three would be free registers to the allocator, and
+          //  an instruction writing one of them waits for the read)
+          if constexpr (XS_ONLY) up.gXs = reinterpret_cast<const float*>(o + 384)[0];
+          else {
+            const f4v g0 = o[384], g1 = o[448];
+            up.gXs = g0.x;
+            up.gXds = g0.y; up.gOm = g0.z; up.gFs = g0.w; up.gFf = g1.x; up.gR0 = g1.y; up.gR1 = g1.z; up.gR2 = g1.w;
+          }
+          ++consumed;
+          seen = vflags[0];
+          asm volatile("" ::: "memory");
+          vflags[1] = consumed;                        // (LDS runs a wave's operations in order: the reads above are done by then)
+        };
+        auto crunch = [&](int n, const StateIn& st, const Saved& sv, const UpIn& up, StateIn& st_next, Saved& sv_next, UpIn& up_next, auto more) {
+          add_upstream_state(up);
+          if constexpr (decltype(more)::value) take(st_next, sv_next, up_next);
+          flush_stash();
+          if constexpr (GCTRL) bstore2(rGctrl, v_ctrl, gctrl_pending, gv_pending, gwc_pending);
+          Rec k;
+          rebuild(st, sv, k);
+          vjp(n, k, up);
+        };
+        using std::true_type;
+        using std::false_type;
+        if (n_steps > 0) {
+          take(sA, vA, uA);
+          for (; n >= 2; n -= 2) {
+            crunch(n, sA, vA, uA, sB, vB, uB, true_type{});
+            crunch(n - 1, sB, vB, uB, sA, vA, uA, true_type{});
+          }
+          if (n == 1) { crunch(1, sA, vA, uA, sB, vB, uB, true_type{}); crunch(0, sB, vB, uB, sA, vA, uA, false_type{}); }
+          else crunch(0, sA, vA, uA, sB, vB, uB, false_type{});
+        }
+        uA = uZ; uB = uZ;                             // (the epilogue reads whichever the last iteration would have requested into)
+      } else {
       auto run = [&](int n, const StateIn& st, const Saved& sv, const UpIn& up, StateIn& st_next, Saved& sv_next, UpIn& up_next, auto more) {
         add_upstream_state(up);
         step_back_up();
@@ -520,6 +626,7 @@ __global__ void __launch_bounds__(64) rollout_bwd_cp_kernel(const RolloutBwdArgs
         }
         if (n == 1) { run(1, sA, vA, uA, sB, vB, uB, true_type{}); run(0, sB, vB, uB, sA, vA, uA, false_type{}); }
         else run(0, sA, vA, uA, sB, vB, uB, false_type{});
+      }
       }
     } else {
     // one iteration: the rows, the record and the upstream gradient of step n - 1 are loaded while step n runs
@@ -608,15 +715,19 @@ int launch_rollout_bwd_cp_dynamics_f32(const RolloutBwdArgs<float>& a, bool xs_o
 // one launch of the variant (positions-only loss?, control gradient?, late recompute?) the arguments call for
 template <int INTEG>
 int launch_rollout_bwd_cp_variant(const RolloutBwdArgs<float>& a, bool xs_only, hipStream_t st) {
-  const int block = 64;
   const long long threads = (long long)a.B * 16;
-  const unsigned grid = (unsigned)((threads + block - 1) / block);
+  const unsigned grid = (unsigned)((threads + 63) / 64);
   const bool gc = a.gcontrols != nullptr;
   static const int forced = getenv("MF_CP_BWD_MODE") ? atoi(getenv("MF_CP_BWD_MODE")) : -1;      // A/B (tools/ab_cp.py): 0 early, 1 late
   // the forward's record when there is one; else at most one wave per SIMD: late recompute
-  const int mode = a.rec ? kCpSaved : (forced >= 0 && forced != kCpSaved ? forced : (grid <= 1024u ? kCpLate : kCpEarly));
+  // (a record with at most one wave per CU: a second wave per workgroup streams it through LDS)
+  constexpr bool can_stream = INTEG == MF_INTEG_ODEINT_EULER;
+  static const unsigned stream_max = getenv("MF_CP_STREAM_MAX_GRID") ? (unsigned)atoi(getenv("MF_CP_STREAM_MAX_GRID")) : 256u;
+  const int saved_mode = can_stream && grid <= stream_max && forced != kCpSaved ? kCpStream : kCpSaved;
+  const int mode = a.rec ? saved_mode : (forced >= 0 && forced < kCpSaved ? forced : (grid <= 1024u ? kCpLate : kCpEarly));
+  const int block = mode == kCpStream ? 128 : 64;
 #define MF_BCP(XS_, GC_, M_) hipLaunchKernelGGL((rollout_bwd_cp_kernel<INTEG, XS_, GC_, M_>), dim3(grid), dim3(block), 0, st, a)
-#define MF_BCP_L(XS_, GC_) do { if (mode == kCpSaved) MF_BCP(XS_, GC_, kCpSaved); else if (mode == kCpLate) MF_BCP(XS_, GC_, kCpLate); else MF_BCP(XS_, GC_, kCpEarly); } while (0)
+#define MF_BCP_L(XS_, GC_) do { if (mode == kCpStream) { if constexpr (can_stream) MF_BCP(XS_, GC_, kCpStream); } else if (mode == kCpSaved) MF_BCP(XS_, GC_, kCpSaved); else if (mode == kCpLate) MF_BCP(XS_, GC_, kCpLate); else MF_BCP(XS_, GC_, kCpEarly); } while (0)
   if (xs_only) { if (gc) MF_BCP_L(true, true); else MF_BCP_L(true, false); }
   else         { if (gc) MF_BCP_L(false, true); else MF_BCP_L(false, false); }
 #undef MF_BCP_L

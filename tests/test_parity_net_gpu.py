@@ -452,7 +452,7 @@ def _record_case():
 
 def test_backward_from_the_forward_record_equals_the_recomputing_backward():
     """Small launches of the default integrator keep a per-step record in the forward (MfRolloutFwdBufs.rec) and the backward
-    reads it instead of recomputing (the default here); a child process with MF_CP_RECORD_MAX_WAVES=0 runs the same problem
+    reads it instead of recomputing (the default here, through a second wave that streams it into LDS); a child process with MF_CP_RECORD_MAX_WAVES=0 runs the same problem
     through the recomputing backward: same outputs bit for bit (the record changes no arithmetic of the forward), gradients to
     float32 rounding, and both within the usual bar of the float64 oracle."""
     import os, subprocess, sys, tempfile
@@ -465,10 +465,18 @@ def test_backward_from_the_forward_record_equals_the_recomputing_backward():
         r = subprocess.run([sys.executable, '-c', _NO_RECORD % (repo, path)], capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
         without = torch.load(path)
+        # the record read by the computing wave itself (MF_CP_BWD_MODE=2) instead of streamed through LDS by a second wave
+        # (the default at this size): the same arithmetic in the same order
+        path1 = os.path.join(td, 'onewave.pt')
+        r = subprocess.run([sys.executable, '-c', _NO_RECORD % (repo, path1)], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, MF_CP_BWD_MODE='2'))
+        assert r.returncode == 0, r.stderr[-2000:]
+        one_wave = torch.load(path1)
     for a_, b_ in zip(with_rec['outs'], without['outs']):
         assert torch.equal(a_, b_)
     for k in ('gz', 'gmu', 'gc'):
         assert hp.rel_err(with_rec[k], without[k]) <= 2e-5, (k, hp.rel_err(with_rec[k], without[k]))
+        assert hp.rel_err(with_rec[k], one_wave[k]) <= 2e-6, (k, hp.rel_err(with_rec[k], one_wave[k]))      # (atomics: arrival order)
     # ... and the recorded route against the oracle
     from monoforce_amd import synthetic as syn
     pts, masks = syn.robot_points_4()
