@@ -739,6 +739,7 @@ bool use_component_parallel_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* 
 long long cp_record_bytes(const MfRolloutDesc* d);      // bytes of the forward's per-step record for this launch shape (0: none)
 int launch_rollout_bwd_cp_f32(const RolloutBwdArgs<float>& a, int integ, bool xs_only, hipStream_t st);   // a.gcontrols may be NULL
 int launch_rollout_bwd_cp_dynamics_f32(const RolloutBwdArgs<float>& a, bool xs_only, hipStream_t st);      // rollout_bwd_dyn_cp_fast.hip
+void launch_rollout_bwd_cp_stream_f32(const RolloutBwdArgs<float>& a, bool xs_only, unsigned grid, hipStream_t st);   // rollout_bwd_cp_stream_fast.hip
 
 // one launch of the variant (positions-only loss?, control gradient?, late recompute?) the arguments call for
 template <int INTEG>
@@ -755,7 +756,7 @@ int launch_rollout_bwd_cp_variant(const RolloutBwdArgs<float>& a, bool xs_only, 
   const int mode = a.rec ? saved_mode : (forced >= 0 && forced < kCpSaved ? forced : (grid <= 1024u ? kCpLate : kCpEarly));
   const int block = mode == kCpStream ? 128 : 64;
 #define MF_BCP(XS_, GC_, M_) hipLaunchKernelGGL((rollout_bwd_cp_kernel<INTEG, XS_, GC_, M_>), dim3(grid), dim3(block), 0, st, a)
-#define MF_BCP_L(XS_, GC_) do { if (mode == kCpStream) { if constexpr (can_stream) MF_BCP(XS_, GC_, kCpStream); } else if (mode == kCpSaved) MF_BCP(XS_, GC_, kCpSaved); else if (mode == kCpLate) MF_BCP(XS_, GC_, kCpLate); else MF_BCP(XS_, GC_, kCpEarly); } while (0)
+#define MF_BCP_L(XS_, GC_) do { if (mode == kCpStream) launch_rollout_bwd_cp_stream_f32(a, xs_only, grid, st); else if (mode == kCpSaved) MF_BCP(XS_, GC_, kCpSaved); else if (mode == kCpLate) MF_BCP(XS_, GC_, kCpLate); else MF_BCP(XS_, GC_, kCpEarly); } while (0)
   if (xs_only) { if (gc) MF_BCP_L(true, true); else MF_BCP_L(true, false); }
   else         { if (gc) MF_BCP_L(false, true); else MF_BCP_L(false, false); }
 #undef MF_BCP_L
