@@ -258,7 +258,13 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
         laFf += act ? up.gFf : zero;
         gFr_up = h * laFs; gFf_up = h * laFf;
       }
-      gxdd = h * lxd; gwd = h * lw;
+      if constexpr (MODE == kCpStream) {
+        // kCpStream keeps the adjoint state UN-SUMMED over the contact points (each quad holds its own part; the state is the
+        // sum of the four): every use of it is linear, and only the two values met by per-point data -- the adjoints of the
+        // linear and angular velocity, here -- need the sum every step.  Five lane sums per step (ten DPP adds) become six
+        // after the loop.
+        gxdd = h * sum_points(lxd); gwd = h * sum_points(lw);
+      } else { gxdd = h * lxd; gwd = h * lw; }
       lxd = fmaf(h, lx, lxd);                               // x' = x + h xd
       // R' = R + h [w]x R, column by column: d/dw of (w x R_j) . g_j = R_j x g_j ; d/dR_j = g_j x w   (g_j = h lR[:, j])
       const float g0 = h * lR0, g1 = h * lR1, g2 = h * lR2;
@@ -341,6 +347,7 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
       gv_p = tv_v * gtv; gwc_p = tv_w * gtv;
     }
     float gF1;
+    float dF, gA;
     if constexpr (MODE == kCpStream) {
       gFr = fmaf(gNn * k.invNn, k.Fr, gFr);
       gF1 = k.mF1 * gFr;
@@ -348,11 +355,17 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
       gFr = fmaf(k.Nn > zero ? gNn * M::div(one, k.Nn) : zero, k.Fr, gFr);
       gF1 = inside(k.F1, -mg, mg) ? gFr : zero;
     }
-    const float dF = dot3(gF1, k.F0);
+    const float gF0 = gF1 * cj * inv_csum;
+    if constexpr (MODE == kCpStream) {
+      const float d1 = dot3(gF1, nrm);                     // F0 = -A n: the lane sums against F0 and against n are one
+      dF = -(k.A * d1);
+      gA = -(cj * inv_csum * d1);
+    } else {
+      dF = dot3(gF1, k.F0);
+      gA = -dot3(gF0, nrm);
+    }
     const float gc_p = dF * inv_csum;
     const float gS = sum_points(-(dF * cj) * inv_csum * inv_csum);
-    const float gF0 = gF1 * cj * inv_csum;
-    const float gA = -dot3(gF0, nrm);
     gn = fmaf(-k.A, gF0, gn);
     const float gdh_p = a.k * gA;
     const float gvn = a.damp * gA;
@@ -386,11 +399,18 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
     const float gw_p = r1 * gvp2 - r2 * gvp1;              // dw += r x gvp
     const float qa = gp + gr;                              // p = R P + x, r = p - x
     // sums over the contact points
-    lx += sum_points(gp);
-    lxd += sum_points(gvp);
-    lw += sum_points(gw_p);
-    lR0 += sum_points(qa * P0); lR1 += sum_points(qa * P1); lR2 += sum_points(qa * P2);
-    const float ge = sum_points(ge_p);
+    float ge;
+    if constexpr (MODE == kCpStream) {                     // (each quad's own part: see the integrator block)
+      lx += gp; lxd += gvp; lw += gw_p;
+      lR0 = fmaf(qa, P0, lR0); lR1 = fmaf(qa, P1, lR1); lR2 = fmaf(qa, P2, lR2);
+      ge = ge_p;
+    } else {
+      lx += sum_points(gp);
+      lxd += sum_points(gvp);
+      lw += sum_points(gw_p);
+      lR0 += sum_points(qa * P0); lR1 += sum_points(qa * P1); lR2 += sum_points(qa * P2);
+      ge = sum_points(ge_p);
+    }
     float gv = zero, gwc = zero;
     if constexpr (GCTRL) { gv = sum_points(gv_p); gwc = sum_points(gwc_p); }
     {   // e = col0(R) / max(|col0|, eps): through |col0| only when it is >= eps
@@ -551,8 +571,13 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
             o[384] = f4v{k.F0, k.cj, k.inv_csum, k.A};
             o[448] = f4v{k.vp, k.inl, k.wq, __builtin_bit_cast(float, k.idx)};
             o[512] = f4v{k.zc, k.mcv, k.wa, k.wb};
-            o[576] = f4v{k.il, cmask, one - k.cj, r.up.gXs};
-            if constexpr (!XS_ONLY) { o[640] = f4v{r.up.gXds, r.up.gOm, r.up.gFs, r.up.gFf}; o[704] = f4v{r.up.gR0, r.up.gR1, r.up.gR2, zero}; }
+            // (the adjoint state is kept un-summed over the points: the upstream gradient of a state row goes to point 0's quad)
+            const float first = p == 0 ? one : zero;
+            o[576] = f4v{k.il, cmask, one - k.cj, first * r.up.gXs};
+            if constexpr (!XS_ONLY) {
+              o[640] = f4v{first * r.up.gXds, first * r.up.gOm, r.up.gFs, r.up.gFf};
+              o[704] = f4v{first * r.up.gR0, first * r.up.gR1, first * r.up.gR2, zero};
+            }
             ++produced;
           };
           auto room = [&](int want) {                 // wait until `want` more slots may be overwritten
@@ -626,6 +651,8 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
           if (n == 1) { crunch(1, recA, uA, recB, uB, true_type{}); crunch(0, recB, uB, recA, uA, false_type{}); }
           else crunch(0, recA, uA, recB, uB, false_type{});
         }
+        lx = sum_points(lx); lxd = sum_points(lxd); lw = sum_points(lw);      // the state proper
+        lR0 = sum_points(lR0); lR1 = sum_points(lR1); lR2 = sum_points(lR2);
         uA = uZ; uB = uZ;                             // (the epilogue reads whichever the last iteration would have requested into)
       } else {
       auto run = [&](int n, const StateIn& st, const Saved& sv, const UpIn& up, StateIn& st_next, Saved& sv_next, UpIn& up_next, auto more) {

@@ -466,7 +466,7 @@ def test_backward_from_the_forward_record_equals_the_recomputing_backward():
         assert r.returncode == 0, r.stderr[-2000:]
         without = torch.load(path)
         # the record read by the computing wave itself (MF_CP_BWD_MODE=2) instead of streamed through LDS by a second wave
-        # (the default at this size): the same arithmetic in the same order
+        # (the default at this size): the same arithmetic, the adjoint state summed over the contact points once instead of every step
         path1 = os.path.join(td, 'onewave.pt')
         r = subprocess.run([sys.executable, '-c', _NO_RECORD % (repo, path1)], capture_output=True, text=True, timeout=600,
                            env=dict(os.environ, MF_CP_BWD_MODE='2'))
@@ -476,7 +476,7 @@ def test_backward_from_the_forward_record_equals_the_recomputing_backward():
         assert torch.equal(a_, b_)
     for k in ('gz', 'gmu', 'gc'):
         assert hp.rel_err(with_rec[k], without[k]) <= 2e-5, (k, hp.rel_err(with_rec[k], without[k]))
-        assert hp.rel_err(with_rec[k], one_wave[k]) <= 2e-6, (k, hp.rel_err(with_rec[k], one_wave[k]))      # (atomics: arrival order)
+        assert hp.rel_err(with_rec[k], one_wave[k]) <= 2e-5, (k, hp.rel_err(with_rec[k], one_wave[k]))      # (sums in another order)
     # ... and the recorded route against the oracle
     from monoforce_amd import synthetic as syn
     pts, masks = syn.robot_points_4()
