@@ -584,13 +584,29 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
             while (produced + want - __builtin_amdgcn_readfirstlane(vflags[1]) > kSlots) __builtin_amdgcn_s_sleep(2);
             asm volatile("" ::: "memory");
           };
-          while (m >= 3) {                            // four steps per trip: their ~36 loads are in flight together
-            Raw r0, r1, r2, r3;
-            fetch(r0); fetch(r1); fetch(r2); fetch(r3);
-            room(4);
-            put(r0); put(r1); put(r2); put(r3);
+          // Three steps per batch, two batches in registers: the loads of one are in flight while the other is rebuilt and
+          // written (alone, this wave runs the launch in 0.175 ms instead of 0.20 with one batch of four at a time -- it has to stay
+          // well ahead of the computing wave's 0.22).
+          auto put3 = [&](const Raw& r0, const Raw& r1, const Raw& r2) {
+            room(3);
+            put(r0); put(r1); put(r2);
             asm volatile("" ::: "memory");
             vflags[0] = produced;
+          };
+          if (m >= 2) {
+            Raw a0, a1, a2, b0, b1, b2;
+            fetch(a0); fetch(a1); fetch(a2);
+            while (m >= 5) {                          // six more steps at least
+              fetch(b0); fetch(b1); fetch(b2);
+              put3(a0, a1, a2);
+              fetch(a0); fetch(a1); fetch(a2);
+              put3(b0, b1, b2);
+            }
+            if (m >= 2) {
+              fetch(b0); fetch(b1); fetch(b2);
+              put3(a0, a1, a2);
+              put3(b0, b1, b2);
+            } else put3(a0, a1, a2);
           }
           while (m >= 0) {
             Raw r0;
