@@ -188,7 +188,6 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
     float R0, R1, R2, w, r1, r2, w1, w2, vp, e, il, coln2, tv, h;
     float wq, wa, wb, zc, mcv, mub, nrm, inl, cj, inv_csum, A, F0, F1, Fr, Nn, cmdv, s, sn, stv, Gf, f1, f2, wraw;
     int idx;
-    float mw, mG, mF1, invNn, omc, cmask;                // kCpStream only: clamp gates as 1 / 0, 1 / |F_n|, 1 - c, |col0| >= eps -- made by the fetching wave
   };
   // first half: the footprint cell of this lane and its two gathers -- issued a whole vector-Jacobian chain (~1000 cycles)
   // before the second half consumes them
@@ -258,13 +257,7 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
         laFf += act ? up.gFf : zero;
         gFr_up = h * laFs; gFf_up = h * laFf;
       }
-      if constexpr (MODE == kCpStream) {
-        // kCpStream keeps the adjoint state UN-SUMMED over the contact points (each quad holds its own part; the state is the
-        // sum of the four): every use of it is linear, and only the two values met by per-point data -- the adjoints of the
-        // linear and angular velocity, here -- need the sum every step.  Five lane sums per step (ten DPP adds) become six
-        // after the loop.
-        gxdd = h * sum_points(lxd); gwd = h * sum_points(lw);
-      } else { gxdd = h * lxd; gwd = h * lw; }
+      gxdd = h * lxd; gwd = h * lw;
       lxd = fmaf(h, lx, lxd);                               // x' = x + h xd
       // R' = R + h [w]x R, column by column: d/dw of (w x R_j) . g_j = R_j x g_j ; d/dR_j = g_j x w   (g_j = h lR[:, j])
       const float g0 = h * lR0, g1 = h * lR1, g2 = h * lR2;
@@ -321,8 +314,7 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
       lR0 = n0; lR1 = n1; lR2 = n2;
     }
     // ---- RHS backward ----
-    float mwd;
-    if constexpr (MODE == kCpStream) mwd = k.mw * gwd; else mwd = inside(k.wraw, -a.omega_max, a.omega_max) ? gwd : zero;
+    const float mwd = inside(k.wraw, -a.omega_max, a.omega_max) ? gwd : zero;
     const float gtau = J0 * dpp<kB0>(mwd) + J1 * dpp<kB1>(mwd) + J2 * dpp<kB2>(mwd);      // I^-T m
     const float gsum = gxdd * a.inv_mass;
     const float gt1 = dpp<kRot1>(gtau), gt2 = dpp<kRot2>(gtau);
@@ -330,8 +322,7 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
     float gr = k.f1 * gt2 - k.f2 * gt1;                   //                dr = f x gtau
     float gFr = gFr_up + gsum + gf;
     const float gFf_ = gFf_up + gsum + gf;
-    float gG;
-    if constexpr (MODE == kCpStream) gG = k.mG * gFf_; else gG = inside(k.Gf, -mg, mg) ? gFf_ : zero;
+    const float gG = inside(k.Gf, -mg, mg) ? gFf_ : zero;
     const float gNn = dot3(gG, k.stv);
     const float gst = k.Nn * gG;
     const float gsn = -dot3(gst, nrm);
@@ -346,33 +337,20 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
       const float gtv = dot3(gcmd, k.e);                   // tv_v = tv_w = 0 for non-driving points
       gv_p = tv_v * gtv; gwc_p = tv_w * gtv;
     }
-    float gF1;
-    float dF, gA;
-    if constexpr (MODE == kCpStream) {
-      gFr = fmaf(gNn * k.invNn, k.Fr, gFr);
-      gF1 = k.mF1 * gFr;
-    } else {
-      gFr = fmaf(k.Nn > zero ? gNn * M::div(one, k.Nn) : zero, k.Fr, gFr);
-      gF1 = inside(k.F1, -mg, mg) ? gFr : zero;
-    }
-    const float gF0 = gF1 * cj * inv_csum;
-    if constexpr (MODE == kCpStream) {
-      const float d1 = dot3(gF1, nrm);                     // F0 = -A n: the lane sums against F0 and against n are one
-      dF = -(k.A * d1);
-      gA = -(cj * inv_csum * d1);
-    } else {
-      dF = dot3(gF1, k.F0);
-      gA = -dot3(gF0, nrm);
-    }
+    gFr = fmaf(k.Nn > zero ? gNn * M::div(one, k.Nn) : zero, k.Fr, gFr);
+    const float gF1 = inside(k.F1, -mg, mg) ? gFr : zero;
+    const float dF = dot3(gF1, k.F0);
     const float gc_p = dF * inv_csum;
     const float gS = sum_points(-(dF * cj) * inv_csum * inv_csum);
+    const float gF0 = gF1 * cj * inv_csum;
+    const float gA = -dot3(gF0, nrm);
     gn = fmaf(-k.A, gF0, gn);
     const float gdh_p = a.k * gA;
     const float gvn = a.damp * gA;
     gvp = fmaf(gvn, nrm, gvp);
     gn = fmaf(gvn, k.vp, gn);
     const float gcw = gc_p + gS;
-    const float gdh = gdh_p + gcw * (-10.0f) * cj * (MODE == kCpStream ? k.omc : one - cj);
+    const float gdh = gdh_p + gcw * (-10.0f) * cj * (one - cj);
     const float gzq = -gdh;
     // n = u / |u|, u = (-gx, -gy, 1): components 0, 1 carry the finite differences
     const float dotn = dot3(gn, nrm);
@@ -399,22 +377,15 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
     const float gw_p = r1 * gvp2 - r2 * gvp1;              // dw += r x gvp
     const float qa = gp + gr;                              // p = R P + x, r = p - x
     // sums over the contact points
-    float ge;
-    if constexpr (MODE == kCpStream) {                     // (each quad's own part: see the integrator block)
-      lx += gp; lxd += gvp; lw += gw_p;
-      lR0 = fmaf(qa, P0, lR0); lR1 = fmaf(qa, P1, lR1); lR2 = fmaf(qa, P2, lR2);
-      ge = ge_p;
-    } else {
-      lx += sum_points(gp);
-      lxd += sum_points(gvp);
-      lw += sum_points(gw_p);
-      lR0 += sum_points(qa * P0); lR1 += sum_points(qa * P1); lR2 += sum_points(qa * P2);
-      ge = sum_points(ge_p);
-    }
+    lx += sum_points(gp);
+    lxd += sum_points(gvp);
+    lw += sum_points(gw_p);
+    lR0 += sum_points(qa * P0); lR1 += sum_points(qa * P1); lR2 += sum_points(qa * P2);
+    const float ge = sum_points(ge_p);
     float gv = zero, gwc = zero;
     if constexpr (GCTRL) { gv = sum_points(gv_p); gwc = sum_points(gwc_p); }
     {   // e = col0(R) / max(|col0|, eps): through |col0| only when it is >= eps
-      const float dote = dot3(ge, k.e) * (MODE == kCpStream ? k.cmask : (k.coln2 >= 1e-12f ? one : zero));   // (a ternary around the lane sum becomes a branch)
+      const float dote = dot3(ge, k.e) * (k.coln2 >= 1e-12f ? one : zero);   // (a ternary around the lane sum becomes a branch)
       lR0 = fmaf(ge - dote * k.e, k.il, lR0);
     }
     gctrl_pending = __builtin_amdgcn_readfirstlane((unsigned)n * 8u); gv_pending = gv; gwc_pending = gwc;      // stored by the next iteration (or after the loop)
@@ -551,8 +522,8 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
             --m;
           };
           // ... and everything of the step's vector-Jacobian product that does not depend on the adjoint is done HERE, on the
-          // wave that has time: the rebuild, the clamp gates (as 1 / 0 factors), 1 / |F_n|.  The computing wave issues ~50 fewer
-          // instructions per step for three more LDS reads.
+          // wave that has time: the rebuild, the clamp gates, 1 / |F_n|, and every product of two such values the chain would
+          // form -- the ring carries the chain's COEFFICIENTS (struct Coef below), forty floats per lane and step.
           auto put = [&](const Raw& r) {
             Rec k;
             rebuild(r.st, r.sv, k);
@@ -561,19 +532,20 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
             const float mF1 = inside(k.F1, -mg, mg) ? one : zero;
             const float invNn = k.Nn > zero ? M::div(one, k.Nn) : zero;
             const float cmask = k.coln2 >= 1e-12f ? one : zero;
+            const float cs = k.cj * k.inv_csum;
+            // (the adjoint state is kept un-summed over the points: the upstream gradient of a state row goes to point 0's quad)
+            const float first = p == 0 ? one : zero;
             f4v* o = ring + (produced & (kSlots - 1)) * (kPlanes * 64) + lane;
             o[0] = f4v{k.R0, k.R1, k.R2, k.h};
             o[64] = f4v{k.w1, k.w2, k.r1, k.r2};
-            o[128] = f4v{k.f1, k.f2, mw, mG};
-            o[192] = f4v{k.stv, k.Nn, k.nrm, k.s};
-            o[256] = f4v{k.sn, k.cmdv, k.mub, k.tv};
-            o[320] = f4v{k.e, k.Fr, invNn, mF1};
-            o[384] = f4v{k.F0, k.cj, k.inv_csum, k.A};
-            o[448] = f4v{k.vp, k.inl, k.wq, __builtin_bit_cast(float, k.idx)};
-            o[512] = f4v{k.zc, k.mcv, k.wa, k.wb};
-            // (the adjoint state is kept un-summed over the points: the upstream gradient of a state row goes to point 0's quad)
-            const float first = p == 0 ? one : zero;
-            o[576] = f4v{k.il, cmask, one - k.cj, first * r.up.gXs};
+            o[128] = f4v{k.f1, k.f2, mw, mG * k.stv};
+            o[192] = f4v{mG * k.Nn, k.nrm, k.s, k.sn};
+            o[256] = f4v{k.cmdv, k.mub, k.tv * k.mub, k.Fr * invNn};
+            o[320] = f4v{mF1 * cs, mF1 * k.nrm, k.A, -(a.k * cs)};
+            o[384] = f4v{-(a.damp * cs), -(k.A * k.inv_csum), k.A * k.cj * k.inv_csum * k.inv_csum, -10.0f * k.cj * (one - k.cj)};
+            o[448] = f4v{k.vp, -(k.inl * a.inv_res), k.wq, __builtin_bit_cast(float, k.idx)};
+            o[512] = f4v{k.zc, k.mcv, wa_s * k.wb * a.inv_res, wb_s * k.wa * a.inv_res};
+            o[576] = f4v{k.e, k.il, cmask * k.e * k.il, first * r.up.gXs};
             if constexpr (!XS_ONLY) {
               o[640] = f4v{first * r.up.gXds, first * r.up.gOm, r.up.gFs, r.up.gFf};
               o[704] = f4v{first * r.up.gR0, first * r.up.gR1, first * r.up.gR2, zero};
@@ -622,23 +594,35 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
         int consumed = 0, seen = 0;                   // records read so far; the fetching wave's counter as last read
         UpIn uZ;                                      // the upstream gradient of output row 0 (the initial state): not in the ring
         load_upstream(0, uZ);
-        auto take = [&](Rec& k, UpIn& up) {           // the next step out of the ring
+        // The coefficients of a step's vector-Jacobian product, as the fetching wave leaves them in the ring.  With
+        // cs = c / sum c, the gates mG, mF1 (1 / 0) and d1 = gFr . (mF1 n) -- the one lane sum that serves F0 = -A n and n both:
+        struct Coef {
+          float R0, R1, R2, h, w1, w2, r1, r2, f1, f2, mw;
+          float stvG, NnG, nrm, s, sn;          // mG stv, mG |F_n|
+          float cmdv, mub, tvm, FrN;            // tv mu_b, Fr / |F_n|
+          float csm, nm1, A, kcs;               // mF1 cs, mF1 n, A, -k cs          (g_dh' = kcs d1)
+          float dcs, Aic, Acc, dcj;             // -d cs (g_vn = dcs d1), -A / sum c (g_c = Aic d1), A c / (sum c)^2 (g_S = sum_points(Acc d1)), -10 c (1 - c)
+          float vp, inlr, wq, zc, mcv, wsb, wsa;      // -(1 / |u|) / res; d wq / d(fx, fy) / res
+          float e, il, eci;                     // gate_col0 e / |col0|
+          int idx;
+        };
+        auto take = [&](Coef& c, UpIn& up) {          // the next step out of the ring
           int have = __builtin_amdgcn_readfirstlane(seen);
           while (have <= consumed) have = __builtin_amdgcn_readfirstlane(vflags[0]);
           asm volatile("" ::: "memory");
           const f4v* o = ring + (consumed & (kSlots - 1)) * (kPlanes * 64) + lane;
           const f4v c0 = o[0], c1 = o[64], c2 = o[128], c3 = o[192], c4 = o[256], c5 = o[320], c6 = o[384], c7 = o[448], c8 = o[512], c9 = o[576];
           const float idx_bits = c7.w;       // (__builtin_bit_cast applied to the element expression itself reads element 0 of the vector)
-          k.R0 = c0.x; k.R1 = c0.y; k.R2 = c0.z; k.h = c0.w;
-          k.w1 = c1.x; k.w2 = c1.y; k.r1 = c1.z; k.r2 = c1.w;
-          k.f1 = c2.x; k.f2 = c2.y; k.mw = c2.z; k.mG = c2.w;
-          k.stv = c3.x; k.Nn = c3.y; k.nrm = c3.z; k.s = c3.w;
-          k.sn = c4.x; k.cmdv = c4.y; k.mub = c4.z; k.tv = c4.w;
-          k.e = c5.x; k.Fr = c5.y; k.invNn = c5.z; k.mF1 = c5.w;
-          k.F0 = c6.x; k.cj = c6.y; k.inv_csum = c6.z; k.A = c6.w;
-          k.vp = c7.x; k.inl = c7.y; k.wq = c7.z; k.idx = __builtin_bit_cast(int, idx_bits);
-          k.zc = c8.x; k.mcv = c8.y; k.wa = c8.z; k.wb = c8.w;
-          k.il = c9.x; k.cmask = c9.y; k.omc = c9.z; up.gXs = c9.w;
+          c.R0 = c0.x; c.R1 = c0.y; c.R2 = c0.z; c.h = c0.w;
+          c.w1 = c1.x; c.w2 = c1.y; c.r1 = c1.z; c.r2 = c1.w;
+          c.f1 = c2.x; c.f2 = c2.y; c.mw = c2.z; c.stvG = c2.w;
+          c.NnG = c3.x; c.nrm = c3.y; c.s = c3.z; c.sn = c3.w;
+          c.cmdv = c4.x; c.mub = c4.y; c.tvm = c4.z; c.FrN = c4.w;
+          c.csm = c5.x; c.nm1 = c5.y; c.A = c5.z; c.kcs = c5.w;
+          c.dcs = c6.x; c.Aic = c6.y; c.Acc = c6.z; c.dcj = c6.w;
+          c.vp = c7.x; c.inlr = c7.y; c.wq = c7.z; c.idx = __builtin_bit_cast(int, idx_bits);
+          c.zc = c8.x; c.mcv = c8.y; c.wsb = c8.z; c.wsa = c8.w;
+          c.e = c9.x; c.il = c9.y; c.eci = c9.z; up.gXs = c9.w;
           if constexpr (!XS_ONLY) {
             const f4v g0 = o[640];
             const float* g1 = reinterpret_cast<const float*>(o + 704);      // (three floats: an unused fourth would be a free register to the allocator)
@@ -649,23 +633,105 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
           asm volatile("" ::: "memory");
           vflags[1] = consumed;                        // (LDS runs a wave's operations in order: the reads above are done by then)
         };
-        auto crunch = [&](int n, const Rec& k, const UpIn& up, Rec& k_next, UpIn& up_next, auto more) {
+        // The chain of `vjp` (default integrator) on those coefficients, with the adjoint state UN-SUMMED over the contact points:
+        // each quad holds its own part and the state is the sum of the four.  Every use of it is linear, and only the two values
+        // met by per-point data -- the adjoints of the linear and angular velocity -- need the sum every step: five lane sums
+        // per step (ten DPP adds; tools/microbench/dpp_latency.hip prices them) become six after the loop.
+        auto chain = [&](int n, const Coef& c, const UpIn& up) {
+          const float h = c.h;
+          float gFr_up = zero, gFf_up = zero;
+          if constexpr (!XS_ONLY) {
+            laFs += act ? up.gFs : zero;
+            laFf += act ? up.gFf : zero;
+            gFr_up = h * laFs; gFf_up = h * laFf;
+          }
+          const float gxdd = h * sum_points(lxd), gwd = h * sum_points(lw);
+          lxd = fmaf(h, lx, lxd);
+          const float g0 = h * lR0, g1 = h * lR1, g2 = h * lR2;
+          const float g01 = dpp<kRot1>(g0), g02 = dpp<kRot2>(g0), g11 = dpp<kRot1>(g1), g12 = dpp<kRot2>(g1), g21 = dpp<kRot1>(g2), g22 = dpp<kRot2>(g2);
+          lw += (dpp<kRot1>(c.R0) * g02 - dpp<kRot2>(c.R0) * g01) + (dpp<kRot1>(c.R1) * g12 - dpp<kRot2>(c.R1) * g11) + (dpp<kRot1>(c.R2) * g22 - dpp<kRot2>(c.R2) * g21);
+          lR0 += g01 * c.w2 - g02 * c.w1;
+          lR1 += g11 * c.w2 - g12 * c.w1;
+          lR2 += g21 * c.w2 - g22 * c.w1;
+          // ---- RHS backward ----
+          const float mwd = c.mw * gwd;
+          const float gtau = J0 * dpp<kB0>(mwd) + J1 * dpp<kB1>(mwd) + J2 * dpp<kB2>(mwd);      // I^-T m
+          const float gt1 = dpp<kRot1>(gtau), gt2 = dpp<kRot2>(gtau);
+          const float gq = fmaf(gxdd, a.inv_mass, gt1 * c.r2 - gt2 * c.r1);      // to both force outputs: sum + (tau += r x f)
+          float gr = c.f1 * gt2 - c.f2 * gt1;
+          float gFr = gFr_up + gq;
+          const float gFf_ = gFf_up + gq;
+          const float gNn = dot3(gFf_, c.stvG);
+          const float gst = c.NnG * gFf_;
+          const float gsn = -dot3(gst, c.nrm);
+          float gn = gsn * c.s - c.sn * gst;
+          const float gslip = fmaf(gsn, c.nrm, gst);
+          const float gmuq = dot3(gslip, c.cmdv);
+          const float gcmd = c.mub * gslip;
+          float gvp = -gcmd;
+          const float ge_p = c.tvm * gslip;
+          float gv_p = zero, gwc_p = zero;
+          if constexpr (GCTRL) {
+            const float gtv = dot3(gcmd, c.e);                 // tv_v = tv_w = 0 for non-driving points
+            gv_p = tv_v * gtv; gwc_p = tv_w * gtv;
+          }
+          gFr = fmaf(gNn, c.FrN, gFr);
+          const float gF0 = gFr * c.csm;
+          const float d1 = dot3(gFr, c.nm1);
+          gn = fmaf(-c.A, gF0, gn);
+          const float gvn = c.dcs * d1;
+          gvp = fmaf(gvn, c.nrm, gvp);
+          gn = fmaf(gvn, c.vp, gn);
+          const float gcw = fmaf(c.Aic, d1, sum_points(c.Acc * d1));
+          const float gdh = fmaf(gcw, c.dcj, c.kcs * d1);
+          const float gzq = -gdh;
+          // the terrain / friction gradient of the footprint cell: n = u / |u|, u = (-gx, -gy, 1)
+          const float dotn = dot3(gn, c.nrm);
+          const float gg = (gn - dotn * c.nrm) * c.inlr;                // lane 0: ggx, lane 1: ggy
+          const float ggp = dpp<0x51>(gg);                               // quad_perm [1,0,1,1]
+          const float nz = fmaf(gzq, c.wq, cgA * gg + cgB * ggp);
+          const float nm = gmuq * c.wq;
+          {   // this lane's cell accumulator
+            const unsigned ni = (unsigned)c.idx;
+            const bool same = !act | (ni == acc_idx);            // absent points contribute exact zeros: never flushed
+            st_pending = !same;
+            st_idx = acc_idx; st_z = acc_z; st_m = acc_m;
+            acc_idx = act ? ni : acc_idx;
+            acc_z = same ? acc_z + nz : nz;
+            acc_m = same ? acc_m + nm : nm;
+          }
+          const float vq = gzq * c.zc + gmuq * c.mcv;
+          const float gpx = dot4(vq, c.wsb), gpy = dot4(vq, c.wsa);
+          const float gp = mask_or(mask_or(mask_or(zero, gpx, lane0), gpy, lane1), gdh, lane2);
+          const float gvp1 = dpp<kRot1>(gvp), gvp2 = dpp<kRot2>(gvp);
+          gr += gvp1 * c.w2 - gvp2 * c.w1;                       // dr += gvp x w
+          const float gw_p = c.r1 * gvp2 - c.r2 * gvp1;          // dw += r x gvp
+          const float qa = gp + gr;
+          lx += gp; lxd += gvp; lw += gw_p;
+          lR0 = fmaf(qa, P0, lR0); lR1 = fmaf(qa, P1, lR1); lR2 = fmaf(qa, P2, lR2);
+          float gv = zero, gwc = zero;
+          if constexpr (GCTRL) { gv = sum_points(gv_p); gwc = sum_points(gwc_p); }
+          lR0 = fmaf(-dot3(ge_p, c.e), c.eci, fmaf(ge_p, c.il, lR0));      // e = col0(R) / max(|col0|, eps)
+          gctrl_pending = __builtin_amdgcn_readfirstlane((unsigned)n * 8u); gv_pending = gv; gwc_pending = gwc;
+        };
+        auto crunch = [&](int n, const Coef& c, const UpIn& up, Coef& c_next, UpIn& up_next, auto more) {
           add_upstream_state(up);
-          if constexpr (decltype(more)::value) take(k_next, up_next);
+          if constexpr (decltype(more)::value) take(c_next, up_next);
           flush_stash();
           if constexpr (GCTRL) bstore2(rGctrl, v_ctrl, gctrl_pending, gv_pending, gwc_pending);
-          vjp(n, k, up);
+          chain(n, c, up);
         };
         using std::true_type;
         using std::false_type;
+        Coef cA, cB;
         if (n_steps > 0) {
-          take(recA, uA);
+          take(cA, uA);
           for (; n >= 2; n -= 2) {
-            crunch(n, recA, uA, recB, uB, true_type{});
-            crunch(n - 1, recB, uB, recA, uA, true_type{});
+            crunch(n, cA, uA, cB, uB, true_type{});
+            crunch(n - 1, cB, uB, cA, uA, true_type{});
           }
-          if (n == 1) { crunch(1, recA, uA, recB, uB, true_type{}); crunch(0, recB, uB, recA, uA, false_type{}); }
-          else crunch(0, recA, uA, recB, uB, false_type{});
+          if (n == 1) { crunch(1, cA, uA, cB, uB, true_type{}); crunch(0, cB, uB, cA, uA, false_type{}); }
+          else crunch(0, cA, uA, cB, uB, false_type{});
         }
         lx = sum_points(lx); lxd = sum_points(lxd); lw = sum_points(lw);      // the state proper
         lR0 = sum_points(lR0); lR1 = sum_points(lR1); lR2 = sum_points(lR2);
