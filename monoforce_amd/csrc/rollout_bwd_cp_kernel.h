@@ -147,7 +147,13 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
       u.gFs = bload1(rgFs, u_fs, uo * sg_fs); u.gFf = bload1(rgFf, u_ff, uo * sg_ff);
     }
   };
-  auto add_upstream_state = [&](const UpIn& u) {
+  // The adjoint state (lx, lxd, lw, lR) is kept UN-SUMMED over the contact points: each quad holds its own part and the state
+  // is the sum of the four.  Every use of it is linear, and only the two values met by per-point data -- the adjoints of the
+  // linear and angular velocity -- need the sum every step: five lane sums per step (ten DPP adds, ~7 cycles each at one wave
+  // per SIMD: tools/microbench/dpp_latency.hip) become six after the loop.  The upstream gradient of a state row goes to the
+  // quad of point 0.
+  const float first = p == 0 ? one : zero;
+  auto add_upstream_masked = [&](const UpIn& u) {       // u: already zero outside point 0's quad
     lx += u.gXs;
     lR2 = fmaf(u.gXs, a.sink, lR2);                     // Xs = x + R[:, 2] * sink
     if constexpr (!XS_ONLY) {
@@ -155,6 +161,12 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
       lR0 += u.gR0; lR1 += u.gR1; lR2 += u.gR2;
       lw += u.gOm;
     }
+  };
+  auto add_upstream_state = [&](const UpIn& u) {
+    UpIn m = u;
+    m.gXs = first * u.gXs;
+    if constexpr (!XS_ONLY) { m.gXds = first * u.gXds; m.gR0 = first * u.gR0; m.gR1 = first * u.gR1; m.gR2 = first * u.gR2; m.gOm = first * u.gOm; }
+    add_upstream_masked(m);
   };
 
   // ODEINT: the last control is never used by the explicit scheme.  DYNAMICS uses all T of them: the deferred store below
@@ -257,7 +269,7 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
         laFf += act ? up.gFf : zero;
         gFr_up = h * laFs; gFf_up = h * laFf;
       }
-      gxdd = h * lxd; gwd = h * lw;
+      gxdd = h * sum_points(lxd); gwd = h * sum_points(lw);
       lxd = fmaf(h, lx, lxd);                               // x' = x + h xd
       // R' = R + h [w]x R, column by column: d/dw of (w x R_j) . g_j = R_j x g_j ; d/dR_j = g_j x w   (g_j = h lR[:, j])
       const float g0 = h * lR0, g1 = h * lR1, g2 = h * lR2;
@@ -304,9 +316,9 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
       gth = fmaf(-gkw, idn2, gth);
       const float ith = th2 > zero ? M::div(one, th) : zero;    // d|w'|/dw' = w' / |w'|, 0 at 0
       lw += fmaf(gth * ith, wn, gk * idn);
-      gwd = h * lw;
+      gwd = h * sum_points(lw);
       lxd = fmaf(h, lx, lxd);
-      gxdd = h * lxd;
+      gxdd = h * sum_points(lxd);
       // lR <- lR M^T: column m of the result = sum_j lR[:, j] M[m][j], M[m][j] sits in lane m as m_{(j - m) % 3}
       const float n0 = lR0 * dpp<kB0>(m0) + lR1 * dpp<kB0>(m1) + lR2 * dpp<kB0>(m2);
       const float n1 = lR0 * dpp<kB1>(m2) + lR1 * dpp<kB1>(m0) + lR2 * dpp<kB1>(m1);
@@ -377,11 +389,9 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
     const float gw_p = r1 * gvp2 - r2 * gvp1;              // dw += r x gvp
     const float qa = gp + gr;                              // p = R P + x, r = p - x
     // sums over the contact points
-    lx += sum_points(gp);
-    lxd += sum_points(gvp);
-    lw += sum_points(gw_p);
-    lR0 += sum_points(qa * P0); lR1 += sum_points(qa * P1); lR2 += sum_points(qa * P2);
-    const float ge = sum_points(ge_p);
+    lx += gp; lxd += gvp; lw += gw_p;                      // (each quad's own part)
+    lR0 = fmaf(qa, P0, lR0); lR1 = fmaf(qa, P1, lR1); lR2 = fmaf(qa, P2, lR2);
+    const float ge = ge_p;
     float gv = zero, gwc = zero;
     if constexpr (GCTRL) { gv = sum_points(gv_p); gwc = sum_points(gwc_p); }
     {   // e = col0(R) / max(|col0|, eps): through |col0| only when it is >= eps
@@ -533,8 +543,7 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
             const float invNn = k.Nn > zero ? M::div(one, k.Nn) : zero;
             const float cmask = k.coln2 >= 1e-12f ? one : zero;
             const float cs = k.cj * k.inv_csum;
-            // (the adjoint state is kept un-summed over the points: the upstream gradient of a state row goes to point 0's quad)
-            const float first = p == 0 ? one : zero;
+            // (the upstream gradient of a state row goes to point 0's quad: add_upstream_masked)
             f4v* o = ring + (produced & (kSlots - 1)) * (kPlanes * 64) + lane;
             o[0] = f4v{k.R0, k.R1, k.R2, k.h};
             o[64] = f4v{k.w1, k.w2, k.r1, k.r2};
@@ -633,10 +642,7 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
           asm volatile("" ::: "memory");
           vflags[1] = consumed;                        // (LDS runs a wave's operations in order: the reads above are done by then)
         };
-        // The chain of `vjp` (default integrator) on those coefficients, with the adjoint state UN-SUMMED over the contact points:
-        // each quad holds its own part and the state is the sum of the four.  Every use of it is linear, and only the two values
-        // met by per-point data -- the adjoints of the linear and angular velocity -- need the sum every step: five lane sums
-        // per step (ten DPP adds; tools/microbench/dpp_latency.hip prices them) become six after the loop.
+        // The chain of `vjp` (default integrator) on those coefficients.
         auto chain = [&](int n, const Coef& c, const UpIn& up) {
           const float h = c.h;
           float gFr_up = zero, gFf_up = zero;
@@ -715,7 +721,7 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
           gctrl_pending = __builtin_amdgcn_readfirstlane((unsigned)n * 8u); gv_pending = gv; gwc_pending = gwc;
         };
         auto crunch = [&](int n, const Coef& c, const UpIn& up, Coef& c_next, UpIn& up_next, auto more) {
-          add_upstream_state(up);
+          add_upstream_masked(up);
           if constexpr (decltype(more)::value) take(c_next, up_next);
           flush_stash();
           if constexpr (GCTRL) bstore2(rGctrl, v_ctrl, gctrl_pending, gv_pending, gwc_pending);
@@ -733,8 +739,6 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
           if (n == 1) { crunch(1, cA, uA, cB, uB, true_type{}); crunch(0, cB, uB, cA, uA, false_type{}); }
           else crunch(0, cA, uA, cB, uB, false_type{});
         }
-        lx = sum_points(lx); lxd = sum_points(lxd); lw = sum_points(lw);      // the state proper
-        lR0 = sum_points(lR0); lR1 = sum_points(lR1); lR2 = sum_points(lR2);
         uA = uZ; uB = uZ;                             // (the epilogue reads whichever the last iteration would have requested into)
       } else {
       auto run = [&](int n, const StateIn& st, const Saved& sv, const UpIn& up, StateIn& st_next, Saved& sv_next, UpIn& up_next, auto more) {
@@ -813,6 +817,8 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
     if (n_steps == 0) load_upstream(0, up);    // T == 1: the loop never ran
     add_upstream_state(up);
   }
+  lx = sum_points(lx); lxd = sum_points(lxd); lw = sum_points(lw);      // the adjoint of the initial state proper
+  lR0 = sum_points(lR0); lR1 = sum_points(lR1); lR2 = sum_points(lR2);
 
   // terrain snap of the initial height: x.z = mean_i blend(z; cell((R0 P_i + x0).xy))   (dphysics.py:567-571)
   float gx0 = lx;
