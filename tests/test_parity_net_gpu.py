@@ -488,3 +488,33 @@ def test_backward_from_the_forward_record_equals_the_recomputing_backward():
     rs, rf = orc.rollout(spec, z.unsqueeze(0).expand(B, -1, -1), ctrl, friction=mu.unsqueeze(0).expand(B, -1, -1))
     hp.probe_loss(list(rs) + list(rf), torch.float64).backward()
     assert hp.rel_err(with_rec['gz'], z.grad) <= 2e-4 and hp.rel_err(with_rec['gmu'], mu.grad) <= 2e-4 and hp.rel_err(with_rec['gc'], ctrl.grad) <= 2e-4
+
+
+@pytest.mark.parametrize('loss_on', ['all', 'positions'])
+def test_streaming_backward_every_horizon_remainder(loss_on):
+    """The backward that streams the forward's record through LDS (rollout_bwd_cp_kernel.h, MODE = kCpStream) fetches in batches
+    of three steps, two batches in registers, and peels the last steps; the computing wave runs two steps per trip.  Horizons
+    1 .. 14 and 20 / 47 / 48 put every remainder of those loops through it (all-outputs loss with control gradients, and the
+    positions-only variant of the training loss), against the one-point-per-lane kernels: float32 rounding apart."""
+    from monoforce_amd import synthetic as syn
+    pts, masks = syn.robot_points_4()
+    B = 6
+    z = torch.stack([syn.bump_terrain(syn.bump_params(20 + k), 1.6, 0.1) * 0.3 for k in range(B)])
+    mu = torch.stack([syn.wave_friction(1.6, 0.1, 0.5, 1.0, 1.1 + 0.2 * k, 0.8) for k in range(B)])
+    for T in list(range(1, 15)) + [20, 47, 48]:
+        ctrl = syn.varying_controls(B, max(T, 2), seed=3)[:, :T]
+        res = {}
+        for ppl in (16, 1):
+            dp = make_dphysics(pts, masks, 1, 0.1, 1.6, points_per_lane=ppl)
+            zd, md, cd = z.cuda().requires_grad_(True), mu.cuda().requires_grad_(True), ctrl.cuda().requires_grad_(True)
+            st, fo = dp(zd, cd, friction=md)
+            if loss_on == 'all':
+                hp.probe_loss(list(st) + list(fo), torch.float32).backward()
+            else:
+                (st[0] * syn.probe_weights(st[0].shape, phase=0.4).cuda()).sum().backward()
+            res[ppl] = (zd.grad.cpu(), md.grad.cpu(), cd.grad.cpu())
+        for name, a_, b_ in zip(('gz', 'gmu', 'gctrl'), res[16], res[1]):
+            if float(b_.abs().max()) == 0.0:
+                assert float(a_.abs().max()) == 0.0, (T, name)
+            else:
+                assert hp.rel_err(a_, b_) <= 2e-5, (T, name, hp.rel_err(a_, b_))
