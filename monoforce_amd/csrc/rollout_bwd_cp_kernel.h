@@ -615,10 +615,14 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
           float e, il, eci;                     // gate_col0 e / |col0|
           int idx;
         };
-        auto take = [&](Coef& c, UpIn& up) {          // the next step out of the ring
+        // (the loop asks for the two steps of a trip at once, and reports them read at once: the counters cost an LDS
+        //  instruction each, ~14 cycles of this wave)
+        auto ensure = [&](int k) {                    // until k more steps are in the ring
           int have = __builtin_amdgcn_readfirstlane(seen);
-          while (have <= consumed) have = __builtin_amdgcn_readfirstlane(vflags[0]);
+          while (have < consumed + k) have = __builtin_amdgcn_readfirstlane(vflags[0]);
           asm volatile("" ::: "memory");
+        };
+        auto grab = [&](Coef& c, UpIn& up) {          // the next step out of the ring (it is there: ensure)
           const f4v* o = ring + (consumed & (kSlots - 1)) * (kPlanes * 64) + lane;
           const f4v c0 = o[0], c1 = o[64], c2 = o[128], c3 = o[192], c4 = o[256], c5 = o[320], c6 = o[384], c7 = o[448], c8 = o[512], c9 = o[576];
           const float idx_bits = c7.w;       // (__builtin_bit_cast applied to the element expression itself reads element 0 of the vector)
@@ -638,10 +642,13 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
             up.gXds = g0.x; up.gOm = g0.y; up.gFs = g0.z; up.gFf = g0.w; up.gR0 = g1[0]; up.gR1 = g1[1]; up.gR2 = g1[2];
           }
           ++consumed;
+        };
+        auto release = [&]() {                        // the steps grabbed so far may be overwritten
           seen = vflags[0];
           asm volatile("" ::: "memory");
-          vflags[1] = consumed;                        // (LDS runs a wave's operations in order: the reads above are done by then)
+          vflags[1] = consumed;                        // (LDS runs a wave's operations in order: the reads of grab are done by then)
         };
+        auto take = [&](Coef& c, UpIn& up) { ensure(1); grab(c, up); release(); };
         // The chain of `vjp` (default integrator) on those coefficients.
         auto chain = [&](int n, const Coef& c, const UpIn& up) {
           const float h = c.h;
@@ -720,9 +727,11 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
           lR0 = fmaf(-dot3(ge_p, c.e), c.eci, fmaf(ge_p, c.il, lR0));      // e = col0(R) / max(|col0|, eps)
           gctrl_pending = __builtin_amdgcn_readfirstlane((unsigned)n * 8u); gv_pending = gv; gwc_pending = gwc;
         };
-        auto crunch = [&](int n, const Coef& c, const UpIn& up, Coef& c_next, UpIn& up_next, auto more) {
+        auto crunch = [&](int n, const Coef& c, const UpIn& up, Coef& c_next, UpIn& up_next, auto more, auto paired) {
           add_upstream_masked(up);
-          if constexpr (decltype(more)::value) take(c_next, up_next);
+          if constexpr (decltype(paired)::value == 1) grab(c_next, up_next);                     // first of a pair: ensured by the loop
+          else if constexpr (decltype(paired)::value == 2) { grab(c_next, up_next); release(); } // second of a pair
+          else if constexpr (decltype(more)::value) take(c_next, up_next);
           flush_stash();
           if constexpr (GCTRL) bstore2(rGctrl, v_ctrl, gctrl_pending, gv_pending, gwc_pending);
           chain(n, c, up);
@@ -732,12 +741,14 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
         Coef cA, cB;
         if (n_steps > 0) {
           take(cA, uA);
+          using single = std::integral_constant<int, 0>;
           for (; n >= 2; n -= 2) {
-            crunch(n, cA, uA, cB, uB, true_type{});
-            crunch(n - 1, cB, uB, cA, uA, true_type{});
+            ensure(2);
+            crunch(n, cA, uA, cB, uB, true_type{}, std::integral_constant<int, 1>{});
+            crunch(n - 1, cB, uB, cA, uA, true_type{}, std::integral_constant<int, 2>{});
           }
-          if (n == 1) { crunch(1, cA, uA, cB, uB, true_type{}); crunch(0, cB, uB, cA, uA, false_type{}); }
-          else crunch(0, cA, uA, cB, uB, false_type{});
+          if (n == 1) { crunch(1, cA, uA, cB, uB, true_type{}, single{}); crunch(0, cB, uB, cA, uA, false_type{}, single{}); }
+          else crunch(0, cA, uA, cB, uB, false_type{}, single{});
         }
         uA = uZ; uB = uZ;                             // (the epilogue reads whichever the last iteration would have requested into)
       } else {
