@@ -477,6 +477,13 @@ def main():
             for name in ('c1', 'c2'):
                 others[name] = brief(r.run(name, short, 3)[0])
             others['shoot'] = shoot_workload(r, T, N, args.integrator)
+            if args.integrator == 1:      # the other integrator side by side -- dynamics() (use_odeint=False), same shapes
+                args.integrator = 0
+                try:
+                    others['c3_dynamics'] = brief(r.run('c3', short, 3)[0])
+                    others['c3f_dynamics'] = brief(r.run('c3f', short, 3)[0])
+                finally:
+                    args.integrator = 1
             others['c4'] = brief(r.run('c4', 5, 4)[0])
         else:
             others['strong_c3'] = brief(r.run('c3', short, 3, batch=max(8192 // r.world, 1))[0])
