@@ -509,10 +509,11 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
         // MODE = kCpStream: the record-reading kernel waits for HBM -- SQ_WAIT_ANY 22 % with the record and the rows requested one
         // step (0.6 us) ahead, and a single wave cannot request further ahead (the values crossing the loop's back edge get copied
         // there, which drains them).  A SECOND wave of the workgroup (B <= 1024 leaves three SIMDs of every CU idle) therefore
-        // does nothing but fetch: four steps per trip straight into registers -- thirty-odd loads in flight -- then into an LDS
-        // ring of eight slots; the first wave reads a step's planes from LDS and runs the same rebuild + chain as before.  Two
-        // LDS counters (records written / records read) instead of barriers; LDS executes a wave's operations in order, so a
-        // counter written after a slot is seen after it.
+        // fetches: three steps per batch straight into registers, two batches in flight, and -- it has the time -- turns each
+        // step's rows and record into the COEFFICIENTS of its vector-Jacobian product (struct Coef) before writing them into an
+        // LDS ring of eight slots; the first wave reads a step's coefficients from LDS and runs the adjoint recurrence on them
+        // (`chain`).  Two LDS counters (steps written / steps read) instead of barriers; LDS executes a wave's operations in
+        // order, so a counter written after a slot is seen after it.  (0.30 -> 0.20 ms at B = 1024: DESIGN.md 4.2b has the steps.)
         constexpr int kSlots = 8, kPlanes = XS_ONLY ? 10 : 12;
         __shared__ f4v ring[kSlots * kPlanes * 64];
         __shared__ int flags[2];
