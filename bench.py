@@ -179,9 +179,20 @@ class Runner:
         self.dev = torch.device('cuda', local_rank)
         self.backend = os.environ.get('MF_BENCH_BACKEND', 'nccl')      # "nccl" is RCCL on ROCm
         self.dist_world = 1
-        if self.world > 1:
+        # MF_BENCH_FORCE_DIST=1 with ONE rank: a one-rank process group, every collective of the N > 1 step still issued (RCCL
+        # init with device_id, all_reduce(AVG) in place behind a hipGraph replay, the hooked bucket exchange) -- so that code has run
+        # on a one-GPU box before the first multi-GPU run
+        self.force_dist = bool(os.environ.get('MF_BENCH_FORCE_DIST')) and self.world == 1
+        self.dist_on = self.world > 1 or self.force_dist
+        if self.dist_on:
             import torch.distributed as dist
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            if self.force_dist:
+                from monoforce_amd import dist as mfdist
+                os.environ.setdefault('MASTER_PORT', str(_free_port()))
+                os.environ.setdefault('RANK', '0')
+                os.environ.setdefault('WORLD_SIZE', '1')
+                mfdist.FORCE = True
             if self.backend == 'nccl':
                 dist.init_process_group('nccl', device_id=self.dev)
             else:
@@ -191,18 +202,29 @@ class Runner:
         self.traffic = json.load(open(traffic_file)) if os.path.exists(traffic_file) else {}
 
     def barrier(self):
-        if self.world > 1:
+        if self.dist_on:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
 
-    def max_over_ranks(self, v):
-        if self.world > 1:
+    def max_over_ranks(self, v, op='MAX'):
+        if self.dist_on:
             import torch.distributed as dist
             tt = torch.tensor([v], device=self.dev if self.backend == 'nccl' else 'cpu', dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dist.all_reduce(tt, op=getattr(dist.ReduceOp, op))
             v = float(tt.item())
         return v
+
+    def time_exchange(self, fn, n=20):
+        """ms per call of the step's gradient exchange ALONE (its collectives and nothing else), max over ranks."""
+        for _ in range(3):
+            fn()
+        self.barrier()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize(self.dev)
+        return self.max_over_ranks((time.perf_counter() - t) / n * 1e3)
 
     def run(self, name, steps, warmup, batch=0):
         from monoforce_amd import _timing
@@ -304,7 +326,15 @@ class Runner:
         self.barrier()
         elapsed = time.perf_counter() - t0
         kern = {k: float(np.mean(v)) for k, v in _timing.stop().items()}       # average launch duration per kernel, ms
-        elapsed = self.max_over_ranks(elapsed)
+        elapsed_min, elapsed = self.max_over_ranks(elapsed, 'MIN'), self.max_over_ranks(elapsed)
+        # the exchange step on its own (the backward's one collective), so that a scaling curve can be read
+        comm_ms = None
+        if self.dist_on and wl['backward']:
+            if wl.get('encoder'):
+                comm_ms = self.time_exchange(estep.exchange_only, n=5)
+            else:
+                zero = torch.zeros((), device=dev)
+                comm_ms = self.time_exchange(lambda: prob._exchange(zleaf, mleaf, zero))
 
         P4 = 4 * 59 * 16 * 32                                  # frustum points per sample at the config-4 shapes
         alg = {'rollout_fwd_kernel': fwd_bytes_per_rollout_step(N) * B * T, 'rollout_bwd_kernel': bwd_bytes_per_rollout_step(N) * B * T,
@@ -334,6 +364,7 @@ class Runner:
             rec_bytes = int(_lib.lib().mf_rollout_record_bytes(C.byref(d)))
         out = {
             'value': B_total * T * steps / elapsed, 'steps': steps, 'warmup': warmup, 'ms_per_step': elapsed / steps * 1e3,
+            'ms_per_step_ranks': {'min': elapsed_min / steps * 1e3, 'max': elapsed / steps * 1e3}, 'comm_ms': comm_ms,
             'scaling': 'strong' if strong else 'weak',
             'config': {'workload': f'{name}: B={B}/GPU x T={T} x N={N} contact points, {H}x{H} grid (res {res} m), one shared '
                                    f'terrain+friction map (the same on every rank), integrator={integ}, {mode}; {wl["desc"]}',
@@ -470,9 +501,10 @@ def main():
         res['roofline']['per_kernel']['rollout_fwd_kernel_all_outputs'] = f['roofline']['per_kernel']['rollout_fwd_kernel']
 
         def brief(o):
-            return {'value': o['value'], 'unit': 'rollout-steps/s', 'ms_per_step': o['ms_per_step'], 'scaling': o['scaling'],
+            return {'value': o['value'], 'unit': 'rollout-steps/s', 'ms_per_step': o['ms_per_step'], 'ms_per_step_ranks': o['ms_per_step_ranks'],
+                    'comm_ms': o['comm_ms'], 'scaling': o['scaling'],
                     'workload': o['config']['workload'], 'launch': o['config'].get('launch'), 'per_kernel': o['roofline']['per_kernel']}
-        if r.world == 1:
+        if r.world == 1 and not r.force_dist:
             res['roofline']['batch_sweep'] = r.batch_sweep(N, T)
             for name in ('c1', 'c2'):
                 others[name] = brief(r.run(name, short, 3)[0])
@@ -491,17 +523,18 @@ def main():
             others['c5'] = brief(r.run('c5', 5, 4)[0])
     if r.rank == 0:
         out = {'metric': 'rollout-steps/sec (batch x horizon) on 256x256 terrain', 'value': res['value'], 'unit': 'rollout-steps/s',
-               'n_gpus': r.world, 'world_size': r.dist_world, 'backend': ('rccl' if r.backend == 'nccl' else r.backend) if r.world > 1 else None,
+               'n_gpus': r.world, 'world_size': r.dist_world, 'backend': ('rccl' if r.backend == 'nccl' else r.backend) if r.dist_on else None,
                'steps': res['steps'], 'warmup': res['warmup'], 'ms_per_step': res['ms_per_step'],
+               'ms_per_step_ranks': res['ms_per_step_ranks'], 'comm_ms': res['comm_ms'],
                'higher_is_better': True, 'scaling': res['scaling'], 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
                'config': res['config'], 'roofline': res['roofline']}
         out.update(extras)
         if others:
             out['other_workloads'] = others
         if not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(N, args.integrator, T) if r.world == 1 else None      # timed at N=1 only
+            out['cpu_baseline'] = cpu_baseline(N, args.integrator, T) if not r.dist_on else None      # timed at N=1 only
         print(json.dumps(out))
-    if r.world > 1:
+    if r.dist_on:
         import torch.distributed as dist
         dist.destroy_process_group()
 

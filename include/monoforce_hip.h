@@ -61,9 +61,9 @@ enum {
 
 /* MfRolloutDesc.points_per_lane, besides 0 / 1 / 4: the component-parallel mapping -- a rollout over a 16-lane row, four lanes
  * per contact point (lane = vector component / footprint cell).  float32 MF_MATH_FAST rigid bodies of <= 4 points, full or
- * states-only outputs; with points_per_lane = 0 it is chosen by itself for small launches (forward: B <= 4096, backward --
- * default integrator only -- B <= 8192), where a step costs ~2x fewer instructions per wave than one point per lane.  Other configurations fall
- * back to the automatic choice. */
+ * states-only outputs, BOTH integrators (forward and backward); with points_per_lane = 0 it is chosen by itself for small
+ * launches (forward: up to 1024 waves = B <= 4096, backward: up to 2048 waves = B <= 8192), where a step costs ~2x fewer
+ * instructions per wave than one point per lane.  Other configurations fall back to the automatic choice. */
 enum { MF_LANES_COMPONENT = 16 };
 
 /* Shapes and physical constants of one rollout launch.  Scalars are double here and are rounded ONCE to the
@@ -329,6 +329,23 @@ typedef struct MfHeightmapDesc {
 } MfHeightmapDesc;
 int mf_estimate_heightmap_f32(const MfHeightmapDesc* desc, const float* points, const float* x_bins, const float* y_bins,
                               int32_t* scratch, float* hm, void* hip_stream);
+
+/* ---- interpolate_grid (dphysics.py:385-455) on its own: the reference's public sampling method, bug for bug --
+ * grid[Bg][H][W] with Bg = B, or one map for all rows (map_shared); xq, yq [B][N] query positions; z_out [B][N];
+ * n_out [B][N][3] unit normals (may be NULL: return_normals=False); cells_out [B][N][4] int32 (may be NULL) = the CLAMPED flat
+ * indices (c, f, l, fl) the value was read from, and frac_out [B][N][2] (may be NULL) = (x_frac, y_frac): the integer half of
+ * the function, exposed so a test can compare it with `((q + d_max) / grid_res).long()` directly.  The device code is the
+ * rollout kernels' own (locate_m / gather / blend of rollout_fwd_kernel.h), in either arithmetic mode. */
+typedef struct MfInterpDesc {
+  int32_t B, N, H, W;
+  int32_t map_shared;
+  int32_t math_mode; /* MF_MATH_* (float32; float64 is always exact) */
+  double grid_res, d_max;
+} MfInterpDesc;
+int mf_interpolate_grid_f32(const MfInterpDesc* desc, const float* grid, const float* xq, const float* yq, float* z_out, float* n_out,
+                            int32_t* cells_out, float* frac_out, void* hip_stream);
+int mf_interpolate_grid_f64(const MfInterpDesc* desc, const double* grid, const double* xq, const double* yq, double* z_out, double* n_out,
+                            int32_t* cells_out, double* frac_out, void* hip_stream);
 
 /* Text of the calling thread's last error ("" if none). */
 const char* mf_last_error(void);

@@ -53,6 +53,11 @@ class MfStageDesc(C.Structure):
     _fields_ = [('B', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('k', C.c_int32)]
 
 
+class MfInterpDesc(C.Structure):
+    _fields_ = [('B', C.c_int32), ('N', C.c_int32), ('H', C.c_int32), ('W', C.c_int32), ('map_shared', C.c_int32), ('math_mode', C.c_int32),
+                ('grid_res', C.c_double), ('d_max', C.c_double)]
+
+
 class MfHeightmapDesc(C.Structure):
     _fields_ = [('n_points', C.c_int32), ('nx', C.c_int32), ('ny', C.c_int32), ('d_max', C.c_float), ('h_min', C.c_float),
                 ('h_max', C.c_float), ('r_min', C.c_float), ('inv_res', C.c_float)]
@@ -62,7 +67,7 @@ class MfHeightmapDesc(C.Structure):
 SYMBOLS = ['mf_rollout_force_stride', 'mf_rollout_fwd_f32', 'mf_rollout_fwd_f64', 'mf_rollout_default_state_f32', 'mf_rollout_default_state_f64', 'mf_rollout_bwd_f32', 'mf_rollout_bwd_f64', 'mf_rollout_bwd_wants_gcontrols', 'mf_rollout_record_bytes', 'mf_bev_splat_workspace_bytes', 'mf_bev_splat_prepare', 'mf_bev_splat_prepare_cameras',
            'mf_bev_splat_fwd_f32', 'mf_bev_splat_fwd_f64', 'mf_bev_splat_bwd_f32', 'mf_bev_splat_bwd_f64',
            'mf_bev_lift_splat_fwd_f32', 'mf_bev_lift_splat_fwd_f64', 'mf_bev_lift_splat_bwd_f32', 'mf_bev_lift_splat_bwd_f64',
-           'mf_physics_loss_fwd_f32', 'mf_physics_loss_fwd_f64', 'mf_physics_loss_bwd_f32', 'mf_physics_loss_bwd_f64', 'mf_physics_loss_value_f32', 'mf_physics_loss_value_f64', 'mf_reduce_grad_copies_f32', 'mf_reduce_grad_copies_f64', 'mf_estimate_heightmap_f32', 'mf_terrain_stage_fwd_f32', 'mf_terrain_stage_bwd_f32', 'mf_last_error', 'mf_version', 'mf_sizeof']
+           'mf_physics_loss_fwd_f32', 'mf_physics_loss_fwd_f64', 'mf_physics_loss_bwd_f32', 'mf_physics_loss_bwd_f64', 'mf_physics_loss_value_f32', 'mf_physics_loss_value_f64', 'mf_reduce_grad_copies_f32', 'mf_reduce_grad_copies_f64', 'mf_estimate_heightmap_f32', 'mf_interpolate_grid_f32', 'mf_interpolate_grid_f64', 'mf_terrain_stage_fwd_f32', 'mf_terrain_stage_bwd_f32', 'mf_last_error', 'mf_version', 'mf_sizeof']
 
 _lib = None
 _lock = threading.Lock()
@@ -86,7 +91,7 @@ def lib():
                 L.mf_version.restype = C.c_char_p
                 for name in SYMBOLS:
                     fn = getattr(L, name)   # AttributeError if the build is stale
-                    if name.startswith(('mf_rollout', 'mf_bev', 'mf_physics', 'mf_estimate', 'mf_terrain', 'mf_reduce')):
+                    if name.startswith(('mf_rollout', 'mf_bev', 'mf_physics', 'mf_estimate', 'mf_terrain', 'mf_reduce', 'mf_interpolate')):
                         fn.restype = C.c_int
                 L.mf_bev_splat_workspace_bytes.restype = C.c_size_t
                 L.mf_rollout_record_bytes.restype = C.c_longlong
@@ -94,8 +99,13 @@ def lib():
     return _lib
 
 
+ON_ERROR = []      # callables run when an entry point reports an error (state that assumed the launch completed is dropped)
+
+
 def check(rc, what):
     if rc != 0:
+        for fn in list(ON_ERROR):
+            fn()
         raise RuntimeError(f'{what} failed (code {rc}): {lib().mf_last_error().decode()}')
 
 

@@ -34,6 +34,11 @@ def estimate_heightmap(points, grid_res, d_max, h_max, r_min=None, h_min=None):
     home = points.device
     dev = home if points.is_cuda else torch.device('cuda', torch.cuda.current_device())
     pts = points.detach()[:, :3].to(device=dev, dtype=torch.float32).contiguous()
+    if points.shape[1] > 3:
+        # the reference drops a row when ANY of its columns is NaN (cloudproc.py:90: `~torch.isnan(points).any(dim=1)`), the extra
+        # fields (intensity, ...) included: such a row gets a NaN x here, which the kernel's own filter then discards
+        extra_nan = torch.isnan(points.detach()[:, 3:]).any(dim=1).to(dev)
+        pts[:, 0] = torch.where(extra_nan, torch.full_like(pts[:, 0], float('nan')), pts[:, 0])
     xb = _bin_edges(d_max, grid_res, dev)
     n = xb.numel()
     desc = _lib.MfHeightmapDesc(n_points=pts.shape[0], nx=n, ny=n, d_max=float(d_max), h_min=float(-h_max if h_min is None else h_min),

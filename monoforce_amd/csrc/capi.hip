@@ -19,5 +19,6 @@ extern "C" int mf_sizeof(const char* name) {
   if (!strcmp(name, "MfLossDesc")) return (int)sizeof(MfLossDesc);
   if (!strcmp(name, "MfHeightmapDesc")) return (int)sizeof(MfHeightmapDesc);
   if (!strcmp(name, "MfStageDesc")) return (int)sizeof(MfStageDesc);
+  if (!strcmp(name, "MfInterpDesc")) return (int)sizeof(MfInterpDesc);
   return -1;
 }

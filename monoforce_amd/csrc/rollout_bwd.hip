@@ -30,7 +30,7 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
   a.B = d->B; a.T = d->T; a.N = d->N; a.H = d->H; a.W = d->W;
   a.n_tracks = d->n_tracks; a.layout = d->layout; a.map_shared = d->map_shared; a.skip_snap = d->skip_snap;
   a.grad_copies = d->grad_copies > 1 ? d->grad_copies : 1;
-  a.mass = (S)d->mass; a.inv_mass = (S)(1.0 / d->mass); a.inv_res = (S)(1.0 / d->grid_res); a.mg = (S)(d->mass * d->gravity); a.k = (S)d->stiffness; a.damp = (S)d->damping;
+  a.mass = (S)d->mass; a.inv_mass = (S)(1.0 / d->mass); a.inv_res = (S)(1.0 / (double)(S)d->grid_res); a.mg = (S)(d->mass * d->gravity); a.k = (S)d->stiffness; a.damp = (S)d->damping;
   a.omega_max = (S)d->omega_max; a.res = (S)d->grid_res; a.d_max = (S)d->d_max; a.dt = (S)d->dt;
   a.half_ly = (S)(d->robot_size_y / 2.0);
   a.sink = (S)(d->mass * d->gravity / (d->stiffness + 1e-6));
@@ -70,7 +70,7 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
   }
   const bool cp = sizeof(S) == 4 && use_component_parallel_bwd(d, p);
   MF_REQUIRE(p->gcontrols || cp, MF_ERR_INVALID, "rollout_bwd: gcontrols may be NULL only where the component-parallel kernels run "
-             "(float32 MF_MATH_FAST, N <= 4, default integrator, small batch)");
+             "(float32 MF_MATH_FAST, rigid body of N <= 4 points, either integrator, B <= 8192: mf_rollout_bwd_wants_gcontrols() == 0)");
   if (cp) {   // few rollouts of a small body: a rollout over 16 lanes
     if (p->rec && cp_record_bytes(d) > 0) {      // the forward kept its per-step record: read it instead of recomputing
       MF_REQUIRE(((uintptr_t)p->rec & 15) == 0, MF_ERR_INVALID, "rollout_bwd: rec must be 16-byte aligned");

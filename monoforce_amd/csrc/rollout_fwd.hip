@@ -39,7 +39,7 @@ static int fill_args(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutA
   MF_REQUIRE(a->ctrl_sb >= 0 && a->ctrl_st >= 0, MF_ERR_INVALID, "rollout_fwd: negative controls stride");
   a->fstride = fstride;
   a->mass = (S)d->mass; a->inv_mass = (S)(1.0 / d->mass); a->mg = (S)(d->mass * d->gravity); a->k = (S)d->stiffness;
-  a->damp = (S)d->damping; a->omega_max = (S)d->omega_max; a->res = (S)d->grid_res; a->inv_res = (S)(1.0 / d->grid_res);
+  a->damp = (S)d->damping; a->omega_max = (S)d->omega_max; a->res = (S)d->grid_res; a->inv_res = (S)(1.0 / (double)(S)d->grid_res);   // RN(1 / res) of the ROUNDED res (Mth::cell_coord)
   a->d_max = (S)d->d_max; a->dt = (S)d->dt;
   a->half_ly = (S)(d->robot_size_y / 2.0);
   a->sink = (S)(d->mass * d->gravity / (d->stiffness + 1e-6));

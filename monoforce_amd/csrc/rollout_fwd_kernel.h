@@ -76,7 +76,17 @@ struct Mth {
 template <>
 struct Mth<float, true> {
   static __device__ __forceinline__ float div(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
-  static __device__ __forceinline__ float cell_coord(float q, float d_max, float, float inv_res) { return (q + d_max) * inv_res; }
+  // The cell coordinate decides an INDEX (`.long()`, dphysics.py:419-420) and the interpolation is discontinuous across cell edges
+  // (SURVEY fact 5), so this one quotient is the reference's IEEE division bit for bit also in fast mode: u = a * (1 / res) is off
+  // by an ulp for about one argument in four -- enough to truncate a query on a cell edge into the neighbouring cell -- and one
+  // Newton step on the exact remainder, u' = fma(fma(-u, res, a), 1 / res, u), is the correctly rounded a / res when 1 / res is
+  // itself correctly rounded (Markstein's theorem; the host passes inv_res = RN(1 / res): tools/check_exact_div.py verifies it
+  // against the division for every float32 argument on the map at res = 0.05 / 0.1).  Two instructions on two lanes.
+  static __device__ __forceinline__ float cell_coord(float q, float d_max, float res, float inv_res) {
+    const float a = q + d_max;
+    const float u = a * inv_res;
+    return fmaf(fmaf(-u, res, a), inv_res, u);
+  }
   static __device__ __forceinline__ float sqrt(float v) { return __builtin_amdgcn_sqrtf(v); }
   static __device__ __forceinline__ float sigmoid_m10(float dh) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(14.426950408889634f * dh));  // exp(10 dh) = 2^(10 log2(e) dh)

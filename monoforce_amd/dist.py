@@ -13,19 +13,33 @@ import os
 import torch
 import torch.distributed as dist
 
-__all__ = ['init', 'world', 'rank', 'shard_range', 'shard', 'allreduce_sum_', 'FlatBucket', 'GradBuckets']
+__all__ = ['init', 'world', 'rank', 'active', 'shard_range', 'shard', 'allreduce_sum_', 'FlatBucket', 'GradBuckets']
+
+# MF_DIST_FORCE=1: run every collective even in a process group of ONE rank.  A one-GPU box can then execute the exact RCCL
+# code path of the multi-GPU step (init_process_group('nccl', device_id=...), all_reduce(AVG) in place, the hooked bucket
+# exchange, a hipGraph replay followed by a collective on the same stream) -- tests/test_dist_nccl_gpu.py, bench.py
+# MF_BENCH_FORCE_DIST=1 -- instead of the first 8-GPU run being the first run of that code.
+FORCE = bool(os.environ.get('MF_DIST_FORCE'))
 
 
-def init(backend=None, device=None):
-    """Initialise the default process group from torchrun's env (RANK / WORLD_SIZE / MASTER_*); no-op for 1 process."""
-    if int(os.environ.get('WORLD_SIZE', '1')) <= 1 or dist.is_initialized():
+def init(backend=None, device=None, force=False):
+    """Initialise the default process group from torchrun's env (RANK / WORLD_SIZE / MASTER_*); no-op for 1 process unless
+    `force` (a one-rank group: see FORCE)."""
+    if (int(os.environ.get('WORLD_SIZE', '1')) <= 1 and not force) or dist.is_initialized():
         return
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('MASTER_PORT', '29500')
+    os.environ.setdefault('RANK', '0')
+    os.environ.setdefault('WORLD_SIZE', '1')
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
     kw = {'device_id': device} if (backend == 'nccl' and device is not None) else {}
     dist.init_process_group(backend, **kw)
+
+
+def active():
+    """True when collectives have to run: more than one rank, or a one-rank group under MF_DIST_FORCE / `FORCE`."""
+    return dist.is_initialized() and (dist.get_world_size() > 1 or FORCE)
 
 
 def world():
@@ -95,7 +109,7 @@ def shared_flat_buffer(tensors):
 
 def allreduce_mean_inplace_(flat):
     """Mean of one buffer across ranks, in place, as ONE collective (RCCL computes the average itself: no divide launch)."""
-    if world() == 1:
+    if not active():
         return flat
     if flat.is_cuda and dist.get_backend() == 'gloo':      # CPU-only test rigs: stage through the host
         host = flat.cpu()
@@ -112,7 +126,7 @@ def allreduce_mean_inplace_(flat):
 def allreduce_sum_(tensors, bucket=None, average=False):
     """In-place sum (or mean) of `tensors` across ranks through one flat bucket; returns the bucket for reuse."""
     tensors = [t for t in tensors if t is not None]
-    if world() == 1 or not tensors:
+    if not active() or not tensors:
         return bucket
     if bucket is None:
         bucket = FlatBucket(tensors)
@@ -191,7 +205,7 @@ class GradBuckets:
                 v.zero_()
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])      # one multi-tensor pack
-        if world() > 1:
+        if active():
             buf = b['buf']
             if buf.is_cuda and dist.get_backend() == 'gloo':      # CPU-only test rigs: stage through the host, synchronously
                 host = buf.cpu()

@@ -450,6 +450,39 @@ class DPhysics(torch.nn.Module):
         steps = self._cache[key]
         return dict(cost_rows=rows.transpose(0, 1), Xs=Xs.transpose(0, 1), Rs=Rs.transpose(0, 1), pose_steps=steps, force_cost=force_cost)
 
+    def interpolate_grid(self, grid, x_query, y_query, return_normals=False, return_cells=False):
+        """The reference's public sampling method (dphysics.py:385-455), bug for bug, as one HIP launch
+        (`mf_interpolate_grid_*`, the rollout kernels' own device code): grid (B,H,W), x_query / y_query (B,N) ->
+        values (B,N) [, unit normals (B,N,3)].  `return_cells=True` (no reference equivalent) appends the clamped flat indices
+        (B,N,4) of the four cells (c, f, l, fl) and the fractions (B,N,2).  No autograd through this entry (the rollout has its
+        own backward)."""
+        cfg = self.dphys_cfg
+        dev = torch.device(self.device)
+        grid = torch.as_tensor(grid).to(dev)
+        _lib.require_hip_tensor(grid, 'grid')
+        dt = grid.dtype
+        sfx = _scalar_suffix(dt)
+        if any(torch.is_tensor(t) and t.requires_grad for t in (grid, x_query, y_query)) and torch.is_grad_enabled():
+            raise RuntimeError('DPhysics.interpolate_grid: not differentiable on its own (gradients flow through forward())')
+        B, H, W = grid.shape
+        xq = torch.as_tensor(x_query).to(device=dev, dtype=dt).reshape(B, -1).contiguous()
+        yq = torch.as_tensor(y_query).to(device=dev, dtype=dt).reshape(B, -1).contiguous()
+        assert xq.shape == yq.shape, f'x_query {tuple(xq.shape)} and y_query {tuple(yq.shape)} differ'
+        N = xq.shape[1]
+        gc = grid.detach().contiguous()
+        desc = _lib.MfInterpDesc(B=B, N=N, H=H, W=W, map_shared=0, math_mode=_lib.MF_MATH_EXACT if self.precise else _lib.MF_MATH_FAST,
+                                 grid_res=float(cfg.grid_res), d_max=float(cfg.d_max))
+        z = torch.empty(B, N, dtype=dt, device=dev)
+        n = torch.empty(B, N, 3, dtype=dt, device=dev) if return_normals else None
+        cells = torch.empty(B, N, 4, dtype=torch.int32, device=dev) if return_cells else None
+        frac = torch.empty(B, N, 2, dtype=dt, device=dev) if return_cells else None
+        with torch.cuda.device(dev):
+            _lib.check(getattr(_lib.lib(), 'mf_interpolate_grid_' + sfx)(C.byref(desc), _lib.ptr(gc), _lib.ptr(xq), _lib.ptr(yq), _lib.ptr(z),
+                                                                         _lib.ptr(n), _lib.ptr(cells), _lib.ptr(frac), _stream_ptr(dev)),
+                       'mf_interpolate_grid')
+        out = (z,) + ((n,) if return_normals else ()) + ((cells, frac) if return_cells else ())
+        return out[0] if len(out) == 1 else out
+
     def _time_grid(self, n, dtype, dev):
         key = ('ts', n, dtype, str(dev))
         if key not in self._cache:

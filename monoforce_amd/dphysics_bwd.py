@@ -20,17 +20,27 @@ class GradPool:
     gradients point at), kept ZEROED between steps: `mf_reduce_grad_copies_*` sums the copies and clears them in one launch, so a
     step pays neither the zero fill nor a separate reduction (~10 us of dependent-launch latency each at the BASELINE shape).
     `busy` is set while a backward is between its kernel launch and the reduction; a pool found busy (an exception in between,
-    or two streams at once) is not trusted and gets refilled."""
+    or two streams at once) is not trusted and gets refilled.
+    `pinned`: a hipGraph capture used this pool -- its address is baked into the graph, so the pool must outlive every replay
+    (`grad_pool` never evicts it).  `done` is an event recorded behind the last reduction: a later acquire on ANOTHER stream
+    waits for it before it clears the buffer."""
 
     def __init__(self, n_maps, copies, n, dt, dev):
         self.n_maps, self.copies, self.n = n_maps, copies, n
         self.buf = torch.zeros(n_maps * copies * n + 16, dtype=dt, device=dev)
         self.busy = False
         self.stream = None
+        self.pinned = False
+        self.done = None
 
     def acquire(self):
-        cur = torch.cuda.current_stream(self.buf.device).cuda_stream
+        cur_s = torch.cuda.current_stream(self.buf.device)
+        cur = cur_s.cuda_stream
+        capturing = torch.cuda.is_current_stream_capturing()
+        self.pinned = self.pinned or capturing
         if self.busy or (self.stream is not None and self.stream != cur):
+            if self.done is not None and not capturing:
+                cur_s.wait_event(self.done)       # the other stream's scatter / reduction may still be in flight
             self.buf.zero_()
         self.busy, self.stream = True, cur
 
@@ -44,19 +54,30 @@ class GradPool:
         with torch.cuda.device(self.buf.device):
             _lib.check(fn(_lib.ptr(self.buf), self.n_maps, self.copies, C.c_longlong(self.n), _lib.ptr(out),
                           C.c_void_p(self.stream)), 'mf_reduce_grad_copies')
+        if not torch.cuda.is_current_stream_capturing():
+            if self.done is None:
+                self.done = torch.cuda.Event()
+            self.done.record(torch.cuda.current_stream(self.buf.device))
         self.busy = False
         return out
 
 
+MAX_IDLE_POOLS = 4      # per owner; pools a captured graph references are kept on top of these
+
+
 def grad_pool(owner, n_maps, copies, n, dt, dev):
-    """The owner's (a DPhysics module's) pool for this shape, acquired for one backward."""
+    """The owner's (a DPhysics module's) pool for this shape, acquired for one backward.  Shapes come and go (tests, sweeps), so
+    the least recently used pools beyond MAX_IDLE_POOLS are dropped -- never one a hipGraph capture has used (`pinned`: the
+    graph replays into its address) and never one between its scatter and its reduction."""
     pools = owner.__dict__.setdefault('_grad_pools', {})
     key = (n_maps, copies, n, dt, dev)
-    p = pools.get(key)
+    p = pools.pop(key, None)
     if p is None:
-        if len(pools) >= 4:                    # shapes come and go (tests, sweeps): keep the memory bounded
-            pools.clear()
-        p = pools[key] = GradPool(n_maps, copies, n, dt, dev)
+        idle = [k for k, q in pools.items() if not q.pinned and not q.busy]
+        for k in idle[:max(len(idle) - (MAX_IDLE_POOLS - 1), 0)]:       # dicts keep insertion order: oldest first
+            del pools[k]
+        p = GradPool(n_maps, copies, n, dt, dev)
+    pools[key] = p                                 # (re-)inserted last = most recently used
     p.acquire()
     return p
 

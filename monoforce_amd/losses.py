@@ -72,10 +72,25 @@ def _ticket(device, stream):
     """The zero-initialised counter `mf_physics_loss_value_*` needs, one per (device, stream): launches ordered on one stream
     share it (the kernel resets it)."""
     key = (device.index, stream.cuda_stream)
-    t = _TICKETS.get(key)
+    t = _TICKETS.pop(key, None)
     if t is None:
-        t = _TICKETS[key] = torch.zeros(1, dtype=torch.int32, device=device)
+        while len(_TICKETS) >= 32:                 # stream handles come and go: the oldest counters leave first
+            _TICKETS.pop(next(iter(_TICKETS)))
+        t = torch.zeros(1, dtype=torch.int32, device=device)
+    _TICKETS[key] = t                              # re-inserted last = most recently used
     return t
+
+
+def _reset_tickets():
+    """After a failed launch: a counter some blocks already ticked would never reach gridDim - 1 again, and every later loss on
+    that stream would stay unwritten.  Dropping the counters makes the next call start from fresh zeros."""
+    _TICKETS.clear()
+
+
+def _register_reset():
+    from . import _lib
+    if _reset_tickets not in _lib.ON_ERROR:
+        _lib.ON_ERROR.append(_reset_tickets)
 
 
 class _FusedPhysicsLoss(torch.autograd.Function):
@@ -87,6 +102,7 @@ class _FusedPhysicsLoss(torch.autograd.Function):
         import ctypes as C
         from . import _lib, _timing
         _lib.require_hip_tensor(X_pred, 'X_pred')
+        _register_reset()
         B, T1, _ = X_pred.shape
         T2 = X_gt.shape[1]
         assert X_pred.stride(2) == 1, 'positions must have their xyz components contiguous'

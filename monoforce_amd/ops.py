@@ -96,8 +96,24 @@ def _time_grid(consts, T, dt, dev):
     return _TS[key]
 
 
-def _prep(z, mu, controls, pts, part_id):
+def _prep(z, mu, controls, pts, part_id, states=()):
+    """Inputs in the kernels' dtype and layout, after the shape checks `DPhysics._make_desc` applies to the module path: both maps
+    [1 or B, H, W] over the same H x W; when one is shared and the other per rollout the kernels index both at b*H*W, so the shared
+    one is expanded for real (the backward sums its gradient back over the rollouts); every start-state tensor has the B rows of
+    `controls`."""
     dt = z.dtype
+    B = controls.shape[0]
+    assert controls.dim() == 3 and controls.shape[2] == 2, f'controls must be [B,T,2], got {tuple(controls.shape)}'
+    assert z.dim() == 3 and z.shape[0] in (1, B), f'z must be [B,H,W] or [1,H,W] (one map shared by all {B} rollouts), got {tuple(z.shape)}'
+    if mu is not None:
+        assert mu.dim() == 3 and tuple(mu.shape[1:]) == tuple(z.shape[1:]), \
+            f'mu shape {tuple(mu.shape)} does not match the {z.shape[1]}x{z.shape[2]} height grid'
+        assert mu.shape[0] in (1, B), f'mu batch {mu.shape[0]} is neither 1 (shared map) nor the {B} rollouts of controls'
+        if mu.shape[0] != z.shape[0]:
+            z, mu = z.expand(B, -1, -1), mu.expand(B, -1, -1)
+    for name, t in states:
+        assert t.shape[0] == B, f'{name} has {t.shape[0]} rows, controls {B} rollouts'
+    assert pts.dim() == 2 and pts.shape[1] == 3 and part_id.shape[0] == pts.shape[0], 'pts must be [N,3] with one part id per point'
     cont = lambda t: None if t is None else t.to(dt).contiguous()  # noqa: E731
     return cont(z), cont(mu), cont(controls), cont(pts), part_id.to(torch.int32).contiguous()
 
@@ -105,7 +121,7 @@ def _prep(z, mu, controls, pts, part_id):
 @torch.library.impl(_L, 'dphys_rollout_fwd', 'CUDA')
 def _rollout_fwd(z, mu, controls, x0, xd0, R0, w0, pts, part_id, Iinv, consts, integrator, save_for_bwd):
     dev, dt = z.device, z.dtype
-    zc, muc, cc, pc, part = _prep(z, mu, controls, pts, part_id)
+    zc, muc, cc, pc, part = _prep(z, mu, controls, pts, part_id, (('x0', x0), ('xd0', xd0), ('R0', R0), ('w0', w0)))
     d = _rollout_desc(zc, cc, pc, Iinv, consts, integrator)
     if dt == torch.float64:
         d.math_mode = _lib.MF_MATH_EXACT
@@ -134,7 +150,7 @@ def _rollout_fwd(z, mu, controls, x0, xd0, R0, w0, pts, part_id, Iinv, consts, i
 @torch.library.impl(_L, 'dphys_rollout_bwd', 'CUDA')
 def _rollout_bwd(z, mu, controls, x_init, xd0, R0, w0, pts, part_id, Iinv, consts, integrator, Xraw, Xds, Rs, Om, rec, gXs, gXds, gRs, gOm, gFs, gFf):
     dev, dt = z.device, z.dtype
-    zc, muc, cc, pc, part = _prep(z, mu, controls, pts, part_id)
+    zc, muc, cc, pc, part = _prep(z, mu, controls, pts, part_id, (('x_init', x_init), ('xd0', xd0), ('R0', R0), ('w0', w0)))
     d = _rollout_desc(zc, cc, pc, Iinv, consts, integrator)
     if dt == torch.float64:
         d.math_mode = _lib.MF_MATH_EXACT
@@ -169,6 +185,11 @@ def _rollout_bwd(z, mu, controls, x_init, xd0, R0, w0, pts, part_id, Iinv, const
         summed = pool.reduce(zc.shape[1:])
         gz = summed[0].unsqueeze(0)
         gmu = summed[1].unsqueeze(0) if muc is not None else None
+    # a map that came in as ONE shared map next to a per-rollout one was expanded in _prep: its gradient is the sum over the rollouts
+    if gz.shape[0] != z.shape[0]:
+        gz = gz.sum(0, keepdim=True)
+    if gmu is not None and gmu.shape[0] != mu.shape[0]:
+        gmu = gmu.sum(0, keepdim=True)
     if gmu is None:
         gmu = torch.zeros(0, dtype=dt, device=dev)
     return gz, gmu, gcontrols, gx0, gxd0, gR0, gw0

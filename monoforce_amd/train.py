@@ -46,7 +46,7 @@ class TerrainFitProblem:
         """The one exchange step of the backward: 2 x H x W floats (+ the loss scalar) over RCCL.  Every rank's loss is the MEAN
         over its own rollouts (equal shares), so the mean over ranks is the gradient of the global-mean loss: the step does
         not depend on the number of GPUs."""
-        if mfdist.world() == 1:
+        if not mfdist.active():
             return loss.detach()
         # The shared-map backward hands both gradients out as views of one buffer with a spare scalar behind them: the loss goes
         # there and the buffer is averaged in place by one collective -- no pack, divide or unpack launches around it (eight
@@ -161,6 +161,23 @@ class EncoderTrainStep:
         states, _ = self.dp(z_grid=z, controls=controls, state=state0, friction=mu)
         l_phys = physics_loss_fused(states, states_gt, pred_ts, gt_ts, nearest=nearest)       # losses.py:102-127 on mf_physics_loss_*
         return l_geom, l_terr, l_phys
+
+    def exchange_only(self):
+        """The step's collectives alone, on the buckets as they stand (bench.py: `comm_ms`)."""
+        import torch.distributed as tdist
+        if not mfdist.active():
+            return
+        works = []
+        for b in self.buckets.buckets:
+            buf = b['buf']
+            if buf.is_cuda and tdist.get_backend() == 'gloo':
+                host = buf.cpu()
+                tdist.all_reduce(host)
+                buf.copy_(host)
+            else:
+                works.append(tdist.all_reduce(buf, async_op=True))
+        for w in works:
+            w.wait()
 
     def step(self, batch):
         self.buckets.zero()

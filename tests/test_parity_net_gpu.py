@@ -37,7 +37,7 @@ def probe_body(dp, dtype):
 
 
 @pytest.mark.parametrize('tag', ['f32', 'f64'])
-@pytest.mark.parametrize('ppl', [0, 1, 4])
+@pytest.mark.parametrize('ppl', [0, 1, 4, 16])
 @pytest.mark.parametrize('precise', [False, True])
 def test_interpolate_grid_golden_through_the_snap(tag, ppl, precise):
     """SURVEY 8 row a5, directly: the 16 edge / out-of-range queries of tests/golden/interp.npz (values of the reference's
@@ -63,16 +63,11 @@ def test_interpolate_grid_golden_through_the_snap(tag, ppl, precise):
         F = outs[4][:, 0, 0].numpy().astype(np.float64)
         n_hip = F / np.linalg.norm(F, axis=-1, keepdims=True)
         z_ref, n_ref = g[f'{tag}/z'][gi].astype(np.float64), g[f'{tag}/n'][gi].astype(np.float64)
-        # queries sitting ON a cell boundary: the fast-math kernels scale by 1/res instead of dividing by res, which may
-        # land the truncation in the neighbouring cell (the reference's own fp32 and fp64 disagree there too)
-        u = np.stack([(qx.astype(np.float64) + d_max) / res, (qy.astype(np.float64) + d_max) / res])
-        clear = (np.abs(u - np.round(u)) > 1e-4).all(0)
+        # (queries sitting ON a cell boundary included: since round 3 the fast-math kernels form the cell coordinate as the correctly
+        # rounded quotient -- Mth::cell_coord -- so they truncate into the reference's cell like the exact ones)
         tol = 1e-12 if tag == 'f64' else 2e-6
         ok = (np.abs(z_hip - z_ref) <= tol * np.abs(z_ref).max()) & (np.abs(n_hip - n_ref).max(-1) <= (1e-10 if tag == 'f64' else 2e-6))
-        if precise or tag == 'f64':
-            assert ok.all(), (gi, np.nonzero(~ok)[0])
-        else:      # fast math: every query clear of a boundary, and most of the ten that sit on one
-            assert clear.sum() == 6 and ok[clear].all() and ok.sum() >= 12, (gi, np.nonzero(~ok)[0], z_hip - z_ref, np.abs(n_hip - n_ref).max(-1))
+        assert ok.all(), (gi, np.nonzero(~ok)[0], z_hip - z_ref, np.abs(n_hip - n_ref).max(-1))
 
 
 def _c1_problem(dtype):
