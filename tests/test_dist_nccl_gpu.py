@@ -20,7 +20,7 @@ def _child(code, env_extra=None, timeout=600):
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
     env.update({'MF_DIST_FORCE': '1', 'HSA_ENABLE_IPC_MODE_LEGACY': '0', 'PYTHONPATH': REPO})
     env.update(env_extra or {})
-    r = subprocess.run([sys.executable, '-c', textwrap.dedent(code)], env=env, capture_output=True, text=True, timeout=timeout, cwd=REPO)
+    r = subprocess.run([sys.executable, '-c', PRELUDE + textwrap.dedent(code)], env=env, capture_output=True, text=True, timeout=timeout, cwd=REPO)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     return r.stdout
 
@@ -39,7 +39,7 @@ assert dist.is_initialized() and dist.get_backend() == 'nccl' and dist.get_world
 
 
 def test_one_rank_rccl_collectives_are_identities():
-    _child(PRELUDE + '''
+    _child('''
     g = torch.Generator(device=dev).manual_seed(0)
     a = torch.randn(2 * 256 * 256 + 1, device=dev, generator=g)
     ref = a.clone()
@@ -57,7 +57,7 @@ def test_one_rank_rccl_collectives_are_identities():
 
 
 def test_one_rank_bucketed_exchange_equals_plain_backward():
-    _child(PRELUDE + '''
+    _child('''
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.ReLU(), torch.nn.Linear(256, 256), torch.nn.ReLU(), torch.nn.Linear(256, 8)).to(dev)
     x = torch.randn(32, 64, device=dev)
@@ -83,7 +83,7 @@ def test_one_rank_bucketed_exchange_equals_plain_backward():
 def test_graph_replay_followed_by_the_collective():
     """`TerrainFitProblem(graph=True)`: forward + loss + backward replayed as one hipGraph, then the in-place all_reduce(AVG) of
     the gradient buffer the graph wrote, on the same stream -- equal to the launch-by-launch step without a process group."""
-    _child(PRELUDE + '''
+    _child('''
     sys.path.insert(0, os.getcwd())
     from bench import build_problem
     from monoforce_amd import synthetic as syn
