@@ -26,22 +26,20 @@ static bool cp_bwd_covers(const MfRolloutDesc* d, bool joints) {
 }
 bool use_component_parallel_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p) { return cp_bwd_covers(d, p->joint_angles != nullptr); }
 
-// The per-step record (rollout_fwd_cp_kernel.h REC): kept where BOTH directions run component-parallel with the default
-// integrator and the launch leaves at least three of four SIMDs idle -- the record is 1 KiB per rollout and step (524 MB at
-// B = 1024, T = 500): four more stores per wave-step forward, ~65 instructions, 7 transcendentals and both gathers fewer backward
-// while the launch is bound by its instruction stream; beyond that the forward becomes bound by the record's stores.  Measured
-// (ms forward + backward, record / none): B = 256 0.172 + 0.285 / 0.163 + 0.346, 1024 0.175 + 0.301 / 0.166 + 0.363, 2048
-// 0.228 + 0.350 / 0.173 + 0.386, 4096 0.49 + 0.57 / 0.25 + 0.59; dynamics() at 1024 0.261 + 0.464 / 0.234 + 0.443 (no gain: its
-// backward is dominated by the Rodrigues adjoint).  MF_CP_RECORD_MAX_WAVES overrides (0 disables).
+// The compact per-step record (rollout_fwd_cp_kernel.h REC, layout in rollout_cp_common.h): kept where BOTH directions run
+// component-parallel and the launch has at most one wave per SIMD -- 256 B per rollout and step (131 MB at B = 1024, T = 500; round
+// 2's record was 1 KiB and stopped paying at B = 2048, where its stores bound the forward): one more store per wave-step forward;
+// backward no contact chain to recompute (~65 instructions, 7 transcendentals), and the forward's own values at every clamp and
+// kink.  Both integrators.  MF_CP_RECORD_MAX_WAVES overrides (0 disables).
 long long cp_record_bytes(const MfRolloutDesc* d) {
-  static const long long max_waves = getenv("MF_CP_RECORD_MAX_WAVES") ? atoll(getenv("MF_CP_RECORD_MAX_WAVES")) : 256;
+  static const long long max_waves = getenv("MF_CP_RECORD_MAX_WAVES") ? atoll(getenv("MF_CP_RECORD_MAX_WAVES")) : 1024;
   if (!d || d->B <= 0 || d->T <= 0) return 0;
   MfRolloutFwdBufs f{};
-  if (d->has_joints || d->integrator != MF_INTEG_ODEINT_EULER) return 0;
+  if (d->has_joints) return 0;
   if (!use_component_parallel(d, &f) || !cp_bwd_covers(d, false)) return 0;
   const long long waves = ((long long)d->B + 3) / 4;
   if (waves > max_waves) return 0;
-  const long long bytes = (long long)d->T * d->B * 16 * 64;
+  const long long bytes = (long long)d->T * d->B * 16 * cp::kRecBytesPerLane;
   if (bytes >= (1ll << 32)) return 0;
   return bytes;
 }

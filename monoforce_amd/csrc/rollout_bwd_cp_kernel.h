@@ -44,7 +44,7 @@ __device__ __forceinline__ float ld1(const float* base, unsigned off) {
 // BESIDE the chain of step n, three register sets, unrolled by three): the same ~350 instructions per step, interleaved by
 // the compiler instead of run one stream after the other, and slower: 0.399 vs 0.367 ms (dynamics(): 0.548 vs 0.448).
 enum { kCpEarly = 0, kCpLate = 1, kCpSaved = 2, kCpStream = 3 };
-template <int INTEG, bool XS_ONLY, bool GCTRL, int MODE>
+template <int INTEG, bool XS_ONLY, bool GCTRL, int MODE, int SLOTS = 8>
 __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
   constexpr bool ODE = INTEG == MF_INTEG_ODEINT_EULER;
   constexpr bool LATE = MODE == kCpLate, STREAM = MODE == kCpStream, SAVED = MODE == kCpSaved || STREAM;
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
     k.x = st.x; k.xd = st.xd; k.w = st.w; k.cv = st.cv; k.cw = st.cw;
     k.R0 = st.R0; k.R1 = st.R1; k.R2 = st.R2;
     k.h = ODE ? st.t1 - st.t0 : a.dt;
-    k.r = P0 * st.R0 + P1 * st.R1 + P2 * st.R2;
+    k.r = cp_body_r(P0, P1, P2, st.R0, st.R1, st.R2);      // (the forward's own formulas, rollout_cp_common.h: same bits, same decisions)
     k.pc = k.r + st.x;
     const float lim = 262144.0f;
     const float uq = M::cell_coord(k.pc, a.d_max, a.res, a.inv_res);
@@ -224,11 +224,11 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
     k.wq = k.wa * k.wb;
     k.r1 = dpp<kRot1>(r); k.r2 = dpp<kRot2>(r);
     k.w1 = dpp<kRot1>(w); k.w2 = dpp<kRot2>(w);
-    k.vp = xd + (k.w1 * k.r2 - k.w2 * k.r1);
+    k.vp = cp_vel(xd, w, r);
     k.coln2 = dot3(k.R0, k.R0);
     k.il = M::inv_len(k.coln2);
     k.e = k.R0 * k.il;
-    k.tv = tv_v * k.cv + tv_w * k.cw;
+    k.tv = cp_track(tv_v, tv_w, k.cv, k.cw);
     const float zq = dot4(k.wq, k.zc);
     k.mcv = has_mu ? k.mc : one;
     k.mub = dot4(k.wq, k.mcv);
@@ -241,21 +241,21 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
     k.cj = act ? cj : zero;
     k.inv_csum = M::div(one, sum_points(k.cj));
     const float vn = dot3(k.vp, k.nrm);
-    k.A = a.k * dh + a.damp * vn;
+    k.A = cp_normal_force(a.k, dh, a.damp, vn);
     k.F0 = -(k.A * k.nrm);
-    k.F1 = k.F0 * k.cj * k.inv_csum;
+    k.F1 = cp_spring(k.A, k.nrm, k.cj, k.inv_csum);
     k.Fr = M::clamp(k.F1, -mg, mg);
     k.Nn = M::sqrt(dot3(k.Fr, k.Fr));
-    k.cmdv = k.tv * k.e - k.vp;
+    k.cmdv = cp_cmd(k.tv, k.e, k.vp);
     k.s = k.mub * k.cmdv;
     k.sn = dot3(k.s, k.nrm);
-    k.stv = k.s - k.sn * k.nrm;
+    k.stv = cp_tangent(k.s, k.sn, k.nrm);
     k.Gf = k.Nn * k.stv;
     const float Ff = M::clamp(k.Gf, -mg, mg);
     const float f = k.Fr + Ff;
     k.f1 = dpp<kRot1>(f); k.f2 = dpp<kRot2>(f);
-    const float Tsum = sum_points(k.r1 * k.f2 - k.r2 * k.f1);
-    k.wraw = I0 * dpp<kB0>(Tsum) + I1 * dpp<kB1>(Tsum) + I2 * dpp<kB2>(Tsum);
+    const float Tsum = sum_points(unrot(cross_pre(r, f)));
+    k.wraw = cp_wraw(I0, I1, I2, Tsum);
   };
 
   // vector-Jacobian product of step n given its recomputed intermediates and the upstream gradient of the forces it fed
@@ -427,59 +427,74 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
   Rec recA, recB;
   int n = n_steps - 1;
   if constexpr (SAVED) {
-    // The forward kept its per-step record (rollout_fwd_cp_kernel.h REC): 16 floats per lane and step -- cell index, the gathered
-    // height and friction, footprint weights, normal and 1 / |u|, blended friction, contact weight, 1 / sum of the weights,
-    // A = k dh + d v_n, |F_n|, s . n, the unclamped angular acceleration, 1 / |R[:, 0]| and its square.  What is left of the
-    // recompute is ~35 instructions of 3-vector algebra: no gathers, no cell arithmetic, no transcendentals.
+    // The forward kept its COMPACT per-step record (layout: rollout_cp_common.h): per lane and step one 16-byte quad -- the cell
+    // coordinates and fractions, |F_n|, s . n, the contact weight, A = k dh + d v_n and the unclamped angular acceleration.  The
+    // reading wave re-gathers its footprint cell from the L2 (gather_cells) and rebuilds the rest with the forward's own
+    // instructions (rebuild): no cell arithmetic from positions, no exponentials, no square roots, and -- because the
+    // values that decide a clamp or the sign at the |F_n| kink are the forward's own -- no way to differentiate a different
+    // function than the forward evaluated.  256 B per rollout-step (round 2: 1 KiB).
     typedef float f4v __attribute__((ext_vector_type(4)));
-    struct Saved { f4v q0, q1, q2, q3; };
-    // (a step's slab: four planes of one 16-byte quad per lane -- every load of a wave is one contiguous kilobyte)
-    const char* prec = reinterpret_cast<const char*>(a.rec) + (size_t)tid * 16u;
-    const size_t rec_plane = (size_t)a.B * 16u * 16u, rec_step = 4u * rec_plane;
+    struct Saved { f4v q; float zc, mc; int idx; };
+    const char* const prec = reinterpret_cast<const char*>(a.rec) + (size_t)tid * kRecBytesPerLane;
+    const unsigned rec_step = (unsigned)a.B * 16u * kRecBytesPerLane;      // bytes between consecutive steps
     auto load_saved = [&](int m, Saved& v) {
-      const char* o = prec + (size_t)__builtin_amdgcn_readfirstlane((unsigned)m) * rec_step;
-      v.q0 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(o));
-      v.q1 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(o + rec_plane));
-      v.q2 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(o + 2 * rec_plane));
-      v.q3 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(o + 3 * rec_plane));
+      v.q = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(prec + (size_t)__builtin_amdgcn_readfirstlane((unsigned)m) * (size_t)rec_step));
+    };
+    // the lane's footprint cell from the recorded cell coordinates (lanes 0, 1 of the quad hold ix, iy), and its two gathers
+    auto gather_cells = [&](Saved& v) {
+      const float uf = v.q.y;                    // (__builtin_bit_cast applied to the element expression itself reads element 0)
+      const int ui = __builtin_bit_cast(int, uf);
+      const int base = dppi<kB1>(ui) + __mul24(a.H, dppi<kB0>(ui));
+      v.idx = min(max(base + cell_off, 0), last);
+      v.zc = ld32(zmap, moff + (unsigned)v.idx);
+      v.mc = ld32(mumap, moff + (unsigned)v.idx);
     };
     auto rebuild = [&](const StateIn& st, const Saved& v, Rec& k) {
       k.R0 = st.R0; k.R1 = st.R1; k.R2 = st.R2; k.w = st.w;
       k.h = ODE ? st.t1 - st.t0 : a.dt;
-      const float r = P0 * st.R0 + P1 * st.R1 + P2 * st.R2;
+      const float r = cp_body_r(P0, P1, P2, st.R0, st.R1, st.R2);
       k.r1 = dpp<kRot1>(r); k.r2 = dpp<kRot2>(r);
       k.w1 = dpp<kRot1>(st.w); k.w2 = dpp<kRot2>(st.w);
-      k.vp = st.xd + (k.w1 * k.r2 - k.w2 * k.r1);
-      k.idx = __builtin_bit_cast(int, v.q0.x); k.zc = v.q0.y; k.mcv = v.q0.z; k.wa = v.q0.w;
-      k.wb = v.q1.x; k.nrm = v.q1.y; k.inl = v.q1.z; k.mub = v.q1.w;
-      k.cj = v.q2.x; k.inv_csum = v.q2.y; k.A = v.q2.z; k.Nn = v.q2.w;
-      k.sn = v.q3.x; k.wraw = v.q3.y; k.il = v.q3.z; k.coln2 = v.q3.w;
+      k.vp = cp_vel(st.xd, st.w, r);
+      const float qx = v.q.x, qy = v.q.y, qz = v.q.z, qw = v.q.w;
+      k.wa = fmaf(wa_s, dpp<kB0>(qx), wa_o); k.wb = fmaf(wb_s, dpp<kB1>(qx), wb_o);
       k.wq = k.wa * k.wb;
+      k.Nn = dpp<kB2>(qx); k.sn = dpp<kB2>(qy); k.cj = dpp<kB3>(qz); k.A = qw;
+      k.wraw = dpp<kMir2>(qz);
+      k.idx = v.idx; k.zc = v.zc; k.mcv = has_mu ? v.mc : one;
+      k.mub = dot4(k.wq, k.mcv);
+      const float dz = v.zc - dpp<kB0>(v.zc);
+      const float u = fmaf(dpp<kN12>(dz), n_mul, n_add);
+      k.inl = M::inv_len(dot3(u, u));
+      k.nrm = u * k.inl;
+      k.inv_csum = M::div(one, sum_points(k.cj));
+      k.coln2 = dot3(st.R0, st.R0);
+      k.il = M::inv_len(k.coln2);
       k.e = st.R0 * k.il;
-      k.tv = tv_v * st.cv + tv_w * st.cw;
+      k.tv = cp_track(tv_v, tv_w, st.cv, st.cw);
       k.F0 = -(k.A * k.nrm);
-      k.F1 = k.F0 * k.cj * k.inv_csum;
+      k.F1 = cp_spring(k.A, k.nrm, k.cj, k.inv_csum);
       k.Fr = M::clamp(k.F1, -mg, mg);
-      k.cmdv = k.tv * k.e - k.vp;
+      k.cmdv = cp_cmd(k.tv, k.e, k.vp);
       k.s = k.mub * k.cmdv;
-      k.stv = k.s - k.sn * k.nrm;
+      k.stv = cp_tangent(k.s, k.sn, k.nrm);
       k.Gf = k.Nn * k.stv;
       const float f = k.Fr + M::clamp(k.Gf, -mg, mg);
       k.f1 = dpp<kRot1>(f); k.f2 = dpp<kRot2>(f);
     };
-    Saved vA, vB;
-    if constexpr (ODE) {
-      // Addresses: constant scalar bases + RUNNING 32-bit per-lane byte offsets, one vector subtract per array and step.  (With
-      // a wave-uniform step offset added to a scalar base the compiler formed 64-bit addresses with ~10 vector adds and ~25
-      // scalar multiplies / adds per step -- scalar instructions take a full issue slot when a SIMD holds one wave.)  The offsets
-      // point at the rows of the step being REQUESTED; the last iteration requests nothing but the upstream row 0.
+    if constexpr (STREAM) {
+      // MODE = kCpStream (default integrator): a SECOND wave of the workgroup fetches -- the rows and the record of three steps per
+      // batch straight into registers -- and, since it has the time, turns each step into the COEFFICIENTS of its vector-Jacobian
+      // product (struct Coef) before writing them into an LDS ring; the first wave reads a step's coefficients from LDS and runs
+      // the adjoint recurrence on them (`chain`).  Two LDS counters (steps written / steps read) instead of barriers; LDS
+      // executes a wave's operations in order, so a counter written after a slot is seen after it.  The fetching wave is a
+      // three-stage pipeline over batches: HBM loads of batch k + 2 | cell gathers (L2) of batch k + 1 | rebuild + ring
+      // writes of batch k -- three register sets, unrolled by three, so that neither round trip is ever waited for.
+      // Addresses: constant scalar bases + RUNNING 32-bit per-lane byte offsets, one vector subtract per array and step.
       const unsigned un = (unsigned)max(n, 0);
-      unsigned o3 = v3 + un * s3, o9 = v9 + un * s9, oc = v_ctrl + un * 8u, orc = un * (unsigned)rec_step;
+      unsigned o3 = v3 + un * s3, o9 = v9 + un * s9, oc = v_ctrl + un * 8u, orc = un * rec_step;
       unsigned og_xs = u_xs + (un + 1u) * sg_xs, og_xds = u_xds + (un + 1u) * sg_xds, og_om = u_om + (un + 1u) * sg_om;
       unsigned og_r = u_r + (un + 1u) * sg_r, og_fs = u_fs + (un + 1u) * sg_fs, og_ff = u_ff + (un + 1u) * sg_ff;
-      const char* const prec1 = prec + rec_plane;
-      const char* const prec2 = prec + 2 * rec_plane;
-      const char* const prec3 = prec + 3 * rec_plane;
       int ti = max(n, 0);                        // index of the lower time stamp of the requested step
       float t_hi = a.ts[min(ti + 1, a.T - 1)];
       auto request_state = [&](StateIn& d, Saved& v) {      // rows + record of the step the offsets point at
@@ -488,10 +503,7 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
         bload3(rRs, o9, 0u, &d.R0, &d.R1, &d.R2);
         bload2(rCtrl, oc, 0u, &d.cv, &d.cw);
         d.t1 = t_hi; d.t0 = a.ts[ti]; t_hi = d.t0;
-        v.q0 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(prec + (size_t)orc));
-        v.q1 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(prec1 + (size_t)orc));
-        v.q2 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(prec2 + (size_t)orc));
-        v.q3 = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(prec3 + (size_t)orc));
+        v.q = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(prec + (size_t)orc));
       };
       auto request_up = [&](UpIn& u) {                       // upstream gradients of the row that step produced
         u.gXs = bload1(rgXs, og_xs, 0u);
@@ -505,37 +517,30 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
         og_xs -= sg_xs;
         if constexpr (!XS_ONLY) { og_xds -= sg_xds; og_om -= sg_om; og_r -= sg_r; og_fs -= sg_fs; og_ff -= sg_ff; }
       };
-      if constexpr (STREAM) {
-        // MODE = kCpStream: the record-reading kernel waits for HBM -- SQ_WAIT_ANY 22 % with the record and the rows requested one
-        // step (0.6 us) ahead, and a single wave cannot request further ahead (the values crossing the loop's back edge get copied
-        // there, which drains them).  A SECOND wave of the workgroup (B <= 1024 leaves three SIMDs of every CU idle) therefore
-        // fetches: three steps per batch straight into registers, two batches in flight, and -- it has the time -- turns each
-        // step's rows and record into the COEFFICIENTS of its vector-Jacobian product (struct Coef) before writing them into an
-        // LDS ring of eight slots; the first wave reads a step's coefficients from LDS and runs the adjoint recurrence on them
-        // (`chain`).  Two LDS counters (steps written / steps read) instead of barriers; LDS executes a wave's operations in
-        // order, so a counter written after a slot is seen after it.  (0.30 -> 0.20 ms at B = 1024: DESIGN.md 4.2b has the steps.)
-        constexpr int kSlots = 8, kPlanes = XS_ONLY ? 10 : 12;
-        __shared__ f4v ring[kSlots * kPlanes * 64];
-        __shared__ int flags[2];
-        typedef __attribute__((address_space(3))) volatile int LdsCounter;      // (a generic volatile pointer would make FLAT accesses)
-        LdsCounter* vflags = (LdsCounter*)flags;
-        if (threadIdx.x == 0) { flags[0] = 0; flags[1] = 0; }
-        __syncthreads();
-        if (threadIdx.x >= 64) {
-          // ---------------- the fetching wave ----------------
-          struct Raw { StateIn st; Saved sv; UpIn up; };
-          int produced = 0, m = n;                    // m: the step the offsets point at
-          auto fetch = [&](Raw& r) {                  // everything of step m; then the offsets move to step m - 1
-            request_state(r.st, r.sv);                // (after step 0 the offsets wrap around; nothing reads them again)
-            request_up(r.up);
-            o3 -= s3; o9 -= s9; oc -= 8u; orc -= (unsigned)rec_step; --ti;
-            step_back_up();
-            --m;
-          };
-          // ... and everything of the step's vector-Jacobian product that does not depend on the adjoint is done HERE, on the
-          // wave that has time: the rebuild, the clamp gates, 1 / |F_n|, and every product of two such values the chain would
-          // form -- the ring carries the chain's COEFFICIENTS (struct Coef below), forty floats per lane and step.
-          auto put = [&](const Raw& r) {
+      constexpr int kSlots = SLOTS, kPlanes = XS_ONLY ? 10 : 12;
+      constexpr bool kPow2 = (kSlots & (kSlots - 1)) == 0;
+      __shared__ f4v ring[kSlots * kPlanes * 64];
+      __shared__ int flags[2];
+      typedef __attribute__((address_space(3))) volatile int LdsCounter;      // (a generic volatile pointer would make FLAT accesses)
+      LdsCounter* vflags = (LdsCounter*)flags;
+      if (threadIdx.x == 0) { flags[0] = 0; flags[1] = 0; }
+      __syncthreads();
+      if (threadIdx.x >= 64) {
+        // ---------------- the fetching wave ----------------
+        struct Slot { StateIn st; Saved sv; UpIn up; };
+        int produced = 0, m = n;                    // m: the step the offsets point at
+        unsigned wslot = 0u;                        // ring slot written next (running, wraps at kSlots)
+        auto fetch = [&](Slot& r) {                 // everything of step m; then the offsets move to step m - 1
+          request_state(r.st, r.sv);                // (after step 0 the offsets wrap around; nothing reads them again)
+          request_up(r.up);
+          o3 -= s3; o9 -= s9; oc -= 8u; orc -= rec_step; --ti;
+          step_back_up();
+          --m;
+        };
+        // ... and everything of the step's vector-Jacobian product that does not depend on the adjoint is done HERE, on the
+        // wave that has time: the rebuild, the clamp gates, 1 / |F_n|, and every product of two such values the chain would
+        // form -- the ring carries the chain's COEFFICIENTS (struct Coef below), forty floats per lane and step.
+          auto put = [&](const Slot& r) {
             Rec k;
             rebuild(r.st, r.sv, k);
             const float mw = inside(k.wraw, -a.omega_max, a.omega_max) ? one : zero;
@@ -545,7 +550,8 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
             const float cmask = k.coln2 >= 1e-12f ? one : zero;
             const float cs = k.cj * k.inv_csum;
             // (the upstream gradient of a state row goes to point 0's quad: add_upstream_masked)
-            f4v* o = ring + (produced & (kSlots - 1)) * (kPlanes * 64) + lane;
+            f4v* o = ring + (kPow2 ? (unsigned)(produced & (kSlots - 1)) : wslot) * (unsigned)(kPlanes * 64) + lane;
+            if constexpr (!kPow2) wslot = wslot + 1u == (unsigned)kSlots ? 0u : wslot + 1u;
             o[0] = f4v{k.R0, k.R1, k.R2, k.h};
             o[64] = f4v{k.w1, k.w2, k.r1, k.r2};
             o[128] = f4v{k.f1, k.f2, mw, mG * k.stv};
@@ -562,46 +568,47 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
             }
             ++produced;
           };
-          auto room = [&](int want) {                 // wait until `want` more slots may be overwritten
-            while (produced + want - __builtin_amdgcn_readfirstlane(vflags[1]) > kSlots) __builtin_amdgcn_s_sleep(2);
-            asm volatile("" ::: "memory");
-          };
-          // Three steps per batch, two batches in registers: the loads of one are in flight while the other is rebuilt and
-          // written (alone, this wave runs the launch in 0.175 ms instead of 0.20 with one batch of four at a time -- it has to stay
-          // well ahead of the computing wave's 0.22).
-          auto put3 = [&](const Raw& r0, const Raw& r1, const Raw& r2) {
-            room(3);
-            put(r0); put(r1); put(r2);
-            asm volatile("" ::: "memory");
-            vflags[0] = produced;
-          };
-          if (m >= 2) {
-            Raw a0, a1, a2, b0, b1, b2;
-            fetch(a0); fetch(a1); fetch(a2);
-            while (m >= 5) {                          // six more steps at least
-              fetch(b0); fetch(b1); fetch(b2);
-              put3(a0, a1, a2);
-              fetch(a0); fetch(a1); fetch(a2);
-              put3(b0, b1, b2);
-            }
-            if (m >= 2) {
-              fetch(b0); fetch(b1); fetch(b2);
-              put3(a0, a1, a2);
-              put3(b0, b1, b2);
-            } else put3(a0, a1, a2);
+        auto room = [&](int want) {                 // wait until `want` more slots may be overwritten
+          while (produced + want - __builtin_amdgcn_readfirstlane(vflags[1]) > kSlots) __builtin_amdgcn_s_sleep(2);
+          asm volatile("" ::: "memory");
+        };
+        auto fetch3 = [&](Slot (&s)[3]) { fetch(s[0]); fetch(s[1]); fetch(s[2]); };
+        auto gather3 = [&](Slot (&s)[3]) { gather_cells(s[0].sv); gather_cells(s[1].sv); gather_cells(s[2].sv); };
+        auto put3 = [&](const Slot (&s)[3]) {
+          room(3);
+          put(s[0]); put(s[1]); put(s[2]);
+          asm volatile("" ::: "memory");
+          vflags[0] = produced;
+        };
+        Slot A[3], B[3], C[3];
+        int full = (m + 1) / 3;                     // whole batches of three steps still to fetch (m + 1 steps are left)
+        if (full >= 2) {
+          fetch3(A); fetch3(B); gather3(A);
+          full -= 2;                                // invariant: A fetched and gathered, B fetched, `full` batches not yet fetched
+          while (full >= 3) {
+            fetch3(C); gather3(B); put3(A);
+            fetch3(A); gather3(C); put3(B);
+            fetch3(B); gather3(A); put3(C);
+            full -= 3;
           }
-          while (m >= 0) {
-            Raw r0;
-            fetch(r0);
-            room(1);
-            put(r0);
-            asm volatile("" ::: "memory");
-            vflags[0] = produced;
-          }
-          return;
+          if (full == 0) { gather3(B); put3(A); put3(B); }
+          else if (full == 1) { fetch3(C); gather3(B); put3(A); gather3(C); put3(B); put3(C); }
+          else { fetch3(C); gather3(B); put3(A); fetch3(A); gather3(C); put3(B); gather3(A); put3(C); put3(A); }
+        } else if (full == 1) { fetch3(A); gather3(A); put3(A); }
+        while (m >= 0) {                            // the last one or two steps
+          Slot r0;
+          fetch(r0);
+          gather_cells(r0.sv);
+          room(1);
+          put(r0);
+          asm volatile("" ::: "memory");
+          vflags[0] = produced;
         }
+        return;
+      }
         // ---------------- the computing wave ----------------
         int consumed = 0, seen = 0;                   // records read so far; the fetching wave's counter as last read
+        unsigned rslot = 0u;                          // ring slot read next (running, wraps at kSlots)
         UpIn uZ;                                      // the upstream gradient of output row 0 (the initial state): not in the ring
         load_upstream(0, uZ);
         // The coefficients of a step's vector-Jacobian product, as the fetching wave leaves them in the ring.  With
@@ -624,7 +631,8 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
           asm volatile("" ::: "memory");
         };
         auto grab = [&](Coef& c, UpIn& up) {          // the next step out of the ring (it is there: ensure)
-          const f4v* o = ring + (consumed & (kSlots - 1)) * (kPlanes * 64) + lane;
+          const f4v* o = ring + (kPow2 ? (unsigned)(consumed & (kSlots - 1)) : rslot) * (unsigned)(kPlanes * 64) + lane;
+          if constexpr (!kPow2) rslot = rslot + 1u == (unsigned)kSlots ? 0u : rslot + 1u;
           const f4v c0 = o[0], c1 = o[64], c2 = o[128], c3 = o[192], c4 = o[256], c5 = o[320], c6 = o[384], c7 = o[448], c8 = o[512], c9 = o[576];
           const float idx_bits = c7.w;       // (__builtin_bit_cast applied to the element expression itself reads element 0 of the vector)
           c.R0 = c0.x; c.R1 = c0.y; c.R2 = c0.z; c.h = c0.w;
@@ -752,57 +760,40 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
           else crunch(0, cA, uA, cB, uB, false_type{}, single{});
         }
         uA = uZ; uB = uZ;                             // (the epilogue reads whichever the last iteration would have requested into)
-      } else {
-      auto run = [&](int n, const StateIn& st, const Saved& sv, const UpIn& up, StateIn& st_next, Saved& sv_next, UpIn& up_next, auto more) {
+    } else {
+      // MODE = kCpSaved: ONE wave reads the record itself (either integrator; launches the streaming form does not cover, and the
+      // A/B leg of the parity tests).  Three stages again, in one instruction stream: the rows and the record of step n - 2 are
+      // requested, the cells of step n - 1 gathered at the top of the iteration; the vector-Jacobian chain of step n (~1000
+      // cycles) runs; then step n - 1 is rebuilt from what has arrived meanwhile.  Two register sets, unrolled by two.
+      struct Raw { StateIn st; Saved sv; };
+      auto run = [&](int n, const Rec& kc, const UpIn& up, Raw& X, Raw& Y, Rec& k_next, UpIn& up_next) {
         add_upstream_state(up);
-        step_back_up();
-        if constexpr (decltype(more)::value) {          // n >= 1: the rows and the record of step n - 1 ...
-          o3 -= s3; o9 -= s9; oc -= 8u; orc -= (unsigned)rec_step; --ti;
-          request_state(st_next, sv_next);
-        }
-        request_up(up_next);                            // ... and the upstream gradient of the row it produced (n = 0: row 0 itself)
+        gather_cells(X.sv);                                   // step n - 1 (n = 0: a harmless repeat of step 0)
+        load_state(max(n - 2, 0), Y.st);
+        load_saved(max(n - 2, 0), Y.sv);
+        load_upstream(ODE ? n : max(n - 1, 0), up_next);      // the row step n - 1 produced (ODEINT's row 0: added after the loop)
         flush_stash();
         if constexpr (GCTRL) bstore2(rGctrl, v_ctrl, gctrl_pending, gv_pending, gwc_pending);
-        Rec k;
-        rebuild(st, sv, k);
-        vjp(n, k, up);
+        vjp(n, kc, up);
+        // (the gathered values pass through an empty asm that also reads the adjoint the chain ends in: their consumers stay behind it)
+        asm("" : "+v"(X.sv.zc), "+v"(X.sv.mc) : "v"(lR0));
+        rebuild(X.st, X.sv, k_next);
       };
-      using std::true_type;
-      using std::false_type;
-      if (n_steps > 0) {
-        request_state(sA, vA);
-        request_up(uA);
-        __builtin_amdgcn_s_waitcnt(0);
-        for (; n >= 2; n -= 2) {
-          run(n, sA, vA, uA, sB, vB, uB, true_type{});
-          run(n - 1, sB, vB, uB, sA, vA, uA, true_type{});
-        }
-        if (n == 1) { run(1, sA, vA, uA, sB, vB, uB, true_type{}); run(0, sB, vB, uB, sA, vA, uA, false_type{}); }
-        else run(0, sA, vA, uA, sB, vB, uB, false_type{});
+      Raw rA, rB;
+      Rec kA, kB;
+      load_state(max(n, 0), rA.st);
+      load_saved(max(n, 0), rA.sv);
+      load_upstream(min(max(n, 0) + (ODE ? 1 : 0), a.T - 1), uA);
+      load_state(max(n - 1, 0), rB.st);
+      load_saved(max(n - 1, 0), rB.sv);
+      gather_cells(rA.sv);
+      rebuild(rA.st, rA.sv, kA);
+      __builtin_amdgcn_s_waitcnt(0);
+      for (; n >= 1; n -= 2) {
+        run(n, kA, uA, rB, rA, kB, uB);
+        run(n - 1, kB, uB, rA, rB, kA, uA);
       }
-      }
-    } else {
-    // one iteration: the rows, the record and the upstream gradient of step n - 1 are loaded while step n runs
-    auto saved_body = [&](int n, const StateIn& st, const Saved& sv, const UpIn& up, StateIn& st_next, Saved& sv_next, UpIn& up_next) {
-      add_upstream_state(up);
-      load_state(max(n - 1, 0), st_next);
-      load_saved(max(n - 1, 0), sv_next);
-      load_upstream(ODE ? n : max(n - 1, 0), up_next);
-      flush_stash();
-      if constexpr (GCTRL) bstore2(rGctrl, v_ctrl, gctrl_pending, gv_pending, gwc_pending);
-      Rec k;
-      rebuild(st, sv, k);
-      vjp(n, k, up);
-    };
-    load_state(max(n, 0), sA);
-    load_saved(max(n, 0), vA);
-    load_upstream(min(max(n, 0) + (ODE ? 1 : 0), a.T - 1), uA);
-    __builtin_amdgcn_s_waitcnt(0);
-    for (; n >= 1; n -= 2) {
-      saved_body(n, sA, vA, uA, sB, vB, uB);
-      saved_body(n - 1, sB, vB, uB, sA, vA, uA);
-    }
-    if (n == 0) saved_body(0, sA, vA, uA, sB, vB, uB);
+      if (n == 0) run(0, kA, uA, rB, rA, kB, uB);
     }
   } else {
   load_state(max(n, 0), sA);
@@ -868,21 +859,26 @@ int launch_rollout_bwd_cp_f32(const RolloutBwdArgs<float>& a, int integ, bool xs
 int launch_rollout_bwd_cp_dynamics_f32(const RolloutBwdArgs<float>& a, bool xs_only, hipStream_t st);      // rollout_bwd_dyn_cp_fast.hip
 void launch_rollout_bwd_cp_stream_f32(const RolloutBwdArgs<float>& a, bool xs_only, unsigned grid, hipStream_t st);   // rollout_bwd_cp_stream_fast.hip
 
+// Largest grid (workgroups = waves of rollouts) the streaming form takes: its LDS ring allows two workgroups per CU with six slots
+// (2 x 72 KB of the CU's 160 KB), one with eight.  MF_CP_STREAM_MAX_GRID overrides (A/B runs).
+inline unsigned cp_stream_max_grid() {
+  static const unsigned v = getenv("MF_CP_STREAM_MAX_GRID") ? (unsigned)atoi(getenv("MF_CP_STREAM_MAX_GRID")) : 512u;
+  return v;
+}
+
 // one launch of the variant (positions-only loss?, control gradient?, late recompute?) the arguments call for
 template <int INTEG>
 int launch_rollout_bwd_cp_variant(const RolloutBwdArgs<float>& a, bool xs_only, hipStream_t st) {
   const long long threads = (long long)a.B * 16;
   const unsigned grid = (unsigned)((threads + 63) / 64);
   const bool gc = a.gcontrols != nullptr;
-  static const int forced = getenv("MF_CP_BWD_MODE") ? atoi(getenv("MF_CP_BWD_MODE")) : -1;      // A/B (tools/ab_cp.py): 0 early, 1 late
-  // the forward's record when there is one; else at most one wave per SIMD: late recompute
-  // (a record with at most one wave per CU: a second wave per workgroup streams it through LDS)
+  static const int forced = getenv("MF_CP_BWD_MODE") ? atoi(getenv("MF_CP_BWD_MODE")) : -1;      // A/B (tools/ab_cp.py): 0 early, 1 late, 2 record read by one wave
+  // the forward's record when there is one: a second wave per workgroup streams it through LDS (default integrator, while the
+  // rings fit the CUs' LDS), else one wave reads it itself; without a record at most one wave per SIMD: late recompute
   constexpr bool can_stream = INTEG == MF_INTEG_ODEINT_EULER;
-  static const unsigned stream_max = getenv("MF_CP_STREAM_MAX_GRID") ? (unsigned)atoi(getenv("MF_CP_STREAM_MAX_GRID")) : 256u;
-  const int saved_mode = can_stream && grid <= stream_max && forced != kCpSaved ? kCpStream : kCpSaved;
+  const int saved_mode = can_stream && grid <= cp_stream_max_grid() && forced != kCpSaved ? kCpStream : kCpSaved;
   const int mode = a.rec ? saved_mode : (forced >= 0 && forced < kCpSaved ? forced : (grid <= 1024u ? kCpLate : kCpEarly));
-  const int block = mode == kCpStream ? 128 : 64;
-#define MF_BCP(XS_, GC_, M_) hipLaunchKernelGGL((rollout_bwd_cp_kernel<INTEG, XS_, GC_, M_>), dim3(grid), dim3(block), 0, st, a)
+#define MF_BCP(XS_, GC_, M_) hipLaunchKernelGGL((rollout_bwd_cp_kernel<INTEG, XS_, GC_, M_>), dim3(grid), dim3(64), 0, st, a)
 #define MF_BCP_L(XS_, GC_) do { if (mode == kCpStream) launch_rollout_bwd_cp_stream_f32(a, xs_only, grid, st); else if (mode == kCpSaved) MF_BCP(XS_, GC_, kCpSaved); else if (mode == kCpLate) MF_BCP(XS_, GC_, kCpLate); else MF_BCP(XS_, GC_, kCpEarly); } while (0)
   if (xs_only) { if (gc) MF_BCP_L(true, true); else MF_BCP_L(true, false); }
   else         { if (gc) MF_BCP_L(false, true); else MF_BCP_L(false, false); }

@@ -66,6 +66,45 @@ __device__ __forceinline__ float cross_pre(float a, float b) {
 }
 __device__ __forceinline__ float unrot(float d) { return dpp<kRot1>(d); }
 
+// ---- the contact model's formulas, ONE definition for the forward and the backward -------------------------------------------
+// The backward rebuilds a step's intermediates from the saved state rows (and, where the forward kept one, from its compact
+// per-step record).  Autograd differentiates the function the forward EVALUATED -- its clamp decisions, the sign of the normal
+// force at the |F_n| kink -- so the rebuild has to reproduce the forward's values bit for bit, not to rounding: every formula
+// both sides evaluate is written once, here, with its fused multiply-adds spelled out (left to the compiler, a * b + c * d may
+// contract one way in the forward's loop and the other way in the backward's).  Same inputs, same instructions, same bits.
+__device__ __forceinline__ float cp_body_r(float P0, float P1, float P2, float g0, float g1, float g2) {      // r = R P, this lane's row (dphysics.py:200)
+  return fmaf(P2, g2, fmaf(P1, g1, P0 * g0));
+}
+__device__ __forceinline__ float cp_vel(float xd, float w, float r) { return xd + unrot(cross_pre(w, r)); }      // v_p = xd + w x r (:204)
+__device__ __forceinline__ float cp_track(float tv_v, float tv_w, float cv, float cw) { return fmaf(tv_v, cv, tv_w * cw); }   // (:75-104)
+__device__ __forceinline__ float cp_normal_force(float k, float dh, float damp, float vn) { return fmaf(k, dh, damp * vn); }    // A = k dh + d v_n (:230)
+__device__ __forceinline__ float cp_spring(float A, float nrm, float cj, float inv_csum) {                      // F_spring before its clamp (:230-232)
+#pragma clang fp contract(off)
+  return -(A * nrm) * (cj * inv_csum);
+}
+__device__ __forceinline__ float cp_cmd(float tv, float e, float vp) { return fmaf(tv, e, -vp); }               // cmd - v_p (:247)
+__device__ __forceinline__ float cp_tangent(float s, float sn, float nrm) { return fmaf(-sn, nrm, s); }         // s - (s . n) n (:248-249)
+// omega_d before its clamp: row c of I^-1 times the torque (the total sits replicated in the quad's component lanes)   (:256)
+__device__ __forceinline__ float cp_wraw(float I0, float I1, float I2, float Tsum) {
+  return fmaf(I2, dpp<kB2>(Tsum), fmaf(I1, dpp<kB1>(Tsum), I0 * dpp<kB0>(Tsum)));
+}
+// bitwise merge (a where the mask is set, b elsewhere): one v_bfi_b32
+__device__ __forceinline__ float bfi(unsigned m, float a, float b) {
+  return __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, a) & m) | (__builtin_bit_cast(unsigned, b) & ~m));
+}
+constexpr int kMir2 = 0xA4;    // quad_perm [0,1,2,2]: lane 3 <- lane 2 (a per-component value stored by lanes 0..2 of a quad)
+
+// ---- the forward's compact per-step record (MfRolloutFwdBufs.rec): ONE 16-byte quad per lane and step, 256 B per rollout-step ----
+// What the backward cannot get back from the saved state rows without redoing the contact chain, and nothing else:
+//   x : lanes 0, 1 of a quad: the cell fractions (fx, fy)          lanes 2, 3: |F_n| of the point
+//   y : lanes 0, 1: the cell coordinates (ix, iy), int bits        lanes 2, 3: s . n
+//   z : lanes 0..2: the unclamped angular acceleration (component) lane 3: the contact weight c of the point
+//   w : A = k dh + d v_n of the point
+// -- 28 + 3 unique floats of the 64.  Everything else of round 2's 1 KiB record is rebuilt by the wave that reads it: the gathered
+// cells come back from the L2 (the maps are 512 KiB), normal, blended friction, 1 / sum c, |R[:, 0]| from those and the state rows
+// with the forward's own instructions.  A step's slab is [B * 16 lanes] quads: each store / load of a wave is one contiguous KiB.
+constexpr unsigned kRecBytesPerLane = 16;
+
 // ---- rows of the [T][B][...] arrays -----------------------------------------------------------------------------------------
 // A row is addressed as wave-uniform base pointer + wave-uniform byte offset of the time step + a per-lane byte offset that
 // never changes (32 bits: the host keeps every array of a component-parallel launch below 4 GiB).

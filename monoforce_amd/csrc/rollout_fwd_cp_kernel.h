@@ -58,7 +58,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
   }
 
   // footprint of the point under position component pc: this lane's cell index and weight
-  auto footprint = [&](float pc, int* idx, float* wq, float* owa = nullptr, float* owb = nullptr) {
+  auto footprint = [&](float pc, int* idx, float* wq, float* ofr = nullptr, int* oui = nullptr) {
     const float lim = 262144.0f;
     const float u = M::cell_coord(pc, a.d_max, a.res, a.inv_res);      // lanes 0, 1: ux, uy
     const int ui = (int)M::clamp(u, -lim, lim);                         // trunc toward zero, like .long()
@@ -67,7 +67,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
     *idx = min(max(base + cell_off, 0), last);                          // the reference clamps the FLAT index (:432-435)
     const float wa = fmaf(wa_s, dpp<kB0>(fr), wa_o), wb = fmaf(wb_s, dpp<kB1>(fr), wb_o);   // exact: 1 - f or f
     *wq = wa * wb;
-    if (owa) { *owa = wa; *owb = wb; }
+    if (ofr) { *ofr = fr; *oui = ui; }
   };
 
   // start at the terrain height: x.z <- mean_i interp(z, (P R^T + x)_i)   (dphysics.py:567-571)
@@ -126,12 +126,12 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
   // (x' = x + h xd, R' = R + h [w]x R use the old xd, w), so its kernels compute the geometry of step n + 1 -- and issue its
   // gathers -- while the contact chain of step n runs: two independent instruction streams in one basic block fill each
   // other's dependency stalls, and a gather has a whole step to arrive.
-  struct Geo { float r, pc, wq, zc, mc, e, wa, wb, il, coln2; int idx; };
+  struct Geo { float r, pc, wq, zc, mc, e, fr, il, coln2; int idx, ui; };
   auto geometry = [&](float gx, float g0, float g1, float g2) {
     Geo g;
-    g.r = P0 * g0 + P1 * g1 + P2 * g2;               // (:200)
+    g.r = cp_body_r(P0, P1, P2, g0, g1, g2);         // (:200)
     g.pc = g.r + gx;
-    footprint(g.pc, &g.idx, &g.wq, &g.wa, &g.wb);
+    footprint(g.pc, &g.idx, &g.wq, &g.fr, &g.ui);
     const int idx = g.idx;
     if constexpr (ZMU) {
       const float2 zm = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(a.zmu) + (size_t)((unsigned)idx * 8u));
@@ -146,22 +146,16 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
     return g;
   };
   // contact model + wrench of one step from its geometry and the state's velocities: (xdd, wd, F_spring, F_friction)
-  // REC: what the backward would otherwise recompute from the saved state -- the two gathered cells and their footprint weights,
-  // the normal, the contact weight, the normal-force and slip scalars, the unclamped angular acceleration: 16 floats per lane
-  // and step, four 16-byte stores here, four 16-byte loads there, against ~100 instructions, 7 transcendentals and the two
-  // gathers of the recompute (rollout_bwd_cp_kernel.h).  A step's slab is four planes of one 16-byte quad per lane,
-  // [4][B * 16 lanes][4 floats]: each of the four stores of a wave is one contiguous kilobyte (with the 16 floats of a lane
-  // side by side a store touched 64 separate 64-byte segments and the forward went from 0.17 to 0.48 ms at B = 1024).
-  // (four loop-invariant scalar plane bases + one running 32-bit per-lane offset: mf_rollout_record_bytes keeps the record < 4 GiB)
-  const size_t rec_plane = (size_t)a.B * 16u * 16u;
+  // REC: the compact per-step record for the backward (layout: rollout_cp_common.h) -- one 16-byte store per lane and step, three
+  // bit-field merges to assemble it (round 2 wrote four stores, 1 KiB per rollout-step: forward-with-record 4.05x its algorithmic
+  // HBM bytes, backward 2.06x).  One scalar plane base + one running 32-bit per-lane offset: mf_rollout_record_bytes keeps the
+  // record < 4 GiB.
   char* const pRec0 = reinterpret_cast<char*>(a.rec);
-  char* const pRec1 = pRec0 + rec_plane;
-  char* const pRec2 = pRec0 + 2 * rec_plane;
-  char* const pRec3 = pRec0 + 3 * rec_plane;
-  unsigned rec_off = (unsigned)tid * 16u;
-  const unsigned rec_step = (unsigned)(4u * rec_plane);
+  unsigned rec_off = (unsigned)tid * kRecBytesPerLane;
+  const unsigned rec_step = (unsigned)a.B * 16u * kRecBytesPerLane;
+  const unsigned m_q01 = q < 2 ? ~0u : 0u, m_q012 = q < 3 ? ~0u : 0u;
   auto contact = [&](const Geo& g, float vxd, float vw, float tv, float* xdd, float* wd, float* oFr, float* oFf) {
-    const float vp = vxd + unrot(cross_pre(vw, g.r));                  // v_p = xd + w x r   (:204)
+    const float vp = cp_vel(vxd, vw, g.r);                             // v_p = xd + w x r   (:204)
     const float zq = dot4(g.wq, g.zc);                               // height under the point (:211)
     const float mub = dot4(g.wq, has_mu ? g.mc : one);             // friction (:216); no map = a map of ones (:562)
     const float dz = g.zc - dpp<kB0>(g.zc);                           // lane 1: z_f - z_c, lane 2: z_l - z_c
@@ -173,28 +167,25 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
     cj = act ? cj : zero;
     const float csum = sum_points(cj);                                // n_contact_pts (:231)
     const float inv_csum = M::div(one, csum);
-    const float cjn = cj * inv_csum;
     const float vn = dot3(vp, nrm);
-    const float A = a.k * dh + a.damp * vn;
-    const float Fr = M::clamp(-(A * nrm) * cjn, -a.mg, a.mg);         // (:232-233)
+    const float A = cp_normal_force(a.k, dh, a.damp, vn);
+    const float Fr = M::clamp(cp_spring(A, nrm, cj, inv_csum), -a.mg, a.mg);      // (:232-233)
     const float Nn = M::sqrt(dot3(Fr, Fr));                           // (:238)
-    const float s = mub * (tv * g.e - vp);                            // slip (:247)
+    const float s = mub * cp_cmd(tv, g.e, vp);                        // slip (:247)
     const float sn = dot3(s, nrm);
-    const float Ff = M::clamp(Nn * (s - sn * nrm), -a.mg, a.mg);      // (:248-251); absent points: cj = 0 -> Fr = Nn = Ff = 0
+    const float Ff = M::clamp(Nn * cp_tangent(s, sn, nrm), -a.mg, a.mg);   // (:248-251); absent points: cj = 0 -> Fr = Nn = Ff = 0
     const float f = Fr + Ff;
     const float tau = unrot(cross_pre(g.r, f));                        // r x (Fs + Ff)   (:255)
     const float Fsum = sum_points(f), Tsum = sum_points(tau);
     // omega_d = clamp(I^-1 tau)   (:256-257); xdd = (m g ghat + sum F) / m   (:264-266)
-    const float wraw = I0 * dpp<kB0>(Tsum) + I1 * dpp<kB1>(Tsum) + I2 * dpp<kB2>(Tsum);
+    const float wraw = cp_wraw(I0, I1, I2, Tsum);
     *wd = M::clamp(wraw, -a.omega_max, a.omega_max);
     *xdd = Fsum * a.inv_mass - grav_c;
     *oFr = Fr; *oFf = Ff;
     if constexpr (REC) {
       typedef float f4v __attribute__((ext_vector_type(4)));
-      __builtin_nontemporal_store(f4v{__builtin_bit_cast(float, g.idx), g.zc, has_mu ? g.mc : one, g.wa}, reinterpret_cast<f4v*>(pRec0 + (size_t)rec_off));
-      __builtin_nontemporal_store(f4v{g.wb, nrm, inl, mub}, reinterpret_cast<f4v*>(pRec1 + (size_t)rec_off));
-      __builtin_nontemporal_store(f4v{cj, inv_csum, A, Nn}, reinterpret_cast<f4v*>(pRec2 + (size_t)rec_off));
-      __builtin_nontemporal_store(f4v{sn, wraw, g.il, g.coln2}, reinterpret_cast<f4v*>(pRec3 + (size_t)rec_off));
+      const f4v rq = {bfi(m_q01, g.fr, Nn), bfi(m_q01, __builtin_bit_cast(float, g.ui), sn), bfi(m_q012, wraw, cj), A};
+      __builtin_nontemporal_store(rq, reinterpret_cast<f4v*>(pRec0 + (size_t)rec_off));
       rec_off += rec_step;
     }
   };
@@ -211,7 +202,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
       v_ctrl = min(v_ctrl + ctrl_step, v_ctrl_last);
       bload2(rCtrl, v_ctrl, 0u, &cv_next, &cw_next);
       const float t_next = a.ts[min(n + 2, a.T - 1)];
-      const float tv = tv_v * cv_n + tv_w * cw_n;
+      const float tv = cp_track(tv_v, tv_w, cv_n, cw_n);
       // ---- stream B: pose and geometry of step n + 1 (torchdiffeq fixed-grid euler: y_{n+1} = y_n + h f(t_n, y_n)) ----
       // (column j of R is a 3-vector over the lanes: dR_j = w x R_j)
       const float d0 = h * cross_pre(w, R0), d1 = h * cross_pre(w, R1), d2 = h * cross_pre(w, R2);
@@ -248,7 +239,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
       const int nn = min(n + 1, a.T - 1);
       float cv_next, cw_next;
       bload2(rCtrl, v_ctrl, __builtin_amdgcn_readfirstlane((unsigned)(nn * a.ctrl_st) * 4u), &cv_next, &cw_next);
-      const float tv = tv_v * cv + tv_w * cw;
+      const float tv = cp_track(tv_v, tv_w, cv, cw);
       float xdd, wd, Fr, Ff;
       // dynamics(): the next pose needs this step's forces (x += xd_new h, R <- R M(w_new)): one stream
       const Geo g = geometry(x, R0, R1, R2);

@@ -54,7 +54,7 @@ struct RolloutArgs {
   int pose_stride;        // COST kernels: Xs / Rs hold every pose_stride-th output row only
   S* path_cost;           // COST kernels, optional: S[B] std over the T output rows of the 4th cost-row component
   const S* zmu;           // ZMU kernels: the shared height and friction maps interleaved, S[H*W][2] = (z, mu) per cell
-  S* rec;                 // component-parallel kernels, optional: the per-step record for the backward, S[T][B*16 lanes][16]
+  S* rec;                 // component-parallel kernels, optional: the compact per-step record for the backward, [T][B*16 lanes] 16-byte quads
 };
 
 // Arithmetic policy.  Exact: IEEE divide / sqrt, libm exp and sincos, un-fused mul+add (the TU is built with

@@ -65,8 +65,9 @@ def test_force_stride_query(built_lib):
 
 
 def test_record_bytes_query(built_lib):
-    """`mf_rollout_record_bytes` is a host-side policy: 1 KiB per rollout and step where both directions run component-parallel
-    with the default integrator and at most 256 waves; 0 everywhere else (the caller then passes rec = NULL)."""
+    """`mf_rollout_record_bytes` is a host-side policy: 256 B per rollout and step where both directions run component-parallel
+    (either integrator) with at most one wave per SIMD (1024 waves = 4096 rollouts); 0 everywhere else (the caller then passes
+    rec = NULL).  VERDICT r2 item 1: <= 131 MB at the BASELINE shape (round 2: 524 MB, and only up to 1024 rollouts)."""
     import ctypes as C
     from monoforce_amd import _lib
     built_lib.mf_rollout_record_bytes.restype = C.c_longlong
@@ -76,11 +77,12 @@ def test_record_bytes_query(built_lib):
                  layout=_lib.MF_LAYOUT_TIME_MAJOR)
         d.update(kw)
         return int(built_lib.mf_rollout_record_bytes(C.byref(_lib.MfRolloutDesc(**d))))
-    assert q() == 1024 * 500 * 1024
-    assert q(B=1, T=200) == 200 * 1024
-    assert q(B=3, T=7, N=2) == 3 * 7 * 1024                  # per-lane slabs: absent contact points included
-    assert q(B=1025) == 0 and q(B=2048) == 0                 # more than 256 waves: the forward would be bound by the record's stores
-    assert q(integrator=0) == 0                              # dynamics(): measured, no gain
+    assert q() == 1024 * 500 * 256 <= 131.1e6
+    assert q(B=1, T=200) == 200 * 256
+    assert q(B=3, T=7, N=2) == 3 * 7 * 256                   # per-lane slabs: absent contact points included
+    assert q(B=2048) == 2048 * 500 * 256 and q(B=4096) == 4096 * 500 * 256
+    assert q(B=4097) == 0 and q(B=8192) == 0                 # more than one wave per SIMD: the recomputing kernels
+    assert q(integrator=0) == q()                            # dynamics() keeps the same record
     assert q(N=5, force_stride=5) == 0 and q(math_mode=_lib.MF_MATH_EXACT) == 0 and q(has_joints=1) == 0
     assert q(points_per_lane=1) == 0                         # an explicit other lane mapping
     assert int(built_lib.mf_rollout_record_bytes(None)) == 0

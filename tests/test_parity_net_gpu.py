@@ -426,81 +426,92 @@ _NO_RECORD = r'''
 import sys, torch
 sys.path.insert(0, %r)
 from tests.test_parity_net_gpu import _record_case
-torch.save(_record_case(), %r)
+torch.save(_record_case(%d, %d), %r)
 '''
 
 
-def _record_case():
+def _record_case(integ=1, B=37):
     from monoforce_amd import synthetic as syn
     pts, masks = syn.robot_points_4()
-    B, T = 37, 90
+    T = 90
     z = syn.bump_terrain(syn.bump_params(61), 6.4, 0.05) * 0.8
     mu = syn.wave_friction(6.4, 0.05, 0.5, 1.0, 1.3, 0.9)
     ctrl = syn.varying_controls(B, T, seed=9)
-    dp = make_dphysics(pts, masks, 1, 0.05, 6.4)
+    dp = make_dphysics(pts, masks, integ, 0.05, 6.4)
     zd, md, cd = z.to(DEV).requires_grad_(True), mu.to(DEV).requires_grad_(True), ctrl.to(DEV).requires_grad_(True)
     st, fo = dp(zd.unsqueeze(0), cd, friction=md.unsqueeze(0))
     outs = list(st) + list(fo)
     hp.probe_loss(outs, torch.float32).backward()
-    return dict(outs=[o.detach().cpu() for o in outs], gz=zd.grad.cpu(), gmu=md.grad.cpu(), gc=cd.grad.cpu())
+    keep = slice(0, 64)       # (the larger batches: outputs of the first rollouts only -- the gradients carry all of them)
+    return dict(outs=[o.detach()[keep].cpu() for o in outs], gz=zd.grad.cpu(), gmu=md.grad.cpu(), gc=cd.grad.cpu())
 
 
-def test_backward_from_the_forward_record_equals_the_recomputing_backward():
-    """Small launches of the default integrator keep a per-step record in the forward (MfRolloutFwdBufs.rec) and the backward
-    reads it instead of recomputing (the default here, through a second wave that streams it into LDS); a child process with MF_CP_RECORD_MAX_WAVES=0 runs the same problem
-    through the recomputing backward: same outputs bit for bit (the record changes no arithmetic of the forward), gradients to
-    float32 rounding, and both within the usual bar of the float64 oracle."""
+# B = 37: one workgroup-wave per CU (eight-slot ring); 1500 rollouts = 375 waves: two workgroups per CU (six-slot ring);
+# 3000 rollouts = 750 waves: beyond the streaming form, the record read by one wave.  dynamics() (integ 0): one wave throughout.
+@pytest.mark.parametrize('integ,B', [(1, 37), (0, 37), (1, 1500), (1, 3000), (0, 1500)])
+def test_backward_from_the_forward_record_equals_the_recomputing_backward(integ, B):
+    """Launches of up to one wave per SIMD keep a compact per-step record in the forward (MfRolloutFwdBufs.rec, 256 B per
+    rollout-step) and the backward reads it instead of recomputing (default integrator: through a second wave that streams it
+    into LDS); a child process with MF_CP_RECORD_MAX_WAVES=0 runs the same problem through the recomputing backward: same outputs
+    bit for bit (the record changes no arithmetic of the forward), gradients to float32 rounding, and -- at the small batch --
+    both within the usual bar of the float64 oracle."""
     import os, subprocess, sys, tempfile
     from oracle import dphysics_oracle as orc  # noqa: F401
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with_rec = _record_case()
+    with_rec = _record_case(integ, B)
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, 'norec.pt')
         env = dict(os.environ, MF_CP_RECORD_MAX_WAVES='0')
-        r = subprocess.run([sys.executable, '-c', _NO_RECORD % (repo, path)], capture_output=True, text=True, timeout=600, env=env)
+        r = subprocess.run([sys.executable, '-c', _NO_RECORD % (repo, integ, B, path)], capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, r.stderr[-2000:]
         without = torch.load(path)
         # the record read by the computing wave itself (MF_CP_BWD_MODE=2) instead of streamed through LDS by a second wave
-        # (the default at this size): the same arithmetic, the adjoint state summed over the contact points once instead of every step
+        # (the default integrator's default): the same arithmetic, the adjoint state summed over the contact points once instead of every step
         path1 = os.path.join(td, 'onewave.pt')
-        r = subprocess.run([sys.executable, '-c', _NO_RECORD % (repo, path1)], capture_output=True, text=True, timeout=600,
+        r = subprocess.run([sys.executable, '-c', _NO_RECORD % (repo, integ, B, path1)], capture_output=True, text=True, timeout=600,
                            env=dict(os.environ, MF_CP_BWD_MODE='2'))
         assert r.returncode == 0, r.stderr[-2000:]
         one_wave = torch.load(path1)
     for a_, b_ in zip(with_rec['outs'], without['outs']):
         assert torch.equal(a_, b_)
+    tol = 2e-5 if B <= 64 else 1e-4       # (thousands of rollouts add up in the map gradients: float32 sums in another order)
     for k in ('gz', 'gmu', 'gc'):
-        assert hp.rel_err(with_rec[k], without[k]) <= 2e-5, (k, hp.rel_err(with_rec[k], without[k]))
-        assert hp.rel_err(with_rec[k], one_wave[k]) <= 2e-5, (k, hp.rel_err(with_rec[k], one_wave[k]))      # (sums in another order)
+        assert hp.rel_err(with_rec[k], without[k]) <= tol, (k, hp.rel_err(with_rec[k], without[k]))
+        assert hp.rel_err(with_rec[k], one_wave[k]) <= tol, (k, hp.rel_err(with_rec[k], one_wave[k]))      # (sums in another order)
+    if B > 64:
+        return
     # ... and the recorded route against the oracle
     from monoforce_amd import synthetic as syn
     pts, masks = syn.robot_points_4()
-    B, T = 37, 90
+    T = 90
     z = (syn.bump_terrain(syn.bump_params(61), 6.4, 0.05) * 0.8).double().requires_grad_(True)
     mu = syn.wave_friction(6.4, 0.05, 0.5, 1.0, 1.3, 0.9).double().requires_grad_(True)
     ctrl = syn.varying_controls(B, T, seed=9).double().requires_grad_(True)
-    spec = hp.spec_from(pts, masks, 1, 0.05, 6.4)
+    spec = hp.spec_from(pts, masks, integ, 0.05, 6.4)
     rs, rf = orc.rollout(spec, z.unsqueeze(0).expand(B, -1, -1), ctrl, friction=mu.unsqueeze(0).expand(B, -1, -1))
     hp.probe_loss(list(rs) + list(rf), torch.float64).backward()
     assert hp.rel_err(with_rec['gz'], z.grad) <= 2e-4 and hp.rel_err(with_rec['gmu'], mu.grad) <= 2e-4 and hp.rel_err(with_rec['gc'], ctrl.grad) <= 2e-4
 
 
+@pytest.mark.parametrize('integ', [1, 0])
 @pytest.mark.parametrize('loss_on', ['all', 'positions'])
-def test_streaming_backward_every_horizon_remainder(loss_on):
+def test_streaming_backward_every_horizon_remainder(loss_on, integ):
     """The backward that streams the forward's record through LDS (rollout_bwd_cp_kernel.h, MODE = kCpStream) fetches in batches
-    of three steps, two batches in registers, and peels the last steps; the computing wave runs two steps per trip.  Horizons
-    1 .. 14 and 20 / 47 / 48 put every remainder of those loops through it (all-outputs loss with control gradients, and the
-    positions-only variant of the training loss), against the one-point-per-lane kernels: float32 rounding apart."""
+    of three steps through a three-stage pipeline (loads | cell gathers | rebuild) over three register sets, drains it in one
+    of three ways and peels the last steps; the computing wave runs two steps per trip (dynamics(): one wave reads the record,
+    two steps per trip).  Horizons 1 .. 26 and 47 / 48 put every prologue, drain and remainder of those loops through it
+    (all-outputs loss with control gradients, and the positions-only variant of the training loss), against the
+    one-point-per-lane kernels: float32 rounding apart."""
     from monoforce_amd import synthetic as syn
     pts, masks = syn.robot_points_4()
     B = 6
     z = torch.stack([syn.bump_terrain(syn.bump_params(20 + k), 1.6, 0.1) * 0.3 for k in range(B)])
     mu = torch.stack([syn.wave_friction(1.6, 0.1, 0.5, 1.0, 1.1 + 0.2 * k, 0.8) for k in range(B)])
-    for T in list(range(1, 15)) + [20, 47, 48]:
+    for T in list(range(1, 27)) + [47, 48]:
         ctrl = syn.varying_controls(B, max(T, 2), seed=3)[:, :T]
         res = {}
         for ppl in (16, 1):
-            dp = make_dphysics(pts, masks, 1, 0.1, 1.6, points_per_lane=ppl)
+            dp = make_dphysics(pts, masks, integ, 0.1, 1.6, points_per_lane=ppl)
             zd, md, cd = z.cuda().requires_grad_(True), mu.cuda().requires_grad_(True), ctrl.cuda().requires_grad_(True)
             st, fo = dp(zd, cd, friction=md)
             if loss_on == 'all':
