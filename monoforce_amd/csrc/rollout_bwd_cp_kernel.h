@@ -44,8 +44,29 @@ __device__ __forceinline__ float ld1(const float* base, unsigned off) {
 // BESIDE the chain of step n, three register sets, unrolled by three): the same ~350 instructions per step, interleaved by
 // the compiler instead of run one stream after the other, and slower: 0.399 vs 0.367 ms (dynamics(): 0.548 vs 0.448).
 enum { kCpEarly = 0, kCpLate = 1, kCpSaved = 2, kCpStream = 3 };
-template <int INTEG, bool XS_ONLY, bool GCTRL, int MODE, int SLOTS = 8>
-__global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
+#ifdef MF_STREAM_PROFILE      // A/B build: where the waves of the streaming backward spend their cycles (tools/stream_profile.py)
+extern __device__ unsigned long long mf_stream_prof[16];
+#define MF_PROF_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#define MF_PROF_ACC(name) unsigned long long name = 0
+#define MF_PROF_SUM(name, t0) name += __builtin_readcyclecounter() - (t0)
+#define MF_PROF_OUT(slot, val) do { if (lane == 0) atomicAdd(&mf_stream_prof[slot], (unsigned long long)(val)); } while (0)
+#define MF_PROF_ADD(slot, t0) MF_PROF_OUT(slot, __builtin_readcyclecounter() - (t0))
+#else
+#define MF_PROF_T(v)
+#define MF_PROF_ACC(name)
+#define MF_PROF_SUM(name, t0)
+#define MF_PROF_OUT(slot, val)
+#define MF_PROF_ADD(slot, t0)
+#endif
+#ifdef MF_NO_WPE      // A/B build: no register limit on the streaming kernels
+#define MF_STREAM_WPE
+#else
+#define MF_STREAM_WPE __attribute__((amdgpu_waves_per_eu((MODE == kCpStream && XS_ONLY) ? 2 : 1)))
+#endif
+template <int INTEG, bool XS_ONLY, bool GCTRL, int MODE, int SLOTS = 6>
+// (streaming, positions-only loss: at most 256 registers, so that two workgroups -- six waves -- share a CU's four SIMDs)
+__global__ void __launch_bounds__(MODE == kCpStream ? 192 : 64) MF_STREAM_WPE
+rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
   constexpr bool ODE = INTEG == MF_INTEG_ODEINT_EULER;
   constexpr bool LATE = MODE == kCpLate, STREAM = MODE == kCpStream, SAVED = MODE == kCpSaved || STREAM;
   using namespace cp;
@@ -446,6 +467,10 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
       const int ui = __builtin_bit_cast(int, uf);
       const int base = dppi<kB1>(ui) + __mul24(a.H, dppi<kB0>(ui));
       v.idx = min(max(base + cell_off, 0), last);
+#ifdef MF_STREAM_NO_GATHER   // A/B build: the cells as constants -- what the second round trip of the fetching wave costs
+      v.zc = 0.1f * (float)q; v.mc = 0.8f;
+      return;
+#endif
       v.zc = ld32(zmap, moff + (unsigned)v.idx);
       v.mc = ld32(mumap, moff + (unsigned)v.idx);
     };
@@ -496,16 +521,25 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
       unsigned og_xs = u_xs + (un + 1u) * sg_xs, og_xds = u_xds + (un + 1u) * sg_xds, og_om = u_om + (un + 1u) * sg_om;
       unsigned og_r = u_r + (un + 1u) * sg_r, og_fs = u_fs + (un + 1u) * sg_fs, og_ff = u_ff + (un + 1u) * sg_ff;
       int ti = max(n, 0);                        // index of the lower time stamp of the requested step
-      float t_hi = a.ts[min(ti + 1, a.T - 1)];
       auto request_state = [&](StateIn& d, Saved& v) {      // rows + record of the step the offsets point at
         d.x = zero;                                            // (positions are not needed: the record replaces what used them)
+#ifdef MF_STREAM_NO_FETCH    // A/B build: no loads at all -- times the rebuild + ring writes + the computing wave
+        d.xd = 0.1f; d.w = 0.01f; d.R0 = cc == 0 ? one : zero; d.R1 = cc == 1 ? one : zero; d.R2 = cc == 2 ? one : zero; d.cv = 0.5f; d.cw = 0.1f;
+        d.t1 = 0.01f; d.t0 = zero; v.q = f4v{0.3f, __builtin_bit_cast(float, 100), 0.2f, 50.0f};
+        return;
+#endif
         d.xd = bload1(rXds, o3, 0u); d.w = bload1(rOm, o3, 0u);
         bload3(rRs, o9, 0u, &d.R0, &d.R1, &d.R2);
         bload2(rCtrl, oc, 0u, &d.cv, &d.cw);
-        d.t1 = t_hi; d.t0 = a.ts[ti]; t_hi = d.t0;
+        d.t1 = a.ts[ti + 1]; d.t0 = a.ts[ti];               // (every fetched step is a real one: 0 <= ti <= T - 2)
         v.q = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(prec + (size_t)orc));
       };
       auto request_up = [&](UpIn& u) {                       // upstream gradients of the row that step produced
+#ifdef MF_STREAM_NO_FETCH
+        u.gXs = 0.001f;
+        if constexpr (!XS_ONLY) { u.gXds = u.gOm = u.gR0 = u.gR1 = u.gR2 = u.gFs = u.gFf = 0.001f; }
+        return;
+#endif
         u.gXs = bload1(rgXs, og_xs, 0u);
         if constexpr (!XS_ONLY) {
           u.gXds = bload1(rgXds, og_xds, 0u); u.gOm = bload1(rgOm, og_om, 0u);
@@ -526,21 +560,51 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
       if (threadIdx.x == 0) { flags[0] = 0; flags[1] = 0; }
       __syncthreads();
       if (threadIdx.x >= 64) {
-        // ---------------- the fetching wave ----------------
+        // ---------------- the two fetching waves ----------------
+        // The steps go out in batches of three; fetching wave k (0 / 1) takes every other batch -- one wave's instruction
+        // stream (~150 instructions per step: rebuild, gates, coefficient products, ten LDS writes) could not stay ahead of the
+        // computing wave's ~1000 cycles per step once the cell gathers had joined it (measured: 0.221 ms alone at B = 1024
+        // against the chain's 0.20).  Each runs its own three-stage pipeline over its batches.  Ring: six or twelve slots, a
+        // batch's first step (ordinal 3 j) sits in slot 3 j mod kSlots (six slots: wave k owns slots 3k .. 3k + 2); steps are
+        // published -- `steps written` advanced -- in order: a wave waits for the other one's previous batch.
+        static_assert(kSlots % 6 == 0, "two fetching waves alternate over batches of three steps: a batch must not wrap around the ring");
         struct Slot { StateIn st; Saved sv; UpIn up; };
-        int produced = 0, m = n;                    // m: the step the offsets point at
-        unsigned wslot = 0u;                        // ring slot written next (running, wraps at kSlots)
+        const int fk = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) - 1;      // (wave-uniform, and provably so: scalar branches)
+        int m = n;                                  // m: the step the offsets point at
         auto fetch = [&](Slot& r) {                 // everything of step m; then the offsets move to step m - 1
-          request_state(r.st, r.sv);                // (after step 0 the offsets wrap around; nothing reads them again)
+          request_state(r.st, r.sv);                // (past step 0 the offsets wrap around; nothing reads them again)
           request_up(r.up);
           o3 -= s3; o9 -= s9; oc -= 8u; orc -= rec_step; --ti;
           step_back_up();
           --m;
         };
+        auto skip3 = [&]() {                        // over the other wave's batch
+          o3 -= 3u * s3; o9 -= 3u * s9; oc -= 24u; orc -= 3u * rec_step; ti -= 3; m -= 3;
+          og_xs -= 3u * sg_xs;
+          if constexpr (!XS_ONLY) { og_xds -= 3u * sg_xds; og_om -= 3u * sg_om; og_r -= 3u * sg_r; og_fs -= 3u * sg_fs; og_ff -= 3u * sg_ff; }
+        };
         // ... and everything of the step's vector-Jacobian product that does not depend on the adjoint is done HERE, on the
-        // wave that has time: the rebuild, the clamp gates, 1 / |F_n|, and every product of two such values the chain would
+        // waves that have time: the rebuild, the clamp gates, 1 / |F_n|, and every product of two such values the chain would
         // form -- the ring carries the chain's COEFFICIENTS (struct Coef below), forty floats per lane and step.
-          auto put = [&](const Slot& r) {
+        MF_PROF_T(t_fetcher);
+        MF_PROF_ACC(acc_room); MF_PROF_ACC(acc_pub);
+        auto room = [&](int upto) {                 // until the steps with ordinals < upto may be written (their slots have been read)
+          MF_PROF_T(t0);
+          while (upto - __builtin_amdgcn_readfirstlane(vflags[1]) > kSlots) __builtin_amdgcn_s_sleep(2);
+          asm volatile("" ::: "memory");
+          MF_PROF_SUM(acc_room, t0);
+        };
+        auto publish = [&](int from, int upto) {    // steps [from, upto) are in the ring: in order behind the other wave's
+          asm volatile("" ::: "memory");
+          MF_PROF_T(t0);
+          while (__builtin_amdgcn_readfirstlane(vflags[0]) != from) __builtin_amdgcn_s_sleep(1);
+          asm volatile("" ::: "memory");
+          MF_PROF_SUM(acc_pub, t0);
+          vflags[0] = upto;
+        };
+        // (per step: everything is computed BEFORE the wave asks for room in the ring, the ten writes follow the grant, and the step is
+        //  published at once -- with whole batches behind one grant the computing wave idled 9 % of its time while a batch was rebuilt)
+        auto put = [&](const Slot& r, unsigned slot, int o) {
             Rec k;
             rebuild(r.st, r.sv, k);
             const float mw = inside(k.wraw, -a.omega_max, a.omega_max) ? one : zero;
@@ -550,38 +614,38 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
             const float cmask = k.coln2 >= 1e-12f ? one : zero;
             const float cs = k.cj * k.inv_csum;
             // (the upstream gradient of a state row goes to point 0's quad: add_upstream_masked)
-            f4v* o = ring + (kPow2 ? (unsigned)(produced & (kSlots - 1)) : wslot) * (unsigned)(kPlanes * 64) + lane;
-            if constexpr (!kPow2) wslot = wslot + 1u == (unsigned)kSlots ? 0u : wslot + 1u;
-            o[0] = f4v{k.R0, k.R1, k.R2, k.h};
-            o[64] = f4v{k.w1, k.w2, k.r1, k.r2};
-            o[128] = f4v{k.f1, k.f2, mw, mG * k.stv};
-            o[192] = f4v{mG * k.Nn, k.nrm, k.s, k.sn};
-            o[256] = f4v{k.cmdv, k.mub, k.tv * k.mub, k.Fr * invNn};
-            o[320] = f4v{mF1 * cs, mF1 * k.nrm, k.A, -(a.k * cs)};
-            o[384] = f4v{-(a.damp * cs), -(k.A * k.inv_csum), k.A * k.cj * k.inv_csum * k.inv_csum, -10.0f * k.cj * (one - k.cj)};
-            o[448] = f4v{k.vp, -(k.inl * a.inv_res), k.wq, __builtin_bit_cast(float, k.idx)};
-            o[512] = f4v{k.zc, k.mcv, wa_s * k.wb * a.inv_res, wb_s * k.wa * a.inv_res};
-            o[576] = f4v{k.e, k.il, cmask * k.e * k.il, first * r.up.gXs};
+            const f4v p0 = f4v{k.R0, k.R1, k.R2, k.h};
+            const f4v p1 = f4v{k.w1, k.w2, k.r1, k.r2};
+            const f4v p2 = f4v{k.f1, k.f2, mw, mG * k.stv};
+            const f4v p3 = f4v{mG * k.Nn, k.nrm, k.s, k.sn};
+            const f4v p4 = f4v{k.cmdv, k.mub, k.tv * k.mub, k.Fr * invNn};
+            const f4v p5 = f4v{mF1 * cs, mF1 * k.nrm, k.A, -(a.k * cs)};
+            const f4v p6 = f4v{-(a.damp * cs), -(k.A * k.inv_csum), k.A * k.cj * k.inv_csum * k.inv_csum, -10.0f * k.cj * (one - k.cj)};
+            const f4v p7 = f4v{k.vp, -(k.inl * a.inv_res), k.wq, __builtin_bit_cast(float, k.idx)};
+            const f4v p8 = f4v{k.zc, k.mcv, wa_s * k.wb * a.inv_res, wb_s * k.wa * a.inv_res};
+            const f4v p9 = f4v{k.e, k.il, cmask * k.e * k.il, first * r.up.gXs};
+            room(o + 1);
+            f4v* out = ring + slot * (unsigned)(kPlanes * 64) + lane;
+            out[0] = p0; out[64] = p1; out[128] = p2; out[192] = p3; out[256] = p4; out[320] = p5; out[384] = p6; out[448] = p7; out[512] = p8; out[576] = p9;
             if constexpr (!XS_ONLY) {
-              o[640] = f4v{first * r.up.gXds, first * r.up.gOm, r.up.gFs, r.up.gFf};
-              o[704] = f4v{first * r.up.gR0, first * r.up.gR1, first * r.up.gR2, zero};
+              out[640] = f4v{first * r.up.gXds, first * r.up.gOm, r.up.gFs, r.up.gFf};
+              out[704] = f4v{first * r.up.gR0, first * r.up.gR1, first * r.up.gR2, zero};
             }
-            ++produced;
+            publish(o, o + 1);
           };
-        auto room = [&](int want) {                 // wait until `want` more slots may be overwritten
-          while (produced + want - __builtin_amdgcn_readfirstlane(vflags[1]) > kSlots) __builtin_amdgcn_s_sleep(2);
-          asm volatile("" ::: "memory");
-        };
-        auto fetch3 = [&](Slot (&s)[3]) { fetch(s[0]); fetch(s[1]); fetch(s[2]); };
+        int ord = 3 * fk;                           // ordinal of the first step of this wave's next batch to WRITE
+        unsigned sbase = 3u * (unsigned)fk;         // ... and its ring slot: (3 j) mod kSlots
+        auto fetch3 = [&](Slot (&s)[3]) { fetch(s[0]); fetch(s[1]); fetch(s[2]); skip3(); };
         auto gather3 = [&](Slot (&s)[3]) { gather_cells(s[0].sv); gather_cells(s[1].sv); gather_cells(s[2].sv); };
         auto put3 = [&](const Slot (&s)[3]) {
-          room(3);
-          put(s[0]); put(s[1]); put(s[2]);
-          asm volatile("" ::: "memory");
-          vflags[0] = produced;
+          put(s[0], sbase, ord); put(s[1], sbase + 1u, ord + 1); put(s[2], sbase + 2u, ord + 2);
+          ord += 6;
+          if constexpr (kSlots != 6) sbase = sbase + 6u >= (unsigned)kSlots ? sbase + 6u - (unsigned)kSlots : sbase + 6u;
         };
         Slot A[3], B[3], C[3];
-        int full = (m + 1) / 3;                     // whole batches of three steps still to fetch (m + 1 steps are left)
+        const int n_full = (n + 1) / 3;             // whole batches of three steps in the launch (n + 1 steps)
+        int full = (n_full - fk + 1) / 2;           // ... of which this wave takes every other one, starting with batch fk
+        if (fk == 1) skip3();
         if (full >= 2) {
           fetch3(A); fetch3(B); gather3(A);
           full -= 2;                                // invariant: A fetched and gathered, B fetched, `full` batches not yet fetched
@@ -595,15 +659,20 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
           else if (full == 1) { fetch3(C); gather3(B); put3(A); gather3(C); put3(B); put3(C); }
           else { fetch3(C); gather3(B); put3(A); fetch3(A); gather3(C); put3(B); gather3(A); put3(C); put3(A); }
         } else if (full == 1) { fetch3(A); gather3(A); put3(A); }
-        while (m >= 0) {                            // the last one or two steps
-          Slot r0;
-          fetch(r0);
-          gather_cells(r0.sv);
-          room(1);
-          put(r0);
-          asm volatile("" ::: "memory");
-          vflags[0] = produced;
+        // the last one or two steps: the wave whose turn it would be (its offsets stand on them, its half of the ring is next)
+        if (fk == (n_full & 1)) {
+          int o = 3 * n_full;
+          unsigned sl = sbase;
+          while (m >= 0) {                          // (fetch moves m)
+            Slot r0;
+            fetch(r0);
+            gather_cells(r0.sv);
+            put(r0, sl, o);
+            ++sl; ++o;
+          }
         }
+        MF_PROF_ADD(2 + 4 * fk, t_fetcher);
+        MF_PROF_OUT(0 + 4 * fk, acc_room); MF_PROF_OUT(1 + 4 * fk, acc_pub);
         return;
       }
         // ---------------- the computing wave ----------------
@@ -625,10 +694,14 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
         };
         // (the loop asks for the two steps of a trip at once, and reports them read at once: the counters cost an LDS
         //  instruction each, ~14 cycles of this wave)
+        MF_PROF_T(t_compute);
+        MF_PROF_ACC(acc_wait);
         auto ensure = [&](int k) {                    // until k more steps are in the ring
+          MF_PROF_T(t0);
           int have = __builtin_amdgcn_readfirstlane(seen);
           while (have < consumed + k) have = __builtin_amdgcn_readfirstlane(vflags[0]);
           asm volatile("" ::: "memory");
+          MF_PROF_SUM(acc_wait, t0);
         };
         auto grab = [&](Coef& c, UpIn& up) {          // the next step out of the ring (it is there: ensure)
           const f4v* o = ring + (kPow2 ? (unsigned)(consumed & (kSlots - 1)) : rslot) * (unsigned)(kPlanes * 64) + lane;
@@ -743,7 +816,11 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
           else if constexpr (decltype(more)::value) take(c_next, up_next);
           flush_stash();
           if constexpr (GCTRL) bstore2(rGctrl, v_ctrl, gctrl_pending, gv_pending, gwc_pending);
+#ifdef MF_STREAM_NO_VJP      // A/B build (tools/build_variant.sh): the computing wave only takes the steps -- times the fetching wave alone
+          asm volatile("" :: "v"(c.R0), "v"(c.w1), "v"(c.f1), "v"(c.NnG), "v"(c.cmdv), "v"(c.csm), "v"(c.dcs), "v"(c.vp), "v"(c.zc), "v"(c.e));
+#else
           chain(n, c, up);
+#endif
         };
         using std::true_type;
         using std::false_type;
@@ -759,6 +836,8 @@ __global__ void __launch_bounds__(MODE == kCpStream ? 128 : 64) rollout_bwd_cp_k
           if (n == 1) { crunch(1, cA, uA, cB, uB, true_type{}, single{}); crunch(0, cB, uB, cA, uA, false_type{}, single{}); }
           else crunch(0, cA, uA, cB, uB, false_type{}, single{});
         }
+        MF_PROF_ADD(9, t_compute);
+        MF_PROF_OUT(8, acc_wait);
         uA = uZ; uB = uZ;                             // (the epilogue reads whichever the last iteration would have requested into)
     } else {
       // MODE = kCpSaved: ONE wave reads the record itself (either integrator; launches the streaming form does not cover, and the

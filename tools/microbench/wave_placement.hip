@@ -16,7 +16,8 @@ __global__ void k_place(unsigned* ids, float* sink, int spin) {
 }
 int main(int argc, char** argv) {
   const int block = argc > 1 ? atoi(argv[1]) : 64;
-  for (int waves : {256, 512, 1024, 2048, 4096}) {
+  for (int waves0 : {256, 512, 768, 1024, 1536, 2048, 4096}) {
+    const int waves = waves0 / (block / 64) * (block / 64);
     unsigned* ids; float* sink; hipMalloc(&ids, 8 * waves); hipMalloc(&sink, 4);
     hipLaunchKernelGGL(k_place, dim3(waves * 64 / block), dim3(block), 0, 0, ids, sink, 200000);
     std::vector<unsigned> h(2 * waves); hipMemcpy(h.data(), ids, 8 * waves, hipMemcpyDeviceToHost);
@@ -27,6 +28,19 @@ int main(int argc, char** argv) {
       const unsigned cu_key = (xcc << 12) | (se << 8) | (sh << 4) | cu;
       per_cu[cu_key]++; per_simd[(cu_key << 2) | simd]++; per_xcc[xcc]++;
     }
+    // workgroups of several waves: do the waves of ONE workgroup sit on different SIMDs?
+    const int wpb = block / 64;
+    int shared_simd = 0, split_cu = 0;
+    for (int g = 0; wpb > 1 && g + wpb <= waves; g += wpb) {
+      bool same = false, other_cu = false;
+      for (int i = 0; i < wpb; ++i)
+        for (int j = i + 1; j < wpb; ++j) {
+          same |= ((h[2 * (g + i)] >> 4) & 3) == ((h[2 * (g + j)] >> 4) & 3);
+          other_cu |= ((h[2 * (g + i)] >> 8) & 0xff) != ((h[2 * (g + j)] >> 8) & 0xff);
+        }
+      shared_simd += same; split_cu += other_cu;
+    }
+    if (wpb > 1) printf("      workgroups of %d waves: %d of %d have two waves on one SIMD (%d span CUs)\n", wpb, shared_simd, waves / wpb, split_cu);
     std::map<int, int> hs, hc;
     for (auto& kv : per_simd) hs[kv.second]++;
     for (auto& kv : per_cu) hc[kv.second]++;
