@@ -449,7 +449,7 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
   int n = n_steps - 1;
   if constexpr (SAVED) {
     // The forward kept its COMPACT per-step record (layout: rollout_cp_common.h): per lane and step one 16-byte quad -- the cell
-    // coordinates and fractions, |F_n|, s . n, the contact weight, A = k dh + d v_n and the unclamped angular acceleration.  The
+    // coordinates, the contact weight, A = k dh + d v_n and the unclamped angular acceleration.  The
     // reading wave re-gathers its footprint cell from the L2 (gather_cells) and rebuilds the rest with the forward's own
     // instructions (rebuild): no cell arithmetic from positions, no exponentials, no square roots, and -- because the
     // values that decide a clamp or the sign at the |F_n| kink are the forward's own -- no way to differentiate a different
@@ -461,10 +461,10 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
     auto load_saved = [&](int m, Saved& v) {
       v.q = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(prec + (size_t)__builtin_amdgcn_readfirstlane((unsigned)m) * (size_t)rec_step));
     };
-    // the lane's footprint cell from the recorded cell coordinates (lanes 0, 1 of the quad hold ix, iy), and its two gathers
+    // the lane's footprint cell from the recorded cell coordinates (lanes 0, 1 of the quad hold u_x, u_y), and its two gathers
     auto gather_cells = [&](Saved& v) {
-      const float uf = v.q.y;                    // (__builtin_bit_cast applied to the element expression itself reads element 0)
-      const int ui = __builtin_bit_cast(int, uf);
+      const float lim = 262144.0f;
+      const int ui = (int)M::clamp(v.q.x, -lim, lim);                  // as the forward's footprint(): trunc toward zero
       const int base = dppi<kB1>(ui) + __mul24(a.H, dppi<kB0>(ui));
       v.idx = min(max(base + cell_off, 0), last);
 #ifdef MF_STREAM_NO_GATHER   // A/B build: the cells as constants -- what the second round trip of the fetching wave costs
@@ -481,11 +481,12 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
       k.r1 = dpp<kRot1>(r); k.r2 = dpp<kRot2>(r);
       k.w1 = dpp<kRot1>(st.w); k.w2 = dpp<kRot2>(st.w);
       k.vp = cp_vel(st.xd, st.w, r);
-      const float qx = v.q.x, qy = v.q.y, qz = v.q.z, qw = v.q.w;
-      k.wa = fmaf(wa_s, dpp<kB0>(qx), wa_o); k.wb = fmaf(wb_s, dpp<kB1>(qx), wb_o);
+      const float lim = 262144.0f;
+      const float uq = v.q.x;
+      const float fr = uq - (float)(int)M::clamp(uq, -lim, lim);
+      k.wa = fmaf(wa_s, dpp<kB0>(fr), wa_o); k.wb = fmaf(wb_s, dpp<kB1>(fr), wb_o);
       k.wq = k.wa * k.wb;
-      k.Nn = dpp<kB2>(qx); k.sn = dpp<kB2>(qy); k.cj = dpp<kB3>(qz); k.A = qw;
-      k.wraw = dpp<kMir2>(qz);
+      k.cj = v.q.y; k.wraw = v.q.z; k.A = v.q.w;
       k.idx = v.idx; k.zc = v.zc; k.mcv = has_mu ? v.mc : one;
       k.mub = dot4(k.wq, k.mcv);
       const float dz = v.zc - dpp<kB0>(v.zc);
@@ -500,8 +501,10 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
       k.F0 = -(k.A * k.nrm);
       k.F1 = cp_spring(k.A, k.nrm, k.cj, k.inv_csum);
       k.Fr = M::clamp(k.F1, -mg, mg);
+      k.Nn = M::sqrt(dot3(k.Fr, k.Fr));
       k.cmdv = cp_cmd(k.tv, k.e, k.vp);
       k.s = k.mub * k.cmdv;
+      k.sn = dot3(k.s, k.nrm);
       k.stv = cp_tangent(k.s, k.sn, k.nrm);
       k.Gf = k.Nn * k.stv;
       const float f = k.Fr + M::clamp(k.Gf, -mg, mg);
@@ -525,7 +528,7 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
         d.x = zero;                                            // (positions are not needed: the record replaces what used them)
 #ifdef MF_STREAM_NO_FETCH    // A/B build: no loads at all -- times the rebuild + ring writes + the computing wave
         d.xd = 0.1f; d.w = 0.01f; d.R0 = cc == 0 ? one : zero; d.R1 = cc == 1 ? one : zero; d.R2 = cc == 2 ? one : zero; d.cv = 0.5f; d.cw = 0.1f;
-        d.t1 = 0.01f; d.t0 = zero; v.q = f4v{0.3f, __builtin_bit_cast(float, 100), 0.2f, 50.0f};
+        d.t1 = 0.01f; d.t0 = zero; v.q = f4v{100.3f, 0.2f, 0.1f, 50.0f};
         return;
 #endif
         d.xd = bload1(rXds, o3, 0u); d.w = bload1(rOm, o3, 0u);

@@ -95,14 +95,15 @@ __device__ __forceinline__ float bfi(unsigned m, float a, float b) {
 constexpr int kMir2 = 0xA4;    // quad_perm [0,1,2,2]: lane 3 <- lane 2 (a per-component value stored by lanes 0..2 of a quad)
 
 // ---- the forward's compact per-step record (MfRolloutFwdBufs.rec): ONE 16-byte quad per lane and step, 256 B per rollout-step ----
-// What the backward cannot get back from the saved state rows without redoing the contact chain, and nothing else:
-//   x : lanes 0, 1 of a quad: the cell fractions (fx, fy)          lanes 2, 3: |F_n| of the point
-//   y : lanes 0, 1: the cell coordinates (ix, iy), int bits        lanes 2, 3: s . n
-//   z : lanes 0..2: the unclamped angular acceleration (component) lane 3: the contact weight c of the point
+// What the backward cannot get back from the saved state rows without redoing the contact chain -- and only values the storing
+// lane holds anyway (no merge by lane role in the forward: at one wave per SIMD an issue slot is time):
+//   x : lanes 0, 1 of a quad: the cell coordinates u = (p + d_max) / res of the point (x, y) -- index and fraction follow exactly:
+//       i = trunc(u), f = u - i, and i + f == u in float32; lanes 2, 3: unused
+//   y : the contact weight c of the point          z : the unclamped angular acceleration (this lane's component)
 //   w : A = k dh + d v_n of the point
-// -- 28 + 3 unique floats of the 64.  Everything else of round 2's 1 KiB record is rebuilt by the wave that reads it: the gathered
-// cells come back from the L2 (the maps are 512 KiB), normal, blended friction, 1 / sum c, |R[:, 0]| from those and the state rows
-// with the forward's own instructions.  A step's slab is [B * 16 lanes] quads: each store / load of a wave is one contiguous KiB.
+// Everything else of round 2's 1 KiB record is rebuilt by the waves that read it, with the forward's own instructions on the same
+// inputs (so: the same bits): the gathered cells come back from the L2 (the maps are 512 KiB), normal, blended friction, 1 / sum c,
+// |F_n|, s . n, |R[:, 0]| from those and the state rows.  A step's slab is [B * 16 lanes] quads: a wave's store / load is one KiB.
 constexpr unsigned kRecBytesPerLane = 16;
 
 // ---- rows of the [T][B][...] arrays -----------------------------------------------------------------------------------------

@@ -9,7 +9,9 @@
 namespace mf {
 
 template <int INTEG, bool FORCES, bool ZMU, bool REC>
-__global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<float> a) {
+// (waves_per_eu: these launches hold at most two waves per SIMD -- without the hint the scheduler guards an occupancy of eight and leaves
+//  DPP hazards as s_nops rather than cross 64 registers: 335 -> 309 instructions per two steps with the record, 303 -> 301 without)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) rollout_fwd_cp_kernel(const RolloutArgs<float> a) {
   using namespace cp;
   using M = Mth<float, true>;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -58,7 +60,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
   }
 
   // footprint of the point under position component pc: this lane's cell index and weight
-  auto footprint = [&](float pc, int* idx, float* wq, float* ofr = nullptr, int* oui = nullptr) {
+  auto footprint = [&](float pc, int* idx, float* wq, float* ou = nullptr) {
     const float lim = 262144.0f;
     const float u = M::cell_coord(pc, a.d_max, a.res, a.inv_res);      // lanes 0, 1: ux, uy
     const int ui = (int)M::clamp(u, -lim, lim);                         // trunc toward zero, like .long()
@@ -67,7 +69,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
     *idx = min(max(base + cell_off, 0), last);                          // the reference clamps the FLAT index (:432-435)
     const float wa = fmaf(wa_s, dpp<kB0>(fr), wa_o), wb = fmaf(wb_s, dpp<kB1>(fr), wb_o);   // exact: 1 - f or f
     *wq = wa * wb;
-    if (ofr) { *ofr = fr; *oui = ui; }
+    if (ou) *ou = u;
   };
 
   // start at the terrain height: x.z <- mean_i interp(z, (P R^T + x)_i)   (dphysics.py:567-571)
@@ -126,12 +128,12 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
   // (x' = x + h xd, R' = R + h [w]x R use the old xd, w), so its kernels compute the geometry of step n + 1 -- and issue its
   // gathers -- while the contact chain of step n runs: two independent instruction streams in one basic block fill each
   // other's dependency stalls, and a gather has a whole step to arrive.
-  struct Geo { float r, pc, wq, zc, mc, e, fr, il, coln2; int idx, ui; };
+  struct Geo { float r, pc, wq, zc, mc, e, u, il, coln2; int idx; };
   auto geometry = [&](float gx, float g0, float g1, float g2) {
     Geo g;
     g.r = cp_body_r(P0, P1, P2, g0, g1, g2);         // (:200)
     g.pc = g.r + gx;
-    footprint(g.pc, &g.idx, &g.wq, &g.fr, &g.ui);
+    footprint(g.pc, &g.idx, &g.wq, &g.u);
     const int idx = g.idx;
     if constexpr (ZMU) {
       const float2 zm = *reinterpret_cast<const float2*>(reinterpret_cast<const char*>(a.zmu) + (size_t)((unsigned)idx * 8u));
@@ -146,15 +148,25 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
     return g;
   };
   // contact model + wrench of one step from its geometry and the state's velocities: (xdd, wd, F_spring, F_friction)
-  // REC: the compact per-step record for the backward (layout: rollout_cp_common.h) -- one 16-byte store per lane and step, three
-  // bit-field merges to assemble it (round 2 wrote four stores, 1 KiB per rollout-step: forward-with-record 4.05x its algorithmic
-  // HBM bytes, backward 2.06x).  One scalar plane base + one running 32-bit per-lane offset: mf_rollout_record_bytes keeps the
-  // record < 4 GiB.
+  // REC: the compact per-step record for the backward (layout: rollout_cp_common.h) -- ONE 16-byte store per lane and step of four
+  // values the lane holds anyway (no merging by lane role: a select is a VALU issue slot, and at one wave per SIMD the issue slots
+  // ARE the time; round 2 wrote four stores, 1 KiB per rollout-step: forward-with-record 4.05x its algorithmic HBM bytes, backward
+  // 2.06x).  One scalar base + one running 32-bit per-lane offset: mf_rollout_record_bytes keeps the record < 4 GiB.
   char* const pRec0 = reinterpret_cast<char*>(a.rec);
   unsigned rec_off = (unsigned)tid * kRecBytesPerLane;
   const unsigned rec_step = (unsigned)a.B * 16u * kRecBytesPerLane;
-  const unsigned m_q01 = q < 2 ? ~0u : 0u, m_q012 = q < 3 ? ~0u : 0u;
-  auto contact = [&](const Geo& g, float vxd, float vw, float tv, float* xdd, float* wd, float* oFr, float* oFf) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  auto rec_store = [&](const f4v& rq, unsigned adv) {
+#if defined(MF_REC_NOSTORE)        // A/B builds (tools/build_variant.sh): what the record's store costs / the plain-store form
+    asm volatile("" :: "v"(rq));
+#elif defined(MF_REC_PLAIN)
+    *reinterpret_cast<f4v*>(pRec0 + (size_t)rec_off) = rq;
+#else
+    __builtin_nontemporal_store(rq, reinterpret_cast<f4v*>(pRec0 + (size_t)rec_off));
+#endif
+    if (adv) rec_off += rec_step;
+  };
+  auto contact = [&](const Geo& g, float vxd, float vw, float tv, float* xdd, float* wd, float* oFr, float* oFf, f4v* rq) {
     const float vp = cp_vel(vxd, vw, g.r);                             // v_p = xd + w x r   (:204)
     const float zq = dot4(g.wq, g.zc);                               // height under the point (:211)
     const float mub = dot4(g.wq, has_mu ? g.mc : one);             // friction (:216); no map = a map of ones (:562)
@@ -182,12 +194,7 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
     *wd = M::clamp(wraw, -a.omega_max, a.omega_max);
     *xdd = Fsum * a.inv_mass - grav_c;
     *oFr = Fr; *oFf = Ff;
-    if constexpr (REC) {
-      typedef float f4v __attribute__((ext_vector_type(4)));
-      const f4v rq = {bfi(m_q01, g.fr, Nn), bfi(m_q01, __builtin_bit_cast(float, g.ui), sn), bfi(m_q012, wraw, cj), A};
-      __builtin_nontemporal_store(rq, reinterpret_cast<f4v*>(pRec0 + (size_t)rec_off));
-      rec_off += rec_step;
-    }
+    if constexpr (REC) *rq = f4v{g.u, cj, wraw, A};
   };
 
   if constexpr (INTEG == MF_INTEG_ODEINT_EULER) {
@@ -214,7 +221,12 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
       x = xn; R0 = Rn0; R1 = Rn1; R2 = Rn2;
       // ---- stream A: contact chain of step n ----
       float xdd, wd, Fr, Ff;
-      contact(g, xd, w, tv, &xdd, &wd, &Fr, &Ff);
+      f4v rq;
+      contact(g, xd, w, tv, &xdd, &wd, &Fr, &Ff, &rq);
+      // (measured and not kept: the quad held back and stored a step later next to the row stores -- its last value, the angular
+      //  acceleration, only exists where the next step's chain starts -- 0.1662 -> 0.1698 ms at B = 1024; plain instead of
+      //  non-temporal stores 0.1662 -> 0.1689; the store itself is ~4 us of the launch, keeping its four values alive ~3)
+      if constexpr (REC) rec_store(rq, 1u);
       xd = fmaf(h, xdd, xd);
       w = fmaf(h, wd, w);
       oFs = fmaf(h, Fr, oFs);
@@ -244,7 +256,9 @@ __global__ void __launch_bounds__(256) rollout_fwd_cp_kernel(const RolloutArgs<f
       // dynamics(): the next pose needs this step's forces (x += xd_new h, R <- R M(w_new)): one stream
       const Geo g = geometry(x, R0, R1, R2);
       emit_row(x, xd, w, R0, R1, R2, n > 0 ? 1u : 0u);      // n = 0: the initial state as a placeholder in row 0, overwritten one iteration later
-      contact(g, xd, w, tv, &xdd, &wd, &Fr, &Ff);
+      f4v rq;
+      contact(g, xd, w, tv, &xdd, &wd, &Fr, &Ff, &rq);
+      if constexpr (REC) rec_store(rq, 1u);
       // update_state (:274-288): xd += xdd h ; x += xd_new h ; w += wd h ; R <- R (I + K sin + K^2 (1 - cos))
       const float h = a.dt;
       xd = fmaf(xdd, h, xd);
