@@ -113,6 +113,26 @@ typedef struct MfRolloutDesc {
   double joint_xyz[12]; /* joint positions of the 4 driving parts [fl, fr, rl, rr][xyz] (cfg.joint_positions); has_joints only */
 } MfRolloutDesc;
 
+/* physics_loss (losses.py:102-127: time-discounted position MSE at the output rows nearest to the ground-truth stamps) INSIDE the
+ * rollout kernels: the forward accumulates  mean_{b,j,c} (Xs[b, near[j], c] w_j - gt[b, j, c] w_j)^2  at the
+ * <= T2 stamped rows while it writes them, and the backward synthesises dL/dXs at those rows from Xs and gt instead of reading a
+ * [T][B][3] gradient tensor -- a train step loses two launches and 6 MB of rows.  Float32, component-parallel kernels with the
+ * streaming backward only: ask mf_rollout_loss_fusable(desc).  The ground-truth stamps must be the SAME for every rollout
+ * (near / w / row_stamp are per stamp, not per rollout) and `near` strictly increasing. */
+typedef struct MfRolloutLoss {
+  int32_t T2;               /* ground-truth stamps per rollout */
+  int32_t reserved;
+  const void* gt;           /* S[B][T2][3] ground-truth positions */
+  const int32_t* near;      /* int32[T2]: output row nearest in time to stamp j (losses.py:116), strictly increasing, < T */
+  const void* w;            /* S[T2]: time weights 1 / (1 + gamma t_j) (losses.py:122) */
+  const int32_t* row_stamp; /* int32[T]: stamp index j of output row t, -1 where the row carries none (the inverse of `near`) */
+  void* partial;            /* forward scratch: S[ceil(B / 4)] per-workgroup partial sums */
+  uint32_t* ticket;         /* forward: ONE zero-initialised counter; the launch leaves it zero again */
+  void* loss;               /* forward out: S[1], the mean over B x T2 x 3 */
+  const void* gloss;        /* backward: S[1] upstream gradient of the loss (device scalar) */
+  const void* Xs;           /* backward: the forward's Xs rows (shifted positions, layout of the launch) */
+} MfRolloutLoss;
+
 /* Device buffers of the forward rollout; S = float for _f32, double for _f64.  All contiguous. */
 typedef struct MfRolloutFwdBufs {
   const void* z;        /* S[map_shared ? 1 : B][H][W] height map */
@@ -164,7 +184,14 @@ typedef struct MfRolloutFwdBufs {
                            them instead of recomputing them (autograd saves every intermediate of dphysics.py:172-272; this saves
                            16 scalars per contact point and step).  NULL, or a launch the record does not apply to: nothing is
                            written and the backward recomputes. */
+  const MfRolloutLoss* loss; /* optional: fuse physics_loss into the launch (mf_rollout_loss_fusable(desc) must be 1; Fs = Ff = NULL,
+                           MF_LAYOUT_TIME_MAJOR): fills loss->loss.  NULL = plain rollout. */
 } MfRolloutFwdBufs;
+
+/* 1 where BOTH directions of this launch can carry the fused physics loss (MfRolloutLoss): float32 MF_MATH_FAST, default
+ * integrator, rigid body of <= 4 points, time-major outputs, and few enough rollouts for the streaming backward; else 0 (run
+ * mf_physics_loss_* on the outputs instead). */
+int mf_rollout_loss_fusable(const MfRolloutDesc* desc);
 
 /* Bytes of MfRolloutFwdBufs.rec / MfRolloutBwdBufs.rec for this launch shape; 0 where the kernels chosen for it keep no record
  * (then pass NULL).  The record pays while the launch is bound by the instruction stream of its waves (few rollouts of a small
@@ -219,6 +246,8 @@ typedef struct MfRolloutBwdBufs {
                                (dphysics.py:191-197, 326-358); NULL to skip.  Rows the scheme never reads (the last one of the
                                default integrator) are not written: hand in zeros. */
   const void* rec;          /* the record the forward wrote (MfRolloutFwdBufs.rec of the same desc), or NULL: recompute */
+  const MfRolloutLoss* loss; /* the forward's fused physics loss (then all six upstream pointers are NULL: the kernel forms dL/dXs
+                               itself from loss->Xs, gt, w and gloss), or NULL */
 } MfRolloutBwdBufs;
 
 /* 1 if the backward kernels chosen for this descriptor always write the control gradient (gcontrols must then be a buffer), 0 if

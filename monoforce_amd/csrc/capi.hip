@@ -20,5 +20,6 @@ extern "C" int mf_sizeof(const char* name) {
   if (!strcmp(name, "MfHeightmapDesc")) return (int)sizeof(MfHeightmapDesc);
   if (!strcmp(name, "MfStageDesc")) return (int)sizeof(MfStageDesc);
   if (!strcmp(name, "MfInterpDesc")) return (int)sizeof(MfInterpDesc);
+  if (!strcmp(name, "MfRolloutLoss")) return (int)sizeof(MfRolloutLoss);
   return -1;
 }

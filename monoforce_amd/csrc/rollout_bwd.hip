@@ -39,6 +39,7 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
   a.joint_angles = (const S*)p->joint_angles;
   a.gjoint = (S*)p->gjoint_angles;
   a.rec = nullptr;
+  a.loss_T2 = 0; a.loss_gt = nullptr; a.loss_row_stamp = nullptr; a.loss_w = nullptr; a.loss_gloss = nullptr; a.loss_inv_count = (S)0;
   MF_REQUIRE(!p->gjoint_angles || p->joint_angles, MF_ERR_INVALID, "rollout_bwd: gjoint_angles without joint_angles");
   MF_REQUIRE(!d->has_joints == !p->joint_angles, MF_ERR_INVALID, "rollout_bwd: joint_angles must be given exactly when desc->has_joints is set");
   MF_REQUIRE(!p->joint_angles || d->n_tracks == 4, MF_ERR_INVALID, "rollout_bwd: joint angles need the 4 driving parts of robot 'marv'");
@@ -46,11 +47,22 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
   a.points = (const S*)p->points; a.part = p->part;
   a.x_init = (const S*)p->x_init; a.xd0 = (const S*)p->xd0; a.R0 = (const S*)p->R0; a.w0 = (const S*)p->w0;
   a.Xraw = (const S*)p->Xraw; a.Xds = (const S*)p->Xds; a.Rs = (const S*)p->Rs; a.Om = (const S*)p->Omegas;
+  if (p->loss) {      // the forward's fused physics loss: dL/dXs is formed inside the kernel from Xs, the ground truth and gloss
+    const MfRolloutLoss* L = p->loss;
+    MF_REQUIRE(sizeof(S) == 4 && cp_loss_fusable(d) && p->rec && !p->joint_angles, MF_ERR_UNSUPPORTED,
+               "rollout_bwd: this launch cannot carry the fused physics loss (mf_rollout_loss_fusable; the forward's record is required)");
+    MF_REQUIRE(!p->gXs && !p->gXds && !p->gRs && !p->gOmegas && !p->gFs && !p->gFf, MF_ERR_INVALID,
+               "rollout_bwd: with a fused loss the six upstream gradients must be NULL");
+    MF_REQUIRE(L->T2 > 0 && L->gt && L->row_stamp && L->w && L->gloss && L->Xs, MF_ERR_INVALID, "rollout_bwd: incomplete MfRolloutLoss");
+    a.loss_T2 = L->T2; a.loss_gt = (const S*)L->gt; a.loss_row_stamp = L->row_stamp; a.loss_w = (const S*)L->w; a.loss_gloss = (const S*)L->gloss;
+    a.loss_inv_count = (S)(1.0 / ((double)d->B * L->T2 * 3));
+  }
   const bool any_null = !p->gXs || !p->gXds || !p->gRs || !p->gOmegas || !p->gFs || !p->gFf;
   MF_REQUIRE(!any_null || p->zeros, MF_ERR_INVALID,
              "rollout_bwd: an upstream gradient is NULL but `zeros` (>= max(9, 3) zero scalars) was not provided");
   const S* zr = (const S*)p->zeros;
   a.gXs = p->gXs ? (const S*)p->gXs : zr;       a.sXs = p->gXs ? 3 : 0;
+  if (p->loss) { a.gXs = (const S*)p->loss->Xs; a.sXs = 3; }      // the fetching waves read Xs rows where they would read dL/dXs rows
   a.gXds = p->gXds ? (const S*)p->gXds : zr;    a.sXds = p->gXds ? 3 : 0;
   a.gOm = p->gOmegas ? (const S*)p->gOmegas : zr; a.sOm = p->gOmegas ? 3 : 0;
   a.gRs = p->gRs ? (const S*)p->gRs : zr;       a.sRs = p->gRs ? 9 : 0;
@@ -77,7 +89,7 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
       a.rec = (const S*)p->rec;
     }
     return launch_rollout_bwd_cp_f32(*reinterpret_cast<const RolloutBwdArgs<float>*>(&a), d->integrator,
-                                     p->gXs && !p->gXds && !p->gRs && !p->gOmegas && !p->gFs && !p->gFf, st);
+                                     (p->gXs || p->loss) && !p->gXds && !p->gRs && !p->gOmegas && !p->gFs && !p->gFf, st);
   }
   const LaneMap m = choose_lane_map(d->B, d->N, d->points_per_lane == MF_LANES_COMPONENT ? 0 : d->points_per_lane);
   if (sizeof(S) == 4 && d->math_mode == MF_MATH_FAST) {

@@ -49,7 +49,18 @@ long long cp_record_bytes(const MfRolloutDesc* d) {
   return bytes;
 }
 
+// The fused physics loss rides on the component-parallel forward (LOSS kernels: default integrator, states only) and on the
+// STREAMING backward (its fetching waves form dL/dXs): a launch that keeps a record and streams it.
+bool cp_loss_fusable(const MfRolloutDesc* d) {
+  static const bool one_wave = getenv("MF_CP_BWD_MODE") && atoi(getenv("MF_CP_BWD_MODE")) == kCpSaved;
+  if (!d || d->integrator != MF_INTEG_ODEINT_EULER || d->layout != MF_LAYOUT_TIME_MAJOR || one_wave) return false;
+  if (cp_record_bytes(d) <= 0) return false;
+  const long long grid = ((long long)d->B * 16 + 63) / 64;
+  return grid <= (long long)cp_stream_max_grid();
+}
+
 }  // namespace mf
+extern "C" int mf_rollout_loss_fusable(const MfRolloutDesc* d) { return mf::cp_loss_fusable(d) ? 1 : 0; }
 extern "C" int mf_rollout_bwd_wants_gcontrols(const MfRolloutDesc* d) { return (d && mf::cp_bwd_covers(d, d->has_joints != 0)) ? 0 : 1; }
 extern "C" long long mf_rollout_record_bytes(const MfRolloutDesc* d) { return mf::cp_record_bytes(d); }
 namespace mf {

@@ -510,6 +510,10 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
       const float f = k.Fr + M::clamp(k.Gf, -mg, mg);
       k.f1 = dpp<kRot1>(f); k.f2 = dpp<kRot2>(f);
     };
+    // fused physics loss (MfRolloutLoss): a.gXs points at the forward's Xs rows, dL/dXs of a row is formed where it is consumed
+    const bool loss_on = STREAM && a.loss_gt != nullptr;      // wave-uniform
+    const float loss_scale = loss_on ? 2.0f * a.loss_gloss[0] * a.loss_inv_count : zero;      // as csrc/physics_loss.hip: (2 gloss) / count
+    const float* const loss_gt_lane = loss_on ? a.loss_gt + ((size_t)b * (size_t)a.loss_T2) * 3u + (unsigned)cc : a.z;
     if constexpr (STREAM) {
       // MODE = kCpStream (default integrator): a SECOND wave of the workgroup fetches -- the rows and the record of three steps per
       // batch straight into registers -- and, since it has the time, turns each step into the COEFFICIENTS of its vector-Jacobian
@@ -571,12 +575,19 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
         // batch's first step (ordinal 3 j) sits in slot 3 j mod kSlots (six slots: wave k owns slots 3k .. 3k + 2); steps are
         // published -- `steps written` advanced -- in order: a wave waits for the other one's previous batch.
         static_assert(kSlots % 6 == 0, "two fetching waves alternate over batches of three steps: a batch must not wrap around the ring");
-        struct Slot { StateIn st; Saved sv; UpIn up; };
+        struct Slot { StateIn st; Saved sv; UpIn up; float lg, lw; };      // lg, lw: ground truth / weight of the row's stamp (fused loss)
         const int fk = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) - 1;      // (wave-uniform, and provably so: scalar branches)
         int m = n;                                  // m: the step the offsets point at
         auto fetch = [&](Slot& r) {                 // everything of step m; then the offsets move to step m - 1
           request_state(r.st, r.sv);                // (past step 0 the offsets wrap around; nothing reads them again)
           request_up(r.up);
+          r.lg = zero; r.lw = zero;
+          if (loss_on) {                            // the stamp of output row ti + 1, the row this step produced (wave-uniform)
+            const int sj = a.loss_row_stamp[ti + 1];
+            const int sjc = max(sj, 0);
+            r.lg = loss_gt_lane[(size_t)sjc * 3u];
+            r.lw = sj >= 0 ? a.loss_w[sjc] : zero;  // no stamp: weight 0 -> gradient 0
+          }
           o3 -= s3; o9 -= s9; oc -= 8u; orc -= rec_step; --ti;
           step_back_up();
           --m;
@@ -626,7 +637,9 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
             const f4v p6 = f4v{-(a.damp * cs), -(k.A * k.inv_csum), k.A * k.cj * k.inv_csum * k.inv_csum, -10.0f * k.cj * (one - k.cj)};
             const f4v p7 = f4v{k.vp, -(k.inl * a.inv_res), k.wq, __builtin_bit_cast(float, k.idx)};
             const f4v p8 = f4v{k.zc, k.mcv, wa_s * k.wb * a.inv_res, wb_s * k.wa * a.inv_res};
-            const f4v p9 = f4v{k.e, k.il, cmask * k.e * k.il, first * r.up.gXs};
+            // (fused physics loss: the row's gXs slot holds Xs itself; dL/dXs from it, the stamp's ground truth and weight)
+            const float gXs_row = loss_on ? cp_loss_grad(loss_scale, r.up.gXs, r.lg, r.lw) : r.up.gXs;
+            const f4v p9 = f4v{k.e, k.il, cmask * k.e * k.il, first * gXs_row};
             room(o + 1);
             f4v* out = ring + slot * (unsigned)(kPlanes * 64) + lane;
             out[0] = p0; out[64] = p1; out[128] = p2; out[192] = p3; out[256] = p4; out[320] = p5; out[384] = p6; out[448] = p7; out[512] = p8; out[576] = p9;
@@ -683,6 +696,11 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
         unsigned rslot = 0u;                          // ring slot read next (running, wraps at kSlots)
         UpIn uZ;                                      // the upstream gradient of output row 0 (the initial state): not in the ring
         load_upstream(0, uZ);
+        if (loss_on) {
+          const int sj = a.loss_row_stamp[0];
+          const int sjc = max(sj, 0);
+          uZ.gXs = cp_loss_grad(loss_scale, uZ.gXs, loss_gt_lane[(size_t)sjc * 3u], sj >= 0 ? a.loss_w[sjc] : zero);
+        }
         // The coefficients of a step's vector-Jacobian product, as the fetching wave leaves them in the ring.  With
         // cs = c / sum c, the gates mG, mF1 (1 / 0) and d1 = gFr . (mF1 n) -- the one lane sum that serves F0 = -A n and n both:
         struct Coef {
@@ -937,6 +955,7 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
 
 bool use_component_parallel_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p);
 long long cp_record_bytes(const MfRolloutDesc* d);      // bytes of the forward's per-step record for this launch shape (0: none)
+bool cp_loss_fusable(const MfRolloutDesc* d);           // both directions of this launch can carry the fused physics loss
 int launch_rollout_bwd_cp_f32(const RolloutBwdArgs<float>& a, int integ, bool xs_only, hipStream_t st);   // a.gcontrols may be NULL
 int launch_rollout_bwd_cp_dynamics_f32(const RolloutBwdArgs<float>& a, bool xs_only, hipStream_t st);      // rollout_bwd_dyn_cp_fast.hip
 void launch_rollout_bwd_cp_stream_f32(const RolloutBwdArgs<float>& a, bool xs_only, unsigned grid, hipStream_t st);   // rollout_bwd_cp_stream_fast.hip

@@ -88,6 +88,17 @@ __device__ __forceinline__ float cp_tangent(float s, float sn, float nrm) { retu
 __device__ __forceinline__ float cp_wraw(float I0, float I1, float I2, float Tsum) {
   return fmaf(I2, dpp<kB2>(Tsum), fmaf(I1, dpp<kB1>(Tsum), I0 * dpp<kB0>(Tsum)));
 }
+// physics_loss (losses.py:122-127) of one position component at a stamped row, and its derivative: the arithmetic of
+// csrc/physics_loss.hip (pred w - gt w, squared; products rounded on their own), so the fused and the two-kernel route agree bit for bit
+__device__ __forceinline__ float cp_loss_term(float xs, float g, float w) {
+#pragma clang fp contract(off)
+  const float d = xs * w - g * w;
+  return d * d;
+}
+__device__ __forceinline__ float cp_loss_grad(float scale, float xs, float g, float w) {      // scale = 2 gloss / (B T2 3)
+#pragma clang fp contract(off)
+  return scale * w * (xs * w - g * w);
+}
 // bitwise merge (a where the mask is set, b elsewhere): one v_bfi_b32
 __device__ __forceinline__ float bfi(unsigned m, float a, float b) {
   return __builtin_bit_cast(float, (__builtin_bit_cast(unsigned, a) & m) | (__builtin_bit_cast(unsigned, b) & ~m));

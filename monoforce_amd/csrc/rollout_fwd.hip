@@ -54,6 +54,8 @@ static int fill_args(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutA
   a->path_cost = (S*)p->path_cost;
   a->zmu = nullptr;
   a->rec = nullptr;
+  a->loss_T2 = 0; a->loss_gt = nullptr; a->loss_near = nullptr; a->loss_w = nullptr; a->loss_partial = nullptr; a->loss_ticket = nullptr;
+  a->loss_out = nullptr; a->loss_inv_count = (S)0;
   for (int i = 0; i < 12; ++i) a->joint_xyz[i] = (S)d->joint_xyz[i];
   if (p->joint_angles) {
     MF_REQUIRE(d->n_tracks == 4, MF_ERR_UNSUPPORTED, "rollout_fwd: joint angles need 4 driving parts (fl, fr, rl, rr)");
@@ -134,8 +136,18 @@ extern "C" int mf_rollout_fwd_f32(const MfRolloutDesc* d, const MfRolloutFwdBufs
         MF_REQUIRE(((uintptr_t)p->rec & 15) == 0, MF_ERR_INVALID, "rollout_fwd: rec must be 16-byte aligned");
         a.rec = (float*)p->rec;
       }
+      if (p->loss) {      // physics_loss inside the launch (MfRolloutLoss)
+        const MfRolloutLoss* L = p->loss;
+        MF_REQUIRE(mf::cp_loss_fusable(d), MF_ERR_UNSUPPORTED, "rollout_fwd: this launch cannot carry the fused physics loss (mf_rollout_loss_fusable)");
+        MF_REQUIRE(!forces && d->layout == MF_LAYOUT_TIME_MAJOR, MF_ERR_INVALID, "rollout_fwd: the fused physics loss needs Fs = Ff = NULL and MF_LAYOUT_TIME_MAJOR");
+        MF_REQUIRE(L->T2 > 0 && L->gt && L->near && L->w && L->partial && L->ticket && L->loss, MF_ERR_INVALID, "rollout_fwd: incomplete MfRolloutLoss");
+        a.loss_T2 = L->T2; a.loss_gt = (const float*)L->gt; a.loss_near = L->near; a.loss_w = (const float*)L->w;
+        a.loss_partial = (float*)L->partial; a.loss_ticket = L->ticket; a.loss_out = (float*)L->loss;
+        a.loss_inv_count = (float)(1.0 / ((double)d->B * L->T2 * 3));
+      }
       return mf::launch_rollout_fwd_cp_f32(a, d->integrator, forces, zmu, (hipStream_t)s);
     }
+    MF_REQUIRE(!p->loss, MF_ERR_UNSUPPORTED, "rollout_fwd: this launch cannot carry the fused physics loss (mf_rollout_loss_fusable)");
     if (!forces && m.PPL == 4 && m.G < 64) m = mf::choose_lane_map(d->B, d->N, 1);
     // >= one wave per SIMD (1024) and a one-point-per-lane mapping within a wave: the split-store kernels (rollout_fwd_kernel.h)
     const bool split = m.PPL == 1 && m.G <= 64 && (long long)d->B * m.G >= 1024ll * 64;
@@ -145,6 +157,7 @@ extern "C" int mf_rollout_fwd_f32(const MfRolloutDesc* d, const MfRolloutFwdBufs
       return mf::launch_rollout_fwd_split_fast_f32(a, m, d->integrator, block, forces, (hipStream_t)s);
     return mf::launch_rollout_fwd_fast_f32(a, m, d->integrator, block, forces, (hipStream_t)s);
   }
+  MF_REQUIRE(!p->loss, MF_ERR_UNSUPPORTED, "rollout_fwd: the fused physics loss exists for the float32 fast-math kernels only");
   return mf::launch_rollout_fwd<float, false>(a, m, d->integrator, block, (hipStream_t)s);
 }
 
@@ -156,6 +169,7 @@ extern "C" int mf_rollout_fwd_f64(const MfRolloutDesc* d, const MfRolloutFwdBufs
   if (rc != MF_OK) return rc;
   if (!p->Fs) { mf::set_error("rollout_fwd: float64 needs the force buffers"); return MF_ERR_UNSUPPORTED; }
   if (p->cost_rows) { mf::set_error("rollout_fwd: cost rows exist for float32 only"); return MF_ERR_UNSUPPORTED; }
+  if (p->loss) { mf::set_error("rollout_fwd: the fused physics loss exists for the float32 fast-math kernels only"); return MF_ERR_UNSUPPORTED; }
   if (p->joint_angles) return mf::launch_rollout_fwd<double, false, true>(a, m, d->integrator, block, (hipStream_t)s);
   return mf::launch_rollout_fwd<double, false>(a, m, d->integrator, block, (hipStream_t)s);   // float64 is always exact
 }

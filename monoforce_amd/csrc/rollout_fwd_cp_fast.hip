@@ -32,6 +32,16 @@ int launch_rollout_fwd_cp_f32(const RolloutArgs<float>& a, int integ, bool force
   const long long threads = (long long)a.B * 16;
   const unsigned grid = (unsigned)((threads + block - 1) / block);
   const bool rec = a.rec != nullptr;
+  if (a.loss_gt) {      // fused physics loss: default integrator, states only (the host checked)
+    constexpr int I = MF_INTEG_ODEINT_EULER;
+    if (rec) { if (zmu) hipLaunchKernelGGL((rollout_fwd_cp_kernel<I, false, true, true, true>), dim3(grid), dim3(block), 0, st, a);
+               else hipLaunchKernelGGL((rollout_fwd_cp_kernel<I, false, false, true, true>), dim3(grid), dim3(block), 0, st, a); }
+    else     { if (zmu) hipLaunchKernelGGL((rollout_fwd_cp_kernel<I, false, true, false, true>), dim3(grid), dim3(block), 0, st, a);
+               else hipLaunchKernelGGL((rollout_fwd_cp_kernel<I, false, false, false, true>), dim3(grid), dim3(block), 0, st, a); }
+    hipError_t e = hipGetLastError();
+    MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("rollout_fwd (component-parallel, fused loss) launch: ") + hipGetErrorString(e));
+    return MF_OK;
+  }
 #define MF_CP(INTEG_, FORCES_, ZMU_) do { if (rec) hipLaunchKernelGGL((rollout_fwd_cp_kernel<INTEG_, FORCES_, ZMU_, true>), dim3(grid), dim3(block), 0, st, a); \
                                           else hipLaunchKernelGGL((rollout_fwd_cp_kernel<INTEG_, FORCES_, ZMU_, false>), dim3(grid), dim3(block), 0, st, a); } while (0)
 #define MF_CP_F(INTEG_)                                          \

@@ -8,7 +8,11 @@
 
 namespace mf {
 
-template <int INTEG, bool FORCES, bool ZMU, bool REC>
+// LOSS (default integrator, states only): physics_loss (losses.py:102-127) accumulated while the stamped rows are written
+// (MfRolloutLoss): per lane the squared, time-weighted error of its position component at the <= T2 rows `near` names -- a
+// scalar compare per row, a dozen instructions at a stamped one, its ground truth prefetched one stamp ahead -- then one
+// partial sum per workgroup and the mean by the workgroup that takes the last ticket.  No [T][B][3] gradient rows, no loss launches.
+template <int INTEG, bool FORCES, bool ZMU, bool REC, bool LOSS = false>
 // (waves_per_eu: these launches hold at most two waves per SIMD -- without the hint the scheduler guards an occupancy of eight and leaves
 //  DPP hazards as s_nops rather than cross 64 registers: 335 -> 309 instructions per two steps with the record, 303 -> 301 without)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) rollout_fwd_cp_kernel(const RolloutArgs<float> a) {
@@ -197,6 +201,27 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
     if constexpr (REC) *rq = f4v{g.u, cj, wraw, A};
   };
 
+  // ---- fused physics loss: the next stamped row (wave-uniform: the stamps are the same for every rollout) and its ground truth ----
+  float l_acc = zero, l_g = zero, l_w = zero;
+  int l_j = 0, l_next = -1;
+  const float* l_gt = nullptr;
+  if constexpr (LOSS) {
+    l_gt = a.loss_gt + ((size_t)b * (size_t)a.loss_T2) * 3u + (unsigned)cc;
+    if (a.loss_T2 > 0) { l_next = a.loss_near[0]; l_g = l_gt[0]; l_w = a.loss_w[0]; }
+  }
+  auto loss_row = [&](int row, float ex, float e2) {        // output row `row` = (ex, ..., e2): position component, R[:, 2] component
+    if constexpr (LOSS) {
+      if (row == l_next) {                                     // scalar compare, wave-uniform branch: every ~10th row
+        l_acc += cp_loss_term(fmaf(e2, a.sink, ex), l_g, l_w);
+        ++l_j;
+        const int jn = min(l_j, a.loss_T2 - 1);
+        l_next = l_j < a.loss_T2 ? a.loss_near[jn] : -1;
+        l_g = l_gt[(size_t)jn * 3u];
+        l_w = a.loss_w[jn];
+      }
+    }
+  };
+
   if constexpr (INTEG == MF_INTEG_ODEINT_EULER) {
     // One step of the two-stream pipeline: geometry `g` / controls (cv, cw) / step size h of step n come in, those of step
     // n + 1 go out into the OTHER buffer set -- the loop below alternates two sets, so nothing is moved between iterations.
@@ -218,6 +243,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
       g_next = geometry(xn, Rn0, Rn1, Rn2);           // (after the last step: the final pose -- unused, in range)
       // ---- row n, AFTER the gathers in program order: their wait a step later then covers no store of this step ----
       emit_row(x, xd, w, R0, R1, R2, 1u);
+      loss_row(n, x, R2);
       x = xn; R0 = Rn0; R1 = Rn1; R2 = Rn2;
       // ---- stream A: contact chain of step n ----
       float xdd, wd, Fr, Ff;
@@ -286,12 +312,48 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
     }
   }
   if (n_steps > 0 || INTEG == MF_INTEG_ODEINT_EULER) emit_row(x, xd, w, R0, R1, R2, 1u);
+  if constexpr (LOSS) {
+    static_assert(!LOSS || INTEG == MF_INTEG_ODEINT_EULER, "the fused loss rides on the default integrator's kernels");
+    loss_row(n_steps, x, R2);                                  // the last row
+    // One partial sum per workgroup (= wave), in a fixed order: the three component lanes of each rollout's first quad leave their
+    // sums in LDS, lane 0 adds them row by row (a trailing workgroup may hold fewer than four rollouts: its absent rows stay zero).
+    __shared__ float l_sh[80];
+    const int lane = threadIdx.x;                              // (one wave per workgroup)
+    if (lane < 16) l_sh[lane] = zero;
+    if (p == 0 && q < 3) l_sh[(lane >> 4) * 4 + q] = l_acc;    // LDS executes a wave's operations in order
+    __syncthreads();
+    unsigned last = 0u;
+    if (lane == 0) {
+      float tot = zero;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) tot += (l_sh[r * 4 + 0] + l_sh[r * 4 + 1]) + l_sh[r * 4 + 2];
+      __builtin_nontemporal_store(tot, a.loss_partial + blockIdx.x);
+      __threadfence();
+      last = atomicAdd(a.loss_ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (last) {                                                // every workgroup has written its partial sum: the mean, in index order
+      __threadfence();
+      const int n_act = min(64, (a.B - (int)blockIdx.x * 4) * 16);     // live lanes of this (possibly trailing) workgroup: the first n_act
+      float tot = zero;
+      for (unsigned k2 = (unsigned)lane; k2 < gridDim.x; k2 += (unsigned)n_act) tot += __builtin_nontemporal_load(a.loss_partial + k2);
+      l_sh[16 + lane] = tot;
+      __syncthreads();
+      if (lane == 0) {
+        float sum = zero;
+        for (int k2 = 0; k2 < n_act; ++k2) sum += l_sh[16 + k2];
+        a.loss_out[0] = sum * a.loss_inv_count;
+        *a.loss_ticket = 0u;
+      }
+    }
+  }
 }
 
 // true when the component-parallel kernels cover this launch: float32 fast math, a rigid body of <= 4 points, full outputs
 // (or states only), and few enough rollouts that the launch is bound by the instruction stream of its waves
 bool use_component_parallel(const MfRolloutDesc* d, const MfRolloutFwdBufs* p);
-int launch_rollout_fwd_cp_f32(const RolloutArgs<float>& a, int integ, bool forces, bool zmu, hipStream_t st);   // a.rec: record wanted
+int launch_rollout_fwd_cp_f32(const RolloutArgs<float>& a, int integ, bool forces, bool zmu, hipStream_t st);   // a.rec: record wanted; a.loss_gt: fused loss
+bool cp_loss_fusable(const MfRolloutDesc* d);           // both directions of this launch can carry the fused physics loss
 long long cp_record_bytes(const MfRolloutDesc* d);      // bytes of the per-step record a launch of this shape writes (0: none)
 
 }  // namespace mf

@@ -55,6 +55,15 @@ struct RolloutArgs {
   S* path_cost;           // COST kernels, optional: S[B] std over the T output rows of the 4th cost-row component
   const S* zmu;           // ZMU kernels: the shared height and friction maps interleaved, S[H*W][2] = (z, mu) per cell
   S* rec;                 // component-parallel kernels, optional: the compact per-step record for the backward, [T][B*16 lanes] 16-byte quads
+  // fused physics loss (MfRolloutLoss; component-parallel LOSS kernels): stamps, weights, ground truth, reduction scratch
+  int loss_T2;
+  const S* loss_gt;
+  const int* loss_near;
+  const S* loss_w;
+  S* loss_partial;
+  unsigned* loss_ticket;
+  S* loss_out;
+  S loss_inv_count;
 };
 
 // Arithmetic policy.  Exact: IEEE divide / sqrt, libm exp and sincos, un-fused mul+add (the TU is built with

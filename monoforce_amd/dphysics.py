@@ -139,74 +139,132 @@ def _zmu_scratch(mod, desc, z):
     return None
 
 
+class LossSpec:
+    """Ground-truth stamps of `physics_loss` (losses.py:102-127) prepared for the kernels that carry the loss themselves
+    (MfRolloutLoss): the SAME stamp times for every rollout.  near[j] = output row nearest in time to stamp j (losses.py:116),
+    w[j] = 1 / (1 + gamma t_j), row_stamp = the inverse table.  Built once per time grid (one small host round trip)."""
+
+    def __init__(self, pred_ts, gt_ts, gamma, device, dtype=torch.float32):
+        pred_ts = torch.as_tensor(pred_ts, dtype=dtype).reshape(-1).cpu()
+        gt_ts = torch.as_tensor(gt_ts, dtype=dtype).reshape(-1).cpu()
+        near = (pred_ts.unsqueeze(0) - gt_ts.unsqueeze(1)).abs().argmin(dim=1)
+        self.fusable = bool((near[1:] > near[:-1]).all()) if near.numel() > 1 else near.numel() == 1      # one stamp per row at most
+        self.T, self.T2, self.gamma = int(pred_ts.numel()), int(gt_ts.numel()), float(gamma)
+        row_stamp = torch.full((self.T,), -1, dtype=torch.int32)
+        row_stamp[near] = torch.arange(self.T2, dtype=torch.int32)
+        self.near = near.to(torch.int32).to(device)
+        self.w = (1. / (1. + gamma * gt_ts)).to(device)
+        self.row_stamp = row_stamp.to(device)
+        self.gt_ts = gt_ts.to(device)
+        self.ticket = torch.zeros(1, dtype=torch.int32, device=device)      # the launch leaves it zero
+
+
+def _rollout_forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_grad, joint_angles=None, want_forces=True,
+                     x0_buf=None, x0_private=False, default_state=False, loss=None):
+    """One `mf_rollout_fwd_*` launch; `loss` = (LossSpec, X_gt[B,T2,3]) fuses physics_loss into it (outs then start with the loss)."""
+    # x_arg is the autograd input (the caller's start position when it requires grad); the kernel works on x0_buf, the
+    # detached contiguous buffer that receives the snapped height.  x0_private: nobody else sees that buffer.
+    x0 = x0_buf if x0_buf is not None else x_arg
+    # inference reads a time-constant (expanded) control tensor as it is; the backward kernel wants [B][T][2]
+    controls, sb, st = _kernel_controls(controls, allow_view=not want_grad)
+    desc, keep = mod._make_desc(z, mu, controls)
+    desc.controls_stride_b, desc.controls_stride_t = sb, st
+    desc.default_state = int(default_state)     # the kernel computes the start state and fills x0 / xd0 / R0 / w0
+    if joint_angles is not None:
+        desc.has_joints = 1
+        for i, v in enumerate(sum((list(p) for p in mod.dphys_cfg.joint_positions.values()), [])[:12]):
+            desc.joint_xyz[i] = float(v)
+    B, T, N = desc.B, desc.T, desc.N
+    dt, dev = z.dtype, z.device
+    tm = desc.layout == _lib.MF_LAYOUT_TIME_MAJOR
+    lead = (T, B) if tm else (B, T)
+    new = lambda *tail: torch.empty(*lead, *tail, dtype=dt, device=dev)  # noqa: E731
+    Np = _lib.lib().mf_rollout_force_stride(C.byref(desc))      # point slots per force row the chosen kernel writes
+    if Np < N:
+        raise RuntimeError('mf_rollout_force_stride rejected the descriptor')
+    desc.force_stride = Np
+    Xs, Xds, Rs, Om = new(3), new(3), new(3, 3), new(3)
+    Fs, Ff = (new(Np, 3), new(Np, 3)) if want_forces else (None, None)
+    Xraw = new(3) if want_grad else None
+    # the per-step record of the component-parallel kernels (MfRolloutFwdBufs.rec): kept for the backward where the library
+    # says it pays (few rollouts of a small body), 1 KiB per rollout and step
+    rec = None
+    if want_grad and dt == torch.float32 and joint_angles is None:
+        nbytes = int(_lib.lib().mf_rollout_record_bytes(C.byref(desc)))
+        if nbytes > 0:
+            rec = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    bufs = _lib.MfRolloutFwdBufs(
+        z=_lib.ptr(keep['z']), mu=_lib.ptr(keep['mu']), controls=_lib.ptr(controls), ts=_lib.ptr(ts),
+        points=_lib.ptr(keep['points']), part=_lib.ptr(mod._part_dev(dev)),
+        x0=_lib.ptr(x0), xd0=_lib.ptr(xd0), R0=_lib.ptr(R0), w0=_lib.ptr(w0),
+        Xs=_lib.ptr(Xs), Xds=_lib.ptr(Xds), Rs=_lib.ptr(Rs), Omegas=_lib.ptr(Om), Fs=_lib.ptr(Fs), Ff=_lib.ptr(Ff),
+        Xraw=_lib.ptr(Xraw), joint_angles=_lib.ptr(joint_angles),
+        zmu_scratch=_lib.ptr(_zmu_scratch(mod, desc, keep['z'])), zmu=_lib.ptr(mod._staged_zmu(desc, z, mu)), rec=_lib.ptr(rec))
+    loss_val = lstruct = None
+    if loss is not None:
+        spec, X_gt = loss
+        loss_val = torch.empty((), dtype=dt, device=dev)
+        partial = torch.empty((B + 3) // 4, dtype=dt, device=dev)
+        lstruct = _lib.MfRolloutLoss(T2=spec.T2, gt=_lib.ptr(X_gt), near=_lib.ptr(spec.near), w=_lib.ptr(spec.w), row_stamp=_lib.ptr(spec.row_stamp),
+                                     partial=_lib.ptr(partial), ticket=_lib.ptr(spec.ticket), loss=_lib.ptr(loss_val))
+        bufs.loss = C.cast(C.pointer(lstruct), C.c_void_p)       # (lstruct stays alive until the launch call below returns)
+    fn = getattr(_lib.lib(), 'mf_rollout_fwd_' + _scalar_suffix(dt))
+    with torch.cuda.device(dev), _timing.timed('rollout_fwd_kernel', dev):
+        _lib.check(fn(C.byref(desc), C.byref(bufs), _stream_ptr(dev)), 'mf_rollout_fwd')
+    outs = (Xs, Xds, Rs, Om) + ((Fs[..., :N, :], Ff[..., :N, :]) if want_forces else ())
+    if tm:
+        outs = tuple(o.transpose(0, 1) for o in outs)
+    if loss is not None:
+        outs = (loss_val,) + outs
+        ctx.loss = (spec, X_gt, Xs) if want_grad else None
+    ctx.n_force_outs = 2 if want_forces else 0
+    # outputs the loss does not touch arrive as None in backward (= NULL upstream pointers), not as zero-filled tensors
+    ctx.set_materialize_grads(False)
+    if want_grad:
+        ctx.mod, ctx.desc, ctx.keep = mod, desc, keep
+        ctx.z_shape, ctx.mu_shape, ctx.mu_given = z.shape, (mu.shape if mu is not None else None), mu is not None
+        ctx.z_expanded = z.stride(0) == 0 and z.shape[0] > 1
+        ctx.mu_expanded = mu is not None and mu.stride(0) == 0 and mu.shape[0] > 1
+        ctx.joint_angles = joint_angles.detach() if joint_angles is not None else None
+        ctx.rec = rec
+        # x0 now holds the snapped start position; a caller-visible buffer is copied, the module's own default is not
+        ctx.save_for_backward(controls, x0 if x0_private else x0.clone(), xd0, R0, w0, ts, Xraw, Xds, Rs, Om)
+    return outs
+
+
 class _RolloutFn(torch.autograd.Function):
     """forward = mf_rollout_fwd_*; backward = mf_rollout_bwd_* (reverse-time adjoint of the same scan)."""
 
     @staticmethod
     def forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_grad, joint_angles=None, want_forces=True,
                 x0_buf=None, x0_private=False, default_state=False):
-        # x_arg is the autograd input (the caller's start position when it requires grad); the kernel works on x0_buf, the
-        # detached contiguous buffer that receives the snapped height.  x0_private: nobody else sees that buffer.
-        x0 = x0_buf if x0_buf is not None else x_arg
-        # inference reads a time-constant (expanded) control tensor as it is; the backward kernel wants [B][T][2]
-        controls, sb, st = _kernel_controls(controls, allow_view=not want_grad)
-        desc, keep = mod._make_desc(z, mu, controls)
-        desc.controls_stride_b, desc.controls_stride_t = sb, st
-        desc.default_state = int(default_state)     # the kernel computes the start state and fills x0 / xd0 / R0 / w0
-        if joint_angles is not None:
-            desc.has_joints = 1
-            for i, v in enumerate(sum((list(p) for p in mod.dphys_cfg.joint_positions.values()), [])[:12]):
-                desc.joint_xyz[i] = float(v)
-        B, T, N = desc.B, desc.T, desc.N
-        dt, dev = z.dtype, z.device
-        tm = desc.layout == _lib.MF_LAYOUT_TIME_MAJOR
-        lead = (T, B) if tm else (B, T)
-        new = lambda *tail: torch.empty(*lead, *tail, dtype=dt, device=dev)  # noqa: E731
-        Np = _lib.lib().mf_rollout_force_stride(C.byref(desc))      # point slots per force row the chosen kernel writes
-        if Np < N:
-            raise RuntimeError('mf_rollout_force_stride rejected the descriptor')
-        desc.force_stride = Np
-        Xs, Xds, Rs, Om = new(3), new(3), new(3, 3), new(3)
-        Fs, Ff = (new(Np, 3), new(Np, 3)) if want_forces else (None, None)
-        Xraw = new(3) if want_grad else None
-        # the per-step record of the component-parallel kernels (MfRolloutFwdBufs.rec): kept for the backward where the library
-        # says it pays (few rollouts of a small body), 1 KiB per rollout and step
-        rec = None
-        if want_grad and dt == torch.float32 and joint_angles is None:
-            nbytes = int(_lib.lib().mf_rollout_record_bytes(C.byref(desc)))
-            if nbytes > 0:
-                rec = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
-        bufs = _lib.MfRolloutFwdBufs(
-            z=_lib.ptr(keep['z']), mu=_lib.ptr(keep['mu']), controls=_lib.ptr(controls), ts=_lib.ptr(ts),
-            points=_lib.ptr(keep['points']), part=_lib.ptr(mod._part_dev(dev)),
-            x0=_lib.ptr(x0), xd0=_lib.ptr(xd0), R0=_lib.ptr(R0), w0=_lib.ptr(w0),
-            Xs=_lib.ptr(Xs), Xds=_lib.ptr(Xds), Rs=_lib.ptr(Rs), Omegas=_lib.ptr(Om), Fs=_lib.ptr(Fs), Ff=_lib.ptr(Ff),
-            Xraw=_lib.ptr(Xraw), joint_angles=_lib.ptr(joint_angles),
-            zmu_scratch=_lib.ptr(_zmu_scratch(mod, desc, keep['z'])), zmu=_lib.ptr(mod._staged_zmu(desc, z, mu)), rec=_lib.ptr(rec))
-        fn = getattr(_lib.lib(), 'mf_rollout_fwd_' + _scalar_suffix(dt))
-        with torch.cuda.device(dev), _timing.timed('rollout_fwd_kernel', dev):
-            _lib.check(fn(C.byref(desc), C.byref(bufs), _stream_ptr(dev)), 'mf_rollout_fwd')
-        outs = (Xs, Xds, Rs, Om) + ((Fs[..., :N, :], Ff[..., :N, :]) if want_forces else ())
-        if tm:
-            outs = tuple(o.transpose(0, 1) for o in outs)
-        ctx.n_force_outs = 2 if want_forces else 0
-        # outputs the loss does not touch arrive as None in backward (= NULL upstream pointers), not as zero-filled tensors
-        ctx.set_materialize_grads(False)
-        if want_grad:
-            ctx.mod, ctx.desc, ctx.keep = mod, desc, keep
-            ctx.z_shape, ctx.mu_shape, ctx.mu_given = z.shape, (mu.shape if mu is not None else None), mu is not None
-            ctx.z_expanded = z.stride(0) == 0 and z.shape[0] > 1
-            ctx.mu_expanded = mu is not None and mu.stride(0) == 0 and mu.shape[0] > 1
-            ctx.joint_angles = joint_angles.detach() if joint_angles is not None else None
-            ctx.rec = rec
-            # x0 now holds the snapped start position; a caller-visible buffer is copied, the module's own default is not
-            ctx.save_for_backward(controls, x0 if x0_private else x0.clone(), xd0, R0, w0, ts, Xraw, Xds, Rs, Om)
-        return outs
+        return _rollout_forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_grad, joint_angles, want_forces,
+                                x0_buf, x0_private, default_state)
 
     @staticmethod
     def backward(ctx, gXs, gXds, gRs, gOm, gFs=None, gFf=None):
         from .dphysics_bwd import rollout_backward
         return rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf) + (None, None, None, None)
+
+
+class _RolloutLossFn(torch.autograd.Function):
+    """The rollout with `physics_loss` inside both launches (MfRolloutLoss): outputs (loss, Xs, Xds, Rs, Omegas), of which only the
+    loss is differentiable -- the backward forms dL/dXs itself at the stamped rows."""
+
+    @staticmethod
+    def forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_grad, x0_buf, x0_private, default_state, spec, X_gt):
+        outs = _rollout_forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_grad, None, False, x0_buf, x0_private,
+                                default_state, loss=(spec, X_gt))
+        ctx.mark_non_differentiable(*outs[1:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, gloss, *_unused):
+        from .dphysics_bwd import rollout_backward
+        if gloss is None:
+            return (None,) * 15
+        grads = rollout_backward(ctx, None, None, None, None, None, None, gloss=gloss)      # (mod, z, mu, controls, x, xd0, R0, w0, ts, want_grad, ja)
+        return grads[:10] + (None, None, None, None, None)
 
 
 class DPhysics(torch.nn.Module):
@@ -321,7 +379,7 @@ class DPhysics(torch.nn.Module):
         return desc, keep
 
     # -- reference API --------------------------------------------------------------------------------------
-    def dphysics(self, z_grid, controls, joint_angles=None, state=None, friction=None):
+    def dphysics(self, z_grid, controls, joint_angles=None, state=None, friction=None, _loss=None):
         """Simulate the robot on the terrain (dphysics.py:530-594).
 
         z_grid (B,H,W), controls (B,N,2), joint_angles (B,N,4) or None, state=(x,xd,R,omega) or None, friction (B,H,W).
@@ -381,14 +439,56 @@ class DPhysics(torch.nn.Module):
         # a start position that requires grad is the autograd input itself (its gradient: x and y through the contact geometry,
         # z none -- the snap overwrites it); the kernel works on the detached buffer x0 either way
         x_arg = x_in if (want_grad and x_in.requires_grad) else x0
-        outs = _RolloutFn.apply(self, z_grid, friction, controls, x_arg, xd0, R0, w0, ts, want_grad, ja_dev, want_forces,
-                                x0, own_state, state_in_kernel)
+        loss_val = None
+        if _loss is not None:       # physics_loss inside the launches (physics_loss_rollout)
+            spec, X_gt = _loss
+            outs = _RolloutLossFn.apply(self, z_grid, friction, controls, x_arg, xd0, R0, w0, ts, want_grad, x0, own_state,
+                                        state_in_kernel, spec, X_gt)
+            loss_val, outs = outs[0], outs[1:]
+        else:
+            outs = _RolloutFn.apply(self, z_grid, friction, controls, x_arg, xd0, R0, w0, ts, want_grad, ja_dev, want_forces,
+                                    x0, own_state, state_in_kernel)
         if not aliased:
             with torch.no_grad():       # the reference's in-place write (through .data: no version bump on a tensor autograd saved)
                 x_in.data[..., 2] = x0[..., 2].to(device=x_in.device, dtype=x_in.dtype)
         Xs, Xds, Rs, Omegas = outs[:4]
         F_springs, F_frictions = outs[4:] if len(outs) == 6 else (None, None)
+        if _loss is not None:
+            return loss_val, (Xs, Xds, Rs, Omegas)
         return (Xs, Xds, Rs, Omegas), (F_springs, F_frictions)
+
+    def loss_spec(self, gt_ts, gamma=0.9, n_steps=None):
+        """Prepare the ground-truth stamps of `physics_loss` for `physics_loss_rollout`: gt_ts [T2] (the same stamp times for every
+        rollout), weights 1 / (1 + gamma t) (losses.py:122); the predicted stamps are this module's time grid."""
+        n = len(self.ts) if n_steps is None else int(n_steps)
+        return LossSpec(self._time_grid(n, torch.float32, torch.device('cpu')), gt_ts, gamma, torch.device(self.device))
+
+    def physics_loss_rollout(self, z_grid, controls, X_gt, spec, state=None, friction=None):
+        """`physics_loss(self(z_grid, controls, ...), [X_gt], pred_ts, gt_ts, gamma)` (losses.py:102-127, the position term the training
+        scripts use: scripts/train.py:399-406, scripts/fit_terrain.py:53-62) with the loss INSIDE the rollout's two launches (SURVEY.md
+        8f rank 1): the forward kernel accumulates the time-weighted squared error at the stamped rows while it writes them, the
+        backward forms dL/dXs there itself -- no loss launches, no [B,T,3] gradient tensor.  X_gt [B,T2,3]; `spec` = self.loss_spec(gt_ts).
+        Returns (loss, (Xs, Xds, Rs, Omegas)); the states come back detached from the graph (only the loss is differentiable).
+        Where the library cannot fuse (mf_rollout_loss_fusable: other than float32 fast math, default integrator, a rigid body of <= 4
+        points, <= 2048 rollouts; several stamps on one row) the same value and gradient come from the unfused route."""
+        from .losses import physics_loss_fused
+        ok = spec.fusable and not self.precise and z_grid.dtype == torch.float32 and self.dphys_cfg.use_odeint and not self.contiguous_outputs
+        B = controls.shape[0]
+        if ok:
+            ok = spec.T == min(int(self.dphys_cfg.traj_sim_time / self.dphys_cfg.dt), controls.shape[1])
+        if ok:
+            d = _lib.MfRolloutDesc(B=B, T=spec.T, N=self.x_points.shape[1], H=z_grid.shape[-2], W=z_grid.shape[-1], integrator=_lib.MF_INTEG_ODEINT_EULER,
+                                   math_mode=_lib.MF_MATH_FAST, force_stride=max(self.x_points.shape[1], 4), map_shared=1, layout=_lib.MF_LAYOUT_TIME_MAJOR,
+                                   points_per_lane=self.points_per_lane)
+            ok = bool(_lib.lib().mf_rollout_loss_fusable(C.byref(d)))
+        if not ok:
+            states, _ = self.dphysics(z_grid, controls, state=state, friction=friction)
+            B_, T2 = X_gt.shape[:2]
+            gt_ts = spec.gt_ts.unsqueeze(0).expand(B_, -1)
+            return physics_loss_fused(states, [X_gt], None, gt_ts, gamma=spec.gamma, nearest=spec.near.unsqueeze(0).expand(B_, -1)), states
+        Xg = X_gt.detach().to(device=torch.device(self.device), dtype=torch.float32).contiguous()
+        assert Xg.shape == (B, spec.T2, 3), f'X_gt shape {tuple(Xg.shape)} != {(B, spec.T2, 3)}'
+        return self.dphysics(z_grid, controls, state=state, friction=friction, _loss=(spec, Xg))
 
     @torch.no_grad()
     def rollout_costs(self, z_grid, controls, state=None, friction=None, pose_stride=None, project=True):

@@ -81,7 +81,7 @@ def grad_pool(owner, n_maps, copies, n, dt, dev):
     p.acquire()
     return p
 
-def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf):
+def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf, gloss=None):
     from .dphysics import _scalar_suffix, _stream_ptr
     controls, x_init, xd0, R0, w0, ts, Xraw, Xds, Rs, Om = ctx.saved_tensors
     desc, keep, mod = ctx.desc, ctx.keep, ctx.mod
@@ -130,6 +130,12 @@ def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf):
         gz=_lib.ptr(gz), gmu=_lib.ptr(gmu), gcontrols=_lib.ptr(gcontrols), gx0=_lib.ptr(gx0),
         gxd0=_lib.ptr(gxd0), gR0=_lib.ptr(gR0), gw0=_lib.ptr(gw0), joint_angles=_lib.ptr(ja), gjoint_angles=_lib.ptr(gja),
         rec=_lib.ptr(getattr(ctx, 'rec', None)))
+    if gloss is not None:       # the forward carried physics_loss itself (MfRolloutLoss): the kernel forms dL/dXs from Xs and the ground truth
+        spec, X_gt, Xs_rows = ctx.loss
+        gl = gloss.to(dt).reshape(1).contiguous()
+        lstruct = _lib.MfRolloutLoss(T2=spec.T2, gt=_lib.ptr(X_gt), near=_lib.ptr(spec.near), w=_lib.ptr(spec.w), row_stamp=_lib.ptr(spec.row_stamp),
+                                     gloss=_lib.ptr(gl), Xs=_lib.ptr(Xs_rows))
+        bufs.loss = C.cast(C.pointer(lstruct), C.c_void_p)
     fn = getattr(_lib.lib(), 'mf_rollout_bwd_' + _scalar_suffix(dt))
     with torch.cuda.device(dev), _timing.timed('rollout_bwd_kernel', dev):
         _lib.check(fn(C.byref(desc), C.byref(bufs), _stream_ptr(dev)), 'mf_rollout_bwd')

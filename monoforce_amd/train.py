@@ -14,9 +14,12 @@ class TerrainFitProblem:
     The ground truth is a rollout of the same controls on a "true" terrain, generated once with the HIP forward.
     """
 
-    def __init__(self, dphysics, z_true, mu_true, controls, gt_every=10, fused_loss=True, graph=False):
+    def __init__(self, dphysics, z_true, mu_true, controls, gt_every=10, fused_loss=True, graph=False, loss_in_kernel=True):
         self.dp = dphysics
         self.fused_loss = fused_loss      # mf_physics_loss_* instead of ~25 small ATen kernels (same value and gradient)
+        # physics_loss inside the rollout's own two launches (DPhysics.physics_loss_rollout; SURVEY 8f rank 1): a step is four
+        # launches instead of six and the [B,T,3] gradient rows are never built; where the library cannot fuse, the route above
+        self.loss_in_kernel = bool(loss_in_kernel) and fused_loss and controls.is_cuda
         self.controls = controls
         B, T = controls.shape[:2]
         cfg = dphysics.dphys_cfg
@@ -28,6 +31,7 @@ class TerrainFitProblem:
         self.gt_ts = full_ts[sel].unsqueeze(0).expand(B, -1).contiguous()
         self.states_gt = [Xs[:, sel].contiguous(), Xds[:, sel].contiguous(), Rs[:, sel].contiguous(), Om[:, sel].contiguous()]
         self.nearest = nearest_steps(self.pred_ts, self.gt_ts).to(torch.int32)      # time stamps are fixed: computed once
+        self.spec = dphysics.loss_spec(full_ts[sel], gamma=0.9, n_steps=T) if self.loss_in_kernel else None
         self.bucket = None
         self._one = None
         self.fast_exchange = None         # True once a step exchanged gradients and loss in place (one collective, no copies)
@@ -69,12 +73,16 @@ class TerrainFitProblem:
             return self._step_graph(z, mu)
         z.grad = None
         mu.grad = None
-        states, _ = self.dp(z.unsqueeze(0), self.controls, friction=mu.unsqueeze(0))
-        loss_fn = physics_loss_fused if self.fused_loss else physics_loss
-        loss = loss_fn(states, self.states_gt, self.pred_ts, self.gt_ts,
-                       nearest=self.nearest if self.fused_loss else self.nearest.long())
+        loss = self._loss(z, mu)
         loss.backward(self._seed(loss))   # (the default seed is a fresh ones_like: one more launch in front of the backward)
         return self._exchange(z, mu, loss)
+
+    def _loss(self, z, mu):
+        if self.loss_in_kernel:
+            return self.dp.physics_loss_rollout(z.unsqueeze(0), self.controls, self.states_gt[0], self.spec, friction=mu.unsqueeze(0))[0]
+        states, _ = self.dp(z.unsqueeze(0), self.controls, friction=mu.unsqueeze(0))
+        loss_fn = physics_loss_fused if self.fused_loss else physics_loss
+        return loss_fn(states, self.states_gt, self.pred_ts, self.gt_ts, nearest=self.nearest if self.fused_loss else self.nearest.long())
 
     def _step_graph(self, z, mu):
         cap = self._captured
@@ -95,8 +103,7 @@ class TerrainFitProblem:
         dev = z.device
 
         def fwd_bwd():
-            states, _ = self.dp(z.unsqueeze(0), self.controls, friction=mu.unsqueeze(0))
-            loss = physics_loss_fused(states, self.states_gt, self.pred_ts, self.gt_ts, nearest=self.nearest)
+            loss = self._loss(z, mu)
             gz, gmu = torch.autograd.grad(loss, [z, mu], grad_outputs=self._seed(loss))
             return loss.detach(), gz, gmu
 
@@ -133,6 +140,8 @@ class EncoderTrainStep:
         self.terrain_preproc = torch.nn.AvgPool2d(kernel_size=k, stride=k) if k > 1 else torch.nn.Identity()
         self.pool_k = k
         self.fused_stage = True        # terrain = geom - diff, both poolings and the (z, mu) interleave as one kernel
+        self.loss_in_kernel = True     # physics_loss inside the rollout launches where the stamps are shared by the rollouts
+        self._specs = {}
         self.w = (geom_weight, terrain_weight, phys_weight)
         # train.py:374-375; the fused (single multi-tensor kernel) implementation where the parameters live on the GPU
         on_gpu = all(p.is_cuda for p in encoder.parameters())
@@ -158,9 +167,24 @@ class EncoderTrainStep:
         l_terr = hm_loss(terrain['terrain'], hm_terrain[:, 0:1], hm_terrain[:, 1:2])         # train.py:395-398
         x0 = pose0[:, :3, 3].clone()
         state0 = (x0, torch.zeros_like(x0), pose0[:, :3, :3].contiguous(), torch.zeros_like(x0))   # train.py:237-241
-        states, _ = self.dp(z_grid=z, controls=controls, state=state0, friction=mu)
-        l_phys = physics_loss_fused(states, states_gt, pred_ts, gt_ts, nearest=nearest)       # losses.py:102-127 on mf_physics_loss_*
+        spec = self._loss_spec(gt_ts, controls.shape[1])
+        if spec is not None:      # losses.py:102-127 inside the rollout's own launches
+            l_phys = self.dp.physics_loss_rollout(z, controls, states_gt[0], spec, state=state0, friction=mu)[0]
+        else:
+            states, _ = self.dp(z_grid=z, controls=controls, state=state0, friction=mu)
+            l_phys = physics_loss_fused(states, states_gt, pred_ts, gt_ts, nearest=nearest)       # losses.py:102-127 on mf_physics_loss_*
         return l_geom, l_terr, l_phys
+
+    def _loss_spec(self, gt_ts, T):
+        """LossSpec of a batch whose ground-truth stamps are the same for every rollout (an expanded row, or rows checked equal once per
+        tensor); None = per-rollout stamps: the unfused physics loss."""
+        if not (self.loss_in_kernel and gt_ts.is_cuda):
+            return None
+        key = (gt_ts.data_ptr(), tuple(gt_ts.shape), T)
+        if key not in self._specs:
+            shared = gt_ts.stride(0) == 0 or bool((gt_ts == gt_ts[:1]).all())
+            self._specs[key] = self.dp.loss_spec(gt_ts[0], gamma=0.9, n_steps=T) if shared else None
+        return self._specs[key]
 
     def exchange_only(self):
         """The step's collectives alone, on the buckets as they stand (bench.py: `comm_ms`)."""

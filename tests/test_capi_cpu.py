@@ -37,7 +37,7 @@ def test_struct_layout_matches_header(built_lib):
     from monoforce_amd import _lib
     built_lib.mf_sizeof.restype = ctypes.c_int
     built_lib.mf_sizeof.argtypes = [ctypes.c_char_p]
-    for name in ('MfRolloutDesc', 'MfRolloutFwdBufs', 'MfRolloutBwdBufs', 'MfSplatDesc', 'MfLossDesc', 'MfHeightmapDesc', 'MfStageDesc', 'MfInterpDesc'):
+    for name in ('MfRolloutDesc', 'MfRolloutFwdBufs', 'MfRolloutBwdBufs', 'MfSplatDesc', 'MfLossDesc', 'MfHeightmapDesc', 'MfStageDesc', 'MfInterpDesc', 'MfRolloutLoss'):
         assert built_lib.mf_sizeof(name.encode()) == ctypes.sizeof(getattr(_lib, name)), name
 
 

@@ -101,3 +101,93 @@ def test_gradient_copy_pool_is_reused_clean():
         assert hp.rel_err(gz, grads[0][0]) <= 1e-5 and hp.rel_err(gm, grads[0][1]) <= 1e-5
     pool = next(iter(dp._grad_pools.values()))
     assert float(pool.buf.abs().max()) == 0.0 and not pool.busy
+
+
+# ---- physics_loss inside the rollout's own launches (MfRolloutLoss; DPhysics.physics_loss_rollout) ----------------
+def _fit_problem(B, T, loss_in_kernel, graph=False, res=0.1, d_max=3.2, gt_every=10):
+    from monoforce_amd import synthetic as syn
+    from monoforce_amd.train import TerrainFitProblem
+    from tests.test_rollout_gpu import make_dphysics
+    pts, masks = syn.robot_points_4()
+    dp = make_dphysics(pts, masks, 1, res, d_max)
+    z_true = (syn.bump_terrain(syn.bump_params(3), d_max, res) * 0.3).to(DEV)
+    mu = syn.wave_friction(d_max, res).to(DEV)
+    ctrl = syn.const_controls(B, T, seed=2).to(DEV)
+    prob = TerrainFitProblem(dp, z_true, mu, ctrl, gt_every=gt_every, graph=graph, loss_in_kernel=loss_in_kernel)
+    z = (z_true * 0.5).clone().requires_grad_(True)
+    m = mu.clone().requires_grad_(True)
+    return prob, z, m
+
+
+@pytest.mark.parametrize('B,T,gt_every', [(48, 300, 10), (37, 95, 10), (3, 41, 1), (1, 12, 5), (1500, 120, 10)])
+def test_loss_inside_the_rollout_kernels_equals_the_two_kernel_route(B, T, gt_every):
+    """Forward: the mean the rollout kernel finishes itself == mf_physics_loss_value_* on its outputs (and == the plain-torch
+    restatement of losses.py:102-127); backward: dL/dXs formed by the fetching waves == the gradient rows mf_physics_loss_bwd_* writes,
+    so the terrain / friction gradients agree to the rounding of the atomics' arrival order.  Batches with a trailing partial
+    workgroup (37, 3, 1 rollouts), every row stamped (gt_every = 1), two workgroups per CU (1500)."""
+    from monoforce_amd.losses import physics_loss
+    out = []
+    for in_kernel in (False, True):
+        prob, z, m = _fit_problem(B, T, in_kernel, gt_every=gt_every)
+        vals = []
+        for _ in range(3):                                   # launch after launch: the ticket comes back to zero
+            loss = prob.step(z, m)
+            vals.append(float(loss))
+        assert len(set(vals)) == 1, vals
+        out.append((vals[0], z.grad.clone(), m.grad.clone(), prob))
+    assert out[1][3].loss_in_kernel and out[1][3].spec.fusable
+    assert abs(out[0][0] - out[1][0]) <= 2e-6 * abs(out[0][0]), (out[0][0], out[1][0])
+    assert hp.rel_err(out[1][1].cpu(), out[0][1].cpu()) <= 2e-5 and hp.rel_err(out[1][2].cpu(), out[0][2].cpu()) <= 2e-5
+    # ... and the value against the reference formula in plain torch on the rollout's outputs
+    prob = out[1][3]
+    with torch.no_grad():
+        states, _ = prob.dp(z.detach().unsqueeze(0), prob.controls, friction=m.detach().unsqueeze(0))
+        ref = physics_loss(states, prob.states_gt, prob.pred_ts, prob.gt_ts, nearest=prob.nearest.long())
+    assert abs(float(ref) - out[1][0]) <= 2e-6 * abs(float(ref))
+
+
+def test_loss_inside_the_kernels_replayed_as_a_graph_and_non_unit_upstream():
+    """The four-launch step captured as ONE hipGraph replays to the same loss and gradients; a scaled loss scales the gradients
+    (the upstream scalar reaches the fetching waves through MfRolloutLoss.gloss)."""
+    prob, z, m = _fit_problem(256, 150, True)
+    l0 = float(prob.step(z, m)); g0 = (z.grad.clone(), m.grad.clone())
+    pg, zg, mg = _fit_problem(256, 150, True, graph=True)
+    for _ in range(3):
+        lg = float(pg.step(zg, mg))
+        assert pg.graph and abs(lg - l0) <= 1e-6 * abs(l0)
+        assert hp.rel_err(zg.grad.cpu(), g0[0].cpu()) <= 1e-5 and hp.rel_err(mg.grad.cpu(), g0[1].cpu()) <= 1e-5
+    z.grad = None; m.grad = None
+    loss, _ = prob.dp.physics_loss_rollout(z.unsqueeze(0), prob.controls, prob.states_gt[0], prob.spec, friction=m.unsqueeze(0))
+    (loss * 3.0).backward()
+    assert hp.rel_err(z.grad.cpu(), (g0[0] * 3.0).cpu()) <= 1e-5
+
+
+def test_loss_rollout_falls_back_where_the_library_cannot_fuse():
+    """dynamics(), exact arithmetic, float64, or two stamps on one output row: `physics_loss_rollout` returns the same value and
+    gradient through the unfused route (`mf_rollout_loss_fusable` / LossSpec.fusable say no)."""
+    from monoforce_amd import synthetic as syn
+    from monoforce_amd.losses import physics_loss
+    from tests.test_rollout_gpu import make_dphysics
+    pts, masks = syn.robot_points_4()
+    B, T = 16, 60
+    z = (syn.bump_terrain(syn.bump_params(3), 3.2, 0.1) * 0.3)
+    ctrl = syn.const_controls(B, T, seed=2)
+    gen = torch.Generator().manual_seed(0)
+    for kw, integ, dtype, crowded in (({}, 0, torch.float32, False), ({'precise': True}, 1, torch.float32, False),
+                                      ({}, 1, torch.float64, False), ({}, 1, torch.float32, True)):
+        dp = make_dphysics(pts, masks, integ, 0.1, 3.2, **kw)
+        ts = torch.linspace(0, dp.dphys_cfg.traj_sim_time, int(dp.dphys_cfg.traj_sim_time / dp.dphys_cfg.dt))[:T]
+        gt_ts = (ts[9::10] if not crowded else torch.tensor([0.091, 0.092, 0.3]))         # crowded: two stamps nearest to row 9
+        Xgt = torch.randn(B, gt_ts.numel(), 3, generator=gen).to(DEV, dtype)
+        spec = dp.loss_spec(gt_ts, gamma=0.9, n_steps=T)
+        assert spec.fusable == (not crowded)
+        zl = z.to(DEV, dtype).requires_grad_(True)
+        loss, states = dp.physics_loss_rollout(zl.unsqueeze(0), ctrl.to(DEV, dtype), Xgt, spec)
+        loss.backward()
+        z2 = z.to(DEV, dtype).requires_grad_(True)
+        st2, _ = dp(z2.unsqueeze(0), ctrl.to(DEV, dtype))
+        ref = physics_loss(st2, [Xgt], ts.to(DEV, dtype).unsqueeze(0).expand(B, -1), gt_ts.to(DEV, dtype).unsqueeze(0).expand(B, -1))
+        ref.backward()
+        tol = 1e-5 if dtype == torch.float32 else 1e-10
+        assert abs(float(loss) - float(ref)) <= tol * abs(float(ref)), (kw, integ, dtype, crowded)
+        assert hp.rel_err(zl.grad.cpu(), z2.grad.cpu()) <= 10 * tol
