@@ -126,6 +126,8 @@ typedef struct MfRolloutLoss {
   const int32_t* near;      /* int32[T2]: output row nearest in time to stamp j (losses.py:116), strictly increasing, < T */
   const void* w;            /* S[T2]: time weights 1 / (1 + gamma t_j) (losses.py:122) */
   const int32_t* row_stamp; /* int32[T]: stamp index j of output row t, -1 where the row carries none (the inverse of `near`) */
+  const void* row_w;        /* S[T]: w[row_stamp[t]], 0 where the row carries no stamp (the kernels read the stamps through the two
+                               row tables; near / w document them and serve mf_physics_loss_* callers) */
   void* partial;            /* forward scratch: S[ceil(B / 4)] per-workgroup partial sums */
   uint32_t* ticket;         /* forward: ONE zero-initialised counter; the launch leaves it zero again */
   void* loss;               /* forward out: S[1], the mean over B x T2 x 3 */

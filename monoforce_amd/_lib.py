@@ -26,7 +26,7 @@ class MfRolloutDesc(C.Structure):
 
 
 class MfRolloutLoss(C.Structure):
-    _fields_ = [('T2', C.c_int32), ('reserved', C.c_int32)] + [(n, C.c_void_p) for n in ('gt', 'near', 'w', 'row_stamp', 'partial', 'ticket', 'loss', 'gloss', 'Xs')]
+    _fields_ = [('T2', C.c_int32), ('reserved', C.c_int32)] + [(n, C.c_void_p) for n in ('gt', 'near', 'w', 'row_stamp', 'row_w', 'partial', 'ticket', 'loss', 'gloss', 'Xs')]
 
 
 class MfRolloutFwdBufs(C.Structure):

@@ -514,6 +514,9 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
     const bool loss_on = STREAM && a.loss_gt != nullptr;      // wave-uniform
     const float loss_scale = loss_on ? 2.0f * a.loss_gloss[0] * a.loss_inv_count : zero;      // as csrc/physics_loss.hip: (2 gloss) / count
     const float* const loss_gt_lane = loss_on ? a.loss_gt + ((size_t)b * (size_t)a.loss_T2) * 3u + (unsigned)cc : a.z;
+    const int* const l_row_stamp = loss_on ? a.loss_row_stamp : reinterpret_cast<const int*>(a.ts);      // dummies: T valid words
+    const float* const l_row_w = loss_on ? a.loss_row_w : a.ts;
+    const int l_T2m1 = loss_on ? a.loss_T2 - 1 : 0;
     if constexpr (STREAM) {
       // MODE = kCpStream (default integrator): a SECOND wave of the workgroup fetches -- the rows and the record of three steps per
       // batch straight into registers -- and, since it has the time, turns each step into the COEFFICIENTS of its vector-Jacobian
@@ -575,19 +578,23 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
         // batch's first step (ordinal 3 j) sits in slot 3 j mod kSlots (six slots: wave k owns slots 3k .. 3k + 2); steps are
         // published -- `steps written` advanced -- in order: a wave waits for the other one's previous batch.
         static_assert(kSlots % 6 == 0, "two fetching waves alternate over batches of three steps: a batch must not wrap around the ring");
-        struct Slot { StateIn st; Saved sv; UpIn up; float lg, lw; };      // lg, lw: ground truth / weight of the row's stamp (fused loss)
+        struct Slot { StateIn st; Saved sv; UpIn up; float lg, lw; int sj; };      // stamp of the row, its weight and ground truth (fused loss)
+        unsigned zero_lane = 0u;                                                   // 0, as a per-lane value the compiler cannot see through:
+        asm("" : "+v"(zero_lane));                                                 // keeps the loads of the stamp tables VECTOR loads
         const int fk = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) - 1;      // (wave-uniform, and provably so: scalar branches)
         int m = n;                                  // m: the step the offsets point at
         auto fetch = [&](Slot& r) {                 // everything of step m; then the offsets move to step m - 1
           request_state(r.st, r.sv);                // (past step 0 the offsets wrap around; nothing reads them again)
           request_up(r.up);
-          r.lg = zero; r.lw = zero;
-          if (loss_on) {                            // the stamp of output row ti + 1, the row this step produced (wave-uniform)
-            const int sj = a.loss_row_stamp[ti + 1];
-            const int sjc = max(sj, 0);
-            r.lg = loss_gt_lane[(size_t)sjc * 3u];
-            r.lw = sj >= 0 ? a.loss_w[sjc] : zero;  // no stamp: weight 0 -> gradient 0
-          }
+          // The stamp of output row ti + 1 (the row this step produced) and its weight -- UNCONDITIONAL vector loads of a wave-uniform
+          // address: without a fused loss they read a dummy table (the time grid) and the result is never used.  Unconditional,
+          // because loads inside a branch leave the wait-count pass unable to tell how many are in flight behind the step's other
+          // requests (it then waits for everything: 0.21 -> 0.27 ms); vector, because scalar loads would be consumed at once (two
+          // dependent round trips in front of the step's other requests).  The ground truth they address is requested a stage
+          // later, with the cell gathers.
+          r.sj = ld32(l_row_stamp, (unsigned)(ti + 1) + zero_lane);
+          r.lw = ld32(l_row_w, (unsigned)(ti + 1) + zero_lane);            // 0 where the row carries no stamp -> gradient 0
+          r.lg = zero;
           o3 -= s3; o9 -= s9; oc -= 8u; orc -= rec_step; --ti;
           step_back_up();
           --m;
@@ -652,7 +659,11 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
         int ord = 3 * fk;                           // ordinal of the first step of this wave's next batch to WRITE
         unsigned sbase = 3u * (unsigned)fk;         // ... and its ring slot: (3 j) mod kSlots
         auto fetch3 = [&](Slot (&s)[3]) { fetch(s[0]); fetch(s[1]); fetch(s[2]); skip3(); };
-        auto gather3 = [&](Slot (&s)[3]) { gather_cells(s[0].sv); gather_cells(s[1].sv); gather_cells(s[2].sv); };
+        auto gather1 = [&](Slot& r) {
+          gather_cells(r.sv);
+          r.lg = loss_gt_lane[(size_t)(unsigned)min(max(r.sj, 0), l_T2m1) * 3u];      // (no fused loss: element 0 of the height map, unused)
+        };
+        auto gather3 = [&](Slot (&s)[3]) { gather1(s[0]); gather1(s[1]); gather1(s[2]); };
         auto put3 = [&](const Slot (&s)[3]) {
           put(s[0], sbase, ord); put(s[1], sbase + 1u, ord + 1); put(s[2], sbase + 2u, ord + 2);
           ord += 6;
@@ -682,7 +693,7 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
           while (m >= 0) {                          // (fetch moves m)
             Slot r0;
             fetch(r0);
-            gather_cells(r0.sv);
+            gather1(r0);
             put(r0, sl, o);
             ++sl; ++o;
           }
@@ -696,11 +707,7 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
         unsigned rslot = 0u;                          // ring slot read next (running, wraps at kSlots)
         UpIn uZ;                                      // the upstream gradient of output row 0 (the initial state): not in the ring
         load_upstream(0, uZ);
-        if (loss_on) {
-          const int sj = a.loss_row_stamp[0];
-          const int sjc = max(sj, 0);
-          uZ.gXs = cp_loss_grad(loss_scale, uZ.gXs, loss_gt_lane[(size_t)sjc * 3u], sj >= 0 ? a.loss_w[sjc] : zero);
-        }
+        if (loss_on) uZ.gXs = cp_loss_grad(loss_scale, uZ.gXs, loss_gt_lane[(size_t)max(a.loss_row_stamp[0], 0) * 3u], a.loss_row_w[0]);
         // The coefficients of a step's vector-Jacobian product, as the fetching wave leaves them in the ring.  With
         // cs = c / sum c, the gates mG, mF1 (1 / 0) and d1 = gFr . (mF1 n) -- the one lane sum that serves F0 = -A n and n both:
         struct Coef {

@@ -35,7 +35,7 @@ struct RolloutBwdArgs {
   int loss_T2;
   const S* loss_gt;        // NULL: no fused loss
   const int* loss_row_stamp;
-  const S* loss_w;
+  const S* loss_row_w;
   const S* loss_gloss;
   S loss_inv_count;
 };
@@ -143,7 +143,9 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_bwd_kernel(const Ro
   };
   auto make_ptrs = [&](int m, Ptrs& p) {       // rows of step m: the state it started from, the upstream of the row it produced
     const size_t in_row = row0 + (size_t)(INTEG == MF_INTEG_ODEINT_EULER ? m : m - 1) * row_stride;   // (m - 1 unused for m = 0)
-    const size_t out_row = row0 + (size_t)(INTEG == MF_INTEG_ODEINT_EULER ? m + 1 : m) * row_stride;
+    // (T = 1 with the default integrator has no step at all: the prologue's prefetch of "step 0" must stay inside the one row there is --
+    //  unclamped it read one row past every upstream array, a fault whenever such an array ended on a page boundary)
+    const size_t out_row = row0 + (size_t)(INTEG == MF_INTEG_ODEINT_EULER ? min(m + 1, a.T - 1) : m) * row_stride;
     p.x = a.Xraw + in_row * 3; p.xd = a.Xds + in_row * 3; p.w = a.Om + in_row * 3; p.R = a.Rs + in_row * 9;
     p.c = ctrl + (size_t)m * 2; p.t = a.ts + m;
     p.g1 = a.gXs + out_row * a.sXs; p.g2 = a.gXds + out_row * a.sXds; p.g3 = a.gOm + out_row * a.sOm; p.g4 = a.gRs + out_row * a.sRs;

@@ -54,7 +54,7 @@ static int fill_args(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutA
   a->path_cost = (S*)p->path_cost;
   a->zmu = nullptr;
   a->rec = nullptr;
-  a->loss_T2 = 0; a->loss_gt = nullptr; a->loss_near = nullptr; a->loss_w = nullptr; a->loss_partial = nullptr; a->loss_ticket = nullptr;
+  a->loss_T2 = 0; a->loss_gt = nullptr; a->loss_row_w = nullptr; a->loss_partial = nullptr; a->loss_ticket = nullptr;
   a->loss_out = nullptr; a->loss_inv_count = (S)0;
   for (int i = 0; i < 12; ++i) a->joint_xyz[i] = (S)d->joint_xyz[i];
   if (p->joint_angles) {
@@ -140,8 +140,9 @@ extern "C" int mf_rollout_fwd_f32(const MfRolloutDesc* d, const MfRolloutFwdBufs
         const MfRolloutLoss* L = p->loss;
         MF_REQUIRE(mf::cp_loss_fusable(d), MF_ERR_UNSUPPORTED, "rollout_fwd: this launch cannot carry the fused physics loss (mf_rollout_loss_fusable)");
         MF_REQUIRE(!forces && d->layout == MF_LAYOUT_TIME_MAJOR, MF_ERR_INVALID, "rollout_fwd: the fused physics loss needs Fs = Ff = NULL and MF_LAYOUT_TIME_MAJOR");
-        MF_REQUIRE(L->T2 > 0 && L->gt && L->near && L->w && L->partial && L->ticket && L->loss, MF_ERR_INVALID, "rollout_fwd: incomplete MfRolloutLoss");
-        a.loss_T2 = L->T2; a.loss_gt = (const float*)L->gt; a.loss_near = L->near; a.loss_w = (const float*)L->w;
+        MF_REQUIRE(L->T2 > 0 && L->gt && L->row_w && L->partial && L->ticket && L->loss, MF_ERR_INVALID, "rollout_fwd: incomplete MfRolloutLoss");
+        MF_REQUIRE((long long)d->B * L->T2 * 3 * 4 < (1ll << 32), MF_ERR_UNSUPPORTED, "rollout_fwd: ground truth of 4 GiB or more");
+        a.loss_T2 = L->T2; a.loss_gt = (const float*)L->gt; a.loss_row_w = (const float*)L->row_w;
         a.loss_partial = (float*)L->partial; a.loss_ticket = L->ticket; a.loss_out = (float*)L->loss;
         a.loss_inv_count = (float)(1.0 / ((double)d->B * L->T2 * 3));
       }

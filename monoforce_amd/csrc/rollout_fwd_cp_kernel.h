@@ -202,23 +202,30 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
   };
 
   // ---- fused physics loss: the next stamped row (wave-uniform: the stamps are the same for every rollout) and its ground truth ----
-  float l_acc = zero, l_g = zero, l_w = zero;
-  int l_j = 0, l_next = -1;
-  const float* l_gt = nullptr;
-  if constexpr (LOSS) {
-    l_gt = a.loss_gt + ((size_t)b * (size_t)a.loss_T2) * 3u + (unsigned)cc;
-    if (a.loss_T2 > 0) { l_next = a.loss_near[0]; l_g = l_gt[0]; l_w = a.loss_w[0]; }
-  }
-  auto loss_row = [&](int row, float ex, float e2) {        // output row `row` = (ex, ..., e2): position component, R[:, 2] component
+  // The stamp the rollout is waiting for is re-read EVERY step (one vector load that hits L1, two scalar loads), next to the step's
+  // other loads.  (With the loads inside a branch taken at the stamped rows the wait-count pass could no longer tell how many
+  // loads are in flight behind the step's gathers and waited for them a step early -- a full L2 round trip per step:
+  // 0.165 -> 0.189 ms.)
+  float l_acc = zero;
+  int l_j = 0;                                                    // stamps met so far = index of the one the rollout is waiting for
+  const int l_last = LOSS ? a.loss_T2 - 1 : 0;
+  const unsigned l_lane = LOSS ? ((unsigned)b * (unsigned)a.loss_T2 * 3u + (unsigned)cc) : 0u;      // this lane's component of its rollout's first stamp
+  struct Stamp { float g, w; };
+  auto loss_peek = [&](int row) {                               // weight of output row `row` (0: no stamp) and the awaited stamp's ground truth
+    Stamp st = {zero, zero};
     if constexpr (LOSS) {
-      if (row == l_next) {                                     // scalar compare, wave-uniform branch: every ~10th row
-        l_acc += cp_loss_term(fmaf(e2, a.sink, ex), l_g, l_w);
-        ++l_j;
-        const int jn = min(l_j, a.loss_T2 - 1);
-        l_next = l_j < a.loss_T2 ? a.loss_near[jn] : -1;
-        l_g = l_gt[(size_t)jn * 3u];
-        l_w = a.loss_w[jn];
-      }
+      st.g = ld32(a.loss_gt, l_lane + (unsigned)(min(l_j, l_last) * 3));
+      st.w = a.loss_row_w[row];
+    }
+    return st;
+  };
+  auto loss_row = [&](float ex, float e2, const Stamp& st) {      // an output row: ex = position component, e2 = R[:, 2] component
+    if constexpr (LOSS) {
+      // branch-free: the term is formed at EVERY row, with weight 0 off the stamps (six VALU instructions; a branch at the stamped
+      // rows -- even one holding arithmetic only -- ends the basic block, and the tail of one step and the head of the next no
+      // longer fill each other's stalls: 0.165 -> 0.20 ms)
+      l_acc += cp_loss_term(fmaf(e2, a.sink, ex), st.g, st.w);
+      l_j += st.w != zero ? 1 : 0;                               // (weights are 1 / (1 + gamma t) > 0)
     }
   };
 
@@ -234,6 +241,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
       v_ctrl = min(v_ctrl + ctrl_step, v_ctrl_last);
       bload2(rCtrl, v_ctrl, 0u, &cv_next, &cw_next);
       const float t_next = a.ts[min(n + 2, a.T - 1)];
+      const Stamp stamp = loss_peek(n + 1);
       const float tv = cp_track(tv_v, tv_w, cv_n, cw_n);
       // ---- stream B: pose and geometry of step n + 1 (torchdiffeq fixed-grid euler: y_{n+1} = y_n + h f(t_n, y_n)) ----
       // (column j of R is a 3-vector over the lanes: dR_j = w x R_j)
@@ -243,7 +251,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
       g_next = geometry(xn, Rn0, Rn1, Rn2);           // (after the last step: the final pose -- unused, in range)
       // ---- row n, AFTER the gathers in program order: their wait a step later then covers no store of this step ----
       emit_row(x, xd, w, R0, R1, R2, 1u);
-      loss_row(n, x, R2);
       x = xn; R0 = Rn0; R1 = Rn1; R2 = Rn2;
       // ---- stream A: contact chain of step n ----
       float xdd, wd, Fr, Ff;
@@ -259,10 +266,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
       oFf = fmaf(h, Ff, oFf);
       h_next = t_next - t_cur;          // (after the last step: 0, unused)
       t_cur = t_next;
+      // fused loss: row n + 1 (the pose is already the next one's) -- its wave-uniform branch sits at the very END of the step, so the
+      // step's two instruction streams stay in one basic block
+      loss_row(x, R2, stamp);
     };
     Geo gA, gB;
     float cvA = cv, cwA = cw, hA = h_ode, cvB = zero, cwB = zero, hB = zero;
     if (n_steps > 0) gA = geometry(x, R0, R1, R2);
+    loss_row(x, R2, loss_peek(0));     // (row 0 = the start state)
     __builtin_amdgcn_s_waitcnt(0);
     int n = 0;
     for (; n + 1 < n_steps; n += 2) {
@@ -314,7 +325,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
   if (n_steps > 0 || INTEG == MF_INTEG_ODEINT_EULER) emit_row(x, xd, w, R0, R1, R2, 1u);
   if constexpr (LOSS) {
     static_assert(!LOSS || INTEG == MF_INTEG_ODEINT_EULER, "the fused loss rides on the default integrator's kernels");
-    loss_row(n_steps, x, R2);                                  // the last row
     // One partial sum per workgroup (= wave), in a fixed order: the three component lanes of each rollout's first quad leave their
     // sums in LDS, lane 0 adds them row by row (a trailing workgroup may hold fewer than four rollouts: its absent rows stay zero).
     __shared__ float l_sh[80];

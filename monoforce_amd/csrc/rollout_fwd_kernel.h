@@ -58,8 +58,7 @@ struct RolloutArgs {
   // fused physics loss (MfRolloutLoss; component-parallel LOSS kernels): stamps, weights, ground truth, reduction scratch
   int loss_T2;
   const S* loss_gt;
-  const int* loss_near;
-  const S* loss_w;
+  const S* loss_row_w;
   S* loss_partial;
   unsigned* loss_ticket;
   S* loss_out;

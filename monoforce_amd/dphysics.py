@@ -13,6 +13,7 @@ returns (`dphysics.py:515-526` permutes torchdiffeq's `[T, B, ...]` stacks); pas
 constructor to get batch-major contiguous tensors instead.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -152,11 +153,21 @@ class LossSpec:
         self.T, self.T2, self.gamma = int(pred_ts.numel()), int(gt_ts.numel()), float(gamma)
         row_stamp = torch.full((self.T,), -1, dtype=torch.int32)
         row_stamp[near] = torch.arange(self.T2, dtype=torch.int32)
+        w = 1. / (1. + gamma * gt_ts)
+        row_w = torch.zeros(self.T, dtype=dtype)
+        row_w[near] = w
         self.near = near.to(torch.int32).to(device)
-        self.w = (1. / (1. + gamma * gt_ts)).to(device)
-        self.row_stamp = row_stamp.to(device)
+        self.w = w.to(device)
+        self.row_stamp, self.row_w = row_stamp.to(device), row_w.to(device)
         self.gt_ts = gt_ts.to(device)
         self.ticket = torch.zeros(1, dtype=torch.int32, device=device)      # the launch leaves it zero
+        self._full = {}
+
+    def per_rollout(self, B):
+        """(nearest [B,T2] int32, gt_ts [B,T2]) as `mf_physics_loss_value_*` reads them (one row per rollout), built once per batch size."""
+        if B not in self._full:
+            self._full[B] = (self.near.unsqueeze(0).expand(B, -1).contiguous(), self.gt_ts.unsqueeze(0).expand(B, -1).contiguous())
+        return self._full[B]
 
 
 def _rollout_forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_grad, joint_angles=None, want_forces=True,
@@ -201,11 +212,13 @@ def _rollout_forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_gra
         Xraw=_lib.ptr(Xraw), joint_angles=_lib.ptr(joint_angles),
         zmu_scratch=_lib.ptr(_zmu_scratch(mod, desc, keep['z'])), zmu=_lib.ptr(mod._staged_zmu(desc, z, mu)), rec=_lib.ptr(rec))
     loss_val = lstruct = None
+    in_forward = loss is not None and mod.loss_in_forward
     if loss is not None:
         spec, X_gt = loss
         loss_val = torch.empty((), dtype=dt, device=dev)
+    if in_forward:
         partial = torch.empty((B + 3) // 4, dtype=dt, device=dev)
-        lstruct = _lib.MfRolloutLoss(T2=spec.T2, gt=_lib.ptr(X_gt), near=_lib.ptr(spec.near), w=_lib.ptr(spec.w), row_stamp=_lib.ptr(spec.row_stamp),
+        lstruct = _lib.MfRolloutLoss(T2=spec.T2, gt=_lib.ptr(X_gt), near=_lib.ptr(spec.near), w=_lib.ptr(spec.w), row_stamp=_lib.ptr(spec.row_stamp), row_w=_lib.ptr(spec.row_w),
                                      partial=_lib.ptr(partial), ticket=_lib.ptr(spec.ticket), loss=_lib.ptr(loss_val))
         bufs.loss = C.cast(C.pointer(lstruct), C.c_void_p)       # (lstruct stays alive until the launch call below returns)
     fn = getattr(_lib.lib(), 'mf_rollout_fwd_' + _scalar_suffix(dt))
@@ -214,6 +227,20 @@ def _rollout_forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_gra
     outs = (Xs, Xds, Rs, Om) + ((Fs[..., :N, :], Ff[..., :N, :]) if want_forces else ())
     if tm:
         outs = tuple(o.transpose(0, 1) for o in outs)
+    if loss is not None and not in_forward:
+        # The VALUE of the loss from one small launch on the rows just written (mf_physics_loss_value_*: gather-reduce over the B x T2
+        # stamped rows, the mean finished inside it).  Measured against the rollout kernel accumulating it itself (LOSS kernels,
+        # `loss_in_forward`): that forward pays ~15 instructions and two loads at EVERY step of a launch bound by the issue slots of
+        # one wave per SIMD -- 0.165 -> 0.185 ms at B = 1024 -- where this launch is 0.012 ms.  The BACKWARD half of the fusion is
+        # the one that pays: no loss-gradient launch, no [T][B][3] gradient rows (rollout_backward).
+        near_b, gt_ts_b = spec.per_rollout(B)
+        Xp = outs[0]
+        ldesc = _lib.MfLossDesc(B=B, T1=T, T2=spec.T2, x_stride_b=Xp.stride(0), x_stride_t=Xp.stride(1), gamma=spec.gamma)
+        lpart = torch.empty((B * spec.T2 + 255) // 256, dtype=dt, device=dev)
+        with torch.cuda.device(dev), _timing.timed('physics_loss_fwd', dev):
+            _lib.check(getattr(_lib.lib(), 'mf_physics_loss_value_' + _scalar_suffix(dt))(
+                C.byref(ldesc), _lib.ptr(Xp), _lib.ptr(X_gt), _lib.ptr(gt_ts_b), _lib.ptr(near_b), _lib.ptr(lpart), _lib.ptr(spec.ticket),
+                _lib.ptr(loss_val), None, C.c_longlong(0), _stream_ptr(dev)), 'mf_physics_loss_value')
     if loss is not None:
         outs = (loss_val,) + outs
         ctx.loss = (spec, X_gt, Xs) if want_grad else None
@@ -298,6 +325,9 @@ class DPhysics(torch.nn.Module):
         self.return_forces = return_forces
         self.interleave_maps = True      # shared float32 maps: let the library read an interleaved (z, mu) copy (same bits, fewer loads)
         self.precise = precise      # True: float32 kernels in the reference's exact op order (IEEE div/sqrt, no FMA); ~1.5x slower
+        # physics_loss_rollout: True = the forward rollout kernel accumulates the loss itself (LOSS kernels); False (default) = its value
+        # comes from one small launch on the written rows -- measured faster, see _rollout_forward; the backward is fused either way
+        self.loss_in_forward = bool(int(os.environ.get('MF_LOSS_IN_FORWARD', '0')))
         self.staged_handoffs = 0    # rollouts that read an interleaved map pair staged by terrain_stage.stage_terrain
         self._cache = {}
 

@@ -133,7 +133,7 @@ def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf, gloss=None):
     if gloss is not None:       # the forward carried physics_loss itself (MfRolloutLoss): the kernel forms dL/dXs from Xs and the ground truth
         spec, X_gt, Xs_rows = ctx.loss
         gl = gloss.to(dt).reshape(1).contiguous()
-        lstruct = _lib.MfRolloutLoss(T2=spec.T2, gt=_lib.ptr(X_gt), near=_lib.ptr(spec.near), w=_lib.ptr(spec.w), row_stamp=_lib.ptr(spec.row_stamp),
+        lstruct = _lib.MfRolloutLoss(T2=spec.T2, gt=_lib.ptr(X_gt), near=_lib.ptr(spec.near), w=_lib.ptr(spec.w), row_stamp=_lib.ptr(spec.row_stamp), row_w=_lib.ptr(spec.row_w),
                                      gloss=_lib.ptr(gl), Xs=_lib.ptr(Xs_rows))
         bufs.loss = C.cast(C.pointer(lstruct), C.c_void_p)
     fn = getattr(_lib.lib(), 'mf_rollout_bwd_' + _scalar_suffix(dt))

@@ -104,12 +104,13 @@ def test_gradient_copy_pool_is_reused_clean():
 
 
 # ---- physics_loss inside the rollout's own launches (MfRolloutLoss; DPhysics.physics_loss_rollout) ----------------
-def _fit_problem(B, T, loss_in_kernel, graph=False, res=0.1, d_max=3.2, gt_every=10):
+def _fit_problem(B, T, loss_in_kernel, graph=False, res=0.1, d_max=3.2, gt_every=10, in_forward=False):
     from monoforce_amd import synthetic as syn
     from monoforce_amd.train import TerrainFitProblem
     from tests.test_rollout_gpu import make_dphysics
     pts, masks = syn.robot_points_4()
     dp = make_dphysics(pts, masks, 1, res, d_max)
+    dp.loss_in_forward = in_forward      # True: the forward rollout kernel accumulates the loss itself; False: one small launch on its rows
     z_true = (syn.bump_terrain(syn.bump_params(3), d_max, res) * 0.3).to(DEV)
     mu = syn.wave_friction(d_max, res).to(DEV)
     ctrl = syn.const_controls(B, T, seed=2).to(DEV)
@@ -119,16 +120,19 @@ def _fit_problem(B, T, loss_in_kernel, graph=False, res=0.1, d_max=3.2, gt_every
     return prob, z, m
 
 
+@pytest.mark.parametrize('in_forward', [False, True])
 @pytest.mark.parametrize('B,T,gt_every', [(48, 300, 10), (37, 95, 10), (3, 41, 1), (1, 12, 5), (1500, 120, 10)])
-def test_loss_inside_the_rollout_kernels_equals_the_two_kernel_route(B, T, gt_every):
+def test_loss_inside_the_rollout_kernels_equals_the_two_kernel_route(B, T, gt_every, in_forward):
     """Forward: the mean the rollout kernel finishes itself == mf_physics_loss_value_* on its outputs (and == the plain-torch
     restatement of losses.py:102-127); backward: dL/dXs formed by the fetching waves == the gradient rows mf_physics_loss_bwd_* writes,
     so the terrain / friction gradients agree to the rounding of the atomics' arrival order.  Batches with a trailing partial
-    workgroup (37, 3, 1 rollouts), every row stamped (gt_every = 1), two workgroups per CU (1500)."""
+    workgroup (37, 3, 1 rollouts), every row stamped (gt_every = 1), two workgroups per CU (1500).  Both forms of the forward half:
+    the rollout kernel accumulating the loss itself (`loss_in_forward`, the LOSS kernels) and -- the default, measured faster --
+    one small launch on the rows it wrote; the backward half is the same."""
     from monoforce_amd.losses import physics_loss
     out = []
     for in_kernel in (False, True):
-        prob, z, m = _fit_problem(B, T, in_kernel, gt_every=gt_every)
+        prob, z, m = _fit_problem(B, T, in_kernel, gt_every=gt_every, in_forward=in_forward)
         vals = []
         for _ in range(3):                                   # launch after launch: the ticket comes back to zero
             loss = prob.step(z, m)
@@ -151,7 +155,7 @@ def test_loss_inside_the_kernels_replayed_as_a_graph_and_non_unit_upstream():
     (the upstream scalar reaches the fetching waves through MfRolloutLoss.gloss)."""
     prob, z, m = _fit_problem(256, 150, True)
     l0 = float(prob.step(z, m)); g0 = (z.grad.clone(), m.grad.clone())
-    pg, zg, mg = _fit_problem(256, 150, True, graph=True)
+    pg, zg, mg = _fit_problem(256, 150, True, graph=True, in_forward=True)
     for _ in range(3):
         lg = float(pg.step(zg, mg))
         assert pg.graph and abs(lg - l0) <= 1e-6 * abs(l0)
