@@ -66,6 +66,12 @@ WORKLOADS = {
     'c3': dict(B=1024, T=500, N=4, backward=True, desc='BASELINE configs[2]: 1024 rollouts x 500 steps, forward + physics loss + backward to terrain'),
     'c4': dict(B=1024, T=500, N=4, backward=True, encoder=True,
                desc='BASELINE configs[3]: TerrainEncoder (4 cams 3x256x512 -> 256x256 BEV) + 1024 rollouts per GPU, end-to-end train step'),
+    # the reference's own operating point (examples/diff_physics.ipynb:199-226: 64 rollouts x 600 steps of the 223-point `marv` body on a
+    # 128 x 128 grid -- the only timing the reference records) and two more body sizes of its robots
+    'ref_nb': dict(B=64, T=600, N=223, backward=True, grid_res=0.1,
+                   desc='the reference notebook shape (examples/diff_physics.ipynb:199-226): 64 rollouts x 600 steps x 223 contact points, 128x128 grid'),
+    'n32': dict(B=1024, T=500, N=32, backward=True, desc='1024 rollouts x 500 steps x 32 contact points'),
+    'n175': dict(B=64, T=500, N=175, backward=True, desc='64 rollouts x 500 steps x 175 contact points (tradr-sized body; open3d down-sampling itself unpinned)'),
     'c5': dict(B=8192, T=500, N=4, backward=True, encoder=True, strong=True,
                desc='BASELINE configs[4]: 8192 rollouts in total + encoder (one 4-camera sample per GPU), data-parallel with RCCL gradient all-reduce'),
 }
@@ -92,6 +98,8 @@ def build_problem(B, T, N, device, integ, seed=0, grid_res=0.05, terrain_seed=0)
         pts, masks = syn.robot_points_box(N, seed=1, n_tracks=2)
     cfg = DPhysConfig(robot='tradr', grid_res=grid_res, robot_points=pts, driving_parts=masks)
     cfg.use_odeint = (integ == 1)
+    if T > int(cfg.traj_sim_time / cfg.dt):
+        cfg.traj_sim_time = T * cfg.dt + 1e-9      # a longer horizon than the default 5 s (the notebook's 6 s)
     z = syn.bump_terrain(syn.bump_params(terrain_seed), 6.4, grid_res)
     mu = syn.wave_friction(6.4, grid_res)
     ctrl = syn.const_controls(B, T, seed=seed)
@@ -138,7 +146,8 @@ def cpu_baseline(N, integ, T, budget_s=12.0):
     t, n = _time_cpu(fwd, budget_s)
     head = dict(value=Bs * T / t, unit='rollout-steps/s', cores=cores, kind='port',
                 sample=f'oracle/dphysics_oracle.py (torch-CPU port), B={Bs} x T={T} x N={N}, 256x256 shared map, forward '
-                       f'no_grad, median of {n} runs; os.cpu_count()={os.cpu_count()}')
+                       f'no_grad, median of {n} runs; os.cpu_count()={os.cpu_count()}.  (legs: the autograd forward + backward of '
+                       f'config 3 is timed on a B=32 sample -- its cost grows with B^2 -- and config 1 at its own size)')
     # forward + autograd backward to the terrain (C3), loss on every 10th pose like physics_loss
     Ba = 32       # every gather's autograd node materialises a [B,H,W] gradient (as in the reference): time grows with B^2
     ctrl_a = syn.const_controls(Ba, T, seed=0)
@@ -148,7 +157,7 @@ def cpu_baseline(N, integ, T, budget_s=12.0):
         ml = mu.clone().requires_grad_(True)
         (Xs, _, _, _), _ = orc.rollout(spec, zl.unsqueeze(0).expand(Ba, -1, -1), ctrl_a, friction=ml.unsqueeze(0).expand(Ba, -1, -1))
         (Xs[:, 9::10] ** 2).mean().backward()
-    t, n = _time_cpu(fwd_bwd, budget_s, max_runs=6)
+    t, n = _time_cpu(fwd_bwd, 3.2 * budget_s, max_runs=5)       # (one run is ~7 s: a warm-up and >= 3 timed ones)
     legs['c3_autograd'] = dict(value=Ba * T / t, unit='rollout-steps/s', cores=cores, kind='port',
                                sample=f'B={Ba} x T={T} x N={N}, 256x256 shared map, forward + torch autograd backward to '
                                       f'terrain and friction, median of {n} runs')
@@ -255,7 +264,7 @@ class Runner:
             gc = dict(xbound=[-6.4, 6.4, 0.05], ybound=[-6.4, 6.4, 0.05], zbound=[-3.2, 3.2, 6.4], dbound=[0.6, 6.4, 0.1])
             enc = LiftSplatShoot(gc, dict(final_dim=(256, 512))).to(dev).train()
             ebatch = synthetic_encoder_batch(enc, dp, n_rollouts=B, device=dev, seed=rank)    # the encoder batch is sharded too
-            estep = EncoderTrainStep(enc, dp, lr=1e-4)
+            estep = EncoderTrainStep(enc, dp, lr=1e-4, graph=not os.environ.get('MF_BENCH_NO_GRAPH'))
         elif wl['backward']:
             from monoforce_amd.train import TerrainFitProblem
             from monoforce_amd import synthetic as syn
@@ -265,7 +274,7 @@ class Runner:
             zleaf = z.to(dev).clone().requires_grad_(True)
             mleaf = mu.to(dev).clone().requires_grad_(True)
 
-        use_graph = not os.environ.get('MF_BENCH_NO_GRAPH') and not wl.get('encoder')
+        use_graph = not os.environ.get('MF_BENCH_NO_GRAPH')
         mode = {'graph': False}
         fwd_graph = None
 
@@ -274,9 +283,9 @@ class Runner:
                 return dp(zd, cd, friction=md)
 
         def step():
-            if wl.get('encoder'):
-                return estep.step(ebatch)
             eager = _timing.sampled() or not mode['graph']       # steps bracketed with HIP events run launch by launch
+            if wl.get('encoder'):
+                return estep.step(ebatch, eager=eager)
             if wl['backward']:
                 return prob.step(zleaf, mleaf, eager=eager)
             if eager:
@@ -292,7 +301,7 @@ class Runner:
             # launched call by call (0.15 ms of Python and launch calls forward, 0.3 ms forward + backward: faster while the host
             # keeps ahead of the kernels, host-bound on a loaded or slower box and at the small configs).  Same kernels, same
             # work either way.
-            if not wl['backward']:
+            if not wl['backward'] and not wl.get('encoder'):
                 side = torch.cuda.Stream(device=dev)
                 side.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(side):
@@ -302,7 +311,7 @@ class Runner:
                 with torch.cuda.graph(fwd_graph, stream=side, capture_error_mode='thread_local'):
                     forward_eager()
 
-            def timed(graph, n=32):
+            def timed(graph, n=8 if wl.get('encoder') else 32):
                 mode['graph'] = graph
                 step()
                 torch.cuda.synchronize(dev)
@@ -506,8 +515,8 @@ def main():
                     'workload': o['config']['workload'], 'launch': o['config'].get('launch'), 'per_kernel': o['roofline']['per_kernel']}
         if r.world == 1 and not r.force_dist:
             res['roofline']['batch_sweep'] = r.batch_sweep(N, T)
-            for name in ('c1', 'c2'):
-                others[name] = brief(r.run(name, short, 3)[0])
+            for name in ('c1', 'c2', 'ref_nb', 'n32', 'n175'):
+                others[name] = brief(r.run(name, short if name in ('c1', 'c2') else 6, 3)[0])
             others['shoot'] = shoot_workload(r, T, N, args.integrator)
             if args.integrator == 1:      # the other integrator side by side -- dynamics() (use_odeint=False), same shapes
                 args.integrator = 0

@@ -140,6 +140,7 @@ class LiftSplatShoot(nn.Module):
         self.fuse_lift = True            # lift (depth x context) inside the splat kernels; False: get_cam_feats + voxel_pooling
         self.fuse_geometry = True        # with fuse_lift: get_geometry inside the splat's key pass (no [B,N,D,fH,fW,3] tensor)
         self._grid_host = None
+        self._plan_cache = None          # (the five calibration tensors, their versions, plan): see splat_plan_cached
 
     def create_frustum(self):
         """(u, v, d) of every lifted point: pixel centres on the /16 feature grid x depth bins (lss.py:191-202)."""
@@ -188,13 +189,26 @@ class LiftSplatShoot(nn.Module):
         return splat.SplatPlan.from_cameras(self.frustum, rots, trans, intrins, post_rots, post_trans, self.dx, self.bx, self.nx,
                                             grid=self._grid_host[1])
 
+    def splat_plan_cached(self, rots, trans, intrins, post_rots, post_trans):
+        """`splat_plan` for the SAME five tensor objects, unmodified since the last call (identity + version counters; the cache holds
+        the tensors, so their storage cannot be recycled under it): a fixed camera rig -- a frame loop, a synthetic benchmark batch, a
+        captured train step -- pays the two 3x3 inversions (`torch.inverse` synchronises) and the key / scan / CSR passes once instead of
+        every forward.  New tensors every step (a data loader with augmentation) simply miss."""
+        cal = (rots, trans, intrins, post_rots, post_trans)
+        c = self._plan_cache
+        if c is not None and all(a is b for a, b in zip(c[0], cal)) and c[1] == tuple(t._version for t in cal):
+            return c[2]
+        plan = self.splat_plan(*cal)
+        self._plan_cache = (cal, tuple(t._version for t in cal), plan)
+        return plan
+
     def get_voxels(self, x, rots, trans, intrins, post_rots, post_trans, plan=None):
         if self.fuse_lift and x.is_cuda:
             # lift fused into the splat: the [B,N,D,fH,fW,C] tensor of get_cam_feats() is never materialised
             B, N, C, imH, imW = x.shape
             depth, context = self.camencode.get_depth_and_context(x.view(B * N, C, imH, imW))
             if plan is None and self.fuse_geometry:
-                plan = self.splat_plan(rots, trans, intrins, post_rots, post_trans)
+                plan = self.splat_plan_cached(rots, trans, intrins, post_rots, post_trans)
             geom = None if plan is not None else self.get_geometry(rots, trans, intrins, post_rots, post_trans)
             return splat.lift_voxel_pooling(geom, depth, context, self.dx, self.bx, self.nx, plan=plan)
         geom = self.get_geometry(rots, trans, intrins, post_rots, post_trans)

@@ -133,8 +133,14 @@ class EncoderTrainStep:
     one 4-camera sample, 1024 rollouts), which maps onto the rollout kernels' shared-map path.
     """
 
-    def __init__(self, encoder, dphysics, lr=1e-3, geom_weight=1.0, terrain_weight=1.0, phys_weight=1.0):
+    def __init__(self, encoder, dphysics, lr=1e-3, geom_weight=1.0, terrain_weight=1.0, phys_weight=1.0, graph=False):
         self.enc, self.dp = encoder, dphysics
+        # graph = True: the whole step -- encoder forward, lift-splat, heads, staging, rollout + loss, backward, clip, Adam -- is
+        # captured once per batch object and replayed as ONE hipGraph launch: ~4000 launches of ~17 ms of kernels otherwise spend a
+        # quarter of the 23 ms step in launch gaps.  Needs the batch tensors to stay the same objects (a fixed-rig loop would copy
+        # each sample into them) and one process (collectives are not captured: multi-rank steps run launch by launch).
+        self.graph = bool(graph)
+        self._cap = None
         # coarser grid for the physics than for the encoder: average pooling (scripts/train.py:93-99, 233-235)
         k = max(int(round(dphysics.dphys_cfg.grid_res / float(encoder.dx[0]))), 1)
         self.terrain_preproc = torch.nn.AvgPool2d(kernel_size=k, stride=k) if k > 1 else torch.nn.Identity()
@@ -142,10 +148,12 @@ class EncoderTrainStep:
         self.fused_stage = True        # terrain = geom - diff, both poolings and the (z, mu) interleave as one kernel
         self.loss_in_kernel = True     # physics_loss inside the rollout launches where the stamps are shared by the rollouts
         self._specs = {}
+        self._nearest = {}
         self.w = (geom_weight, terrain_weight, phys_weight)
         # train.py:374-375; the fused (single multi-tensor kernel) implementation where the parameters live on the GPU
         on_gpu = all(p.is_cuda for p in encoder.parameters())
-        self.opt = torch.optim.Adam(encoder.parameters(), lr=lr, betas=(0.8, 0.999), weight_decay=1e-7, fused=on_gpu)
+        self.opt = torch.optim.Adam(encoder.parameters(), lr=lr, betas=(0.8, 0.999), weight_decay=1e-7, fused=on_gpu,
+                                    capturable=bool(graph) and on_gpu)
         self.params = [p for p in encoder.parameters() if p.requires_grad]
         # gradients live in a few flat buckets whose all-reduce (RCCL) starts from autograd hooks while the backward is still
         # running; one zero fill per bucket replaces the per-parameter zero_grad
@@ -175,6 +183,20 @@ class EncoderTrainStep:
             l_phys = physics_loss_fused(states, states_gt, pred_ts, gt_ts, nearest=nearest)       # losses.py:102-127 on mf_physics_loss_*
         return l_geom, l_terr, l_phys
 
+    def compute_losses(self, batch):
+        """`TrainerLSS.compute_losses` (scripts/train.py:377-410) on the reference's ROUGH sample tuple, in ITS order
+        (datasets/rough.py:651-663, as the DataLoader collates it):
+            (imgs, rots, trans, intrins, post_rots, post_trans, hm_geom, hm_terrain, control_ts, controls, pose0, traj_ts, Xs, Xds, Rs, Omegas)
+        -> (loss_geom, loss_terrain, loss_phys).  One predicted map per sample; `controls` may hold one trajectory per sample
+        ([Bs,T,2], the reference's case: per-rollout maps) or, with a single sample, many ([B,T,2]: they share its map)."""
+        (imgs, rots, trans, intrins, post_rots, post_trans, hm_geom, hm_terrain, control_ts, controls, pose0,
+         traj_ts, Xs, Xds, Rs, Omegas) = batch
+        key = (control_ts.data_ptr(), traj_ts.data_ptr(), tuple(control_ts.shape), tuple(traj_ts.shape))
+        if key not in self._nearest:       # the stamps of a batch are fixed: the [N,T2,T1] argmin once (losses.py:116)
+            self._nearest = {key: nearest_steps(control_ts, traj_ts).to(torch.int32)}
+        return self.losses(((imgs, rots, trans, intrins, post_rots, post_trans), hm_geom, hm_terrain, controls, pose0,
+                            [Xs, Xds, Rs, Omegas], control_ts, traj_ts, self._nearest[key]))
+
     def _loss_spec(self, gt_ts, T):
         """LossSpec of a batch whose ground-truth stamps are the same for every rollout (an expanded row, or rows checked equal once per
         tensor); None = per-rollout stamps: the unfused physics loss."""
@@ -203,7 +225,37 @@ class EncoderTrainStep:
         for w in works:
             w.wait()
 
-    def step(self, batch):
+    def step(self, batch, eager=False):
+        """One training step; `eager=True` runs this one launch by launch even in graph mode."""
+        if self.graph and not eager and not mfdist.active():
+            return self._step_graph(batch)
+        return self._step_eager(batch)
+
+    def _step_graph(self, batch):
+        cap = self._cap
+        if cap is None or cap['batch'] is not batch:
+            dev = next(self.enc.parameters()).device
+            s = torch.cuda.Stream(device=dev)
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):      # warm-up on the capture stream: MIOpen's solvers chosen, workspaces, pools, Adam state in place
+                for _ in range(3):
+                    self._step_eager(batch)
+            torch.cuda.current_stream(dev).wait_stream(s)
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g, stream=s, capture_error_mode='thread_local'):
+                    out = self._step_eager(batch)
+            except RuntimeError as e:
+                import warnings
+                warnings.warn(f'EncoderTrainStep: hipGraph capture failed ({str(e).splitlines()[0][:160]}); running launch by launch')
+                self.graph = False
+                torch.cuda.synchronize(dev)
+                return self._step_eager(batch)
+            cap = self._cap = dict(graph=g, batch=batch, out=out)
+        cap['graph'].replay()
+        return cap['out']
+
+    def _step_eager(self, batch):
         self.buckets.zero()
         l_geom, l_terr, l_phys = self.losses(batch)
         loss = self.w[0] * l_geom + self.w[1] * l_terr + self.w[2] * l_phys
@@ -212,6 +264,14 @@ class EncoderTrainStep:
         torch.nn.utils.clip_grad_norm_(self.params, max_norm=1.0)                   # train.py:167
         self.opt.step()
         return loss.detach(), (l_geom.detach(), l_terr.detach(), l_phys.detach())
+
+
+def synthetic_rough_batch(encoder, dphysics, n_rollouts, device, seed=0, img_hw=(256, 512)):
+    """The same synthetic sample as `synthetic_encoder_batch`, as the reference's 16-tuple (datasets/rough.py:651-663 order) --
+    what `EncoderTrainStep.compute_losses` / scripts/train.py:377-410 consume."""
+    (inputs, hm_geom, hm_terrain, controls, pose0, states_gt, pred_ts, gt_ts, _near) = synthetic_encoder_batch(
+        encoder, dphysics, n_rollouts, device, seed=seed, img_hw=img_hw)
+    return (*inputs, hm_geom, hm_terrain, pred_ts, controls, pose0, gt_ts, *states_gt)
 
 
 def synthetic_encoder_batch(encoder, dphysics, n_rollouts, device, seed=0, img_hw=(256, 512)):

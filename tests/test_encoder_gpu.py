@@ -59,3 +59,73 @@ def test_training_step_runs_and_learns():
     g = [p.grad for p in enc.parameters() if p.requires_grad and p.grad is not None]
     assert len(g) > 100 and all(torch.isfinite(t).all() for t in g)
     assert any(float(p.grad.abs().max()) > 0 for n, p in enc.named_parameters() if n.startswith('camencode.depthnet'))
+
+
+def test_compute_losses_on_the_references_sample_tuple():
+    """the ROUGH sample tuple in the reference's order (datasets/rough.py:651-663) through
+    `EncoderTrainStep.compute_losses` (scripts/train.py:377-410): same three losses as the package's own batch layout, and the
+    reference's own case -- ONE trajectory per sample, per-sample predicted maps -- runs through the same entry."""
+    from monoforce_amd.dphys_config import DPhysConfig
+    from monoforce_amd.dphysics import DPhysics
+    from monoforce_amd import synthetic as syn
+    from monoforce_amd.terrain_encoder import LiftSplatShoot
+    from monoforce_amd.train import EncoderTrainStep, synthetic_encoder_batch, synthetic_rough_batch
+    torch.manual_seed(0)
+    gc = dict(xbound=[-3.2, 3.2, 0.1], ybound=[-3.2, 3.2, 0.1], zbound=[-3.2, 3.2, 6.4], dbound=[0.6, 3.4, 0.2])
+    enc = LiftSplatShoot(gc, dict(final_dim=(64, 128))).to(DEV).eval()
+    pts, masks = syn.robot_points_4()
+    cfg = DPhysConfig(robot='tradr', grid_res=0.1, robot_points=pts, driving_parts=masks)
+    cfg.d_max, cfg.traj_sim_time = 3.2, 1.0
+    dp = DPhysics(cfg, device=DEV)
+    step = EncoderTrainStep(enc, dp, lr=2e-4)
+    b9 = synthetic_encoder_batch(enc, dp, n_rollouts=32, device=DEV, img_hw=(64, 128))
+    b16 = synthetic_rough_batch(enc, dp, n_rollouts=32, device=DEV, img_hw=(64, 128))
+    assert len(b16) == 16
+    (imgs, rots, trans, intrins, post_rots, post_trans, hm_geom, hm_terrain, control_ts, controls, pose0, traj_ts, Xs, Xds, Rs, Om) = b16
+    assert imgs.shape == (1, 4, 3, 64, 128) and hm_geom.shape == (1, 2, 64, 64) and controls.shape == (32, 100, 2) and pose0.shape == (32, 4, 4)
+    assert control_ts.shape == (32, 100) and traj_ts.shape == (32, 10) and Xs.shape == (32, 10, 3) and Rs.shape == (32, 10, 3, 3)
+    with torch.no_grad():
+        a = [float(v) for v in step.losses(b9)]
+        b = [float(v) for v in step.compute_losses(b16)]
+    assert all(np.isfinite(a)) and all(abs(x - y) <= 1e-5 * max(abs(x), 1e-6) for x, y in zip(a, b)), (a, b)
+    # the reference's collation: Bs samples, each with its own images, maps and ONE trajectory
+    Bs = 3
+    rep = lambda t: t.repeat(Bs, *([1] * (t.dim() - 1)))  # noqa: E731
+    per_sample = (rep(imgs), rep(rots), rep(trans), rep(intrins), rep(post_rots), rep(post_trans), rep(hm_geom), rep(hm_terrain),
+                  control_ts[:Bs], controls[:Bs], pose0[:Bs], traj_ts[:Bs], Xs[:Bs], Xds[:Bs], Rs[:Bs], Om[:Bs])
+    with torch.no_grad():
+        c = [float(v) for v in step.compute_losses(per_sample)]
+    assert all(np.isfinite(c)) and abs(c[0] - a[0]) <= 1e-4 * abs(a[0])      # identical samples: the same height-map loss
+
+
+def test_train_step_replayed_as_one_graph_equals_launch_by_launch():
+    """`EncoderTrainStep(graph=True)`: encoder forward, lift-splat, heads, staging, rollout + physics loss, backward, gradient
+    clipping and Adam captured once and replayed as ONE hipGraph launch.  In eval mode (no drop-connect randomness, batch norm on
+    its running statistics) the replayed steps follow the launch-by-launch ones: same losses step by step, same parameters after."""
+    from monoforce_amd.dphys_config import DPhysConfig
+    from monoforce_amd.dphysics import DPhysics
+    from monoforce_amd import synthetic as syn
+    from monoforce_amd.terrain_encoder import LiftSplatShoot
+    from monoforce_amd.train import EncoderTrainStep, synthetic_encoder_batch
+    gc = dict(xbound=[-3.2, 3.2, 0.1], ybound=[-3.2, 3.2, 0.1], zbound=[-3.2, 3.2, 6.4], dbound=[0.6, 3.4, 0.2])
+    pts, masks = syn.robot_points_4()
+    runs = []
+    for graph in (False, True):
+        torch.manual_seed(0)
+        enc = LiftSplatShoot(gc, dict(final_dim=(64, 128))).to(DEV).eval()
+        cfg = DPhysConfig(robot='tradr', grid_res=0.1, robot_points=pts, driving_parts=masks)
+        cfg.d_max, cfg.traj_sim_time = 3.2, 1.0
+        dp = DPhysics(cfg, device=DEV)
+        batch = synthetic_encoder_batch(enc, dp, n_rollouts=64, device=DEV, img_hw=(64, 128))
+        step = EncoderTrainStep(enc, dp, lr=2e-4, graph=graph)
+        # graph mode: its first call runs three launch-by-launch steps (warm-up), captures, replays once = step 4
+        losses = [float(step.step(batch)[0]) for _ in range(7 if not graph else 4)]
+        assert not graph or (step.graph and step._cap is not None), 'the capture fell back to launch by launch'
+        runs.append((losses, [p.detach().clone() for p in enc.parameters()]))
+    eager, graphed = runs
+    assert np.isfinite(eager[0]).all() and np.isfinite(graphed[0]).all()
+    # replay k is step 3 + k of the same optimisation
+    for k, lg in enumerate(graphed[0]):
+        assert abs(lg - eager[0][3 + k]) <= 2e-2 * abs(eager[0][3 + k]), (k, lg, eager[0])
+    worst = max(float((a - b).abs().max() / b.abs().max().clamp_min(1e-6)) for a, b in zip(graphed[1], eager[1]))
+    assert worst <= 5e-2, worst
