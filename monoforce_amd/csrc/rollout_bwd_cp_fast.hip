@@ -30,20 +30,22 @@ bool use_component_parallel_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* 
 // component-parallel and the launch has at most one wave per SIMD -- 256 B per rollout and step (131 MB at B = 1024, T = 500; round
 // 2's record was 1 KiB and stopped paying at B = 2048, where its stores bound the forward): one more store per wave-step forward;
 // backward no contact chain to recompute (~65 instructions, 7 transcendentals), and the forward's own values at every clamp and
-// kink.  Default integrator: its backward streams the record through LDS with two more waves per workgroup (<= 512 workgroups) or
-// reads it in the computing wave itself (<= 1024).  dynamics() has no streaming form yet, and read by the one wave the record
-// LOSES against recomputing (B = 1024: 0.499 vs 0.436 ms backward, profiles/r3_ab_backward_modes.txt), so it keeps none
-// (MF_CP_RECORD_DYNAMICS=1 switches it on for A/B runs and the parity tests of that kernel).  MF_CP_RECORD_MAX_WAVES overrides
-// the size limit (0 disables).
+// kink.  Its backward streams the record through LDS with two more waves per workgroup (default integrator: <= 512 workgroups;
+// dynamics(), whose ring slots carry the Rodrigues coefficients as well: <= 256) or, default integrator only, reads it in the
+// computing wave itself up to 1024 waves.  dynamics() read by the one wave LOSES against recomputing (B = 1024: 0.499 vs 0.436 ms
+// backward), so beyond its streaming range it keeps no record (MF_CP_RECORD_DYNAMICS=1 forces one: A/B runs, parity tests of that
+// kernel).  MF_CP_RECORD_MAX_WAVES overrides the size limit (0 disables).
 long long cp_record_bytes(const MfRolloutDesc* d) {
   static const long long max_waves = getenv("MF_CP_RECORD_MAX_WAVES") ? atoll(getenv("MF_CP_RECORD_MAX_WAVES")) : 1024;
   if (!d || d->B <= 0 || d->T <= 0) return 0;
   MfRolloutFwdBufs f{};
   static const bool dyn = getenv("MF_CP_RECORD_DYNAMICS") && atoi(getenv("MF_CP_RECORD_DYNAMICS")) != 0;
-  if (d->has_joints || (d->integrator != MF_INTEG_ODEINT_EULER && !dyn)) return 0;
+  static const bool one_wave = getenv("MF_CP_BWD_MODE") && atoi(getenv("MF_CP_BWD_MODE")) == kCpSaved;
+  if (d->has_joints) return 0;
   if (!use_component_parallel(d, &f) || !cp_bwd_covers(d, false)) return 0;
   const long long waves = ((long long)d->B + 3) / 4;
   if (waves > max_waves) return 0;
+  if (d->integrator != MF_INTEG_ODEINT_EULER && !dyn && (one_wave || waves > (long long)cp_stream_max_grid(d->integrator))) return 0;
   const long long bytes = (long long)d->T * d->B * 16 * cp::kRecBytesPerLane;
   if (bytes >= (1ll << 32)) return 0;
   return bytes;

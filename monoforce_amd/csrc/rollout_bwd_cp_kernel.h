@@ -528,9 +528,11 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
       // Addresses: constant scalar bases + RUNNING 32-bit per-lane byte offsets, one vector subtract per array and step.
       const unsigned un = (unsigned)max(n, 0);
       unsigned o3 = v3 + un * s3, o9 = v9 + un * s9, oc = v_ctrl + un * 8u, orc = un * rec_step;
-      unsigned og_xs = u_xs + (un + 1u) * sg_xs, og_xds = u_xds + (un + 1u) * sg_xds, og_om = u_om + (un + 1u) * sg_om;
-      unsigned og_r = u_r + (un + 1u) * sg_r, og_fs = u_fs + (un + 1u) * sg_fs, og_ff = u_ff + (un + 1u) * sg_ff;
-      int ti = max(n, 0);                        // index of the lower time stamp of the requested step
+      // (the row a step PRODUCES: default integrator row m + 1, dynamics() row m)
+      constexpr unsigned kUp = ODE ? 1u : 0u;
+      unsigned og_xs = u_xs + (un + kUp) * sg_xs, og_xds = u_xds + (un + kUp) * sg_xds, og_om = u_om + (un + kUp) * sg_om;
+      unsigned og_r = u_r + (un + kUp) * sg_r, og_fs = u_fs + (un + kUp) * sg_fs, og_ff = u_ff + (un + kUp) * sg_ff;
+      int ti = max(n, 0);                        // the requested step (default integrator: index of its lower time stamp)
       auto request_state = [&](StateIn& d, Saved& v) {      // rows + record of the step the offsets point at
         d.x = zero;                                            // (positions are not needed: the record replaces what used them)
 #ifdef MF_STREAM_NO_FETCH    // A/B build: no loads at all -- times the rebuild + ring writes + the computing wave
@@ -538,10 +540,24 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
         d.t1 = 0.01f; d.t0 = zero; v.q = f4v{100.3f, 0.2f, 0.1f, 50.0f};
         return;
 #endif
-        d.xd = bload1(rXds, o3, 0u); d.w = bload1(rOm, o3, 0u);
-        bload3(rRs, o9, 0u, &d.R0, &d.R1, &d.R2);
+        if constexpr (ODE) {
+          d.xd = bload1(rXds, o3, 0u); d.w = bload1(rOm, o3, 0u);
+          bload3(rRs, o9, 0u, &d.R0, &d.R1, &d.R2);
+          d.t1 = a.ts[ti + 1]; d.t0 = a.ts[ti];             // (every fetched step is a real one: 0 <= ti <= T - 2)
+        } else {
+          // dynamics(): step m starts from output row m - 1 (step 0: from the initial state, held in registers) and ends in row m,
+          // whose angular velocity is the w' of its Rodrigues step -- loaded, not recomputed
+          const bool init = ti == 0;                          // wave-uniform
+          const unsigned p3 = init ? o3 : o3 - s3, p9 = init ? o9 : o9 - s9;
+          const float xd = bload1(rXds, p3, 0u), w = bload1(rOm, p3, 0u);
+          float R0, R1, R2;
+          bload3(rRs, p9, 0u, &R0, &R1, &R2);
+          d.xd = init ? ini.xd : xd; d.w = init ? ini.w : w;
+          d.R0 = init ? ini.R0 : R0; d.R1 = init ? ini.R1 : R1; d.R2 = init ? ini.R2 : R2;
+          d.x = bload1(rOm, o3, 0u);                          // (the unused position slot carries w' of row m)
+          d.t1 = a.dt; d.t0 = zero;
+        }
         bload2(rCtrl, oc, 0u, &d.cv, &d.cw);
-        d.t1 = a.ts[ti + 1]; d.t0 = a.ts[ti];               // (every fetched step is a real one: 0 <= ti <= T - 2)
         v.q = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(prec + (size_t)orc));
       };
       auto request_up = [&](UpIn& u) {                       // upstream gradients of the row that step produced
@@ -561,7 +577,7 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
         og_xs -= sg_xs;
         if constexpr (!XS_ONLY) { og_xds -= sg_xds; og_om -= sg_om; og_r -= sg_r; og_fs -= sg_fs; og_ff -= sg_ff; }
       };
-      constexpr int kSlots = SLOTS, kPlanes = XS_ONLY ? 10 : 12;
+      constexpr int kSlots = SLOTS, kPlanesD = ODE ? 0 : 6, kPlanes = (XS_ONLY ? 10 : 12) + kPlanesD;      // dynamics(): six more (struct CoefD)
       constexpr bool kPow2 = (kSlots & (kSlots - 1)) == 0;
       __shared__ f4v ring[kSlots * kPlanes * 64];
       __shared__ int flags[2];
@@ -586,14 +602,14 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
         auto fetch = [&](Slot& r) {                 // everything of step m; then the offsets move to step m - 1
           request_state(r.st, r.sv);                // (past step 0 the offsets wrap around; nothing reads them again)
           request_up(r.up);
-          // The stamp of output row ti + 1 (the row this step produced) and its weight -- UNCONDITIONAL vector loads of a wave-uniform
+          // The stamp of the output row this step produced (ti + kUp) and its weight -- UNCONDITIONAL vector loads of a wave-uniform
           // address: without a fused loss they read a dummy table (the time grid) and the result is never used.  Unconditional,
           // because loads inside a branch leave the wait-count pass unable to tell how many are in flight behind the step's other
           // requests (it then waits for everything: 0.21 -> 0.27 ms); vector, because scalar loads would be consumed at once (two
           // dependent round trips in front of the step's other requests).  The ground truth they address is requested a stage
           // later, with the cell gathers.
-          r.sj = ld32(l_row_stamp, (unsigned)(ti + 1) + zero_lane);
-          r.lw = ld32(l_row_w, (unsigned)(ti + 1) + zero_lane);            // 0 where the row carries no stamp -> gradient 0
+          r.sj = ld32(l_row_stamp, (unsigned)ti + kUp + zero_lane);
+          r.lw = ld32(l_row_w, (unsigned)ti + kUp + zero_lane);            // 0 where the row carries no stamp -> gradient 0
           r.lg = zero;
           o3 -= s3; o9 -= s9; oc -= 8u; orc -= rec_step; --ti;
           step_back_up();
@@ -647,12 +663,42 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
             // (fused physics loss: the row's gXs slot holds Xs itself; dL/dXs from it, the stamp's ground truth and weight)
             const float gXs_row = loss_on ? cp_loss_grad(loss_scale, r.up.gXs, r.lg, r.lw) : r.up.gXs;
             const f4v p9 = f4v{k.e, k.il, cmask * k.e * k.il, first * gXs_row};
+            // dynamics(): everything of the Rodrigues step R' = R M(w'), M = I + K sin(th h) + K^2 (1 - cos(th h)), K = [kv]x,
+            // kv = w' / max(|w'|, eps), that does not depend on the adjoint -- from w' as the forward left it in row m
+            f4v d0 = {zero, zero, zero, zero}, d1 = d0, d2 = d0, d3 = d0, d4 = d0, d5 = d0;
+            if constexpr (!ODE) {
+              const float h = a.dt, wn = r.st.x;
+              const float th2 = dot3(wn, wn);
+              const float idn = M::inv_len(th2);                    // 1 / max(th, 1e-6)
+              const float kv = wn * idn;
+              const float th = M::sqrt(th2);
+              float sn_, oc;
+              M::sincos_small(th * h, &sn_, &oc);
+              const float kk = dot3(kv, kv);
+              const float kv1 = dpp<kRot1>(kv), kv2 = dpp<kRot2>(kv);
+              const float ok = oc * kv;
+              const float m0 = fmaf(ok, kv, fmaf(-oc, kk, one)), m1 = fmaf(ok, kv1, -(sn_ * kv2)), m2 = fmaf(ok, kv2, sn_ * kv1);   // M[c][c], M[c][c+1], M[c][c+2]
+              const float q0 = dpp<kB0>(kv), q1 = dpp<kB1>(kv), q2 = dpp<kB2>(kv);
+              const float Rk = k.R0 * q0 + k.R1 * q1 + k.R2 * q2;
+              const float idn2 = th2 >= 1e-12f ? idn * idn : zero;      // through max(th, eps) only when th >= eps
+              const float ith = th2 > zero ? M::div(one, th) : zero;    // d|w'|/dw' = w' / |w'|, 0 at 0
+              d0 = f4v{wn, kv, q0, q1};
+              d1 = f4v{q2, Rk, kk, sn_};
+              d2 = f4v{oc, h * (one - oc), h * sn_, idn};
+              d3 = f4v{idn2, ith, dpp<kB0>(m0), dpp<kB0>(m1)};          // M[0][0], M[0][1]
+              d4 = f4v{dpp<kB0>(m2), dpp<kB1>(m2), dpp<kB1>(m0), dpp<kB1>(m1)};      // M[0][2], M[1][0], M[1][1], M[1][2]
+              d5 = f4v{dpp<kB2>(m1), dpp<kB2>(m2), dpp<kB2>(m0), zero};  // M[2][0], M[2][1], M[2][2]
+            }
             room(o + 1);
             f4v* out = ring + slot * (unsigned)(kPlanes * 64) + lane;
             out[0] = p0; out[64] = p1; out[128] = p2; out[192] = p3; out[256] = p4; out[320] = p5; out[384] = p6; out[448] = p7; out[512] = p8; out[576] = p9;
             if constexpr (!XS_ONLY) {
               out[640] = f4v{first * r.up.gXds, first * r.up.gOm, r.up.gFs, r.up.gFf};
               out[704] = f4v{first * r.up.gR0, first * r.up.gR1, first * r.up.gR2, zero};
+            }
+            if constexpr (!ODE) {
+              constexpr int D0 = (XS_ONLY ? 10 : 12) * 64;
+              out[D0] = d0; out[D0 + 64] = d1; out[D0 + 128] = d2; out[D0 + 192] = d3; out[D0 + 256] = d4; out[D0 + 320] = d5;
             }
             publish(o, o + 1);
           };
@@ -719,6 +765,9 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
           float vp, inlr, wq, zc, mcv, wsb, wsa;      // -(1 / |u|) / res; d wq / d(fx, fy) / res
           float e, il, eci;                     // gate_col0 e / |col0|
           int idx;
+          // dynamics() only (struct "CoefD", six more planes): the adjoint-independent half of the Rodrigues step's backward
+          float wn, kv, q0, q1, q2, Rk, kk, sn_, oc, cga, cgb, idn, idn2, ith;      // cga = h (1 - cos), cgb = h sin
+          float M00, M01, M02, M10, M11, M12, M20, M21, M22;                      // M[m][j], every lane holds all nine
         };
         // (the loop asks for the two steps of a trip at once, and reports them read at once: the counters cost an LDS
         //  instruction each, ~14 cycles of this wave)
@@ -751,6 +800,17 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
             const float* g1 = reinterpret_cast<const float*>(o + 704);      // (three floats: an unused fourth would be a free register to the allocator)
             up.gXds = g0.x; up.gOm = g0.y; up.gFs = g0.z; up.gFf = g0.w; up.gR0 = g1[0]; up.gR1 = g1[1]; up.gR2 = g1[2];
           }
+          if constexpr (!ODE) {
+            constexpr int D0 = (XS_ONLY ? 10 : 12) * 64;
+            const f4v e0 = o[D0], e1 = o[D0 + 64], e2 = o[D0 + 128], e3 = o[D0 + 192], e4 = o[D0 + 256];
+            const float* e5 = reinterpret_cast<const float*>(o + D0 + 320);
+            c.wn = e0.x; c.kv = e0.y; c.q0 = e0.z; c.q1 = e0.w;
+            c.q2 = e1.x; c.Rk = e1.y; c.kk = e1.z; c.sn_ = e1.w;
+            c.oc = e2.x; c.cga = e2.y; c.cgb = e2.z; c.idn = e2.w;
+            c.idn2 = e3.x; c.ith = e3.y; c.M00 = e3.z; c.M01 = e3.w;
+            c.M02 = e4.x; c.M10 = e4.y; c.M11 = e4.z; c.M12 = e4.w;
+            c.M20 = e5[0]; c.M21 = e5[1]; c.M22 = e5[2];
+          }
           ++consumed;
         };
         auto release = [&]() {                        // the steps grabbed so far may be overwritten
@@ -762,13 +822,14 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
         // The chain of `vjp` (default integrator) on those coefficients.
         auto chain = [&](int n, const Coef& c, const UpIn& up) {
           const float h = c.h;
-          float gFr_up = zero, gFf_up = zero;
+          float gFr_up = zero, gFf_up = zero, gxdd, gwd;
+          if constexpr (ODE) {
           if constexpr (!XS_ONLY) {
             laFs += act ? up.gFs : zero;
             laFf += act ? up.gFf : zero;
             gFr_up = h * laFs; gFf_up = h * laFf;
           }
-          const float gxdd = h * sum_points(lxd), gwd = h * sum_points(lw);
+          gxdd = h * sum_points(lxd); gwd = h * sum_points(lw);
           lxd = fmaf(h, lx, lxd);
           const float g0 = h * lR0, g1 = h * lR1, g2 = h * lR2;
           const float g01 = dpp<kRot1>(g0), g02 = dpp<kRot2>(g0), g11 = dpp<kRot1>(g1), g12 = dpp<kRot2>(g1), g21 = dpp<kRot1>(g2), g22 = dpp<kRot2>(g2);
@@ -776,6 +837,32 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
           lR0 += g01 * c.w2 - g02 * c.w1;
           lR1 += g11 * c.w2 - g12 * c.w1;
           lR2 += g21 * c.w2 - g22 * c.w1;
+          } else {
+            // dynamics(): the adjoint of  xd' = xd + xdd h, x' = x + xd' h, w' = w + wd h, R' = R M(w')  on the fetching waves'
+            // coefficients (the derivation: `vjp` above); the forces of this step are outputs themselves
+            if constexpr (!XS_ONLY) { gFr_up = act ? up.gFs : zero; gFf_up = act ? up.gFf : zero; }
+            const float Lk = lR0 * c.q0 + lR1 * c.q1 + lR2 * c.q2;
+            const float Gk0 = dot3(c.R0, Lk), Gk1 = dot3(c.R1, Lk), Gk2 = dot3(c.R2, Lk);
+            const float Gt0 = dot3(c.Rk, lR0), Gt1 = dot3(c.Rk, lR1), Gt2 = dot3(c.Rk, lR2);
+            const float trG = sum3(c.R0 * lR0 + c.R1 * lR1 + c.R2 * lR2);
+            const float a0 = sum3(c.R1 * lR2 - c.R2 * lR1), a1 = sum3(c.R2 * lR0 - c.R0 * lR2), a2 = sum3(c.R0 * lR1 - c.R1 * lR0);
+            const float ga = -(c.q0 * a0 + c.q1 * a1 + c.q2 * a2);
+            const float gb = (c.q0 * Gk0 + c.q1 * Gk1 + c.q2 * Gk2) - c.kk * trG;
+            float gth = ga * c.cga + gb * c.cgb;
+            const float ac = mask_or(mask_or(mask_or(zero, a0, lane0), a1, lane1), a2, lane2);
+            const float sc = mask_or(mask_or(mask_or(zero, Gk0 + Gt0, lane0), Gk1 + Gt1, lane1), Gk2 + Gt2, lane2);
+            const float gk = -(c.sn_ * ac) - c.oc * (2.0f * trG * c.kv - sc);
+            const float gkw = dot3(gk, c.wn);
+            gth = fmaf(-gkw, c.idn2, gth);
+            lw += fmaf(gth * c.ith, c.wn, gk * c.idn);
+            gwd = h * sum_points(lw);
+            lxd = fmaf(h, lx, lxd);
+            gxdd = h * sum_points(lxd);
+            const float n0 = lR0 * c.M00 + lR1 * c.M01 + lR2 * c.M02;      // lR <- lR M^T
+            const float n1 = lR0 * c.M10 + lR1 * c.M11 + lR2 * c.M12;
+            const float n2 = lR0 * c.M20 + lR1 * c.M21 + lR2 * c.M22;
+            lR0 = n0; lR1 = n1; lR2 = n2;
+          }
           // ---- RHS backward ----
           const float mwd = c.mw * gwd;
           const float gtau = J0 * dpp<kB0>(mwd) + J1 * dpp<kB1>(mwd) + J2 * dpp<kB2>(mwd);      // I^-T m
@@ -966,12 +1053,14 @@ bool cp_loss_fusable(const MfRolloutDesc* d);           // both directions of th
 int launch_rollout_bwd_cp_f32(const RolloutBwdArgs<float>& a, int integ, bool xs_only, hipStream_t st);   // a.gcontrols may be NULL
 int launch_rollout_bwd_cp_dynamics_f32(const RolloutBwdArgs<float>& a, bool xs_only, hipStream_t st);      // rollout_bwd_dyn_cp_fast.hip
 void launch_rollout_bwd_cp_stream_f32(const RolloutBwdArgs<float>& a, bool xs_only, unsigned grid, hipStream_t st);   // rollout_bwd_cp_stream_fast.hip
+void launch_rollout_bwd_cp_stream_dynamics_f32(const RolloutBwdArgs<float>& a, bool xs_only, unsigned grid, hipStream_t st);   // rollout_bwd_dyn_cp_stream_fast.hip
 
 // Largest grid (workgroups = waves of rollouts) the streaming form takes: its LDS ring allows two workgroups per CU with six slots
-// (2 x 72 KB of the CU's 160 KB), one with eight.  MF_CP_STREAM_MAX_GRID overrides (A/B runs).
-inline unsigned cp_stream_max_grid() {
+// (2 x 60 / 72 KB of the CU's 160 KB), one with twelve; dynamics() carries six more planes per slot (96 / 108 KB with six slots: one
+// workgroup per CU).  MF_CP_STREAM_MAX_GRID overrides the default integrator's limit (A/B runs).
+inline unsigned cp_stream_max_grid(int integ = MF_INTEG_ODEINT_EULER) {
   static const unsigned v = getenv("MF_CP_STREAM_MAX_GRID") ? (unsigned)atoi(getenv("MF_CP_STREAM_MAX_GRID")) : 512u;
-  return v;
+  return integ == MF_INTEG_ODEINT_EULER ? v : (v < 256u ? v : 256u);
 }
 
 // one launch of the variant (positions-only loss?, control gradient?, late recompute?) the arguments call for
@@ -983,11 +1072,10 @@ int launch_rollout_bwd_cp_variant(const RolloutBwdArgs<float>& a, bool xs_only, 
   static const int forced = getenv("MF_CP_BWD_MODE") ? atoi(getenv("MF_CP_BWD_MODE")) : -1;      // A/B (tools/ab_cp.py): 0 early, 1 late, 2 record read by one wave
   // the forward's record when there is one: a second wave per workgroup streams it through LDS (default integrator, while the
   // rings fit the CUs' LDS), else one wave reads it itself; without a record at most one wave per SIMD: late recompute
-  constexpr bool can_stream = INTEG == MF_INTEG_ODEINT_EULER;
-  const int saved_mode = can_stream && grid <= cp_stream_max_grid() && forced != kCpSaved ? kCpStream : kCpSaved;
+  const int saved_mode = grid <= cp_stream_max_grid(INTEG) && forced != kCpSaved ? kCpStream : kCpSaved;
   const int mode = a.rec ? saved_mode : (forced >= 0 && forced < kCpSaved ? forced : (grid <= 1024u ? kCpLate : kCpEarly));
 #define MF_BCP(XS_, GC_, M_) hipLaunchKernelGGL((rollout_bwd_cp_kernel<INTEG, XS_, GC_, M_>), dim3(grid), dim3(64), 0, st, a)
-#define MF_BCP_L(XS_, GC_) do { if (mode == kCpStream) launch_rollout_bwd_cp_stream_f32(a, xs_only, grid, st); else if (mode == kCpSaved) MF_BCP(XS_, GC_, kCpSaved); else if (mode == kCpLate) MF_BCP(XS_, GC_, kCpLate); else MF_BCP(XS_, GC_, kCpEarly); } while (0)
+#define MF_BCP_L(XS_, GC_) do { if (mode == kCpStream) { if (INTEG == MF_INTEG_ODEINT_EULER) launch_rollout_bwd_cp_stream_f32(a, xs_only, grid, st); else launch_rollout_bwd_cp_stream_dynamics_f32(a, xs_only, grid, st); } else if (mode == kCpSaved) MF_BCP(XS_, GC_, kCpSaved); else if (mode == kCpLate) MF_BCP(XS_, GC_, kCpLate); else MF_BCP(XS_, GC_, kCpEarly); } while (0)
   if (xs_only) { if (gc) MF_BCP_L(true, true); else MF_BCP_L(true, false); }
   else         { if (gc) MF_BCP_L(false, true); else MF_BCP_L(false, false); }
 #undef MF_BCP_L

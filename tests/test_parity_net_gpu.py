@@ -447,8 +447,8 @@ def _record_case(integ=1, B=37):
 
 
 # B = 37: one workgroup per CU (twelve-slot ring); 1500 rollouts = 375 workgroups: two per CU (six-slot ring); 3000 rollouts = 750
-# waves: beyond the streaming form, the record read by one wave.  dynamics() (integ 0) keeps no record by default (no streaming form
-# yet; read by one wave it loses to recomputing): MF_CP_RECORD_DYNAMICS=1 puts its record kernels through the same comparison.
+# waves: beyond the streaming form, the record read by one wave.  dynamics() (integ 0) streams up to 256 workgroups (B = 37) and keeps no
+# record beyond (read by one wave it loses to recomputing): MF_CP_RECORD_DYNAMICS=1 puts that kernel through the same comparison (1500).
 @pytest.mark.parametrize('integ,B', [(1, 37), (0, 37), (1, 1500), (1, 3000), (0, 1500)])
 def test_backward_from_the_forward_record_equals_the_recomputing_backward(integ, B):
     """Launches of up to one wave per SIMD keep a compact per-step record in the forward (MfRolloutFwdBufs.rec, 256 B per

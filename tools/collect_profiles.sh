@@ -28,16 +28,20 @@ names = {'rollout_fwd': 'rollout_fwd_kernel', 'rollout_bwd': 'rollout_bwd_kernel
          'lift_splat_bwd': 'lift_splat_bwd_kernel'}
 res = {}
 for w in ('c3f', 'c3', 'c4'):
-    per = {}
+    per, calls = {}, {}
     for c, mult in (('FETCH_SIZE', 2), ('WRITE_SIZE', 1)):
         try:
+            best = {}       # per kernel family: the template instantiation with the most dispatches (the timed steps', not the set-up rollout's)
             for line in open(f'{out}/{tag}_pmc_{c}_{w}.txt'):
-                m = re.match(r'(.*?) (\{.*\})\s*$', line)
+                m = re.match(r'(.*?) (\{.*?\})(?: dispatches (\d+))?\s*$', line)
                 if not m:
                     continue
                 key = next((v for k, v in names.items() if k in m.group(1)), None)
-                if key:
-                    per[key] = per.get(key, 0) + mult * ast.literal_eval(m.group(2))[c] * 1024
+                n = int(m.group(3) or 1)
+                if key and n > best.get(key, (0, 0))[0]:
+                    best[key] = (n, mult * ast.literal_eval(m.group(2))[c] * 1024)
+            for key, (n, val) in best.items():
+                per[key] = per.get(key, 0) + val
         except FileNotFoundError:
             pass
     if per:

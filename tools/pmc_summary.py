@@ -1,4 +1,4 @@
-"""Summarise a rocprofv3 --pmc counter_collection.csv: per-kernel mean of each counter over dispatches."""
+"""Summarise a rocprofv3 --pmc counter_collection.csv: per-kernel mean of each counter over dispatches (and the dispatch count)."""
 import collections
 import csv
 import sys
@@ -14,4 +14,4 @@ for r in rows:
     agg[k][r['Counter_Name']] += float(r['Counter_Value'])
     cnt[k][r['Counter_Name']] += 1
 for k, v in agg.items():
-    print(k, {a: round(b / cnt[k][a]) for a, b in v.items()})
+    print(k, {a: round(b / cnt[k][a]) for a, b in v.items()}, 'dispatches', max(cnt[k].values()))
