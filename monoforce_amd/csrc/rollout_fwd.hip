@@ -1,6 +1,6 @@
 // Forward rollout: host side of mf_rollout_fwd_* and the reference-order (exact) kernel instantiations.
 // This TU is compiled with -ffp-contract=off; the FMA-contracted float32 kernels live in rollout_fwd_fast.hip.
-#include "rollout_fwd_cp_kernel.h"
+#include "rollout_fwd_cp2_kernel.h"
 
 namespace mf {
 
@@ -146,6 +146,9 @@ extern "C" int mf_rollout_fwd_f32(const MfRolloutDesc* d, const MfRolloutFwdBufs
         a.loss_partial = (float*)L->partial; a.loss_ticket = L->ticket; a.loss_out = (float*)L->loss;
         a.loss_inv_count = (float)(1.0 / ((double)d->B * L->T2 * 3));
       }
+#ifdef MF_EXPERIMENTS
+      if (!p->loss && mf::use_two_wave_forward(d)) return mf::launch_rollout_fwd_cp2_f32(a, forces, zmu, (hipStream_t)s);
+#endif
       return mf::launch_rollout_fwd_cp_f32(a, d->integrator, forces, zmu, (hipStream_t)s);
     }
     MF_REQUIRE(!p->loss, MF_ERR_UNSUPPORTED, "rollout_fwd: this launch cannot carry the fused physics loss (mf_rollout_loss_fusable)");
