@@ -109,6 +109,13 @@ struct GroupSum {
   }
   template <int K>
   __device__ __forceinline__ void sum_n(S (&v)[K]) {
+    post<K>(v);
+    wait<K>(v);
+  }
+  // The two halves of sum_n for callers with work to put between them (multi-wave groups: under the LDS write and ahead of the
+  // barrier): post = every wave's own total, written to its LDS row; wait = the barrier and the sum over the rows, fixed order.
+  template <int K>
+  __device__ __forceinline__ void post(S (&v)[K]) {
     static_assert(K <= kGroupSumMaxValues, "raise kGroupSumMaxValues");
 #pragma unroll
     for (int k = 0; k < K; ++k) v[k] = group_sum<(G <= 64 ? G : 64)>(v[k]);
@@ -119,15 +126,37 @@ struct GroupSum {
     // would change which multiply-add pairs around a call get contracted, i.e. the bits of the trajectory)
 #pragma unroll
     for (int k = 0; k < K; ++k) slot[wave * kGroupSumMaxValues + k] = v[k];
+  }
+  template <int K>
+  __device__ __forceinline__ void wait(S (&v)[K]) {
+    if (G <= 64) return;
+    S t[K * NW];
+    fetch<K>(t);
+    fold<K>(t, v);
+  }
+  // ... and wait = fetch (the barrier and the reads of every wave's row) + fold (their sum), for callers that also have work to put
+  // under the reads
+  template <int K>
+  __device__ __forceinline__ void fetch(S (&t)[K * NW]) {
+    if (G <= 64) return;
+    S* slot = lds + par * (NW * kGroupSumMaxValues);
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      S t = slot[k];
+    for (int k = 0; k < K; ++k)
 #pragma unroll
-      for (int w = 1; w < NW; ++w) t += slot[w * kGroupSumMaxValues + k];
-      v[k] = t;
-    }
+      for (int w = 0; w < NW; ++w) t[k * NW + w] = slot[w * kGroupSumMaxValues + k];
     par ^= 1u;
+  }
+  template <int K>
+  __device__ __forceinline__ void fold(const S (&t)[K * NW], S (&v)[K]) {
+    if (G <= 64) return;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      S acc = t[k * NW];
+#pragma unroll
+      for (int w = 1; w < NW; ++w) acc += t[k * NW + w];
+      v[k] = acc;
+    }
   }
 };
 

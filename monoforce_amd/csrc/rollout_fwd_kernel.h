@@ -461,6 +461,258 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
   // everything loaded so far is complete before the loop: otherwise the waits inside it also have to cover these loads, and a
   // conservative in-loop wait is a wait for the previous step's stores
   __builtin_amdgcn_s_waitcnt(0);
+  // PIPE: a rollout spread over several waves (G > 64), default integrator.  Its two group sums cost an LDS round trip and a
+  // barrier each, and one wave per SIMD has nothing to put under them -- unless the step is software-pipelined like the
+  // component-parallel kernels' (rollout_fwd_cp_kernel.h): the explicit scheme knows pose n + 1 when step n starts, so its
+  // body-frame arms go between the contact count's LDS write and its barrier, its footprints and the requests for their cells
+  // between the wrench's write and its barrier, and the cells have the rest of the step and the head of the next to arrive.
+  constexpr bool PIPE = FAST && G > 64 && PPL == 1 && INTEG == MF_INTEG_ODEINT_EULER && !JOINTS && COST == 0;
+  if constexpr (PIPE) {
+    // ---- the pieces of one step ----
+    // geometry of the contact points under the pose (x, R) and the gathers that depend only on it.  PIPE kernels request the cells
+    // (`request`) a step before they select the clamped corners out of them (`arrive`); the others do both at once.
+    struct Geo {
+      S r[PPL][3], pz[PPL];
+      Cell<S> cell[PPL];
+      S zc[PPL][4], mc[PPL][4];
+      CellQuad<S> q1, q2;          // PIPE: the loads as they were requested (ZMU: (z, mu) x 2 cells; else q1 = z pairs, q2 = mu pairs)
+    };
+    auto locate_points = [&](Geo& g) {
+  #pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        // p = P R^T + x ; r = p - x   (:200)
+        S px = P[j][0] * R[0] + P[j][1] * R[1] + P[j][2] * R[2] + x[0];
+        S py = P[j][0] * R[3] + P[j][1] * R[4] + P[j][2] * R[5] + x[1];
+        g.pz[j] = P[j][0] * R[6] + P[j][1] * R[7] + P[j][2] * R[8] + x[2];
+        g.r[j][0] = px - x[0]; g.r[j][1] = py - x[1]; g.r[j][2] = g.pz[j] - x[2];
+        g.cell[j] = locate_m<S, FAST>(px, py, a.d_max, a.res, a.inv_res, a.H, last);
+      }
+    };
+    auto geometry = [&](Geo& g) {
+      locate_points(g);
+  #pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        const Cell<S>& c = g.cell[j];
+        if constexpr (ZMU) gather4x2(a.zmu, c, last, g.zc[j], g.mc[j]);
+        else gather4(zmap, moff, c, last, g.zc[j]);
+      }
+  #pragma unroll
+      for (int j = 0; j < PPL; ++j) {   // unconditional (mumap aliases z without a friction map; selected after the blend): no branch
+        const Cell<S>& c = g.cell[j];
+        if constexpr (!ZMU) gather4(mumap, moff, c, last, g.mc[j]);
+      }
+    };
+    // kinematics that need no gathered cell: point velocities, thrust direction, track speeds
+    struct Kin { S vp[PPL][3], e0, e1, e2, tv_lo, tv_hi; };
+    auto kinematics = [&](const Geo& g, Kin& k) {
+  #pragma unroll
+      for (int j = 0; j < PPL; ++j) {  // v_p = xd + w x r   (:204)
+        k.vp[j][0] = xd[0] + (w[1] * g.r[j][2] - w[2] * g.r[j][1]);
+        k.vp[j][1] = xd[1] + (w[2] * g.r[j][0] - w[0] * g.r[j][2]);
+        k.vp[j][2] = xd[2] + (w[0] * g.r[j][1] - w[1] * g.r[j][0]);
+      }
+      // thrust direction = normalized first column of R   (:237)
+      const S il = M::inv_len(R[0] * R[0] + R[3] * R[3] + R[6] * R[6]);
+      if (M::kReciprocalNorm) { k.e0 = R[0] * il; k.e1 = R[3] * il; k.e2 = R[6] * il; }
+      else { const S el = mf_max(M::sqrt(R[0] * R[0] + R[3] * R[3] + R[6] * R[6]), (S)1e-6); k.e0 = R[0] / el; k.e1 = R[3] / el; k.e2 = R[6] / el; }
+      k.tv_lo = cv - cw * a.half_ly; k.tv_hi = cv + cw * a.half_ly;  // (:75-104)
+    };
+    // The explicit scheme moves x with the OLD xd and R with the OLD w: neither depends on this step's forces.
+    auto advance_pose = [&](S h) {
+      S dR[9];
+  #pragma unroll
+      for (int j2 = 0; j2 < 3; ++j2) {
+        dR[0 * 3 + j2] = w[1] * R[2 * 3 + j2] - w[2] * R[1 * 3 + j2];
+        dR[1 * 3 + j2] = w[2] * R[0 * 3 + j2] - w[0] * R[2 * 3 + j2];
+        dR[2 * 3 + j2] = w[0] * R[1 * 3 + j2] - w[1] * R[0 * 3 + j2];
+      }
+  #pragma unroll
+      for (int c = 0; c < 3; ++c) x[c] = x[c] + h * xd[c];
+  #pragma unroll
+      for (int c = 0; c < 9; ++c) R[c] = R[c] + h * dR[c];
+    };
+    // contact model, up to the (per-lane partial of the) contact count
+    struct Con { S nrm[PPL][3], muq[PPL], cw8[PPL], Fr[PPL][3], Ff[PPL][3]; };
+    auto contact_normal = [&](const Geo& g, const Kin& k, Con& q) {
+      S csum = zero;
+  #pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+        const Cell<S>& c = g.cell[j];
+        S zq, mub;                                                 // height, normal, friction under the point (:211-216)
+        blend2(c, g.zc[j], g.mc[j], &zq, &mub);
+        // no friction map = a map of ones (dphysics.py:562): its blend is the (rounded) sum of the four weights, no loads involved
+        q.muq[j] = has_mu ? mub : blend_ones(c);
+        S gx = M::div(g.zc[j][1] - g.zc[j][0], a.res), gy = M::div(g.zc[j][2] - g.zc[j][0], a.res);
+        if (M::kReciprocalNorm) {
+          const S inl = M::inv_len(gx * gx + gy * gy + one);
+          q.nrm[j][0] = -gx * inl; q.nrm[j][1] = -gy * inl; q.nrm[j][2] = inl;
+        } else {
+          const S nl = mf_max(M::sqrt(gx * gx + gy * gy + one), (S)1e-6);
+          q.nrm[j][0] = -gx / nl; q.nrm[j][1] = -gy / nl; q.nrm[j][2] = one / nl;
+        }
+        S dh = g.pz[j] - zq;  // soft contact + spring-damper along the normal   (:220-230)
+        S cj = M::sigmoid_m10(dh);
+        cj = act[j] ? cj : zero;
+        q.cw8[j] = cj;
+        csum += cj;
+        S vn = k.vp[j][0] * q.nrm[j][0] + k.vp[j][1] * q.nrm[j][1] + k.vp[j][2] * q.nrm[j][2];
+        S A = a.k * dh + a.damp * vn;
+        q.Fr[j][0] = -(A * q.nrm[j][0]); q.Fr[j][1] = -(A * q.nrm[j][1]); q.Fr[j][2] = -(A * q.nrm[j][2]);
+      }
+      return csum;
+    };
+    // ... from the contact count to the (per-lane partials of the) wrench: wr = (sum F [or sum Fs, sum Ff], sum tau)
+    constexpr int kWr = FAST ? 6 : 9;
+    auto contact_wrench = [&](const Geo& g, const Kin& k, Con& q, S csum, S (&wr)[kWr]) {
+      const S inv_csum = FAST ? M::div(one, csum) : one;
+      S sFr[3] = {zero, zero, zero}, sFf[3] = {zero, zero, zero}, sTau[3] = {zero, zero, zero};
+  #pragma unroll
+      for (int j = 0; j < PPL; ++j) {
+  #pragma unroll
+        for (int c = 0; c < 3; ++c) {  // (:232-233)
+          S f = FAST ? q.Fr[j][c] * q.cw8[j] * inv_csum : q.Fr[j][c] * q.cw8[j] / csum;
+          q.Fr[j][c] = M::clamp(f, -a.mg, a.mg);
+        }
+        S Nn = M::sqrt(q.Fr[j][0] * q.Fr[j][0] + q.Fr[j][1] * q.Fr[j][1] + q.Fr[j][2] * q.Fr[j][2]);  // (:238)
+        S tv = (part[j] < 0) ? zero : ((part[j] & 1) ? k.tv_hi : k.tv_lo);
+        S s0 = q.muq[j] * (tv * k.e0 - k.vp[j][0]);  // slip (:247); cmd = 0 for non-driving points
+        S s1 = q.muq[j] * (tv * k.e1 - k.vp[j][1]);
+        S s2 = q.muq[j] * (tv * k.e2 - k.vp[j][2]);
+        S sn = s0 * q.nrm[j][0] + s1 * q.nrm[j][1] + s2 * q.nrm[j][2];
+        q.Ff[j][0] = M::clamp(Nn * (s0 - sn * q.nrm[j][0]), -a.mg, a.mg);  // (:248-251)
+        q.Ff[j][1] = M::clamp(Nn * (s1 - sn * q.nrm[j][1]), -a.mg, a.mg);
+        q.Ff[j][2] = M::clamp(Nn * (s2 - sn * q.nrm[j][2]), -a.mg, a.mg);
+        if (!act[j]) {
+  #pragma unroll
+          for (int c = 0; c < 3; ++c) q.Fr[j][c] = q.Ff[j][c] = zero;
+        }
+        S f0 = q.Fr[j][0] + q.Ff[j][0], f1 = q.Fr[j][1] + q.Ff[j][1], f2 = q.Fr[j][2] + q.Ff[j][2];
+        sTau[0] += g.r[j][1] * f2 - g.r[j][2] * f1;  // r x (Fs + Ff)   (:255)
+        sTau[1] += g.r[j][2] * f0 - g.r[j][0] * f2;
+        sTau[2] += g.r[j][0] * f1 - g.r[j][1] * f0;
+        if (FAST) { sFr[0] += f0; sFr[1] += f1; sFr[2] += f2; }
+        else {
+  #pragma unroll
+          for (int c = 0; c < 3; ++c) { sFr[c] += q.Fr[j][c]; sFf[c] += q.Ff[j][c]; }
+        }
+      }
+      if constexpr (FAST) {   // one batched reduction of the wrench (multi-wave groups: one LDS exchange)
+  #pragma unroll
+        for (int c = 0; c < 3; ++c) { wr[c] = sFr[c]; wr[3 + c] = sTau[c]; }
+      } else {                // exact mode keeps the reference's two separate force sums
+  #pragma unroll
+        for (int c = 0; c < 3; ++c) { wr[c] = sFr[c]; wr[3 + c] = sFf[c]; wr[6 + c] = sTau[c]; }
+      }
+    };
+    // ... and from the summed wrench to the accelerations: wd = clamp(I^-1 tau), xdd = (m g ghat + sum F) / m
+    auto accelerations = [&](const S (&wr)[kWr], S (&xdd)[3], S (&wd)[3]) {
+      const S* sTau = wr + (FAST ? 3 : 6);
+      // omega_d = clamp(I^-1 tau) (body-frame I with world-frame torque, as the reference)   (:256-257)
+  #pragma unroll
+      for (int c = 0; c < 3; ++c)
+        wd[c] = M::clamp(Iv[c * 3 + 0] * sTau[0] + Iv[c * 3 + 1] * sTau[1] + Iv[c * 3 + 2] * sTau[2],
+                         -a.omega_max, a.omega_max);
+      // xdd = (m g ghat + sum Fs + sum Ff) / m   (:264-266)
+      if (FAST) { xdd[0] = wr[0] * a.inv_mass; xdd[1] = wr[1] * a.inv_mass; xdd[2] = (wr[2] - a.mg) * a.inv_mass; }
+      else { xdd[0] = (wr[0] + wr[3]) / a.mass; xdd[1] = (wr[1] + wr[4]) / a.mass; xdd[2] = ((-a.mg + wr[2]) + wr[5]) / a.mass; }
+    };
+    // the force-dependent half of torchdiffeq's fixed-grid euler: y_{n+1} = y_n + (t_{n+1} - t_n) f(t_n, y_n), f = (xd, xdd, [w]x R, wd, Fs, Ff)
+    auto advance_velocities = [&](const Con& q, const S (&xdd)[3], const S (&wd)[3], S h) {
+  #pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        xd[c] = xd[c] + h * xdd[c];
+        w[c] = w[c] + h * wd[c];
+      }
+  #pragma unroll
+      for (int j = 0; j < PPL; ++j)
+  #pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          oFs[j][c] = oFs[j][c] + h * q.Fr[j][c];
+          oFf[j][c] = oFf[j][c] + h * q.Ff[j][c];
+        }
+    };
+
+    auto request = [&](Geo& g) {      // the footprint's cells as they lie in memory; no dependent instruction here
+      const Cell<S>& c = g.cell[0];
+      const int p1 = min(c.ic, last - 1), p2 = min(c.i_f, last - 1);
+      if constexpr (ZMU) {
+        g.q1 = *reinterpret_cast<const CellQuad<S>*>(reinterpret_cast<const char*>(a.zmu) + (size_t)((unsigned)p1 * (unsigned)(2 * sizeof(S))));
+        g.q2 = *reinterpret_cast<const CellQuad<S>*>(reinterpret_cast<const char*>(a.zmu) + (size_t)((unsigned)p2 * (unsigned)(2 * sizeof(S))));
+      } else {
+        const CellPair<S> z1 = *reinterpret_cast<const CellPair<S>*>(reinterpret_cast<const char*>(zmap) + (size_t)((moff + (unsigned)p1) * (unsigned)sizeof(S)));
+        const CellPair<S> z2 = *reinterpret_cast<const CellPair<S>*>(reinterpret_cast<const char*>(zmap) + (size_t)((moff + (unsigned)p2) * (unsigned)sizeof(S)));
+        const CellPair<S> m1 = *reinterpret_cast<const CellPair<S>*>(reinterpret_cast<const char*>(mumap) + (size_t)((moff + (unsigned)p1) * (unsigned)sizeof(S)));
+        const CellPair<S> m2 = *reinterpret_cast<const CellPair<S>*>(reinterpret_cast<const char*>(mumap) + (size_t)((moff + (unsigned)p2) * (unsigned)sizeof(S)));
+        g.q1 = CellQuad<S>{z1.a, z1.b, z2.a, z2.b};      // (za, ma, zb, mb) reused as (z1.a, z1.b, z2.a, z2.b)
+        g.q2 = CellQuad<S>{m1.a, m1.b, m2.a, m2.b};
+      }
+    };
+    auto arrive = [&](Geo& g) {       // gather4 / gather4x2's choice among the loaded cells (the reference clamps the FLAT index)
+      const Cell<S>& c = g.cell[0];
+      const int p1 = min(c.ic, last - 1), p2 = min(c.i_f, last - 1);
+      const bool ec = c.ic != p1, el = c.il != p1, ef = c.i_f != p2, efl = c.ifl != p2;
+      if constexpr (ZMU) {
+        g.zc[0][0] = ec ? g.q1.zb : g.q1.za;   g.mc[0][0] = ec ? g.q1.mb : g.q1.ma;
+        g.zc[0][2] = el ? g.q1.zb : g.q1.za;   g.mc[0][2] = el ? g.q1.mb : g.q1.ma;
+        g.zc[0][1] = ef ? g.q2.zb : g.q2.za;   g.mc[0][1] = ef ? g.q2.mb : g.q2.ma;
+        g.zc[0][3] = efl ? g.q2.zb : g.q2.za;  g.mc[0][3] = efl ? g.q2.mb : g.q2.ma;
+      } else {
+        g.zc[0][0] = ec ? g.q1.ma : g.q1.za;   g.mc[0][0] = ec ? g.q2.ma : g.q2.za;
+        g.zc[0][2] = el ? g.q1.ma : g.q1.za;   g.mc[0][2] = el ? g.q2.ma : g.q2.za;
+        g.zc[0][1] = ef ? g.q1.mb : g.q1.zb;   g.mc[0][1] = ef ? g.q2.mb : g.q2.zb;
+        g.zc[0][3] = efl ? g.q1.mb : g.q1.zb;  g.mc[0][3] = efl ? g.q2.mb : g.q2.zb;
+      }
+    };
+    const S* ts_pair = a.ts;
+    auto pipe_step = [&](int n, Geo& g, Geo& g_next) {
+      // next step's controls and step size: requested before this step's stores (vmcnt retires in order)
+      const int nn = min(n + 1, a.T - 1);
+      const S cv_next = ctrl[nn * a.ctrl_st + 0], cw_next = ctrl[nn * a.ctrl_st + 1];
+      const int tp = max(min(n + 1, a.T - 2), 0);
+      const S ts_a = ts_pair[tp], ts_b = ts_pair[tp + 1];
+      emit_row(row_stride);                       // row n: the state as it stands
+      Kin k;
+      kinematics(g, k);
+      arrive(g);                                  // cells requested a step ago
+      Con q;
+      S csum = contact_normal(g, k, q);
+      // (The empty asm statements pin the independent work into its slot: arithmetic has no position of its own in the compiler's
+      //  eyes, and the scheduler otherwise issues it ahead of the LDS write it is meant to follow.  `after_memory` makes a value
+      //  depend on everything stored / loaded so far; `after_value` makes one depend on another.)
+      auto after_memory = [](S& v) { asm volatile("" : "+v"(v) :: "memory"); };
+      auto after_value = [](S& v, int dep) { asm volatile("" : "+v"(v) : "v"(dep)); };
+      constexpr int NWv = G / 64;
+      S cs1[1] = {csum};
+      gs.template post<1>(cs1);
+      S h_pose = h_ode;
+      after_memory(h_pose);
+      advance_pose(h_pose);                       // ---- under the contact count's LDS write: pose n + 1
+      after_memory(x[0]); after_memory(R[0]); after_memory(R[4]); after_memory(R[8]);
+      S t1[NWv];
+      gs.template fetch<1>(t1);
+      after_memory(x[1]);
+      locate_points(g_next);                      // ---- under its reads: the arms and footprints of pose n + 1
+      after_value(t1[0], g_next.cell[0].ic);
+      gs.template fold<1>(t1, cs1);
+      S wr[kWr];
+      contact_wrench(g, k, q, cs1[0], wr);
+      gs.template post<kWr>(wr);
+      asm volatile("" : "+v"(g_next.cell[0].ic) :: "memory");
+      request(g_next);                            // ---- under the wrench's LDS write: the cells of step n + 1
+      gs.template wait<kWr>(wr);
+      S xdd[3], wd[3];
+      accelerations(wr, xdd, wd);
+      advance_velocities(q, xdd, wd, h_ode);
+      cv = cv_next; cw = cw_next;
+      h_ode = ts_b - ts_a;
+    };
+    Geo gA, gB;
+    if (n_steps > 0) { locate_points(gA); request(gA); }
+    __builtin_amdgcn_s_waitcnt(0);
+    int n = 0;
+    for (; n + 1 < n_steps; n += 2) { pipe_step(n, gA, gB); pipe_step(n + 1, gB, gA); }
+    if (n < n_steps) pipe_step(n, gA, gB);
+  } else {
   for (int n = 0; n < n_steps; ++n) {
     if (JOINTS) articulate_body<S, G, PPL, FAST>(gs, a.joint_angles + ((size_t)b * a.T + n) * 4, a.joint_xyz, a.mass / (S)a.N, P0, part, act, P, Iv);
     // ---- geometry of the contact points and the gathers that depend only on it ----
@@ -680,6 +932,7 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
       pXs += due ? row_stride * 3 : 0; pRs += due ? row_stride * 9 : 0;
       pose_wait = due ? a.pose_stride - 1 : pose_wait - 1;
     }
+  }
   }
   if (n_steps > 0 || INTEG == MF_INTEG_ODEINT_EULER) emit_row(row_stride);
   // the force path cost itself: norm(F_springs).std(points).std(time) (monoforce_node.py:91), unbiased like torch.std
