@@ -141,6 +141,41 @@ def test_point_counts_vs_oracle_f64(N, n_tracks, ppl):
             assert hp.rel_err(o, r) <= 1e-9, (N, integ, k, hp.rel_err(o, r))
 
 
+@pytest.mark.parametrize('N,n_tracks', [(100, 4), (175, 2), (223, 4), (300, 2)])
+@pytest.mark.parametrize('integ', [0, 1])
+def test_large_bodies_fast_f32_multi_wave_kernels(N, n_tracks, integ):
+    """The float32 fast-math kernels that spread ONE rollout over several waves (G = 128 / 256 / 512 lanes, one point per lane -- the
+    mapping the reference's own robots, 175 / 223 points, run on at small batches; the default integrator's are software-pipelined
+    around their two LDS exchanges, rollout_fwd_kernel.h PIPE): against the float64 oracle on the same inputs, against the
+    one-wave mapping with 2 / 4 / 8 points per lane (another kernel: sums in another order, no pipelining), with forces and states only."""
+    from monoforce_amd import synthetic as syn
+    from oracle import dphysics_oracle as orc
+    pts, masks = syn.robot_points_box(N, seed=N, n_tracks=n_tracks)
+    B, T = 5, 60
+    z64 = torch.stack([syn.bump_terrain(syn.bump_params(40 + b), 3.2, 0.1, torch.float64) * 0.3 for b in range(B)])
+    mu64 = torch.stack([syn.wave_friction(3.2, 0.1, 0.5, 1.0, 1.0 + b, 0.8, torch.float64) for b in range(B)])
+    ctrl64 = syn.varying_controls(B, T, seed=N, dtype=torch.float64)
+    spec = hp.spec_from(pts, masks, integ, 0.1, 3.2)
+    with torch.no_grad():
+        st, fo = orc.rollout(spec, z64, ctrl64, friction=mu64)
+    ref = list(st) + list(fo)
+    z, mu, ctrl = z64.float(), mu64.float(), ctrl64.float()
+    wide, _ = run_hip(make_dphysics(pts, masks, integ, 0.1, 3.2), z, ctrl, None, mu)                       # auto: G > 64 at this batch size
+    narrow, _ = run_hip(make_dphysics(pts, masks, integ, 0.1, 3.2, points_per_lane=4), z, ctrl, None, mu)   # one wave, several points per lane
+    for k, a, b, r in zip(hp.OUT_KEYS, wide, narrow, ref):
+        # float32 vs float64 over 60 steps of a stiff contact model; dynamics() reports the step's own forces (not impulses summed
+        # over the horizon), which carry the state's rounding through the stiffness
+        tol = (1e-2 if integ == 0 else 2e-3) if k in ('Fs', 'Ff') else 2e-4
+        assert hp.rel_err(a, r.float()) <= tol, (N, integ, k, 'vs oracle', hp.rel_err(a, r.float()))
+        assert hp.rel_err(a, b) <= 5e-5, (N, integ, k, 'vs one-wave mapping', hp.rel_err(a, b))
+    dp = make_dphysics(pts, masks, integ, 0.1, 3.2)
+    dp.return_forces = False                                                                              # the states-only kernels
+    lean, forces = dp(z_grid=z.to(DEV), controls=ctrl.to(DEV), friction=mu.to(DEV))
+    assert forces == (None, None)
+    for k, a, b in zip(hp.OUT_KEYS[:4], lean, wide[:4]):
+        assert torch.equal(a.cpu(), b), (N, integ, k)
+
+
 def _c2_inputs(B, T=500, dtype=torch.float32):
     from monoforce_amd import synthetic as syn
     pts, masks = syn.robot_points_4()
