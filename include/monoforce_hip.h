@@ -119,18 +119,24 @@ typedef struct MfRolloutDesc {
  * [T][B][3] gradient tensor -- a train step loses two launches and 6 MB of rows.  Float32, component-parallel kernels with the
  * streaming backward only: ask mf_rollout_loss_fusable(desc).  The ground-truth stamps must be the SAME for every rollout
  * (near / w / row_stamp are per stamp, not per rollout) and `near` strictly increasing. */
+/* MfRolloutLoss.flags.  MF_LOSS_VALUE_IN_BACKWARD: a caller that ALWAYS runs the backward after the forward (a train step) lets the
+ * backward form the loss VALUE as well -- its fetching waves hold Xs, the ground truth and the weight of every stamped row anyway and
+ * have issue slots to spare, the forward (one wave per SIMD, issue-bound) has none: the forward then only marks loss[0] as not yet
+ * known (NaN; needs `loss` alone), the backward fills it (needs partial, ticket, loss besides gloss / Xs / the tables).  One launch
+ * and ~10 us less per step than forming the value in a launch of its own. */
+#define MF_LOSS_VALUE_IN_BACKWARD 1
 typedef struct MfRolloutLoss {
   int32_t T2;               /* ground-truth stamps per rollout */
-  int32_t reserved;
+  int32_t flags;            /* 0, or MF_LOSS_VALUE_IN_BACKWARD */
   const void* gt;           /* S[B][T2][3] ground-truth positions */
   const int32_t* near;      /* int32[T2]: output row nearest in time to stamp j (losses.py:116), strictly increasing, < T */
   const void* w;            /* S[T2]: time weights 1 / (1 + gamma t_j) (losses.py:122) */
   const int32_t* row_stamp; /* int32[T]: stamp index j of output row t, -1 where the row carries none (the inverse of `near`) */
   const void* row_w;        /* S[T]: w[row_stamp[t]], 0 where the row carries no stamp (the kernels read the stamps through the two
                                row tables; near / w document them and serve mf_physics_loss_* callers) */
-  void* partial;            /* forward scratch: S[ceil(B / 4)] per-workgroup partial sums */
-  uint32_t* ticket;         /* forward: ONE zero-initialised counter; the launch leaves it zero again */
-  void* loss;               /* forward out: S[1], the mean over B x T2 x 3 */
+  void* partial;            /* scratch of the direction that forms the value: S[ceil(B / 4)] per-workgroup partial sums */
+  uint32_t* ticket;         /* the same direction: ONE zero-initialised counter; the launch leaves it zero again */
+  void* loss;               /* out: S[1], the mean over B x T2 x 3 (written by the forward, or by the backward: flags) */
   const void* gloss;        /* backward: S[1] upstream gradient of the loss (device scalar) */
   const void* Xs;           /* backward: the forward's Xs rows (shifted positions, layout of the launch) */
 } MfRolloutLoss;

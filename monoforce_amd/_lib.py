@@ -12,6 +12,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libmonoforce_hip.so')
 
 MF_INTEG_DYNAMICS, MF_INTEG_ODEINT_EULER = 0, 1
 MF_LAYOUT_BATCH_MAJOR, MF_LAYOUT_TIME_MAJOR = 0, 1
+MF_LOSS_VALUE_IN_BACKWARD = 1
 MF_MATH_EXACT, MF_MATH_FAST = 0, 1
 MF_LANES_COMPONENT = 16
 
@@ -26,7 +27,7 @@ class MfRolloutDesc(C.Structure):
 
 
 class MfRolloutLoss(C.Structure):
-    _fields_ = [('T2', C.c_int32), ('reserved', C.c_int32)] + [(n, C.c_void_p) for n in ('gt', 'near', 'w', 'row_stamp', 'row_w', 'partial', 'ticket', 'loss', 'gloss', 'Xs')]
+    _fields_ = [('T2', C.c_int32), ('flags', C.c_int32)] + [(n, C.c_void_p) for n in ('gt', 'near', 'w', 'row_stamp', 'row_w', 'partial', 'ticket', 'loss', 'gloss', 'Xs')]
 
 
 class MfRolloutFwdBufs(C.Structure):

@@ -40,6 +40,7 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
   a.gjoint = (S*)p->gjoint_angles;
   a.rec = nullptr;
   a.loss_T2 = 0; a.loss_gt = nullptr; a.loss_row_stamp = nullptr; a.loss_row_w = nullptr; a.loss_gloss = nullptr; a.loss_inv_count = (S)0;
+  a.loss_partial = nullptr; a.loss_ticket = nullptr; a.loss_out = nullptr;
   MF_REQUIRE(!p->gjoint_angles || p->joint_angles, MF_ERR_INVALID, "rollout_bwd: gjoint_angles without joint_angles");
   MF_REQUIRE(!d->has_joints == !p->joint_angles, MF_ERR_INVALID, "rollout_bwd: joint_angles must be given exactly when desc->has_joints is set");
   MF_REQUIRE(!p->joint_angles || d->n_tracks == 4, MF_ERR_INVALID, "rollout_bwd: joint angles need the 4 driving parts of robot 'marv'");
@@ -56,6 +57,10 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
     MF_REQUIRE(L->T2 > 0 && L->gt && L->row_stamp && L->row_w && L->gloss && L->Xs, MF_ERR_INVALID, "rollout_bwd: incomplete MfRolloutLoss");
     a.loss_T2 = L->T2; a.loss_gt = (const S*)L->gt; a.loss_row_stamp = L->row_stamp; a.loss_row_w = (const S*)L->row_w; a.loss_gloss = (const S*)L->gloss;
     a.loss_inv_count = (S)(1.0 / ((double)d->B * L->T2 * 3));
+    if (L->flags & MF_LOSS_VALUE_IN_BACKWARD) {      // the fetching waves also form the loss value
+      MF_REQUIRE(L->partial && L->ticket && L->loss, MF_ERR_INVALID, "rollout_bwd: MF_LOSS_VALUE_IN_BACKWARD needs MfRolloutLoss.partial / ticket / loss");
+      a.loss_partial = (S*)L->partial; a.loss_ticket = L->ticket; a.loss_out = (S*)L->loss;
+    }
   }
   const bool any_null = !p->gXs || !p->gXds || !p->gRs || !p->gOmegas || !p->gFs || !p->gFf;
   MF_REQUIRE(!any_null || p->zeros, MF_ERR_INVALID,

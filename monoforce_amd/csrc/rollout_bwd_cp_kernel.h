@@ -512,6 +512,7 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
     };
     // fused physics loss (MfRolloutLoss): a.gXs points at the forward's Xs rows, dL/dXs of a row is formed where it is consumed
     const bool loss_on = STREAM && a.loss_gt != nullptr;      // wave-uniform
+    const unsigned loss_mask = loss_on ? ~0u : 0u;
     const float loss_scale = loss_on ? 2.0f * a.loss_gloss[0] * a.loss_inv_count : zero;      // as csrc/physics_loss.hip: (2 gloss) / count
     const float* const loss_gt_lane = loss_on ? a.loss_gt + ((size_t)b * (size_t)a.loss_T2) * 3u + (unsigned)cc : a.z;
     const int* const l_row_stamp = loss_on ? a.loss_row_stamp : reinterpret_cast<const int*>(a.ts);      // dummies: T valid words
@@ -585,6 +586,45 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
       LdsCounter* vflags = (LdsCounter*)flags;
       if (threadIdx.x == 0) { flags[0] = 0; flags[1] = 0; }
       __syncthreads();
+      // MF_LOSS_VALUE_IN_BACKWARD: the loss VALUE as well.  The fetching waves add up the weighted squared errors of the stamped rows
+      // they convert into dL/dXs anyway (the computing wave row 0's); at the end one partial sum per workgroup in a fixed order, and the
+      // workgroup that takes the last ticket adds the partial sums in index order (as rollout_fwd_cp_kernel.h's LOSS kernels do).
+      const bool loss_val = loss_on && a.loss_out != nullptr;      // wave-uniform
+      __shared__ float l_part[3 * 16 + 64];
+      auto loss_value_finish = [&](float acc) {     // every wave of the workgroup, once
+        if (!loss_val) return;
+        const int wv = (int)(threadIdx.x >> 6);
+        if (lane < 16) l_part[wv * 16 + lane] = zero;             // (LDS executes a wave's operations in order)
+        if (p == 0 && q < 3) l_part[wv * 16 + (lane >> 4) * 4 + q] = acc;
+        __syncthreads();
+        if (wv != 0) return;
+        unsigned last_wg = 0u;
+        if (lane == 0) {
+          float tot = zero;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int v = 0; v < 3; ++v) tot += (l_part[v * 16 + r * 4 + 0] + l_part[v * 16 + r * 4 + 1]) + l_part[v * 16 + r * 4 + 2];
+          __builtin_nontemporal_store(tot, a.loss_partial + blockIdx.x);
+          __threadfence();
+          last_wg = atomicAdd(a.loss_ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+        }
+        last_wg = __builtin_amdgcn_readfirstlane(last_wg);
+        if (last_wg) {                                            // every workgroup has written its partial sum: the mean, in index order
+          __threadfence();
+          const int n_act = min(64, (a.B - (int)blockIdx.x * 4) * 16);      // live lanes of this (possibly trailing) workgroup: the first n_act
+          float tot = zero;
+          for (unsigned k2 = (unsigned)lane; k2 < gridDim.x; k2 += (unsigned)n_act) tot += __builtin_nontemporal_load(a.loss_partial + k2);
+          l_part[48 + lane] = tot;
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (one wave: its LDS operations execute in order)
+          if (lane == 0) {
+            float sum = zero;
+            for (int k2 = 0; k2 < n_act; ++k2) sum += l_part[48 + k2];
+            a.loss_out[0] = sum * a.loss_inv_count;
+            *a.loss_ticket = 0u;
+          }
+        }
+      };
       if (threadIdx.x >= 64) {
         // ---------------- the two fetching waves ----------------
         // The steps go out in batches of three; fetching wave k (0 / 1) takes every other batch -- one wave's instruction
@@ -599,6 +639,7 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
         asm("" : "+v"(zero_lane));                                                 // keeps the loads of the stamp tables VECTOR loads
         const int fk = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) - 1;      // (wave-uniform, and provably so: scalar branches)
         int m = n;                                  // m: the step the offsets point at
+        float l_acc = zero;                         // this wave's share of the loss value
         auto fetch = [&](Slot& r) {                 // everything of step m; then the offsets move to step m - 1
           request_state(r.st, r.sv);                // (past step 0 the offsets wrap around; nothing reads them again)
           request_up(r.up);
@@ -661,7 +702,10 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
             const f4v p7 = f4v{k.vp, -(k.inl * a.inv_res), k.wq, __builtin_bit_cast(float, k.idx)};
             const f4v p8 = f4v{k.zc, k.mcv, wa_s * k.wb * a.inv_res, wb_s * k.wa * a.inv_res};
             // (fused physics loss: the row's gXs slot holds Xs itself; dL/dXs from it, the stamp's ground truth and weight)
-            const float gXs_row = loss_on ? cp_loss_grad(loss_scale, r.up.gXs, r.lg, r.lw) : r.up.gXs;
+            // (a bitwise merge, not a select on `loss_on`: with the value's term next to it the compiler turned the select into a
+            //  branch around both -- nine exec-masked blocks per batch, 0.217 -> 0.229 ms)
+            const float gXs_row = bfi(loss_mask, cp_loss_grad(loss_scale, r.up.gXs, r.lg, r.lw), r.up.gXs);
+            l_acc += cp_loss_term(r.up.gXs, r.lg, r.lw);      // (the value: used with MF_LOSS_VALUE_IN_BACKWARD only)
             const f4v p9 = f4v{k.e, k.il, cmask * k.e * k.il, first * gXs_row};
             // dynamics(): everything of the Rodrigues step R' = R M(w'), M = I + K sin(th h) + K^2 (1 - cos(th h)), K = [kv]x,
             // kv = w' / max(|w'|, eps), that does not depend on the adjoint -- from w' as the forward left it in row m
@@ -746,6 +790,7 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
         }
         MF_PROF_ADD(2 + 4 * fk, t_fetcher);
         MF_PROF_OUT(0 + 4 * fk, acc_room); MF_PROF_OUT(1 + 4 * fk, acc_pub);
+        loss_value_finish(l_acc);
         return;
       }
         // ---------------- the computing wave ----------------
@@ -753,7 +798,12 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
         unsigned rslot = 0u;                          // ring slot read next (running, wraps at kSlots)
         UpIn uZ;                                      // the upstream gradient of output row 0 (the initial state): not in the ring
         load_upstream(0, uZ);
-        if (loss_on) uZ.gXs = cp_loss_grad(loss_scale, uZ.gXs, loss_gt_lane[(size_t)max(a.loss_row_stamp[0], 0) * 3u], a.loss_row_w[0]);
+        float l_row0 = zero;                          // row 0's term of the loss value (the other rows' are the fetching waves')
+        if (loss_on) {
+          const float g0 = loss_gt_lane[(size_t)max(a.loss_row_stamp[0], 0) * 3u], w0 = a.loss_row_w[0];
+          l_row0 = cp_loss_term(uZ.gXs, g0, w0);
+          uZ.gXs = cp_loss_grad(loss_scale, uZ.gXs, g0, w0);
+        }
         // The coefficients of a step's vector-Jacobian product, as the fetching wave leaves them in the ring.  With
         // cs = c / sum c, the gates mG, mF1 (1 / 0) and d1 = gFr . (mF1 n) -- the one lane sum that serves F0 = -A n and n both:
         struct Coef {
@@ -953,6 +1003,7 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
         }
         MF_PROF_ADD(9, t_compute);
         MF_PROF_OUT(8, acc_wait);
+        loss_value_finish(l_row0);
         uA = uZ; uB = uZ;                             // (the epilogue reads whichever the last iteration would have requested into)
     } else {
       // MODE = kCpSaved: ONE wave reads the record itself (either integrator; launches the streaming form does not cover, and the

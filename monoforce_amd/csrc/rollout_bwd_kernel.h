@@ -38,6 +38,9 @@ struct RolloutBwdArgs {
   const S* loss_row_w;
   const S* loss_gloss;
   S loss_inv_count;
+  S* loss_partial;         // MF_LOSS_VALUE_IN_BACKWARD (NULL otherwise): per-workgroup partial sums, the ticket, the mean
+  unsigned* loss_ticket;
+  S* loss_out;
 };
 
 #ifdef MF_NO_ATOMICS

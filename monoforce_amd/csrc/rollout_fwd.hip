@@ -55,7 +55,7 @@ static int fill_args(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutA
   a->zmu = nullptr;
   a->rec = nullptr;
   a->loss_T2 = 0; a->loss_gt = nullptr; a->loss_row_w = nullptr; a->loss_partial = nullptr; a->loss_ticket = nullptr;
-  a->loss_out = nullptr; a->loss_inv_count = (S)0;
+  a->loss_out = nullptr; a->loss_inv_count = (S)0; a->loss_poison = nullptr;
   for (int i = 0; i < 12; ++i) a->joint_xyz[i] = (S)d->joint_xyz[i];
   if (p->joint_angles) {
     MF_REQUIRE(d->n_tracks == 4, MF_ERR_UNSUPPORTED, "rollout_fwd: joint angles need 4 driving parts (fl, fr, rl, rr)");
@@ -136,7 +136,11 @@ extern "C" int mf_rollout_fwd_f32(const MfRolloutDesc* d, const MfRolloutFwdBufs
         MF_REQUIRE(((uintptr_t)p->rec & 15) == 0, MF_ERR_INVALID, "rollout_fwd: rec must be 16-byte aligned");
         a.rec = (float*)p->rec;
       }
-      if (p->loss) {      // physics_loss inside the launch (MfRolloutLoss)
+      if (p->loss && (p->loss->flags & MF_LOSS_VALUE_IN_BACKWARD)) {      // the backward will form the value: mark it as not yet known
+        MF_REQUIRE(mf::cp_loss_fusable(d), MF_ERR_UNSUPPORTED, "rollout_fwd: this launch cannot carry the fused physics loss (mf_rollout_loss_fusable)");
+        MF_REQUIRE(p->loss->loss, MF_ERR_INVALID, "rollout_fwd: MF_LOSS_VALUE_IN_BACKWARD needs MfRolloutLoss.loss");
+        a.loss_poison = (float*)p->loss->loss;
+      } else if (p->loss) {      // physics_loss inside the launch (MfRolloutLoss)
         const MfRolloutLoss* L = p->loss;
         MF_REQUIRE(mf::cp_loss_fusable(d), MF_ERR_UNSUPPORTED, "rollout_fwd: this launch cannot carry the fused physics loss (mf_rollout_loss_fusable)");
         MF_REQUIRE(!forces && d->layout == MF_LAYOUT_TIME_MAJOR, MF_ERR_INVALID, "rollout_fwd: the fused physics loss needs Fs = Ff = NULL and MF_LAYOUT_TIME_MAJOR");

@@ -21,6 +21,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = (tid >> 4) + a.b0;      // one 16-lane row per rollout
   if (b >= a.B) return;                  // whole rows leave together; DPP never crosses a row
+  if (a.loss_poison != nullptr && tid == 0) a.loss_poison[0] = __builtin_nanf("");      // MF_LOSS_VALUE_IN_BACKWARD: not yet known
   const int p = (tid >> 2) & 3;          // quad = contact point
   const int q = tid & 3;                 // lane of the quad: cell role q, component role cc
   const int cc = q < 3 ? q : 2;

@@ -63,6 +63,7 @@ struct RolloutArgs {
   unsigned* loss_ticket;
   S* loss_out;
   S loss_inv_count;
+  S* loss_poison;          // MF_LOSS_VALUE_IN_BACKWARD: the launch marks the loss as not yet known (NaN)
 };
 
 // Arithmetic policy.  Exact: IEEE divide / sqrt, libm exp and sincos, un-fused mul+add (the TU is built with

@@ -212,10 +212,14 @@ def _rollout_forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_gra
         Xraw=_lib.ptr(Xraw), joint_angles=_lib.ptr(joint_angles),
         zmu_scratch=_lib.ptr(_zmu_scratch(mod, desc, keep['z'])), zmu=_lib.ptr(mod._staged_zmu(desc, z, mu)), rec=_lib.ptr(rec))
     loss_val = lstruct = None
-    in_forward = loss is not None and mod.loss_in_forward
+    in_backward = loss is not None and len(loss) > 2 and bool(loss[2]) and want_grad      # MF_LOSS_VALUE_IN_BACKWARD
+    in_forward = loss is not None and mod.loss_in_forward and not in_backward
     if loss is not None:
-        spec, X_gt = loss
+        spec, X_gt = loss[:2]
         loss_val = torch.empty((), dtype=dt, device=dev)
+    if in_backward:     # the launch only marks the value as not yet known (NaN); mf_rollout_bwd_* fills it
+        lstruct = _lib.MfRolloutLoss(T2=spec.T2, flags=_lib.MF_LOSS_VALUE_IN_BACKWARD, loss=_lib.ptr(loss_val))
+        bufs.loss = C.cast(C.pointer(lstruct), C.c_void_p)
     if in_forward:
         partial = torch.empty((B + 3) // 4, dtype=dt, device=dev)
         lstruct = _lib.MfRolloutLoss(T2=spec.T2, gt=_lib.ptr(X_gt), near=_lib.ptr(spec.near), w=_lib.ptr(spec.w), row_stamp=_lib.ptr(spec.row_stamp), row_w=_lib.ptr(spec.row_w),
@@ -227,7 +231,7 @@ def _rollout_forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_gra
     outs = (Xs, Xds, Rs, Om) + ((Fs[..., :N, :], Ff[..., :N, :]) if want_forces else ())
     if tm:
         outs = tuple(o.transpose(0, 1) for o in outs)
-    if loss is not None and not in_forward:
+    if loss is not None and not in_forward and not in_backward:
         # The VALUE of the loss from one small launch on the rows just written (mf_physics_loss_value_*: gather-reduce over the B x T2
         # stamped rows, the mean finished inside it).  Measured against the rollout kernel accumulating it itself (LOSS kernels,
         # `loss_in_forward`): that forward pays ~15 instructions and two loads at EVERY step of a launch bound by the issue slots of
@@ -243,7 +247,10 @@ def _rollout_forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_gra
                 _lib.ptr(loss_val), None, C.c_longlong(0), _stream_ptr(dev)), 'mf_physics_loss_value')
     if loss is not None:
         outs = (loss_val,) + outs
-        ctx.loss = (spec, X_gt, Xs) if want_grad else None
+        # (the backward launch's scratch is allocated HERE: under a hipGraph capture the autograd thread must not allocate)
+        # (... and the scalar is held through an ALIAS: the tensor handed out gets this node as its grad_fn, and a node holding its own
+        #  output is a reference cycle -- garbage that the collector then frees whenever it runs, e.g. in the middle of a later capture)
+        ctx.loss = (spec, X_gt, Xs, (loss_val.detach(), torch.empty((B + 3) // 4, dtype=dt, device=dev)) if in_backward else None) if want_grad else None
     ctx.n_force_outs = 2 if want_forces else 0
     # outputs the loss does not touch arrive as None in backward (= NULL upstream pointers), not as zero-filled tensors
     ctx.set_materialize_grads(False)
@@ -279,9 +286,10 @@ class _RolloutLossFn(torch.autograd.Function):
     loss is differentiable -- the backward forms dL/dXs itself at the stamped rows."""
 
     @staticmethod
-    def forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_grad, x0_buf, x0_private, default_state, spec, X_gt):
+    def forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_grad, x0_buf, x0_private, default_state, spec, X_gt,
+                value_in_backward=False):
         outs = _rollout_forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_grad, None, False, x0_buf, x0_private,
-                                default_state, loss=(spec, X_gt))
+                                default_state, loss=(spec, X_gt, value_in_backward))
         ctx.mark_non_differentiable(*outs[1:])
         return outs
 
@@ -289,9 +297,9 @@ class _RolloutLossFn(torch.autograd.Function):
     def backward(ctx, gloss, *_unused):
         from .dphysics_bwd import rollout_backward
         if gloss is None:
-            return (None,) * 15
+            return (None,) * 16
         grads = rollout_backward(ctx, None, None, None, None, None, None, gloss=gloss)      # (mod, z, mu, controls, x, xd0, R0, w0, ts, want_grad, ja)
-        return grads[:10] + (None, None, None, None, None)
+        return grads[:10] + (None, None, None, None, None, None)
 
 
 class DPhysics(torch.nn.Module):
@@ -471,9 +479,9 @@ class DPhysics(torch.nn.Module):
         x_arg = x_in if (want_grad and x_in.requires_grad) else x0
         loss_val = None
         if _loss is not None:       # physics_loss inside the launches (physics_loss_rollout)
-            spec, X_gt = _loss
+            spec, X_gt = _loss[:2]
             outs = _RolloutLossFn.apply(self, z_grid, friction, controls, x_arg, xd0, R0, w0, ts, want_grad, x0, own_state,
-                                        state_in_kernel, spec, X_gt)
+                                        state_in_kernel, spec, X_gt, len(_loss) > 2 and bool(_loss[2]))
             loss_val, outs = outs[0], outs[1:]
         else:
             outs = _RolloutFn.apply(self, z_grid, friction, controls, x_arg, xd0, R0, w0, ts, want_grad, ja_dev, want_forces,
@@ -493,12 +501,15 @@ class DPhysics(torch.nn.Module):
         n = len(self.ts) if n_steps is None else int(n_steps)
         return LossSpec(self._time_grid(n, torch.float32, torch.device('cpu')), gt_ts, gamma, torch.device(self.device))
 
-    def physics_loss_rollout(self, z_grid, controls, X_gt, spec, state=None, friction=None):
+    def physics_loss_rollout(self, z_grid, controls, X_gt, spec, state=None, friction=None, value_in_backward=False):
         """`physics_loss(self(z_grid, controls, ...), [X_gt], pred_ts, gt_ts, gamma)` (losses.py:102-127, the position term the training
         scripts use: scripts/train.py:399-406, scripts/fit_terrain.py:53-62) with the loss INSIDE the rollout's two launches (SURVEY.md
         8f rank 1): the forward kernel accumulates the time-weighted squared error at the stamped rows while it writes them, the
         backward forms dL/dXs there itself -- no loss launches, no [B,T,3] gradient tensor.  X_gt [B,T2,3]; `spec` = self.loss_spec(gt_ts).
         Returns (loss, (Xs, Xds, Rs, Omegas)); the states come back detached from the graph (only the loss is differentiable).
+        `value_in_backward` (MF_LOSS_VALUE_IN_BACKWARD): for a caller that ALWAYS calls `loss.backward()` next and reads the value
+        only afterwards (a fit loop): the backward launch forms the value too -- the returned scalar is NaN until then -- and the
+        step loses its one remaining loss launch.
         Where the library cannot fuse (mf_rollout_loss_fusable: other than float32 fast math, default integrator, a rigid body of <= 4
         points, <= 2048 rollouts; several stamps on one row) the same value and gradient come from the unfused route."""
         from .losses import physics_loss_fused
@@ -518,7 +529,7 @@ class DPhysics(torch.nn.Module):
             return physics_loss_fused(states, [X_gt], None, gt_ts, gamma=spec.gamma, nearest=spec.near.unsqueeze(0).expand(B_, -1)), states
         Xg = X_gt.detach().to(device=torch.device(self.device), dtype=torch.float32).contiguous()
         assert Xg.shape == (B, spec.T2, 3), f'X_gt shape {tuple(Xg.shape)} != {(B, spec.T2, 3)}'
-        return self.dphysics(z_grid, controls, state=state, friction=friction, _loss=(spec, Xg))
+        return self.dphysics(z_grid, controls, state=state, friction=friction, _loss=(spec, Xg, bool(value_in_backward)))
 
     @torch.no_grad()
     def rollout_costs(self, z_grid, controls, state=None, friction=None, pose_stride=None, project=True):

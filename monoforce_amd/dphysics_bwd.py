@@ -131,10 +131,13 @@ def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf, gloss=None):
         gxd0=_lib.ptr(gxd0), gR0=_lib.ptr(gR0), gw0=_lib.ptr(gw0), joint_angles=_lib.ptr(ja), gjoint_angles=_lib.ptr(gja),
         rec=_lib.ptr(getattr(ctx, 'rec', None)))
     if gloss is not None:       # the forward carried physics_loss itself (MfRolloutLoss): the kernel forms dL/dXs from Xs and the ground truth
-        spec, X_gt, Xs_rows = ctx.loss
+        spec, X_gt, Xs_rows, loss_out = ctx.loss
         gl = gloss.to(dt).reshape(1).contiguous()
         lstruct = _lib.MfRolloutLoss(T2=spec.T2, gt=_lib.ptr(X_gt), near=_lib.ptr(spec.near), w=_lib.ptr(spec.w), row_stamp=_lib.ptr(spec.row_stamp), row_w=_lib.ptr(spec.row_w),
                                      gloss=_lib.ptr(gl), Xs=_lib.ptr(Xs_rows))
+        if loss_out is not None:       # MF_LOSS_VALUE_IN_BACKWARD: this launch also forms the value the forward left as NaN
+            lstruct.flags = _lib.MF_LOSS_VALUE_IN_BACKWARD
+            lstruct.partial, lstruct.ticket, lstruct.loss = _lib.ptr(loss_out[1]), _lib.ptr(spec.ticket), _lib.ptr(loss_out[0])
         bufs.loss = C.cast(C.pointer(lstruct), C.c_void_p)
     fn = getattr(_lib.lib(), 'mf_rollout_bwd_' + _scalar_suffix(dt))
     with torch.cuda.device(dev), _timing.timed('rollout_bwd_kernel', dev):

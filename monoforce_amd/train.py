@@ -1,6 +1,8 @@
 """Train-step drivers for the hot path: the call pattern of `scripts/fit_terrain.py:53-62` (optimise a terrain through
 the physics) and `scripts/train.py:377-410` (physics loss on predicted terrain), sharded over GPUs.
 """
+import os
+
 import torch
 
 from . import dist as mfdist
@@ -20,6 +22,7 @@ class TerrainFitProblem:
         # physics_loss inside the rollout's own two launches (DPhysics.physics_loss_rollout): a step is four
         # launches instead of six and the [B,T,3] gradient rows are never built; where the library cannot fuse, the route above
         self.loss_in_kernel = bool(loss_in_kernel) and fused_loss and controls.is_cuda
+        self.loss_value_in_backward = os.environ.get('MF_LOSS_VALUE_IN_BACKWARD', '1') != '0'      # (A/B switch; DPhysics.physics_loss_rollout)
         self.controls = controls
         B, T = controls.shape[:2]
         cfg = dphysics.dphys_cfg
@@ -79,7 +82,9 @@ class TerrainFitProblem:
 
     def _loss(self, z, mu):
         if self.loss_in_kernel:
-            return self.dp.physics_loss_rollout(z.unsqueeze(0), self.controls, self.states_gt[0], self.spec, friction=mu.unsqueeze(0))[0]
+            # (the step always runs the backward next and hands the value out afterwards: the backward launch forms it too)
+            return self.dp.physics_loss_rollout(z.unsqueeze(0), self.controls, self.states_gt[0], self.spec, friction=mu.unsqueeze(0),
+                                                value_in_backward=self.loss_value_in_backward)[0]
         states, _ = self.dp(z.unsqueeze(0), self.controls, friction=mu.unsqueeze(0))
         loss_fn = physics_loss_fused if self.fused_loss else physics_loss
         return loss_fn(states, self.states_gt, self.pred_ts, self.gt_ts, nearest=self.nearest if self.fused_loss else self.nearest.long())

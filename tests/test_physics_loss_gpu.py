@@ -104,7 +104,7 @@ def test_gradient_copy_pool_is_reused_clean():
 
 
 # ---- physics_loss inside the rollout's own launches (MfRolloutLoss; DPhysics.physics_loss_rollout) ----------------
-def _fit_problem(B, T, loss_in_kernel, graph=False, res=0.1, d_max=3.2, gt_every=10, in_forward=False):
+def _fit_problem(B, T, loss_in_kernel, graph=False, res=0.1, d_max=3.2, gt_every=10, in_forward=False, value='backward'):
     from monoforce_amd import synthetic as syn
     from monoforce_amd.train import TerrainFitProblem
     from tests.test_rollout_gpu import make_dphysics
@@ -115,24 +115,28 @@ def _fit_problem(B, T, loss_in_kernel, graph=False, res=0.1, d_max=3.2, gt_every
     mu = syn.wave_friction(d_max, res).to(DEV)
     ctrl = syn.const_controls(B, T, seed=2).to(DEV)
     prob = TerrainFitProblem(dp, z_true, mu, ctrl, gt_every=gt_every, graph=graph, loss_in_kernel=loss_in_kernel)
+    # where the loss VALUE is formed: by the backward launch (the fit step's default), by the forward rollout kernel (in_forward), or
+    # by one small launch on the forward's rows (value = 'launch')
+    prob.loss_value_in_backward = value == 'backward' and not in_forward
     z = (z_true * 0.5).clone().requires_grad_(True)
     m = mu.clone().requires_grad_(True)
     return prob, z, m
 
 
-@pytest.mark.parametrize('in_forward', [False, True])
+@pytest.mark.parametrize('in_forward,value', [(False, 'launch'), (True, 'forward'), (False, 'backward')])
 @pytest.mark.parametrize('B,T,gt_every', [(48, 300, 10), (37, 95, 10), (3, 41, 1), (1, 12, 5), (1500, 120, 10)])
-def test_loss_inside_the_rollout_kernels_equals_the_two_kernel_route(B, T, gt_every, in_forward):
+def test_loss_inside_the_rollout_kernels_equals_the_two_kernel_route(B, T, gt_every, in_forward, value):
     """Forward: the mean the rollout kernel finishes itself == mf_physics_loss_value_* on its outputs (and == the plain-torch
     restatement of losses.py:102-127); backward: dL/dXs formed by the fetching waves == the gradient rows mf_physics_loss_bwd_* writes,
     so the terrain / friction gradients agree to the rounding of the atomics' arrival order.  Batches with a trailing partial
     workgroup (37, 3, 1 rollouts), every row stamped (gt_every = 1), two workgroups per CU (1500).  Both forms of the forward half:
-    the rollout kernel accumulating the loss itself (`loss_in_forward`, the LOSS kernels) and -- the default, measured faster --
-    one small launch on the rows it wrote; the backward half is the same."""
+    the rollout kernel accumulating the loss itself (`loss_in_forward`, the LOSS kernels) and one small launch on the rows it wrote; the
+    backward half is the same -- and, third form (the fit step's default), the backward launch forming the VALUE as well
+    (MF_LOSS_VALUE_IN_BACKWARD)."""
     from monoforce_amd.losses import physics_loss
     out = []
     for in_kernel in (False, True):
-        prob, z, m = _fit_problem(B, T, in_kernel, gt_every=gt_every, in_forward=in_forward)
+        prob, z, m = _fit_problem(B, T, in_kernel, gt_every=gt_every, in_forward=in_forward, value=value)
         vals = []
         for _ in range(3):                                   # launch after launch: the ticket comes back to zero
             loss = prob.step(z, m)
@@ -164,6 +168,31 @@ def test_loss_inside_the_kernels_replayed_as_a_graph_and_non_unit_upstream():
     loss, _ = prob.dp.physics_loss_rollout(z.unsqueeze(0), prob.controls, prob.states_gt[0], prob.spec, friction=m.unsqueeze(0))
     (loss * 3.0).backward()
     assert hp.rel_err(z.grad.cpu(), (g0[0] * 3.0).cpu()) <= 1e-5
+
+
+def test_loss_value_formed_by_the_backward_launch():
+    """MF_LOSS_VALUE_IN_BACKWARD through `physics_loss_rollout(value_in_backward=True)`: the scalar is NaN between the forward and
+    the backward (not a stale or uninitialised number), afterwards the value of the separate launch to rounding; the gradients do
+    not depend on which launch forms the value; without `requires_grad` inputs (no backward to come) the forward's own route runs."""
+    prob, z, m = _fit_problem(1024, 200, True, value='launch')
+    args = (z.unsqueeze(0), prob.controls, prob.states_gt[0], prob.spec)
+    res = {}
+    for mode in (False, True):
+        z.grad = None; m.grad = None
+        loss, _ = prob.dp.physics_loss_rollout(*args, friction=m.unsqueeze(0), value_in_backward=mode)
+        torch.cuda.synchronize()
+        before = float(loss)
+        assert (before != before) == mode, (mode, before)      # NaN exactly when the backward is to form it
+        loss.backward()
+        torch.cuda.synchronize()
+        res[mode] = (float(loss), z.grad.clone(), m.grad.clone())
+    assert abs(res[True][0] - res[False][0]) <= 2e-6 * abs(res[False][0]), (res[True][0], res[False][0])
+    # (the pool's atomics arrive in a launch-dependent order: equal to rounding, not bit for bit)
+    assert hp.rel_err(res[True][1].cpu(), res[False][1].cpu()) <= 1e-5 and hp.rel_err(res[True][2].cpu(), res[False][2].cpu()) <= 1e-5
+    with torch.no_grad():
+        loss, _ = prob.dp.physics_loss_rollout(z.detach().unsqueeze(0), prob.controls, prob.states_gt[0], prob.spec, friction=m.detach().unsqueeze(0),
+                                               value_in_backward=True)
+    assert abs(float(loss) - res[False][0]) <= 2e-6 * abs(res[False][0])
 
 
 def test_loss_rollout_falls_back_where_the_library_cannot_fuse():
