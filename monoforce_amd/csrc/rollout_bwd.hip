@@ -1,6 +1,7 @@
 // Backward rollout: host side of mf_rollout_bwd_* and the reference-order (exact) kernel instantiations.
 // Compiled with -ffp-contract=off; the FMA-contracted float32 kernels live in rollout_bwd_fast.hip.
 #include "rollout_bwd_cp_kernel.h"
+#include "rollout_bwd_mw_kernel.h"
 
 namespace mf {
 
@@ -97,6 +98,12 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
                                      (p->gXs || p->loss) && !p->gXds && !p->gRs && !p->gOmegas && !p->gFs && !p->gFf, st);
   }
   const LaneMap m = choose_lane_map(d->B, d->N, d->points_per_lane == MF_LANES_COMPONENT ? 0 : d->points_per_lane);
+  if (sizeof(S) == 4 && use_multiwave_bwd(d, p)) {   // one rollout over several waves, from the forward's 16-byte record
+    MF_REQUIRE(((uintptr_t)p->rec & 15) == 0, MF_ERR_INVALID, "rollout_bwd: rec must be 16-byte aligned");
+    a.rec = (const S*)p->rec;
+    return launch_rollout_bwd_mw_f32(*reinterpret_cast<const RolloutBwdArgs<float>*>(&a), m.G,
+                                     !p->gXds && !p->gRs && !p->gOmegas && !p->gFs && !p->gFf, st);
+  }
   if (sizeof(S) == 4 && d->math_mode == MF_MATH_FAST) {
     // accumulator carry-over between adjacent cells (rollout_bwd_kernel.h): ~55 more instructions per step, half the atomics --
     // a gain from ~3 waves per 4 CUs upwards (B = 4096 at N = 4: 1.00 -> 0.94 ms; B = 65536: 9.5 -> 5.5 ms), a loss below

@@ -64,7 +64,11 @@ bool cp_loss_fusable(const MfRolloutDesc* d) {
 }  // namespace mf
 extern "C" int mf_rollout_loss_fusable(const MfRolloutDesc* d) { return mf::cp_loss_fusable(d) ? 1 : 0; }
 extern "C" int mf_rollout_bwd_wants_gcontrols(const MfRolloutDesc* d) { return (d && mf::cp_bwd_covers(d, d->has_joints != 0)) ? 0 : 1; }
-extern "C" long long mf_rollout_record_bytes(const MfRolloutDesc* d) { return mf::cp_record_bytes(d); }
+namespace mf { long long mw_record_bytes(const MfRolloutDesc* d); }   // rollout_bwd_mw_fast.hip
+extern "C" long long mf_rollout_record_bytes(const MfRolloutDesc* d) {
+  const long long cp = mf::cp_record_bytes(d);
+  return cp > 0 ? cp : mf::mw_record_bytes(d);
+}
 namespace mf {
 
 int launch_rollout_bwd_cp_f32(const RolloutBwdArgs<float>& a, int integ, bool xs_only, hipStream_t st) {

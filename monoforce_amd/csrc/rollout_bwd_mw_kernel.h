@@ -1,0 +1,441 @@
+// Fused DPhysics rollout, backward pass for ONE ROLLOUT OVER SEVERAL WAVES (gfx950): bodies of 65..512 contact points at small
+// batch sizes -- the reference's own operating point, 4..64 rollouts of its 175- / 223-point robots
+// (/root/reference/monoforce/examples/diff_physics.ipynb:199-226, scripts/train.py --bsz 4, n_sim_trajs = 64).  float32
+// MF_MATH_FAST, default integrator (torchdiffeq fixed-grid euler, dphysics.py:499-528), rigid body.
+//
+// Same adjoint as rollout_bwd_kernel.h (reverse-time vector-Jacobian product of `forward_kinematics`, dphysics.py:172-272, from
+// the saved state rows), re-organised around what one wave per SIMD pays for: instructions and workgroup exchanges.  The general
+// kernel spends, per step, four LDS exchanges (contact count, torque, one adjoint scalar, 23 adjoint sums) and 168 DPP
+// reductions of 1425 instructions.  Here
+//   * the forward keeps a 16-byte record per rollout-step -- the contact count and the unclamped angular acceleration it
+//     evaluated (MfRolloutFwdBufs.rec for this mapping) -- so the recompute of a step needs no reduction at all, and the clamp
+//     of omega_d is gated on the forward's own value;
+//   * the adjoint of the body state (x, xd, R, w) is kept UN-SUMMED over the contact points: every lane carries the partial its
+//     point contributed, pushed through the step's linear recurrence (the coefficients -- R, w, h -- are workgroup-uniform),
+//     and summed once after the loop.  Only what a step's per-point chain reads as a total is exchanged: the six components of
+//     the velocity adjoints, the two control-gradient outputs and the scalar gS = dL/d(sum of contact weights) -- nine values;
+//   * gS enters the step linearly (through dL/d(dh) = ... + gS kappa_j), and nothing that depends on it is read as a total
+//     before the step after next: it rides in the SAME exchange as the velocity adjoints and is applied one step late as a
+//     correction (position and rotation partials, the four cell accumulators of the point).
+// One exchange and one barrier per step; the state rows, controls, time grid and record are workgroup-uniform loads.
+#pragma once
+#include "rollout_bwd_kernel.h"
+
+namespace mf {
+
+constexpr int kMwRecFloats = 4;   // per rollout-step: (sum of contact weights, omega_d before its clamp [3])
+
+template <int G, bool XS_ONLY>
+__global__ void __launch_bounds__(G) rollout_bwd_mw_kernel(const RolloutBwdArgs<float> a) {
+  using S = float;
+  using M = Mth<float, true>;
+  constexpr int NW = G / 64;
+  const int b = blockIdx.x;        // one rollout per workgroup
+  const int gl = threadIdx.x;      // one contact point per lane
+  const S one = 1.0f, zero = 0.0f;
+  const int HW = a.H * a.W, last = HW - 1;
+  __shared__ S gs_lds[2 * NW * kGroupSumMaxValues];
+  GroupSum<G, S> gs;
+  gs.lds = gs_lds;
+  const unsigned moff = a.map_shared ? 0u : (unsigned)b * (unsigned)HW;
+  const S* zmap = a.z;
+  const bool has_mu = a.mu != nullptr;
+  const S* mumap = has_mu ? a.mu : a.z;
+  const unsigned goff = a.map_shared ? (unsigned)(b % a.grad_copies) * (unsigned)HW : (unsigned)b * (unsigned)HW;
+  S* gzmap = a.gz;
+  const bool want_gmu = a.gmu != nullptr && has_mu;
+  S* gmumap = want_gmu ? a.gmu : a.gz;
+
+  const bool act = gl < a.N;
+  const int ii = act ? gl : 0;
+  const S P[3] = {a.points[ii * 3 + 0], a.points[ii * 3 + 1], a.points[ii * 3 + 2]};
+  const int part = act ? a.part[ii] : -1;
+  const S tcw = part < 0 ? zero : ((part & 1) ? a.half_ly : -a.half_ly);   // d(track speed)/d(w command); d/d(v command) = drv
+  const S drv = part >= 0 ? one : zero;
+  const S m0 = gl == 0 ? one : zero;     // upstream gradients of the body state enter ONE lane's partial
+  S Iv[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) Iv[c] = a.Iinv[c];
+
+  const size_t row_stride = (a.layout == MF_LAYOUT_TIME_MAJOR) ? (size_t)a.B : 1;
+  const size_t row0 = (a.layout == MF_LAYOUT_TIME_MAJOR) ? (size_t)b : (size_t)b * a.T;
+  const S* ctrl = a.controls + (size_t)b * a.T * 2;
+  S* gctrl = a.gcontrols + (size_t)b * a.T * 2;
+  const int n_steps = a.T - 1;
+
+  // un-summed adjoint of the body state: the sum over the workgroup's lanes is the adjoint
+  S lx[3] = {zero, zero, zero}, lxd[3] = {zero, zero, zero}, lw[3] = {zero, zero, zero}, lR[9];
+#pragma unroll
+  for (int c = 0; c < 9; ++c) lR[c] = zero;
+  S laFs[3] = {zero, zero, zero}, laFf[3] = {zero, zero, zero};   // adjoint of this point's impulse accumulators (ODEINT outputs)
+
+  struct StepIn {   // workgroup-uniform inputs of step n: the state it started from, its controls, step size and the forward's record
+    S x[3], xd[3], R[9], w[3], cv, cw, t0, t1, csum, wraw[3];
+  };
+  struct UpIn {     // upstream gradients of output row n + 1
+    S gXs[3], gXds[3], gRs[9], gOm[3], gFs[3], gFf[3];
+  };
+  auto load_step = [&](int n, StepIn& s) {
+    const size_t row = row0 + (size_t)n * row_stride;
+    const S* px = a.Xraw + row * 3; const S* pxd = a.Xds + row * 3; const S* pw = a.Om + row * 3; const S* pR = a.Rs + row * 9;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { s.x[c] = px[c]; s.xd[c] = pxd[c]; s.w[c] = pw[c]; }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) s.R[c] = pR[c];
+    s.cv = ctrl[n * 2 + 0]; s.cw = ctrl[n * 2 + 1];
+    s.t0 = a.ts[n]; s.t1 = a.ts[min(n + 1, a.T - 1)];
+    const S* pr = a.rec + ((size_t)n * a.B + b) * kMwRecFloats;
+    s.csum = pr[0]; s.wraw[0] = pr[1]; s.wraw[1] = pr[2]; s.wraw[2] = pr[3];
+  };
+  auto load_up = [&](int m, UpIn& u) {   // output row m
+    const size_t row = row0 + (size_t)m * row_stride;
+    const S* g1 = a.gXs + row * a.sXs;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) u.gXs[c] = g1[c];
+    if constexpr (!XS_ONLY) {
+      const S* g2 = a.gXds + row * a.sXds; const S* g3 = a.gOm + row * a.sOm; const S* g4 = a.gRs + row * a.sRs;
+      const size_t pt = row * a.N + min(gl, a.N - 1);
+      const S* f1 = a.gFs + pt * a.sFs; const S* f2 = a.gFf + pt * a.sFf;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { u.gXds[c] = g2[c]; u.gOm[c] = g3[c]; u.gFs[c] = f1[c]; u.gFf[c] = f2[c]; }
+#pragma unroll
+      for (int c = 0; c < 9; ++c) u.gRs[c] = g4[c];
+    }
+  };
+  // upstream gradient of a state row: into lane 0's partials (and, by the caller, into the totals the step reads)
+  auto add_upstream_partials = [&](const UpIn& u) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      lx[c] += m0 * u.gXs[c];
+      lR[c * 3 + 2] += (m0 * a.sink) * u.gXs[c];     // Xs = x + R[:, 2] * sink
+    }
+    if constexpr (!XS_ONLY) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { lxd[c] += m0 * u.gXds[c]; lw[c] += m0 * u.gOm[c]; }
+#pragma unroll
+      for (int c = 0; c < 9; ++c) lR[c] += m0 * u.gRs[c];
+    }
+  };
+
+  // map-gradient accumulators of the point's footprint (rollout_bwd_kernel.h, plain form): a robot moves <= 0.2 cell per step
+  unsigned acc_idx[4] = {0u, 0u, 0u, 0u}, st_idx[4] = {0u, 0u, 0u, 0u};
+  S acc_z[4] = {zero, zero, zero, zero}, acc_m[4] = {zero, zero, zero, zero}, st_z[4], st_m[4];
+  bool st_pending = false;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) st_z[q] = st_m[q] = zero;
+  auto flush_stash = [&]() {
+    if (st_pending) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) atomic_add(at32(gzmap, goff + st_idx[q]), st_z[q]);
+      if (want_gmu) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) atomic_add(at32(gmumap, goff + st_idx[q]), st_m[q]);
+      }
+    }
+    st_pending = false;
+  };
+  // what the deferred gS correction of the previous iteration's step needs: kappa = d(dh adjoint)/d(gS), the footprint's weights
+  // and the height blend's derivatives over res
+  S dk = zero, dzx = zero, dzy = zero, dw4[4] = {zero, zero, zero, zero};
+
+  if (gl == 0 && a.gcontrols) { gctrl[(a.T - 1) * 2 + 0] = zero; gctrl[(a.T - 1) * 2 + 1] = zero; }   // the last control is never used
+
+  StepIn cur;
+  UpIn up;
+  load_step(max(n_steps - 1, 0), cur);
+  load_up(min(n_steps, a.T - 1), up);
+  {   // the exchange the first iteration fetches: nothing yet
+    S ex0[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) ex0[k] = zero;
+    gs.template post<9>(ex0);
+  }
+  __builtin_amdgcn_s_waitcnt(0);
+  for (int n = n_steps - 1; n >= 0; --n) {
+    S x[3], xd[3], R[9], w[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { x[c] = cur.x[c]; xd[c] = cur.xd[c]; w[c] = cur.w[c]; }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) R[c] = cur.R[c];
+    const S cv = cur.cv, cw = cur.cw, h = cur.t1 - cur.t0;
+    const S csum = cur.csum;
+    const S wraw[3] = {cur.wraw[0], cur.wraw[1], cur.wraw[2]};
+    const UpIn upn = up;
+
+    // ---- geometry of the point under pose n, requests for its cells ----
+    const S px = P[0] * R[0] + P[1] * R[1] + P[2] * R[2] + x[0];
+    const S py = P[0] * R[3] + P[1] * R[4] + P[2] * R[5] + x[1];
+    const S pz = P[0] * R[6] + P[1] * R[7] + P[2] * R[8] + x[2];
+    const S r[3] = {px - x[0], py - x[1], pz - x[2]};
+    const Cell<S> cell = locate_m<S, true>(px, py, a.d_max, a.res, a.inv_res, a.H, last);
+    S zc[4], mc[4];
+    gather4(zmap, moff, cell, last, zc);
+    gather4(mumap, moff, cell, last, mc);
+    // ---- deferred atomics of the previous iteration, prefetch of the next one's rows (younger than the gathers) ----
+    flush_stash();
+    load_step(max(n - 1, 0), cur);
+    load_up(n, up);
+
+    // ---- the exchange posted by the previous iteration: totals of the velocity adjoints, the control gradient of step n + 1, gS ----
+    S ex[9];
+    gs.template wait<9>(ex);
+    if (a.gcontrols && n + 1 < n_steps) { gctrl[(n + 1) * 2 + 0] = ex[6]; gctrl[(n + 1) * 2 + 1] = ex[7]; }
+    {   // gS of step n + 1, one step late: dh adjoint += gS kappa  ->  height sample, position, rotation partials, cell accumulators
+      const S dl = ex[8] * dk;
+      const S g0 = -(dl * dzx), g1 = -(dl * dzy);
+      lx[0] += g0; lx[1] += g1; lx[2] += dl;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { lR[0 * 3 + c] += g0 * P[c]; lR[1 * 3 + c] += g1 * P[c]; lR[2 * 3 + c] += dl * P[c]; }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc_z[q] -= dl * dw4[q];
+    }
+    // ---- upstream of output row n + 1 ----
+    S Sxd[3] = {ex[0], ex[1], ex[2]}, Sw[3] = {ex[3], ex[4], ex[5]};
+    add_upstream_partials(upn);
+    if constexpr (!XS_ONLY) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        Sxd[c] += upn.gXds[c]; Sw[c] += upn.gOm[c];
+        laFs[c] += act ? upn.gFs[c] : zero; laFf[c] += act ? upn.gFf[c] : zero;
+      }
+    }
+    // ---- integrator backward: y' = y + h f(y) ----
+    const S gxdd[3] = {h * Sxd[0], h * Sxd[1], h * Sxd[2]};
+    const S gwd[3] = {h * Sw[0], h * Sw[1], h * Sw[2]};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) lxd[c] += h * lx[c];                 // x' = x + h xd
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {                                    // R' = R + h [w]x R, column by column
+      const S gcol[3] = {h * lR[0 * 3 + c], h * lR[1 * 3 + c], h * lR[2 * 3 + c]};
+      const S rc[3] = {R[0 * 3 + c], R[1 * 3 + c], R[2 * 3 + c]};
+      S t1[3], t2[3];
+      MF_CROSS(t1, rc, gcol);
+      lw[0] += t1[0]; lw[1] += t1[1]; lw[2] += t1[2];
+      MF_CROSS(t2, gcol, w);
+      lR[0 * 3 + c] += t2[0]; lR[1 * 3 + c] += t2[1]; lR[2 * 3 + c] += t2[2];
+    }
+
+    // ---- forward recompute of the point's contact (rollout_fwd_kernel.h, PIPE path) ----
+    const S vp[3] = {xd[0] + (w[1] * r[2] - w[2] * r[1]), xd[1] + (w[2] * r[0] - w[0] * r[2]), xd[2] + (w[0] * r[1] - w[1] * r[0])};
+    const S len2 = R[0] * R[0] + R[3] * R[3] + R[6] * R[6];
+    const S il = M::inv_len(len2);
+    const S e[3] = {R[0] * il, R[3] * il, R[6] * il};
+    const S tv_lo = cv - cw * a.half_ly, tv_hi = cv + cw * a.half_ly;
+    const S tv = (part < 0) ? zero : ((part & 1) ? tv_hi : tv_lo);
+    S zq, mub;
+    blend2(cell, zc, mc, &zq, &mub);
+    const S muq = has_mu ? mub : blend_ones(cell);
+    const S gx = M::div(zc[1] - zc[0], a.res), gy = M::div(zc[2] - zc[0], a.res);
+    const S inl = M::inv_len(gx * gx + gy * gy + one);
+    const S nrm[3] = {-gx * inl, -gy * inl, inl};
+    const S dh = pz - zq;
+    const S cj = act ? M::sigmoid_m10(dh) : zero;
+    const S vn = vp[0] * nrm[0] + vp[1] * nrm[1] + vp[2] * nrm[2];
+    const S A = a.k * dh + a.damp * vn;
+    const S F0[3] = {-(A * nrm[0]), -(A * nrm[1]), -(A * nrm[2])};
+    const S inv_csum = M::div(one, csum);
+    S F1[3], Fr[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { F1[c] = F0[c] * cj * inv_csum; Fr[c] = M::clamp(F1[c], -a.mg, a.mg); }
+    const S Nn = M::sqrt(Fr[0] * Fr[0] + Fr[1] * Fr[1] + Fr[2] * Fr[2]);
+    const S cmdv[3] = {tv * e[0] - vp[0], tv * e[1] - vp[1], tv * e[2] - vp[2]};
+    const S slip[3] = {muq * cmdv[0], muq * cmdv[1], muq * cmdv[2]};
+    const S sn = slip[0] * nrm[0] + slip[1] * nrm[1] + slip[2] * nrm[2];
+    S st[3], Gf[3], Ff[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { st[c] = slip[c] - sn * nrm[c]; Gf[c] = Nn * st[c]; Ff[c] = M::clamp(Gf[c], -a.mg, a.mg); }
+    if (!act) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Fr[c] = Ff[c] = zero;
+    }
+
+    // ---- RHS backward ----
+    S gtau[3];
+    {
+      const S m0_ = inside(wraw[0], -a.omega_max, a.omega_max) ? gwd[0] : zero;
+      const S m1_ = inside(wraw[1], -a.omega_max, a.omega_max) ? gwd[1] : zero;
+      const S m2_ = inside(wraw[2], -a.omega_max, a.omega_max) ? gwd[2] : zero;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gtau[c] = Iv[0 * 3 + c] * m0_ + Iv[1 * 3 + c] * m1_ + Iv[2 * 3 + c] * m2_;   // Iinv^T
+    }
+    const S f[3] = {Fr[0] + Ff[0], Fr[1] + Ff[1], Fr[2] + Ff[2]};
+    S gf[3], gr[3];
+    MF_CROSS(gf, gtau, r);            // tau += r x f : df = gtau x r
+    MF_CROSS(gr, f, gtau);            //                dr = f x gtau
+    S gFr_[3], gG[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const S com = gxdd[c] * a.inv_mass + gf[c];
+      gFr_[c] = XS_ONLY ? com : h * laFs[c] + com;
+      const S gFf_ = XS_ONLY ? com : h * laFf[c] + com;
+      gG[c] = inside(Gf[c], -a.mg, a.mg) ? gFf_ : zero;
+    }
+    const S gNn = gG[0] * st[0] + gG[1] * st[1] + gG[2] * st[2];
+    const S gst[3] = {Nn * gG[0], Nn * gG[1], Nn * gG[2]};
+    const S gsn = -(gst[0] * nrm[0] + gst[1] * nrm[1] + gst[2] * nrm[2]);
+    S gn[3], gslip[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { gn[c] = -sn * gst[c] + gsn * slip[c]; gslip[c] = gst[c] + gsn * nrm[c]; }
+    const S gmuq = gslip[0] * cmdv[0] + gslip[1] * cmdv[1] + gslip[2] * cmdv[2];
+    const S gcmd[3] = {muq * gslip[0], muq * gslip[1], muq * gslip[2]};
+    S gvp[3] = {-gcmd[0], -gcmd[1], -gcmd[2]};
+    const S gtv = drv * (gcmd[0] * e[0] + gcmd[1] * e[1] + gcmd[2] * e[2]);      // track speed of a driving point (tv = 0 elsewhere)
+    const S ge[3] = {tv * gcmd[0], tv * gcmd[1], tv * gcmd[2]};
+    if (Nn > zero) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gFr_[c] += M::div(gNn * Fr[c], Nn);
+    }
+    S gF1[3], d = zero, gA = zero;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { gF1[c] = inside(F1[c], -a.mg, a.mg) ? gFr_[c] : zero; d += gF1[c] * F0[c]; }
+    const S gc_p = d * inv_csum;
+    const S gS_p = -(d * cj) * inv_csum * inv_csum;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const S gF0 = gF1[c] * cj * inv_csum;
+      gA += -(gF0 * nrm[c]);
+      gn[c] += -A * gF0;
+    }
+    const S gvn = a.damp * gA;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { gvp[c] += gvn * nrm[c]; gn[c] += gvn * vp[c]; }
+    // dh adjoint WITHOUT the share of gS (applied by the next iteration: dl = gS kappa)
+    const S kappa = (S)-10 * cj * (one - cj);
+    const S gdh = a.k * gA + gc_p * kappa;
+    const S gzq = -gdh;
+    const S dotn = gn[0] * nrm[0] + gn[1] * nrm[1] + gn[2] * nrm[2];
+    const S gu0 = (gn[0] - dotn * nrm[0]) * inl, gu1 = (gn[1] - dotn * nrm[1]) * inl;   // n = u / |u|, u = (-gx, -gy, 1)
+    const S ggx = M::div(-gu0, a.res), ggy = M::div(-gu1, a.res);
+    const BlendW<S> bw = blend_weights(cell);
+    const S w4[4] = {bw.w00, bw.w01, bw.w10, bw.w11};
+    const S nz[4] = {gzq * w4[0] - ggx - ggy, gzq * w4[1] + ggx, gzq * w4[2] + ggy, gzq * w4[3]};
+    {   // cell accumulators: same footprint as the previous iteration's -> add; else stash the old ones for the next flush
+      const bool same = !act | (((unsigned)cell.ic == acc_idx[0]) & ((unsigned)cell.ifl == acc_idx[3]));
+      const unsigned ni[4] = {(unsigned)cell.ic, (unsigned)cell.i_f, (unsigned)cell.il, (unsigned)cell.ifl};
+      st_pending = !same;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        st_idx[q] = acc_idx[q]; st_z[q] = acc_z[q]; st_m[q] = acc_m[q];
+        acc_idx[q] = ni[q];
+        acc_z[q] = (same ? acc_z[q] : zero) + nz[q];
+        acc_m[q] = (same ? acc_m[q] : zero) + gmuq * w4[q];
+      }
+    }
+    S zfx, zfy, mfx, mfy;
+    blend_grad(cell, zc[0], zc[1], zc[2], zc[3], &zfx, &zfy);
+    {
+      S ofx, ofy;
+      blend_grad(cell, mc[0], mc[1], mc[2], mc[3], &mfx, &mfy);
+      blend_grad(cell, one, one, one, one, &ofx, &ofy);
+      mfx = has_mu ? mfx : ofx; mfy = has_mu ? mfy : ofy;
+    }
+    dk = kappa; dzx = zfx * a.inv_res; dzy = zfy * a.inv_res;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dw4[q] = w4[q];
+    const S gp[3] = {M::div(gzq * zfx + gmuq * mfx, a.res), M::div(gzq * zfy + gmuq * mfy, a.res), gdh};
+    {   // v_p = xd + w x r;  p = R P + x, r = p - x
+      S t1[3], t2[3];
+      MF_CROSS(t1, gvp, w);           // dr += gvp x w
+      MF_CROSS(t2, r, gvp);           // dw += r x gvp
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        lw[q] += t2[q];
+        lxd[q] += gvp[q];
+        lx[q] += gp[q];
+        const S qa = gp[q] + gr[q] + t1[q];
+        lR[q * 3 + 0] += qa * P[0];
+        lR[q * 3 + 1] += qa * P[1];
+        lR[q * 3 + 2] += qa * P[2];
+      }
+    }
+    {   // e = col0(R) / max(|col0|, eps): through |col0| only when it is >= eps
+      const S dote = (len2 >= (S)1e-12) ? ge[0] * e[0] + ge[1] * e[1] + ge[2] * e[2] : zero;
+      lR[0] += (ge[0] - dote * e[0]) * il;
+      lR[3] += (ge[1] - dote * e[1]) * il;
+      lR[6] += (ge[2] - dote * e[2]) * il;
+    }
+    // ---- what the next iteration reads as totals ----
+    S exo[9] = {lxd[0], lxd[1], lxd[2], lw[0], lw[1], lw[2], gtv, tcw * gtv, gS_p};
+    gs.template post<9>(exo);
+  }
+  {   // the last exchange: control gradient of step 0 and its gS
+    S ex[9];
+    gs.template wait<9>(ex);
+    if (a.gcontrols && n_steps > 0) { gctrl[0] = ex[6]; gctrl[1] = ex[7]; }
+    const S dl = ex[8] * dk;
+    const S g0 = -(dl * dzx), g1 = -(dl * dzy);
+    lx[0] += g0; lx[1] += g1; lx[2] += dl;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { lR[0 * 3 + c] += g0 * P[c]; lR[1 * 3 + c] += g1 * P[c]; lR[2 * 3 + c] += dl * P[c]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc_z[q] -= dl * dw4[q];
+  }
+  flush_stash();
+  if (act) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) atomic_add(at32(gzmap, goff + acc_idx[q]), acc_z[q]);
+    if (want_gmu) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) atomic_add(at32(gmumap, goff + acc_idx[q]), acc_m[q]);
+    }
+  }
+  // output row 0 is the initial state itself (its forces are constant zeros)
+  load_up(0, up);
+  add_upstream_partials(up);
+  S tot[18];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { tot[c] = lx[c]; tot[3 + c] = lxd[c]; tot[6 + c] = lw[c]; }
+#pragma unroll
+  for (int c = 0; c < 9; ++c) tot[9 + c] = lR[c];
+  gs.sum_n(tot);
+
+  // terrain snap of the initial height: x.z = mean_i blend(z; cell((R0 P_i + x0).xy))   (dphysics.py:567-571)
+  S gx0[3] = {tot[0], tot[1], tot[2]};
+  if (!a.skip_snap) {
+    S R0[9], x0[2];
+#pragma unroll
+    for (int c = 0; c < 9; ++c) R0[c] = a.R0[b * 9 + c];
+    x0[0] = a.x_init[b * 3 + 0]; x0[1] = a.x_init[b * 3 + 1];
+    const S g = tot[2] / (S)a.N;
+    S sn6[8] = {zero, zero, zero, zero, zero, zero, zero, zero};   // gpx, gpy, gpx P, gpy P
+    if (act) {
+      const S px = P[0] * R0[0] + P[1] * R0[1] + P[2] * R0[2] + x0[0];
+      const S py = P[0] * R0[3] + P[1] * R0[4] + P[2] * R0[5] + x0[1];
+      const Cell<S> c = locate_m<S, true>(px, py, a.d_max, a.res, a.inv_res, a.H, last);
+      const S v0 = ld32(zmap, moff + (unsigned)c.ic), v1 = ld32(zmap, moff + (unsigned)c.i_f), v2 = ld32(zmap, moff + (unsigned)c.il), v3 = ld32(zmap, moff + (unsigned)c.ifl);
+      atomic_add(at32(gzmap, goff + (unsigned)c.ic), g * (one - c.fx) * (one - c.fy));
+      atomic_add(at32(gzmap, goff + (unsigned)c.i_f), g * (one - c.fx) * c.fy);
+      atomic_add(at32(gzmap, goff + (unsigned)c.il), g * c.fx * (one - c.fy));
+      atomic_add(at32(gzmap, goff + (unsigned)c.ifl), g * c.fx * c.fy);
+      S dfx, dfy;
+      blend_grad(c, v0, v1, v2, v3, &dfx, &dfy);
+      const S gpx = M::div(g * dfx, a.res), gpy = M::div(g * dfy, a.res);
+      sn6[0] = gpx; sn6[1] = gpy;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { sn6[2 + q] = gpx * P[q]; sn6[5 + q] = gpy * P[q]; }
+    }
+    gs.sum_n(sn6);
+    gx0[0] += sn6[0];
+    gx0[1] += sn6[1];
+    gx0[2] = zero;                          // the caller's x0.z is overwritten, so nothing flows to it
+#pragma unroll
+    for (int q = 0; q < 6; ++q) tot[9 + q] += sn6[2 + q];
+  }
+  if (gl == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      if (a.gx0) a.gx0[b * 3 + c] = gx0[c];
+      a.gxd0[b * 3 + c] = tot[3 + c];
+      a.gw0[b * 3 + c] = tot[6 + c];
+    }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) a.gR0[b * 9 + c] = tot[9 + c];
+  }
+}
+
+// defined in rollout_bwd_mw_fast.hip
+bool use_multiwave_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p);   // this backward goes to the kernels above
+long long mw_record_bytes(const MfRolloutDesc* d);                           // bytes of the record the forward keeps for them (0: none)
+int launch_rollout_bwd_mw_f32(const RolloutBwdArgs<float>& a, int G, bool xs_only, hipStream_t st);
+
+}  // namespace mf

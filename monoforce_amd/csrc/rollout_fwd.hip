@@ -2,6 +2,8 @@
 // This TU is compiled with -ffp-contract=off; the FMA-contracted float32 kernels live in rollout_fwd_fast.hip.
 #include "rollout_fwd_cp2_kernel.h"
 
+namespace mf { long long mw_record_bytes(const MfRolloutDesc* d); }   // rollout_bwd_mw_fast.hip
+
 namespace mf {
 
 template <typename S>
@@ -163,6 +165,10 @@ extern "C" int mf_rollout_fwd_f32(const MfRolloutDesc* d, const MfRolloutFwdBufs
       return mf::launch_rollout_fwd_zmu_f32(a, m, d->integrator, block, forces, split, 0, (hipStream_t)s);
     if (split)
       return mf::launch_rollout_fwd_split_fast_f32(a, m, d->integrator, block, forces, (hipStream_t)s);
+    if (p->rec && mf::mw_record_bytes(d) > 0) {      // one rollout over several waves: the record of its backward (rollout_bwd_mw_kernel.h)
+      MF_REQUIRE(((uintptr_t)p->rec & 15) == 0, MF_ERR_INVALID, "rollout_fwd: rec must be 16-byte aligned");
+      a.rec = (float*)p->rec;
+    }
     return mf::launch_rollout_fwd_fast_f32(a, m, d->integrator, block, forces, (hipStream_t)s);
   }
   MF_REQUIRE(!p->loss, MF_ERR_UNSUPPORTED, "rollout_fwd: the fused physics loss exists for the float32 fast-math kernels only");

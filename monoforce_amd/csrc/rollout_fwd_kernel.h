@@ -218,7 +218,7 @@ __device__ __forceinline__ void articulate_body(GroupSum<G, S>& gs, const S* ja,
   Iv[6] = c02 * idet; Iv[7] = c12 * idet; Iv[8] = c22 * idet;
 }
 
-template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS = false, bool FORCES = true, int COST = 0, bool SPLIT = false, bool ZMU = false>
+template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS = false, bool FORCES = true, int COST = 0, bool SPLIT = false, bool ZMU = false, bool REC = false>
 __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const RolloutArgs<S> a) {
   using M = Mth<S, FAST>;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -606,13 +606,14 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
       }
     };
     // ... and from the summed wrench to the accelerations: wd = clamp(I^-1 tau), xdd = (m g ghat + sum F) / m
-    auto accelerations = [&](const S (&wr)[kWr], S (&xdd)[3], S (&wd)[3]) {
+    auto accelerations = [&](const S (&wr)[kWr], S (&xdd)[3], S (&wd)[3], S (&wraw)[3]) {
       const S* sTau = wr + (FAST ? 3 : 6);
       // omega_d = clamp(I^-1 tau) (body-frame I with world-frame torque, as the reference)   (:256-257)
   #pragma unroll
-      for (int c = 0; c < 3; ++c)
-        wd[c] = M::clamp(Iv[c * 3 + 0] * sTau[0] + Iv[c * 3 + 1] * sTau[1] + Iv[c * 3 + 2] * sTau[2],
-                         -a.omega_max, a.omega_max);
+      for (int c = 0; c < 3; ++c) {
+        wraw[c] = Iv[c * 3 + 0] * sTau[0] + Iv[c * 3 + 1] * sTau[1] + Iv[c * 3 + 2] * sTau[2];
+        wd[c] = M::clamp(wraw[c], -a.omega_max, a.omega_max);
+      }
       // xdd = (m g ghat + sum Fs + sum Ff) / m   (:264-266)
       if (FAST) { xdd[0] = wr[0] * a.inv_mass; xdd[1] = wr[1] * a.inv_mass; xdd[2] = (wr[2] - a.mg) * a.inv_mass; }
       else { xdd[0] = (wr[0] + wr[3]) / a.mass; xdd[1] = (wr[1] + wr[4]) / a.mass; xdd[2] = ((-a.mg + wr[2]) + wr[5]) / a.mass; }
@@ -701,8 +702,16 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
       asm volatile("" : "+v"(g_next.cell[0].ic) :: "memory");
       request(g_next);                            // ---- under the wrench's LDS write: the cells of step n + 1
       gs.template wait<kWr>(wr);
-      S xdd[3], wd[3];
-      accelerations(wr, xdd, wd);
+      S xdd[3], wd[3], wraw[3];
+      accelerations(wr, xdd, wd, wraw);
+      if constexpr (REC) {
+        // the multi-wave backward's record (rollout_bwd_mw_kernel.h): the contact count and the unclamped angular acceleration
+        // this step evaluated, 16 bytes per rollout-step; every lane stores the same quad to the same address (no branch: the
+        // arithmetic of the step stays one basic block, so the trajectory's bits are those of the kernel without a record)
+        typedef float f4v __attribute__((ext_vector_type(4)));
+        const f4v rv = {cs1[0], wraw[0], wraw[1], wraw[2]};
+        __builtin_nontemporal_store(rv, reinterpret_cast<f4v*>(a.rec + ((size_t)n * a.B + b) * 4));
+      }
       advance_velocities(q, xdd, wd, h_ode);
       cv = cv_next; cw = cw_next;
       h_ode = ts_b - ts_a;
@@ -1005,6 +1014,24 @@ int launch_rollout_fwd(const RolloutArgs<S>& a, LaneMap m, int integ, int block,
 #undef MF_CASE
   MF_REQUIRE(launched, MF_ERR_UNSUPPORTED, "rollout_fwd: no kernel for this lane mapping");
   }
+  hipError_t e = hipGetLastError();
+  MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("rollout_fwd launch: ") + hipGetErrorString(e));
+  return MF_OK;
+}
+
+// The multi-wave mappings of the default integrator with the record for their backward (rollout_bwd_mw_kernel.h): a.rec != NULL.
+template <bool FORCES>
+int launch_rollout_fwd_mw_rec(const RolloutArgs<float>& a, LaneMap m, hipStream_t st) {
+  bool launched = false;
+#define MF_CASE(G_)                                                                                                          \
+  if (!launched && m.G == G_ && m.PPL == 1) {                                                                                \
+    launched = true;                                                                                                         \
+    hipLaunchKernelGGL((rollout_fwd_kernel<float, G_, 1, MF_INTEG_ODEINT_EULER, true, false, FORCES, 0, false, false, true>), \
+                       dim3(a.B), dim3(G_), 0, st, a);                                                                       \
+  }
+  MF_CASE(128) MF_CASE(256) MF_CASE(512)
+#undef MF_CASE
+  MF_REQUIRE(launched, MF_ERR_UNSUPPORTED, "rollout_fwd: no recording kernel for this lane mapping");
   hipError_t e = hipGetLastError();
   MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("rollout_fwd launch: ") + hipGetErrorString(e));
   return MF_OK;

@@ -1,0 +1,124 @@
+"""The multi-wave backward (csrc/rollout_bwd_mw_kernel.h): ONE rollout of a 65..512-point body over 2 / 4 / 8 waves, float32 fast
+math, default integrator, reading the forward's 16-byte record -- against the CPU oracle (the restated reference autograd,
+dphysics.py:172-272, 499-528) and against the general one-wave kernel (`points_per_lane=4`, which recomputes everything)."""
+import ctypes as C
+
+import pytest
+import torch
+
+from tests import helpers as hp
+from tests.test_rollout_gpu import make_dphysics
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _problem(B, N, T, n_tracks, shared):
+    from monoforce_amd import synthetic as syn
+    pts, masks = syn.robot_points_box(N, seed=N + B, n_tracks=n_tracks)
+    nb = 1 if shared else B
+    z = torch.stack([syn.bump_terrain(syn.bump_params(20 + b), 3.2, 0.1, torch.float64) * 0.3 for b in range(nb)]).float()
+    mu = torch.stack([syn.wave_friction(3.2, 0.1, 0.5, 1.0, 1.0 + b, 0.8, torch.float64) for b in range(nb)]).float()
+    ctrl = syn.varying_controls(B, T, seed=N, dtype=torch.float64).float()
+    return pts, masks, z, mu, ctrl
+
+
+def _loss(outs, xs_only):
+    if xs_only:      # positions at a few rows only: every other upstream gradient arrives as None (physics_loss, losses.py:102-127)
+        Xs = outs[0]
+        from monoforce_amd import synthetic as syn
+        return (Xs[:, ::7] * syn.probe_weights(Xs[:, ::7].shape, phase=0.3, dtype=torch.float32).to(Xs.device)).sum()
+    return hp.probe_loss(outs, torch.float32)
+
+
+def _grads(fn, dev, z, mu, ctrl, B, xs_only, state=None):
+    zl, ml, cl = (t.clone().to(dev).requires_grad_(True) for t in (z, mu, ctrl))
+    st = None
+    if state is not None:
+        st = [s.clone().float().to(dev) for s in state]
+        for s in st[1:]:
+            s.requires_grad_(True)
+    expand = lambda m: m.expand(B, -1, -1) if m.shape[0] == 1 else m  # noqa: E731
+    outs = fn(expand(zl), cl, expand(ml), None if st is None else tuple(st))
+    _loss(outs, xs_only).backward()
+    leaves = [zl, ml, cl] + (st[1:] if st is not None else [])
+    g = [l.grad if l.grad is not None else torch.zeros_like(l) for l in leaves]      # (T = 1: nothing depends on mu / controls)
+    return [o.detach().cpu() for o in outs], [t.cpu() for t in g]
+
+
+def test_the_record_is_requested_for_these_launches():
+    from monoforce_amd import _lib
+    def rec_bytes(B, N, integ=1, ppl=0, fast=1, T=100):  # noqa: E306
+        d = _lib.MfRolloutDesc(B=B, T=T, N=N, H=64, W=64, n_tracks=2, integrator=integ, points_per_lane=ppl, math_mode=fast)
+        return int(_lib.lib().mf_rollout_record_bytes(C.byref(d)))
+    assert rec_bytes(64, 223) == 100 * 64 * 16 and rec_bytes(4, 100) == 100 * 4 * 16 and rec_bytes(8, 400) == 100 * 8 * 16
+    assert rec_bytes(64, 223, integ=0) == 0 and rec_bytes(64, 223, ppl=4) == 0 and rec_bytes(64, 223, fast=0) == 0
+    assert rec_bytes(4096, 223) == 0 and rec_bytes(64, 64) == 0      # one wave per rollout there
+
+
+@pytest.mark.parametrize('B,N,n_tracks,T', [(3, 100, 2, 40), (5, 223, 4, 40), (2, 300, 2, 25), (2, 400, 4, 25), (64, 223, 2, 12), (1, 175, 2, 1), (2, 175, 2, 2)])
+@pytest.mark.parametrize('xs_only', [False, True])
+@pytest.mark.parametrize('shared', [False, True])
+def test_multiwave_backward_vs_oracle_and_one_wave_kernel(B, N, n_tracks, T, xs_only, shared):
+    from oracle import dphysics_oracle as orc
+    from tests.golden_state import given_state
+    pts, masks, z, mu, ctrl = _problem(B, N, T, n_tracks, shared)
+    state = given_state(B) if (B <= 5 and not xs_only) else None
+    spec = hp.spec_from(pts, masks, 1, 0.1, 3.2)
+
+    def f_oracle(zz, cc, mm, st):
+        so, fo = orc.rollout(spec, zz, cc, state=st, friction=mm)
+        return list(so) + list(fo)
+
+    def f_hip(ppl):
+        dp = make_dphysics(pts, masks, 1, 0.1, 3.2, points_per_lane=ppl)
+        def run(zz, cc, mm, st):  # noqa: E306
+            so, fo = dp(zz, cc, state=st, friction=mm)
+            return list(so) + list(fo)
+        return run
+
+    o_ref, g_ref = _grads(f_oracle, 'cpu', z, mu, ctrl, B, xs_only, state)
+    o_mw, g_mw = _grads(f_hip(0), DEV, z, mu, ctrl, B, xs_only, state)
+    o_1w, g_1w = _grads(f_hip(4), DEV, z, mu, ctrl, B, xs_only, state)
+    names = ('z', 'mu', 'controls', 'xd0', 'R0', 'w0')
+    for nm, a, b, c in zip(names, g_mw, g_ref, g_1w):
+        assert torch.isfinite(a).all(), nm
+        # two float32 evaluation orders of these contact-rich rollouts sit 1-2e-4 apart themselves (test_random_shapes_gpu.py)
+        assert hp.rel_err(a, b) <= 2e-3, (nm, 'vs oracle', hp.rel_err(a, b))
+        assert hp.rel_err(a, c) <= 2e-3, (nm, 'vs the one-wave kernel', hp.rel_err(a, c))
+    for k, a, b in zip(hp.OUT_KEYS, o_mw, o_1w):      # the recording forward writes the outputs of the plain one
+        tol = 5e-4 if k in ('Xs', 'Rs') else (3e-2 if k in ('Fs', 'Ff') else 2e-3)
+        assert hp.rel_err(a, b) <= tol, (k, hp.rel_err(a, b))
+
+
+def test_recording_forward_is_bit_identical_to_the_plain_one():
+    """The record's store must not change a bit of the trajectory (no_grad runs the kernels without it)."""
+    pts, masks, z, mu, ctrl = _problem(4, 223, 60, 2, True)
+    dp = make_dphysics(pts, masks, 1, 0.1, 3.2)
+    zz, mm, cc = z.to(DEV).expand(4, -1, -1), mu.to(DEV).expand(4, -1, -1), ctrl.to(DEV)
+    with torch.no_grad():
+        s0, f0 = dp(zz, cc, friction=mm)
+    s1, f1 = dp(zz.clone().requires_grad_(True), cc, friction=mm)
+    for a, b in zip(list(s0) + list(f0), list(s1) + list(f1)):
+        assert torch.equal(a, b.detach())
+
+
+def test_multiwave_backward_is_deterministic_and_independent_of_the_batch():
+    """Run to run the same bits for the state gradients (the map gradients are float atomics), and rollout b of a batch has the
+    gradients it has alone."""
+    pts, masks, z, mu, ctrl = _problem(6, 223, 50, 4, False)
+    dp = make_dphysics(pts, masks, 1, 0.1, 3.2)
+
+    def run(sel):
+        zl, cl = z[sel].to(DEV).requires_grad_(True), ctrl[sel].to(DEV).requires_grad_(True)
+        so, fo = dp(zl, cl, friction=mu[sel].to(DEV))
+        sum((o * o).sum() * sc for o, sc in zip(list(so) + list(fo), (1.0, 1.0, 1.0, 1.0, 1e-6, 1e-6))).backward()
+        return zl.grad.cpu(), cl.grad.cpu()
+
+    za, ca = run(slice(0, 6))
+    zb, cb = run(slice(0, 6))
+    assert torch.equal(ca, cb)
+    assert hp.rel_err(za, zb) <= 1e-6
+    z1, c1 = run(slice(2, 3))
+    assert torch.equal(c1[0], ca[2])
+    assert hp.rel_err(z1[0], za[2]) <= 1e-6
