@@ -5,14 +5,19 @@
 
 namespace mf {
 
-// The launches the multi-wave mapping of choose_lane_map serves (a body of 65..512 points, <= 2048 waves), float32 MF_MATH_FAST,
-// default integrator, rigid body.  MF_MW_BWD=0 keeps the general kernel (A/B runs, parity tests of the two against each other).
+// The launches these kernels serve: float32 MF_MATH_FAST, default integrator, rigid body, one point per lane --
+//   * bodies of 65..512 points spread over 2 / 4 / 8 waves by choose_lane_map (<= 2048 waves per launch), and
+//   * bodies of 5..64 points (8 / 16 / 32 / 64 lanes per rollout) below one wave per SIMD, where the forward runs a kernel with
+//     plain stores (the split-store kernels of larger launches keep no record).  N <= 4 has the component-parallel kernels.
+// MF_MW_BWD=0 keeps the general kernel (A/B runs, parity tests of the two against each other).
 static bool mw_shape(const MfRolloutDesc* d) {
   static const bool off = getenv("MF_MW_BWD") && atoi(getenv("MF_MW_BWD")) == 0;
-  if (off || !d || d->B <= 0 || d->T <= 0 || d->N <= 64 || d->N > 512) return false;
+  if (off || !d || d->B <= 0 || d->T <= 0 || d->N <= 4 || d->N > 512) return false;
   if (d->math_mode != MF_MATH_FAST || d->integrator != MF_INTEG_ODEINT_EULER || d->has_joints) return false;
   if (d->points_per_lane == 4) return false;
-  return choose_lane_map(d->B, d->N, d->points_per_lane == MF_LANES_COMPONENT ? 0 : d->points_per_lane).G > 64;
+  const LaneMap m = choose_lane_map(d->B, d->N, d->points_per_lane == MF_LANES_COMPONENT ? 0 : d->points_per_lane);
+  if (m.PPL != 1 || m.G < 8) return false;
+  return m.G > 64 || (long long)d->B * m.G < 1024ll * 64;
 }
 long long mw_record_bytes(const MfRolloutDesc* d) {
   if (!mw_shape(d)) return 0;
@@ -23,14 +28,29 @@ bool use_multiwave_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p) {
 }
 
 int launch_rollout_bwd_mw_f32(const RolloutBwdArgs<float>& a, int G, bool xs_only, hipStream_t st) {
+  // LDS gradient tiles (rollout_bwd_mw_kernel.h) while every workgroup of the launch is resident with its tiles: 160 KB per CU,
+  // 256 CUs.  MF_MW_TILE=0 keeps the register accumulators (A/B runs, parity of the two routes).
+  static const bool tile_off = getenv("MF_MW_TILE") && atoi(getenv("MF_MW_TILE")) == 0;
   bool launched = false;
 #define MF_CASE(G_)                                                                                              \
   if (!launched && G == G_) {                                                                                    \
     launched = true;                                                                                             \
-    if (xs_only) hipLaunchKernelGGL((rollout_bwd_mw_kernel<G_, true>), dim3(a.B), dim3(G_), 0, st, a);           \
-    else hipLaunchKernelGGL((rollout_bwd_mw_kernel<G_, false>), dim3(a.B), dim3(G_), 0, st, a);                  \
+    constexpr int blk = G_ > 64 ? G_ : 64;                                                                       \
+    constexpr int TE = mw_tile_edge(G_);                                                                         \
+    constexpr long long lds = (long long)(G_ > 64 ? 1 : 64 / G_) * 2 * (TE + 1) * TE * 4 + 4096;                       \
+    const unsigned grid = (unsigned)(((long long)a.B * G_ + blk - 1) / blk);                                     \
+    const bool tile = TE > 0 && !tile_off && (long long)((grid + 255) / 256) * lds <= 160 * 1024 && (long long)a.H * a.W < (1ll << 30); \
+    if (tile) {                                                                                                  \
+      if constexpr (TE > 0) {                                                                                    \
+        if (xs_only) hipLaunchKernelGGL((rollout_bwd_mw_kernel<G_, true, TE>), dim3(grid), dim3(blk), 0, st, a); \
+        else hipLaunchKernelGGL((rollout_bwd_mw_kernel<G_, false, TE>), dim3(grid), dim3(blk), 0, st, a);        \
+      }                                                                                                          \
+    } else {                                                                                                     \
+      if (xs_only) hipLaunchKernelGGL((rollout_bwd_mw_kernel<G_, true, 0>), dim3(grid), dim3(blk), 0, st, a);    \
+      else hipLaunchKernelGGL((rollout_bwd_mw_kernel<G_, false, 0>), dim3(grid), dim3(blk), 0, st, a);           \
+    }                                                                                                            \
   }
-  MF_CASE(128) MF_CASE(256) MF_CASE(512)
+  MF_CASE(8) MF_CASE(16) MF_CASE(32) MF_CASE(64) MF_CASE(128) MF_CASE(256) MF_CASE(512)
 #undef MF_CASE
   MF_REQUIRE(launched, MF_ERR_UNSUPPORTED, "rollout_bwd: no multi-wave kernel for this lane mapping");
   hipError_t e = hipGetLastError();

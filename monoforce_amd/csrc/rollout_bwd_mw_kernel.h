@@ -23,18 +23,49 @@
 
 namespace mf {
 
+// o += a x b with every product fused into the accumulation: two instructions per component (a cross product formed on its own
+// and added afterwards takes three)
+#define MF_CROSS_ACC(o0, o1, o2, a, b)                                 \
+  do {                                                                 \
+    (o0) = fmaf(-(a)[2], (b)[1], fmaf((a)[1], (b)[2], (o0)));          \
+    (o1) = fmaf(-(a)[0], (b)[2], fmaf((a)[2], (b)[0], (o1)));          \
+    (o2) = fmaf(-(a)[1], (b)[0], fmaf((a)[0], (b)[1], (o2)));          \
+  } while (0)
+
 constexpr int kMwRecFloats = 4;   // per rollout-step: (sum of contact weights, omega_d before its clamp [3])
 
-template <int G, bool XS_ONLY>
-__global__ void __launch_bounds__(G) rollout_bwd_mw_kernel(const RolloutBwdArgs<float> a) {
+// Map gradients.  A point adds to the four cells of its footprint per map and step; it moves <= 0.2 cell per step, so the
+// contributions are summed in registers while the footprint stays (rollout_bwd_kernel.h) and written out when it changes, one
+// iteration late, behind that step's loads.  TILE = 0 writes them with device-scope float atomics: they execute at the memory side
+// (a fabric transaction each, ~20 ns apart on one address) and sit in the wave's in-order `vmcnt` queue in front of every later
+// load -- 0.20-0.24 ms of a 1.0-1.1 ms launch (A/B build without them).  TILE > 0 sends them to an LDS tile of TILE x TILE cells
+// (x 2 maps) that follows the robot: `ds_add_f32` from the lanes whose footprint just changed; the tile goes out to the gradient
+// maps (one atomic per touched cell) when the body has moved a quarter of the window from its centre, and after the loop.
+// Points off the map edge or outside the window (the reference folds and wraps their flat indices, dphysics.py:427-435) keep
+// the direct route.  (Measured and dropped: EVERY step's contributions straight into the tile, no register accumulators --
+// the LDS retires about one atomic lane per cycle and CU, so 8 instructions x 64 lanes x 4 waves cost 2000 cycles per step:
+// 1.53 instead of 1.10 ms at 64 rollouts x 223 points.)  The host picks TILE > 0 where all workgroups fit the CUs' LDS at once.
+template <int G, bool XS_ONLY, int TILE>
+__global__ void __launch_bounds__(G > 64 ? G : 64) rollout_bwd_mw_kernel(const RolloutBwdArgs<float> a) {
   using S = float;
   using M = Mth<float, true>;
-  constexpr int NW = G / 64;
-  const int b = blockIdx.x;        // one rollout per workgroup
-  const int gl = threadIdx.x;      // one contact point per lane
+  constexpr int NW = G > 64 ? G / 64 : 1;
+  // G > 64: one rollout per workgroup of G / 64 waves.  G <= 64: 64 / G rollouts per one-wave workgroup, the exchange is a DPP sum
+  const int tid = blockIdx.x * (G > 64 ? G : 64) + threadIdx.x;
+  const int b = tid / G;
+  const int gl = tid % G;          // one contact point per lane
+  if (b >= a.B) return;            // whole groups leave together (G <= 64 only: no barrier in those kernels)
   const S one = 1.0f, zero = 0.0f;
   const int HW = a.H * a.W, last = HW - 1;
-  __shared__ S gs_lds[2 * NW * kGroupSumMaxValues];
+  __shared__ S gs_lds[G > 64 ? 2 * NW * kGroupSumMaxValues : 1];
+  constexpr int NT = G > 64 ? 1 : 64 / G;                       // rollouts = tiles per workgroup
+  // (rows of TILE cells at a pitch of TILE + 1 words: neighbours in x would otherwise share an LDS bank, and a wave's 64 points
+  //  spread over a dozen columns -- measured at TILE = 64 without the pad: 1.54 instead of 1.10 ms at 64 x 223 points)
+  constexpr int TS = TILE + 1;
+  constexpr int T2 = TS * TILE;                                 // words per plane
+  __shared__ S tile_lds[TILE > 0 ? NT * 2 * T2 : 1];
+  S* const tile_z = tile_lds + (G > 64 ? 0 : (int)(threadIdx.x / G) * 2 * T2);      // this rollout's tile: z plane, then mu plane
+  int ocx = 0, ocy = 0;                                        // cell under the tile's centre (group-uniform)
   GroupSum<G, S> gs;
   gs.lds = gs_lds;
   const unsigned moff = a.map_shared ? 0u : (unsigned)b * (unsigned)HW;
@@ -121,37 +152,73 @@ __global__ void __launch_bounds__(G) rollout_bwd_mw_kernel(const RolloutBwdArgs<
   unsigned acc_idx[4] = {0u, 0u, 0u, 0u}, st_idx[4] = {0u, 0u, 0u, 0u};
   S acc_z[4] = {zero, zero, zero, zero}, acc_m[4] = {zero, zero, zero, zero}, st_z[4], st_m[4];
   bool st_pending = false;
+  int acc_t = -1, st_t = -1;      // TILE: tile index of the accumulators' / the stash's first cell, -1 = direct route (acc_idx / st_idx)
 #pragma unroll
   for (int q = 0; q < 4; ++q) st_z[q] = st_m[q] = zero;
-  auto flush_stash = [&]() {
-    if (st_pending) {
+  // four cells per map to the LDS tile (t >= 0: index of the footprint's first cell) or straight to the gradient maps
+  auto emit_cells = [&](int t, const unsigned (&idx)[4], const S (&vz)[4], const S (&vm)[4]) {
+    if (TILE > 0 && t >= 0) {
+      S* tz = tile_z + t;
+      __hip_atomic_fetch_add(tz, vz[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(tz + TS, vz[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(tz + 1, vz[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(tz + TS + 1, vz[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (want_gmu) {
+        S* tm = tz + T2;
+        __hip_atomic_fetch_add(tm, vm[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(tm + TS, vm[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(tm + 1, vm[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(tm + TS + 1, vm[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    } else {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) atomic_add(at32(gzmap, goff + st_idx[q]), st_z[q]);
+      for (int q = 0; q < 4; ++q) atomic_add(at32(gzmap, goff + idx[q]), vz[q]);
       if (want_gmu) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) atomic_add(at32(gmumap, goff + st_idx[q]), st_m[q]);
+        for (int q = 0; q < 4; ++q) atomic_add(at32(gmumap, goff + idx[q]), vm[q]);
       }
     }
+  };
+  auto flush_stash = [&]() {
+    if (st_pending) emit_cells(st_t, st_idx, st_z, st_m);
     st_pending = false;
   };
   // what the deferred gS correction of the previous iteration's step needs: kappa = d(dh adjoint)/d(gS), the footprint's weights
   // and the height blend's derivatives over res
   S dk = zero, dzx = zero, dzy = zero, dw4[4] = {zero, zero, zero, zero};
 
+  auto tile_sync = [&]() { if constexpr (G > 64) __syncthreads(); };
+  auto tile_clear = [&]() {
+    if constexpr (TILE > 0) {
+      for (int i = gl; i < 2 * T2; i += G) tile_z[i] = zero;
+    }
+  };
+  auto tile_flush = [&]() {   // the tile's non-zero cells to the gradient maps, the tile back to zero
+    if constexpr (TILE > 0) {
+      const int ox = ocx - TILE / 2, oy = ocy - TILE / 2;
+      for (int k = gl; k < TILE * TILE; k += G) {
+        const int i = (k % TILE) + TS * (k / TILE);
+        const S vz = tile_z[i], vm = tile_z[T2 + i];
+        tile_z[i] = zero; tile_z[T2 + i] = zero;
+        if (vz != zero || vm != zero) {
+          const unsigned flat = (unsigned)((oy + (k % TILE)) + a.H * (ox + (k / TILE)));
+          atomic_add(at32(gzmap, goff + flat), vz);
+          if (want_gmu) atomic_add(at32(gmumap, goff + flat), vm);
+        }
+      }
+    }
+  };
+  auto centre_cell = [&](const S* xs, int& cx, int& cy) {
+    const S lim = (S)262144.0;
+    cx = (int)M::clamp((xs[0] + a.d_max) * a.inv_res, -lim, lim);
+    cy = (int)M::clamp((xs[1] + a.d_max) * a.inv_res, -lim, lim);
+  };
   if (gl == 0 && a.gcontrols) { gctrl[(a.T - 1) * 2 + 0] = zero; gctrl[(a.T - 1) * 2 + 1] = zero; }   // the last control is never used
 
-  StepIn cur;
-  UpIn up;
-  load_step(max(n_steps - 1, 0), cur);
-  load_up(min(n_steps, a.T - 1), up);
-  {   // the exchange the first iteration fetches: nothing yet
-    S ex0[9];
-#pragma unroll
-    for (int k = 0; k < 9; ++k) ex0[k] = zero;
-    gs.template post<9>(ex0);
-  }
-  __builtin_amdgcn_s_waitcnt(0);
-  for (int n = n_steps - 1; n >= 0; --n) {
+  S ex[9];      // the step's exchange: partials in, group totals out
+  // One step of the reverse scan.  (cur, upn) = the inputs of step n, loaded an iteration ago; (nxt, up_nxt) receive those of step
+  // n - 1.  The loop calls it twice per trip with the two buffer pairs swapped: no register copies at the back edge.
+  auto one_step = [&](const int n, const StepIn& cur, const UpIn& upn, StepIn& nxt, UpIn& up_nxt) {
     S x[3], xd[3], R[9], w[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) { x[c] = cur.x[c]; xd[c] = cur.xd[c]; w[c] = cur.w[c]; }
@@ -160,7 +227,6 @@ __global__ void __launch_bounds__(G) rollout_bwd_mw_kernel(const RolloutBwdArgs<
     const S cv = cur.cv, cw = cur.cw, h = cur.t1 - cur.t0;
     const S csum = cur.csum;
     const S wraw[3] = {cur.wraw[0], cur.wraw[1], cur.wraw[2]};
-    const UpIn upn = up;
 
     // ---- geometry of the point under pose n, requests for its cells ----
     const S px = P[0] * R[0] + P[1] * R[1] + P[2] * R[2] + x[0];
@@ -168,17 +234,25 @@ __global__ void __launch_bounds__(G) rollout_bwd_mw_kernel(const RolloutBwdArgs<
     const S pz = P[0] * R[6] + P[1] * R[7] + P[2] * R[8] + x[2];
     const S r[3] = {px - x[0], py - x[1], pz - x[2]};
     const Cell<S> cell = locate_m<S, true>(px, py, a.d_max, a.res, a.inv_res, a.H, last);
+    // (ix, iy) of the footprint's first cell: locate_m's own arithmetic (trunc(u) == u - fraction exactly)
+    const int ix = (int)(M::cell_coord(px, a.d_max, a.res, a.inv_res) - cell.fx), iy = (int)(M::cell_coord(py, a.d_max, a.res, a.inv_res) - cell.fy);
     S zc[4], mc[4];
+#ifdef MF_MW_DBG_NOGATHER      // A/B hook (tools/build_variant.sh): the step without its map gathers
+    zc[0] = zc[1] = zc[2] = zc[3] = P[2]; mc[0] = mc[1] = mc[2] = mc[3] = one;
+#else
     gather4(zmap, moff, cell, last, zc);
     gather4(mumap, moff, cell, last, mc);
+#endif
     // ---- deferred atomics of the previous iteration, prefetch of the next one's rows (younger than the gathers) ----
     flush_stash();
-    load_step(max(n - 1, 0), cur);
-    load_up(n, up);
+    load_step(max(n - 1, 0), nxt);
+    load_up(n, up_nxt);
 
     // ---- the exchange posted by the previous iteration: totals of the velocity adjoints, the control gradient of step n + 1, gS ----
-    S ex[9];
+    // (`ex` lives across iterations: within a wave, G <= 64, post() leaves the group totals in it and wait() is empty)
+#ifndef MF_MW_DBG_NOEXCHANGE
     gs.template wait<9>(ex);
+#endif
     if (a.gcontrols && n + 1 < n_steps) { gctrl[(n + 1) * 2 + 0] = ex[6]; gctrl[(n + 1) * 2 + 1] = ex[7]; }
     {   // gS of step n + 1, one step late: dh adjoint += gS kappa  ->  height sample, position, rotation partials, cell accumulators
       const S dl = ex[8] * dk;
@@ -188,6 +262,22 @@ __global__ void __launch_bounds__(G) rollout_bwd_mw_kernel(const RolloutBwdArgs<
       for (int c = 0; c < 3; ++c) { lR[0 * 3 + c] += g0 * P[c]; lR[1 * 3 + c] += g1 * P[c]; lR[2 * 3 + c] += dl * P[c]; }
 #pragma unroll
       for (int q = 0; q < 4; ++q) acc_z[q] -= dl * dw4[q];
+    }
+    if constexpr (TILE > 0) {
+      // the window follows the body: once it has moved a quarter of the window, the accumulators go to the tile, the tile out to
+      // the maps, and the window is centred under the body again (group-uniform; a workgroup-uniform branch for G > 64)
+      int cx, cy;
+      centre_cell(x, cx, cy);
+      if (abs(cx - ocx) > TILE / 4 || abs(cy - ocy) > TILE / 4) {
+        if (act) emit_cells(acc_t, acc_idx, acc_z, acc_m);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { acc_z[q] = acc_m[q] = zero; }
+        acc_t = -1;      // (the zeroed accumulators keep their cells: the next change of footprint stashes zeros for them)
+        tile_sync();
+        tile_flush();
+        ocx = cx; ocy = cy;
+        tile_sync();
+      }
     }
     // ---- upstream of output row n + 1 ----
     S Sxd[3] = {ex[0], ex[1], ex[2]}, Sw[3] = {ex[3], ex[4], ex[5]};
@@ -208,11 +298,8 @@ __global__ void __launch_bounds__(G) rollout_bwd_mw_kernel(const RolloutBwdArgs<
     for (int c = 0; c < 3; ++c) {                                    // R' = R + h [w]x R, column by column
       const S gcol[3] = {h * lR[0 * 3 + c], h * lR[1 * 3 + c], h * lR[2 * 3 + c]};
       const S rc[3] = {R[0 * 3 + c], R[1 * 3 + c], R[2 * 3 + c]};
-      S t1[3], t2[3];
-      MF_CROSS(t1, rc, gcol);
-      lw[0] += t1[0]; lw[1] += t1[1]; lw[2] += t1[2];
-      MF_CROSS(t2, gcol, w);
-      lR[0 * 3 + c] += t2[0]; lR[1 * 3 + c] += t2[1]; lR[2 * 3 + c] += t2[2];
+      MF_CROSS_ACC(lw[0], lw[1], lw[2], rc, gcol);                                // d/dw of (w x R_c) . g  =  R_c x g
+      MF_CROSS_ACC(lR[0 * 3 + c], lR[1 * 3 + c], lR[2 * 3 + c], gcol, w);         // d/dR_c                  =  g x w
     }
 
     // ---- forward recompute of the point's contact (rollout_fwd_kernel.h, PIPE path) ----
@@ -259,13 +346,12 @@ __global__ void __launch_bounds__(G) rollout_bwd_mw_kernel(const RolloutBwdArgs<
       for (int c = 0; c < 3; ++c) gtau[c] = Iv[0 * 3 + c] * m0_ + Iv[1 * 3 + c] * m1_ + Iv[2 * 3 + c] * m2_;   // Iinv^T
     }
     const S f[3] = {Fr[0] + Ff[0], Fr[1] + Ff[1], Fr[2] + Ff[2]};
-    S gf[3], gr[3];
-    MF_CROSS(gf, gtau, r);            // tau += r x f : df = gtau x r
-    MF_CROSS(gr, f, gtau);            //                dr = f x gtau
+    S gf[3] = {gxdd[0] * a.inv_mass, gxdd[1] * a.inv_mass, gxdd[2] * a.inv_mass};      // xdd = sum F / m ...
+    MF_CROSS_ACC(gf[0], gf[1], gf[2], gtau, r);      // ... and tau += r x f : df = gtau x r
     S gFr_[3], gG[3];
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      const S com = gxdd[c] * a.inv_mass + gf[c];
+      const S com = gf[c];
       gFr_[c] = XS_ONLY ? com : h * laFs[c] + com;
       const S gFf_ = XS_ONLY ? com : h * laFf[c] + com;
       gG[c] = inside(Gf[c], -a.mg, a.mg) ? gFf_ : zero;
@@ -281,9 +367,10 @@ __global__ void __launch_bounds__(G) rollout_bwd_mw_kernel(const RolloutBwdArgs<
     S gvp[3] = {-gcmd[0], -gcmd[1], -gcmd[2]};
     const S gtv = drv * (gcmd[0] * e[0] + gcmd[1] * e[1] + gcmd[2] * e[2]);      // track speed of a driving point (tv = 0 elsewhere)
     const S ge[3] = {tv * gcmd[0], tv * gcmd[1], tv * gcmd[2]};
-    if (Nn > zero) {
+    {      // |F_n|: zero gradient at F_n = 0
+      const S s_ = gNn * (Nn > zero ? M::div(one, Nn) : zero);
 #pragma unroll
-      for (int c = 0; c < 3; ++c) gFr_[c] += M::div(gNn * Fr[c], Nn);
+      for (int c = 0; c < 3; ++c) gFr_[c] += s_ * Fr[c];
     }
     S gF1[3], d = zero, gA = zero;
 #pragma unroll
@@ -309,10 +396,19 @@ __global__ void __launch_bounds__(G) rollout_bwd_mw_kernel(const RolloutBwdArgs<
     const BlendW<S> bw = blend_weights(cell);
     const S w4[4] = {bw.w00, bw.w01, bw.w10, bw.w11};
     const S nz[4] = {gzq * w4[0] - ggx - ggy, gzq * w4[1] + ggx, gzq * w4[2] + ggy, gzq * w4[3]};
-    {   // cell accumulators: same footprint as the previous iteration's -> add; else stash the old ones for the next flush
-      const bool same = !act | (((unsigned)cell.ic == acc_idx[0]) & ((unsigned)cell.ifl == acc_idx[3]));
+    int new_t = -1;
+    if constexpr (TILE > 0) {
+      const int tix = ix - (ocx - TILE / 2), tiy = iy - (ocy - TILE / 2);
+      const bool inmap = (ix >= 0) & (ix < a.W - 1) & (iy >= 0) & (iy < a.H - 1);       // no fold, no wrap of the flat indices
+      const bool inwin = ((unsigned)tix < (unsigned)(TILE - 1)) & ((unsigned)tiy < (unsigned)(TILE - 1));
+      new_t = (inmap & inwin) ? tiy + TS * tix : -1;
+    }
+    {   // cell accumulators: same footprint    {   // cell accumulators: same footprint as the previous iteration's -> add; else stash the old ones for the next flush
+      // (after a re-centring the same footprint has another tile index: new_t != acc_t writes the -- zeroed -- accumulators out once)
+      const bool same = !act | (((unsigned)cell.ic == acc_idx[0]) & ((unsigned)cell.ifl == acc_idx[3]) & (new_t == acc_t));
       const unsigned ni[4] = {(unsigned)cell.ic, (unsigned)cell.i_f, (unsigned)cell.il, (unsigned)cell.ifl};
       st_pending = !same;
+      st_t = acc_t; acc_t = new_t;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         st_idx[q] = acc_idx[q]; st_z[q] = acc_z[q]; st_m[q] = acc_m[q];
@@ -323,29 +419,25 @@ __global__ void __launch_bounds__(G) rollout_bwd_mw_kernel(const RolloutBwdArgs<
     }
     S zfx, zfy, mfx, mfy;
     blend_grad(cell, zc[0], zc[1], zc[2], zc[3], &zfx, &zfy);
-    {
-      S ofx, ofy;
-      blend_grad(cell, mc[0], mc[1], mc[2], mc[3], &mfx, &mfy);
-      blend_grad(cell, one, one, one, one, &ofx, &ofy);
-      mfx = has_mu ? mfx : ofx; mfy = has_mu ? mfy : ofy;
-    }
+    blend_grad(cell, mc[0], mc[1], mc[2], mc[3], &mfx, &mfy);
+    // (a map of ones without a friction map: its blend is the sum of the weights, whose derivative is zero up to rounding)
+    mfx = has_mu ? mfx : zero; mfy = has_mu ? mfy : zero;
     dk = kappa; dzx = zfx * a.inv_res; dzy = zfy * a.inv_res;
 #pragma unroll
     for (int q = 0; q < 4; ++q) dw4[q] = w4[q];
     const S gp[3] = {M::div(gzq * zfx + gmuq * mfx, a.res), M::div(gzq * zfy + gmuq * mfy, a.res), gdh};
     {   // v_p = xd + w x r;  p = R P + x, r = p - x
-      S t1[3], t2[3];
-      MF_CROSS(t1, gvp, w);           // dr += gvp x w
-      MF_CROSS(t2, r, gvp);           // dw += r x gvp
+      S qa[3] = {gp[0], gp[1], gp[2]};
+      MF_CROSS_ACC(qa[0], qa[1], qa[2], f, gtau);        // tau += r x f : dr = f x gtau
+      MF_CROSS_ACC(qa[0], qa[1], qa[2], gvp, w);         // dr += gvp x w
+      MF_CROSS_ACC(lw[0], lw[1], lw[2], r, gvp);         // dw += r x gvp
 #pragma unroll
       for (int q = 0; q < 3; ++q) {
-        lw[q] += t2[q];
         lxd[q] += gvp[q];
         lx[q] += gp[q];
-        const S qa = gp[q] + gr[q] + t1[q];
-        lR[q * 3 + 0] += qa * P[0];
-        lR[q * 3 + 1] += qa * P[1];
-        lR[q * 3 + 2] += qa * P[2];
+        lR[q * 3 + 0] += qa[q] * P[0];
+        lR[q * 3 + 1] += qa[q] * P[1];
+        lR[q * 3 + 2] += qa[q] * P[2];
       }
     }
     {   // e = col0(R) / max(|col0|, eps): through |col0| only when it is >= eps
@@ -355,11 +447,40 @@ __global__ void __launch_bounds__(G) rollout_bwd_mw_kernel(const RolloutBwdArgs<
       lR[6] += (ge[2] - dote * e[2]) * il;
     }
     // ---- what the next iteration reads as totals ----
-    S exo[9] = {lxd[0], lxd[1], lxd[2], lw[0], lw[1], lw[2], gtv, tcw * gtv, gS_p};
-    gs.template post<9>(exo);
+    ex[0] = lxd[0]; ex[1] = lxd[1]; ex[2] = lxd[2]; ex[3] = lw[0]; ex[4] = lw[1]; ex[5] = lw[2];
+    ex[6] = gtv; ex[7] = tcw * gtv; ex[8] = gS_p;
+#ifndef MF_MW_DBG_NOEXCHANGE   // A/B hook: the step without its exchange (wrong gradients, the instruction stream minus the sums)
+    gs.template post<9>(ex);
+#endif
+  };
+
+  StepIn sA, sB;
+  UpIn uA, uB;
+  load_step(max(n_steps - 1, 0), sA);
+  load_up(min(n_steps, a.T - 1), uA);
+  {   // the exchange the first iteration fetches: nothing yet
+#pragma unroll
+    for (int k = 0; k < 9; ++k) ex[k] = zero;
+    gs.template post<9>(ex);
   }
+  __builtin_amdgcn_s_waitcnt(0);
+  if constexpr (TILE > 0) {      // the window starts centred under the pose the scan starts from
+    tile_clear();
+    centre_cell(sA.x, ocx, ocy);
+    tile_sync();
+  }
+  int n = n_steps - 1;
+  if (n >= 0 && (n_steps & 1)) {      // an odd number of steps: one ahead of the pairs, leaving the next step's inputs in (sA, uA) again
+    one_step(n, sA, uA, sB, uB);
+    sA = sB; uA = uB;
+    --n;
+  }
+  for (; n >= 1; n -= 2) {
+    one_step(n, sA, uA, sB, uB);
+    one_step(n - 1, sB, uB, sA, uA);
+  }
+  UpIn up;
   {   // the last exchange: control gradient of step 0 and its gS
-    S ex[9];
     gs.template wait<9>(ex);
     if (a.gcontrols && n_steps > 0) { gctrl[0] = ex[6]; gctrl[1] = ex[7]; }
     const S dl = ex[8] * dk;
@@ -371,13 +492,10 @@ __global__ void __launch_bounds__(G) rollout_bwd_mw_kernel(const RolloutBwdArgs<
     for (int q = 0; q < 4; ++q) acc_z[q] -= dl * dw4[q];
   }
   flush_stash();
-  if (act) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) atomic_add(at32(gzmap, goff + acc_idx[q]), acc_z[q]);
-    if (want_gmu) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) atomic_add(at32(gmumap, goff + acc_idx[q]), acc_m[q]);
-    }
+  if (act) emit_cells(acc_t, acc_idx, acc_z, acc_m);      // what is still accumulated in registers
+  if constexpr (TILE > 0) {
+    tile_sync();
+    tile_flush();
   }
   // output row 0 is the initial state itself (its forces are constant zeros)
   load_up(0, up);
@@ -437,5 +555,8 @@ __global__ void __launch_bounds__(G) rollout_bwd_mw_kernel(const RolloutBwdArgs<
 bool use_multiwave_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p);   // this backward goes to the kernels above
 long long mw_record_bytes(const MfRolloutDesc* d);                           // bytes of the record the forward keeps for them (0: none)
 int launch_rollout_bwd_mw_f32(const RolloutBwdArgs<float>& a, int G, bool xs_only, hipStream_t st);
+// cells per side of a rollout's LDS gradient tile; 0 = none.  Measured (B = 64 x N = 223: 1.094 -> 1.038 ms; 256 x 64: 0.861 -> 0.845;
+// 1024 x 32: 0.971 -> 0.967; 256 x 16: 0.692 -> 0.883 -- four tiles per wave collide in the LDS): whole-wave groups only
+constexpr int mw_tile_edge(int G) { return G >= 64 ? 64 : 0; }
 
 }  // namespace mf

@@ -161,14 +161,14 @@ extern "C" int mf_rollout_fwd_f32(const MfRolloutDesc* d, const MfRolloutFwdBufs
     if (!forces && m.PPL == 4 && m.G < 64) m = mf::choose_lane_map(d->B, d->N, 1);
     // >= one wave per SIMD (1024) and a one-point-per-lane mapping within a wave: the split-store kernels (rollout_fwd_kernel.h)
     const bool split = m.PPL == 1 && m.G <= 64 && (long long)d->B * m.G >= 1024ll * 64;
+    if (p->rec && mf::mw_record_bytes(d) > 0) {      // the 16-byte record of rollout_bwd_mw_kernel.h (never a split-store launch)
+      MF_REQUIRE(((uintptr_t)p->rec & 15) == 0, MF_ERR_INVALID, "rollout_fwd: rec must be 16-byte aligned");
+      a.rec = (float*)p->rec;
+    }
     if (mf::use_interleaved_maps(d, p, &a, m, (hipStream_t)s))
       return mf::launch_rollout_fwd_zmu_f32(a, m, d->integrator, block, forces, split, 0, (hipStream_t)s);
     if (split)
       return mf::launch_rollout_fwd_split_fast_f32(a, m, d->integrator, block, forces, (hipStream_t)s);
-    if (p->rec && mf::mw_record_bytes(d) > 0) {      // one rollout over several waves: the record of its backward (rollout_bwd_mw_kernel.h)
-      MF_REQUIRE(((uintptr_t)p->rec & 15) == 0, MF_ERR_INVALID, "rollout_fwd: rec must be 16-byte aligned");
-      a.rec = (float*)p->rec;
-    }
     return mf::launch_rollout_fwd_fast_f32(a, m, d->integrator, block, forces, (hipStream_t)s);
   }
   MF_REQUIRE(!p->loss, MF_ERR_UNSUPPORTED, "rollout_fwd: the fused physics loss exists for the float32 fast-math kernels only");

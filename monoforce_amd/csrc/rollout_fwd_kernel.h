@@ -666,7 +666,25 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
       }
     };
     const S* ts_pair = a.ts;
-    auto pipe_step = [&](int n, Geo& g, Geo& g_next) {
+    // The height-dependent half of the contact model: terrain sample, normal, friction, penetration and the contact weight of a
+    // point under a POSE -- no velocity in it, so it is evaluated a step ahead (pose n + 1 is known when step n starts) and the
+    // contact count of step n + 1 rides in the SAME workgroup exchange as the wrench of step n: one LDS round trip and one
+    // barrier per step instead of two.
+    struct Hgt { S nrm[3], muq, dh, cj; };
+    auto height_part = [&](const Geo& g, Hgt& hq) {
+      const Cell<S>& c = g.cell[0];
+      S zq, mub;                                                   // height, normal, friction under the point (:211-216)
+      blend2(c, g.zc[0], g.mc[0], &zq, &mub);
+      hq.muq = has_mu ? mub : blend_ones(c);
+      const S gx = M::div(g.zc[0][1] - g.zc[0][0], a.res), gy = M::div(g.zc[0][2] - g.zc[0][0], a.res);
+      const S inl = M::inv_len(gx * gx + gy * gy + one);
+      hq.nrm[0] = -gx * inl; hq.nrm[1] = -gy * inl; hq.nrm[2] = inl;
+      hq.dh = g.pz[0] - zq;                                        // soft contact (:220-222)
+      const S cj = M::sigmoid_m10(hq.dh);
+      hq.cj = act[0] ? cj : zero;
+    };
+    S csum_cur = zero;      // contact count of the step about to run (total over the workgroup)
+    auto pipe_step = [&](int n, Geo& g, Hgt& hq, Geo& g_next, Hgt& hq_next) {
       // next step's controls and step size: requested before this step's stores (vmcnt retires in order)
       const int nn = min(n + 1, a.T - 1);
       const S cv_next = ctrl[nn * a.ctrl_st + 0], cw_next = ctrl[nn * a.ctrl_st + 1];
@@ -675,33 +693,28 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
       emit_row(row_stride);                       // row n: the state as it stands
       Kin k;
       kinematics(g, k);
-      arrive(g);                                  // cells requested a step ago
-      Con q;
-      S csum = contact_normal(g, k, q);
-      // (The empty asm statements pin the independent work into its slot: arithmetic has no position of its own in the compiler's
-      //  eyes, and the scheduler otherwise issues it ahead of the LDS write it is meant to follow.  `after_memory` makes a value
-      //  depend on everything stored / loaded so far; `after_value` makes one depend on another.)
-      auto after_memory = [](S& v) { asm volatile("" : "+v"(v) :: "memory"); };
-      auto after_value = [](S& v, int dep) { asm volatile("" : "+v"(v) : "v"(dep)); };
-      constexpr int NWv = G / 64;
-      S cs1[1] = {csum};
-      gs.template post<1>(cs1);
-      S h_pose = h_ode;
-      after_memory(h_pose);
-      advance_pose(h_pose);                       // ---- under the contact count's LDS write: pose n + 1
-      after_memory(x[0]); after_memory(R[0]); after_memory(R[4]); after_memory(R[8]);
-      S t1[NWv];
-      gs.template fetch<1>(t1);
-      after_memory(x[1]);
-      locate_points(g_next);                      // ---- under its reads: the arms and footprints of pose n + 1
-      after_value(t1[0], g_next.cell[0].ic);
-      gs.template fold<1>(t1, cs1);
+      advance_pose(h_ode);                        // pose n + 1 (the explicit scheme moves x with the OLD xd, R with the OLD w)
+      locate_points(g_next);
+      request(g_next);                            // its cells: in flight under the contact chain of step n
+      Con q;                                      // spring-damper along the normal (:224-230), velocities of step n
+      {
+        const S vn = k.vp[0][0] * hq.nrm[0] + k.vp[0][1] * hq.nrm[1] + k.vp[0][2] * hq.nrm[2];
+        const S A = a.k * hq.dh + a.damp * vn;
+        q.nrm[0][0] = hq.nrm[0]; q.nrm[0][1] = hq.nrm[1]; q.nrm[0][2] = hq.nrm[2];
+        q.muq[0] = hq.muq; q.cw8[0] = hq.cj;
+        q.Fr[0][0] = -(A * hq.nrm[0]); q.Fr[0][1] = -(A * hq.nrm[1]); q.Fr[0][2] = -(A * hq.nrm[2]);
+      }
       S wr[kWr];
-      contact_wrench(g, k, q, cs1[0], wr);
-      gs.template post<kWr>(wr);
-      asm volatile("" : "+v"(g_next.cell[0].ic) :: "memory");
-      request(g_next);                            // ---- under the wrench's LDS write: the cells of step n + 1
-      gs.template wait<kWr>(wr);
+      contact_wrench(g, k, q, csum_cur, wr);
+      arrive(g_next);
+      height_part(g_next, hq_next);
+      S ex[kWr + 1];
+  #pragma unroll
+      for (int c = 0; c < kWr; ++c) ex[c] = wr[c];
+      ex[kWr] = hq_next.cj;
+      gs.template sum_n<kWr + 1>(ex);             // wrench of step n + contact count of step n + 1
+  #pragma unroll
+      for (int c = 0; c < kWr; ++c) wr[c] = ex[c];
       S xdd[3], wd[3], wraw[3];
       accelerations(wr, xdd, wd, wraw);
       if constexpr (REC) {
@@ -709,19 +722,27 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
         // this step evaluated, 16 bytes per rollout-step; every lane stores the same quad to the same address (no branch: the
         // arithmetic of the step stays one basic block, so the trajectory's bits are those of the kernel without a record)
         typedef float f4v __attribute__((ext_vector_type(4)));
-        const f4v rv = {cs1[0], wraw[0], wraw[1], wraw[2]};
+        const f4v rv = {csum_cur, wraw[0], wraw[1], wraw[2]};
         __builtin_nontemporal_store(rv, reinterpret_cast<f4v*>(a.rec + ((size_t)n * a.B + b) * 4));
       }
       advance_velocities(q, xdd, wd, h_ode);
+      csum_cur = ex[kWr];
       cv = cv_next; cw = cw_next;
       h_ode = ts_b - ts_a;
     };
     Geo gA, gB;
-    if (n_steps > 0) { locate_points(gA); request(gA); }
+    Hgt hA, hB;
+    if (n_steps > 0) {      // prologue: cells and contact count of step 0
+      locate_points(gA); request(gA);
+      __builtin_amdgcn_s_waitcnt(0);
+      arrive(gA);
+      height_part(gA, hA);
+      csum_cur = gs.sum(hA.cj);
+    }
     __builtin_amdgcn_s_waitcnt(0);
     int n = 0;
-    for (; n + 1 < n_steps; n += 2) { pipe_step(n, gA, gB); pipe_step(n + 1, gB, gA); }
-    if (n < n_steps) pipe_step(n, gA, gB);
+    for (; n + 1 < n_steps; n += 2) { pipe_step(n, gA, hA, gB, hB); pipe_step(n + 1, gB, hB, gA, hA); }
+    if (n < n_steps) pipe_step(n, gA, hA, gB, hB);
   } else {
   for (int n = 0; n < n_steps; ++n) {
     if (JOINTS) articulate_body<S, G, PPL, FAST>(gs, a.joint_angles + ((size_t)b * a.T + n) * 4, a.joint_xyz, a.mass / (S)a.N, P0, part, act, P, Iv);
@@ -870,11 +891,17 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
       for (int c = 0; c < 3; ++c) { sFr[c] = wr[c]; sFf[c] = wr[3 + c]; sTau[c] = wr[6 + c]; }
     }
     // omega_d = clamp(I^-1 tau) (body-frame I with world-frame torque, as the reference)   (:256-257)
-    S wd[3];
+    S wd[3], wraw[3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
-      wd[c] = M::clamp(Iv[c * 3 + 0] * sTau[0] + Iv[c * 3 + 1] * sTau[1] + Iv[c * 3 + 2] * sTau[2],
-                       -a.omega_max, a.omega_max);
+    for (int c = 0; c < 3; ++c) {
+      wraw[c] = Iv[c * 3 + 0] * sTau[0] + Iv[c * 3 + 1] * sTau[1] + Iv[c * 3 + 2] * sTau[2];
+      wd[c] = M::clamp(wraw[c], -a.omega_max, a.omega_max);
+    }
+    if constexpr (REC) {   // the record of rollout_bwd_mw_kernel.h: every lane of the group stores the same quad (no branch)
+      typedef float f4v __attribute__((ext_vector_type(4)));
+      const f4v rv = {csum, wraw[0], wraw[1], wraw[2]};
+      __builtin_nontemporal_store(rv, reinterpret_cast<f4v*>(a.rec + ((size_t)n * a.B + b) * 4));
+    }
     // xdd = (m g ghat + sum Fs + sum Ff) / m   (:264-266)
     S xdd[3];
     if (FAST) { xdd[0] = sFr[0] * a.inv_mass; xdd[1] = sFr[1] * a.inv_mass; xdd[2] = (sFr[2] - a.mg) * a.inv_mass; }
@@ -1019,17 +1046,21 @@ int launch_rollout_fwd(const RolloutArgs<S>& a, LaneMap m, int integ, int block,
   return MF_OK;
 }
 
-// The multi-wave mappings of the default integrator with the record for their backward (rollout_bwd_mw_kernel.h): a.rec != NULL.
-template <bool FORCES>
+// The one-point-per-lane mappings of the default integrator with the record for their backward (rollout_bwd_mw_kernel.h):
+// a.rec != NULL.  Bodies of 5..64 points (several rollouts per wave; plain or interleaved maps) and of 65..512 (one per workgroup).
+template <bool FORCES, bool ZMU = false>
 int launch_rollout_fwd_mw_rec(const RolloutArgs<float>& a, LaneMap m, hipStream_t st) {
   bool launched = false;
 #define MF_CASE(G_)                                                                                                          \
   if (!launched && m.G == G_ && m.PPL == 1) {                                                                                \
     launched = true;                                                                                                         \
-    hipLaunchKernelGGL((rollout_fwd_kernel<float, G_, 1, MF_INTEG_ODEINT_EULER, true, false, FORCES, 0, false, false, true>), \
-                       dim3(a.B), dim3(G_), 0, st, a);                                                                       \
+    const int blk = G_ > 64 ? G_ : 64;                                                                                       \
+    const unsigned grid = (unsigned)(((long long)a.B * G_ + blk - 1) / blk);                                                 \
+    hipLaunchKernelGGL((rollout_fwd_kernel<float, G_, 1, MF_INTEG_ODEINT_EULER, true, false, FORCES, 0, false, ZMU, true>),  \
+                       dim3(grid), dim3(blk), 0, st, a);                                                                     \
   }
-  MF_CASE(128) MF_CASE(256) MF_CASE(512)
+  MF_CASE(8) MF_CASE(16) MF_CASE(32) MF_CASE(64)
+  if constexpr (!ZMU) { MF_CASE(128) MF_CASE(256) MF_CASE(512) }
 #undef MF_CASE
   MF_REQUIRE(launched, MF_ERR_UNSUPPORTED, "rollout_fwd: no recording kernel for this lane mapping");
   hipError_t e = hipGetLastError();

@@ -127,5 +127,8 @@ def test_train_step_replayed_as_one_graph_equals_launch_by_launch():
     # replay k is step 3 + k of the same optimisation
     for k, lg in enumerate(graphed[0]):
         assert abs(lg - eager[0][3 + k]) <= 2e-2 * abs(eager[0][3 + k]), (k, lg, eager[0])
-    worst = max(float((a - b).abs().max() / b.abs().max().clamp_min(1e-6)) for a, b in zip(graphed[1], eager[1]))
+    # (Adam moves a parameter whose gradient is at the noise level of the float atomics by up to lr per step in EITHER direction:
+    #  tensors that are still ~0 after 7 steps are held to that absolute bound, the others to 5 % of their largest entry)
+    atol = 2 * 7 * 2e-4
+    worst = max(float(((a - b).abs().max() - atol).clamp_min(0) / b.abs().max().clamp_min(1e-6)) for a, b in zip(graphed[1], eager[1]))
     assert worst <= 5e-2, worst

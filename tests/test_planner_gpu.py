@@ -81,21 +81,27 @@ def test_cost_rows_match_full_outputs(integ, N, n_tracks, stride):
     out = dp.rollout_costs(z, ctrl, state=st, friction=mu, pose_stride=stride)
     rows = out['cost_rows']
     assert rows.shape == (B, T, 4)
+    # Bit equality with the full-output kernel wherever both run the same step code.  A body over several waves (N > 64) under the
+    # default integrator does not: its full-output forward is software-pipelined around ONE workgroup exchange per step (contact
+    # count of step n + 1 with the wrench of step n, rollout_fwd_kernel.h), the cost kernel keeps the plain two-exchange step --
+    # same formulas, FMA contraction chosen per code shape: equal to float32 rounding over the horizon instead
+    same = torch.equal if not (N > 64 and integ == 1) else (lambda u, v: hp.rel_err(u, v) <= 2e-5)
     if integ == 0:          # dynamics(): R stays orthonormal and its third row is stored as is
         assert torch.equal(rows[..., :3], Rs[:, :, 2, :])
     else:                   # odeint-euler: third row of the nearest rotation (two Newton steps in the kernel vs SVD here)
         U, _, Vh = torch.linalg.svd(Rs.double().cpu())
         assert float((rows[..., :3].double().cpu() - (U @ Vh)[:, :, 2, :]).abs().max()) <= 2e-6
         raw = dp.rollout_costs(z, ctrl, state=st, friction=mu, pose_stride=stride, project=False)      # ... or the raw row
-        assert torch.equal(raw['cost_rows'][..., :3], Rs[:, :, 2, :]) and torch.equal(raw['force_cost'], out['force_cost'])
+        assert same(raw['cost_rows'][..., :3], Rs[:, :, 2, :]) and torch.equal(raw['force_cost'], out['force_cost'])
         from monoforce_amd.planner import nearest_rotation_row2
         assert float((nearest_rotation_row2(Rs).double().cpu() - (U @ Vh)[:, :, 2, :]).abs().max()) <= 2e-6
     s_ref = torch.norm(Fs, dim=-1).std(dim=-1)
-    assert hp.rel_err(rows[..., 3].cpu(), s_ref.cpu()) <= 2e-6, hp.rel_err(rows[..., 3].cpu(), s_ref.cpu())
-    assert hp.rel_err(out['force_cost'].cpu(), s_ref.std(dim=-1).cpu()) <= 2e-5      # std over time, Welford in the kernel
+    ftol = 2e-6 if same is torch.equal else 1e-4
+    assert hp.rel_err(rows[..., 3].cpu(), s_ref.cpu()) <= ftol, hp.rel_err(rows[..., 3].cpu(), s_ref.cpu())
+    assert hp.rel_err(out['force_cost'].cpu(), s_ref.std(dim=-1).cpu()) <= 10 * ftol      # std over time, Welford in the kernel
     steps = out['pose_steps']
     assert steps[-1] == T - 1 and steps.numel() == 1 + -(-(T - 1) // stride)
-    assert torch.equal(out['Xs'], Xs[:, steps]) and torch.equal(out['Rs'], Rs[:, steps])
+    assert same(out['Xs'], Xs[:, steps]) and same(out['Rs'], Rs[:, steps])
     assert torch.equal(st[0].cpu(), _start_state(B)[0])      # the caller's start state is untouched (the snap works on a copy)
 
 

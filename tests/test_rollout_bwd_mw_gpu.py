@@ -1,6 +1,7 @@
-"""The multi-wave backward (csrc/rollout_bwd_mw_kernel.h): ONE rollout of a 65..512-point body over 2 / 4 / 8 waves, float32 fast
-math, default integrator, reading the forward's 16-byte record -- against the CPU oracle (the restated reference autograd,
-dphysics.py:172-272, 499-528) and against the general one-wave kernel (`points_per_lane=4`, which recomputes everything)."""
+"""The record-reading backward (csrc/rollout_bwd_mw_kernel.h): float32 fast math, default integrator, one contact point per lane --
+ONE rollout of a 65..512-point body over 2 / 4 / 8 waves, or 8 / 16 / 32 / 64 lanes per rollout for bodies of 5..64 points --
+against the CPU oracle (the restated reference autograd, dphysics.py:172-272, 499-528) and against the general kernel
+(`points_per_lane=4`, which recomputes everything and keeps no record)."""
 import ctypes as C
 
 import pytest
@@ -53,10 +54,13 @@ def test_the_record_is_requested_for_these_launches():
         return int(_lib.lib().mf_rollout_record_bytes(C.byref(d)))
     assert rec_bytes(64, 223) == 100 * 64 * 16 and rec_bytes(4, 100) == 100 * 4 * 16 and rec_bytes(8, 400) == 100 * 8 * 16
     assert rec_bytes(64, 223, integ=0) == 0 and rec_bytes(64, 223, ppl=4) == 0 and rec_bytes(64, 223, fast=0) == 0
-    assert rec_bytes(4096, 223) == 0 and rec_bytes(64, 64) == 0      # one wave per rollout there
+    assert rec_bytes(4096, 223) == 0      # one wave per rollout, several points per lane
+    assert rec_bytes(64, 64) == 100 * 64 * 16 and rec_bytes(1024, 32) == 100 * 1024 * 16 and rec_bytes(5, 7) == 100 * 5 * 16
+    assert rec_bytes(2048, 32) == 0       # >= one wave per SIMD: the split-store forward keeps no record
 
 
-@pytest.mark.parametrize('B,N,n_tracks,T', [(3, 100, 2, 40), (5, 223, 4, 40), (2, 300, 2, 25), (2, 400, 4, 25), (64, 223, 2, 12), (1, 175, 2, 1), (2, 175, 2, 2)])
+@pytest.mark.parametrize('B,N,n_tracks,T', [(3, 100, 2, 40), (5, 223, 4, 40), (2, 300, 2, 25), (2, 400, 4, 25), (64, 223, 2, 12), (1, 175, 2, 1), (2, 175, 2, 2),
+                                             (5, 7, 2, 40), (130, 16, 2, 20), (70, 33, 4, 20), (3, 64, 2, 40), (9, 5, 2, 3)])
 @pytest.mark.parametrize('xs_only', [False, True])
 @pytest.mark.parametrize('shared', [False, True])
 def test_multiwave_backward_vs_oracle_and_one_wave_kernel(B, N, n_tracks, T, xs_only, shared):
