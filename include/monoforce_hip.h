@@ -186,12 +186,16 @@ typedef struct MfRolloutFwdBufs {
                            values as z / mu (mf_terrain_stage_fwd_f32 writes all three in one pass).  Kernels that gather from an
                            interleaved pair (float32 MF_MATH_FAST, rigid body of <= 64 points, one point per lane or component-
                            parallel) read it whatever the batch size and skip their own interleave pass; the others read z / mu. */
-  void* rec;            /* optional, float32: mf_rollout_record_bytes(desc) bytes (16-byte aligned) that receive the per-step record
-                           of the component-parallel kernels -- per lane and step the two gathered map cells, the footprint weights,
-                           the terrain normal, the contact weight and the force / slip scalars -- for a backward that then reads
-                           them instead of recomputing them (autograd saves every intermediate of dphysics.py:172-272; this saves
-                           16 scalars per contact point and step).  NULL, or a launch the record does not apply to: nothing is
-                           written and the backward recomputes. */
+  void* rec;            /* optional, float32: mf_rollout_record_bytes(desc) bytes (16-byte aligned) that receive the forward's per-step
+                           record for a backward that then reads it instead of recomputing (autograd saves every intermediate of
+                           dphysics.py:172-272).  Two forms, chosen by the launch shape:
+                           component-parallel kernels (rigid body of <= 4 points): [T][B * 16 lanes] quads (u, c, omega_d raw, A) --
+                           cell coordinate, contact weight, unclamped angular acceleration component, A = k dh + d v_n -- 256 B per
+                           rollout-step;
+                           one point per lane, bodies of 5..512 points, default integrator, below one wave per SIMD: [T][B] quads
+                           (sum of the contact weights, omega_d before its clamp) -- 16 B per rollout-step, what the record-reading
+                           backward (rollout_bwd_mw_kernel.h) cannot rebuild without a reduction over the contact points.
+                           NULL, or a launch the record does not apply to: nothing is written and the backward recomputes. */
   const MfRolloutLoss* loss; /* optional: fuse physics_loss into the launch (mf_rollout_loss_fusable(desc) must be 1; Fs = Ff = NULL,
                            MF_LAYOUT_TIME_MAJOR): fills loss->loss.  NULL = plain rollout. */
 } MfRolloutFwdBufs;
@@ -202,8 +206,9 @@ typedef struct MfRolloutFwdBufs {
 int mf_rollout_loss_fusable(const MfRolloutDesc* desc);
 
 /* Bytes of MfRolloutFwdBufs.rec / MfRolloutBwdBufs.rec for this launch shape; 0 where the kernels chosen for it keep no record
- * (then pass NULL).  The record pays while the launch is bound by the instruction stream of its waves (few rollouts of a small
- * body, default integrator): forward +5 %, backward -17 % at 1024 rollouts. */
+ * (then pass NULL).  The record pays while the launch is bound by the instruction stream of its waves: few rollouts of a small
+ * body (forward +5 %, backward -17 % at 1024 rollouts x 4 points), and bodies of 5..512 points below one wave per SIMD under the
+ * default integrator (16 bytes per rollout-step; backward 2.05 -> 1.04 ms at 64 rollouts x 223 points, 1.38 -> 0.97 ms at 1024 x 32). */
 long long mf_rollout_record_bytes(const MfRolloutDesc* desc);
 
 /* Point slots per Fs/Ff row the kernels chosen for (B, N, points_per_lane) need (>= N; -1 on a bad descriptor). */

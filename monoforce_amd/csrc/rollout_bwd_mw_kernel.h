@@ -18,6 +18,10 @@
 //     before the step after next: it rides in the SAME exchange as the velocity adjoints and is applied one step late as a
 //     correction (position and rotation partials, the four cell accumulators of the point).
 // One exchange and one barrier per step; the state rows, controls, time grid and record are workgroup-uniform loads.
+// (Measured and dropped: the adjoint-independent half of step n - 1 -- pose, gathers, contact model, gates -- rebuilt in the shadow
+//  of step n's exchange.  The ~75 values it carries across the loop edge push the kernel past 256 architectural VGPRs; the
+//  accumulator-register copies that follow cost more than the covered latency: 1.04 -> 1.12 ms at 64 x 223 points, 0.97 -> 1.06 ms
+//  at 1024 x 32.  The loop runs at ~6.6 cycles per instruction of ONE wave per SIMD: its time is its instruction count.)
 #pragma once
 #include "rollout_bwd_kernel.h"
 
@@ -403,7 +407,7 @@ __global__ void __launch_bounds__(G > 64 ? G : 64) rollout_bwd_mw_kernel(const R
       const bool inwin = ((unsigned)tix < (unsigned)(TILE - 1)) & ((unsigned)tiy < (unsigned)(TILE - 1));
       new_t = (inmap & inwin) ? tiy + TS * tix : -1;
     }
-    {   // cell accumulators: same footprint    {   // cell accumulators: same footprint as the previous iteration's -> add; else stash the old ones for the next flush
+    {   // cell accumulators: same footprint as the previous iteration's -> add; else stash the old ones for the next flush
       // (after a re-centring the same footprint has another tile index: new_t != acc_t writes the -- zeroed -- accumulators out once)
       const bool same = !act | (((unsigned)cell.ic == acc_idx[0]) & ((unsigned)cell.ifl == acc_idx[3]) & (new_t == acc_t));
       const unsigned ni[4] = {(unsigned)cell.ic, (unsigned)cell.i_f, (unsigned)cell.il, (unsigned)cell.ifl};
