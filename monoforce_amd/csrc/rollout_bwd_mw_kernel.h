@@ -220,6 +220,23 @@ __global__ void __launch_bounds__(G > 64 ? G : 64) rollout_bwd_mw_kernel(const R
   if (gl == 0 && a.gcontrols) { gctrl[(a.T - 1) * 2 + 0] = zero; gctrl[(a.T - 1) * 2 + 1] = zero; }   // the last control is never used
 
   S ex[9];      // the step's exchange: partials in, group totals out
+  // The exchange itself.  Within a wave (G <= 64): nine DPP group sums.  Over several waves: TransposedExchange (mf_common.h) --
+  // about half the instructions of nine plain workgroup sums (the loop: 762 -> 632 instructions per step at G = 256).
+  __shared__ __attribute__((aligned(16))) S xch_lds[G > 64 ? TransposedExchange<NW>::kWords : 4];
+  TransposedExchange<NW> xch;
+  xch.lds = xch_lds;
+  auto post9 = [&](S (&v)[9]) {
+    if constexpr (G <= 64) {
+      gs.template post<9>(v);
+    } else {
+      const S v8[8] = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
+      xch.post(v8, v[8]);
+    }
+  };
+  auto wait9 = [&](S (&v)[9]) {
+    if constexpr (G <= 64) gs.template wait<9>(v);
+    else xch.template wait<9>(v);
+  };
   // One step of the reverse scan.  (cur, upn) = the inputs of step n, loaded an iteration ago; (nxt, up_nxt) receive those of step
   // n - 1.  The loop calls it twice per trip with the two buffer pairs swapped: no register copies at the back edge.
   auto one_step = [&](const int n, const StepIn& cur, const UpIn& upn, StepIn& nxt, UpIn& up_nxt) {
@@ -255,7 +272,7 @@ __global__ void __launch_bounds__(G > 64 ? G : 64) rollout_bwd_mw_kernel(const R
     // ---- the exchange posted by the previous iteration: totals of the velocity adjoints, the control gradient of step n + 1, gS ----
     // (`ex` lives across iterations: within a wave, G <= 64, post() leaves the group totals in it and wait() is empty)
 #ifndef MF_MW_DBG_NOEXCHANGE
-    gs.template wait<9>(ex);
+    wait9(ex);
 #endif
     if (a.gcontrols && n + 1 < n_steps) { gctrl[(n + 1) * 2 + 0] = ex[6]; gctrl[(n + 1) * 2 + 1] = ex[7]; }
     {   // gS of step n + 1, one step late: dh adjoint += gS kappa  ->  height sample, position, rotation partials, cell accumulators
@@ -454,7 +471,7 @@ __global__ void __launch_bounds__(G > 64 ? G : 64) rollout_bwd_mw_kernel(const R
     ex[0] = lxd[0]; ex[1] = lxd[1]; ex[2] = lxd[2]; ex[3] = lw[0]; ex[4] = lw[1]; ex[5] = lw[2];
     ex[6] = gtv; ex[7] = tcw * gtv; ex[8] = gS_p;
 #ifndef MF_MW_DBG_NOEXCHANGE   // A/B hook: the step without its exchange (wrong gradients, the instruction stream minus the sums)
-    gs.template post<9>(ex);
+    post9(ex);
 #endif
   };
 
@@ -465,7 +482,7 @@ __global__ void __launch_bounds__(G > 64 ? G : 64) rollout_bwd_mw_kernel(const R
   {   // the exchange the first iteration fetches: nothing yet
 #pragma unroll
     for (int k = 0; k < 9; ++k) ex[k] = zero;
-    gs.template post<9>(ex);
+    post9(ex);
   }
   __builtin_amdgcn_s_waitcnt(0);
   if constexpr (TILE > 0) {      // the window starts centred under the pose the scan starts from
@@ -485,7 +502,7 @@ __global__ void __launch_bounds__(G > 64 ? G : 64) rollout_bwd_mw_kernel(const R
   }
   UpIn up;
   {   // the last exchange: control gradient of step 0 and its gS
-    gs.template wait<9>(ex);
+    wait9(ex);
     if (a.gcontrols && n_steps > 0) { gctrl[0] = ex[6]; gctrl[1] = ex[7]; }
     const S dl = ex[8] * dk;
     const S g0 = -(dl * dzx), g1 = -(dl * dzy);

@@ -684,6 +684,10 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
       hq.cj = act[0] ? cj : zero;
     };
     S csum_cur = zero;      // contact count of the step about to run (total over the workgroup)
+    static_assert(kWr == 6, "the pipelined step exchanges the fast-math wrench (6) and one contact count");
+    __shared__ __attribute__((aligned(16))) float xch_lds[TransposedExchange<(G > 64 ? G / 64 : 1)>::kWords];
+    TransposedExchange<(G > 64 ? G / 64 : 1)> xch;
+    xch.lds = xch_lds;
     auto pipe_step = [&](int n, Geo& g, Hgt& hq, Geo& g_next, Hgt& hq_next) {
       // next step's controls and step size: requested before this step's stores (vmcnt retires in order)
       const int nn = min(n + 1, a.T - 1);
@@ -712,7 +716,15 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
   #pragma unroll
       for (int c = 0; c < kWr; ++c) ex[c] = wr[c];
       ex[kWr] = hq_next.cj;
-      gs.template sum_n<kWr + 1>(ex);             // wrench of step n + contact count of step n + 1
+      // wrench of step n + contact count of step n + 1: one transposed workgroup exchange (mf_common.h)
+      {
+        const float v8[8] = {(float)ex[0], (float)ex[1], (float)ex[2], (float)ex[3], (float)ex[4], (float)ex[5], (float)ex[6], 0.0f};
+        xch.post(v8, 0.0f);
+        float tot[7];
+        xch.template wait<7>(tot);
+  #pragma unroll
+        for (int c = 0; c < 7; ++c) ex[c] = (S)tot[c];
+      }
   #pragma unroll
       for (int c = 0; c < kWr; ++c) wr[c] = ex[c];
       S xdd[3], wd[3], wraw[3];
