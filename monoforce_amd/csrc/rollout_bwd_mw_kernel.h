@@ -222,11 +222,12 @@ __global__ void __launch_bounds__(G > 64 ? G : 64) rollout_bwd_mw_kernel(const R
   S ex[9];      // the step's exchange: partials in, group totals out
   // The exchange itself.  Within a wave (G <= 64): nine DPP group sums.  Over several waves: TransposedExchange (mf_common.h) --
   // about half the instructions of nine plain workgroup sums (the loop: 762 -> 632 instructions per step at G = 256).
-  __shared__ __attribute__((aligned(16))) S xch_lds[G > 64 ? TransposedExchange<NW>::kWords : 4];
+  // (a whole-wave group, G = 64, takes it too: 26 DPP adds and one LDS round trip instead of 54 DPP adds and nine readlanes)
+  __shared__ __attribute__((aligned(16))) S xch_lds[G >= 64 ? TransposedExchange<NW>::kWords : 4];
   TransposedExchange<NW> xch;
   xch.lds = xch_lds;
   auto post9 = [&](S (&v)[9]) {
-    if constexpr (G <= 64) {
+    if constexpr (G < 64) {
       gs.template post<9>(v);
     } else {
       const S v8[8] = {v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7]};
@@ -234,7 +235,7 @@ __global__ void __launch_bounds__(G > 64 ? G : 64) rollout_bwd_mw_kernel(const R
     }
   };
   auto wait9 = [&](S (&v)[9]) {
-    if constexpr (G <= 64) gs.template wait<9>(v);
+    if constexpr (G < 64) gs.template wait<9>(v);
     else xch.template wait<9>(v);
   };
   // One step of the reverse scan.  (cur, upn) = the inputs of step n, loaded an iteration ago; (nxt, up_nxt) receive those of step
