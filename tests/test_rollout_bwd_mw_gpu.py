@@ -126,3 +126,35 @@ def test_multiwave_backward_is_deterministic_and_independent_of_the_batch():
     z1, c1 = run(slice(2, 3))
     assert torch.equal(c1[0], ca[2])
     assert hp.rel_err(z1[0], za[2]) <= 1e-6
+
+
+@pytest.mark.parametrize('B,N,n_tracks', [(3, 223, 2), (37, 32, 4), (2, 64, 2)])
+@pytest.mark.parametrize('variant', ['no_friction_map', 'batch_major', 'no_snap_default_state'])
+def test_multiwave_backward_input_variants(B, N, n_tracks, variant):
+    """The kernel's other input forms: no friction map (the reference's map of ones, dphysics.py:562), batch-major outputs,
+    the default start state with the terrain snap switched off -- gradients against the general kernel and the oracle."""
+    from oracle import dphysics_oracle as orc
+    T = 30
+    pts, masks, z, mu, ctrl = _problem(B, N, T, n_tracks, False)
+    spec = hp.spec_from(pts, masks, 1, 0.1, 3.2)
+    kw = dict(contiguous_outputs=True) if variant == 'batch_major' else (dict(snap_to_terrain=False) if variant == 'no_snap_default_state' else {})
+    use_mu = variant != 'no_friction_map'
+
+    def run(fn, dev):
+        zl, cl = z.clone().to(dev).requires_grad_(True), ctrl.clone().to(dev).requires_grad_(True)
+        ml = mu.clone().to(dev).requires_grad_(True) if use_mu else None
+        outs = fn(zl, cl, ml)
+        _loss(outs, False).backward()
+        return [zl.grad.cpu(), cl.grad.cpu()] + ([ml.grad.cpu()] if use_mu else [])
+
+    def f_hip(ppl):
+        dp = make_dphysics(pts, masks, 1, 0.1, 3.2, points_per_lane=ppl, **kw)
+        return lambda zz, cc, mm: [o for grp in dp(zz, cc, friction=mm) for o in grp]
+
+    g_mw, g_1w = run(f_hip(0), DEV), run(f_hip(4), DEV)
+    for nm, a, c in zip(('z', 'controls', 'mu'), g_mw, g_1w):
+        assert torch.isfinite(a).all() and hp.rel_err(a, c) <= 2e-3, (variant, nm, hp.rel_err(a, c))
+    if variant != 'no_snap_default_state':      # (the oracle always snaps)
+        g_ref = run(lambda zz, cc, mm: [o for grp in orc.rollout(spec, zz, cc, friction=mm) for o in grp], 'cpu')
+        for nm, a, b in zip(('z', 'controls', 'mu'), g_mw, g_ref):
+            assert hp.rel_err(a, b) <= 2e-3, (variant, nm, 'vs oracle', hp.rel_err(a, b))
