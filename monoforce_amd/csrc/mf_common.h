@@ -62,6 +62,26 @@ __device__ __forceinline__ double mf_readlane(double v, int l) {
   return __builtin_bit_cast(double, p);
 }
 __device__ __forceinline__ float lane_xor(float v, int m) { return __shfl_xor(v, m, 64); }
+// v(lane) + v(lane ^ 16) / v(lane) + v(lane ^ 32) on gfx950's row / half-wave swaps: V_PERMLANE16_SWAP exchanges the odd rows of its
+// first operand with the even rows of its second, V_PERMLANE32_SWAP the upper half of the first with the lower half of the second --
+// given the same value twice they return (rows 0 0 2 2, rows 1 1 3 3) and (lower lower, upper upper), whose sum is the pair sum in
+// every lane.  Plain VALU instructions: no LDS-crossbar round trip (ds_bpermute_b32), no address register; the operands are added
+// in the order (even row + odd row), so the result is the bits of own + partner.
+__device__ __forceinline__ float pair_sum_xor16(float v) {
+#ifdef MF_NO_PERMLANE_SWAP      // A/B hook (tools/build_variant.sh): the LDS-crossbar permute
+  return v + lane_xor(v, 16);
+#endif
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ float pair_sum_xor32(float v) {
+  const unsigned u = __builtin_bit_cast(unsigned, v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ double pair_sum_xor16(double v) { return v + lane_xor(v, 16); }
+__device__ __forceinline__ double pair_sum_xor32(double v) { return v + lane_xor(v, 32); }
 __device__ __forceinline__ double lane_xor(double v, int m) { return __shfl_xor(v, m, 64); }
 
 // All-reduce (sum) over aligned groups of G consecutive lanes; every lane of the group gets the total.
@@ -75,7 +95,7 @@ __device__ __forceinline__ S group_sum(S v) {
   if (G >= 4) v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
   if (G >= 8) v += dpp_mov<0x141>(v);  // row_half_mirror
   if (G >= 16) v += dpp_mov<0x140>(v); // row_mirror
-  if (G == 32) v += lane_xor(v, 16);
+  if (G == 32) v = pair_sum_xor16(v);
   if (G >= 64 && sizeof(S) == 8) {   // float64: the permute form (the scalar-register form below miscompiled in the largest
     v += lane_xor(v, 16);            // float64 backward kernel, 64 lanes x 8 points, which spills heavily)
     v += lane_xor(v, 32);
