@@ -62,6 +62,7 @@ __device__ __forceinline__ double mf_readlane(double v, int l) {
   return __builtin_bit_cast(double, p);
 }
 __device__ __forceinline__ float lane_xor(float v, int m) { return __shfl_xor(v, m, 64); }
+__device__ __forceinline__ double lane_xor(double v, int m) { return __shfl_xor(v, m, 64); }
 // v(lane) + v(lane ^ 16) / v(lane) + v(lane ^ 32) on gfx950's row / half-wave swaps: V_PERMLANE16_SWAP exchanges the odd rows of its
 // first operand with the even rows of its second, V_PERMLANE32_SWAP the upper half of the first with the lower half of the second --
 // given the same value twice they return (rows 0 0 2 2, rows 1 1 3 3) and (lower lower, upper upper), whose sum is the pair sum in
@@ -82,7 +83,6 @@ __device__ __forceinline__ float pair_sum_xor32(float v) {
 }
 __device__ __forceinline__ double pair_sum_xor16(double v) { return v + lane_xor(v, 16); }
 __device__ __forceinline__ double pair_sum_xor32(double v) { return v + lane_xor(v, 32); }
-__device__ __forceinline__ double lane_xor(double v, int m) { return __shfl_xor(v, m, 64); }
 
 // All-reduce (sum) over aligned groups of G consecutive lanes; every lane of the group gets the total.
 // G <= 16 stays on DPP (no LDS crossbar round trip): the butterfly xor1, xor2, then the mirror steps, which

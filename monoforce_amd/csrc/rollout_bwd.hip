@@ -101,7 +101,7 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
   if (sizeof(S) == 4 && use_multiwave_bwd(d, p)) {   // one rollout over several waves, from the forward's 16-byte record
     MF_REQUIRE(((uintptr_t)p->rec & 15) == 0, MF_ERR_INVALID, "rollout_bwd: rec must be 16-byte aligned");
     a.rec = (const S*)p->rec;
-    return launch_rollout_bwd_mw_f32(*reinterpret_cast<const RolloutBwdArgs<float>*>(&a), m.G,
+    return launch_rollout_bwd_mw_f32(*reinterpret_cast<const RolloutBwdArgs<float>*>(&a), m.G, d->integrator,
                                      !p->gXds && !p->gRs && !p->gOmegas && !p->gFs && !p->gFf, st);
   }
   if (sizeof(S) == 4 && d->math_mode == MF_MATH_FAST) {

@@ -49,7 +49,10 @@ constexpr int kMwRecFloats = 4;   // per rollout-step: (sum of contact weights, 
 // the direct route.  (Measured and dropped: EVERY step's contributions straight into the tile, no register accumulators --
 // the LDS retires about one atomic lane per cycle and CU, so 8 instructions x 64 lanes x 4 waves cost 2000 cycles per step:
 // 1.53 instead of 1.10 ms at 64 rollouts x 223 points.)  The host picks TILE > 0 where all workgroups fit the CUs' LDS at once.
-template <int G, bool XS_ONLY, int TILE>
+// INTEG: the default integrator (torchdiffeq fixed-grid euler, dphysics.py:499-528) keeps ONE exchange per step; dynamics()
+// (semi-implicit Euler + Rodrigues, :467-497, :274-324) reads the totals of the velocity adjoints AFTER its own step's rotation
+// update has been pushed through the partials, so it takes a second, six-value exchange in the middle of the step.
+template <int G, bool XS_ONLY, int TILE, int INTEG = MF_INTEG_ODEINT_EULER>
 __global__ void __launch_bounds__(G > 64 ? G : 64) rollout_bwd_mw_kernel(const RolloutBwdArgs<float> a) {
   using S = float;
   using M = Mth<float, true>;
@@ -96,7 +99,8 @@ __global__ void __launch_bounds__(G > 64 ? G : 64) rollout_bwd_mw_kernel(const R
   const size_t row0 = (a.layout == MF_LAYOUT_TIME_MAJOR) ? (size_t)b : (size_t)b * a.T;
   const S* ctrl = a.controls + (size_t)b * a.T * 2;
   S* gctrl = a.gcontrols + (size_t)b * a.T * 2;
-  const int n_steps = a.T - 1;
+  constexpr bool DYN = INTEG == MF_INTEG_DYNAMICS;
+  const int n_steps = DYN ? a.T : a.T - 1;
 
   // un-summed adjoint of the body state: the sum over the workgroup's lanes is the adjoint
   S lx[3] = {zero, zero, zero}, lxd[3] = {zero, zero, zero}, lw[3] = {zero, zero, zero}, lR[9];
@@ -111,14 +115,19 @@ __global__ void __launch_bounds__(G > 64 ? G : 64) rollout_bwd_mw_kernel(const R
     S gXs[3], gXds[3], gRs[9], gOm[3], gFs[3], gFf[3];
   };
   auto load_step = [&](int n, StepIn& s) {
-    const size_t row = row0 + (size_t)n * row_stride;
-    const S* px = a.Xraw + row * 3; const S* pxd = a.Xds + row * 3; const S* pw = a.Om + row * 3; const S* pR = a.Rs + row * 9;
+    // the state step n started from: output row n (default integrator: rows are the grid points); dynamics() records the state AFTER
+    // each step, so step n starts from row n - 1 and step 0 from the initial state (pointer selects, no branch)
+    const size_t row = row0 + (size_t)(DYN ? max(n - 1, 0) : n) * row_stride;
+    const bool init = DYN && n == 0;
+    const S* px = init ? a.x_init + b * 3 : a.Xraw + row * 3; const S* pxd = init ? a.xd0 + b * 3 : a.Xds + row * 3;
+    const S* pw = init ? a.w0 + b * 3 : a.Om + row * 3; const S* pR = init ? a.R0 + b * 9 : a.Rs + row * 9;
 #pragma unroll
     for (int c = 0; c < 3; ++c) { s.x[c] = px[c]; s.xd[c] = pxd[c]; s.w[c] = pw[c]; }
 #pragma unroll
     for (int c = 0; c < 9; ++c) s.R[c] = pR[c];
     s.cv = ctrl[n * 2 + 0]; s.cw = ctrl[n * 2 + 1];
-    s.t0 = a.ts[n]; s.t1 = a.ts[min(n + 1, a.T - 1)];
+    if constexpr (DYN) { s.t0 = zero; s.t1 = a.dt; }
+    else { s.t0 = a.ts[n]; s.t1 = a.ts[min(n + 1, a.T - 1)]; }
     const S* pr = a.rec + ((size_t)n * a.B + b) * kMwRecFloats;
     s.csum = pr[0]; s.wraw[0] = pr[1]; s.wraw[1] = pr[2]; s.wraw[2] = pr[3];
   };
@@ -217,7 +226,7 @@ __global__ void __launch_bounds__(G > 64 ? G : 64) rollout_bwd_mw_kernel(const R
     cx = (int)M::clamp((xs[0] + a.d_max) * a.inv_res, -lim, lim);
     cy = (int)M::clamp((xs[1] + a.d_max) * a.inv_res, -lim, lim);
   };
-  if (gl == 0 && a.gcontrols) { gctrl[(a.T - 1) * 2 + 0] = zero; gctrl[(a.T - 1) * 2 + 1] = zero; }   // the last control is never used
+  if (!DYN && gl == 0 && a.gcontrols) { gctrl[(a.T - 1) * 2 + 0] = zero; gctrl[(a.T - 1) * 2 + 1] = zero; }   // the last control is never used by the explicit scheme
 
   S ex[9];      // the step's exchange: partials in, group totals out
   // The exchange itself.  Within a wave (G <= 64): nine DPP group sums.  Over several waves: TransposedExchange (mf_common.h) --
@@ -268,7 +277,7 @@ __global__ void __launch_bounds__(G > 64 ? G : 64) rollout_bwd_mw_kernel(const R
     // ---- deferred atomics of the previous iteration, prefetch of the next one's rows (younger than the gathers) ----
     flush_stash();
     load_step(max(n - 1, 0), nxt);
-    load_up(n, up_nxt);
+    load_up(DYN ? max(n - 1, 0) : n, up_nxt);      // the row step n - 1 produced
 
     // ---- the exchange posted by the previous iteration: totals of the velocity adjoints, the control gradient of step n + 1, gS ----
     // (`ex` lives across iterations: within a wave, G <= 64, post() leaves the group totals in it and wait() is empty)
@@ -301,27 +310,94 @@ __global__ void __launch_bounds__(G > 64 ? G : 64) rollout_bwd_mw_kernel(const R
         tile_sync();
       }
     }
-    // ---- upstream of output row n + 1 ----
+    // ---- upstream of the output row this step produced (default integrator: row n + 1; dynamics(): row n) ----
     S Sxd[3] = {ex[0], ex[1], ex[2]}, Sw[3] = {ex[3], ex[4], ex[5]};
     add_upstream_partials(upn);
-    if constexpr (!XS_ONLY) {
+    if constexpr (!XS_ONLY && !DYN) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         Sxd[c] += upn.gXds[c]; Sw[c] += upn.gOm[c];
         laFs[c] += act ? upn.gFs[c] : zero; laFf[c] += act ? upn.gFf[c] : zero;
       }
     }
-    // ---- integrator backward: y' = y + h f(y) ----
-    const S gxdd[3] = {h * Sxd[0], h * Sxd[1], h * Sxd[2]};
-    const S gwd[3] = {h * Sw[0], h * Sw[1], h * Sw[2]};
+    S gxdd[3], gwd[3];
+    if constexpr (!DYN) {
+      // ---- integrator backward: y' = y + h f(y) ----
 #pragma unroll
-    for (int c = 0; c < 3; ++c) lxd[c] += h * lx[c];                 // x' = x + h xd
+      for (int c = 0; c < 3; ++c) { gxdd[c] = h * Sxd[c]; gwd[c] = h * Sw[c]; }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {                                    // R' = R + h [w]x R, column by column
-      const S gcol[3] = {h * lR[0 * 3 + c], h * lR[1 * 3 + c], h * lR[2 * 3 + c]};
-      const S rc[3] = {R[0 * 3 + c], R[1 * 3 + c], R[2 * 3 + c]};
-      MF_CROSS_ACC(lw[0], lw[1], lw[2], rc, gcol);                                // d/dw of (w x R_c) . g  =  R_c x g
-      MF_CROSS_ACC(lR[0 * 3 + c], lR[1 * 3 + c], lR[2 * 3 + c], gcol, w);         // d/dR_c                  =  g x w
+      for (int c = 0; c < 3; ++c) lxd[c] += h * lx[c];                 // x' = x + h xd
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {                                    // R' = R + h [w]x R, column by column
+        const S gcol[3] = {h * lR[0 * 3 + c], h * lR[1 * 3 + c], h * lR[2 * 3 + c]};
+        const S rc[3] = {R[0 * 3 + c], R[1 * 3 + c], R[2 * 3 + c]};
+        MF_CROSS_ACC(lw[0], lw[1], lw[2], rc, gcol);                                // d/dw of (w x R_c) . g  =  R_c x g
+        MF_CROSS_ACC(lR[0 * 3 + c], lR[1 * 3 + c], lR[2 * 3 + c], gcol, w);         // d/dR_c                  =  g x w
+      }
+    } else {
+      // ---- update_state backward (dphysics.py:274-324), on the PARTIALS: every map below is linear in the adjoint with group-uniform
+      //      coefficients.  R' = R M(w'),  w' = w + wd h,  M = I + K sin(th h) + K^2 (1 - cos(th h)),  K = [w']x / max(|w'|, eps) ----
+      S wn[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) wn[c] = w[c] + M::clamp(wraw[c], -a.omega_max, a.omega_max) * h;
+      const S th = M::sqrt(wn[0] * wn[0] + wn[1] * wn[1] + wn[2] * wn[2]);
+      const S den = mf_max(th, (S)1e-6);
+      const S kv[3] = {M::div(wn[0], den), M::div(wn[1], den), M::div(wn[2], den)};
+      S sn_, oc;
+      M::sincos_small(th * h, &sn_, &oc);
+      const S cs_ = one - oc;
+      const S K[9] = {zero, -kv[2], kv[1], kv[2], zero, -kv[0], -kv[1], kv[0], zero};
+      S K2[9], Mx[9];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j2 = 0; j2 < 3; ++j2) {
+          K2[i * 3 + j2] = K[i * 3 + 0] * K[0 * 3 + j2] + K[i * 3 + 1] * K[1 * 3 + j2] + K[i * 3 + 2] * K[2 * 3 + j2];
+          Mx[i * 3 + j2] = ((i == j2 ? one : zero) + K[i * 3 + j2] * sn_) + K2[i * 3 + j2] * oc;
+        }
+      S gM[9], lRn[9];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j2 = 0; j2 < 3; ++j2) {
+          gM[i * 3 + j2] = R[0 * 3 + i] * lR[0 * 3 + j2] + R[1 * 3 + i] * lR[1 * 3 + j2] + R[2 * 3 + i] * lR[2 * 3 + j2];      // R^T lR
+          lRn[i * 3 + j2] = lR[i * 3 + 0] * Mx[j2 * 3 + 0] + lR[i * 3 + 1] * Mx[j2 * 3 + 1] + lR[i * 3 + 2] * Mx[j2 * 3 + 2];   // lR M^T
+        }
+      S ga = zero, gb = zero, gK[9];
+#pragma unroll
+      for (int c = 0; c < 9; ++c) { ga += gM[c] * K[c]; gb += gM[c] * K2[c]; }
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j2 = 0; j2 < 3; ++j2) {
+          S t = zero;      // d(K K) -> gM K^T + K^T gM
+#pragma unroll
+          for (int m = 0; m < 3; ++m) t += gM[i * 3 + m] * K[j2 * 3 + m] + K[m * 3 + i] * gM[m * 3 + j2];
+          gK[i * 3 + j2] = sn_ * gM[i * 3 + j2] + oc * t;
+        }
+      const S gk[3] = {gK[7] - gK[5], gK[2] - gK[6], gK[3] - gK[1]};
+      S gth = ga * h * cs_ + gb * h * sn_;
+      S gwn[3] = {M::div(gk[0], den), M::div(gk[1], den), M::div(gk[2], den)};
+      if (th >= (S)1e-6) gth += M::div(-(gk[0] * wn[0] + gk[1] * wn[1] + gk[2] * wn[2]), den * den);
+      if (th > zero) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) gwn[c] += M::div(gth * wn[c], th);
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { lw[c] += gwn[c]; lxd[c] += h * lx[c]; }      // w' = w + wd h;  x' = x + xd' h
+#pragma unroll
+      for (int c = 0; c < 9; ++c) lR[c] = lRn[c];
+      // the totals this step's chain reads: a second exchange, after the rotation update has gone through the partials
+      S tot6[6] = {lxd[0], lxd[1], lxd[2], lw[0], lw[1], lw[2]};
+      if constexpr (G < 64) {
+        gs.sum_n(tot6);
+      } else {
+        const S v8[8] = {tot6[0], tot6[1], tot6[2], tot6[3], tot6[4], tot6[5], zero, zero};
+        xch.post(v8, zero);
+        xch.template wait<6>(tot6);
+      }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { gxdd[c] = h * tot6[c]; gwd[c] = h * tot6[3 + c]; }      // xd' = xd + xdd h;  w' = w + wd h
     }
 
     // ---- forward recompute of the point's contact (rollout_fwd_kernel.h, PIPE path) ----
@@ -374,8 +450,9 @@ __global__ void __launch_bounds__(G > 64 ? G : 64) rollout_bwd_mw_kernel(const R
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
       const S com = gf[c];
-      gFr_[c] = XS_ONLY ? com : h * laFs[c] + com;
-      const S gFf_ = XS_ONLY ? com : h * laFf[c] + com;
+      // (default integrator: the force outputs are running impulses, their adjoints accumulate; dynamics(): the forces themselves)
+      gFr_[c] = XS_ONLY ? com : (DYN ? (act ? upn.gFs[c] : zero) : h * laFs[c]) + com;
+      const S gFf_ = XS_ONLY ? com : (DYN ? (act ? upn.gFf[c] : zero) : h * laFf[c]) + com;
       gG[c] = inside(Gf[c], -a.mg, a.mg) ? gFf_ : zero;
     }
     const S gNn = gG[0] * st[0] + gG[1] * st[1] + gG[2] * st[2];
@@ -469,7 +546,8 @@ __global__ void __launch_bounds__(G > 64 ? G : 64) rollout_bwd_mw_kernel(const R
       lR[6] += (ge[2] - dote * e[2]) * il;
     }
     // ---- what the next iteration reads as totals ----
-    ex[0] = lxd[0]; ex[1] = lxd[1]; ex[2] = lxd[2]; ex[3] = lw[0]; ex[4] = lw[1]; ex[5] = lw[2];
+    if constexpr (DYN) { ex[0] = ex[1] = ex[2] = ex[3] = ex[4] = ex[5] = zero; }      // (dynamics(): summed in the middle of the step)
+    else { ex[0] = lxd[0]; ex[1] = lxd[1]; ex[2] = lxd[2]; ex[3] = lw[0]; ex[4] = lw[1]; ex[5] = lw[2]; }
     ex[6] = gtv; ex[7] = tcw * gtv; ex[8] = gS_p;
 #ifndef MF_MW_DBG_NOEXCHANGE   // A/B hook: the step without its exchange (wrong gradients, the instruction stream minus the sums)
     post9(ex);
@@ -479,7 +557,7 @@ __global__ void __launch_bounds__(G > 64 ? G : 64) rollout_bwd_mw_kernel(const R
   StepIn sA, sB;
   UpIn uA, uB;
   load_step(max(n_steps - 1, 0), sA);
-  load_up(min(n_steps, a.T - 1), uA);
+  load_up(DYN ? max(n_steps - 1, 0) : min(n_steps, a.T - 1), uA);
   {   // the exchange the first iteration fetches: nothing yet
 #pragma unroll
     for (int k = 0; k < 9; ++k) ex[k] = zero;
@@ -519,9 +597,10 @@ __global__ void __launch_bounds__(G > 64 ? G : 64) rollout_bwd_mw_kernel(const R
     tile_sync();
     tile_flush();
   }
-  // output row 0 is the initial state itself (its forces are constant zeros)
-  load_up(0, up);
-  add_upstream_partials(up);
+  if constexpr (!DYN) {      // output row 0 is the initial state itself (its forces are constant zeros)
+    load_up(0, up);
+    add_upstream_partials(up);
+  }
   S tot[18];
 #pragma unroll
   for (int c = 0; c < 3; ++c) { tot[c] = lx[c]; tot[3 + c] = lxd[c]; tot[6 + c] = lw[c]; }
@@ -576,7 +655,7 @@ __global__ void __launch_bounds__(G > 64 ? G : 64) rollout_bwd_mw_kernel(const R
 // defined in rollout_bwd_mw_fast.hip
 bool use_multiwave_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p);   // this backward goes to the kernels above
 long long mw_record_bytes(const MfRolloutDesc* d);                           // bytes of the record the forward keeps for them (0: none)
-int launch_rollout_bwd_mw_f32(const RolloutBwdArgs<float>& a, int G, bool xs_only, hipStream_t st);
+int launch_rollout_bwd_mw_f32(const RolloutBwdArgs<float>& a, int G, int integ, bool xs_only, hipStream_t st);
 // cells per side of a rollout's LDS gradient tile; 0 = none.  Measured (B = 64 x N = 223: 1.094 -> 1.038 ms; 256 x 64: 0.861 -> 0.845;
 // 1024 x 32: 0.971 -> 0.967; 256 x 16: 0.692 -> 0.883 -- four tiles per wave collide in the LDS): whole-wave groups only
 constexpr int mw_tile_edge(int G) { return G >= 64 ? 64 : 0; }

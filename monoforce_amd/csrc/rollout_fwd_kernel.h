@@ -756,6 +756,9 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
     for (; n + 1 < n_steps; n += 2) { pipe_step(n, gA, hA, gB, hB); pipe_step(n + 1, gB, hB, gA, hA); }
     if (n < n_steps) pipe_step(n, gA, hA, gB, hB);
   } else {
+  __shared__ __attribute__((aligned(16))) float xg_lds[(FAST && G > 64) ? TransposedExchange<(G > 64 ? G / 64 : 1)>::kWords : 4];
+  TransposedExchange<(G > 64 ? G / 64 : 1)> xch_g;
+  xch_g.lds = xg_lds;
   for (int n = 0; n < n_steps; ++n) {
     if (JOINTS) articulate_body<S, G, PPL, FAST>(gs, a.joint_angles + ((size_t)b * a.T + n) * 4, a.joint_xyz, a.mass / (S)a.N, P0, part, act, P, Iv);
     // ---- geometry of the contact points and the gathers that depend only on it ----
@@ -893,7 +896,16 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
     }
     if (FAST) {   // one batched reduction of the wrench (multi-wave groups: one LDS exchange)
       S wr[6] = {sFr[0], sFr[1], sFr[2], sTau[0], sTau[1], sTau[2]};
-      gs.sum_n(wr);
+      if constexpr (FAST && G > 64) {      // ... the transposed one (mf_common.h): about half the instructions of six plain workgroup sums
+        const float v8[8] = {(float)wr[0], (float)wr[1], (float)wr[2], (float)wr[3], (float)wr[4], (float)wr[5], 0.0f, 0.0f};
+        xch_g.post(v8, 0.0f);
+        float tot[6];
+        xch_g.template wait<6>(tot);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) wr[c] = (S)tot[c];
+      } else {
+        gs.sum_n(wr);
+      }
 #pragma unroll
       for (int c = 0; c < 3; ++c) { sFr[c] = wr[c]; sTau[c] = wr[3 + c]; }
     } else {      // exact mode keeps the reference's two separate force sums
@@ -1058,18 +1070,22 @@ int launch_rollout_fwd(const RolloutArgs<S>& a, LaneMap m, int integ, int block,
   return MF_OK;
 }
 
-// The one-point-per-lane mappings of the default integrator with the record for their backward (rollout_bwd_mw_kernel.h):
+// The one-point-per-lane mappings (both integrators) with the record for their backward (rollout_bwd_mw_kernel.h):
 // a.rec != NULL.  Bodies of 5..64 points (several rollouts per wave; plain or interleaved maps) and of 65..512 (one per workgroup).
 template <bool FORCES, bool ZMU = false>
-int launch_rollout_fwd_mw_rec(const RolloutArgs<float>& a, LaneMap m, hipStream_t st) {
+int launch_rollout_fwd_mw_rec(const RolloutArgs<float>& a, LaneMap m, int integ, hipStream_t st) {
   bool launched = false;
 #define MF_CASE(G_)                                                                                                          \
   if (!launched && m.G == G_ && m.PPL == 1) {                                                                                \
     launched = true;                                                                                                         \
     const int blk = G_ > 64 ? G_ : 64;                                                                                       \
     const unsigned grid = (unsigned)(((long long)a.B * G_ + blk - 1) / blk);                                                 \
-    hipLaunchKernelGGL((rollout_fwd_kernel<float, G_, 1, MF_INTEG_ODEINT_EULER, true, false, FORCES, 0, false, ZMU, true>),  \
-                       dim3(grid), dim3(blk), 0, st, a);                                                                     \
+    if (integ == MF_INTEG_DYNAMICS)                                                                                          \
+      hipLaunchKernelGGL((rollout_fwd_kernel<float, G_, 1, MF_INTEG_DYNAMICS, true, false, FORCES, 0, false, ZMU, true>),    \
+                         dim3(grid), dim3(blk), 0, st, a);                                                                   \
+    else                                                                                                                     \
+      hipLaunchKernelGGL((rollout_fwd_kernel<float, G_, 1, MF_INTEG_ODEINT_EULER, true, false, FORCES, 0, false, ZMU, true>), \
+                         dim3(grid), dim3(blk), 0, st, a);                                                                   \
   }
   MF_CASE(8) MF_CASE(16) MF_CASE(32) MF_CASE(64)
   if constexpr (!ZMU) { MF_CASE(128) MF_CASE(256) MF_CASE(512) }

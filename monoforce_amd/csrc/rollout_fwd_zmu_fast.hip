@@ -11,8 +11,8 @@ int launch_rollout_fwd_zmu_f32(const RolloutArgs<float>& a, LaneMap m, int integ
     if (!forces) return launch_rollout_fwd<float, true, false, false, 0, true, true>(a, m, integ, block, st);
     return launch_rollout_fwd<float, true, false, true, 0, true, true>(a, m, integ, block, st);
   }
-  if (a.rec != nullptr && m.G >= 8 && m.G <= 64 && m.PPL == 1 && integ == MF_INTEG_ODEINT_EULER)      // the record of rollout_bwd_mw_kernel.h
-    return forces ? launch_rollout_fwd_mw_rec<true, true>(a, m, st) : launch_rollout_fwd_mw_rec<false, true>(a, m, st);
+  if (a.rec != nullptr && m.G >= 8 && m.G <= 64 && m.PPL == 1)      // the record of rollout_bwd_mw_kernel.h
+    return forces ? launch_rollout_fwd_mw_rec<true, true>(a, m, integ, st) : launch_rollout_fwd_mw_rec<false, true>(a, m, integ, st);
   if (!forces) return launch_rollout_fwd<float, true, false, false, 0, false, true>(a, m, integ, block, st);
   return launch_rollout_fwd<float, true, false, true, 0, false, true>(a, m, integ, block, st);
 }
