@@ -5,7 +5,7 @@
 
 namespace mf {
 
-// The launches these kernels serve: float32 MF_MATH_FAST, default integrator, rigid body, one point per lane --
+// The launches these kernels serve: float32 MF_MATH_FAST, either integrator, rigid body, one point per lane --
 //   * bodies of 65..512 points spread over 2 / 4 / 8 waves by choose_lane_map (<= 2048 waves per launch), and
 //   * bodies of 5..64 points (8 / 16 / 32 / 64 lanes per rollout) below one wave per SIMD, where the forward runs a kernel with
 //     plain stores (the split-store kernels of larger launches keep no record).  N <= 4 has the component-parallel kernels.

@@ -1,7 +1,7 @@
 // Fused DPhysics rollout, backward pass for ONE ROLLOUT OVER SEVERAL WAVES (gfx950): bodies of 65..512 contact points at small
 // batch sizes -- the reference's own operating point, 4..64 rollouts of its 175- / 223-point robots
 // (/root/reference/monoforce/examples/diff_physics.ipynb:199-226, scripts/train.py --bsz 4, n_sim_trajs = 64).  float32
-// MF_MATH_FAST, default integrator (torchdiffeq fixed-grid euler, dphysics.py:499-528), rigid body.
+// MF_MATH_FAST, rigid body; the default integrator (torchdiffeq fixed-grid euler, dphysics.py:499-528) and dynamics() (:467-497).
 //
 // Same adjoint as rollout_bwd_kernel.h (reverse-time vector-Jacobian product of `forward_kinematics`, dphysics.py:172-272, from
 // the saved state rows), re-organised around what one wave per SIMD pays for: instructions and workgroup exchanges.  The general
