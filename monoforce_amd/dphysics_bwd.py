@@ -15,6 +15,17 @@ import os
 GRAD_COPIES = int(os.environ.get('MF_GRAD_COPIES', '16'))     # 16 and 64 measure the same kernel time; 16 zero-fills 4x less
 
 
+def grad_copies_for(B, N):
+    """Private gradient copies of a shared map for B rollouts of an N-point body.  Bodies of up to 4 points: ~64 rollouts per copy
+    between GRAD_COPIES and 256 (16 and 64 copies measure the same kernel time there).  Larger bodies put N points of every
+    rollout on nearly the same cells (the rollouts of a batch start from one pose): at least 64 copies -- measured with
+    tools/ab_grad_copies.py, backward kernel at 16 / 64 / 256 copies: 256 x 223 points 1.20 / 0.94 / 0.88 ms, 1024 x 32 points
+    0.98 / 0.81 / 0.78 ms, 64 x 223 0.91 / 0.85 / 0.85 ms (one copy per rollout) -- 64, not 256: the zero fill and the
+    reduction over the copies grow with them (2 x 256 KiB each at 256 x 256)."""
+    floor = GRAD_COPIES if N <= 4 else max(GRAD_COPIES, 64)
+    return max(1, min(max(floor, B // 64), 256, B))
+
+
 class GradPool:
     """The private gradient copies of a shared-map backward, [n_maps][copies][H*W] + 16 zeros (the row absent upstream
     gradients point at), kept ZEROED between steps: `mf_reduce_grad_copies_*` sums the copies and clears them in one launch, so a
@@ -101,7 +112,7 @@ def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf, gloss=None):
     if desc.map_shared:
         # private gradient copies: rollout b scatters into copy b % copies, summed below (same-address atomics serialise)
         # ~64 rollouts per copy (same-address atomics serialise), between GRAD_COPIES and 256 copies
-        copies = max(1, min(max(GRAD_COPIES, B // 64), 256, B))
+        copies = grad_copies_for(B, desc.N)
         desc.grad_copies = copies
         # one zero fill for [gz copies | gmu copies | the zero row absent upstream gradients point at]
         n_maps = 2 if want_gmu else 1

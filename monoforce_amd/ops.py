@@ -33,7 +33,7 @@ import ctypes as C
 import torch
 
 from . import _lib, _timing
-from .dphysics_bwd import grad_pool
+from .dphysics_bwd import grad_copies_for, grad_pool
 
 
 class _PoolOwner:       # the registered ops have no module to hang the persistent gradient-copy pools on
@@ -159,7 +159,7 @@ def _rollout_bwd(z, mu, controls, x_init, xd0, R0, w0, pts, part_id, Iinv, const
     saved = [tm(t) for t in (Xraw, Xds, Rs, Om)]
     ups = [tm(t) for t in (gXs, gXds, gRs, gOm, gFs, gFf)]
     if d.map_shared:
-        copies = max(1, min(max(16, B // 64), 256, B))
+        copies = grad_copies_for(B, int(d.N))
         d.grad_copies = copies
         n_maps = 2 if muc is not None else 1
         pool = grad_pool(_POOL_OWNER, n_maps, copies, zc[0].numel(), dt, dev)
