@@ -12,12 +12,14 @@ from . import _lib, _timing
 import os
 
 # private copies of a shared map's gradient (2 x 256 KiB each at 256x256); MF_GRAD_COPIES overrides (tuning)
-GRAD_COPIES = int(os.environ.get('MF_GRAD_COPIES', '16'))     # 16 and 64 measure the same kernel time; 16 zero-fills 4x less
+# (c3, 1024 rollouts x 4 points, streaming backward: 16 / 32 / 64 copies -> kernel 0.218 / 0.210 / 0.207 ms, step 0.3865 / 0.3831 /
+#  0.3887 ms -- the reduction over the copies grows with them: 32)
+GRAD_COPIES = int(os.environ.get('MF_GRAD_COPIES', '32'))
 
 
 def grad_copies_for(B, N):
     """Private gradient copies of a shared map for B rollouts of an N-point body.  Bodies of up to 4 points: ~64 rollouts per copy
-    between GRAD_COPIES and 256 (16 and 64 copies measure the same kernel time there).  Larger bodies put N points of every
+    between GRAD_COPIES (32) and 256.  Larger bodies put N points of every
     rollout on nearly the same cells (the rollouts of a batch start from one pose): at least 64 copies -- measured with
     tools/ab_grad_copies.py, backward kernel at 16 / 64 / 256 copies: 256 x 223 points 1.20 / 0.94 / 0.88 ms, 1024 x 32 points
     0.98 / 0.81 / 0.78 ms, 64 x 223 0.91 / 0.85 / 0.85 ms (one copy per rollout) -- 64, not 256: the zero fill and the
