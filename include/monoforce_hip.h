@@ -90,7 +90,10 @@ typedef struct MfRolloutDesc {
                            (only valid when N is a multiple of the lane tile, e.g. N = 4).  Padding slots get zeros. */
   int32_t grad_copies;  /* backward, shared map only: number of private copies of the gz / gmu maps (rollout b scatters into
                            copy b % grad_copies; the caller sums the copies).  Thousands of rollouts of one batch cross the
-                           same cells, and same-address float atomics serialise in L2 at ~20 ns each; 0 or 1 = one copy. */
+                           same cells, and same-address float atomics serialise in L2 at ~20 ns each; 0 or 1 = one copy.
+                           Measured: 32 copies for bodies of up to 4 points (~64 rollouts per copy beyond 2048 rollouts), at least
+                           64 for larger bodies, whose points sit on nearly the same cells in every rollout of a batch
+                           (1024 rollouts x 32 points: backward 0.98 ms at 16 copies, 0.81 ms at 64). */
   int32_t has_joints;   /* 1: MfRolloutFwdBufs.joint_angles will be given (selects the articulated kernels / force stride) */
   int32_t pose_stride;  /* path-cost mode (MfRolloutFwdBufs.cost_rows): Xs / Rs keep every pose_stride-th output row; else 0 */
   int32_t cost_project; /* path-cost mode, MF_INTEG_ODEINT_EULER: 1 = the cost rows carry the third row of the NEAREST ROTATION to
