@@ -164,3 +164,43 @@ def test_multiwave_backward_input_variants(B, N, n_tracks, variant, integ):
         g_ref = run(lambda zz, cc, mm: [o for grp in orc.rollout(spec, zz, cc, friction=mm) for o in grp], 'cpu')
         for nm, a, b in zip(('z', 'controls', 'mu'), g_mw, g_ref):
             assert hp.rel_err(a, b) <= 2e-3, (variant, nm, 'vs oracle', hp.rel_err(a, b))
+
+
+@pytest.mark.parametrize('N,integ', [(100, 1), (64, 1), (223, 0), (32, 1)])
+@pytest.mark.parametrize('start', ['centre', 'edge'])
+def test_long_drives_move_the_gradient_window_and_leave_the_map(N, integ, start):
+    """400 steps on a smooth terrain at res 0.05 (non-chaotic: two float32 evaluation orders stay together).  From the centre the
+    body travels > 0.8 m = 16 cells, so the LDS gradient tile of whole-wave groups (64 cells, re-centred after a quarter of it) moves
+    with it; started 0.4 m from the map's edge it drives over it, where the reference folds and wraps the flat cell indices
+    (dphysics.py:427-435) and the points take the direct route.  Map gradients against the general kernel."""
+    from monoforce_amd import synthetic as syn
+    B, T, res, d_max = 3, 400, 0.05, 3.2
+    pts, masks = syn.robot_points_box(N, seed=N, n_tracks=2)
+    z = (syn.bump_terrain(syn.bump_params(0, smooth=True), d_max, res, torch.float64) * 0.5).float()
+    mu = syn.wave_friction(d_max, res, 0.6, 0.9, 0.7, 0.5, torch.float64).float()
+    ctrl = torch.zeros(B, T, 2)
+    ctrl[..., 0] = torch.tensor([1.0, 0.9, 0.8])[:, None]
+    ctrl[..., 1] = torch.tensor([0.0, 0.15, -0.2])[:, None]
+    x0 = torch.zeros(B, 3)
+    x0[:, 0] = d_max - 0.4 if start == 'edge' else 0.0
+    state = (x0, torch.tensor([[1.0, 0.0, 0.0]]).repeat(B, 1), torch.eye(3).repeat(B, 1, 1), torch.zeros(B, 3))
+
+    def run(ppl):
+        dp = make_dphysics(pts, masks, integ, res, d_max, points_per_lane=ppl)
+        zl, ml, cl = (t.clone().to(DEV).requires_grad_(True) for t in (z, mu, ctrl))
+        (Xs, Xds, Rs, Om), _ = dp(zl.unsqueeze(0).expand(B, -1, -1), cl, state=tuple(t.clone().to(DEV) for t in state),
+                                  friction=ml.unsqueeze(0).expand(B, -1, -1))
+        w_t = torch.linspace(0.2, 1.0, T, device=DEV)[None, :, None]
+        ((Xs * w_t).pow(2).sum() + 0.1 * (Xds * w_t).pow(2).sum()).backward()
+        return Xs.detach().cpu(), [zl.grad.cpu(), ml.grad.cpu(), cl.grad.cpu()]
+
+    xs_mw, g_mw = run(0)
+    xs_1w, g_1w = run(4)
+    travelled = float((xs_mw[:, -1, :2] - xs_mw[:, 0, :2]).norm(dim=-1).max())
+    assert travelled > 0.8, travelled
+    if start == 'edge':
+        assert float(xs_mw[..., 0].max()) > d_max, float(xs_mw[..., 0].max())      # the body origin itself is off the map
+    assert hp.rel_err(xs_mw, xs_1w) <= 1e-3
+    for nm, a, c in zip(('z', 'mu', 'controls'), g_mw, g_1w):
+        assert torch.isfinite(a).all(), nm
+        assert hp.rel_err(a, c) <= 5e-3, (nm, hp.rel_err(a, c))
