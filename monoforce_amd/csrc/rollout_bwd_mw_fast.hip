@@ -7,8 +7,8 @@ namespace mf {
 
 // The launches these kernels serve: float32 MF_MATH_FAST, either integrator, rigid body, one point per lane --
 //   * bodies of 65..512 points spread over 2 / 4 / 8 waves by choose_lane_map (<= 2048 waves per launch), and
-//   * bodies of 5..64 points (8 / 16 / 32 / 64 lanes per rollout) below one wave per SIMD, where the forward runs a kernel with
-//     plain stores (the split-store kernels of larger launches keep no record).  N <= 4 has the component-parallel kernels.
+//   * bodies of 5..64 points (8 / 16 / 32 / 64 lanes per rollout) up to two waves per SIMD (the positions-only instantiations hold
+//     237 registers; beyond, the forward goes out in chunks and the general kernels take over).  N <= 4 has the component-parallel kernels.
 // MF_MW_BWD=0 keeps the general kernel (A/B runs, parity tests of the two against each other).
 static bool mw_shape(const MfRolloutDesc* d) {
   static const bool off = getenv("MF_MW_BWD") && atoi(getenv("MF_MW_BWD")) == 0;
@@ -18,7 +18,7 @@ static bool mw_shape(const MfRolloutDesc* d) {
   if (d->points_per_lane == 4) return false;
   const LaneMap m = choose_lane_map(d->B, d->N, d->points_per_lane == MF_LANES_COMPONENT ? 0 : d->points_per_lane);
   if (m.PPL != 1 || m.G < 8) return false;
-  return m.G > 64 || (long long)d->B * m.G < 1024ll * 64;
+  return m.G > 64 || (long long)d->B * m.G <= 2048ll * 64;
 }
 long long mw_record_bytes(const MfRolloutDesc* d) {
   if (!mw_shape(d)) return 0;

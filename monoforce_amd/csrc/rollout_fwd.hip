@@ -161,7 +161,7 @@ extern "C" int mf_rollout_fwd_f32(const MfRolloutDesc* d, const MfRolloutFwdBufs
     if (!forces && m.PPL == 4 && m.G < 64) m = mf::choose_lane_map(d->B, d->N, 1);
     // >= one wave per SIMD (1024) and a one-point-per-lane mapping within a wave: the split-store kernels (rollout_fwd_kernel.h)
     const bool split = m.PPL == 1 && m.G <= 64 && (long long)d->B * m.G >= 1024ll * 64;
-    if (p->rec && mf::mw_record_bytes(d) > 0) {      // the 16-byte record of rollout_bwd_mw_kernel.h (never a split-store launch)
+    if (p->rec && mf::mw_record_bytes(d) > 0) {      // the 16-byte record of rollout_bwd_mw_kernel.h
       MF_REQUIRE(((uintptr_t)p->rec & 15) == 0, MF_ERR_INVALID, "rollout_fwd: rec must be 16-byte aligned");
       a.rec = (float*)p->rec;
     }

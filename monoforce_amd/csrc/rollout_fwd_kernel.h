@@ -1072,7 +1072,7 @@ int launch_rollout_fwd(const RolloutArgs<S>& a, LaneMap m, int integ, int block,
 
 // The one-point-per-lane mappings (both integrators) with the record for their backward (rollout_bwd_mw_kernel.h):
 // a.rec != NULL.  Bodies of 5..64 points (several rollouts per wave; plain or interleaved maps) and of 65..512 (one per workgroup).
-template <bool FORCES, bool ZMU = false>
+template <bool FORCES, bool ZMU = false, bool SPLIT = false>
 int launch_rollout_fwd_mw_rec(const RolloutArgs<float>& a, LaneMap m, int integ, hipStream_t st) {
   bool launched = false;
 #define MF_CASE(G_)                                                                                                          \
@@ -1081,14 +1081,14 @@ int launch_rollout_fwd_mw_rec(const RolloutArgs<float>& a, LaneMap m, int integ,
     const int blk = G_ > 64 ? G_ : 64;                                                                                       \
     const unsigned grid = (unsigned)(((long long)a.B * G_ + blk - 1) / blk);                                                 \
     if (integ == MF_INTEG_DYNAMICS)                                                                                          \
-      hipLaunchKernelGGL((rollout_fwd_kernel<float, G_, 1, MF_INTEG_DYNAMICS, true, false, FORCES, 0, false, ZMU, true>),    \
+      hipLaunchKernelGGL((rollout_fwd_kernel<float, G_, 1, MF_INTEG_DYNAMICS, true, false, FORCES, 0, SPLIT, ZMU, true>),    \
                          dim3(grid), dim3(blk), 0, st, a);                                                                   \
     else                                                                                                                     \
-      hipLaunchKernelGGL((rollout_fwd_kernel<float, G_, 1, MF_INTEG_ODEINT_EULER, true, false, FORCES, 0, false, ZMU, true>), \
+      hipLaunchKernelGGL((rollout_fwd_kernel<float, G_, 1, MF_INTEG_ODEINT_EULER, true, false, FORCES, 0, SPLIT, ZMU, true>), \
                          dim3(grid), dim3(blk), 0, st, a);                                                                   \
   }
   MF_CASE(8) MF_CASE(16) MF_CASE(32) MF_CASE(64)
-  if constexpr (!ZMU) { MF_CASE(128) MF_CASE(256) MF_CASE(512) }
+  if constexpr (!ZMU && !SPLIT) { MF_CASE(128) MF_CASE(256) MF_CASE(512) }
 #undef MF_CASE
   MF_REQUIRE(launched, MF_ERR_UNSUPPORTED, "rollout_fwd: no recording kernel for this lane mapping");
   hipError_t e = hipGetLastError();

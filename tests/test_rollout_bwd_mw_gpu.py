@@ -56,11 +56,13 @@ def test_the_record_is_requested_for_these_launches():
     assert rec_bytes(64, 223, integ=0) == 100 * 64 * 16 and rec_bytes(64, 223, ppl=4) == 0 and rec_bytes(64, 223, fast=0) == 0
     assert rec_bytes(4096, 223) == 0      # one wave per rollout, several points per lane
     assert rec_bytes(64, 64) == 100 * 64 * 16 and rec_bytes(1024, 32) == 100 * 1024 * 16 and rec_bytes(5, 7) == 100 * 5 * 16
-    assert rec_bytes(2048, 32) == 0       # >= one wave per SIMD: the split-store forward keeps no record
+    assert rec_bytes(2048, 32) == 100 * 2048 * 16 and rec_bytes(4096, 32) == 100 * 4096 * 16      # up to two waves per SIMD (split-store forward)
+    assert rec_bytes(4100, 32) == 0       # beyond: the forward goes out in chunks, the general kernels run
 
 
 @pytest.mark.parametrize('B,N,n_tracks,T', [(3, 100, 2, 40), (5, 223, 4, 40), (2, 300, 2, 25), (2, 400, 4, 25), (64, 223, 2, 12), (1, 175, 2, 1), (2, 175, 2, 2),
-                                             (5, 7, 2, 40), (130, 16, 2, 20), (70, 33, 4, 20), (3, 64, 2, 40), (9, 5, 2, 3)])
+                                             (5, 7, 2, 40), (130, 16, 2, 20), (70, 33, 4, 20), (3, 64, 2, 40), (9, 5, 2, 3),
+                                             (2100, 20, 2, 6)])      # > 1024 waves: the split-store forward with the record
 @pytest.mark.parametrize('xs_only', [False, True])
 @pytest.mark.parametrize('shared', [False, True])
 @pytest.mark.parametrize('integ', [1, 0])
@@ -89,6 +91,12 @@ def test_multiwave_backward_vs_oracle_and_one_wave_kernel(B, N, n_tracks, T, xs_
     for nm, a, b, c in zip(names, g_mw, g_ref, g_1w):
         assert torch.isfinite(a).all(), nm
         # two float32 evaluation orders of these contact-rich rollouts sit 1-2e-4 apart themselves (test_random_shapes_gpu.py)
+        if B > 500 and a.shape[0] == B:
+            # thousands of float32 rollouts: a few per thousand take a clamp / kink decision differently in two evaluation orders
+            # (4 of 1500 random problems) -- per rollout, all but 0.5 % within the bar
+            e = torch.tensor([hp.rel_err(a[i], c[i]) for i in range(B)])
+            assert float((e <= 2e-3).float().mean()) >= 0.995, (nm, 'vs the one-wave kernel', float((e <= 2e-3).float().mean()), float(e.max()))
+            continue
         assert hp.rel_err(a, c) <= 2e-3, (nm, 'vs the one-wave kernel', hp.rel_err(a, c))
         # (... and now and then a float32 rollout of the oracle takes a clamp / kink decision the other way than the HIP float32
         #  forward -- one rollout of 70 in the dynamics() case of 33 points: BOTH kernels then sit the same distance from it; the
