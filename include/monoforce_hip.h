@@ -195,7 +195,7 @@ typedef struct MfRolloutFwdBufs {
                            component-parallel kernels (rigid body of <= 4 points): [T][B * 16 lanes] quads (u, c, omega_d raw, A) --
                            cell coordinate, contact weight, unclamped angular acceleration component, A = k dh + d v_n -- 256 B per
                            rollout-step;
-                           one point per lane, bodies of 5..512 points, either integrator, below one wave per SIMD: [T][B] quads
+                           one point per lane, bodies of 5..512 points, either integrator, up to two waves per SIMD: [T][B] quads
                            (sum of the contact weights, omega_d before its clamp) -- 16 B per rollout-step, what the record-reading
                            backward (rollout_bwd_mw_kernel.h) cannot rebuild without a reduction over the contact points.
                            NULL, or a launch the record does not apply to: nothing is written and the backward recomputes. */
@@ -210,7 +210,7 @@ int mf_rollout_loss_fusable(const MfRolloutDesc* desc);
 
 /* Bytes of MfRolloutFwdBufs.rec / MfRolloutBwdBufs.rec for this launch shape; 0 where the kernels chosen for it keep no record
  * (then pass NULL).  The record pays while the launch is bound by the instruction stream of its waves: few rollouts of a small
- * body (forward +5 %, backward -17 % at 1024 rollouts x 4 points), and bodies of 5..512 points below one wave per SIMD
+ * body (forward +5 %, backward -17 % at 1024 rollouts x 4 points), and bodies of 5..512 points up to two waves per SIMD
  * (16 bytes per rollout-step; backward 2.05 -> 1.04 ms at 64 rollouts x 223 points, 1.38 -> 0.97 ms at 1024 x 32). */
 long long mf_rollout_record_bytes(const MfRolloutDesc* desc);
 

@@ -84,7 +84,7 @@ def test_record_bytes_query(built_lib):
     assert q(B=4097) == 0 and q(B=8192) == 0                 # more than one wave per SIMD: the recomputing kernels
     assert q(integrator=0) == q() and q(integrator=0, B=2048) == 0      # dynamics(): while its backward streams the record (one workgroup per CU)
     assert q(math_mode=_lib.MF_MATH_EXACT) == 0 and q(has_joints=1) == 0
-    # bodies of 5..512 points, one point per lane, either integrator, below one wave per SIMD: the 16-byte record of
+    # bodies of 5..512 points, one point per lane, either integrator, up to two waves per SIMD: the 16-byte record of
     # rollout_bwd_mw_kernel.h (contact count + unclamped angular acceleration per rollout-step)
     assert q(N=5, force_stride=8) == 1024 * 500 * 16 and q(N=32, force_stride=32) == 1024 * 500 * 16 and q(B=64, T=600, N=223, force_stride=256) == 64 * 600 * 16
     assert q(N=32, force_stride=32, B=2048) == 2048 * 500 * 16 and q(N=32, force_stride=32, B=8192) == 0 and q(N=32, force_stride=32, integrator=0) == 1024 * 500 * 16 and q(N=223, force_stride=256, B=4096) == 0
