@@ -467,7 +467,15 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
   // component-parallel kernels' (rollout_fwd_cp_kernel.h): the explicit scheme knows pose n + 1 when step n starts, so its
   // body-frame arms go between the contact count's LDS write and its barrier, its footprints and the requests for their cells
   // between the wrench's write and its barrier, and the cells have the rest of the step and the head of the next to arrive.
-  constexpr bool PIPE = FAST && G > 64 && PPL == 1 && INTEG == MF_INTEG_ODEINT_EULER && !JOINTS && COST == 0;
+  // (Rollouts INSIDE a wave, G = 8 .. 64, keep the plain step: measured with -DMF_PIPE_MIN_G=8, forward with forces, pipelined / plain --
+  //  1024 x 32 points 0.395 / 0.358 ms, 256 x 64 0.394 / 0.367, 2048 x 20 0.437 / 0.419; 256 x 16 0.304 / 0.308, 512 x 8 0.297 / 0.299:
+  //  their group sums are DPP adds with nothing to hide, and the pipelined form holds two footprints in registers.)
+#ifdef MF_PIPE_MIN_G      // A/B hook: the smallest group that takes the pipelined step
+  constexpr int kPipeMinG = MF_PIPE_MIN_G;
+#else
+  constexpr int kPipeMinG = 128;
+#endif
+  constexpr bool PIPE = FAST && G >= kPipeMinG && PPL == 1 && INTEG == MF_INTEG_ODEINT_EULER && !JOINTS && COST == 0;
   if constexpr (PIPE) {
     // ---- the pieces of one step ----
     // geometry of the contact points under the pose (x, R) and the gathers that depend only on it.  PIPE kernels request the cells
@@ -685,7 +693,7 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
     };
     S csum_cur = zero;      // contact count of the step about to run (total over the workgroup)
     static_assert(kWr == 6, "the pipelined step exchanges the fast-math wrench (6) and one contact count");
-    __shared__ __attribute__((aligned(16))) float xch_lds[TransposedExchange<(G > 64 ? G / 64 : 1)>::kWords];
+    __shared__ __attribute__((aligned(16))) float xch_lds[G > 64 ? TransposedExchange<(G > 64 ? G / 64 : 1)>::kWords : 4];
     TransposedExchange<(G > 64 ? G / 64 : 1)> xch;
     xch.lds = xch_lds;
     auto pipe_step = [&](int n, Geo& g, Hgt& hq, Geo& g_next, Hgt& hq_next) {
@@ -717,13 +725,15 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
       for (int c = 0; c < kWr; ++c) ex[c] = wr[c];
       ex[kWr] = hq_next.cj;
       // wrench of step n + contact count of step n + 1: one transposed workgroup exchange (mf_common.h)
-      {
+      if constexpr (G > 64) {
         const float v8[8] = {(float)ex[0], (float)ex[1], (float)ex[2], (float)ex[3], (float)ex[4], (float)ex[5], (float)ex[6], 0.0f};
         xch.post(v8, 0.0f);
         float tot[7];
         xch.template wait<7>(tot);
   #pragma unroll
         for (int c = 0; c < 7; ++c) ex[c] = (S)tot[c];
+      } else {      // a rollout inside a wave: seven DPP group sums
+        gs.template sum_n<kWr + 1>(ex);
       }
   #pragma unroll
       for (int c = 0; c < kWr; ++c) wr[c] = ex[c];
