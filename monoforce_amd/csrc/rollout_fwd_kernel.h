@@ -426,14 +426,31 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
       }
       return;
     }
-    st(pXraw + 0, x[0]); st(pXraw + 1, x[1]); st(pXraw + 2, x[2]);
-    st(pXs + 0, x[0] + R[2] * a.sink);  // Xs += Rs[..., :, 2] * m g / (k + 1e-6)   (dphysics.py:587-589)
-    st(pXs + 1, x[1] + R[5] * a.sink);
-    st(pXs + 2, x[2] + R[8] * a.sink);
-    st(pXds + 0, xd[0]); st(pXds + 1, xd[1]); st(pXds + 2, xd[2]);
-    st(pOm + 0, w[0]); st(pOm + 1, w[1]); st(pOm + 2, w[2]);
+    // A rollout over several waves (default integrator's fast kernels): the waves hold the same state, so they share its stores --
+    // wave 0 the positions, wave 1 the velocities, wave 2 the rotation (two waves: 0 and 1 split them) -- by wave-uniform branches.
+    // -DMF_NO_SHARED_STATE_STORES: every wave stores everything (A/B).
+#ifdef MF_NO_SHARED_STATE_STORES
+    constexpr bool kShare = false;
+#else
+    constexpr bool kShare = FAST && G > 64 && PPL == 1 && INTEG == MF_INTEG_ODEINT_EULER && !JOINTS;
+#endif
+    const int wv = kShare ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    constexpr int kNW = G > 64 ? G / 64 : 1;
+    const bool do_x = !kShare || wv == 0, do_v = !kShare || wv == (kNW > 2 ? 1 : 0), do_R = !kShare || wv == (kNW > 2 ? 2 : 1);
+    if (do_x) {
+      st(pXraw + 0, x[0]); st(pXraw + 1, x[1]); st(pXraw + 2, x[2]);
+      st(pXs + 0, x[0] + R[2] * a.sink);  // Xs += Rs[..., :, 2] * m g / (k + 1e-6)   (dphysics.py:587-589)
+      st(pXs + 1, x[1] + R[5] * a.sink);
+      st(pXs + 2, x[2] + R[8] * a.sink);
+    }
+    if (do_v) {
+      st(pXds + 0, xd[0]); st(pXds + 1, xd[1]); st(pXds + 2, xd[2]);
+      st(pOm + 0, w[0]); st(pOm + 1, w[1]); st(pOm + 2, w[2]);
+    }
+    if (do_R) {
 #pragma unroll
-    for (int c = 0; c < 9; ++c) st(pRs + c, R[c]);
+      for (int c = 0; c < 9; ++c) st(pRs + c, R[c]);
+    }
     pXs += adv * 3; pXds += adv * 3; pOm += adv * 3; pRs += adv * 9; pXraw += adv * 3;
     if (FORCES) {   // compile-time: callers that only consume the states (training) skip 24 N of the 80 + 56 N bytes per step
 #pragma unroll
