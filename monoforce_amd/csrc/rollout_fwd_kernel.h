@@ -426,13 +426,13 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
       }
       return;
     }
-    // A rollout over several waves (default integrator's fast kernels): the waves hold the same state, so they share its stores --
+    // A rollout over several waves (fast kernels): the waves hold the same state, so they share its stores --
     // wave 0 the positions, wave 1 the velocities, wave 2 the rotation (two waves: 0 and 1 split them) -- by wave-uniform branches.
     // -DMF_NO_SHARED_STATE_STORES: every wave stores everything (A/B).
 #ifdef MF_NO_SHARED_STATE_STORES
     constexpr bool kShare = false;
 #else
-    constexpr bool kShare = FAST && G > 64 && PPL == 1 && INTEG == MF_INTEG_ODEINT_EULER && !JOINTS;
+    constexpr bool kShare = FAST && G > 64 && PPL == 1 && !JOINTS;
 #endif
     const int wv = kShare ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
     constexpr int kNW = G > 64 ? G / 64 : 1;
