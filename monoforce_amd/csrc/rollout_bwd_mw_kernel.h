@@ -1,23 +1,27 @@
-// Fused DPhysics rollout, backward pass for ONE ROLLOUT OVER SEVERAL WAVES (gfx950): bodies of 65..512 contact points at small
-// batch sizes -- the reference's own operating point, 4..64 rollouts of its 175- / 223-point robots
-// (/root/reference/monoforce/examples/diff_physics.ipynb:199-226, scripts/train.py --bsz 4, n_sim_trajs = 64).  float32
-// MF_MATH_FAST, rigid body; the default integrator (torchdiffeq fixed-grid euler, dphysics.py:499-528) and dynamics() (:467-497).
+// Fused DPhysics rollout, backward pass for bodies of 5..512 contact points in launches of up to two waves per SIMD (gfx950) --
+// the reference's own operating point, 4..64 rollouts of its 175- / 223-point robots
+// (/root/reference/monoforce/examples/diff_physics.ipynb:199-226, scripts/train.py --bsz 4, n_sim_trajs = 64), and everything between
+// that and the component-parallel kernels of 4-point bodies.  One contact point per lane: G = 8 / 16 / 32 / 64 lanes per rollout
+// inside a wave, or ONE rollout over 2 / 4 / 8 waves of a workgroup.  float32 MF_MATH_FAST, rigid body; the default integrator
+// (torchdiffeq fixed-grid euler, dphysics.py:499-528) and dynamics() (:467-497).
 //
 // Same adjoint as rollout_bwd_kernel.h (reverse-time vector-Jacobian product of `forward_kinematics`, dphysics.py:172-272, from
-// the saved state rows), re-organised around what one wave per SIMD pays for: instructions and workgroup exchanges.  The general
-// kernel spends, per step, four LDS exchanges (contact count, torque, one adjoint scalar, 23 adjoint sums) and 168 DPP
-// reductions of 1425 instructions.  Here
+// the saved state rows), re-organised around what one wave per SIMD pays for: instructions and group exchanges.  The general
+// kernel spends, per step, four exchanges (contact count, torque, one adjoint scalar, 23 adjoint sums) and 168 DPP
+// reductions of 1425 instructions (G = 256).  Here
 //   * the forward keeps a 16-byte record per rollout-step -- the contact count and the unclamped angular acceleration it
 //     evaluated (MfRolloutFwdBufs.rec for this mapping) -- so the recompute of a step needs no reduction at all, and the clamp
 //     of omega_d is gated on the forward's own value;
 //   * the adjoint of the body state (x, xd, R, w) is kept UN-SUMMED over the contact points: every lane carries the partial its
-//     point contributed, pushed through the step's linear recurrence (the coefficients -- R, w, h -- are workgroup-uniform),
+//     point contributed, pushed through the step's linear recurrence (the coefficients -- R, w, h -- are group-uniform),
 //     and summed once after the loop.  Only what a step's per-point chain reads as a total is exchanged: the six components of
 //     the velocity adjoints, the two control-gradient outputs and the scalar gS = dL/d(sum of contact weights) -- nine values;
 //   * gS enters the step linearly (through dL/d(dh) = ... + gS kappa_j), and nothing that depends on it is read as a total
 //     before the step after next: it rides in the SAME exchange as the velocity adjoints and is applied one step late as a
-//     correction (position and rotation partials, the four cell accumulators of the point).
-// One exchange and one barrier per step; the state rows, controls, time grid and record are workgroup-uniform loads.
+//     correction (position and rotation partials, the four cell accumulators of the point);
+//   * over several waves (and for a whole-wave group) the exchange is TransposedExchange (mf_common.h).
+// One exchange -- and over several waves one barrier -- per step (dynamics(): two); the state rows, controls, time grid and record
+// are group-uniform loads.  632 instructions per step at G = 256.
 // (Measured and dropped: the adjoint-independent half of step n - 1 -- pose, gathers, contact model, gates -- rebuilt in the shadow
 //  of step n's exchange.  The ~75 values it carries across the loop edge push the kernel past 256 architectural VGPRs; the
 //  accumulator-register copies that follow cost more than the covered latency: 1.04 -> 1.12 ms at 64 x 223 points, 0.97 -> 1.06 ms
