@@ -322,7 +322,8 @@ class Runner:
                 return (time.perf_counter() - t) / n * 1e3
             t_graph, t_eager = self.max_over_ranks(timed(True)), self.max_over_ranks(timed(False))
             mode['graph'] = t_graph < 1.03 * t_eager       # near a tie the replay wins: its timed region does not depend on the host keeping ahead
-            launch = {'mode': 'one hipGraph replay per step' if mode['graph'] else 'launch by launch',
+            split = bool(wl.get('encoder')) and self.dist_on      # collectives are not captured: two graphs around the live exchange
+            launch = {'mode': ('two hipGraph replays around the exchange' if split else 'one hipGraph replay per step') if mode['graph'] else 'launch by launch',
                       'calibration_ms_per_step': {'graph': t_graph, 'eager': t_eager}}
         self.barrier()
         # HIP events around the C-ABI launches of every 8th step of the timed region, on the stream the kernel is launched on

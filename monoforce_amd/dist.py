@@ -19,12 +19,15 @@ __all__ = ['init', 'world', 'rank', 'active', 'shard_range', 'shard', 'allreduce
 # code path of the multi-GPU step (init_process_group('nccl', device_id=...), all_reduce(AVG) in place, the hooked bucket
 # exchange, a hipGraph replay followed by a collective on the same stream) -- tests/test_dist_nccl_gpu.py, bench.py
 # MF_BENCH_FORCE_DIST=1 -- instead of the first 8-GPU run being the first run of that code.
-FORCE = bool(os.environ.get('MF_DIST_FORCE'))
+FORCE = os.environ.get('MF_DIST_FORCE', '0') not in ('', '0')
 
 
-def init(backend=None, device=None, force=False):
+def init(backend=None, device=None, force=None):
     """Initialise the default process group from torchrun's env (RANK / WORLD_SIZE / MASTER_*); no-op for 1 process unless
-    `force` (a one-rank group: see FORCE)."""
+    `force` (a one-rank group; default: FORCE, i.e. MF_DIST_FORCE -- a forced group also makes `active()` true)."""
+    global FORCE
+    force = FORCE if force is None else bool(force)
+    FORCE = FORCE or force
     if (int(os.environ.get('WORLD_SIZE', '1')) <= 1 and not force) or dist.is_initialized():
         return
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -143,6 +146,16 @@ def allreduce_sum_(tensors, bucket=None, average=False):
     return bucket
 
 
+def _allreduce_sum_async(buf):
+    """Start the sum of one flat buffer across ranks; returns the work handle (None where the exchange already completed)."""
+    if buf.is_cuda and dist.get_backend() == 'gloo':      # CPU-only test rigs: stage through the host, synchronously
+        host = buf.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        buf.copy_(host)
+        return None
+    return dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)        # RCCL over xGMI, on its own stream
+
+
 class GradBuckets:
     """Data-parallel gradient exchange of a parameter list, overlapped with the backward pass (encoder weights, BASELINE
     config 5: ~14 M parameters = 55 MB per step over RCCL).
@@ -163,6 +176,7 @@ class GradBuckets:
     def __init__(self, params, bucket_mb=32.0, average=True):
         self.params = [p for p in params if p.requires_grad]
         self.average = average
+        self.defer = False       # True: hooks and `pack()` only pack; the collectives run in `exchange()` (graph-replayed steps)
         self.buckets = []
         cap = int(bucket_mb * (1 << 20))
         group, nbytes = [], 0
@@ -205,29 +219,38 @@ class GradBuckets:
                 v.zero_()
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])      # one multi-tensor pack
-        if active():
-            buf = b['buf']
-            if buf.is_cuda and dist.get_backend() == 'gloo':      # CPU-only test rigs: stage through the host, synchronously
-                host = buf.cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM)
-                buf.copy_(host)
-            else:
-                b['work'] = dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True)
+        if active() and not self.defer:
+            b['work'] = _allreduce_sum_async(b['buf'])
 
     def _on_grad(self, p):
         b = self.buckets[p._mf_bucket]
         b['ready'] += 1
-        if b['ready'] == len(b['params']) and not b['launched']:
+        if b['ready'] == len(b['params']) and not b['launched'] and not self.defer:
             self._launch(b)
 
-    def finish(self):
-        """After `loss.backward()`: launch what has not been launched, wait, average; `p.grad` then views the reduced buffers."""
+    def pack(self):
+        """After `loss.backward()`: pack (and, unless deferred, start exchanging) every bucket the hooks have not launched."""
         for b in self.buckets:
             if not b['launched']:
                 self._launch(b)
+
+    def exchange(self):
+        """All-reduce every bucket as it stands and wait: the exchange of a deferred step (a step replayed as hipGraphs packs
+        its buckets inside the first graph; collectives are launched live between the graphs), and `comm_ms` of bench.py."""
+        if not active():
+            return
+        works = [_allreduce_sum_async(b['buf']) for b in self.buckets]
+        for w in works:
+            if w is not None:
+                w.wait()
+
+    def finish(self):
+        """After `loss.backward()`: launch what has not been launched, wait, average; `p.grad` then views the reduced buffers."""
+        self.pack()
         for b in self.buckets:
             if b['work'] is not None:
                 b['work'].wait()
+                b['work'] = None
             if self.average and world() > 1:
                 b['buf'].div_(world())
             for v, p, got in zip(b['views'], b['params'], b['got']):

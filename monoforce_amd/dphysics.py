@@ -143,7 +143,9 @@ def _zmu_scratch(mod, desc, z):
 class LossSpec:
     """Ground-truth stamps of `physics_loss` (losses.py:102-127) prepared for the kernels that carry the loss themselves
     (MfRolloutLoss): the SAME stamp times for every rollout.  near[j] = output row nearest in time to stamp j (losses.py:116),
-    w[j] = 1 / (1 + gamma t_j), row_stamp = the inverse table.  Built once per time grid (one small host round trip)."""
+    w[j] = 1 / (1 + gamma t_j), row_stamp = the inverse table.  Built once per time grid (one small host round trip); the tables
+    live in persistent device buffers that `refresh_` rebuilds in place from a new batch's stamps WITHOUT a host round trip, so a
+    captured train step can carry the rebuild (a replay then reads the stamps the caller copied into the batch tensors)."""
 
     def __init__(self, pred_ts, gt_ts, gamma, device, dtype=torch.float32):
         pred_ts = torch.as_tensor(pred_ts, dtype=dtype).reshape(-1).cpu()
@@ -160,8 +162,44 @@ class LossSpec:
         self.w = w.to(device)
         self.row_stamp, self.row_w = row_stamp.to(device), row_w.to(device)
         self.gt_ts = gt_ts.to(device)
-        self.ticket = torch.zeros(1, dtype=torch.int32, device=device)      # the launch leaves it zero
+        self.pred_ts = pred_ts.to(device)
+        self._stamp_ids = torch.arange(self.T2, dtype=torch.int32, device=device)
+        # 0, or NaN once `refresh_` met stamps the fused kernels cannot carry (two stamps on one output row, rows that differ between
+        # the rollouts): callers add it to the loss, so such a batch fails LOUDLY instead of being scored against stale tables
+        self.poison = torch.zeros((), dtype=dtype, device=device)
+        self._tickets = {}
         self._full = {}
+
+    def ticket(self, device, stream):
+        """The zero-initialised launch counter of the loss reductions, one per (device, stream) like `losses._ticket`: launches
+        ordered on one stream share it (the kernel leaves it zero); two streams using one spec (a capture stream beside the default
+        one) no longer tick the same counter."""
+        from . import losses
+        losses._register_reset()
+        t = losses._ticket(device, stream)
+        self._tickets[(device.index, stream.cuda_stream)] = t      # a captured graph replays into this address: it lives as long as the spec
+        return t
+
+    def refresh_(self, gt_ts):
+        """Rebuild the tables in place from new stamps `gt_ts` ([T2], or [B,T2] with every row the same): device ops only, no host
+        synchronisation, capturable.  Returns self."""
+        rows = gt_ts if gt_ts.dim() == 2 else gt_ts.unsqueeze(0)
+        row = rows[0].to(device=self.gt_ts.device, dtype=self.gt_ts.dtype)
+        assert row.numel() == self.T2, f'{row.numel()} stamps, this LossSpec was built for {self.T2}'
+        near = (self.pred_ts.unsqueeze(0) - row.unsqueeze(1)).abs().argmin(dim=1)
+        self.near.copy_(near)
+        self.gt_ts.copy_(row)
+        torch.reciprocal(1. + self.gamma * row, out=self.w)
+        self.row_stamp.fill_(-1).scatter_(0, near, self._stamp_ids)
+        self.row_w.zero_().scatter_(0, near, self.w)
+        bad = (near[1:] <= near[:-1]).any() if self.T2 > 1 else torch.zeros((), dtype=torch.bool, device=row.device)
+        if rows.shape[0] > 1 and rows.stride(0) != 0:
+            bad = bad | (rows != rows[:1]).any()
+        self.poison.copy_(torch.where(bad, float('nan'), 0.))
+        for B, (near_b, ts_b) in self._full.items():
+            near_b.copy_(self.near.unsqueeze(0).expand(B, -1))
+            ts_b.copy_(self.gt_ts.unsqueeze(0).expand(B, -1))
+        return self
 
     def per_rollout(self, B):
         """(nearest [B,T2] int32, gt_ts [B,T2]) as `mf_physics_loss_value_*` reads them (one row per rollout), built once per batch size."""
@@ -223,7 +261,7 @@ def _rollout_forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_gra
     if in_forward:
         partial = torch.empty((B + 3) // 4, dtype=dt, device=dev)
         lstruct = _lib.MfRolloutLoss(T2=spec.T2, gt=_lib.ptr(X_gt), near=_lib.ptr(spec.near), w=_lib.ptr(spec.w), row_stamp=_lib.ptr(spec.row_stamp), row_w=_lib.ptr(spec.row_w),
-                                     partial=_lib.ptr(partial), ticket=_lib.ptr(spec.ticket), loss=_lib.ptr(loss_val))
+                                     partial=_lib.ptr(partial), ticket=_lib.ptr(spec.ticket(dev, torch.cuda.current_stream(dev))), loss=_lib.ptr(loss_val))
         bufs.loss = C.cast(C.pointer(lstruct), C.c_void_p)       # (lstruct stays alive until the launch call below returns)
     fn = getattr(_lib.lib(), 'mf_rollout_fwd_' + _scalar_suffix(dt))
     with torch.cuda.device(dev), _timing.timed('rollout_fwd_kernel', dev):
@@ -243,7 +281,7 @@ def _rollout_forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_gra
         lpart = torch.empty((B * spec.T2 + 255) // 256, dtype=dt, device=dev)
         with torch.cuda.device(dev), _timing.timed('physics_loss_fwd', dev):
             _lib.check(getattr(_lib.lib(), 'mf_physics_loss_value_' + _scalar_suffix(dt))(
-                C.byref(ldesc), _lib.ptr(Xp), _lib.ptr(X_gt), _lib.ptr(gt_ts_b), _lib.ptr(near_b), _lib.ptr(lpart), _lib.ptr(spec.ticket),
+                C.byref(ldesc), _lib.ptr(Xp), _lib.ptr(X_gt), _lib.ptr(gt_ts_b), _lib.ptr(near_b), _lib.ptr(lpart), _lib.ptr(spec.ticket(dev, torch.cuda.current_stream(dev))),
                 _lib.ptr(loss_val), None, C.c_longlong(0), _stream_ptr(dev)), 'mf_physics_loss_value')
     if loss is not None:
         outs = (loss_val,) + outs

@@ -151,7 +151,7 @@ def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf, gloss=None):
                                      gloss=_lib.ptr(gl), Xs=_lib.ptr(Xs_rows))
         if loss_out is not None:       # MF_LOSS_VALUE_IN_BACKWARD: this launch also forms the value the forward left as NaN
             lstruct.flags = _lib.MF_LOSS_VALUE_IN_BACKWARD
-            lstruct.partial, lstruct.ticket, lstruct.loss = _lib.ptr(loss_out[1]), _lib.ptr(spec.ticket), _lib.ptr(loss_out[0])
+            lstruct.partial, lstruct.ticket, lstruct.loss = _lib.ptr(loss_out[1]), _lib.ptr(spec.ticket(dev, torch.cuda.current_stream(dev))), _lib.ptr(loss_out[0])
         bufs.loss = C.cast(C.pointer(lstruct), C.c_void_p)
     fn = getattr(_lib.lib(), 'mf_rollout_bwd_' + _scalar_suffix(dt))
     with torch.cuda.device(dev), _timing.timed('rollout_bwd_kernel', dev):

@@ -143,7 +143,8 @@ class EncoderTrainStep:
         # graph = True: the whole step -- encoder forward, lift-splat, heads, staging, rollout + loss, backward, clip, Adam -- is
         # captured once per batch object and replayed as ONE hipGraph launch: ~4000 launches of ~17 ms of kernels otherwise spend a
         # quarter of the 23 ms step in launch gaps.  Needs the batch tensors to stay the same objects (a fixed-rig loop would copy
-        # each sample into them) and one process (collectives are not captured: multi-rank steps run launch by launch).
+        # each sample into them: stamps included, the captured step rebuilds its stamp tables on the device).  Several ranks: two
+        # graphs around the live exchange (`_step_graph`).
         self.graph = bool(graph)
         self._cap = None
         # coarser grid for the physics than for the encoder: average pooling (scripts/train.py:93-99, 233-235)
@@ -152,8 +153,8 @@ class EncoderTrainStep:
         self.pool_k = k
         self.fused_stage = True        # terrain = geom - diff, both poolings and the (z, mu) interleave as one kernel
         self.loss_in_kernel = True     # physics_loss inside the rollout launches where the stamps are shared by the rollouts
-        self._specs = {}
-        self._nearest = {}
+        self._specs = {}        # per batch STRUCTURE (shape, shared stamps or not): the fused-loss tables, refreshed from each batch's stamps
+        self._nearest = None    # the unfused route's nearest-step table of the last batch (same tensor objects and versions only)
         self.w = (geom_weight, terrain_weight, phys_weight)
         # train.py:374-375; the fused (single multi-tensor kernel) implementation where the parameters live on the GPU
         on_gpu = all(p.is_cuda for p in encoder.parameters())
@@ -182,7 +183,7 @@ class EncoderTrainStep:
         state0 = (x0, torch.zeros_like(x0), pose0[:, :3, :3].contiguous(), torch.zeros_like(x0))   # train.py:237-241
         spec = self._loss_spec(gt_ts, controls.shape[1])
         if spec is not None:      # losses.py:102-127 inside the rollout's own launches
-            l_phys = self.dp.physics_loss_rollout(z, controls, states_gt[0], spec, state=state0, friction=mu)[0]
+            l_phys = self.dp.physics_loss_rollout(z, controls, states_gt[0], spec, state=state0, friction=mu)[0] + spec.poison
         else:
             states, _ = self.dp(z_grid=z, controls=controls, state=state0, friction=mu)
             l_phys = physics_loss_fused(states, states_gt, pred_ts, gt_ts, nearest=nearest)       # losses.py:102-127 on mf_physics_loss_*
@@ -196,79 +197,157 @@ class EncoderTrainStep:
         ([Bs,T,2], the reference's case: per-rollout maps) or, with a single sample, many ([B,T,2]: they share its map)."""
         (imgs, rots, trans, intrins, post_rots, post_trans, hm_geom, hm_terrain, control_ts, controls, pose0,
          traj_ts, Xs, Xds, Rs, Omegas) = batch
-        key = (control_ts.data_ptr(), traj_ts.data_ptr(), tuple(control_ts.shape), tuple(traj_ts.shape))
-        if key not in self._nearest:       # the stamps of a batch are fixed: the [N,T2,T1] argmin once (losses.py:116)
-            self._nearest = {key: nearest_steps(control_ts, traj_ts).to(torch.int32)}
         return self.losses(((imgs, rots, trans, intrins, post_rots, post_trans), hm_geom, hm_terrain, controls, pose0,
-                            [Xs, Xds, Rs, Omegas], control_ts, traj_ts, self._nearest[key]))
+                            [Xs, Xds, Rs, Omegas], control_ts, traj_ts, self._nearest_for(control_ts, traj_ts)))
+
+    @staticmethod
+    def _same_tensor(entry, *tensors):
+        """True when `entry` was built from exactly these tensor OBJECTS at their current versions.  The entry holds the tensors, so
+        their memory cannot have been recycled for another batch; an in-place refill (`copy_`) bumps `_version`."""
+        return (entry is not None and len(entry['src']) == len(tensors)
+                and all(a is b and v == b._version for (a, v), b in zip(entry['src'], tensors)))
+
+    def _nearest_for(self, control_ts, traj_ts):
+        """`nearest_steps(control_ts, traj_ts)` ([N,T2,T1] argmin, losses.py:116) for THIS batch's stamps.  The reference's
+        `traj_ts` are measured per sample (datasets/rough.py:261-296), so nothing is reused across batches by address: the
+        result is kept only for the same tensor objects at the same versions, and always rebuilt (on the device, no host round
+        trip) inside a graph capture, so that a replay follows stamps copied into the batch tensors."""
+        e = self._nearest
+        if torch.cuda.is_current_stream_capturing() or not self._same_tensor(e, control_ts, traj_ts):
+            if control_ts.stride(0) == 0 and traj_ts.stride(0) == 0 and control_ts.shape[0] > 1:      # one row expanded: one argmin
+                near = nearest_steps(control_ts[:1], traj_ts[:1]).to(torch.int32).expand(traj_ts.shape[0], -1)
+            else:
+                near = nearest_steps(control_ts, traj_ts).to(torch.int32)
+            e = self._nearest = dict(src=[(control_ts, control_ts._version), (traj_ts, traj_ts._version)], near=near)
+        return e['near']
 
     def _loss_spec(self, gt_ts, T):
-        """LossSpec of a batch whose ground-truth stamps are the same for every rollout (an expanded row, or rows checked equal once per
-        tensor); None = per-rollout stamps: the unfused physics loss."""
+        """LossSpec of a batch whose ground-truth stamps are the same for every rollout (one row expanded, one rollout, or rows found
+        equal when this batch structure was first seen); None = per-rollout stamps: the unfused physics loss.  WHICH route a
+        batch structure takes is decided once (one host round trip); the tables themselves are rebuilt on the device from every
+        new batch's stamps (`LossSpec.refresh_`: same tensor objects at the same versions are the only thing reused; inside a graph
+        capture always), and a later batch the fused route cannot carry (rows that differ, two stamps on one row) poisons the
+        loss with NaN instead of being scored against another batch's stamps."""
         if not (self.loss_in_kernel and gt_ts.is_cuda):
             return None
-        key = (gt_ts.data_ptr(), tuple(gt_ts.shape), T)
-        if key not in self._specs:
-            shared = gt_ts.stride(0) == 0 or bool((gt_ts == gt_ts[:1]).all())
-            self._specs[key] = self.dp.loss_spec(gt_ts[0], gamma=0.9, n_steps=T) if shared else None
-        return self._specs[key]
+        structural = gt_ts.stride(0) == 0 or gt_ts.shape[0] == 1
+        key = (tuple(gt_ts.shape), structural, T)
+        e = self._specs.get(key)
+        if e is None:
+            shared = structural or bool((gt_ts == gt_ts[:1]).all())
+            spec = self.dp.loss_spec(gt_ts[0], gamma=0.9, n_steps=T) if shared else None
+            if spec is not None and not spec.fusable:
+                spec = None
+            while len(self._specs) >= 8:      # batch structures are few; bounded all the same
+                self._specs.pop(next(iter(self._specs)))
+            e = self._specs[key] = dict(spec=spec, src=[(gt_ts, gt_ts._version)])
+            if spec is None or not torch.cuda.is_current_stream_capturing():
+                return spec
+        spec = e['spec']
+        if spec is None:
+            return None
+        if torch.cuda.is_current_stream_capturing() or not self._same_tensor(e, gt_ts):
+            spec.refresh_(gt_ts)
+            e['src'] = [(gt_ts, gt_ts._version)]
+        return spec
 
     def exchange_only(self):
         """The step's collectives alone, on the buckets as they stand (bench.py: `comm_ms`)."""
-        import torch.distributed as tdist
-        if not mfdist.active():
-            return
-        works = []
-        for b in self.buckets.buckets:
-            buf = b['buf']
-            if buf.is_cuda and tdist.get_backend() == 'gloo':
-                host = buf.cpu()
-                tdist.all_reduce(host)
-                buf.copy_(host)
-            else:
-                works.append(tdist.all_reduce(buf, async_op=True))
-        for w in works:
-            w.wait()
+        self.buckets.exchange()
 
     def step(self, batch, eager=False):
-        """One training step; `eager=True` runs this one launch by launch even in graph mode."""
-        if self.graph and not eager and not mfdist.active():
+        """One training step; `eager=True` runs this one launch by launch even in graph mode.  Several ranks: the step replays
+        as TWO graphs around its one exchange (`_step_graph`)."""
+        if self.graph and not eager:
             return self._step_graph(batch)
         return self._step_eager(batch)
 
+    # -- graph mode ------------------------------------------------------------------------------------------------------------
+    def _snapshot(self):
+        """Everything a step changes: parameters and buffers (batch-norm statistics) of the encoder, the optimizer's state."""
+        import copy
+        return ([t.detach().clone() for t in self.enc.state_dict().values()], copy.deepcopy(self.opt.state_dict()['state']))
+
+    def _restore(self, snap):
+        """Back to `_snapshot()` IN PLACE (captured graphs and Adam's capturable state keep their addresses).  Optimizer state that
+        did not exist at the snapshot (the first step creates it) is reset to what a fresh optimizer holds: zeros."""
+        tensors, opt_state = snap
+        with torch.no_grad():
+            for t, old in zip(self.enc.state_dict().values(), tensors):
+                t.copy_(old)
+            ids = {id(p): i for i, p in enumerate(p for g in self.opt.param_groups for p in g['params'])}
+            for p, st in self.opt.state.items():
+                old = opt_state.get(ids[id(p)])
+                for k, v in st.items():
+                    if torch.is_tensor(v):
+                        v.copy_(old[k]) if old is not None else v.zero_()
+
     def _step_graph(self, batch):
+        """The step as hipGraph replays, captured once per batch object.  One rank: ONE graph.  Several ranks (collectives are not
+        captured): graph A = zero the buckets, forward, backward, pack the buckets | the bucket all-reduces, launched live |
+        graph B = average, clip, Adam.  The exchange then starts after the backward instead of from its hooks -- ~55 MB over xGMI
+        against the ~3 ms of launch gaps a 1000-launch step pays launch by launch.
+        The warm-up steps in front of the capture (MIOpen picks its solvers, workspaces and Adam state come into being) run on
+        real data but leave no trace: parameters, batch-norm statistics and optimizer state are restored afterwards, so the first
+        `step()` applies exactly ONE update, like the launch-by-launch step."""
         cap = self._cap
-        if cap is None or cap['batch'] is not batch:
+        split = mfdist.active()
+        if cap is None or cap['batch'] is not batch or cap['split'] != split:
             dev = next(self.enc.parameters()).device
+            snap = self._snapshot()
             s = torch.cuda.Stream(device=dev)
             s.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(s):      # warm-up on the capture stream: MIOpen's solvers chosen, workspaces, pools, Adam state in place
-                for _ in range(3):
-                    self._step_eager(batch)
-            torch.cuda.current_stream(dev).wait_stream(s)
-            g = torch.cuda.CUDAGraph()
+            self.buckets.defer = split
             try:
+                with torch.cuda.stream(s):
+                    for _ in range(3):
+                        self._step_eager(batch)
+                    self._restore(snap)
+                torch.cuda.current_stream(dev).wait_stream(s)
+                g, g2 = torch.cuda.CUDAGraph(), None
                 with torch.cuda.graph(g, stream=s, capture_error_mode='thread_local'):
-                    out = self._step_eager(batch)
+                    out = self._forward_backward(batch) if split else self._step_eager(batch)
+                if split:
+                    g2 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g2, stream=s, pool=g.pool(), capture_error_mode='thread_local'):
+                        self._apply()
             except RuntimeError as e:
                 import warnings
                 warnings.warn(f'EncoderTrainStep: hipGraph capture failed ({str(e).splitlines()[0][:160]}); running launch by launch')
-                self.graph = False
+                self.graph, self.buckets.defer = False, False
                 torch.cuda.synchronize(dev)
+                self._restore(snap)
                 return self._step_eager(batch)
-            cap = self._cap = dict(graph=g, batch=batch, out=out)
+            cap = self._cap = dict(graph=g, apply=g2, batch=batch, out=out, split=split)
         cap['graph'].replay()
+        if cap['split']:
+            self.buckets.exchange()
+            cap['apply'].replay()
         return cap['out']
 
-    def _step_eager(self, batch):
+    # -- the step itself ---------------------------------------------------------------------------------------------------
+    def _forward_backward(self, batch):
+        """Zero the buckets, forward, backward: afterwards every bucket holds this rank's packed gradients; their all-reduces are
+        running (launched from the hooks) unless the buckets are in deferred mode."""
         self.buckets.zero()
         l_geom, l_terr, l_phys = self.losses(batch)
         loss = self.w[0] * l_geom + self.w[1] * l_terr + self.w[2] * l_phys
         loss.backward()                      # bucket all-reduces are launched from the hooks as their gradients complete
+        self.buckets.pack()                  # (whatever the hooks have not packed)
+        return loss.detach(), (l_geom.detach(), l_terr.detach(), l_phys.detach())
+
+    def _apply(self):
+        """Average the exchanged buckets, clip, Adam (scripts/train.py:165-168)."""
         self.buckets.finish()                # wait + average (no-op for one process)
         torch.nn.utils.clip_grad_norm_(self.params, max_norm=1.0)                   # train.py:167
         self.opt.step()
-        return loss.detach(), (l_geom.detach(), l_terr.detach(), l_phys.detach())
+
+    def _step_eager(self, batch):
+        out = self._forward_backward(batch)
+        if self.buckets.defer:
+            self.buckets.exchange()
+        self._apply()
+        return out
 
 
 def synthetic_rough_batch(encoder, dphysics, n_rollouts, device, seed=0, img_hw=(256, 512)):

@@ -1,0 +1,135 @@
+"""BASELINE configs[4] (c5: 8192 rollouts in total + encoder, data-parallel) on the one-GPU rig, so that an 8-GPU run is not the
+first run of its code: `bench.py --workload c5` as two gloo ranks sharing GPU 0 and as ONE forced RCCL rank, the
+default multi-rank line (strong_c3 and c5 among its `other_workloads`), and the exchanged encoder gradients of a two-rank step
+-- launch by launch with the hooked bucket exchange, and replayed as two hipGraphs around the live exchange -- against the
+single-process gradients of both ranks' samples."""
+import json
+import os
+import subprocess
+import sys
+import tempfile
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, env_extra, timeout=1500):
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
+    env.update({'HSA_ENABLE_IPC_MODE_LEGACY': '0'})
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py')] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+
+
+def _check_c5(out, world, backend):
+    assert out['n_gpus'] == world and out['world_size'] == world and out['backend'] == backend
+    assert out['scaling'] == 'strong'
+    assert out['config']['rollouts_total'] == 8192 and out['config']['rollouts_per_gpu'] == 8192 // world
+    assert out['comm_ms'] is not None and 0 < out['comm_ms'] < 500
+    assert out['value'] > 0 and out['ms_per_step_ranks']['min'] <= out['ms_per_step_ranks']['max']
+    assert 'c5' in out['config']['workload'] and 'encoder train step' in out['config']['workload']
+    assert set(out['roofline']['per_kernel']) >= {'rollout_fwd_kernel', 'rollout_bwd_kernel', 'lift_splat_fwd_kernel', 'lift_splat_bwd_kernel'}
+
+
+def test_c5_two_gloo_ranks_sharing_the_gpu():
+    """2 ranks x (4096 rollouts + one 4-camera sample) on GPU 0; the step replays as two hipGraphs around the live exchange."""
+    out = _bench(['--workload', 'c5', '--gpus', '2', '--steps', '2', '--warmup', '1', '--no-cpu-baseline'],
+                 {'MF_BENCH_SINGLE_DEVICE': '1', 'MF_BENCH_BACKEND': 'gloo'})
+    _check_c5(out, 2, 'gloo')
+    assert out['config']['launch']['mode'] in ('two hipGraph replays around the exchange', 'launch by launch')
+
+
+def test_c5_one_forced_rccl_rank():
+    """8192 rollouts + the encoder on one rank whose collectives all run (RCCL, world size 1)."""
+    out = _bench(['--workload', 'c5', '--gpus', '1', '--steps', '2', '--warmup', '1', '--no-cpu-baseline'], {'MF_BENCH_FORCE_DIST': '1'})
+    _check_c5(out, 1, 'rccl')
+
+
+def test_default_multi_rank_line_carries_strong_c3_and_c5():
+    """The DEFAULT command at N = 2 (no --no-others): weak-scaling headline + forward_only + strong_c3 + c5."""
+    out = _bench(['--gpus', '2', '--steps', '4', '--warmup', '2', '--no-cpu-baseline'], {'MF_BENCH_SINGLE_DEVICE': '1', 'MF_BENCH_BACKEND': 'gloo'})
+    assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['config']['rollouts_total'] == 2048
+    ow = out['other_workloads']
+    assert set(ow) >= {'strong_c3', 'c5'}
+    assert ow['strong_c3']['scaling'].startswith('strong') and '4096/GPU' in ow['strong_c3']['workload'] and ow['strong_c3']['comm_ms'] > 0
+    assert ow['c5']['scaling'] == 'strong' and '4096/GPU' in ow['c5']['workload'] and ow['c5']['comm_ms'] > 0
+    assert out['forward_only']['value'] > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+def _small_rig(dev, seed, graph):
+    from monoforce_amd import synthetic as syn
+    from monoforce_amd.dphys_config import DPhysConfig
+    from monoforce_amd.dphysics import DPhysics
+    from monoforce_amd.terrain_encoder import LiftSplatShoot
+    from monoforce_amd.train import EncoderTrainStep, synthetic_encoder_batch
+    torch.manual_seed(0)                      # identical initial weights everywhere (DDP convention)
+    gc = dict(xbound=[-3.2, 3.2, 0.1], ybound=[-3.2, 3.2, 0.1], zbound=[-3.2, 3.2, 6.4], dbound=[0.6, 3.4, 0.2])
+    enc = LiftSplatShoot(gc, dict(final_dim=(64, 128))).to(dev).eval()      # eval: no drop-connect randomness
+    pts, masks = syn.robot_points_4()
+    cfg = DPhysConfig(robot='tradr', grid_res=0.1, robot_points=pts, driving_parts=masks)
+    cfg.d_max, cfg.traj_sim_time = 3.2, 1.0
+    dp = DPhysics(cfg, device=dev)
+    batch = synthetic_encoder_batch(enc, dp, n_rollouts=64, device=dev, seed=seed, img_hw=(64, 128))
+    return enc, EncoderTrainStep(enc, dp, lr=1e-4, graph=graph), batch
+
+
+def _enc_worker(rank, world, store, graph, out_path):
+    import torch.distributed as dist
+    sys.path.insert(0, REPO)
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group('gloo', init_method='file://' + store, rank=rank, world_size=world)
+    enc, step, batch = _small_rig(dev, seed=rank, graph=graph)
+    before = [p.detach().clone() for p in enc.parameters()]
+    loss, _ = step.step(batch)               # graph: three traceless warm-up steps, two captures, replay | exchange | replay
+    if graph:
+        assert step.graph and step._cap is not None and step._cap['split'], 'the capture fell back to launch by launch'
+        assert step.buckets.defer
+    else:
+        assert not step.buckets.defer
+    torch.cuda.synchronize()
+    if rank == 0:
+        grads = [None if p.grad is None else p.grad.detach().cpu().clone() for p in step.params]
+        moved = max(float((p.detach() - b).abs().max()) for p, b in zip(enc.parameters(), before))
+        torch.save({'grads': grads, 'loss': float(loss), 'moved': moved}, out_path)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('graph', [False, True])
+def test_two_rank_encoder_gradients_equal_the_single_process_ones(graph):
+    """Each rank: its own 4-camera sample + 64 rollouts.  The rank-averaged, clipped gradients every rank applies == the mean of
+    the two samples' single-process gradients, clipped -- with the hooked (overlapped) bucket exchange of the launch-by-launch
+    step, and with the deferred exchange between the two hipGraphs of the replayed step (whose first call must apply ONE update)."""
+    import torch.multiprocessing as mp
+    dev = torch.device('cuda', 0)
+    with tempfile.TemporaryDirectory() as td:
+        mp.spawn(_enc_worker, args=(2, os.path.join(td, 'store'), graph, os.path.join(td, 'two.pt')), nprocs=2, join=True)
+        two = torch.load(os.path.join(td, 'two.pt'))
+    per_sample = []
+    for seed in (0, 1):
+        enc, step, batch = _small_rig(dev, seed=seed, graph=False)
+        l_geom, l_terr, l_phys = step.losses(batch)
+        (l_geom + l_terr + l_phys).backward()
+        per_sample.append([None if p.grad is None else p.grad.detach().clone() for p in step.params])
+    mean = [None if a is None else (a + b) / 2 for a, b in zip(*per_sample)]
+    params = [torch.nn.Parameter(torch.zeros_like(g)) for g in mean if g is not None]
+    for p, g in zip(params, [g for g in mean if g is not None]):
+        p.grad = g
+    torch.nn.utils.clip_grad_norm_(params, max_norm=1.0)
+    it = iter(params)
+    checked = 0
+    gmax = max(float(p.grad.abs().max()) for p in params)
+    for g2, g1 in zip(two['grads'], mean):
+        assert (g2 is None) == (g1 is None)
+        if g1 is None:
+            continue
+        ref = next(it).grad.cpu()
+        # float atomics (rollout, splat) make single gradients noisy at the 1e-6 level of the largest one
+        assert float((g2 - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-5 * gmax, checked
+        checked += 1
+    assert checked > 100 and 0 < two['moved'] <= 1.5e-4        # ONE Adam update of lr = 1e-4 (graph mode: the warm-up left no trace)

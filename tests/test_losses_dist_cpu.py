@@ -82,7 +82,7 @@ def test_two_rank_gloo_gradient_allreduce(tmp_path):
     assert hp.rel_err(got['gmu'], mu.grad) <= 1e-10
 
 
-def _ddp_worker(rank, world, port, out):
+def _ddp_worker(rank, world, port, out, defer=False):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     from monoforce_amd import dist as mfd
     mfd.init(backend='gloo')
@@ -92,6 +92,7 @@ def _ddp_worker(rank, world, port, out):
     params = list(net.parameters()) + [unused]
     gb = mfd.GradBuckets(params, bucket_mb=0.0001)          # ~100 bytes per bucket: several buckets, launched during backward
     assert len(gb.buckets) >= 3
+    gb.defer = defer                                       # True: the hooks only count; pack() packs, exchange() runs the collectives
     opt = torch.optim.SGD(params, lr=0.1)
     g = torch.Generator().manual_seed(7)
     X, Y = torch.randn(12, 8, generator=g), torch.randn(12, 1, generator=g)
@@ -99,6 +100,10 @@ def _ddp_worker(rank, world, port, out):
     for _ in range(3):
         gb.zero()
         ((net(X[lo:hi]) - Y[lo:hi]) ** 2).mean().backward()
+        if defer:                                          # the order of a step replayed as two hipGraphs around its exchange
+            assert all(b['work'] is None and not b['launched'] for b in gb.buckets)
+            gb.pack()
+            gb.exchange()
         gb.finish()
         opt.step()
     if rank == 0:
@@ -106,12 +111,16 @@ def _ddp_worker(rank, world, port, out):
     torch.distributed.destroy_process_group()
 
 
-def test_two_rank_gloo_bucketed_overlapped_gradient_exchange(tmp_path):
-    """GradBuckets (gradients as views of flat buckets, all-reduce launched from autograd hooks, averaged) == single-process
-    training on the whole batch."""
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize('defer', [False, True])
+def test_two_rank_gloo_bucketed_overlapped_gradient_exchange(tmp_path, defer):
+    """GradBuckets (gradients as views of flat buckets, all-reduce launched from autograd hooks -- or, deferred, after the
+    backward: the graph-replayed step's order --, averaged) == single-process training on the whole batch."""
     out = str(tmp_path / 'ddp.npz')
-    port = 31000 + os.getpid() % 2000
-    mp.spawn(_ddp_worker, args=(2, port, out), nprocs=2, join=True)
+    port = 31000 + os.getpid() % 2000 + (2000 if defer else 0)
+    mp.spawn(_ddp_worker, args=(2, port, out, defer), nprocs=2, join=True)
     got = np.load(out)
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(), torch.nn.Linear(16, 1))
