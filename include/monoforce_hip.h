@@ -213,6 +213,11 @@ int mf_rollout_loss_fusable(const MfRolloutDesc* desc);
  * body (forward +5 %, backward -17 % at 1024 rollouts x 4 points), and bodies of 5..512 points up to two waves per SIMD
  * (16 bytes per rollout-step; backward 2.05 -> 1.04 ms at 64 rollouts x 223 points, 1.38 -> 0.97 ms at 1024 x 32). */
 long long mf_rollout_record_bytes(const MfRolloutDesc* desc);
+/* The same for the _f64 entry points: non-zero only for the float64 VALIDATION build of the component-parallel kernels
+ * (points_per_lane = MF_LANES_COMPONENT: the float32 kernels' source instantiated on double, 32-byte quads), which exists so that the
+ * code the BASELINE configurations run can be held to the float64 oracle (dphysics.py:172-272, 467-528 under float64) over the full
+ * horizon, where float32 trajectories are chaotic. */
+long long mf_rollout_record_bytes_f64(const MfRolloutDesc* desc);
 
 /* Point slots per Fs/Ff row the kernels chosen for (B, N, points_per_lane) need (>= N; -1 on a bad descriptor). */
 int mf_rollout_force_stride(const MfRolloutDesc* desc);

@@ -180,7 +180,7 @@ struct GroupSum {
   }
 };
 
-// Workgroup sum of up to nine float32 values per step for ONE rollout spread over NW = G / 64 waves (the multi-wave rollout kernels).
+// Workgroup sum of up to nine values (float32; float64 in the validation build) per step for ONE rollout spread over NW = G / 64 waves (the multi-wave rollout kernels).
 // GroupSum's plain form -- every value summed over the wave's 64 lanes (6 DPP steps each), one LDS word per wave, NW partials added
 // by every lane -- costs ~13 instructions per value.  Here the first EIGHT values are reduced TRANSPOSED within each 16-lane row:
 // every DPP step (row mirror, half-row mirror, quad reverse) exchanges HALF of the values a lane still holds with a partner that
@@ -188,49 +188,49 @@ struct GroupSum {
 // value (l >> 1) & 7.  Row totals go to LDS ([value][wave x 4 rows]); after ONE barrier lanes 0..8 add the 4 NW partials of
 // "their" value in a fixed order (deterministic) and the totals come back through scalar registers (v_readlane).  A ninth value
 // takes the plain row sum.  Two LDS slots alternate (a wave runs at most one barrier ahead of the slowest).
-template <int NW>
+template <int NW, typename S = float>
 struct TransposedExchange {
   static constexpr int RS = 4 * NW;               // row totals per value
-  static constexpr int kWords = 2 * 9 * RS;       // floats of (16-byte aligned) shared memory
-  float* lds = nullptr;
+  static constexpr int kWords = 2 * 9 * RS;       // scalars of shared memory, aligned to four of them (16 bytes; float64: 32)
+  S* lds = nullptr;
   unsigned par = 0;
-  __device__ __forceinline__ void post(const float (&v)[8], float v9) {
+  __device__ __forceinline__ void post(const S (&v)[8], S v9) {
     const int l = threadIdx.x & 63;
     const bool b3 = (l & 8) != 0, b2 = (l & 4) != 0, b1 = (l & 2) != 0;
-    float t[4], u[2];
+    S t[4], u[2];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {      // row mirror (i <-> 15 - i): the lanes of the upper half-row keep values 4..7
-      const float keep = b3 ? v[k + 4] : v[k], send = b3 ? v[k] : v[k + 4];
+      const S keep = b3 ? v[k + 4] : v[k], send = b3 ? v[k] : v[k + 4];
       t[k] = keep + dpp_mov<0x140>(send);
     }
 #pragma unroll
     for (int k = 0; k < 2; ++k) {      // half-row mirror (i <-> 7 - i)
-      const float keep = b2 ? t[k + 2] : t[k], send = b2 ? t[k] : t[k + 2];
+      const S keep = b2 ? t[k + 2] : t[k], send = b2 ? t[k] : t[k + 2];
       u[k] = keep + dpp_mov<0x141>(send);
     }
-    float xv;
+    S xv;
     {                                  // quad reverse (i <-> 3 - i)
-      const float keep = b1 ? u[1] : u[0], send = b1 ? u[0] : u[1];
+      const S keep = b1 ? u[1] : u[0], send = b1 ? u[0] : u[1];
       xv = keep + dpp_mov<0x1B>(send);
     }
     xv += dpp_mov<0xB1>(xv);           // the neighbour holds the same value's other half
-    float yv = v9;                     // the ninth value: plain row sum
+    S yv = v9;                     // the ninth value: plain row sum
     yv += dpp_mov<0xB1>(yv); yv += dpp_mov<0x4E>(yv); yv += dpp_mov<0x141>(yv); yv += dpp_mov<0x140>(yv);
     const int vi = (b3 ? 4 : 0) + (b2 ? 2 : 0) + (b1 ? 1 : 0);
-    float* slot = lds + par * (9 * RS);
+    S* slot = lds + par * (9 * RS);
     const int col = (int)(threadIdx.x >> 6) * 4 + (l >> 4);
     slot[vi * RS + col] = xv;          // (the two lanes of a pair write the same total to the same word)
     slot[8 * RS + col] = yv;
   }
   template <int K>
-  __device__ __forceinline__ void wait(float (&v)[K]) {      // totals of values 0 .. K - 1, workgroup-uniform
+  __device__ __forceinline__ void wait(S (&v)[K]) {      // totals of values 0 .. K - 1, workgroup-uniform
     static_assert(K <= 9, "nine values at most");
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    const float* slot = lds + par * (9 * RS);
+    typedef S f4v __attribute__((ext_vector_type(4)));
+    const S* slot = lds + par * (9 * RS);
     __syncthreads();
     const int rk = min((int)(threadIdx.x & 63), 8);
     const f4v* pr = reinterpret_cast<const f4v*>(slot + rk * RS);
-    float tot = 0.0f;
+    S tot = (S)0;
 #pragma unroll
     for (int wv = 0; wv < NW; ++wv) { const f4v q = pr[wv]; tot += ((q.x + q.y) + (q.z + q.w)); }
     par ^= 1u;
@@ -242,6 +242,8 @@ struct TransposedExchange {
 // ---------------------------------------------------------------------------------------------------------
 // scalar helpers, overloaded on the arithmetic type
 // ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float mf_fma(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ double mf_fma(double a, double b, double c) { return fma(a, b, c); }
 __device__ __forceinline__ float mf_sqrt(float v) { return sqrtf(v); }
 __device__ __forceinline__ double mf_sqrt(double v) { return sqrt(v); }
 __device__ __forceinline__ float mf_exp(float v) { return expf(v); }

@@ -51,7 +51,7 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
   a.Xraw = (const S*)p->Xraw; a.Xds = (const S*)p->Xds; a.Rs = (const S*)p->Rs; a.Om = (const S*)p->Omegas;
   if (p->loss) {      // the forward's fused physics loss: dL/dXs is formed inside the kernel from Xs, the ground truth and gloss
     const MfRolloutLoss* L = p->loss;
-    MF_REQUIRE(sizeof(S) == 4 && cp_loss_fusable(d) && p->rec && !p->joint_angles, MF_ERR_UNSUPPORTED,
+    MF_REQUIRE((sizeof(S) == 4 || d->points_per_lane == MF_LANES_COMPONENT) && cp_loss_fusable(d) && p->rec && !p->joint_angles, MF_ERR_UNSUPPORTED,
                "rollout_bwd: this launch cannot carry the fused physics loss (mf_rollout_loss_fusable; the forward's record is required)");
     MF_REQUIRE(!p->gXs && !p->gXds && !p->gRs && !p->gOmegas && !p->gFs && !p->gFf, MF_ERR_INVALID,
                "rollout_bwd: with a fused loss the six upstream gradients must be NULL");
@@ -86,23 +86,28 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
     if (sizeof(S) == 4) return launch_rollout_bwd_joints_f32(*reinterpret_cast<const RolloutBwdArgs<float>*>(&a), mj, d->integrator, block, st);
     return launch_rollout_bwd_joints_f64(*reinterpret_cast<const RolloutBwdArgs<double>*>(&a), mj, d->integrator, block, st);
   }
-  const bool cp = sizeof(S) == 4 && use_component_parallel_bwd(d, p);
+  // float32: the dispatcher's choice for few rollouts of a small body; float64: the VALIDATION build of the same kernels, on explicit
+  // request only (points_per_lane = MF_LANES_COMPONENT; rollout_bwd_cp_f64.hip)
+  const bool cp = (sizeof(S) == 4 || d->points_per_lane == MF_LANES_COMPONENT) && use_component_parallel_bwd(d, p, (int)sizeof(S));
   MF_REQUIRE(p->gcontrols || cp, MF_ERR_INVALID, "rollout_bwd: gcontrols may be NULL only where the component-parallel kernels run "
              "(float32 MF_MATH_FAST, rigid body of N <= 4 points, either integrator, B <= 8192: mf_rollout_bwd_wants_gcontrols() == 0)");
   if (cp) {   // few rollouts of a small body: a rollout over 16 lanes
-    if (p->rec && cp_record_bytes(d) > 0) {      // the forward kept its per-step record: read it instead of recomputing
+    if (p->rec && cp_record_bytes(d, (int)sizeof(S)) > 0) {      // the forward kept its per-step record: read it instead of recomputing
       MF_REQUIRE(((uintptr_t)p->rec & 15) == 0, MF_ERR_INVALID, "rollout_bwd: rec must be 16-byte aligned");
       a.rec = (const S*)p->rec;
     }
-    return launch_rollout_bwd_cp_f32(*reinterpret_cast<const RolloutBwdArgs<float>*>(&a), d->integrator,
-                                     (p->gXs || p->loss) && !p->gXds && !p->gRs && !p->gOmegas && !p->gFs && !p->gFf, st);
+    const bool xs_only = (p->gXs || p->loss) && !p->gXds && !p->gRs && !p->gOmegas && !p->gFs && !p->gFf;
+    if constexpr (sizeof(S) == 4) return launch_rollout_bwd_cp_f32(a, d->integrator, xs_only, st);
+    else return launch_rollout_bwd_cp_f64(a, d->integrator, xs_only, st);
   }
   const LaneMap m = choose_lane_map(d->B, d->N, d->points_per_lane == MF_LANES_COMPONENT ? 0 : d->points_per_lane);
-  if (sizeof(S) == 4 && use_multiwave_bwd(d, p)) {   // one rollout over several waves, from the forward's 16-byte record
-    MF_REQUIRE(((uintptr_t)p->rec & 15) == 0, MF_ERR_INVALID, "rollout_bwd: rec must be 16-byte aligned");
+  // one rollout over several waves, from the forward's 16-byte record (float64: the validation build, on explicit request)
+  if ((sizeof(S) == 4 || d->points_per_lane == MF_LANES_COMPONENT) && use_multiwave_bwd(d, p)) {
+    MF_REQUIRE(((uintptr_t)p->rec & (4 * sizeof(S) - 1)) == 0, MF_ERR_INVALID, "rollout_bwd: rec must be aligned to its quads");
     a.rec = (const S*)p->rec;
-    return launch_rollout_bwd_mw_f32(*reinterpret_cast<const RolloutBwdArgs<float>*>(&a), m.G, d->integrator,
-                                     !p->gXds && !p->gRs && !p->gOmegas && !p->gFs && !p->gFf, st);
+    const bool xs_only = !p->gXds && !p->gRs && !p->gOmegas && !p->gFs && !p->gFf;
+    if constexpr (sizeof(S) == 4) return launch_rollout_bwd_mw_f32(a, m.G, d->integrator, xs_only, st);
+    else return launch_rollout_bwd_mw_f64(a, m.G, d->integrator, xs_only, st);
   }
   if (sizeof(S) == 4 && d->math_mode == MF_MATH_FAST) {
     // accumulator carry-over between adjacent cells (rollout_bwd_kernel.h): ~55 more instructions per step, half the atomics --

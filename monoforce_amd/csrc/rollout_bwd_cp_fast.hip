@@ -14,17 +14,17 @@ static long long cp_bwd_max_waves() {
   return v;
 }
 
-static bool cp_bwd_covers(const MfRolloutDesc* d, bool joints) {
+static bool cp_bwd_covers(const MfRolloutDesc* d, bool joints, int scalar_bytes = 4) {
   if (d->math_mode != MF_MATH_FAST || d->N > 4 || joints) return false;
   if (d->points_per_lane != 0 && d->points_per_lane != MF_LANES_COMPONENT) return false;
   const long long waves = ((long long)d->B + 3) / 4;
   if (d->points_per_lane == 0 && waves > cp_bwd_max_waves()) return false;
   // 32-bit byte offsets into the saved rows and the upstream gradients
   const long long row = (long long)d->N * 3 > 9 ? (long long)d->N * 3 : 9;
-  if ((long long)d->T * d->B * row * 4 >= (1ll << 32)) return false;
+  if ((long long)d->T * d->B * row * scalar_bytes >= (1ll << 32)) return false;
   return true;
 }
-bool use_component_parallel_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p) { return cp_bwd_covers(d, p->joint_angles != nullptr); }
+bool use_component_parallel_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, int scalar_bytes) { return cp_bwd_covers(d, p->joint_angles != nullptr, scalar_bytes); }
 
 // The compact per-step record (rollout_fwd_cp_kernel.h REC, layout in rollout_cp_common.h): kept where BOTH directions run
 // component-parallel and the launch has at most one wave per SIMD -- 256 B per rollout and step (131 MB at B = 1024, T = 500; round
@@ -35,18 +35,18 @@ bool use_component_parallel_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* 
 // computing wave itself up to 1024 waves.  dynamics() read by the one wave LOSES against recomputing (B = 1024: 0.499 vs 0.436 ms
 // backward), so beyond its streaming range it keeps no record (MF_CP_RECORD_DYNAMICS=1 forces one: A/B runs, parity tests of that
 // kernel).  MF_CP_RECORD_MAX_WAVES overrides the size limit (0 disables).
-long long cp_record_bytes(const MfRolloutDesc* d) {
+long long cp_record_bytes(const MfRolloutDesc* d, int scalar_bytes) {
   static const long long max_waves = getenv("MF_CP_RECORD_MAX_WAVES") ? atoll(getenv("MF_CP_RECORD_MAX_WAVES")) : 1024;
   if (!d || d->B <= 0 || d->T <= 0) return 0;
   MfRolloutFwdBufs f{};
   static const bool dyn = getenv("MF_CP_RECORD_DYNAMICS") && atoi(getenv("MF_CP_RECORD_DYNAMICS")) != 0;
   static const bool one_wave = getenv("MF_CP_BWD_MODE") && atoi(getenv("MF_CP_BWD_MODE")) == kCpSaved;
   if (d->has_joints) return 0;
-  if (!use_component_parallel(d, &f) || !cp_bwd_covers(d, false)) return 0;
+  if (!use_component_parallel(d, &f, scalar_bytes) || !cp_bwd_covers(d, false, scalar_bytes)) return 0;
   const long long waves = ((long long)d->B + 3) / 4;
   if (waves > max_waves) return 0;
   if (d->integrator != MF_INTEG_ODEINT_EULER && !dyn && (one_wave || waves > (long long)cp_stream_max_grid(d->integrator))) return 0;
-  const long long bytes = (long long)d->T * d->B * 16 * cp::kRecBytesPerLane;
+  const long long bytes = (long long)d->T * d->B * 16 * 4 * scalar_bytes;      // cp::kRecBytesPerLane<S> per lane and step
   if (bytes >= (1ll << 32)) return 0;
   return bytes;
 }
@@ -56,7 +56,7 @@ long long cp_record_bytes(const MfRolloutDesc* d) {
 bool cp_loss_fusable(const MfRolloutDesc* d) {
   static const bool one_wave = getenv("MF_CP_BWD_MODE") && atoi(getenv("MF_CP_BWD_MODE")) == kCpSaved;
   if (!d || d->integrator != MF_INTEG_ODEINT_EULER || d->layout != MF_LAYOUT_TIME_MAJOR || one_wave) return false;
-  if (cp_record_bytes(d) <= 0) return false;
+  if (cp_record_bytes(d, 4) <= 0) return false;
   const long long grid = ((long long)d->B * 16 + 63) / 64;
   return grid <= (long long)cp_stream_max_grid();
 }
@@ -64,16 +64,22 @@ bool cp_loss_fusable(const MfRolloutDesc* d) {
 }  // namespace mf
 extern "C" int mf_rollout_loss_fusable(const MfRolloutDesc* d) { return mf::cp_loss_fusable(d) ? 1 : 0; }
 extern "C" int mf_rollout_bwd_wants_gcontrols(const MfRolloutDesc* d) { return (d && mf::cp_bwd_covers(d, d->has_joints != 0)) ? 0 : 1; }
-namespace mf { long long mw_record_bytes(const MfRolloutDesc* d); }   // rollout_bwd_mw_fast.hip
+namespace mf { long long mw_record_bytes(const MfRolloutDesc* d, int scalar_bytes); }   // rollout_bwd_mw_fast.hip
 extern "C" long long mf_rollout_record_bytes(const MfRolloutDesc* d) {
-  const long long cp = mf::cp_record_bytes(d);
-  return cp > 0 ? cp : mf::mw_record_bytes(d);
+  const long long cp = mf::cp_record_bytes(d, 4);
+  return cp > 0 ? cp : mf::mw_record_bytes(d, 4);
+}
+// the float64 validation build of the component-parallel kernels (points_per_lane = MF_LANES_COMPONENT): 32-byte quads
+extern "C" long long mf_rollout_record_bytes_f64(const MfRolloutDesc* d) {
+  if (!d || d->points_per_lane != MF_LANES_COMPONENT) return 0;
+  const long long cp = mf::cp_record_bytes(d, 8);
+  return cp > 0 ? cp : mf::mw_record_bytes(d, 8);      // (bodies of 5..512 points: rollout_bwd_mw_kernel.h's record, 32 bytes per rollout-step)
 }
 namespace mf {
 
 int launch_rollout_bwd_cp_f32(const RolloutBwdArgs<float>& a, int integ, bool xs_only, hipStream_t st) {
   if (integ == MF_INTEG_DYNAMICS) return launch_rollout_bwd_cp_dynamics_f32(a, xs_only, st);
-  return launch_rollout_bwd_cp_variant<MF_INTEG_ODEINT_EULER>(a, xs_only, st);
+  return launch_rollout_bwd_cp_variant<float, MF_INTEG_ODEINT_EULER>(a, xs_only, st);
 }
 
 }  // namespace mf

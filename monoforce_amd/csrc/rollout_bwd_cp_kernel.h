@@ -17,14 +17,6 @@
 
 namespace mf {
 
-struct __attribute__((aligned(4))) CpF3 { float a, b, c; };
-__device__ __forceinline__ CpF3 ld3(const float* base, unsigned off) {
-  return *reinterpret_cast<const CpF3*>(reinterpret_cast<const char*>(base) + (size_t)off);
-}
-__device__ __forceinline__ float ld1(const float* base, unsigned off) {
-  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + (size_t)off);
-}
-
 // XS_ONLY: the loss reads the positions only (physics_loss, losses.py:102-127 -- every training caller): the other five upstream
 // gradients are absent, so their loads, their additions and the adjoint of the impulse accumulators are compiled out
 // (~19 of ~410 instructions per step).
@@ -61,83 +53,85 @@ extern __device__ unsigned long long mf_stream_prof[16];
 #ifdef MF_NO_WPE      // A/B build: no register limit on the streaming kernels
 #define MF_STREAM_WPE
 #else
-#define MF_STREAM_WPE __attribute__((amdgpu_waves_per_eu((MODE == kCpStream && XS_ONLY) ? 2 : 1)))
+#define MF_STREAM_WPE __attribute__((amdgpu_waves_per_eu((MODE == kCpStream && XS_ONLY && sizeof(S) == 4) ? 2 : 1)))
 #endif
-template <int INTEG, bool XS_ONLY, bool GCTRL, int MODE, int SLOTS = 6>
+template <typename S, int INTEG, bool XS_ONLY, bool GCTRL, int MODE, int SLOTS = 6>
 // (streaming, positions-only loss: at most 256 registers, so that two workgroups -- six waves -- share a CU's four SIMDs)
 __global__ void __launch_bounds__(MODE == kCpStream ? 192 : 64) MF_STREAM_WPE
-rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
+rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
   constexpr bool ODE = INTEG == MF_INTEG_ODEINT_EULER;
   constexpr bool LATE = MODE == kCpLate, STREAM = MODE == kCpStream, SAVED = MODE == kCpSaved || STREAM;
   using namespace cp;
-  using M = Mth<float, true>;
+  using M = Mth<S, std::is_same<S, float>::value>;      // float: fast math; double (the validation build): exact
+  using Msk = typename MaskOf<S>::type;
+  constexpr unsigned kS = (unsigned)sizeof(S), kC = 2u * kS;      // bytes of a scalar / of a control row (v, w)
   const int lane = threadIdx.x & 63;
   const int tid = STREAM ? blockIdx.x * 64 + lane : blockIdx.x * blockDim.x + threadIdx.x;
   const int b = tid >> 4;
   if (b >= a.B) return;
   const int p = (tid >> 2) & 3, q = tid & 3, cc = q < 3 ? q : 2;
-  const float one = 1.0f, zero = 0.0f;
+  const S one = S(1.0), zero = S(0.0);
   const int HW = a.H * a.W, last = HW - 1;
   const unsigned moff = a.map_shared ? 0u : (unsigned)b * (unsigned)HW;
-  const float* zmap = a.z;
+  const S* zmap = a.z;
   const bool has_mu = a.mu != nullptr;
-  const float* mumap = has_mu ? a.mu : a.z;
+  const S* mumap = has_mu ? a.mu : a.z;
   const unsigned goff = a.map_shared ? (unsigned)(b % a.grad_copies) * (unsigned)HW : (unsigned)b * (unsigned)HW;
-  float* gzmap = a.gz;
+  S* gzmap = a.gz;
   const bool want_gmu = a.gmu != nullptr && has_mu;
-  float* gmumap = want_gmu ? a.gmu : a.gz;
+  S* gmumap = want_gmu ? a.gmu : a.gz;
 
   // ---- per-lane constants (as the forward, rollout_fwd_cp_kernel.h) ----
   const bool act = p < a.N;
   const int pi = act ? p : 0;
-  const float P0 = a.points[pi * 3 + 0], P1 = a.points[pi * 3 + 1], P2 = a.points[pi * 3 + 2];
+  const S P0 = a.points[pi * 3 + 0], P1 = a.points[pi * 3 + 1], P2 = a.points[pi * 3 + 2];
   const int part = act ? a.part[pi] : -1;
-  const float tv_v = part < 0 ? zero : one;
-  const float tv_w = part < 0 ? zero : ((part & 1) ? a.half_ly : -a.half_ly);
-  const float I0 = a.Iinv[cc * 3 + 0], I1 = a.Iinv[cc * 3 + 1], I2 = a.Iinv[cc * 3 + 2];     // row cc of I^-1
-  const float J0 = a.Iinv[0 * 3 + cc], J1 = a.Iinv[1 * 3 + cc], J2 = a.Iinv[2 * 3 + cc];     // column cc (I^-T)
+  const S tv_v = part < 0 ? zero : one;
+  const S tv_w = part < 0 ? zero : ((part & 1) ? a.half_ly : -a.half_ly);
+  const S I0 = a.Iinv[cc * 3 + 0], I1 = a.Iinv[cc * 3 + 1], I2 = a.Iinv[cc * 3 + 2];     // row cc of I^-1
+  const S J0 = a.Iinv[0 * 3 + cc], J1 = a.Iinv[1 * 3 + cc], J2 = a.Iinv[2 * 3 + cc];     // column cc (I^-T)
   const int cell_off = ((q & 1) ? a.H : 0) + ((q & 2) ? 1 : 0);
-  const float wa_s = (q & 2) ? one : -one, wa_o = (q & 2) ? zero : one;
-  const float wb_s = (q & 1) ? one : -one, wb_o = (q & 1) ? zero : one;
-  const float n_mul = q < 2 ? -a.inv_res : zero, n_add = q < 2 ? zero : one;
+  const S wa_s = (q & 2) ? one : -one, wa_o = (q & 2) ? zero : one;
+  const S wb_s = (q & 1) ? one : -one, wb_o = (q & 1) ? zero : one;
+  const S n_mul = q < 2 ? -a.inv_res : zero, n_add = q < 2 ? zero : one;
   // cell gradient of the normal's finite differences: cells (c, f, l, fl) get (-ggx - ggy, +ggx, +ggy, 0); ggx sits in lane 0,
   // ggy in lane 1, t = quad_perm[1,0,1,1](gg) brings the partner over: nz += cgA * gg + cgB * t
-  const float cgA = q == 0 ? -one : zero, cgB = q == 0 ? -one : (q == 3 ? zero : one);
-  const float sel_xy = q < 2 ? one : zero;       // components that receive d(sample)/d(position) through the fractions
-  const float mg = a.mg;
+  const S cgA = q == 0 ? -one : zero, cgB = q == 0 ? -one : (q == 3 ? zero : one);
+  const S sel_xy = q < 2 ? one : zero;       // components that receive d(sample)/d(position) through the fractions
+  const S mg = a.mg;
   // bit masks of the lane role for mask_or: a ternary on the role around lane sums becomes an exec-masked branch, and a
   // branch splits the basic block the two instruction streams of the loop are interleaved in
-  const unsigned lane0 = q == 0 ? ~0u : 0u, lane1 = q == 1 ? ~0u : 0u, lane2 = q >= 2 ? ~0u : 0u;
+  const Msk lane0 = q == 0 ? ~(Msk)0 : (Msk)0, lane1 = q == 1 ? ~(Msk)0 : (Msk)0, lane2 = q >= 2 ? ~(Msk)0 : (Msk)0;
 
   // ---- adjoint of the state: component cc / row cc ----
-  float lx = zero, lxd = zero, lw = zero, lR0 = zero, lR1 = zero, lR2 = zero;
-  float laFs = zero, laFf = zero;     // adjoint of this point's impulse accumulators (extended ODE state)
+  S lx = zero, lxd = zero, lw = zero, lR0 = zero, lR1 = zero, lR2 = zero;
+  S laFs = zero, laFf = zero;     // adjoint of this point's impulse accumulators (extended ODE state)
 
   // rows: per-lane byte offsets (loop-invariant) + wave-uniform row offsets stepped by scalar arithmetic
   const unsigned row_stride = (a.layout == MF_LAYOUT_TIME_MAJOR) ? (unsigned)a.B : 1u;
   const unsigned row0 = (a.layout == MF_LAYOUT_TIME_MAJOR) ? (unsigned)b : (unsigned)b * (unsigned)a.T;
-  const unsigned v3 = (row0 * 3u + (unsigned)cc) * 4u, v9 = (row0 * 9u + (unsigned)cc * 3u) * 4u;
+  const unsigned v3 = (row0 * 3u + (unsigned)cc) * kS, v9 = (row0 * 9u + (unsigned)cc * 3u) * kS;
   const unsigned pcl = (unsigned)min(p, a.N - 1);      // inactive quads read a valid force row, masked at use
   // upstream rows: element strides 3 / 9 when present, 0 when the host substituted the zero row
-  const unsigned u_xs = (row0 * (unsigned)a.sXs + (unsigned)cc) * 4u, u_xds = (row0 * (unsigned)a.sXds + (unsigned)cc) * 4u;
-  const unsigned u_om = (row0 * (unsigned)a.sOm + (unsigned)cc) * 4u, u_r = (row0 * (unsigned)a.sRs + (unsigned)cc * 3u) * 4u;
-  const unsigned u_fs = ((row0 * (unsigned)a.N + pcl) * (unsigned)a.sFs + (unsigned)cc) * 4u;
-  const unsigned u_ff = ((row0 * (unsigned)a.N + pcl) * (unsigned)a.sFf + (unsigned)cc) * 4u;
+  const unsigned u_xs = (row0 * (unsigned)a.sXs + (unsigned)cc) * kS, u_xds = (row0 * (unsigned)a.sXds + (unsigned)cc) * kS;
+  const unsigned u_om = (row0 * (unsigned)a.sOm + (unsigned)cc) * kS, u_r = (row0 * (unsigned)a.sRs + (unsigned)cc * 3u) * kS;
+  const unsigned u_fs = ((row0 * (unsigned)a.N + pcl) * (unsigned)a.sFs + (unsigned)cc) * kS;
+  const unsigned u_ff = ((row0 * (unsigned)a.N + pcl) * (unsigned)a.sFf + (unsigned)cc) * kS;
 
-  struct StateIn { float x, xd, w, R0, R1, R2, cv, cw, t0, t1; };
-  struct UpIn { float gXs, gXds, gOm, gR0, gR1, gR2, gFs, gFf; };
+  struct StateIn { S x, xd, w, R0, R1, R2, cv, cw, t0, t1; };
+  struct UpIn { S gXs, gXds, gOm, gR0, gR1, gR2, gFs, gFf; };
   // ODEINT: output row 0 is the initial state and step m maps row m -> row m + 1 (the last control is unused); DYNAMICS: step m
   // maps row m - 1 (the initial state for m = 0) -> row m
   const int n_steps = ODE ? a.T - 1 : a.T;
   const Rsrc rXraw = make_rsrc(a.Xraw), rXds = make_rsrc(a.Xds), rOm = make_rsrc(a.Om), rRs = make_rsrc(a.Rs);
   const Rsrc rgXs = make_rsrc(a.gXs), rgXds = make_rsrc(a.gXds), rgOm = make_rsrc(a.gOm), rgRs = make_rsrc(a.gRs);
   const Rsrc rgFs = make_rsrc(a.gFs), rgFf = make_rsrc(a.gFf), rCtrl = make_rsrc(a.controls), rGctrl = make_rsrc(a.gcontrols);
-  const unsigned v_ctrl = (unsigned)b * (unsigned)a.T * 8u;      // this rollout's control rows (bytes)
-  const unsigned s3 = row_stride * 12u, s9 = row_stride * 36u;   // bytes between consecutive time steps
-  const unsigned sg_xs = row_stride * (unsigned)a.sXs * 4u, sg_xds = row_stride * (unsigned)a.sXds * 4u, sg_om = row_stride * (unsigned)a.sOm * 4u;
-  const unsigned sg_r = row_stride * (unsigned)a.sRs * 4u;
-  const unsigned sg_fs = row_stride * (unsigned)a.N * (unsigned)a.sFs * 4u, sg_ff = row_stride * (unsigned)a.N * (unsigned)a.sFf * 4u;
-  struct { float x, xd, w, R0, R1, R2; } ini = {zero, zero, zero, zero, zero, zero};
+  const unsigned v_ctrl = (unsigned)b * (unsigned)a.T * kC;      // this rollout's control rows (bytes)
+  const unsigned s3 = row_stride * 3u * kS, s9 = row_stride * 9u * kS;   // bytes between consecutive time steps
+  const unsigned sg_xs = row_stride * (unsigned)a.sXs * kS, sg_xds = row_stride * (unsigned)a.sXds * kS, sg_om = row_stride * (unsigned)a.sOm * kS;
+  const unsigned sg_r = row_stride * (unsigned)a.sRs * kS;
+  const unsigned sg_fs = row_stride * (unsigned)a.N * (unsigned)a.sFs * kS, sg_ff = row_stride * (unsigned)a.N * (unsigned)a.sFf * kS;
+  struct { S x, xd, w, R0, R1, R2; } ini = {zero, zero, zero, zero, zero, zero};
   if constexpr (!ODE) {
     ini.x = a.x_init[b * 3 + cc]; ini.xd = a.xd0[b * 3 + cc]; ini.w = a.w0[b * 3 + cc];
     ini.R0 = a.R0[b * 9 + cc * 3 + 0]; ini.R1 = a.R0[b * 9 + cc * 3 + 1]; ini.R2 = a.R0[b * 9 + cc * 3 + 2];
@@ -145,27 +139,27 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
   auto load_state = [&](int m, StateIn& s) {            // the state step m started from
     const unsigned um = __builtin_amdgcn_readfirstlane((unsigned)m);    // wave-uniform, and provably so (scalar offsets)
     if constexpr (ODE) {                                // = saved output row m
-      s.x = bload1(rXraw, v3, um * s3); s.xd = bload1(rXds, v3, um * s3); s.w = bload1(rOm, v3, um * s3);
+      s.x = bload1<S>(rXraw, v3, um * s3); s.xd = bload1<S>(rXds, v3, um * s3); s.w = bload1<S>(rOm, v3, um * s3);
       bload3(rRs, v9, um * s9, &s.R0, &s.R1, &s.R2);
       s.t0 = a.ts[m]; s.t1 = a.ts[m + 1 < a.T ? m + 1 : m];
     } else {                                            // = saved output row m - 1; step 0: the initial state, held in registers
       const bool init = um == 0u;                       // (a select between two base pointers becomes a branch around scalar loads)
       const unsigned ur = init ? 0u : um - 1u;
-      float R0, R1, R2;
-      const float x = bload1(rXraw, v3, ur * s3), xd = bload1(rXds, v3, ur * s3), w = bload1(rOm, v3, ur * s3);
+      S R0, R1, R2;
+      const S x = bload1<S>(rXraw, v3, ur * s3), xd = bload1<S>(rXds, v3, ur * s3), w = bload1<S>(rOm, v3, ur * s3);
       bload3(rRs, v9, ur * s9, &R0, &R1, &R2);
       s.x = init ? ini.x : x; s.xd = init ? ini.xd : xd; s.w = init ? ini.w : w;
       s.R0 = init ? ini.R0 : R0; s.R1 = init ? ini.R1 : R1; s.R2 = init ? ini.R2 : R2;
     }
-    bload2(rCtrl, v_ctrl, um * 8u, &s.cv, &s.cw);
+    bload2(rCtrl, v_ctrl, um * kC, &s.cv, &s.cw);
   };
   auto load_upstream = [&](int orow, UpIn& u) {         // upstream gradients of output row `orow`
     const unsigned uo = __builtin_amdgcn_readfirstlane((unsigned)orow);
-    u.gXs = bload1(rgXs, u_xs, uo * sg_xs);
+    u.gXs = bload1<S>(rgXs, u_xs, uo * sg_xs);
     if constexpr (!XS_ONLY) {
-      u.gXds = bload1(rgXds, u_xds, uo * sg_xds); u.gOm = bload1(rgOm, u_om, uo * sg_om);
+      u.gXds = bload1<S>(rgXds, u_xds, uo * sg_xds); u.gOm = bload1<S>(rgOm, u_om, uo * sg_om);
       bload3(rgRs, u_r, uo * sg_r, &u.gR0, &u.gR1, &u.gR2);
-      u.gFs = bload1(rgFs, u_fs, uo * sg_fs); u.gFf = bload1(rgFf, u_ff, uo * sg_ff);
+      u.gFs = bload1<S>(rgFs, u_fs, uo * sg_fs); u.gFf = bload1<S>(rgFf, u_ff, uo * sg_ff);
     }
   };
   // The adjoint state (lx, lxd, lw, lR) is kept UN-SUMMED over the contact points: each quad holds its own part and the state
@@ -173,10 +167,10 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
   // linear and angular velocity -- need the sum every step: five lane sums per step (ten DPP adds, ~7 cycles each at one wave
   // per SIMD: tools/microbench/dpp_latency.hip) become six after the loop.  The upstream gradient of a state row goes to the
   // quad of point 0.
-  const float first = p == 0 ? one : zero;
+  const S first = p == 0 ? one : zero;
   auto add_upstream_masked = [&](const UpIn& u) {       // u: already zero outside point 0's quad
     lx += u.gXs;
-    lR2 = fmaf(u.gXs, a.sink, lR2);                     // Xs = x + R[:, 2] * sink
+    lR2 = mf_fma(u.gXs, a.sink, lR2);                     // Xs = x + R[:, 2] * sink
     if constexpr (!XS_ONLY) {
       lxd += u.gXds;
       lR0 += u.gR0; lR1 += u.gR1; lR2 += u.gR2;
@@ -192,13 +186,13 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
 
   // ODEINT: the last control is never used by the explicit scheme.  DYNAMICS uses all T of them: the deferred store below
   // writes these zeros to the last row first, then that step's own result over them (same lanes, program order).
-  if constexpr (GCTRL && ODE) bstore2(rGctrl, v_ctrl, (unsigned)(a.T - 1) * 8u, zero, zero);
+  if constexpr (GCTRL && ODE) bstore2(rGctrl, v_ctrl, (unsigned)(a.T - 1) * kC, zero, zero);
 
   // Cell-gradient accumulator of this lane's footprint cell: contributions of consecutive steps to the SAME cell (a robot
   // moves <= 0.2 cell per step) add up in registers; when the lane's cell changes, the old pair goes to a stash that is
   // flushed with one atomic per map in the NEXT iteration, after that step's loads (vmcnt retires in order).
   unsigned acc_idx = 0u, st_idx = 0u;
-  float acc_z = zero, acc_m = zero, st_z = zero, st_m = zero;
+  S acc_z = zero, acc_m = zero, st_z = zero, st_m = zero;
   bool st_pending = false;
   auto flush_stash = [&]() {
     if (st_pending) {
@@ -208,8 +202,8 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
     st_pending = false;
   };
 
-  unsigned gctrl_pending = (unsigned)(a.T - 1) * 8u;      // wave-uniform byte offset of the control row written next
-  float gv_pending = zero, gwc_pending = zero;
+  unsigned gctrl_pending = (unsigned)(a.T - 1) * kC;      // wave-uniform byte offset of the control row written next
+  S gv_pending = zero, gwc_pending = zero;
 
   // Everything of a step that does not depend on the adjoint: the forward recompute (the arithmetic of
   // rollout_fwd_cp_kernel.h) from the saved state the step started from.  The adjoint recurrence is the only serial part of
@@ -217,9 +211,9 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
   // recompute of step n - 1 (its gathers included) runs beside it in the same basic block -- two independent instruction
   // streams that fill each other's dependency stalls -- and the saved rows are loaded two steps ahead.
   struct Rec {
-    float x, xd, cv, cw, r, pc, fr, mc;                  // between the two halves of the recompute
-    float R0, R1, R2, w, r1, r2, w1, w2, vp, e, il, coln2, tv, h;
-    float wq, wa, wb, zc, mcv, mub, nrm, inl, cj, inv_csum, A, F0, F1, Fr, Nn, cmdv, s, sn, stv, Gf, f1, f2, wraw;
+    S x, xd, cv, cw, r, pc, fr, mc;                  // between the two halves of the recompute
+    S R0, R1, R2, w, r1, r2, w1, w2, vp, e, il, coln2, tv, h;
+    S wq, wa, wb, zc, mcv, mub, nrm, inl, cj, inv_csum, A, F0, F1, Fr, Nn, cmdv, s, sn, stv, Gf, f1, f2, wraw;
     int idx;
   };
   // first half: the footprint cell of this lane and its two gathers -- issued a whole vector-Jacobian chain (~1000 cycles)
@@ -230,18 +224,18 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
     k.h = ODE ? st.t1 - st.t0 : a.dt;
     k.r = cp_body_r(P0, P1, P2, st.R0, st.R1, st.R2);      // (the forward's own formulas, rollout_cp_common.h: same bits, same decisions)
     k.pc = k.r + st.x;
-    const float lim = 262144.0f;
-    const float uq = M::cell_coord(k.pc, a.d_max, a.res, a.inv_res);
+    const S lim = S(262144.0);
+    const S uq = M::cell_coord(k.pc, a.d_max, a.res, a.inv_res);
     const int ui = (int)M::clamp(uq, -lim, lim);
-    k.fr = uq - (float)ui;
+    k.fr = uq - (S)ui;
     const int base = dppi<kB1>(ui) + __mul24(a.H, dppi<kB0>(ui));
     k.idx = min(max(base + cell_off, 0), last);
     k.zc = ld32(zmap, moff + (unsigned)k.idx);
     k.mc = ld32(mumap, moff + (unsigned)k.idx);
   };
   auto recompute = [&](Rec& k) {
-    const float xd = k.xd, w = k.w, r = k.r, pc = k.pc, fr = k.fr;
-    k.wa = fmaf(wa_s, dpp<kB0>(fr), wa_o); k.wb = fmaf(wb_s, dpp<kB1>(fr), wb_o);
+    const S xd = k.xd, w = k.w, r = k.r, pc = k.pc, fr = k.fr;
+    k.wa = mf_fma(wa_s, dpp<kB0>(fr), wa_o); k.wb = mf_fma(wb_s, dpp<kB1>(fr), wb_o);
     k.wq = k.wa * k.wb;
     k.r1 = dpp<kRot1>(r); k.r2 = dpp<kRot2>(r);
     k.w1 = dpp<kRot1>(w); k.w2 = dpp<kRot2>(w);
@@ -250,18 +244,18 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
     k.il = M::inv_len(k.coln2);
     k.e = k.R0 * k.il;
     k.tv = cp_track(tv_v, tv_w, k.cv, k.cw);
-    const float zq = dot4(k.wq, k.zc);
+    const S zq = dot4(k.wq, k.zc);
     k.mcv = has_mu ? k.mc : one;
     k.mub = dot4(k.wq, k.mcv);
-    const float dz = k.zc - dpp<kB0>(k.zc);
-    const float u = fmaf(dpp<kN12>(dz), n_mul, n_add);
+    const S dz = k.zc - dpp<kB0>(k.zc);
+    const S u = mf_fma(dpp<kN12>(dz), n_mul, n_add);
     k.inl = M::inv_len(dot3(u, u));
     k.nrm = u * k.inl;
-    const float dh = dpp<kB2>(pc) - zq;
-    float cj = M::sigmoid_m10(dh);
+    const S dh = dpp<kB2>(pc) - zq;
+    S cj = M::sigmoid_m10(dh);
     k.cj = act ? cj : zero;
     k.inv_csum = M::div(one, sum_points(k.cj));
-    const float vn = dot3(k.vp, k.nrm);
+    const S vn = dot3(k.vp, k.nrm);
     k.A = cp_normal_force(a.k, dh, a.damp, vn);
     k.F0 = -(k.A * k.nrm);
     k.F1 = cp_spring(k.A, k.nrm, k.cj, k.inv_csum);
@@ -272,18 +266,18 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
     k.sn = dot3(k.s, k.nrm);
     k.stv = cp_tangent(k.s, k.sn, k.nrm);
     k.Gf = k.Nn * k.stv;
-    const float Ff = M::clamp(k.Gf, -mg, mg);
-    const float f = k.Fr + Ff;
+    const S Ff = M::clamp(k.Gf, -mg, mg);
+    const S f = k.Fr + Ff;
     k.f1 = dpp<kRot1>(f); k.f2 = dpp<kRot2>(f);
-    const float Tsum = sum_points(unrot(cross_pre(r, f)));
+    const S Tsum = sum_points(unrot(cross_pre(r, f)));
     k.wraw = cp_wraw(I0, I1, I2, Tsum);
   };
 
   // vector-Jacobian product of step n given its recomputed intermediates and the upstream gradient of the forces it fed
   auto vjp = [&](int n, const Rec& k, const UpIn& up) {
-    const float h = k.h, w1 = k.w1, w2 = k.w2, r1 = k.r1, r2 = k.r2, nrm = k.nrm, cj = k.cj, inv_csum = k.inv_csum;
+    const S h = k.h, w1 = k.w1, w2 = k.w2, r1 = k.r1, r2 = k.r2, nrm = k.nrm, cj = k.cj, inv_csum = k.inv_csum;
     // ---- integrator backward: adjoint of the step's outputs -> (g_xdd, g_wd, g_Fs, g_Ff) ----
-    float gFr_up = zero, gFf_up = zero, gxdd, gwd;
+    S gFr_up = zero, gFf_up = zero, gxdd, gwd;
     if constexpr (ODE) {   // torchdiffeq fixed-grid Euler
       if constexpr (!XS_ONLY) {
         laFs += act ? up.gFs : zero;
@@ -291,10 +285,10 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
         gFr_up = h * laFs; gFf_up = h * laFf;
       }
       gxdd = h * sum_points(lxd); gwd = h * sum_points(lw);
-      lxd = fmaf(h, lx, lxd);                               // x' = x + h xd
+      lxd = mf_fma(h, lx, lxd);                               // x' = x + h xd
       // R' = R + h [w]x R, column by column: d/dw of (w x R_j) . g_j = R_j x g_j ; d/dR_j = g_j x w   (g_j = h lR[:, j])
-      const float g0 = h * lR0, g1 = h * lR1, g2 = h * lR2;
-      const float g01 = dpp<kRot1>(g0), g02 = dpp<kRot2>(g0), g11 = dpp<kRot1>(g1), g12 = dpp<kRot2>(g1), g21 = dpp<kRot1>(g2), g22 = dpp<kRot2>(g2);
+      const S g0 = h * lR0, g1 = h * lR1, g2 = h * lR2;
+      const S g01 = dpp<kRot1>(g0), g02 = dpp<kRot2>(g0), g11 = dpp<kRot1>(g1), g12 = dpp<kRot2>(g1), g21 = dpp<kRot1>(g2), g22 = dpp<kRot2>(g2);
       lw += (dpp<kRot1>(k.R0) * g02 - dpp<kRot2>(k.R0) * g01) + (dpp<kRot1>(k.R1) * g12 - dpp<kRot2>(k.R1) * g11) + (dpp<kRot1>(k.R2) * g22 - dpp<kRot2>(k.R2) * g21);
       lR0 += g01 * w2 - g02 * w1;
       lR1 += g11 * w2 - g12 * w1;
@@ -307,90 +301,90 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
       // -- no 3x3 product is ever formed: a lane holds row c of R and lR, so  (G kv)_m = R[:, m] . (lR kv),
       // (G^T kv)_j = (R kv) . lR[:, j],  ax(G) = sum over the rows of (row of R) x (row of lR),  tr G = sum of their dots.
       if constexpr (!XS_ONLY) { gFr_up = act ? up.gFs : zero; gFf_up = act ? up.gFf : zero; }
-      const float wd = M::clamp(k.wraw, -a.omega_max, a.omega_max);
-      const float wn = fmaf(wd, h, k.w);
-      const float th2 = dot3(wn, wn);
-      const float idn = M::inv_len(th2);                    // 1 / max(th, 1e-6)
-      const float kv = wn * idn;
-      const float th = M::sqrt(th2);
-      float sn_, oc;
+      const S wd = M::clamp(k.wraw, -a.omega_max, a.omega_max);
+      const S wn = mf_fma(wd, h, k.w);
+      const S th2 = dot3(wn, wn);
+      const S idn = M::inv_len(th2);                    // 1 / max(th, 1e-6)
+      const S kv = wn * idn;
+      const S th = M::sqrt(th2);
+      S sn_, oc;
       M::sincos_small(th * h, &sn_, &oc);
-      const float kk = dot3(kv, kv);
-      const float kv1 = dpp<kRot1>(kv), kv2 = dpp<kRot2>(kv);
-      const float ok = oc * kv;
-      const float m0 = fmaf(ok, kv, fmaf(-oc, kk, one)), m1 = fmaf(ok, kv1, -(sn_ * kv2)), m2 = fmaf(ok, kv2, sn_ * kv1);   // M[c][c], M[c][c+1], M[c][c+2]
-      const float q0 = dpp<kB0>(kv), q1 = dpp<kB1>(kv), q2 = dpp<kB2>(kv);
-      const float Lk = lR0 * q0 + lR1 * q1 + lR2 * q2, Rk = k.R0 * q0 + k.R1 * q1 + k.R2 * q2;
-      const float Gk0 = dot3(k.R0, Lk), Gk1 = dot3(k.R1, Lk), Gk2 = dot3(k.R2, Lk);
-      const float Gt0 = dot3(Rk, lR0), Gt1 = dot3(Rk, lR1), Gt2 = dot3(Rk, lR2);
-      const float trG = sum3(k.R0 * lR0 + k.R1 * lR1 + k.R2 * lR2);
-      const float a0 = sum3(k.R1 * lR2 - k.R2 * lR1), a1 = sum3(k.R2 * lR0 - k.R0 * lR2), a2 = sum3(k.R0 * lR1 - k.R1 * lR0);
-      const float ga = -(q0 * a0 + q1 * a1 + q2 * a2);
-      const float gb = (q0 * Gk0 + q1 * Gk1 + q2 * Gk2) - kk * trG;
-      float gth = ga * h * (one - oc) + gb * h * sn_;
+      const S kk = dot3(kv, kv);
+      const S kv1 = dpp<kRot1>(kv), kv2 = dpp<kRot2>(kv);
+      const S ok = oc * kv;
+      const S m0 = mf_fma(ok, kv, mf_fma(-oc, kk, one)), m1 = mf_fma(ok, kv1, -(sn_ * kv2)), m2 = mf_fma(ok, kv2, sn_ * kv1);   // M[c][c], M[c][c+1], M[c][c+2]
+      const S q0 = dpp<kB0>(kv), q1 = dpp<kB1>(kv), q2 = dpp<kB2>(kv);
+      const S Lk = lR0 * q0 + lR1 * q1 + lR2 * q2, Rk = k.R0 * q0 + k.R1 * q1 + k.R2 * q2;
+      const S Gk0 = dot3(k.R0, Lk), Gk1 = dot3(k.R1, Lk), Gk2 = dot3(k.R2, Lk);
+      const S Gt0 = dot3(Rk, lR0), Gt1 = dot3(Rk, lR1), Gt2 = dot3(Rk, lR2);
+      const S trG = sum3(k.R0 * lR0 + k.R1 * lR1 + k.R2 * lR2);
+      const S a0 = sum3(k.R1 * lR2 - k.R2 * lR1), a1 = sum3(k.R2 * lR0 - k.R0 * lR2), a2 = sum3(k.R0 * lR1 - k.R1 * lR0);
+      const S ga = -(q0 * a0 + q1 * a1 + q2 * a2);
+      const S gb = (q0 * Gk0 + q1 * Gk1 + q2 * Gk2) - kk * trG;
+      S gth = ga * h * (one - oc) + gb * h * sn_;
       // component c of a replicated triple: bit masks on the lane role (a ternary on it turns into branches)
-      const float ac = mask_or(mask_or(mask_or(zero, a0, lane0), a1, lane1), a2, lane2);
-      const float sc = mask_or(mask_or(mask_or(zero, Gk0 + Gt0, lane0), Gk1 + Gt1, lane1), Gk2 + Gt2, lane2);
-      const float gk = -(sn_ * ac) - oc * (2.0f * trG * kv - sc);
-      const float gkw = dot3(gk, wn);
-      const float idn2 = th2 >= 1e-12f ? idn * idn : zero;      // through max(th, eps) only when th >= eps
-      gth = fmaf(-gkw, idn2, gth);
-      const float ith = th2 > zero ? M::div(one, th) : zero;    // d|w'|/dw' = w' / |w'|, 0 at 0
-      lw += fmaf(gth * ith, wn, gk * idn);
+      const S ac = mask_or(mask_or(mask_or(zero, a0, lane0), a1, lane1), a2, lane2);
+      const S sc = mask_or(mask_or(mask_or(zero, Gk0 + Gt0, lane0), Gk1 + Gt1, lane1), Gk2 + Gt2, lane2);
+      const S gk = -(sn_ * ac) - oc * (S(2.0) * trG * kv - sc);
+      const S gkw = dot3(gk, wn);
+      const S idn2 = th2 >= S(1e-12) ? idn * idn : zero;      // through max(th, eps) only when th >= eps
+      gth = mf_fma(-gkw, idn2, gth);
+      const S ith = th2 > zero ? M::div(one, th) : zero;    // d|w'|/dw' = w' / |w'|, 0 at 0
+      lw += mf_fma(gth * ith, wn, gk * idn);
       gwd = h * sum_points(lw);
-      lxd = fmaf(h, lx, lxd);
+      lxd = mf_fma(h, lx, lxd);
       gxdd = h * sum_points(lxd);
       // lR <- lR M^T: column m of the result = sum_j lR[:, j] M[m][j], M[m][j] sits in lane m as m_{(j - m) % 3}
-      const float n0 = lR0 * dpp<kB0>(m0) + lR1 * dpp<kB0>(m1) + lR2 * dpp<kB0>(m2);
-      const float n1 = lR0 * dpp<kB1>(m2) + lR1 * dpp<kB1>(m0) + lR2 * dpp<kB1>(m1);
-      const float n2 = lR0 * dpp<kB2>(m1) + lR1 * dpp<kB2>(m2) + lR2 * dpp<kB2>(m0);
+      const S n0 = lR0 * dpp<kB0>(m0) + lR1 * dpp<kB0>(m1) + lR2 * dpp<kB0>(m2);
+      const S n1 = lR0 * dpp<kB1>(m2) + lR1 * dpp<kB1>(m0) + lR2 * dpp<kB1>(m1);
+      const S n2 = lR0 * dpp<kB2>(m1) + lR1 * dpp<kB2>(m2) + lR2 * dpp<kB2>(m0);
       lR0 = n0; lR1 = n1; lR2 = n2;
     }
     // ---- RHS backward ----
-    const float mwd = inside(k.wraw, -a.omega_max, a.omega_max) ? gwd : zero;
-    const float gtau = J0 * dpp<kB0>(mwd) + J1 * dpp<kB1>(mwd) + J2 * dpp<kB2>(mwd);      // I^-T m
-    const float gsum = gxdd * a.inv_mass;
-    const float gt1 = dpp<kRot1>(gtau), gt2 = dpp<kRot2>(gtau);
-    const float gf = gt1 * r2 - gt2 * r1;                 // tau += r x f : df = gtau x r
-    float gr = k.f1 * gt2 - k.f2 * gt1;                   //                dr = f x gtau
-    float gFr = gFr_up + gsum + gf;
-    const float gFf_ = gFf_up + gsum + gf;
-    const float gG = inside(k.Gf, -mg, mg) ? gFf_ : zero;
-    const float gNn = dot3(gG, k.stv);
-    const float gst = k.Nn * gG;
-    const float gsn = -dot3(gst, nrm);
-    float gn = gsn * k.s - k.sn * gst;
-    const float gslip = gst + gsn * nrm;
-    const float gmuq = dot3(gslip, k.cmdv);
-    const float gcmd = k.mub * gslip;
-    float gvp = -gcmd;
-    const float ge_p = k.tv * gcmd;
-    float gv_p = zero, gwc_p = zero;
+    const S mwd = inside(k.wraw, -a.omega_max, a.omega_max) ? gwd : zero;
+    const S gtau = J0 * dpp<kB0>(mwd) + J1 * dpp<kB1>(mwd) + J2 * dpp<kB2>(mwd);      // I^-T m
+    const S gsum = gxdd * a.inv_mass;
+    const S gt1 = dpp<kRot1>(gtau), gt2 = dpp<kRot2>(gtau);
+    const S gf = gt1 * r2 - gt2 * r1;                 // tau += r x f : df = gtau x r
+    S gr = k.f1 * gt2 - k.f2 * gt1;                   //                dr = f x gtau
+    S gFr = gFr_up + gsum + gf;
+    const S gFf_ = gFf_up + gsum + gf;
+    const S gG = inside(k.Gf, -mg, mg) ? gFf_ : zero;
+    const S gNn = dot3(gG, k.stv);
+    const S gst = k.Nn * gG;
+    const S gsn = -dot3(gst, nrm);
+    S gn = gsn * k.s - k.sn * gst;
+    const S gslip = gst + gsn * nrm;
+    const S gmuq = dot3(gslip, k.cmdv);
+    const S gcmd = k.mub * gslip;
+    S gvp = -gcmd;
+    const S ge_p = k.tv * gcmd;
+    S gv_p = zero, gwc_p = zero;
     if constexpr (GCTRL) {
-      const float gtv = dot3(gcmd, k.e);                   // tv_v = tv_w = 0 for non-driving points
+      const S gtv = dot3(gcmd, k.e);                   // tv_v = tv_w = 0 for non-driving points
       gv_p = tv_v * gtv; gwc_p = tv_w * gtv;
     }
-    gFr = fmaf(k.Nn > zero ? gNn * M::div(one, k.Nn) : zero, k.Fr, gFr);
-    const float gF1 = inside(k.F1, -mg, mg) ? gFr : zero;
-    const float dF = dot3(gF1, k.F0);
-    const float gc_p = dF * inv_csum;
-    const float gS = sum_points(-(dF * cj) * inv_csum * inv_csum);
-    const float gF0 = gF1 * cj * inv_csum;
-    const float gA = -dot3(gF0, nrm);
-    gn = fmaf(-k.A, gF0, gn);
-    const float gdh_p = a.k * gA;
-    const float gvn = a.damp * gA;
-    gvp = fmaf(gvn, nrm, gvp);
-    gn = fmaf(gvn, k.vp, gn);
-    const float gcw = gc_p + gS;
-    const float gdh = gdh_p + gcw * (-10.0f) * cj * (one - cj);
-    const float gzq = -gdh;
+    gFr = mf_fma(k.Nn > zero ? gNn * M::div(one, k.Nn) : zero, k.Fr, gFr);
+    const S gF1 = inside(k.F1, -mg, mg) ? gFr : zero;
+    const S dF = dot3(gF1, k.F0);
+    const S gc_p = dF * inv_csum;
+    const S gS = sum_points(-(dF * cj) * inv_csum * inv_csum);
+    const S gF0 = gF1 * cj * inv_csum;
+    const S gA = -dot3(gF0, nrm);
+    gn = mf_fma(-k.A, gF0, gn);
+    const S gdh_p = a.k * gA;
+    const S gvn = a.damp * gA;
+    gvp = mf_fma(gvn, nrm, gvp);
+    gn = mf_fma(gvn, k.vp, gn);
+    const S gcw = gc_p + gS;
+    const S gdh = gdh_p + gcw * (-S(10.0)) * cj * (one - cj);
+    const S gzq = -gdh;
     // n = u / |u|, u = (-gx, -gy, 1): components 0, 1 carry the finite differences
-    const float dotn = dot3(gn, nrm);
-    const float gg = -((gn - dotn * nrm) * k.inl) * a.inv_res;      // lane 0: ggx, lane 1: ggy
-    const float ggp = dpp<0x51>(gg);                                  // quad_perm [1,0,1,1]
-    const float nz = fmaf(gzq, k.wq, cgA * gg + cgB * ggp);
-    const float nm = gmuq * k.wq;
+    const S dotn = dot3(gn, nrm);
+    const S gg = -((gn - dotn * nrm) * k.inl) * a.inv_res;      // lane 0: ggx, lane 1: ggy
+    const S ggp = dpp<0x51>(gg);                                  // quad_perm [1,0,1,1]
+    const S nz = mf_fma(gzq, k.wq, cgA * gg + cgB * ggp);
+    const S nm = gmuq * k.wq;
     {   // this lane's cell accumulator
       const unsigned ni = (unsigned)k.idx;
       const bool same = !act | (ni == acc_idx);          // absent points contribute exact zeros: never flushed
@@ -401,25 +395,25 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
       acc_m = same ? acc_m + nm : nm;
     }
     // d(sample)/d(position) through the fractions only: d wq / d fx = wa_s * wb, d wq / d fy = wb_s * wa
-    const float vq = gzq * k.zc + gmuq * k.mcv;
-    const float gpx = dot4(vq, wa_s * k.wb), gpy = dot4(vq, wb_s * k.wa);
-    const float gp = mask_or(mask_or(mask_or(zero, gpx * a.inv_res, lane0), gpy * a.inv_res, lane1), gdh, lane2);
+    const S vq = gzq * k.zc + gmuq * k.mcv;
+    const S gpx = dot4(vq, wa_s * k.wb), gpy = dot4(vq, wb_s * k.wa);
+    const S gp = mask_or(mask_or(mask_or(zero, gpx * a.inv_res, lane0), gpy * a.inv_res, lane1), gdh, lane2);
     // v_p = xd + w x r
-    const float gvp1 = dpp<kRot1>(gvp), gvp2 = dpp<kRot2>(gvp);
+    const S gvp1 = dpp<kRot1>(gvp), gvp2 = dpp<kRot2>(gvp);
     gr += gvp1 * w2 - gvp2 * w1;                           // dr += gvp x w
-    const float gw_p = r1 * gvp2 - r2 * gvp1;              // dw += r x gvp
-    const float qa = gp + gr;                              // p = R P + x, r = p - x
+    const S gw_p = r1 * gvp2 - r2 * gvp1;              // dw += r x gvp
+    const S qa = gp + gr;                              // p = R P + x, r = p - x
     // sums over the contact points
     lx += gp; lxd += gvp; lw += gw_p;                      // (each quad's own part)
-    lR0 = fmaf(qa, P0, lR0); lR1 = fmaf(qa, P1, lR1); lR2 = fmaf(qa, P2, lR2);
-    const float ge = ge_p;
-    float gv = zero, gwc = zero;
+    lR0 = mf_fma(qa, P0, lR0); lR1 = mf_fma(qa, P1, lR1); lR2 = mf_fma(qa, P2, lR2);
+    const S ge = ge_p;
+    S gv = zero, gwc = zero;
     if constexpr (GCTRL) { gv = sum_points(gv_p); gwc = sum_points(gwc_p); }
     {   // e = col0(R) / max(|col0|, eps): through |col0| only when it is >= eps
-      const float dote = dot3(ge, k.e) * (k.coln2 >= 1e-12f ? one : zero);   // (a ternary around the lane sum becomes a branch)
-      lR0 = fmaf(ge - dote * k.e, k.il, lR0);
+      const S dote = dot3(ge, k.e) * (k.coln2 >= S(1e-12) ? one : zero);   // (a ternary around the lane sum becomes a branch)
+      lR0 = mf_fma(ge - dote * k.e, k.il, lR0);
     }
-    gctrl_pending = __builtin_amdgcn_readfirstlane((unsigned)n * 8u); gv_pending = gv; gwc_pending = gwc;      // stored by the next iteration (or after the loop)
+    gctrl_pending = __builtin_amdgcn_readfirstlane((unsigned)n * kC); gv_pending = gv; gwc_pending = gwc;      // stored by the next iteration (or after the loop)
   };
 
   // One iteration.  Memory operations in program order (vmcnt is one in-order counter over loads, stores and atomics):
@@ -454,21 +448,21 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
     // instructions (rebuild): no cell arithmetic from positions, no exponentials, no square roots, and -- because the
     // values that decide a clamp or the sign at the |F_n| kink are the forward's own -- no way to differentiate a different
     // function than the forward evaluated.  256 B per rollout-step (round 2: 1 KiB).
-    typedef float f4v __attribute__((ext_vector_type(4)));
-    struct Saved { f4v q; float zc, mc; int idx; };
-    const char* const prec = reinterpret_cast<const char*>(a.rec) + (size_t)tid * kRecBytesPerLane;
-    const unsigned rec_step = (unsigned)a.B * 16u * kRecBytesPerLane;      // bytes between consecutive steps
+    typedef S f4v __attribute__((ext_vector_type(4)));
+    struct Saved { f4v q; S zc, mc; int idx; };
+    const char* const prec = reinterpret_cast<const char*>(a.rec) + (size_t)tid * kRecBytesPerLane<S>;
+    const unsigned rec_step = (unsigned)a.B * 16u * kRecBytesPerLane<S>;      // bytes between consecutive steps
     auto load_saved = [&](int m, Saved& v) {
       v.q = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(prec + (size_t)__builtin_amdgcn_readfirstlane((unsigned)m) * (size_t)rec_step));
     };
     // the lane's footprint cell from the recorded cell coordinates (lanes 0, 1 of the quad hold u_x, u_y), and its two gathers
     auto gather_cells = [&](Saved& v) {
-      const float lim = 262144.0f;
+      const S lim = S(262144.0);
       const int ui = (int)M::clamp(v.q.x, -lim, lim);                  // as the forward's footprint(): trunc toward zero
       const int base = dppi<kB1>(ui) + __mul24(a.H, dppi<kB0>(ui));
       v.idx = min(max(base + cell_off, 0), last);
 #ifdef MF_STREAM_NO_GATHER   // A/B build: the cells as constants -- what the second round trip of the fetching wave costs
-      v.zc = 0.1f * (float)q; v.mc = 0.8f;
+      v.zc = S(0.1) * (S)q; v.mc = S(0.8);
       return;
 #endif
       v.zc = ld32(zmap, moff + (unsigned)v.idx);
@@ -477,20 +471,20 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
     auto rebuild = [&](const StateIn& st, const Saved& v, Rec& k) {
       k.R0 = st.R0; k.R1 = st.R1; k.R2 = st.R2; k.w = st.w;
       k.h = ODE ? st.t1 - st.t0 : a.dt;
-      const float r = cp_body_r(P0, P1, P2, st.R0, st.R1, st.R2);
+      const S r = cp_body_r(P0, P1, P2, st.R0, st.R1, st.R2);
       k.r1 = dpp<kRot1>(r); k.r2 = dpp<kRot2>(r);
       k.w1 = dpp<kRot1>(st.w); k.w2 = dpp<kRot2>(st.w);
       k.vp = cp_vel(st.xd, st.w, r);
-      const float lim = 262144.0f;
-      const float uq = v.q.x;
-      const float fr = uq - (float)(int)M::clamp(uq, -lim, lim);
-      k.wa = fmaf(wa_s, dpp<kB0>(fr), wa_o); k.wb = fmaf(wb_s, dpp<kB1>(fr), wb_o);
+      const S lim = S(262144.0);
+      const S uq = v.q.x;
+      const S fr = uq - (S)(int)M::clamp(uq, -lim, lim);
+      k.wa = mf_fma(wa_s, dpp<kB0>(fr), wa_o); k.wb = mf_fma(wb_s, dpp<kB1>(fr), wb_o);
       k.wq = k.wa * k.wb;
       k.cj = v.q.y; k.wraw = v.q.z; k.A = v.q.w;
       k.idx = v.idx; k.zc = v.zc; k.mcv = has_mu ? v.mc : one;
       k.mub = dot4(k.wq, k.mcv);
-      const float dz = v.zc - dpp<kB0>(v.zc);
-      const float u = fmaf(dpp<kN12>(dz), n_mul, n_add);
+      const S dz = v.zc - dpp<kB0>(v.zc);
+      const S u = mf_fma(dpp<kN12>(dz), n_mul, n_add);
       k.inl = M::inv_len(dot3(u, u));
       k.nrm = u * k.inl;
       k.inv_csum = M::div(one, sum_points(k.cj));
@@ -507,16 +501,16 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
       k.sn = dot3(k.s, k.nrm);
       k.stv = cp_tangent(k.s, k.sn, k.nrm);
       k.Gf = k.Nn * k.stv;
-      const float f = k.Fr + M::clamp(k.Gf, -mg, mg);
+      const S f = k.Fr + M::clamp(k.Gf, -mg, mg);
       k.f1 = dpp<kRot1>(f); k.f2 = dpp<kRot2>(f);
     };
     // fused physics loss (MfRolloutLoss): a.gXs points at the forward's Xs rows, dL/dXs of a row is formed where it is consumed
     const bool loss_on = STREAM && a.loss_gt != nullptr;      // wave-uniform
-    const unsigned loss_mask = loss_on ? ~0u : 0u;
-    const float loss_scale = loss_on ? 2.0f * a.loss_gloss[0] * a.loss_inv_count : zero;      // as csrc/physics_loss.hip: (2 gloss) / count
-    const float* const loss_gt_lane = loss_on ? a.loss_gt + ((size_t)b * (size_t)a.loss_T2) * 3u + (unsigned)cc : a.z;
+    const Msk loss_mask = loss_on ? ~(Msk)0 : (Msk)0;
+    const S loss_scale = loss_on ? S(2.0) * a.loss_gloss[0] * a.loss_inv_count : zero;      // as csrc/physics_loss.hip: (2 gloss) / count
+    const S* const loss_gt_lane = loss_on ? a.loss_gt + ((size_t)b * (size_t)a.loss_T2) * 3u + (unsigned)cc : a.z;
     const int* const l_row_stamp = loss_on ? a.loss_row_stamp : reinterpret_cast<const int*>(a.ts);      // dummies: T valid words
-    const float* const l_row_w = loss_on ? a.loss_row_w : a.ts;
+    const S* const l_row_w = loss_on ? a.loss_row_w : a.ts;
     const int l_T2m1 = loss_on ? a.loss_T2 - 1 : 0;
     if constexpr (STREAM) {
       // MODE = kCpStream (default integrator): a SECOND wave of the workgroup fetches -- the rows and the record of three steps per
@@ -528,7 +522,7 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
       // writes of batch k -- three register sets, unrolled by three, so that neither round trip is ever waited for.
       // Addresses: constant scalar bases + RUNNING 32-bit per-lane byte offsets, one vector subtract per array and step.
       const unsigned un = (unsigned)max(n, 0);
-      unsigned o3 = v3 + un * s3, o9 = v9 + un * s9, oc = v_ctrl + un * 8u, orc = un * rec_step;
+      unsigned o3 = v3 + un * s3, o9 = v9 + un * s9, oc = v_ctrl + un * kC, orc = un * rec_step;
       // (the row a step PRODUCES: default integrator row m + 1, dynamics() row m)
       constexpr unsigned kUp = ODE ? 1u : 0u;
       unsigned og_xs = u_xs + (un + kUp) * sg_xs, og_xds = u_xds + (un + kUp) * sg_xds, og_om = u_om + (un + kUp) * sg_om;
@@ -537,12 +531,12 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
       auto request_state = [&](StateIn& d, Saved& v) {      // rows + record of the step the offsets point at
         d.x = zero;                                            // (positions are not needed: the record replaces what used them)
 #ifdef MF_STREAM_NO_FETCH    // A/B build: no loads at all -- times the rebuild + ring writes + the computing wave
-        d.xd = 0.1f; d.w = 0.01f; d.R0 = cc == 0 ? one : zero; d.R1 = cc == 1 ? one : zero; d.R2 = cc == 2 ? one : zero; d.cv = 0.5f; d.cw = 0.1f;
-        d.t1 = 0.01f; d.t0 = zero; v.q = f4v{100.3f, 0.2f, 0.1f, 50.0f};
+        d.xd = S(0.1); d.w = S(0.01); d.R0 = cc == 0 ? one : zero; d.R1 = cc == 1 ? one : zero; d.R2 = cc == 2 ? one : zero; d.cv = S(0.5); d.cw = S(0.1);
+        d.t1 = S(0.01); d.t0 = zero; v.q = f4v{S(100.3), S(0.2), S(0.1), S(50.0)};
         return;
 #endif
         if constexpr (ODE) {
-          d.xd = bload1(rXds, o3, 0u); d.w = bload1(rOm, o3, 0u);
+          d.xd = bload1<S>(rXds, o3, 0u); d.w = bload1<S>(rOm, o3, 0u);
           bload3(rRs, o9, 0u, &d.R0, &d.R1, &d.R2);
           d.t1 = a.ts[ti + 1]; d.t0 = a.ts[ti];             // (every fetched step is a real one: 0 <= ti <= T - 2)
         } else {
@@ -550,12 +544,12 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
           // whose angular velocity is the w' of its Rodrigues step -- loaded, not recomputed
           const bool init = ti == 0;                          // wave-uniform
           const unsigned p3 = init ? o3 : o3 - s3, p9 = init ? o9 : o9 - s9;
-          const float xd = bload1(rXds, p3, 0u), w = bload1(rOm, p3, 0u);
-          float R0, R1, R2;
+          const S xd = bload1<S>(rXds, p3, 0u), w = bload1<S>(rOm, p3, 0u);
+          S R0, R1, R2;
           bload3(rRs, p9, 0u, &R0, &R1, &R2);
           d.xd = init ? ini.xd : xd; d.w = init ? ini.w : w;
           d.R0 = init ? ini.R0 : R0; d.R1 = init ? ini.R1 : R1; d.R2 = init ? ini.R2 : R2;
-          d.x = bload1(rOm, o3, 0u);                          // (the unused position slot carries w' of row m)
+          d.x = bload1<S>(rOm, o3, 0u);                          // (the unused position slot carries w' of row m)
           d.t1 = a.dt; d.t0 = zero;
         }
         bload2(rCtrl, oc, 0u, &d.cv, &d.cw);
@@ -563,15 +557,15 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
       };
       auto request_up = [&](UpIn& u) {                       // upstream gradients of the row that step produced
 #ifdef MF_STREAM_NO_FETCH
-        u.gXs = 0.001f;
-        if constexpr (!XS_ONLY) { u.gXds = u.gOm = u.gR0 = u.gR1 = u.gR2 = u.gFs = u.gFf = 0.001f; }
+        u.gXs = S(0.001);
+        if constexpr (!XS_ONLY) { u.gXds = u.gOm = u.gR0 = u.gR1 = u.gR2 = u.gFs = u.gFf = S(0.001); }
         return;
 #endif
-        u.gXs = bload1(rgXs, og_xs, 0u);
+        u.gXs = bload1<S>(rgXs, og_xs, 0u);
         if constexpr (!XS_ONLY) {
-          u.gXds = bload1(rgXds, og_xds, 0u); u.gOm = bload1(rgOm, og_om, 0u);
+          u.gXds = bload1<S>(rgXds, og_xds, 0u); u.gOm = bload1<S>(rgOm, og_om, 0u);
           bload3(rgRs, og_r, 0u, &u.gR0, &u.gR1, &u.gR2);
-          u.gFs = bload1(rgFs, og_fs, 0u); u.gFf = bload1(rgFf, og_ff, 0u);
+          u.gFs = bload1<S>(rgFs, og_fs, 0u); u.gFf = bload1<S>(rgFf, og_ff, 0u);
         }
       };
       auto step_back_up = [&]() {
@@ -590,8 +584,8 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
       // they convert into dL/dXs anyway (the computing wave row 0's); at the end one partial sum per workgroup in a fixed order, and the
       // workgroup that takes the last ticket adds the partial sums in index order (as rollout_fwd_cp_kernel.h's LOSS kernels do).
       const bool loss_val = loss_on && a.loss_out != nullptr;      // wave-uniform
-      __shared__ float l_part[3 * 16 + 64];
-      auto loss_value_finish = [&](float acc) {     // every wave of the workgroup, once
+      __shared__ S l_part[3 * 16 + 64];
+      auto loss_value_finish = [&](S acc) {     // every wave of the workgroup, once
         if (!loss_val) return;
         const int wv = (int)(threadIdx.x >> 6);
         if (lane < 16) l_part[wv * 16 + lane] = zero;             // (LDS executes a wave's operations in order)
@@ -600,7 +594,7 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
         if (wv != 0) return;
         unsigned last_wg = 0u;
         if (lane == 0) {
-          float tot = zero;
+          S tot = zero;
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -613,12 +607,12 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
         if (last_wg) {                                            // every workgroup has written its partial sum: the mean, in index order
           __threadfence();
           const int n_act = min(64, (a.B - (int)blockIdx.x * 4) * 16);      // live lanes of this (possibly trailing) workgroup: the first n_act
-          float tot = zero;
+          S tot = zero;
           for (unsigned k2 = (unsigned)lane; k2 < gridDim.x; k2 += (unsigned)n_act) tot += __builtin_nontemporal_load(a.loss_partial + k2);
           l_part[48 + lane] = tot;
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // (one wave: its LDS operations execute in order)
           if (lane == 0) {
-            float sum = zero;
+            S sum = zero;
             for (int k2 = 0; k2 < n_act; ++k2) sum += l_part[48 + k2];
             a.loss_out[0] = sum * a.loss_inv_count;
             *a.loss_ticket = 0u;
@@ -634,12 +628,12 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
         // batch's first step (ordinal 3 j) sits in slot 3 j mod kSlots (six slots: wave k owns slots 3k .. 3k + 2); steps are
         // published -- `steps written` advanced -- in order: a wave waits for the other one's previous batch.
         static_assert(kSlots % 6 == 0, "two fetching waves alternate over batches of three steps: a batch must not wrap around the ring");
-        struct Slot { StateIn st; Saved sv; UpIn up; float lg, lw; int sj; };      // stamp of the row, its weight and ground truth (fused loss)
+        struct Slot { StateIn st; Saved sv; UpIn up; S lg, lw; int sj; };      // stamp of the row, its weight and ground truth (fused loss)
         unsigned zero_lane = 0u;                                                   // 0, as a per-lane value the compiler cannot see through:
         asm("" : "+v"(zero_lane));                                                 // keeps the loads of the stamp tables VECTOR loads
         const int fk = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) - 1;      // (wave-uniform, and provably so: scalar branches)
         int m = n;                                  // m: the step the offsets point at
-        float l_acc = zero;                         // this wave's share of the loss value
+        S l_acc = zero;                         // this wave's share of the loss value
         auto fetch = [&](Slot& r) {                 // everything of step m; then the offsets move to step m - 1
           request_state(r.st, r.sv);                // (past step 0 the offsets wrap around; nothing reads them again)
           request_up(r.up);
@@ -652,12 +646,12 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
           r.sj = ld32(l_row_stamp, (unsigned)ti + kUp + zero_lane);
           r.lw = ld32(l_row_w, (unsigned)ti + kUp + zero_lane);            // 0 where the row carries no stamp -> gradient 0
           r.lg = zero;
-          o3 -= s3; o9 -= s9; oc -= 8u; orc -= rec_step; --ti;
+          o3 -= s3; o9 -= s9; oc -= kC; orc -= rec_step; --ti;
           step_back_up();
           --m;
         };
         auto skip3 = [&]() {                        // over the other wave's batch
-          o3 -= 3u * s3; o9 -= 3u * s9; oc -= 24u; orc -= 3u * rec_step; ti -= 3; m -= 3;
+          o3 -= 3u * s3; o9 -= 3u * s9; oc -= 3u * kC; orc -= 3u * rec_step; ti -= 3; m -= 3;
           og_xs -= 3u * sg_xs;
           if constexpr (!XS_ONLY) { og_xds -= 3u * sg_xds; og_om -= 3u * sg_om; og_r -= 3u * sg_r; og_fs -= 3u * sg_fs; og_ff -= 3u * sg_ff; }
         };
@@ -685,12 +679,12 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
         auto put = [&](const Slot& r, unsigned slot, int o) {
             Rec k;
             rebuild(r.st, r.sv, k);
-            const float mw = inside(k.wraw, -a.omega_max, a.omega_max) ? one : zero;
-            const float mG = inside(k.Gf, -mg, mg) ? one : zero;
-            const float mF1 = inside(k.F1, -mg, mg) ? one : zero;
-            const float invNn = k.Nn > zero ? M::div(one, k.Nn) : zero;
-            const float cmask = k.coln2 >= 1e-12f ? one : zero;
-            const float cs = k.cj * k.inv_csum;
+            const S mw = inside(k.wraw, -a.omega_max, a.omega_max) ? one : zero;
+            const S mG = inside(k.Gf, -mg, mg) ? one : zero;
+            const S mF1 = inside(k.F1, -mg, mg) ? one : zero;
+            const S invNn = k.Nn > zero ? M::div(one, k.Nn) : zero;
+            const S cmask = k.coln2 >= S(1e-12) ? one : zero;
+            const S cs = k.cj * k.inv_csum;
             // (the upstream gradient of a state row goes to point 0's quad: add_upstream_masked)
             const f4v p0 = f4v{k.R0, k.R1, k.R2, k.h};
             const f4v p1 = f4v{k.w1, k.w2, k.r1, k.r2};
@@ -698,34 +692,34 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
             const f4v p3 = f4v{mG * k.Nn, k.nrm, k.s, k.sn};
             const f4v p4 = f4v{k.cmdv, k.mub, k.tv * k.mub, k.Fr * invNn};
             const f4v p5 = f4v{mF1 * cs, mF1 * k.nrm, k.A, -(a.k * cs)};
-            const f4v p6 = f4v{-(a.damp * cs), -(k.A * k.inv_csum), k.A * k.cj * k.inv_csum * k.inv_csum, -10.0f * k.cj * (one - k.cj)};
-            const f4v p7 = f4v{k.vp, -(k.inl * a.inv_res), k.wq, __builtin_bit_cast(float, k.idx)};
+            const f4v p6 = f4v{-(a.damp * cs), -(k.A * k.inv_csum), k.A * k.cj * k.inv_csum * k.inv_csum, -S(10.0) * k.cj * (one - k.cj)};
+            const f4v p7 = f4v{k.vp, -(k.inl * a.inv_res), k.wq, idx_as(zero, k.idx)};
             const f4v p8 = f4v{k.zc, k.mcv, wa_s * k.wb * a.inv_res, wb_s * k.wa * a.inv_res};
             // (fused physics loss: the row's gXs slot holds Xs itself; dL/dXs from it, the stamp's ground truth and weight)
             // (a bitwise merge, not a select on `loss_on`: with the value's term next to it the compiler turned the select into a
             //  branch around both -- nine exec-masked blocks per batch, 0.217 -> 0.229 ms)
-            const float gXs_row = bfi(loss_mask, cp_loss_grad(loss_scale, r.up.gXs, r.lg, r.lw), r.up.gXs);
+            const S gXs_row = bfi(loss_mask, cp_loss_grad(loss_scale, r.up.gXs, r.lg, r.lw), r.up.gXs);
             l_acc += cp_loss_term(r.up.gXs, r.lg, r.lw);      // (the value: used with MF_LOSS_VALUE_IN_BACKWARD only)
             const f4v p9 = f4v{k.e, k.il, cmask * k.e * k.il, first * gXs_row};
             // dynamics(): everything of the Rodrigues step R' = R M(w'), M = I + K sin(th h) + K^2 (1 - cos(th h)), K = [kv]x,
             // kv = w' / max(|w'|, eps), that does not depend on the adjoint -- from w' as the forward left it in row m
             f4v d0 = {zero, zero, zero, zero}, d1 = d0, d2 = d0, d3 = d0, d4 = d0, d5 = d0;
             if constexpr (!ODE) {
-              const float h = a.dt, wn = r.st.x;
-              const float th2 = dot3(wn, wn);
-              const float idn = M::inv_len(th2);                    // 1 / max(th, 1e-6)
-              const float kv = wn * idn;
-              const float th = M::sqrt(th2);
-              float sn_, oc;
+              const S h = a.dt, wn = r.st.x;
+              const S th2 = dot3(wn, wn);
+              const S idn = M::inv_len(th2);                    // 1 / max(th, 1e-6)
+              const S kv = wn * idn;
+              const S th = M::sqrt(th2);
+              S sn_, oc;
               M::sincos_small(th * h, &sn_, &oc);
-              const float kk = dot3(kv, kv);
-              const float kv1 = dpp<kRot1>(kv), kv2 = dpp<kRot2>(kv);
-              const float ok = oc * kv;
-              const float m0 = fmaf(ok, kv, fmaf(-oc, kk, one)), m1 = fmaf(ok, kv1, -(sn_ * kv2)), m2 = fmaf(ok, kv2, sn_ * kv1);   // M[c][c], M[c][c+1], M[c][c+2]
-              const float q0 = dpp<kB0>(kv), q1 = dpp<kB1>(kv), q2 = dpp<kB2>(kv);
-              const float Rk = k.R0 * q0 + k.R1 * q1 + k.R2 * q2;
-              const float idn2 = th2 >= 1e-12f ? idn * idn : zero;      // through max(th, eps) only when th >= eps
-              const float ith = th2 > zero ? M::div(one, th) : zero;    // d|w'|/dw' = w' / |w'|, 0 at 0
+              const S kk = dot3(kv, kv);
+              const S kv1 = dpp<kRot1>(kv), kv2 = dpp<kRot2>(kv);
+              const S ok = oc * kv;
+              const S m0 = mf_fma(ok, kv, mf_fma(-oc, kk, one)), m1 = mf_fma(ok, kv1, -(sn_ * kv2)), m2 = mf_fma(ok, kv2, sn_ * kv1);   // M[c][c], M[c][c+1], M[c][c+2]
+              const S q0 = dpp<kB0>(kv), q1 = dpp<kB1>(kv), q2 = dpp<kB2>(kv);
+              const S Rk = k.R0 * q0 + k.R1 * q1 + k.R2 * q2;
+              const S idn2 = th2 >= S(1e-12) ? idn * idn : zero;      // through max(th, eps) only when th >= eps
+              const S ith = th2 > zero ? M::div(one, th) : zero;    // d|w'|/dw' = w' / |w'|, 0 at 0
               d0 = f4v{wn, kv, q0, q1};
               d1 = f4v{q2, Rk, kk, sn_};
               d2 = f4v{oc, h * (one - oc), h * sn_, idn};
@@ -798,26 +792,26 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
         unsigned rslot = 0u;                          // ring slot read next (running, wraps at kSlots)
         UpIn uZ;                                      // the upstream gradient of output row 0 (the initial state): not in the ring
         load_upstream(0, uZ);
-        float l_row0 = zero;                          // row 0's term of the loss value (the other rows' are the fetching waves')
+        S l_row0 = zero;                          // row 0's term of the loss value (the other rows' are the fetching waves')
         if (loss_on) {
-          const float g0 = loss_gt_lane[(size_t)max(a.loss_row_stamp[0], 0) * 3u], w0 = a.loss_row_w[0];
+          const S g0 = loss_gt_lane[(size_t)max(a.loss_row_stamp[0], 0) * 3u], w0 = a.loss_row_w[0];
           l_row0 = cp_loss_term(uZ.gXs, g0, w0);
           uZ.gXs = cp_loss_grad(loss_scale, uZ.gXs, g0, w0);
         }
         // The coefficients of a step's vector-Jacobian product, as the fetching wave leaves them in the ring.  With
         // cs = c / sum c, the gates mG, mF1 (1 / 0) and d1 = gFr . (mF1 n) -- the one lane sum that serves F0 = -A n and n both:
         struct Coef {
-          float R0, R1, R2, h, w1, w2, r1, r2, f1, f2, mw;
-          float stvG, NnG, nrm, s, sn;          // mG stv, mG |F_n|
-          float cmdv, mub, tvm, FrN;            // tv mu_b, Fr / |F_n|
-          float csm, nm1, A, kcs;               // mF1 cs, mF1 n, A, -k cs          (g_dh' = kcs d1)
-          float dcs, Aic, Acc, dcj;             // -d cs (g_vn = dcs d1), -A / sum c (g_c = Aic d1), A c / (sum c)^2 (g_S = sum_points(Acc d1)), -10 c (1 - c)
-          float vp, inlr, wq, zc, mcv, wsb, wsa;      // -(1 / |u|) / res; d wq / d(fx, fy) / res
-          float e, il, eci;                     // gate_col0 e / |col0|
+          S R0, R1, R2, h, w1, w2, r1, r2, f1, f2, mw;
+          S stvG, NnG, nrm, s, sn;          // mG stv, mG |F_n|
+          S cmdv, mub, tvm, FrN;            // tv mu_b, Fr / |F_n|
+          S csm, nm1, A, kcs;               // mF1 cs, mF1 n, A, -k cs          (g_dh' = kcs d1)
+          S dcs, Aic, Acc, dcj;             // -d cs (g_vn = dcs d1), -A / sum c (g_c = Aic d1), A c / (sum c)^2 (g_S = sum_points(Acc d1)), -10 c (1 - c)
+          S vp, inlr, wq, zc, mcv, wsb, wsa;      // -(1 / |u|) / res; d wq / d(fx, fy) / res
+          S e, il, eci;                     // gate_col0 e / |col0|
           int idx;
           // dynamics() only (struct "CoefD", six more planes): the adjoint-independent half of the Rodrigues step's backward
-          float wn, kv, q0, q1, q2, Rk, kk, sn_, oc, cga, cgb, idn, idn2, ith;      // cga = h (1 - cos), cgb = h sin
-          float M00, M01, M02, M10, M11, M12, M20, M21, M22;                      // M[m][j], every lane holds all nine
+          S wn, kv, q0, q1, q2, Rk, kk, sn_, oc, cga, cgb, idn, idn2, ith;      // cga = h (1 - cos), cgb = h sin
+          S M00, M01, M02, M10, M11, M12, M20, M21, M22;                      // M[m][j], every lane holds all nine
         };
         // (the loop asks for the two steps of a trip at once, and reports them read at once: the counters cost an LDS
         //  instruction each, ~14 cycles of this wave)
@@ -834,7 +828,7 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
           const f4v* o = ring + (kPow2 ? (unsigned)(consumed & (kSlots - 1)) : rslot) * (unsigned)(kPlanes * 64) + lane;
           if constexpr (!kPow2) rslot = rslot + 1u == (unsigned)kSlots ? 0u : rslot + 1u;
           const f4v c0 = o[0], c1 = o[64], c2 = o[128], c3 = o[192], c4 = o[256], c5 = o[320], c6 = o[384], c7 = o[448], c8 = o[512], c9 = o[576];
-          const float idx_bits = c7.w;       // (__builtin_bit_cast applied to the element expression itself reads element 0 of the vector)
+          const S idx_bits = c7.w;       // (__builtin_bit_cast applied to the element expression itself reads element 0 of the vector)
           c.R0 = c0.x; c.R1 = c0.y; c.R2 = c0.z; c.h = c0.w;
           c.w1 = c1.x; c.w2 = c1.y; c.r1 = c1.z; c.r2 = c1.w;
           c.f1 = c2.x; c.f2 = c2.y; c.mw = c2.z; c.stvG = c2.w;
@@ -842,18 +836,18 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
           c.cmdv = c4.x; c.mub = c4.y; c.tvm = c4.z; c.FrN = c4.w;
           c.csm = c5.x; c.nm1 = c5.y; c.A = c5.z; c.kcs = c5.w;
           c.dcs = c6.x; c.Aic = c6.y; c.Acc = c6.z; c.dcj = c6.w;
-          c.vp = c7.x; c.inlr = c7.y; c.wq = c7.z; c.idx = __builtin_bit_cast(int, idx_bits);
+          c.vp = c7.x; c.inlr = c7.y; c.wq = c7.z; c.idx = idx_of(idx_bits);
           c.zc = c8.x; c.mcv = c8.y; c.wsb = c8.z; c.wsa = c8.w;
           c.e = c9.x; c.il = c9.y; c.eci = c9.z; up.gXs = c9.w;
           if constexpr (!XS_ONLY) {
             const f4v g0 = o[640];
-            const float* g1 = reinterpret_cast<const float*>(o + 704);      // (three floats: an unused fourth would be a free register to the allocator)
+            const S* g1 = reinterpret_cast<const S*>(o + 704);      // (three floats: an unused fourth would be a free register to the allocator)
             up.gXds = g0.x; up.gOm = g0.y; up.gFs = g0.z; up.gFf = g0.w; up.gR0 = g1[0]; up.gR1 = g1[1]; up.gR2 = g1[2];
           }
           if constexpr (!ODE) {
             constexpr int D0 = (XS_ONLY ? 10 : 12) * 64;
             const f4v e0 = o[D0], e1 = o[D0 + 64], e2 = o[D0 + 128], e3 = o[D0 + 192], e4 = o[D0 + 256];
-            const float* e5 = reinterpret_cast<const float*>(o + D0 + 320);
+            const S* e5 = reinterpret_cast<const S*>(o + D0 + 320);
             c.wn = e0.x; c.kv = e0.y; c.q0 = e0.z; c.q1 = e0.w;
             c.q2 = e1.x; c.Rk = e1.y; c.kk = e1.z; c.sn_ = e1.w;
             c.oc = e2.x; c.cga = e2.y; c.cgb = e2.z; c.idn = e2.w;
@@ -871,8 +865,8 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
         auto take = [&](Coef& c, UpIn& up) { ensure(1); grab(c, up); release(); };
         // The chain of `vjp` (default integrator) on those coefficients.
         auto chain = [&](int n, const Coef& c, const UpIn& up) {
-          const float h = c.h;
-          float gFr_up = zero, gFf_up = zero, gxdd, gwd;
+          const S h = c.h;
+          S gFr_up = zero, gFf_up = zero, gxdd, gwd;
           if constexpr (ODE) {
           if constexpr (!XS_ONLY) {
             laFs += act ? up.gFs : zero;
@@ -880,9 +874,9 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
             gFr_up = h * laFs; gFf_up = h * laFf;
           }
           gxdd = h * sum_points(lxd); gwd = h * sum_points(lw);
-          lxd = fmaf(h, lx, lxd);
-          const float g0 = h * lR0, g1 = h * lR1, g2 = h * lR2;
-          const float g01 = dpp<kRot1>(g0), g02 = dpp<kRot2>(g0), g11 = dpp<kRot1>(g1), g12 = dpp<kRot2>(g1), g21 = dpp<kRot1>(g2), g22 = dpp<kRot2>(g2);
+          lxd = mf_fma(h, lx, lxd);
+          const S g0 = h * lR0, g1 = h * lR1, g2 = h * lR2;
+          const S g01 = dpp<kRot1>(g0), g02 = dpp<kRot2>(g0), g11 = dpp<kRot1>(g1), g12 = dpp<kRot2>(g1), g21 = dpp<kRot1>(g2), g22 = dpp<kRot2>(g2);
           lw += (dpp<kRot1>(c.R0) * g02 - dpp<kRot2>(c.R0) * g01) + (dpp<kRot1>(c.R1) * g12 - dpp<kRot2>(c.R1) * g11) + (dpp<kRot1>(c.R2) * g22 - dpp<kRot2>(c.R2) * g21);
           lR0 += g01 * c.w2 - g02 * c.w1;
           lR1 += g11 * c.w2 - g12 * c.w1;
@@ -891,66 +885,66 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
             // dynamics(): the adjoint of  xd' = xd + xdd h, x' = x + xd' h, w' = w + wd h, R' = R M(w')  on the fetching waves'
             // coefficients (the derivation: `vjp` above); the forces of this step are outputs themselves
             if constexpr (!XS_ONLY) { gFr_up = act ? up.gFs : zero; gFf_up = act ? up.gFf : zero; }
-            const float Lk = lR0 * c.q0 + lR1 * c.q1 + lR2 * c.q2;
-            const float Gk0 = dot3(c.R0, Lk), Gk1 = dot3(c.R1, Lk), Gk2 = dot3(c.R2, Lk);
-            const float Gt0 = dot3(c.Rk, lR0), Gt1 = dot3(c.Rk, lR1), Gt2 = dot3(c.Rk, lR2);
-            const float trG = sum3(c.R0 * lR0 + c.R1 * lR1 + c.R2 * lR2);
-            const float a0 = sum3(c.R1 * lR2 - c.R2 * lR1), a1 = sum3(c.R2 * lR0 - c.R0 * lR2), a2 = sum3(c.R0 * lR1 - c.R1 * lR0);
-            const float ga = -(c.q0 * a0 + c.q1 * a1 + c.q2 * a2);
-            const float gb = (c.q0 * Gk0 + c.q1 * Gk1 + c.q2 * Gk2) - c.kk * trG;
-            float gth = ga * c.cga + gb * c.cgb;
-            const float ac = mask_or(mask_or(mask_or(zero, a0, lane0), a1, lane1), a2, lane2);
-            const float sc = mask_or(mask_or(mask_or(zero, Gk0 + Gt0, lane0), Gk1 + Gt1, lane1), Gk2 + Gt2, lane2);
-            const float gk = -(c.sn_ * ac) - c.oc * (2.0f * trG * c.kv - sc);
-            const float gkw = dot3(gk, c.wn);
-            gth = fmaf(-gkw, c.idn2, gth);
-            lw += fmaf(gth * c.ith, c.wn, gk * c.idn);
+            const S Lk = lR0 * c.q0 + lR1 * c.q1 + lR2 * c.q2;
+            const S Gk0 = dot3(c.R0, Lk), Gk1 = dot3(c.R1, Lk), Gk2 = dot3(c.R2, Lk);
+            const S Gt0 = dot3(c.Rk, lR0), Gt1 = dot3(c.Rk, lR1), Gt2 = dot3(c.Rk, lR2);
+            const S trG = sum3(c.R0 * lR0 + c.R1 * lR1 + c.R2 * lR2);
+            const S a0 = sum3(c.R1 * lR2 - c.R2 * lR1), a1 = sum3(c.R2 * lR0 - c.R0 * lR2), a2 = sum3(c.R0 * lR1 - c.R1 * lR0);
+            const S ga = -(c.q0 * a0 + c.q1 * a1 + c.q2 * a2);
+            const S gb = (c.q0 * Gk0 + c.q1 * Gk1 + c.q2 * Gk2) - c.kk * trG;
+            S gth = ga * c.cga + gb * c.cgb;
+            const S ac = mask_or(mask_or(mask_or(zero, a0, lane0), a1, lane1), a2, lane2);
+            const S sc = mask_or(mask_or(mask_or(zero, Gk0 + Gt0, lane0), Gk1 + Gt1, lane1), Gk2 + Gt2, lane2);
+            const S gk = -(c.sn_ * ac) - c.oc * (S(2.0) * trG * c.kv - sc);
+            const S gkw = dot3(gk, c.wn);
+            gth = mf_fma(-gkw, c.idn2, gth);
+            lw += mf_fma(gth * c.ith, c.wn, gk * c.idn);
             gwd = h * sum_points(lw);
-            lxd = fmaf(h, lx, lxd);
+            lxd = mf_fma(h, lx, lxd);
             gxdd = h * sum_points(lxd);
-            const float n0 = lR0 * c.M00 + lR1 * c.M01 + lR2 * c.M02;      // lR <- lR M^T
-            const float n1 = lR0 * c.M10 + lR1 * c.M11 + lR2 * c.M12;
-            const float n2 = lR0 * c.M20 + lR1 * c.M21 + lR2 * c.M22;
+            const S n0 = lR0 * c.M00 + lR1 * c.M01 + lR2 * c.M02;      // lR <- lR M^T
+            const S n1 = lR0 * c.M10 + lR1 * c.M11 + lR2 * c.M12;
+            const S n2 = lR0 * c.M20 + lR1 * c.M21 + lR2 * c.M22;
             lR0 = n0; lR1 = n1; lR2 = n2;
           }
           // ---- RHS backward ----
-          const float mwd = c.mw * gwd;
-          const float gtau = J0 * dpp<kB0>(mwd) + J1 * dpp<kB1>(mwd) + J2 * dpp<kB2>(mwd);      // I^-T m
-          const float gt1 = dpp<kRot1>(gtau), gt2 = dpp<kRot2>(gtau);
-          const float gq = fmaf(gxdd, a.inv_mass, gt1 * c.r2 - gt2 * c.r1);      // to both force outputs: sum + (tau += r x f)
-          float gr = c.f1 * gt2 - c.f2 * gt1;
-          float gFr = gFr_up + gq;
-          const float gFf_ = gFf_up + gq;
-          const float gNn = dot3(gFf_, c.stvG);
-          const float gst = c.NnG * gFf_;
-          const float gsn = -dot3(gst, c.nrm);
-          float gn = gsn * c.s - c.sn * gst;
-          const float gslip = fmaf(gsn, c.nrm, gst);
-          const float gmuq = dot3(gslip, c.cmdv);
-          const float gcmd = c.mub * gslip;
-          float gvp = -gcmd;
-          const float ge_p = c.tvm * gslip;
-          float gv_p = zero, gwc_p = zero;
+          const S mwd = c.mw * gwd;
+          const S gtau = J0 * dpp<kB0>(mwd) + J1 * dpp<kB1>(mwd) + J2 * dpp<kB2>(mwd);      // I^-T m
+          const S gt1 = dpp<kRot1>(gtau), gt2 = dpp<kRot2>(gtau);
+          const S gq = mf_fma(gxdd, a.inv_mass, gt1 * c.r2 - gt2 * c.r1);      // to both force outputs: sum + (tau += r x f)
+          S gr = c.f1 * gt2 - c.f2 * gt1;
+          S gFr = gFr_up + gq;
+          const S gFf_ = gFf_up + gq;
+          const S gNn = dot3(gFf_, c.stvG);
+          const S gst = c.NnG * gFf_;
+          const S gsn = -dot3(gst, c.nrm);
+          S gn = gsn * c.s - c.sn * gst;
+          const S gslip = mf_fma(gsn, c.nrm, gst);
+          const S gmuq = dot3(gslip, c.cmdv);
+          const S gcmd = c.mub * gslip;
+          S gvp = -gcmd;
+          const S ge_p = c.tvm * gslip;
+          S gv_p = zero, gwc_p = zero;
           if constexpr (GCTRL) {
-            const float gtv = dot3(gcmd, c.e);                 // tv_v = tv_w = 0 for non-driving points
+            const S gtv = dot3(gcmd, c.e);                 // tv_v = tv_w = 0 for non-driving points
             gv_p = tv_v * gtv; gwc_p = tv_w * gtv;
           }
-          gFr = fmaf(gNn, c.FrN, gFr);
-          const float gF0 = gFr * c.csm;
-          const float d1 = dot3(gFr, c.nm1);
-          gn = fmaf(-c.A, gF0, gn);
-          const float gvn = c.dcs * d1;
-          gvp = fmaf(gvn, c.nrm, gvp);
-          gn = fmaf(gvn, c.vp, gn);
-          const float gcw = fmaf(c.Aic, d1, sum_points(c.Acc * d1));
-          const float gdh = fmaf(gcw, c.dcj, c.kcs * d1);
-          const float gzq = -gdh;
+          gFr = mf_fma(gNn, c.FrN, gFr);
+          const S gF0 = gFr * c.csm;
+          const S d1 = dot3(gFr, c.nm1);
+          gn = mf_fma(-c.A, gF0, gn);
+          const S gvn = c.dcs * d1;
+          gvp = mf_fma(gvn, c.nrm, gvp);
+          gn = mf_fma(gvn, c.vp, gn);
+          const S gcw = mf_fma(c.Aic, d1, sum_points(c.Acc * d1));
+          const S gdh = mf_fma(gcw, c.dcj, c.kcs * d1);
+          const S gzq = -gdh;
           // the terrain / friction gradient of the footprint cell: n = u / |u|, u = (-gx, -gy, 1)
-          const float dotn = dot3(gn, c.nrm);
-          const float gg = (gn - dotn * c.nrm) * c.inlr;                // lane 0: ggx, lane 1: ggy
-          const float ggp = dpp<0x51>(gg);                               // quad_perm [1,0,1,1]
-          const float nz = fmaf(gzq, c.wq, cgA * gg + cgB * ggp);
-          const float nm = gmuq * c.wq;
+          const S dotn = dot3(gn, c.nrm);
+          const S gg = (gn - dotn * c.nrm) * c.inlr;                // lane 0: ggx, lane 1: ggy
+          const S ggp = dpp<0x51>(gg);                               // quad_perm [1,0,1,1]
+          const S nz = mf_fma(gzq, c.wq, cgA * gg + cgB * ggp);
+          const S nm = gmuq * c.wq;
           {   // this lane's cell accumulator
             const unsigned ni = (unsigned)c.idx;
             const bool same = !act | (ni == acc_idx);            // absent points contribute exact zeros: never flushed
@@ -960,19 +954,19 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
             acc_z = same ? acc_z + nz : nz;
             acc_m = same ? acc_m + nm : nm;
           }
-          const float vq = gzq * c.zc + gmuq * c.mcv;
-          const float gpx = dot4(vq, c.wsb), gpy = dot4(vq, c.wsa);
-          const float gp = mask_or(mask_or(mask_or(zero, gpx, lane0), gpy, lane1), gdh, lane2);
-          const float gvp1 = dpp<kRot1>(gvp), gvp2 = dpp<kRot2>(gvp);
+          const S vq = gzq * c.zc + gmuq * c.mcv;
+          const S gpx = dot4(vq, c.wsb), gpy = dot4(vq, c.wsa);
+          const S gp = mask_or(mask_or(mask_or(zero, gpx, lane0), gpy, lane1), gdh, lane2);
+          const S gvp1 = dpp<kRot1>(gvp), gvp2 = dpp<kRot2>(gvp);
           gr += gvp1 * c.w2 - gvp2 * c.w1;                       // dr += gvp x w
-          const float gw_p = c.r1 * gvp2 - c.r2 * gvp1;          // dw += r x gvp
-          const float qa = gp + gr;
+          const S gw_p = c.r1 * gvp2 - c.r2 * gvp1;          // dw += r x gvp
+          const S qa = gp + gr;
           lx += gp; lxd += gvp; lw += gw_p;
-          lR0 = fmaf(qa, P0, lR0); lR1 = fmaf(qa, P1, lR1); lR2 = fmaf(qa, P2, lR2);
-          float gv = zero, gwc = zero;
+          lR0 = mf_fma(qa, P0, lR0); lR1 = mf_fma(qa, P1, lR1); lR2 = mf_fma(qa, P2, lR2);
+          S gv = zero, gwc = zero;
           if constexpr (GCTRL) { gv = sum_points(gv_p); gwc = sum_points(gwc_p); }
-          lR0 = fmaf(-dot3(ge_p, c.e), c.eci, fmaf(ge_p, c.il, lR0));      // e = col0(R) / max(|col0|, eps)
-          gctrl_pending = __builtin_amdgcn_readfirstlane((unsigned)n * 8u); gv_pending = gv; gwc_pending = gwc;
+          lR0 = mf_fma(-dot3(ge_p, c.e), c.eci, mf_fma(ge_p, c.il, lR0));      // e = col0(R) / max(|col0|, eps)
+          gctrl_pending = __builtin_amdgcn_readfirstlane((unsigned)n * kC); gv_pending = gv; gwc_pending = gwc;
         };
         auto crunch = [&](int n, const Coef& c, const UpIn& up, Coef& c_next, UpIn& up_next, auto more, auto paired) {
           add_upstream_masked(up);
@@ -1069,23 +1063,23 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
   lR0 = sum_points(lR0); lR1 = sum_points(lR1); lR2 = sum_points(lR2);
 
   // terrain snap of the initial height: x.z = mean_i blend(z; cell((R0 P_i + x0).xy))   (dphysics.py:567-571)
-  float gx0 = lx;
+  S gx0 = lx;
   if (!a.skip_snap) {
-    const float Ra = a.R0[b * 9 + cc * 3 + 0], Rb = a.R0[b * 9 + cc * 3 + 1], Rc = a.R0[b * 9 + cc * 3 + 2];
-    const float x0c = a.x_init[b * 3 + cc];
-    const float g = dpp<kB2>(lx) / (float)a.N;
-    const float pc = (P0 * Ra + P1 * Rb + P2 * Rc) + x0c;
-    const float lim = 262144.0f;
-    const float uq = M::cell_coord(pc, a.d_max, a.res, a.inv_res);
+    const S Ra = a.R0[b * 9 + cc * 3 + 0], Rb = a.R0[b * 9 + cc * 3 + 1], Rc = a.R0[b * 9 + cc * 3 + 2];
+    const S x0c = a.x_init[b * 3 + cc];
+    const S g = dpp<kB2>(lx) / (S)a.N;
+    const S pc = (P0 * Ra + P1 * Rb + P2 * Rc) + x0c;
+    const S lim = S(262144.0);
+    const S uq = M::cell_coord(pc, a.d_max, a.res, a.inv_res);
     const int ui = (int)M::clamp(uq, -lim, lim);
-    const float fr = uq - (float)ui;
+    const S fr = uq - (S)ui;
     const int base = dppi<kB1>(ui) + __mul24(a.H, dppi<kB0>(ui));
     const int idx = min(max(base + cell_off, 0), last);
-    const float wa = fmaf(wa_s, dpp<kB0>(fr), wa_o), wb = fmaf(wb_s, dpp<kB1>(fr), wb_o);
-    const float zc = ld32(zmap, moff + (unsigned)idx);
+    const S wa = mf_fma(wa_s, dpp<kB0>(fr), wa_o), wb = mf_fma(wb_s, dpp<kB1>(fr), wb_o);
+    const S zc = ld32(zmap, moff + (unsigned)idx);
     if (act) atomic_add(at32(gzmap, goff + (unsigned)idx), g * (wa * wb));
-    const float gpx = dot4(zc, wa_s * wb) * g * a.inv_res, gpy = dot4(zc, wb_s * wa) * g * a.inv_res;
-    float gpxy = q == 0 ? gpx : (q == 1 ? gpy : zero);
+    const S gpx = dot4(zc, wa_s * wb) * g * a.inv_res, gpy = dot4(zc, wb_s * wa) * g * a.inv_res;
+    S gpxy = q == 0 ? gpx : (q == 1 ? gpy : zero);
     gpxy = act ? gpxy : zero;
     gx0 = (q < 2 ? lx : zero) + sum_points(gpxy);        // the caller's x0.z is overwritten, so nothing flows to it
     lR0 += sum_points(gpxy * P0); lR1 += sum_points(gpxy * P1); lR2 += sum_points(gpxy * P2);
@@ -1098,8 +1092,8 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<float> a) {
   }
 }
 
-bool use_component_parallel_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p);
-long long cp_record_bytes(const MfRolloutDesc* d);      // bytes of the forward's per-step record for this launch shape (0: none)
+bool use_component_parallel_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, int scalar_bytes = 4);
+long long cp_record_bytes(const MfRolloutDesc* d, int scalar_bytes);      // bytes of the forward's per-step record for this launch shape (0: none)
 bool cp_loss_fusable(const MfRolloutDesc* d);           // both directions of this launch can carry the fused physics loss
 int launch_rollout_bwd_cp_f32(const RolloutBwdArgs<float>& a, int integ, bool xs_only, hipStream_t st);   // a.gcontrols may be NULL
 int launch_rollout_bwd_cp_dynamics_f32(const RolloutBwdArgs<float>& a, bool xs_only, hipStream_t st);      // rollout_bwd_dyn_cp_fast.hip
@@ -1115,18 +1109,33 @@ inline unsigned cp_stream_max_grid(int integ = MF_INTEG_ODEINT_EULER) {
 }
 
 // one launch of the variant (positions-only loss?, control gradient?, late recompute?) the arguments call for
-template <int INTEG>
-int launch_rollout_bwd_cp_variant(const RolloutBwdArgs<float>& a, bool xs_only, hipStream_t st) {
+void launch_rollout_bwd_cp_stream_f64(const RolloutBwdArgs<double>& a, bool xs_only, unsigned grid, hipStream_t st);   // rollout_cp_f64.hip (the validation build)
+int launch_rollout_bwd_cp_f64(const RolloutBwdArgs<double>& a, int integ, bool xs_only, hipStream_t st);
+inline void launch_rollout_bwd_cp_stream_any(const RolloutBwdArgs<float>& a, int integ, bool xs_only, unsigned grid, hipStream_t st) {
+  if (integ == MF_INTEG_ODEINT_EULER) launch_rollout_bwd_cp_stream_f32(a, xs_only, grid, st); else launch_rollout_bwd_cp_stream_dynamics_f32(a, xs_only, grid, st);
+}
+inline void launch_rollout_bwd_cp_stream_any(const RolloutBwdArgs<double>& a, int, bool xs_only, unsigned grid, hipStream_t st) {
+  launch_rollout_bwd_cp_stream_f64(a, xs_only, grid, st);      // (default integrator only: cp_stream_max_grid_of<double>)
+}
+// float64 (validation build): a ring slot is twice the bytes -- six slots of the default integrator's planes fit a CU's LDS (123 / 147 KB,
+// one workgroup per CU), dynamics()' sixteen / eighteen planes do not: its record is read by the computing wave itself (kCpSaved)
+template <typename S>
+inline unsigned cp_stream_max_grid_of(int integ) {
+  if (sizeof(S) == 8) return integ == MF_INTEG_ODEINT_EULER ? cp_stream_max_grid(integ) : 0u;
+  return cp_stream_max_grid(integ);
+}
+template <typename S, int INTEG>
+int launch_rollout_bwd_cp_variant(const RolloutBwdArgs<S>& a, bool xs_only, hipStream_t st) {
   const long long threads = (long long)a.B * 16;
   const unsigned grid = (unsigned)((threads + 63) / 64);
   const bool gc = a.gcontrols != nullptr;
   static const int forced = getenv("MF_CP_BWD_MODE") ? atoi(getenv("MF_CP_BWD_MODE")) : -1;      // A/B (tools/ab_cp.py): 0 early, 1 late, 2 record read by one wave
   // the forward's record when there is one: a second wave per workgroup streams it through LDS (default integrator, while the
   // rings fit the CUs' LDS), else one wave reads it itself; without a record at most one wave per SIMD: late recompute
-  const int saved_mode = grid <= cp_stream_max_grid(INTEG) && forced != kCpSaved ? kCpStream : kCpSaved;
+  const int saved_mode = grid <= cp_stream_max_grid_of<S>(INTEG) && forced != kCpSaved ? kCpStream : kCpSaved;
   const int mode = a.rec ? saved_mode : (forced >= 0 && forced < kCpSaved ? forced : (grid <= 1024u ? kCpLate : kCpEarly));
-#define MF_BCP(XS_, GC_, M_) hipLaunchKernelGGL((rollout_bwd_cp_kernel<INTEG, XS_, GC_, M_>), dim3(grid), dim3(64), 0, st, a)
-#define MF_BCP_L(XS_, GC_) do { if (mode == kCpStream) { if (INTEG == MF_INTEG_ODEINT_EULER) launch_rollout_bwd_cp_stream_f32(a, xs_only, grid, st); else launch_rollout_bwd_cp_stream_dynamics_f32(a, xs_only, grid, st); } else if (mode == kCpSaved) MF_BCP(XS_, GC_, kCpSaved); else if (mode == kCpLate) MF_BCP(XS_, GC_, kCpLate); else MF_BCP(XS_, GC_, kCpEarly); } while (0)
+#define MF_BCP(XS_, GC_, M_) hipLaunchKernelGGL((rollout_bwd_cp_kernel<S, INTEG, XS_, GC_, M_>), dim3(grid), dim3(64), 0, st, a)
+#define MF_BCP_L(XS_, GC_) do { if (mode == kCpStream) launch_rollout_bwd_cp_stream_any(a, INTEG, xs_only, grid, st); else if (mode == kCpSaved) MF_BCP(XS_, GC_, kCpSaved); else if (mode == kCpLate) MF_BCP(XS_, GC_, kCpLate); else MF_BCP(XS_, GC_, kCpEarly); } while (0)
   if (xs_only) { if (gc) MF_BCP_L(true, true); else MF_BCP_L(true, false); }
   else         { if (gc) MF_BCP_L(false, true); else MF_BCP_L(false, false); }
 #undef MF_BCP_L

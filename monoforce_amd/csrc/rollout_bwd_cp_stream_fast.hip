@@ -19,8 +19,8 @@ void launch_rollout_bwd_cp_stream_f32(const RolloutBwdArgs<float>& a, bool xs_on
   constexpr int I = MF_INTEG_ODEINT_EULER;
   const bool gc = a.gcontrols != nullptr;
   static const unsigned big_ring_max = getenv("MF_CP_STREAM_BIG_RING_MAX_GRID") ? (unsigned)atoi(getenv("MF_CP_STREAM_BIG_RING_MAX_GRID")) : 256u;
-#define MF_BCPS(XS_, GC_) do { if (grid <= big_ring_max) hipLaunchKernelGGL((rollout_bwd_cp_kernel<I, XS_, GC_, kCpStream, 12>), dim3(grid), dim3(192), 0, st, a); \
-                               else hipLaunchKernelGGL((rollout_bwd_cp_kernel<I, XS_, GC_, kCpStream, 6>), dim3(grid), dim3(192), 0, st, a); } while (0)
+#define MF_BCPS(XS_, GC_) do { if (grid <= big_ring_max) hipLaunchKernelGGL((rollout_bwd_cp_kernel<float, I, XS_, GC_, kCpStream, 12>), dim3(grid), dim3(192), 0, st, a); \
+                               else hipLaunchKernelGGL((rollout_bwd_cp_kernel<float, I, XS_, GC_, kCpStream, 6>), dim3(grid), dim3(192), 0, st, a); } while (0)
   if (xs_only) { if (gc) MF_BCPS(true, true); else MF_BCPS(true, false); }
   else         { if (gc) MF_BCPS(false, true); else MF_BCPS(false, false); }
 #undef MF_BCPS

@@ -5,7 +5,7 @@
 namespace mf {
 
 int launch_rollout_bwd_cp_dynamics_f32(const RolloutBwdArgs<float>& a, bool xs_only, hipStream_t st) {
-  return launch_rollout_bwd_cp_variant<MF_INTEG_DYNAMICS>(a, xs_only, st);
+  return launch_rollout_bwd_cp_variant<float, MF_INTEG_DYNAMICS>(a, xs_only, st);
 }
 
 }  // namespace mf

@@ -28,6 +28,7 @@
 //  at 1024 x 32.  The loop runs at ~6.6 cycles per instruction of ONE wave per SIMD: its time is its instruction count.)
 #pragma once
 #include "rollout_bwd_kernel.h"
+#include <type_traits>
 
 namespace mf {
 
@@ -35,9 +36,9 @@ namespace mf {
 // and added afterwards takes three)
 #define MF_CROSS_ACC(o0, o1, o2, a, b)                                 \
   do {                                                                 \
-    (o0) = fmaf(-(a)[2], (b)[1], fmaf((a)[1], (b)[2], (o0)));          \
-    (o1) = fmaf(-(a)[0], (b)[2], fmaf((a)[2], (b)[0], (o1)));          \
-    (o2) = fmaf(-(a)[1], (b)[0], fmaf((a)[0], (b)[1], (o2)));          \
+    (o0) = mf_fma(-(a)[2], (b)[1], mf_fma((a)[1], (b)[2], (o0)));          \
+    (o1) = mf_fma(-(a)[0], (b)[2], mf_fma((a)[2], (b)[0], (o1)));          \
+    (o2) = mf_fma(-(a)[1], (b)[0], mf_fma((a)[0], (b)[1], (o2)));          \
   } while (0)
 
 constexpr int kMwRecFloats = 4;   // per rollout-step: (sum of contact weights, omega_d before its clamp [3])
@@ -56,17 +57,19 @@ constexpr int kMwRecFloats = 4;   // per rollout-step: (sum of contact weights, 
 // INTEG: the default integrator (torchdiffeq fixed-grid euler, dphysics.py:499-528) keeps ONE exchange per step; dynamics()
 // (semi-implicit Euler + Rodrigues, :467-497, :274-324) reads the totals of the velocity adjoints AFTER its own step's rotation
 // update has been pushed through the partials, so it takes a second, six-value exchange in the middle of the step.
-template <int G, bool XS_ONLY, int TILE, int INTEG = MF_INTEG_ODEINT_EULER>
-__global__ void __launch_bounds__(G > 64 ? G : 64) rollout_bwd_mw_kernel(const RolloutBwdArgs<float> a) {
-  using S = float;
-  using M = Mth<float, true>;
+// S: float (fast math: the kernels of the reference's own operating point) or double (the VALIDATION build of the same source, exact
+// arithmetic: csrc/rollout_mw_f64.hip)
+template <typename S, int G, bool XS_ONLY, int TILE, int INTEG = MF_INTEG_ODEINT_EULER>
+__global__ void __launch_bounds__(G > 64 ? G : 64) rollout_bwd_mw_kernel(const RolloutBwdArgs<S> a) {
+  constexpr bool kFast = std::is_same<S, float>::value;
+  using M = Mth<S, kFast>;
   constexpr int NW = G > 64 ? G / 64 : 1;
   // G > 64: one rollout per workgroup of G / 64 waves.  G <= 64: 64 / G rollouts per one-wave workgroup, the exchange is a DPP sum
   const int tid = blockIdx.x * (G > 64 ? G : 64) + threadIdx.x;
   const int b = tid / G;
   const int gl = tid % G;          // one contact point per lane
   if (b >= a.B) return;            // whole groups leave together (G <= 64 only: no barrier in those kernels)
-  const S one = 1.0f, zero = 0.0f;
+  const S one = (S)1, zero = (S)0;
   const int HW = a.H * a.W, last = HW - 1;
   __shared__ S gs_lds[G > 64 ? 2 * NW * kGroupSumMaxValues : 1];
   constexpr int NT = G > 64 ? 1 : 64 / G;                       // rollouts = tiles per workgroup
@@ -236,8 +239,8 @@ __global__ void __launch_bounds__(G > 64 ? G : 64) rollout_bwd_mw_kernel(const R
   // The exchange itself.  Within a wave (G <= 64): nine DPP group sums.  Over several waves: TransposedExchange (mf_common.h) --
   // about half the instructions of nine plain workgroup sums (the loop: 762 -> 632 instructions per step at G = 256).
   // (a whole-wave group, G = 64, takes it too: 26 DPP adds and one LDS round trip instead of 54 DPP adds and nine readlanes)
-  __shared__ __attribute__((aligned(16))) S xch_lds[G >= 64 ? TransposedExchange<NW>::kWords : 4];
-  TransposedExchange<NW> xch;
+  __shared__ __attribute__((aligned(4 * sizeof(S)))) S xch_lds[G >= 64 ? TransposedExchange<NW, S>::kWords : 4];
+  TransposedExchange<NW, S> xch;
   xch.lds = xch_lds;
   auto post9 = [&](S (&v)[9]) {
     if constexpr (G < 64) {
@@ -268,7 +271,7 @@ __global__ void __launch_bounds__(G > 64 ? G : 64) rollout_bwd_mw_kernel(const R
     const S py = P[0] * R[3] + P[1] * R[4] + P[2] * R[5] + x[1];
     const S pz = P[0] * R[6] + P[1] * R[7] + P[2] * R[8] + x[2];
     const S r[3] = {px - x[0], py - x[1], pz - x[2]};
-    const Cell<S> cell = locate_m<S, true>(px, py, a.d_max, a.res, a.inv_res, a.H, last);
+    const Cell<S> cell = locate_m<S, kFast>(px, py, a.d_max, a.res, a.inv_res, a.H, last);
     // (ix, iy) of the footprint's first cell: locate_m's own arithmetic (trunc(u) == u - fraction exactly)
     const int ix = (int)(M::cell_coord(px, a.d_max, a.res, a.inv_res) - cell.fx), iy = (int)(M::cell_coord(py, a.d_max, a.res, a.inv_res) - cell.fy);
     S zc[4], mc[4];
@@ -624,7 +627,7 @@ __global__ void __launch_bounds__(G > 64 ? G : 64) rollout_bwd_mw_kernel(const R
     if (act) {
       const S px = P[0] * R0[0] + P[1] * R0[1] + P[2] * R0[2] + x0[0];
       const S py = P[0] * R0[3] + P[1] * R0[4] + P[2] * R0[5] + x0[1];
-      const Cell<S> c = locate_m<S, true>(px, py, a.d_max, a.res, a.inv_res, a.H, last);
+      const Cell<S> c = locate_m<S, kFast>(px, py, a.d_max, a.res, a.inv_res, a.H, last);
       const S v0 = ld32(zmap, moff + (unsigned)c.ic), v1 = ld32(zmap, moff + (unsigned)c.i_f), v2 = ld32(zmap, moff + (unsigned)c.il), v3 = ld32(zmap, moff + (unsigned)c.ifl);
       atomic_add(at32(gzmap, goff + (unsigned)c.ic), g * (one - c.fx) * (one - c.fy));
       atomic_add(at32(gzmap, goff + (unsigned)c.i_f), g * (one - c.fx) * c.fy);
@@ -658,10 +661,48 @@ __global__ void __launch_bounds__(G > 64 ? G : 64) rollout_bwd_mw_kernel(const R
 
 // defined in rollout_bwd_mw_fast.hip
 bool use_multiwave_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p);   // this backward goes to the kernels above
-long long mw_record_bytes(const MfRolloutDesc* d);                           // bytes of the record the forward keeps for them (0: none)
+long long mw_record_bytes(const MfRolloutDesc* d, int scalar_bytes = 4);      // bytes of the record the forward keeps for them (0: none)
 int launch_rollout_bwd_mw_f32(const RolloutBwdArgs<float>& a, int G, int integ, bool xs_only, hipStream_t st);
+int launch_rollout_bwd_mw_f64(const RolloutBwdArgs<double>& a, int G, int integ, bool xs_only, hipStream_t st);      // rollout_mw_f64.hip
 // cells per side of a rollout's LDS gradient tile; 0 = none.  Measured (B = 64 x N = 223: 1.094 -> 1.038 ms; 256 x 64: 0.861 -> 0.845;
 // 1024 x 32: 0.971 -> 0.967; 256 x 16: 0.692 -> 0.883 -- four tiles per wave collide in the LDS): whole-wave groups only
 constexpr int mw_tile_edge(int G) { return G >= 64 ? 64 : 0; }
+
+// one launch of the instantiation the arguments call for (S = float: rollout_bwd_mw_fast.hip; S = double: rollout_mw_f64.hip)
+template <typename S>
+int launch_rollout_bwd_mw_t(const RolloutBwdArgs<S>& a, int G, int integ, bool xs_only, hipStream_t st) {
+  // LDS gradient tiles (rollout_bwd_mw_kernel.h) while every workgroup of the launch is resident with its tiles: 160 KB per CU,
+  // 256 CUs.  MF_MW_TILE=0 keeps the register accumulators (A/B runs, parity of the two routes).
+  static const bool tile_off = getenv("MF_MW_TILE") && atoi(getenv("MF_MW_TILE")) == 0;
+  bool launched = false;
+#define MF_LAUNCH(G_, XS_, T_, I_) hipLaunchKernelGGL((rollout_bwd_mw_kernel<S, G_, XS_, T_, I_>), dim3(grid), dim3(blk), 0, st, a)
+#define MF_CASE(G_)                                                                                              \
+  if (!launched && G == G_) {                                                                                    \
+    launched = true;                                                                                             \
+    constexpr int blk = G_ > 64 ? G_ : 64;                                                                       \
+    constexpr int TE = mw_tile_edge(G_);                                                                         \
+    constexpr long long lds = (long long)(G_ > 64 ? 1 : 64 / G_) * 2 * (TE + 1) * TE * (long long)sizeof(S) + 4096;                       \
+    const unsigned grid = (unsigned)(((long long)a.B * G_ + blk - 1) / blk);                                     \
+    const bool tile = TE > 0 && !tile_off && (long long)((grid + 255) / 256) * lds <= 160 * 1024 && (long long)a.H * a.W < (1ll << 30); \
+    const bool dyn = integ == MF_INTEG_DYNAMICS;                                                                 \
+    if (tile) {                                                                                                  \
+      if constexpr (TE > 0) {                                                                                    \
+        if (dyn) { if (xs_only) MF_LAUNCH(G_, true, TE, MF_INTEG_DYNAMICS); else MF_LAUNCH(G_, false, TE, MF_INTEG_DYNAMICS); }          \
+        else     { if (xs_only) MF_LAUNCH(G_, true, TE, MF_INTEG_ODEINT_EULER); else MF_LAUNCH(G_, false, TE, MF_INTEG_ODEINT_EULER); }  \
+      }                                                                                                          \
+    } else {                                                                                                     \
+      if (dyn) { if (xs_only) MF_LAUNCH(G_, true, 0, MF_INTEG_DYNAMICS); else MF_LAUNCH(G_, false, 0, MF_INTEG_DYNAMICS); }              \
+      else     { if (xs_only) MF_LAUNCH(G_, true, 0, MF_INTEG_ODEINT_EULER); else MF_LAUNCH(G_, false, 0, MF_INTEG_ODEINT_EULER); }      \
+    }                                                                                                            \
+  }
+  MF_CASE(8) MF_CASE(16) MF_CASE(32) MF_CASE(64) MF_CASE(128) MF_CASE(256) MF_CASE(512)
+#undef MF_CASE
+#undef MF_LAUNCH
+  MF_REQUIRE(launched, MF_ERR_UNSUPPORTED, "rollout_bwd: no multi-wave kernel for this lane mapping");
+  hipError_t e = hipGetLastError();
+  MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("rollout_bwd (multi-wave) launch: ") + hipGetErrorString(e));
+  return MF_OK;
+}
+
 
 }  // namespace mf

@@ -1,8 +1,11 @@
 // Forward rollout: host side of mf_rollout_fwd_* and the reference-order (exact) kernel instantiations.
 // This TU is compiled with -ffp-contract=off; the FMA-contracted float32 kernels live in rollout_fwd_fast.hip.
-#include "rollout_fwd_cp2_kernel.h"
+#include "rollout_fwd_cp_kernel.h"
 
-namespace mf { long long mw_record_bytes(const MfRolloutDesc* d); }   // rollout_bwd_mw_fast.hip
+namespace mf {
+long long mw_record_bytes(const MfRolloutDesc* d, int scalar_bytes);   // rollout_bwd_mw_fast.hip
+int launch_rollout_fwd_mw_rec_f64(const RolloutArgs<double>& a, LaneMap m, int integ, bool forces, hipStream_t st);   // rollout_mw_f64.hip
+}
 
 namespace mf {
 
@@ -80,27 +83,61 @@ extern "C" int mf_rollout_force_stride(const MfRolloutDesc* d) {
 
 namespace mf {
 // (z, mu) of the shared maps interleaved for the ZMU kernels; without a friction map the second component is never used
-__global__ void __launch_bounds__(256) interleave_maps_kernel(const float* __restrict__ z, const float* __restrict__ mu, int n,
-                                                             float2* __restrict__ out) {
+template <typename S>
+__global__ void __launch_bounds__(256) interleave_maps_kernel(const S* __restrict__ z, const S* __restrict__ mu, int n,
+                                                             cp::Pk2<S>* __restrict__ out) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = make_float2(z[i], mu ? mu[i] : 1.0f);
+  if (i < n) out[i] = cp::Pk2<S>{z[i], mu ? mu[i] : (S)1};
 }
 // true (and a.zmu set, the interleave pass launched) when this launch can read the interleaved copy
-static bool use_interleaved_maps(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutArgs<float>* a, const LaneMap& m, hipStream_t st) {
+template <typename S>
+static bool use_interleaved_maps(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutArgs<S>* a, const LaneMap& m, hipStream_t st) {
   if ((!p->zmu_scratch && !p->zmu) || !d->map_shared || d->math_mode != MF_MATH_FAST || p->joint_angles || m.PPL != 1 || m.G > 64) return false;
-  if ((long long)d->H * d->W >= (1ll << 29)) return false;   // 32-bit byte offsets into the 8-byte cells
+  if ((long long)d->H * d->W * (long long)sizeof(S) >= (1ll << 31)) return false;   // 32-bit byte offsets into the (z, mu) cells
   if (p->zmu && p->mu) {   // the caller staged the interleaved pair itself (mf_terrain_stage_fwd_f32): no pass, no batch-size condition
-    a->zmu = (const float*)p->zmu;
+    a->zmu = (const S*)p->zmu;
     return true;
   }
   if (!p->zmu_scratch) return false;
   // Below ~half a wave per SIMD the launch is bound by the instruction stream of its waves; the extra pass (a second launch in
   // front of the rollout, ~10 us) then costs what the two saved gathers bring (measured: B = 1024 path costs 0.306 -> 0.323 ms)
-  if ((long long)d->B * m.G < 512ll * 64) return false;
+  // (the float64 validation build takes the pass whenever it is offered: its purpose is to run the ZMU kernels)
+  if (sizeof(S) == 4 && (long long)d->B * m.G < 512ll * 64) return false;
   const int n = d->H * d->W;
-  hipLaunchKernelGGL(interleave_maps_kernel, dim3((n + 255) / 256), dim3(256), 0, st, a->z, a->mu, n, (float2*)p->zmu_scratch);
-  a->zmu = (const float*)p->zmu_scratch;
+  hipLaunchKernelGGL((interleave_maps_kernel<S>), dim3((n + 255) / 256), dim3(256), 0, st, a->z, a->mu, n, (cp::Pk2<S>*)p->zmu_scratch);
+  a->zmu = (const S*)p->zmu_scratch;
   return true;
+}
+
+inline int launch_rollout_fwd_cp_any(const RolloutArgs<float>& a, int integ, bool forces, bool zmu, hipStream_t st) { return launch_rollout_fwd_cp_f32(a, integ, forces, zmu, st); }
+inline int launch_rollout_fwd_cp_any(const RolloutArgs<double>& a, int integ, bool forces, bool zmu, hipStream_t st) { return launch_rollout_fwd_cp_f64(a, integ, forces, zmu, st); }
+
+// The component-parallel launch (a rollout over a 16-lane row, rollout_fwd_cp_kernel.h) with everything that rides on it: the
+// interleaved maps, the per-step record for the backward, the fused physics loss.  S = float: the kernels the dispatcher picks for
+// few rollouts of a small body; S = double: their validation build, on explicit request (points_per_lane = MF_LANES_COMPONENT).
+template <typename S>
+static int rollout_fwd_cp(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutArgs<S>& a, hipStream_t st) {
+  const bool forces = p->Fs != nullptr;
+  const bool zmu = use_interleaved_maps<S>(d, p, &a, LaneMap{16, 1}, st);
+  if (p->rec && cp_record_bytes(d, (int)sizeof(S)) > 0) {      // the per-step record for the backward (MfRolloutFwdBufs.rec)
+    MF_REQUIRE(((uintptr_t)p->rec & 15) == 0, MF_ERR_INVALID, "rollout_fwd: rec must be 16-byte aligned");
+    a.rec = (S*)p->rec;
+  }
+  if (p->loss && (p->loss->flags & MF_LOSS_VALUE_IN_BACKWARD)) {      // the backward will form the value: mark it as not yet known
+    MF_REQUIRE(cp_loss_fusable(d), MF_ERR_UNSUPPORTED, "rollout_fwd: this launch cannot carry the fused physics loss (mf_rollout_loss_fusable)");
+    MF_REQUIRE(p->loss->loss, MF_ERR_INVALID, "rollout_fwd: MF_LOSS_VALUE_IN_BACKWARD needs MfRolloutLoss.loss");
+    a.loss_poison = (S*)p->loss->loss;
+  } else if (p->loss) {      // physics_loss inside the launch (MfRolloutLoss)
+    const MfRolloutLoss* L = p->loss;
+    MF_REQUIRE(cp_loss_fusable(d), MF_ERR_UNSUPPORTED, "rollout_fwd: this launch cannot carry the fused physics loss (mf_rollout_loss_fusable)");
+    MF_REQUIRE(!forces && d->layout == MF_LAYOUT_TIME_MAJOR, MF_ERR_INVALID, "rollout_fwd: the fused physics loss needs Fs = Ff = NULL and MF_LAYOUT_TIME_MAJOR");
+    MF_REQUIRE(L->T2 > 0 && L->gt && L->row_w && L->partial && L->ticket && L->loss, MF_ERR_INVALID, "rollout_fwd: incomplete MfRolloutLoss");
+    MF_REQUIRE((long long)d->B * L->T2 * 3 * (long long)sizeof(S) < (1ll << 32), MF_ERR_UNSUPPORTED, "rollout_fwd: ground truth of 4 GiB or more");
+    a.loss_T2 = L->T2; a.loss_gt = (const S*)L->gt; a.loss_row_w = (const S*)L->row_w;
+    a.loss_partial = (S*)L->partial; a.loss_ticket = L->ticket; a.loss_out = (S*)L->loss;
+    a.loss_inv_count = (S)(1.0 / ((double)d->B * L->T2 * 3));
+  }
+  return launch_rollout_fwd_cp_any(a, d->integrator, forces, zmu, st);
 }
 }  // namespace mf
 
@@ -122,7 +159,7 @@ extern "C" int mf_rollout_fwd_f32(const MfRolloutDesc* d, const MfRolloutFwdBufs
     MF_REQUIRE(!p->Xds && !p->Omegas && !p->Fs && !p->Ff && !p->Xraw, MF_ERR_INVALID,
                "rollout_fwd: with cost_rows only Xs and Rs (decimated) are written -- pass NULL for Xds, Omegas, Fs, Ff, Xraw");
     if (m.PPL == 4 && m.G < 64) m = mf::choose_lane_map(d->B, d->N, 1);
-    if (mf::use_interleaved_maps(d, p, &a, m, (hipStream_t)s))
+    if (mf::use_interleaved_maps<float>(d, p, &a, m, (hipStream_t)s))
       return mf::launch_rollout_fwd_zmu_f32(a, m, d->integrator, block, false, false, d->cost_project != 0 ? 2 : 1, (hipStream_t)s);
     return mf::launch_rollout_fwd_cost_f32(a, m, d->integrator, block, d->cost_project != 0, (hipStream_t)s);
   }
@@ -132,40 +169,17 @@ extern "C" int mf_rollout_fwd_f32(const MfRolloutDesc* d, const MfRolloutFwdBufs
     return MF_ERR_UNSUPPORTED;
   }
   if (d->math_mode == MF_MATH_FAST) {
-    if (mf::use_component_parallel(d, p)) {   // few rollouts of a small body: a rollout over 16 lanes (rollout_fwd_cp_kernel.h)
-      const bool zmu = mf::use_interleaved_maps(d, p, &a, mf::LaneMap{16, 1}, (hipStream_t)s);
-      if (p->rec && mf::cp_record_bytes(d) > 0) {      // the per-step record for the backward (MfRolloutFwdBufs.rec)
-        MF_REQUIRE(((uintptr_t)p->rec & 15) == 0, MF_ERR_INVALID, "rollout_fwd: rec must be 16-byte aligned");
-        a.rec = (float*)p->rec;
-      }
-      if (p->loss && (p->loss->flags & MF_LOSS_VALUE_IN_BACKWARD)) {      // the backward will form the value: mark it as not yet known
-        MF_REQUIRE(mf::cp_loss_fusable(d), MF_ERR_UNSUPPORTED, "rollout_fwd: this launch cannot carry the fused physics loss (mf_rollout_loss_fusable)");
-        MF_REQUIRE(p->loss->loss, MF_ERR_INVALID, "rollout_fwd: MF_LOSS_VALUE_IN_BACKWARD needs MfRolloutLoss.loss");
-        a.loss_poison = (float*)p->loss->loss;
-      } else if (p->loss) {      // physics_loss inside the launch (MfRolloutLoss)
-        const MfRolloutLoss* L = p->loss;
-        MF_REQUIRE(mf::cp_loss_fusable(d), MF_ERR_UNSUPPORTED, "rollout_fwd: this launch cannot carry the fused physics loss (mf_rollout_loss_fusable)");
-        MF_REQUIRE(!forces && d->layout == MF_LAYOUT_TIME_MAJOR, MF_ERR_INVALID, "rollout_fwd: the fused physics loss needs Fs = Ff = NULL and MF_LAYOUT_TIME_MAJOR");
-        MF_REQUIRE(L->T2 > 0 && L->gt && L->row_w && L->partial && L->ticket && L->loss, MF_ERR_INVALID, "rollout_fwd: incomplete MfRolloutLoss");
-        MF_REQUIRE((long long)d->B * L->T2 * 3 * 4 < (1ll << 32), MF_ERR_UNSUPPORTED, "rollout_fwd: ground truth of 4 GiB or more");
-        a.loss_T2 = L->T2; a.loss_gt = (const float*)L->gt; a.loss_row_w = (const float*)L->row_w;
-        a.loss_partial = (float*)L->partial; a.loss_ticket = L->ticket; a.loss_out = (float*)L->loss;
-        a.loss_inv_count = (float)(1.0 / ((double)d->B * L->T2 * 3));
-      }
-#ifdef MF_EXPERIMENTS
-      if (!p->loss && mf::use_two_wave_forward(d)) return mf::launch_rollout_fwd_cp2_f32(a, forces, zmu, (hipStream_t)s);
-#endif
-      return mf::launch_rollout_fwd_cp_f32(a, d->integrator, forces, zmu, (hipStream_t)s);
-    }
+    if (mf::use_component_parallel(d, p))   // few rollouts of a small body: a rollout over 16 lanes (rollout_fwd_cp_kernel.h)
+      return mf::rollout_fwd_cp<float>(d, p, a, (hipStream_t)s);
     MF_REQUIRE(!p->loss, MF_ERR_UNSUPPORTED, "rollout_fwd: this launch cannot carry the fused physics loss (mf_rollout_loss_fusable)");
     if (!forces && m.PPL == 4 && m.G < 64) m = mf::choose_lane_map(d->B, d->N, 1);
     // >= one wave per SIMD (1024) and a one-point-per-lane mapping within a wave: the split-store kernels (rollout_fwd_kernel.h)
     const bool split = m.PPL == 1 && m.G <= 64 && (long long)d->B * m.G >= 1024ll * 64;
-    if (p->rec && mf::mw_record_bytes(d) > 0) {      // the 16-byte record of rollout_bwd_mw_kernel.h
+    if (p->rec && mf::mw_record_bytes(d, 4) > 0) {      // the 16-byte record of rollout_bwd_mw_kernel.h
       MF_REQUIRE(((uintptr_t)p->rec & 15) == 0, MF_ERR_INVALID, "rollout_fwd: rec must be 16-byte aligned");
       a.rec = (float*)p->rec;
     }
-    if (mf::use_interleaved_maps(d, p, &a, m, (hipStream_t)s))
+    if (mf::use_interleaved_maps<float>(d, p, &a, m, (hipStream_t)s))
       return mf::launch_rollout_fwd_zmu_f32(a, m, d->integrator, block, forces, split, 0, (hipStream_t)s);
     if (split)
       return mf::launch_rollout_fwd_split_fast_f32(a, m, d->integrator, block, forces, (hipStream_t)s);
@@ -181,9 +195,21 @@ extern "C" int mf_rollout_fwd_f64(const MfRolloutDesc* d, const MfRolloutFwdBufs
   int block;
   int rc = mf::fill_args<double>(d, p, &a, &m, &block);
   if (rc != MF_OK) return rc;
-  if (!p->Fs) { mf::set_error("rollout_fwd: float64 needs the force buffers"); return MF_ERR_UNSUPPORTED; }
+  // the float64 VALIDATION build of the component-parallel kernels (rollout_fwd_cp_f64.hip): on explicit request only
+  if (d->points_per_lane == MF_LANES_COMPONENT && mf::use_component_parallel(d, p, 8)) {
+    MF_REQUIRE((((uintptr_t)p->zmu_scratch | (uintptr_t)p->zmu) & 15) == 0, MF_ERR_INVALID, "rollout_fwd: zmu_scratch / zmu must be 16-byte aligned");
+    return mf::rollout_fwd_cp<double>(d, p, a, (hipStream_t)s);
+  }
+  // ... and of the recording one-point-per-lane kernels of 5..512-point bodies (rollout_fwd_kernel.h FAST / REC, whose backward is
+  // rollout_bwd_mw_kernel.h): same request, with the record buffer
+  if (d->points_per_lane == MF_LANES_COMPONENT && p->rec && !p->joint_angles && !p->cost_rows && !p->loss && mf::mw_record_bytes(d, 8) > 0) {
+    MF_REQUIRE(((uintptr_t)p->rec & 31) == 0, MF_ERR_INVALID, "rollout_fwd: rec must be 32-byte aligned");
+    a.rec = (double*)p->rec;
+    return mf::launch_rollout_fwd_mw_rec_f64(a, m, d->integrator, p->Fs != nullptr, (hipStream_t)s);
+  }
+  if (!p->Fs) { mf::set_error("rollout_fwd: float64 needs the force buffers (states only: the component-parallel validation build, points_per_lane = MF_LANES_COMPONENT)"); return MF_ERR_UNSUPPORTED; }
   if (p->cost_rows) { mf::set_error("rollout_fwd: cost rows exist for float32 only"); return MF_ERR_UNSUPPORTED; }
-  if (p->loss) { mf::set_error("rollout_fwd: the fused physics loss exists for the float32 fast-math kernels only"); return MF_ERR_UNSUPPORTED; }
+  if (p->loss) { mf::set_error("rollout_fwd: the fused physics loss exists for the component-parallel kernels only"); return MF_ERR_UNSUPPORTED; }
   if (p->joint_angles) return mf::launch_rollout_fwd<double, false, true>(a, m, d->integrator, block, (hipStream_t)s);
   return mf::launch_rollout_fwd<double, false>(a, m, d->integrator, block, (hipStream_t)s);   // float64 is always exact
 }

@@ -14,7 +14,7 @@ static long long cp_max_waves() {
   return v;
 }
 
-bool use_component_parallel(const MfRolloutDesc* d, const MfRolloutFwdBufs* p) {
+bool use_component_parallel(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, int scalar_bytes) {
   if (d->math_mode != MF_MATH_FAST || d->N > 4 || p->joint_angles || p->cost_rows) return false;
   if (d->points_per_lane != 0 && d->points_per_lane != MF_LANES_COMPONENT) return false;   // an explicit other mapping
   const long long waves = ((long long)d->B + 3) / 4;
@@ -22,39 +22,13 @@ bool use_component_parallel(const MfRolloutDesc* d, const MfRolloutFwdBufs* p) {
   // 32-bit byte offsets into every output and into the controls
   const long long fs = d->force_stride ? d->force_stride : d->N;
   const long long row = fs * 3 > 9 ? fs * 3 : 9;
-  if ((long long)d->T * d->B * row * 4 >= (1ll << 32)) return false;
+  if ((long long)d->T * d->B * row * scalar_bytes >= (1ll << 32)) return false;
   if (fs < 4) return false;   // quads of absent points write their (zero) slots
   return true;
 }
 
 int launch_rollout_fwd_cp_f32(const RolloutArgs<float>& a, int integ, bool forces, bool zmu, hipStream_t st) {
-  const int block = 64;   // one wave = 4 rollouts per workgroup: B = 1024 puts one wave on each of the 256 CUs
-  const long long threads = (long long)a.B * 16;
-  const unsigned grid = (unsigned)((threads + block - 1) / block);
-  const bool rec = a.rec != nullptr;
-  if (a.loss_gt) {      // fused physics loss: default integrator, states only (the host checked)
-    constexpr int I = MF_INTEG_ODEINT_EULER;
-    if (rec) { if (zmu) hipLaunchKernelGGL((rollout_fwd_cp_kernel<I, false, true, true, true>), dim3(grid), dim3(block), 0, st, a);
-               else hipLaunchKernelGGL((rollout_fwd_cp_kernel<I, false, false, true, true>), dim3(grid), dim3(block), 0, st, a); }
-    else     { if (zmu) hipLaunchKernelGGL((rollout_fwd_cp_kernel<I, false, true, false, true>), dim3(grid), dim3(block), 0, st, a);
-               else hipLaunchKernelGGL((rollout_fwd_cp_kernel<I, false, false, false, true>), dim3(grid), dim3(block), 0, st, a); }
-    hipError_t e = hipGetLastError();
-    MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("rollout_fwd (component-parallel, fused loss) launch: ") + hipGetErrorString(e));
-    return MF_OK;
-  }
-#define MF_CP(INTEG_, FORCES_, ZMU_) do { if (rec) hipLaunchKernelGGL((rollout_fwd_cp_kernel<INTEG_, FORCES_, ZMU_, true>), dim3(grid), dim3(block), 0, st, a); \
-                                          else hipLaunchKernelGGL((rollout_fwd_cp_kernel<INTEG_, FORCES_, ZMU_, false>), dim3(grid), dim3(block), 0, st, a); } while (0)
-#define MF_CP_F(INTEG_)                                          \
-  do {                                                           \
-    if (forces) { if (zmu) MF_CP(INTEG_, true, true); else MF_CP(INTEG_, true, false); }    \
-    else        { if (zmu) MF_CP(INTEG_, false, true); else MF_CP(INTEG_, false, false); }  \
-  } while (0)
-  if (integ == MF_INTEG_DYNAMICS) MF_CP_F(MF_INTEG_DYNAMICS); else MF_CP_F(MF_INTEG_ODEINT_EULER);
-#undef MF_CP_F
-#undef MF_CP
-  hipError_t e = hipGetLastError();
-  MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("rollout_fwd (component-parallel) launch: ") + hipGetErrorString(e));
-  return MF_OK;
+  return launch_rollout_fwd_cp_t<float>(a, integ, forces, zmu, st);
 }
 
 }  // namespace mf

@@ -710,8 +710,8 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
     };
     S csum_cur = zero;      // contact count of the step about to run (total over the workgroup)
     static_assert(kWr == 6, "the pipelined step exchanges the fast-math wrench (6) and one contact count");
-    __shared__ __attribute__((aligned(16))) float xch_lds[G > 64 ? TransposedExchange<(G > 64 ? G / 64 : 1)>::kWords : 4];
-    TransposedExchange<(G > 64 ? G / 64 : 1)> xch;
+    __shared__ __attribute__((aligned(4 * sizeof(S)))) S xch_lds[G > 64 ? TransposedExchange<(G > 64 ? G / 64 : 1), S>::kWords : 4];
+    TransposedExchange<(G > 64 ? G / 64 : 1), S> xch;
     xch.lds = xch_lds;
     auto pipe_step = [&](int n, Geo& g, Hgt& hq, Geo& g_next, Hgt& hq_next) {
       // next step's controls and step size: requested before this step's stores (vmcnt retires in order)
@@ -743,12 +743,12 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
       ex[kWr] = hq_next.cj;
       // wrench of step n + contact count of step n + 1: one transposed workgroup exchange (mf_common.h)
       if constexpr (G > 64) {
-        const float v8[8] = {(float)ex[0], (float)ex[1], (float)ex[2], (float)ex[3], (float)ex[4], (float)ex[5], (float)ex[6], 0.0f};
-        xch.post(v8, 0.0f);
-        float tot[7];
+        const S v8[8] = {ex[0], ex[1], ex[2], ex[3], ex[4], ex[5], ex[6], zero};
+        xch.post(v8, zero);
+        S tot[7];
         xch.template wait<7>(tot);
   #pragma unroll
-        for (int c = 0; c < 7; ++c) ex[c] = (S)tot[c];
+        for (int c = 0; c < 7; ++c) ex[c] = tot[c];
       } else {      // a rollout inside a wave: seven DPP group sums
         gs.template sum_n<kWr + 1>(ex);
       }
@@ -760,7 +760,7 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
         // the multi-wave backward's record (rollout_bwd_mw_kernel.h): the contact count and the unclamped angular acceleration
         // this step evaluated, 16 bytes per rollout-step; every lane stores the same quad to the same address (no branch: the
         // arithmetic of the step stays one basic block, so the trajectory's bits are those of the kernel without a record)
-        typedef float f4v __attribute__((ext_vector_type(4)));
+        typedef S f4v __attribute__((ext_vector_type(4)));
         const f4v rv = {csum_cur, wraw[0], wraw[1], wraw[2]};
         __builtin_nontemporal_store(rv, reinterpret_cast<f4v*>(a.rec + ((size_t)n * a.B + b) * 4));
       }
@@ -783,8 +783,8 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
     for (; n + 1 < n_steps; n += 2) { pipe_step(n, gA, hA, gB, hB); pipe_step(n + 1, gB, hB, gA, hA); }
     if (n < n_steps) pipe_step(n, gA, hA, gB, hB);
   } else {
-  __shared__ __attribute__((aligned(16))) float xg_lds[(FAST && G > 64) ? TransposedExchange<(G > 64 ? G / 64 : 1)>::kWords : 4];
-  TransposedExchange<(G > 64 ? G / 64 : 1)> xch_g;
+  __shared__ __attribute__((aligned(4 * sizeof(S)))) S xg_lds[(FAST && G > 64) ? TransposedExchange<(G > 64 ? G / 64 : 1), S>::kWords : 4];
+  TransposedExchange<(G > 64 ? G / 64 : 1), S> xch_g;
   xch_g.lds = xg_lds;
   for (int n = 0; n < n_steps; ++n) {
     if (JOINTS) articulate_body<S, G, PPL, FAST>(gs, a.joint_angles + ((size_t)b * a.T + n) * 4, a.joint_xyz, a.mass / (S)a.N, P0, part, act, P, Iv);
@@ -924,12 +924,12 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
     if (FAST) {   // one batched reduction of the wrench (multi-wave groups: one LDS exchange)
       S wr[6] = {sFr[0], sFr[1], sFr[2], sTau[0], sTau[1], sTau[2]};
       if constexpr (FAST && G > 64) {      // ... the transposed one (mf_common.h): about half the instructions of six plain workgroup sums
-        const float v8[8] = {(float)wr[0], (float)wr[1], (float)wr[2], (float)wr[3], (float)wr[4], (float)wr[5], 0.0f, 0.0f};
-        xch_g.post(v8, 0.0f);
-        float tot[6];
+        const S v8[8] = {wr[0], wr[1], wr[2], wr[3], wr[4], wr[5], zero, zero};
+        xch_g.post(v8, zero);
+        S tot[6];
         xch_g.template wait<6>(tot);
 #pragma unroll
-        for (int c = 0; c < 6; ++c) wr[c] = (S)tot[c];
+        for (int c = 0; c < 6; ++c) wr[c] = tot[c];
       } else {
         gs.sum_n(wr);
       }
@@ -949,7 +949,7 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_fwd_kernel(const Ro
       wd[c] = M::clamp(wraw[c], -a.omega_max, a.omega_max);
     }
     if constexpr (REC) {   // the record of rollout_bwd_mw_kernel.h: every lane of the group stores the same quad (no branch)
-      typedef float f4v __attribute__((ext_vector_type(4)));
+      typedef S f4v __attribute__((ext_vector_type(4)));
       const f4v rv = {csum, wraw[0], wraw[1], wraw[2]};
       __builtin_nontemporal_store(rv, reinterpret_cast<f4v*>(a.rec + ((size_t)n * a.B + b) * 4));
     }
@@ -1099,8 +1099,8 @@ int launch_rollout_fwd(const RolloutArgs<S>& a, LaneMap m, int integ, int block,
 
 // The one-point-per-lane mappings (both integrators) with the record for their backward (rollout_bwd_mw_kernel.h):
 // a.rec != NULL.  Bodies of 5..64 points (several rollouts per wave; plain or interleaved maps) and of 65..512 (one per workgroup).
-template <bool FORCES, bool ZMU = false, bool SPLIT = false>
-int launch_rollout_fwd_mw_rec(const RolloutArgs<float>& a, LaneMap m, int integ, hipStream_t st) {
+template <bool FORCES, bool ZMU = false, bool SPLIT = false, typename S = float>
+int launch_rollout_fwd_mw_rec(const RolloutArgs<S>& a, LaneMap m, int integ, hipStream_t st) {
   bool launched = false;
 #define MF_CASE(G_)                                                                                                          \
   if (!launched && m.G == G_ && m.PPL == 1) {                                                                                \
@@ -1108,10 +1108,10 @@ int launch_rollout_fwd_mw_rec(const RolloutArgs<float>& a, LaneMap m, int integ,
     const int blk = G_ > 64 ? G_ : 64;                                                                                       \
     const unsigned grid = (unsigned)(((long long)a.B * G_ + blk - 1) / blk);                                                 \
     if (integ == MF_INTEG_DYNAMICS)                                                                                          \
-      hipLaunchKernelGGL((rollout_fwd_kernel<float, G_, 1, MF_INTEG_DYNAMICS, true, false, FORCES, 0, SPLIT, ZMU, true>),    \
+      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, 1, MF_INTEG_DYNAMICS, true, false, FORCES, 0, SPLIT, ZMU, true>),    \
                          dim3(grid), dim3(blk), 0, st, a);                                                                   \
     else                                                                                                                     \
-      hipLaunchKernelGGL((rollout_fwd_kernel<float, G_, 1, MF_INTEG_ODEINT_EULER, true, false, FORCES, 0, SPLIT, ZMU, true>), \
+      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, 1, MF_INTEG_ODEINT_EULER, true, false, FORCES, 0, SPLIT, ZMU, true>), \
                          dim3(grid), dim3(blk), 0, st, a);                                                                   \
   }
   MF_CASE(8) MF_CASE(16) MF_CASE(32) MF_CASE(64)

@@ -135,8 +135,8 @@ def _kernel_controls(controls, allow_view):
 def _zmu_scratch(mod, desc, z):
     """Scratch for the interleaved (z, mu) copy of a SHARED float32 map pair (MfRolloutFwdBufs.zmu_scratch): the library uses
     it where its kernels gain from it and ignores it elsewhere; stream-ordered, so it may be freed right after the launch."""
-    if mod.interleave_maps and desc.map_shared and z.dtype == torch.float32:
-        return torch.empty(2 * desc.H * desc.W, dtype=torch.float32, device=z.device)
+    if mod.interleave_maps and desc.map_shared and (z.dtype == torch.float32 or mod.points_per_lane == _lib.MF_LANES_COMPONENT):
+        return torch.empty(2 * desc.H * desc.W, dtype=z.dtype, device=z.device)
     return None
 
 
@@ -238,10 +238,11 @@ def _rollout_forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_gra
     # the per-step record of the component-parallel kernels (MfRolloutFwdBufs.rec): kept for the backward where the library
     # says it pays (few rollouts of a small body), 1 KiB per rollout and step
     rec = None
-    if want_grad and dt == torch.float32 and joint_angles is None:
-        nbytes = int(_lib.lib().mf_rollout_record_bytes(C.byref(desc)))
+    if want_grad and joint_angles is None:      # (float64: the validation build of the component-parallel kernels, 32-byte quads)
+        rb = _lib.lib().mf_rollout_record_bytes if dt == torch.float32 else _lib.lib().mf_rollout_record_bytes_f64
+        nbytes = int(rb(C.byref(desc)))
         if nbytes > 0:
-            rec = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+            rec = torch.empty(nbytes // dt.itemsize, dtype=dt, device=dev)
     bufs = _lib.MfRolloutFwdBufs(
         z=_lib.ptr(keep['z']), mu=_lib.ptr(keep['mu']), controls=_lib.ptr(controls), ts=_lib.ptr(ts),
         points=_lib.ptr(keep['points']), part=_lib.ptr(mod._part_dev(dev)),
@@ -511,7 +512,8 @@ class DPhysics(torch.nn.Module):
         xd0, R0, w0 = (s.to(device=dev, dtype=dtype).contiguous() for s in state[1:])
         want_grad = torch.is_grad_enabled() and any(
             t is not None and t.requires_grad for t in (z_grid, friction, controls, x_in, xd0, R0, w0, ja_dev))
-        want_forces = self.return_forces or self.precise or dtype != torch.float32 or ja_dev is not None
+        cp64 = dtype == torch.float64 and self.points_per_lane == _lib.MF_LANES_COMPONENT      # the validation build of the fast kernels
+        want_forces = self.return_forces or self.precise or (dtype != torch.float32 and not cp64) or ja_dev is not None
         # a start position that requires grad is the autograd input itself (its gradient: x and y through the contact geometry,
         # z none -- the snap overwrites it); the kernel works on the detached buffer x0 either way
         x_arg = x_in if (want_grad and x_in.requires_grad) else x0
@@ -533,11 +535,11 @@ class DPhysics(torch.nn.Module):
             return loss_val, (Xs, Xds, Rs, Omegas)
         return (Xs, Xds, Rs, Omegas), (F_springs, F_frictions)
 
-    def loss_spec(self, gt_ts, gamma=0.9, n_steps=None):
+    def loss_spec(self, gt_ts, gamma=0.9, n_steps=None, dtype=torch.float32):
         """Prepare the ground-truth stamps of `physics_loss` for `physics_loss_rollout`: gt_ts [T2] (the same stamp times for every
         rollout), weights 1 / (1 + gamma t) (losses.py:122); the predicted stamps are this module's time grid."""
         n = len(self.ts) if n_steps is None else int(n_steps)
-        return LossSpec(self._time_grid(n, torch.float32, torch.device('cpu')), gt_ts, gamma, torch.device(self.device))
+        return LossSpec(self._time_grid(n, dtype, torch.device('cpu')), gt_ts, gamma, torch.device(self.device), dtype=dtype)
 
     def physics_loss_rollout(self, z_grid, controls, X_gt, spec, state=None, friction=None, value_in_backward=False):
         """`physics_loss(self(z_grid, controls, ...), [X_gt], pred_ts, gt_ts, gamma)` (losses.py:102-127, the position term the training
@@ -551,7 +553,9 @@ class DPhysics(torch.nn.Module):
         Where the library cannot fuse (mf_rollout_loss_fusable: other than float32 fast math, default integrator, a rigid body of <= 4
         points, <= 2048 rollouts; several stamps on one row) the same value and gradient come from the unfused route."""
         from .losses import physics_loss_fused
-        ok = spec.fusable and not self.precise and z_grid.dtype == torch.float32 and self.dphys_cfg.use_odeint and not self.contiguous_outputs
+        cp64 = z_grid.dtype == torch.float64 and self.points_per_lane == _lib.MF_LANES_COMPONENT      # the validation build of the fast kernels
+        ok = (spec.fusable and not self.precise and (z_grid.dtype == torch.float32 or cp64) and spec.w.dtype == z_grid.dtype
+              and self.dphys_cfg.use_odeint and not self.contiguous_outputs)
         B = controls.shape[0]
         if ok:
             ok = spec.T == min(int(self.dphys_cfg.traj_sim_time / self.dphys_cfg.dt), controls.shape[1])
@@ -565,7 +569,7 @@ class DPhysics(torch.nn.Module):
             B_, T2 = X_gt.shape[:2]
             gt_ts = spec.gt_ts.unsqueeze(0).expand(B_, -1)
             return physics_loss_fused(states, [X_gt], None, gt_ts, gamma=spec.gamma, nearest=spec.near.unsqueeze(0).expand(B_, -1)), states
-        Xg = X_gt.detach().to(device=torch.device(self.device), dtype=torch.float32).contiguous()
+        Xg = X_gt.detach().to(device=torch.device(self.device), dtype=z_grid.dtype).contiguous()
         assert Xg.shape == (B, spec.T2, 3), f'X_gt shape {tuple(Xg.shape)} != {(B, spec.T2, 3)}'
         return self.dphysics(z_grid, controls, state=state, friction=friction, _loss=(spec, Xg, bool(value_in_backward)))
 

@@ -128,7 +128,8 @@ def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf, gloss=None):
         gmu = torch.zeros_like(mu) if want_gmu else None
         zero_row = torch.zeros(16, dtype=dt, device=dev)
     # the control gradient is skipped where nobody wants it and the chosen kernels can leave it out (mf_rollout_bwd_wants_gcontrols)
-    need_gc = ctx.needs_input_grad[3] or bool(_lib.lib().mf_rollout_bwd_wants_gcontrols(C.byref(desc))) or dt != torch.float32
+    need_gc = (ctx.needs_input_grad[3] or bool(_lib.lib().mf_rollout_bwd_wants_gcontrols(C.byref(desc)))
+               or (dt != torch.float32 and desc.points_per_lane != _lib.MF_LANES_COMPONENT))      # (float64 + component lanes: the validation build)
     gcontrols = torch.empty_like(controls) if need_gc else None
     gxd0, gR0, gw0 = torch.empty_like(xd0), torch.empty_like(R0), torch.empty_like(w0)
     gx0 = torch.empty_like(xd0) if ctx.needs_input_grad[4] else None

@@ -45,7 +45,7 @@ def test_small_grads_vs_reference_autograd(name, tag, integ, ppl, precise):
 
 
 @pytest.mark.parametrize('integ', [0, 1])
-@pytest.mark.parametrize('ppl', [1, 4])
+@pytest.mark.parametrize('ppl', [1, 4, 0, 16])      # 16: the float64 build of the component-parallel kernels (tests/test_cp_f64_validation_gpu.py: every backward form)
 def test_full_horizon_grads_f64(integ, ppl):
     """T=500 BPTT on 256x256 in float64 vs the reference (gradients explode to 1e3..1e6 there; still <= 1e-6 rel)."""
     g = hp.load('rollout_full')

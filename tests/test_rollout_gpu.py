@@ -74,7 +74,7 @@ def test_teacher_forced_single_step(tag, ppl, precise):
 
 
 @pytest.mark.parametrize('integ', [0, 1])
-@pytest.mark.parametrize('ppl', [1, 4])
+@pytest.mark.parametrize('ppl', [1, 4, 0, 16])      # 16: the float64 build of the component-parallel kernels every BASELINE config runs on
 def test_full_horizon_f64_vs_reference(integ, ppl):
     """T=500 on 256x256 in float64: chaos-proof full-horizon parity with the reference (<= 1e-8 rel)."""
     g = hp.load('rollout_full')
