@@ -87,6 +87,26 @@ def bwd_bytes_per_rollout_step(N):
     return 160 + 120 * N
 
 
+# The same model restricted to what must cross HBM: SURVEY 8d counts the 32 N bytes of gathered map cells (and, backward, the 64 N of
+# scatter read-modify-writes) "even when served from LDS / L2" -- the maps of these workloads are 512 KiB and their gradient copies a
+# few MB, resident in every XCD's L2 / the memory-side cache.  `frac_hbm` next to every `frac` is computed on these bytes, so that
+# a fraction near (or above) the achievable 6.3 TB/s is not read as HBM bandwidth it is not.
+def fwd_hbm_bytes_per_rollout_step(N, forces=True):
+    """controls 8 + states 72 (+ forces 24 N when written): no map cells."""
+    return 80 + (24 * N if forces else 0)
+
+
+def bwd_hbm_bytes_per_rollout_step(N):
+    """upstream grads 72 + 24 N, controls 8, saved state 72, grad-controls 8: no map cells, no scatter RMW."""
+    return 160 + 24 * N
+
+
+def fwd_states_only_bytes_per_rollout_step(N):
+    """A states-only forward (FORCES = false: the fit / train steps discard the forces) is asked to move
+    controls 8 + states 72 + map cells 32 N -- NOT the 24 N of forces: its `algorithmic_bytes` is 80 + 32 N (208 B at N = 4)."""
+    return 80 + 32 * N
+
+
 def build_problem(B, T, N, device, integ, seed=0, grid_res=0.05, terrain_seed=0):
     """Synthetic inputs: terrain / friction from `terrain_seed`, controls from `seed`."""
     from monoforce_amd import synthetic as syn
@@ -207,8 +227,18 @@ class Runner:
             else:
                 dist.init_process_group(self.backend)
             self.dist_world = dist.get_world_size()        # what the collective library itself sees
+        # PMC-measured HBM bytes per launch (tools/collect_profiles.sh): valid for the library build they were measured on -- the file
+        # carries that build's sha256, and a different library gets `traffic: null` with the reason instead of a stale figure
         traffic_file = os.path.join(REPO, 'profiles', 'hbm_traffic.json')
         self.traffic = json.load(open(traffic_file)) if os.path.exists(traffic_file) else {}
+        self.traffic_stale = None
+        want = self.traffic.get('_library_sha256')
+        if self.traffic:
+            have = library_sha256()
+            if want != have:
+                self.traffic_stale = (f'profiles/hbm_traffic.json was measured on library build {str(want)[:12]}, this run loads {have[:12]}: '
+                                      'regenerate with tools/collect_profiles.sh')
+                self.traffic = {}
 
     def barrier(self):
         if self.dist_on:
@@ -263,6 +293,8 @@ class Runner:
             torch.manual_seed(0)        # identical initial weights on every rank (DDP convention)
             gc = dict(xbound=[-6.4, 6.4, 0.05], ybound=[-6.4, 6.4, 0.05], zbound=[-3.2, 3.2, 6.4], dbound=[0.6, 6.4, 0.1])
             enc = LiftSplatShoot(gc, dict(final_dim=(256, 512))).to(dev).train()
+            if os.environ.get('MF_CHANNELS_LAST'):      # A/B (tools/ab_c4_miopen.sh): NHWC weights -> MIOpen's NHWC solvers
+                enc = enc.to(memory_format=torch.channels_last)
             ebatch = synthetic_encoder_batch(enc, dp, n_rollouts=B, device=dev, seed=rank)    # the encoder batch is sharded too
             estep = EncoderTrainStep(enc, dp, lr=1e-4, graph=not os.environ.get('MF_BENCH_NO_GRAPH'))
         elif wl['backward']:
@@ -347,7 +379,12 @@ class Runner:
                 comm_ms = self.time_exchange(lambda: prob._exchange(zleaf, mleaf, zero))
 
         P4 = 4 * 59 * 16 * 32                                  # frustum points per sample at the config-4 shapes
-        alg = {'rollout_fwd_kernel': fwd_bytes_per_rollout_step(N) * B * T, 'rollout_bwd_kernel': bwd_bytes_per_rollout_step(N) * B * T,
+        # the forward of a fit / train step writes no forces (states only; c3f and c2 write all six outputs)
+        states_only = bool(wl['backward'])      # (TerrainFitProblem / EncoderTrainStep run DPhysics.physics_loss_rollout: Fs = Ff = NULL)
+        fwd_alg = (fwd_states_only_bytes_per_rollout_step(N) if states_only else fwd_bytes_per_rollout_step(N)) * B * T
+        hbm = {'rollout_fwd_kernel': fwd_hbm_bytes_per_rollout_step(N, forces=not states_only) * B * T,
+               'rollout_bwd_kernel': bwd_hbm_bytes_per_rollout_step(N) * B * T}
+        alg = {'rollout_fwd_kernel': fwd_alg, 'rollout_bwd_kernel': bwd_bytes_per_rollout_step(N) * B * T,
                'splat_fwd_kernel': 4 * 64 * P4 + 12 * P4 + 4 * 64 * 256 * 256, 'splat_bwd_kernel': 4 * 64 * 256 * 256 + 4 * 64 * P4,
                'splat_prepare': 20 * P4,
                # lift fused into the splat: depth 4 P + context 4*64*pixels + out / the reverse + the voxel-major rows
@@ -357,7 +394,18 @@ class Runner:
         kern = {k: v for k, v in kern.items() if k in alg}
         dom = max(kern, key=kern.get)                          # the dominant hand-written kernel of the step
         per_kernel = {k: {'ms': v, 'algorithmic_bytes': alg[k], 'GB/s': alg[k] / (v * 1e-3) / 1e9,
-                          'frac': alg[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS} for k, v in kern.items()}
+                          'frac': alg[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                          # the bytes of the model that must cross HBM (no cache-served map cells / scatter RMW); splat: all of them
+                          'hbm_bytes_model': hbm.get(k, alg[k]), 'frac_hbm': hbm.get(k, alg[k]) / (v * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                      for k, v in kern.items()}
+        if 'rollout_fwd_kernel' in per_kernel:
+            per_kernel['rollout_fwd_kernel']['bytes_model'] = (
+                f'states only (no force rows): controls 8 + states 72 + map cells 32 N = {fwd_states_only_bytes_per_rollout_step(N)} B per rollout-step'
+                if states_only else f'all six outputs: 80 + 56 N = {fwd_bytes_per_rollout_step(N)} B per rollout-step')
+        if 'rollout_bwd_kernel' in per_kernel:
+            per_kernel['rollout_bwd_kernel']['bytes_model'] = (
+                f'SURVEY 8d: 160 + 120 N = {bwd_bytes_per_rollout_step(N)} B per rollout-step (of which 72 + 24 N are upstream-gradient rows a fused '
+                f'physics loss never reads: the kernel forms dL/dXs itself)')
         achieved = per_kernel[dom]['GB/s']
         mode = 'encoder train step (fwd+bwd+Adam)' if wl.get('encoder') else 'forward+backward' if wl['backward'] else 'forward'
         integ = 'odeint-euler (reference default)' if args.integrator == 1 else 'dynamics()'
@@ -385,7 +433,11 @@ class Runner:
                          **({'record_bytes_per_launch': rec_bytes,
                              'traffic_note': 'traffic includes the per-step record the forward writes and the backward reads instead of '
                                              'recomputing it (record_bytes_per_launch; DESIGN.md 4.2b) -- not re-reads'} if rec_bytes else {}),
-                         'traffic_source': 'profiles/hbm_traffic.json (rocprofv3 PMC passes of this command, static -- not re-measured in this run)' if traffic else None,
+                         'traffic_source': ('profiles/hbm_traffic.json (rocprofv3 PMC passes of this command on THIS library build -- sha256 checked; '
+                                            'not re-measured in this run)' if traffic else self.traffic_stale),
+                         'frac_hbm': per_kernel[dom]['frac_hbm'], 'hbm_bytes_model_per_launch': per_kernel[dom]['hbm_bytes_model'],
+                         'frac_note': '`frac` = SURVEY 8d algorithmic bytes (map cells counted even when cache-served) / kernel time / 8 TB/s; '
+                                      '`frac_hbm` = the same model without the cache-served bytes; `traffic` = PMC-measured HBM bytes',
                          'kernel': dom, 'kernel_ms': kern[dom], 'kernel_ms_from': f'HIP events around the launches of every {EVENT_EVERY}th timed step',
                          'algorithmic_bytes_per_launch': alg[dom], 'bytes_per_rollout_step': alg[dom] // (B * T),
                          'per_kernel': per_kernel},
@@ -422,7 +474,9 @@ class Runner:
             fg = fwd_bytes_per_rollout_step(N) * Bs * T / (f_ms * 1e-3) / 1e9
             bg = bwd_bytes_per_rollout_step(N) * Bs * T / (b_ms * 1e-3) / 1e9
             sweep[str(Bs)] = {'fwd_ms': f_ms, 'fwd_frac': fg / HBM_PEAK_GBS, 'fwd_rollout_steps_per_s': Bs * T / (f_ms * 1e-3),
-                              'bwd_ms': b_ms, 'bwd_frac': bg / HBM_PEAK_GBS}
+                              'fwd_frac_hbm': fwd_hbm_bytes_per_rollout_step(N) * Bs * T / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              'bwd_ms': b_ms, 'bwd_frac': bg / HBM_PEAK_GBS,
+                              'bwd_frac_hbm': bwd_hbm_bytes_per_rollout_step(N) * Bs * T / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
             del dps, prob, cs, zl, ml
             torch.cuda.empty_cache()      # return the sweep's multi-GB blocks now, not inside a later workload's timed region
         first = {leg: next((int(b) for b in sweep if sweep[b][leg + '_frac'] >= 0.4), None) for leg in ('fwd', 'bwd')}
@@ -452,6 +506,17 @@ def shoot_workload(r, T, N, integ, B=16384, iters=8):
             'workload': f'shoot: {B} sampled control sequences x T={T} x N={N}, one shared map, path-cost kernel + force cost + argmin',
             'per_kernel': {'rollout_fwd_kernel': {'ms': kms, 'bytes_per_rollout_step': 8 + 16 + 32 * N,
                                                   'GB/s': (8 + 16 + 32 * N) * B * T / (kms * 1e-3) / 1e9}}}
+
+
+def library_sha256():
+    import hashlib
+    from monoforce_amd import _lib
+    path = getattr(_lib, 'LIB_PATH', None) or os.path.join(REPO, 'monoforce_amd', 'csrc', 'libmonoforce_hip.so')
+    h = hashlib.sha256()
+    with open(path, 'rb') as f:
+        for chunk in iter(lambda: f.read(1 << 20), b''):
+            h.update(chunk)
+    return h.hexdigest()
 
 
 def _free_port():

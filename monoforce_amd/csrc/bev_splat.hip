@@ -20,6 +20,7 @@
 //   backward  the same tiling in reverse: the grad tile is loaded coalesced per channel plane, and each kept point's
 //             feature-gradient row is written as one coalesced row (QuickCumsum.backward is exactly this gather);
 //             rows of dropped points are zero-filled by the keys pass of the backward.
+#include <cstdlib>
 #include "mf_common.h"
 
 namespace mf {
@@ -256,6 +257,156 @@ __device__ __forceinline__ void accumulate_tile_rows(const S* __restrict__ xc, i
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// forward, 16 lanes per point (round 4; float32, C % 4 == 0, plane % 4 == 0 -- the reference's shapes)
+// ---------------------------------------------------------------------------------------------------------
+// accumulate_tile_rows() above walks ONE point per wave iteration (lane = channel, a 4-byte load per lane): ~18 wave instructions
+// per point, and the densest waves of the config-4 rig serialise 256 of them -- PMC (profiles/r4a_pmc_lift_splat.txt): the kernel
+// moves exactly its output bytes (WRITE_SIZE = the BEV tensor, FETCH_SIZE ~ the inputs), no LDS bank conflicts, and sits at 6 %
+// (B = 1) / 19 % (B = 8) of the HBM roofline: instruction issue and the dependent chain of a tile, not traffic.  Here a point is
+// read by a QUARTER wave -- lane q of a 16-lane row loads channels 4q .. 4q + 3 as one 16-byte load -- so a wave instruction covers
+// four points and a tile's points are spread over the workgroup's sixteen rows: row `gid` owns voxels gid, gid + 16, gid + 32, gid +
+// 48 of the 64-voxel tile (round robin: the points of neighbouring dense voxels go to different rows).  Per row the points of its
+// four voxels form one virtual stream, taken sixteen at a time: lane q looks up stream slot k0 + q (its voxel by comparing with the
+// row's prefix counts, then list id, depth weight, row index -- all loads of a chunk are issued before the first is used), and the
+// sixteen points are then accumulated in order with their row index / weight / flags broadcast inside the row (DPP row_share).
+// Sums still run over ascending point ids per voxel with the product rounded on its own: bit-identical to the kernels above.
+// The [voxel][channel] tile in LDS is rotated by 4 (v >> 2) channels per voxel row, so that the 16-byte writes of a row stay
+// aligned and the transposing reads of the output phase (lane = 4 voxels of one channel -> one global_store_dwordx4) hit 64
+// different banks.  Tiles without points skip everything and store zeros (most of a BEV plane at real camera rigs).
+template <int CTRL>
+__device__ __forceinline__ int row_share_i(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x150 + CTRL, 0xF, 0xF, true); }
+template <int CTRL>
+__device__ __forceinline__ float row_share_f(float v) { return __builtin_bit_cast(float, row_share_i<CTRL>(__builtin_bit_cast(int, v))); }
+
+constexpr int kQPitch = 68;      // words per voxel row of the LDS tile (64 channels + 4: rows stay 16-byte aligned)
+
+template <bool WEIGHTED>
+__global__ void __launch_bounds__(256) splat_fwd_quad_kernel(const float* __restrict__ x, const float* __restrict__ weight,
+                                                            const int* __restrict__ offsets, const int* __restrict__ list, int C,
+                                                            int plane, int tiles_per_plane, int d_hw, int hw, float* __restrict__ out) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) float tile[kTileVox * kQPitch];
+  const int bz = blockIdx.x / tiles_per_plane;
+  const int vid0 = (blockIdx.x % tiles_per_plane) * kTileVox;
+  const int nvox = min(kTileVox, plane - vid0);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int key0 = bz * plane + vid0;
+  // CSR bounds of the tile's voxels: lane l holds offsets[key0 + l], every lane the tile's end
+  const int off_l = offsets[key0 + min(lane, nvox)];
+  const int off_end = offsets[key0 + nvox];
+  const int off_beg = __builtin_amdgcn_readfirstlane(off_l);
+  const int q = lane & 15, g = lane >> 4, gid = wave * 4 + g;
+  const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  if (__builtin_amdgcn_readfirstlane(off_end) == off_beg) {      // no points in this tile: zeros, straight from registers
+    for (int c0 = 0; c0 < C; c0 += 64) {
+      const int nch = min(64, C - c0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int cc = wave * 16 + 4 * i + g;
+        if (cc < nch) {
+          float* o = out + ((size_t)bz * C + c0 + cc) * plane + vid0 + 4 * q;
+          if (nvox == kTileVox) __builtin_nontemporal_store(zero4, reinterpret_cast<f4*>(o));
+          else { for (int j = 0; j < 4; ++j) if (4 * q + j < nvox) o[j] = 0.f; }
+        }
+      }
+    }
+    return;
+  }
+  // this row's four voxels: bounds through the LDS crossbar (ds_bpermute), prefix counts of its virtual point stream
+  int ob[4], pre[5];
+  pre[0] = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int v = gid + 16 * j;
+    const int o = __shfl(off_l, min(v, 63), 64);
+    const int e = v + 1 < 64 ? __shfl(off_l, min(v + 1, 63), 64) : off_end;
+    ob[j] = o;
+    pre[j + 1] = pre[j] + (v < nvox ? e - o : 0);
+  }
+  const int n_row = pre[4];
+  // chunks of sixteen stream slots until the busiest row of the wave is through
+  int n_max = max(n_row, __shfl_xor(n_row, 16, 64));
+  n_max = __builtin_amdgcn_readfirstlane(max(n_max, __shfl_xor(n_max, 32, 64)));
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int cq = min(c0 + 4 * q, C - 4);                      // channel quad of this lane (chunks beyond C: clamped, not stored)
+    // the row's own voxel rows start at zero (LDS executes a wave's operations in order: no barrier between these and the sums)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f4*>(&tile[(gid + 16 * j) * kQPitch + 4 * q]) = zero4;
+    f4 acc = zero4;
+    for (int k0 = 0; k0 < n_max; k0 += 16) {
+      const int sl = k0 + q;                                     // this lane's stream slot
+      const bool valid = sl < n_row;
+      const int j = (sl >= pre[1] ? 1 : 0) + (sl >= pre[2] ? 1 : 0) + (sl >= pre[3] ? 1 : 0);
+      const int pj = j == 0 ? 0 : (j == 1 ? pre[1] : (j == 2 ? pre[2] : pre[3]));
+      const int pn = j == 0 ? pre[1] : (j == 1 ? pre[2] : (j == 2 ? pre[3] : pre[4]));
+      const int oj = j == 0 ? ob[0] : (j == 1 ? ob[1] : (j == 2 ? ob[2] : ob[3]));
+      const int pid = list[valid ? oj + (sl - pj) : off_beg];    // (slots past the end read a valid id and are masked)
+      int meta_l = (gid + 16 * j) | (valid ? 0x100 : 0) | (sl == pj ? 0x200 : 0) | (sl + 1 == pn ? 0x400 : 0);
+      float w_l = 1.0f;
+      int row_l = pid;
+      if constexpr (WEIGHTED) { w_l = weight[pid]; row_l = (pid / d_hw) * hw + pid % hw; }
+      const char* xb = reinterpret_cast<const char*>(x) + (size_t)cq * 4;
+      const unsigned rstride = (unsigned)C * 4u;
+      f4 val[16];
+#define MF_SPLAT_LOAD(I) val[I] = *reinterpret_cast<const f4*>(xb + (size_t)((unsigned)row_share_i<I>(row_l) * rstride));
+      MF_SPLAT_LOAD(0) MF_SPLAT_LOAD(1) MF_SPLAT_LOAD(2) MF_SPLAT_LOAD(3) MF_SPLAT_LOAD(4) MF_SPLAT_LOAD(5) MF_SPLAT_LOAD(6) MF_SPLAT_LOAD(7)
+      MF_SPLAT_LOAD(8) MF_SPLAT_LOAD(9) MF_SPLAT_LOAD(10) MF_SPLAT_LOAD(11) MF_SPLAT_LOAD(12) MF_SPLAT_LOAD(13) MF_SPLAT_LOAD(14) MF_SPLAT_LOAD(15)
+#undef MF_SPLAT_LOAD
+#define MF_SPLAT_POINT(I)                                                                                          \
+      {                                                                                                            \
+        const int meta = row_share_i<I>(meta_l);                                                                   \
+        const float wi = row_share_f<I>(w_l);                                                                      \
+        if (meta & 0x100) {                                  /* row-uniform: all sixteen lanes of the row agree */  \
+          f4 pr = val[I];                                                                                          \
+          if constexpr (WEIGHTED) { pr.x = mul_rounded(wi, pr.x); pr.y = mul_rounded(wi, pr.y); pr.z = mul_rounded(wi, pr.z); pr.w = mul_rounded(wi, pr.w); } \
+          const f4 sum = acc + pr;                                                                                 \
+          acc = (meta & 0x200) ? (zero4 + pr) : sum;         /* first point of its voxel: 0 + x, as the kernels above */ \
+          if (meta & 0x400) {                                /* last point of its voxel: its sum goes to the tile */ \
+            const int v = meta & 0xff;                                                                             \
+            *reinterpret_cast<f4*>(&tile[v * kQPitch + ((4 * q + 4 * (v >> 2)) & 63)]) = acc;                      \
+          }                                                                                                        \
+        }                                                                                                          \
+      }
+      {   // point 0 without a branch around its arithmetic: its row is then used unconditionally, so its load cannot be sunk into a
+          // branch (a load inside a branch makes the wait-count pass wait for ALL sixteen; the other rows have LDS writes between
+          // their load and their use and stay where they are)
+        const int meta = row_share_i<0>(meta_l);
+        const float wi = row_share_f<0>(w_l);
+        f4 pr = val[0];
+        if constexpr (WEIGHTED) { pr.x = mul_rounded(wi, pr.x); pr.y = mul_rounded(wi, pr.y); pr.z = mul_rounded(wi, pr.z); pr.w = mul_rounded(wi, pr.w); }
+        const f4 sum = acc + pr;
+        const f4 cand = (meta & 0x200) ? (zero4 + pr) : sum;
+        acc = (meta & 0x100) ? cand : acc;
+        if ((meta & 0x500) == 0x500) {
+          const int v = meta & 0xff;
+          *reinterpret_cast<f4*>(&tile[v * kQPitch + ((4 * q + 4 * (v >> 2)) & 63)]) = acc;
+        }
+      }
+      MF_SPLAT_POINT(1) MF_SPLAT_POINT(2) MF_SPLAT_POINT(3) MF_SPLAT_POINT(4) MF_SPLAT_POINT(5) MF_SPLAT_POINT(6) MF_SPLAT_POINT(7)
+      MF_SPLAT_POINT(8) MF_SPLAT_POINT(9) MF_SPLAT_POINT(10) MF_SPLAT_POINT(11) MF_SPLAT_POINT(12) MF_SPLAT_POINT(13) MF_SPLAT_POINT(14) MF_SPLAT_POINT(15)
+#undef MF_SPLAT_POINT
+    }
+    __syncthreads();
+    // out[(bz * C + c) * plane + vid]: lane (g, q) = channel row wave * 16 + 4 i + g, voxels 4 q .. 4 q + 3 -> one 16-byte store
+    const int nch = min(64, C - c0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int cc = wave * 16 + 4 * i + g;
+      const int col = (cc + 4 * q) & 63;                         // rotation of voxel rows 4 q .. 4 q + 3: (v >> 2) = q
+      f4 r;
+      r.x = tile[(4 * q + 0) * kQPitch + col]; r.y = tile[(4 * q + 1) * kQPitch + col];
+      r.z = tile[(4 * q + 2) * kQPitch + col]; r.w = tile[(4 * q + 3) * kQPitch + col];
+      if (cc < nch) {
+        float* o = out + ((size_t)bz * C + c0 + cc) * plane + vid0 + 4 * q;
+        if (nvox == kTileVox) __builtin_nontemporal_store(r, reinterpret_cast<f4*>(o));
+        else { const float rr[4] = {r.x, r.y, r.z, r.w}; for (int j = 0; j < 4; ++j) if (4 * q + j < nvox) o[j] = rr[j]; }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // forward / backward tiles
 // ---------------------------------------------------------------------------------------------------------
 // A workgroup owns a tile of 64 consecutive voxels of one BEV plane, each of its 4 waves 16 of them.  The CSR segments of
@@ -446,6 +597,118 @@ __global__ void __launch_bounds__(256) lift_splat_bwd_gather_kernel(const S* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// fused backward, 16 lanes per pixel / per voxel row (round 4; float32, C % 4 == 0, plane % 4 == 0)
+// ---------------------------------------------------------------------------------------------------------
+// Step 1, voxel-major rows of the BEV gradient for the voxels that HOLD points (the gather below reads nothing else): the tile comes in
+// as 16-byte loads (lane = four voxels of one channel), is transposed through the rotated LDS tile of splat_fwd_quad_kernel, and every
+// row of the workgroup writes the 256-byte rows of its occupied voxels -- 7 k of a plane's 65 k voxels at the config-4 rig, where the
+// kernel above writes all 64 rows of every occupied tile (13 -> 1.8 MB of writes per sample).
+__global__ void __launch_bounds__(256) lift_splat_bwd_rows_quad_kernel(const float* __restrict__ gout, const int* __restrict__ offsets, int C,
+                                                                      int plane, int tiles_per_plane, float* __restrict__ gT) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) float tile[kTileVox * kQPitch];
+  const int bz = blockIdx.x / tiles_per_plane;
+  const int vid0 = (blockIdx.x % tiles_per_plane) * kTileVox;
+  const int nvox = min(kTileVox, plane - vid0);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int key0 = bz * plane + vid0;
+  const int off_l = offsets[key0 + min(lane, nvox)];
+  const int off_end = offsets[key0 + nvox];
+  if (__builtin_amdgcn_readfirstlane(off_end) == __builtin_amdgcn_readfirstlane(off_l)) return;      // no points: the gather never reads this tile
+  const int q = lane & 15, g = lane >> 4, gid = wave * 4 + g;
+  bool occ[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int v = gid + 16 * j;
+    const int o = __shfl(off_l, min(v, 63), 64);
+    const int e = v + 1 < 64 ? __shfl(off_l, min(v + 1, 63), 64) : off_end;
+    occ[j] = v < nvox && e > o;
+  }
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int nch = min(64, C - c0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int cc = wave * 16 + 4 * i + g;
+      f4 r = {0.f, 0.f, 0.f, 0.f};
+      if (cc < nch) {
+        const float* o = gout + ((size_t)bz * C + c0 + cc) * plane + vid0 + 4 * q;
+        if (nvox == kTileVox) r = *reinterpret_cast<const f4*>(o);
+        else { float rr[4] = {0.f, 0.f, 0.f, 0.f}; for (int j = 0; j < 4; ++j) if (4 * q + j < nvox) rr[j] = o[j]; r = f4{rr[0], rr[1], rr[2], rr[3]}; }
+      }
+      const int col = (cc + 4 * q) & 63;                         // rotation of voxel rows 4 q .. 4 q + 3 (v >> 2 = q)
+      tile[(4 * q + 0) * kQPitch + col] = r.x; tile[(4 * q + 1) * kQPitch + col] = r.y;
+      tile[(4 * q + 2) * kQPitch + col] = r.z; tile[(4 * q + 3) * kQPitch + col] = r.w;
+    }
+    __syncthreads();
+    const int cq = c0 + 4 * q;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int v = gid + 16 * j;
+      if (occ[j] && cq < C) {
+        const f4 r = *reinterpret_cast<const f4*>(&tile[v * kQPitch + ((4 * q + 4 * (v >> 2)) & 63)]);
+        *reinterpret_cast<f4*>(gT + (size_t)(key0 + v) * C + cq) = r;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// Step 2, sixteen lanes per (camera, pixel), lane q = channels 4 q .. 4 q + 3: along the pixel's D depth bins
+//   g_depth[p] = <ctx[pixel], gT[voxel(p)]>  (four products per lane, a 16-lane DPP sum),  g_ctx[pixel] += depth[p] * gT[voxel(p)];
+// a wave instruction covers four pixels (the one-pixel-per-wave kernel above spends ~25 instructions per point, 6 of them the 64-lane
+// sum).  Bins are taken sixteen at a time: lane q looks up bin d0 + q (voxel key, depth weight), all sixteen row loads are issued
+// before the first is used, and lane q keeps the dot product of "its" bin for one strided store per chunk.
+__global__ void __launch_bounds__(256) lift_splat_bwd_gather_quad_kernel(const float* __restrict__ depth, const float* __restrict__ ctx,
+                                                                        const int* __restrict__ keys, const float* __restrict__ gT, int C, int D,
+                                                                        int hw, int n_pix, float* __restrict__ g_depth, float* __restrict__ g_ctx) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x & 63, q = lane & 15;
+  const int pix = (blockIdx.x * 256 + (int)threadIdx.x) >> 4;   // cam * hw + pixel, over all samples and cameras
+  const bool live = pix < n_pix;                                // (whole rows: DPP never crosses a row)
+  const int pc = live ? pix : 0;
+  const int cam = pc / hw, px = pc % hw;
+  const size_t p0 = (size_t)cam * D * hw + px;                  // point index of depth bin 0
+  const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int cq = c0 + 4 * q;
+    const bool on = cq < C;
+    const int cl = on ? cq : 0;
+    const f4 f = on ? *reinterpret_cast<const f4*>(ctx + (size_t)pc * C + cq) : zero4;
+    f4 acc = zero4;
+    for (int d0 = 0; d0 < D; d0 += 16) {
+      const bool has = d0 + q < D;
+      const size_t pl = p0 + (size_t)min(d0 + q, D - 1) * hw;
+      const int key_l = has ? keys[pl] : -1;                     // -1: dropped by the pooling, or past the last bin
+      const float dep_l = has ? depth[pl] : 0.f;
+      f4 val[16];
+#define MF_GLOAD(I) val[I] = *reinterpret_cast<const f4*>(gT + (size_t)max(row_share_i<I>(key_l), 0) * C + cl);
+      MF_GLOAD(0) MF_GLOAD(1) MF_GLOAD(2) MF_GLOAD(3) MF_GLOAD(4) MF_GLOAD(5) MF_GLOAD(6) MF_GLOAD(7)
+      MF_GLOAD(8) MF_GLOAD(9) MF_GLOAD(10) MF_GLOAD(11) MF_GLOAD(12) MF_GLOAD(13) MF_GLOAD(14) MF_GLOAD(15)
+#undef MF_GLOAD
+      float dots = 0.f;
+#define MF_GPOINT(I)                                                                                                      \
+      {                                                                                                                   \
+        const bool kept = row_share_i<I>(key_l) >= 0 && on;                                                               \
+        const float di = row_share_f<I>(dep_l);                                                                           \
+        const f4 gq = kept ? val[I] : zero4;                                                                              \
+        acc.x += di * gq.x; acc.y += di * gq.y; acc.z += di * gq.z; acc.w += di * gq.w;                                   \
+        float dsum = (f.x * gq.x + f.y * gq.y) + (f.z * gq.z + f.w * gq.w);                                               \
+        dsum += dpp_mov<0xB1>(dsum); dsum += dpp_mov<0x4E>(dsum); dsum += dpp_mov<0x141>(dsum); dsum += dpp_mov<0x140>(dsum); \
+        dots = q == I ? dsum : dots;                                                                                      \
+      }
+      MF_GPOINT(0) MF_GPOINT(1) MF_GPOINT(2) MF_GPOINT(3) MF_GPOINT(4) MF_GPOINT(5) MF_GPOINT(6) MF_GPOINT(7)
+      MF_GPOINT(8) MF_GPOINT(9) MF_GPOINT(10) MF_GPOINT(11) MF_GPOINT(12) MF_GPOINT(13) MF_GPOINT(14) MF_GPOINT(15)
+#undef MF_GPOINT
+      if (live && has) {
+        const size_t p = p0 + (size_t)(d0 + q) * hw;
+        g_depth[p] = (c0 == 0) ? dots : g_depth[p] + dots;      // channel chunks beyond the first accumulate (same lane, in order)
+      }
+    }
+    if (live && on) *reinterpret_cast<f4*>(g_ctx + (size_t)pc * C + cq) = acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
 static int check_desc(const MfSplatDesc* d) {
@@ -492,12 +755,27 @@ static int splat_prepare(const MfSplatDesc* d, const float* geom, const float* f
   return MF_OK;
 }
 
+// the 16-lanes-per-point forward: float32 rows of whole channel quads, 16-byte aligned output rows; MF_SPLAT_QUAD=0 keeps the
+// one-point-per-iteration kernels (A/B runs, bit-equality tests of the two)
+static bool quad_forward_ok(const MfSplatDesc* d, int plane) {
+  static const bool off = getenv("MF_SPLAT_QUAD") && atoi(getenv("MF_SPLAT_QUAD")) == 0;
+  return !off && d->C % 4 == 0 && plane % 4 == 0 && (long long)d->C * 4 * ((long long)d->B * d->n_per_sample) < (1ll << 32);
+}
+
 template <typename S>
 static int splat_fwd(const MfSplatDesc* d, const S* x, const void* workspace, S* out, hipStream_t st) {
   SplatWs ws;
   carve(d, const_cast<void*>(workspace), &ws);
   const int plane = d->nx * d->ny;
   const int tpp = (plane + kTileVox - 1) / kTileVox;
+  if constexpr (sizeof(S) == 4) {
+    if (quad_forward_ok(d, plane)) {      // sixteen lanes per point (splat_fwd_quad_kernel)
+      hipLaunchKernelGGL((splat_fwd_quad_kernel<false>), dim3(d->B * d->nz * tpp), dim3(256), 0, st, x, (const float*)nullptr, ws.offsets, ws.list,
+                         d->C, plane, tpp, 1, 1, out);
+      MF_LAUNCH_OK("splat_fwd");
+      return MF_OK;
+    }
+  }
   hipLaunchKernelGGL((splat_fwd_kernel<S>), dim3(d->B * d->nz * tpp), dim3(256), 0, st, x, ws.offsets, ws.list, d->C, plane, tpp, out);
   MF_LAUNCH_OK("splat_fwd");
   return MF_OK;
@@ -531,6 +809,14 @@ static int lift_splat_fwd(const MfSplatDesc* d, const S* depth, const S* ctx, co
   carve(d, const_cast<void*>(workspace), &ws);
   const int plane = d->nx * d->ny;
   const int tpp = (plane + kTileVox - 1) / kTileVox;
+  if constexpr (sizeof(S) == 4) {
+    if (quad_forward_ok(d, plane)) {
+      hipLaunchKernelGGL((splat_fwd_quad_kernel<true>), dim3(d->B * d->nz * tpp), dim3(256), 0, st, ctx, depth, ws.offsets, ws.list, d->C, plane, tpp,
+                         d->lift_D * d->lift_hw, d->lift_hw, out);
+      MF_LAUNCH_OK("lift_splat_fwd");
+      return MF_OK;
+    }
+  }
   hipLaunchKernelGGL((lift_splat_fwd_kernel<S>), dim3(d->B * d->nz * tpp), dim3(256), 0, st, depth, ctx, ws.offsets, ws.list, d->C, plane, tpp,
                      d->lift_D * d->lift_hw, d->lift_hw, out);
   MF_LAUNCH_OK("lift_splat_fwd");
@@ -547,6 +833,15 @@ static int lift_splat_bwd(const MfSplatDesc* d, const S* depth, const S* ctx, co
   const int plane = d->nx * d->ny;
   const int tpp = (plane + kTileVox - 1) / kTileVox;
   const int n_pix = d->B * (d->n_per_sample / d->lift_D);       // samples * cameras * pixels
+  if constexpr (sizeof(S) == 4) {
+    if (quad_forward_ok(d, plane)) {      // sixteen lanes per voxel row / per pixel
+      hipLaunchKernelGGL(lift_splat_bwd_rows_quad_kernel, dim3(d->B * d->nz * tpp), dim3(256), 0, st, gout, ws.offsets, d->C, plane, tpp, gT);
+      hipLaunchKernelGGL(lift_splat_bwd_gather_quad_kernel, dim3((n_pix + 15) / 16), dim3(256), 0, st, depth, ctx, ws.keys, gT, d->C, d->lift_D,
+                         d->lift_hw, n_pix, g_depth, g_ctx);
+      MF_LAUNCH_OK("lift_splat_bwd");
+      return MF_OK;
+    }
+  }
   hipLaunchKernelGGL((lift_splat_bwd_rows_kernel<S>), dim3(d->B * d->nz * tpp), dim3(256), 0, st, gout, ws.offsets, d->C, plane, tpp, gT);
   hipLaunchKernelGGL((lift_splat_bwd_gather_kernel<S>), dim3((n_pix + 3) / 4), dim3(256), 0, st, depth, ctx, ws.keys, gT, d->C, d->lift_D,
                      d->lift_hw, n_pix, g_depth, g_ctx);

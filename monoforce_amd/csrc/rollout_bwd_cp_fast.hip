@@ -51,15 +51,19 @@ long long cp_record_bytes(const MfRolloutDesc* d, int scalar_bytes) {
   return bytes;
 }
 
-// The fused physics loss rides on the component-parallel forward (LOSS kernels: default integrator, states only) and on the
-// STREAMING backward (its fetching waves form dL/dXs): a launch that keeps a record and streams it.
+// The fused physics loss rides on the STREAMING backward (its fetching waves form dL/dXs -- and, with MF_LOSS_VALUE_IN_BACKWARD, the
+// value): a launch that keeps a record and streams it, either integrator (dynamics(): <= 256 workgroups).  The forward half -- the
+// LOSS kernels that accumulate the value while they write the rows -- exists for the default integrator only (cp_loss_in_forward);
+// dynamics() takes the value from the backward launch or from mf_physics_loss_value_* on the written rows.
 bool cp_loss_fusable(const MfRolloutDesc* d) {
   static const bool one_wave = getenv("MF_CP_BWD_MODE") && atoi(getenv("MF_CP_BWD_MODE")) == kCpSaved;
-  if (!d || d->integrator != MF_INTEG_ODEINT_EULER || d->layout != MF_LAYOUT_TIME_MAJOR || one_wave) return false;
+  if (!d || d->layout != MF_LAYOUT_TIME_MAJOR || one_wave) return false;
+  if (d->integrator != MF_INTEG_ODEINT_EULER && d->integrator != MF_INTEG_DYNAMICS) return false;
   if (cp_record_bytes(d, 4) <= 0) return false;
   const long long grid = ((long long)d->B * 16 + 63) / 64;
-  return grid <= (long long)cp_stream_max_grid();
+  return grid <= (long long)cp_stream_max_grid(d->integrator);
 }
+bool cp_loss_in_forward(const MfRolloutDesc* d) { return cp_loss_fusable(d) && d->integrator == MF_INTEG_ODEINT_EULER; }
 
 }  // namespace mf
 extern "C" int mf_rollout_loss_fusable(const MfRolloutDesc* d) { return mf::cp_loss_fusable(d) ? 1 : 0; }

@@ -55,7 +55,7 @@ extern __device__ unsigned long long mf_stream_prof[16];
 #else
 #define MF_STREAM_WPE __attribute__((amdgpu_waves_per_eu((MODE == kCpStream && XS_ONLY && sizeof(S) == 4) ? 2 : 1)))
 #endif
-template <typename S, int INTEG, bool XS_ONLY, bool GCTRL, int MODE, int SLOTS = 6>
+template <typename S, int INTEG, bool XS_ONLY, bool GCTRL, int MODE, int SLOTS = 6, int BATCH = 3>
 // (streaming, positions-only loss: at most 256 registers, so that two workgroups -- six waves -- share a CU's four SIMDs)
 __global__ void __launch_bounds__(MODE == kCpStream ? 192 : 64) MF_STREAM_WPE
 rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
@@ -627,7 +627,9 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
         // against the chain's 0.20).  Each runs its own three-stage pipeline over its batches.  Ring: six or twelve slots, a
         // batch's first step (ordinal 3 j) sits in slot 3 j mod kSlots (six slots: wave k owns slots 3k .. 3k + 2); steps are
         // published -- `steps written` advanced -- in order: a wave waits for the other one's previous batch.
-        static_assert(kSlots % 6 == 0, "two fetching waves alternate over batches of three steps: a batch must not wrap around the ring");
+        // BATCH steps per batch (3; 2 where six waves share a CU's four SIMDs at 256 registers each: three register sets of three steps
+        // spilled 200-250 bytes there, three sets of two do not)
+        static_assert(kSlots % BATCH == 0 && (BATCH == 2 || BATCH == 3), "a batch must not wrap around the ring");
         struct Slot { StateIn st; Saved sv; UpIn up; S lg, lw; int sj; };      // stamp of the row, its weight and ground truth (fused loss)
         unsigned zero_lane = 0u;                                                   // 0, as a per-lane value the compiler cannot see through:
         asm("" : "+v"(zero_lane));                                                 // keeps the loads of the stamp tables VECTOR loads
@@ -650,10 +652,11 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
           step_back_up();
           --m;
         };
+        constexpr unsigned kB = (unsigned)BATCH;
         auto skip3 = [&]() {                        // over the other wave's batch
-          o3 -= 3u * s3; o9 -= 3u * s9; oc -= 3u * kC; orc -= 3u * rec_step; ti -= 3; m -= 3;
-          og_xs -= 3u * sg_xs;
-          if constexpr (!XS_ONLY) { og_xds -= 3u * sg_xds; og_om -= 3u * sg_om; og_r -= 3u * sg_r; og_fs -= 3u * sg_fs; og_ff -= 3u * sg_ff; }
+          o3 -= kB * s3; o9 -= kB * s9; oc -= kB * kC; orc -= kB * rec_step; ti -= BATCH; m -= BATCH;
+          og_xs -= kB * sg_xs;
+          if constexpr (!XS_ONLY) { og_xds -= kB * sg_xds; og_om -= kB * sg_om; og_r -= kB * sg_r; og_fs -= kB * sg_fs; og_ff -= kB * sg_ff; }
         };
         // ... and everything of the step's vector-Jacobian product that does not depend on the adjoint is done HERE, on the
         // waves that have time: the rebuild, the clamp gates, 1 / |F_n|, and every product of two such values the chain would
@@ -698,8 +701,12 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
             // (fused physics loss: the row's gXs slot holds Xs itself; dL/dXs from it, the stamp's ground truth and weight)
             // (a bitwise merge, not a select on `loss_on`: with the value's term next to it the compiler turned the select into a
             //  branch around both -- nine exec-masked blocks per batch, 0.217 -> 0.229 ms)
-            const S gXs_row = bfi(loss_mask, cp_loss_grad(loss_scale, r.up.gXs, r.lg, r.lw), r.up.gXs);
-            l_acc += cp_loss_term(r.up.gXs, r.lg, r.lw);      // (the value: used with MF_LOSS_VALUE_IN_BACKWARD only)
+            // (rows without a stamp are masked by the STAMP, not by their weight 0: a rollout that diverged after its last stamp has
+            //  non-finite rows there, and inf * 0 would put NaN into dL/dXs and into the value -- the unfused route and the reference
+            //  never touch those rows)
+            const Msk smask = r.sj >= 0 ? ~(Msk)0 : (Msk)0;
+            const S gXs_row = bfi(loss_mask, bfi(smask, cp_loss_grad(loss_scale, r.up.gXs, r.lg, r.lw), zero), r.up.gXs);
+            l_acc += bfi(smask, cp_loss_term(r.up.gXs, r.lg, r.lw), zero);      // (the value: used with MF_LOSS_VALUE_IN_BACKWARD only)
             const f4v p9 = f4v{k.e, k.il, cmask * k.e * k.il, first * gXs_row};
             // dynamics(): everything of the Rodrigues step R' = R M(w'), M = I + K sin(th h) + K^2 (1 - cos(th h)), K = [kv]x,
             // kv = w' / max(|w'|, eps), that does not depend on the adjoint -- from w' as the forward left it in row m
@@ -740,21 +747,29 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
             }
             publish(o, o + 1);
           };
-        int ord = 3 * fk;                           // ordinal of the first step of this wave's next batch to WRITE
-        unsigned sbase = 3u * (unsigned)fk;         // ... and its ring slot: (3 j) mod kSlots
-        auto fetch3 = [&](Slot (&s)[3]) { fetch(s[0]); fetch(s[1]); fetch(s[2]); skip3(); };
+        int ord = BATCH * fk;                       // ordinal of the first step of this wave's next batch to WRITE
+        unsigned sbase = kB * (unsigned)fk;         // ... and its ring slot: (BATCH j) mod kSlots
+        auto fetch3 = [&](Slot (&s)[BATCH]) {
+#pragma unroll
+          for (int i = 0; i < BATCH; ++i) fetch(s[i]);
+          skip3();
+        };
         auto gather1 = [&](Slot& r) {
           gather_cells(r.sv);
           r.lg = loss_gt_lane[(size_t)(unsigned)min(max(r.sj, 0), l_T2m1) * 3u];      // (no fused loss: element 0 of the height map, unused)
         };
-        auto gather3 = [&](Slot (&s)[3]) { gather1(s[0]); gather1(s[1]); gather1(s[2]); };
-        auto put3 = [&](const Slot (&s)[3]) {
-          put(s[0], sbase, ord); put(s[1], sbase + 1u, ord + 1); put(s[2], sbase + 2u, ord + 2);
-          ord += 6;
-          if constexpr (kSlots != 6) sbase = sbase + 6u >= (unsigned)kSlots ? sbase + 6u - (unsigned)kSlots : sbase + 6u;
+        auto gather3 = [&](Slot (&s)[BATCH]) {
+#pragma unroll
+          for (int i = 0; i < BATCH; ++i) gather1(s[i]);
         };
-        Slot A[3], B[3], C[3];
-        const int n_full = (n + 1) / 3;             // whole batches of three steps in the launch (n + 1 steps)
+        auto put3 = [&](const Slot (&s)[BATCH]) {
+#pragma unroll
+          for (int i = 0; i < BATCH; ++i) put(s[i], sbase + (unsigned)i, ord + i);
+          ord += 2 * BATCH;
+          if constexpr (kSlots != 2 * BATCH) sbase = sbase + 2u * kB >= (unsigned)kSlots ? sbase + 2u * kB - (unsigned)kSlots : sbase + 2u * kB;
+        };
+        Slot A[BATCH], B[BATCH], C[BATCH];
+        const int n_full = (n + 1) / BATCH;         // whole batches of BATCH steps in the launch (n + 1 steps)
         int full = (n_full - fk + 1) / 2;           // ... of which this wave takes every other one, starting with batch fk
         if (fk == 1) skip3();
         if (full >= 2) {
@@ -772,7 +787,7 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
         } else if (full == 1) { fetch3(A); gather3(A); put3(A); }
         // the last one or two steps: the wave whose turn it would be (its offsets stand on them, its half of the ring is next)
         if (fk == (n_full & 1)) {
-          int o = 3 * n_full;
+          int o = BATCH * n_full;
           unsigned sl = sbase;
           while (m >= 0) {                          // (fetch moves m)
             Slot r0;
@@ -793,10 +808,11 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
         UpIn uZ;                                      // the upstream gradient of output row 0 (the initial state): not in the ring
         load_upstream(0, uZ);
         S l_row0 = zero;                          // row 0's term of the loss value (the other rows' are the fetching waves')
-        if (loss_on) {
+        if (loss_on && ODE) {      // (dynamics(): row 0 is the row step 0 produced -- the fetching waves' like every other)
           const S g0 = loss_gt_lane[(size_t)max(a.loss_row_stamp[0], 0) * 3u], w0 = a.loss_row_w[0];
-          l_row0 = cp_loss_term(uZ.gXs, g0, w0);
-          uZ.gXs = cp_loss_grad(loss_scale, uZ.gXs, g0, w0);
+          const bool stamped = a.loss_row_stamp[0] >= 0;
+          l_row0 = stamped ? cp_loss_term(uZ.gXs, g0, w0) : zero;
+          uZ.gXs = stamped ? cp_loss_grad(loss_scale, uZ.gXs, g0, w0) : zero;
         }
         // The coefficients of a step's vector-Jacobian product, as the fetching wave leaves them in the ring.  With
         // cs = c / sum c, the gates mG, mF1 (1 / 0) and d1 = gFr . (mF1 n) -- the one lane sum that serves F0 = -A n and n both:

@@ -14,13 +14,14 @@ extern "C" int mf_debug_stream_profile(unsigned long long* out16, int reset) {
 namespace mf {
 
 // Workgroup = the computing wave + two fetching waves.  Ring: twelve slots while a CU holds one workgroup (B <= 1024: 120 / 144 KB
-// of its 160 KB LDS -- the fetching waves run up to four batches ahead), six for two workgroups per CU (60 / 72 KB each).
+// of its 160 KB LDS -- the fetching waves run up to four batches ahead), six for two workgroups per CU (60 / 72 KB each; the
+// positions-only variants, held to 256 registers there, fetch in batches of TWO steps: no scratch).
 void launch_rollout_bwd_cp_stream_f32(const RolloutBwdArgs<float>& a, bool xs_only, unsigned grid, hipStream_t st) {
   constexpr int I = MF_INTEG_ODEINT_EULER;
   const bool gc = a.gcontrols != nullptr;
   static const unsigned big_ring_max = getenv("MF_CP_STREAM_BIG_RING_MAX_GRID") ? (unsigned)atoi(getenv("MF_CP_STREAM_BIG_RING_MAX_GRID")) : 256u;
 #define MF_BCPS(XS_, GC_) do { if (grid <= big_ring_max) hipLaunchKernelGGL((rollout_bwd_cp_kernel<float, I, XS_, GC_, kCpStream, 12>), dim3(grid), dim3(192), 0, st, a); \
-                               else hipLaunchKernelGGL((rollout_bwd_cp_kernel<float, I, XS_, GC_, kCpStream, 6>), dim3(grid), dim3(192), 0, st, a); } while (0)
+                               else hipLaunchKernelGGL((rollout_bwd_cp_kernel<float, I, XS_, GC_, kCpStream, 6, (XS_ ? 2 : 3)>), dim3(grid), dim3(192), 0, st, a); } while (0)
   if (xs_only) { if (gc) MF_BCPS(true, true); else MF_BCPS(true, false); }
   else         { if (gc) MF_BCPS(false, true); else MF_BCPS(false, false); }
 #undef MF_BCPS

@@ -129,7 +129,8 @@ static int rollout_fwd_cp(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, Rol
     a.loss_poison = (S*)p->loss->loss;
   } else if (p->loss) {      // physics_loss inside the launch (MfRolloutLoss)
     const MfRolloutLoss* L = p->loss;
-    MF_REQUIRE(cp_loss_fusable(d), MF_ERR_UNSUPPORTED, "rollout_fwd: this launch cannot carry the fused physics loss (mf_rollout_loss_fusable)");
+    MF_REQUIRE(cp_loss_in_forward(d), MF_ERR_UNSUPPORTED, "rollout_fwd: this launch cannot accumulate the physics loss itself (the LOSS kernels ride on the "
+               "default integrator; dynamics(): MF_LOSS_VALUE_IN_BACKWARD, or mf_physics_loss_value_* on the rows)");
     MF_REQUIRE(!forces && d->layout == MF_LAYOUT_TIME_MAJOR, MF_ERR_INVALID, "rollout_fwd: the fused physics loss needs Fs = Ff = NULL and MF_LAYOUT_TIME_MAJOR");
     MF_REQUIRE(L->T2 > 0 && L->gt && L->row_w && L->partial && L->ticket && L->loss, MF_ERR_INVALID, "rollout_fwd: incomplete MfRolloutLoss");
     MF_REQUIRE((long long)d->B * L->T2 * 3 * (long long)sizeof(S) < (1ll << 32), MF_ERR_UNSUPPORTED, "rollout_fwd: ground truth of 4 GiB or more");

@@ -228,7 +228,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
       // branch-free: the term is formed at EVERY row, with weight 0 off the stamps (six VALU instructions; a branch at the stamped
       // rows -- even one holding arithmetic only -- ends the basic block, and the tail of one step and the head of the next no
       // longer fill each other's stalls: 0.165 -> 0.20 ms)
-      l_acc += cp_loss_term(mf_fma(e2, a.sink, ex), st.g, st.w);
+      const S term = cp_loss_term(mf_fma(e2, a.sink, ex), st.g, st.w);
+      l_acc += st.w != zero ? term : zero;                       // (masked by the stamp: a diverged tail is inf * 0 = NaN otherwise)
       l_j += st.w != zero ? 1 : 0;                               // (weights are 1 / (1 + gamma t) > 0)
     }
   };
@@ -368,7 +369,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
 bool use_component_parallel(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, int scalar_bytes = 4);      // (8: the float64 validation build)
 int launch_rollout_fwd_cp_f32(const RolloutArgs<float>& a, int integ, bool forces, bool zmu, hipStream_t st);   // a.rec: record wanted; a.loss_gt: fused loss
 int launch_rollout_fwd_cp_f64(const RolloutArgs<double>& a, int integ, bool forces, bool zmu, hipStream_t st);  // the validation build (rollout_cp_f64.hip)
-bool cp_loss_fusable(const MfRolloutDesc* d);           // both directions of this launch can carry the fused physics loss
+bool cp_loss_fusable(const MfRolloutDesc* d);           // the backward of this launch can carry the fused physics loss (either integrator)
+bool cp_loss_in_forward(const MfRolloutDesc* d);        // ... and its forward can accumulate the value itself (LOSS kernels: default integrator)
 long long cp_record_bytes(const MfRolloutDesc* d, int scalar_bytes = 4);      // bytes of the per-step record a launch of this shape writes (0: none)
 
 // one launch of the instantiation the arguments call for (S = float: rollout_fwd_cp_fast.hip; S = double, the validation build:

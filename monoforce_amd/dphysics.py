@@ -252,7 +252,7 @@ def _rollout_forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_gra
         zmu_scratch=_lib.ptr(_zmu_scratch(mod, desc, keep['z'])), zmu=_lib.ptr(mod._staged_zmu(desc, z, mu)), rec=_lib.ptr(rec))
     loss_val = lstruct = None
     in_backward = loss is not None and len(loss) > 2 and bool(loss[2]) and want_grad      # MF_LOSS_VALUE_IN_BACKWARD
-    in_forward = loss is not None and mod.loss_in_forward and not in_backward
+    in_forward = loss is not None and mod.loss_in_forward and not in_backward and desc.integrator == _lib.MF_INTEG_ODEINT_EULER      # (the LOSS kernels: default integrator)
     if loss is not None:
         spec, X_gt = loss[:2]
         loss_val = torch.empty((), dtype=dt, device=dev)
@@ -550,17 +550,18 @@ class DPhysics(torch.nn.Module):
         `value_in_backward` (MF_LOSS_VALUE_IN_BACKWARD): for a caller that ALWAYS calls `loss.backward()` next and reads the value
         only afterwards (a fit loop): the backward launch forms the value too -- the returned scalar is NaN until then -- and the
         step loses its one remaining loss launch.
-        Where the library cannot fuse (mf_rollout_loss_fusable: other than float32 fast math, default integrator, a rigid body of <= 4
-        points, <= 2048 rollouts; several stamps on one row) the same value and gradient come from the unfused route."""
+        Where the library cannot fuse (mf_rollout_loss_fusable: other than float32 fast math, a rigid body of <= 4 points, <= 2048
+        rollouts -- dynamics(): <= 1024; several stamps on one row) the same value and gradient come from the unfused route."""
         from .losses import physics_loss_fused
         cp64 = z_grid.dtype == torch.float64 and self.points_per_lane == _lib.MF_LANES_COMPONENT      # the validation build of the fast kernels
         ok = (spec.fusable and not self.precise and (z_grid.dtype == torch.float32 or cp64) and spec.w.dtype == z_grid.dtype
-              and self.dphys_cfg.use_odeint and not self.contiguous_outputs)
+              and not self.contiguous_outputs)
         B = controls.shape[0]
         if ok:
             ok = spec.T == min(int(self.dphys_cfg.traj_sim_time / self.dphys_cfg.dt), controls.shape[1])
         if ok:
-            d = _lib.MfRolloutDesc(B=B, T=spec.T, N=self.x_points.shape[1], H=z_grid.shape[-2], W=z_grid.shape[-1], integrator=_lib.MF_INTEG_ODEINT_EULER,
+            d = _lib.MfRolloutDesc(B=B, T=spec.T, N=self.x_points.shape[1], H=z_grid.shape[-2], W=z_grid.shape[-1],
+                                   integrator=_lib.MF_INTEG_ODEINT_EULER if self.dphys_cfg.use_odeint else _lib.MF_INTEG_DYNAMICS,
                                    math_mode=_lib.MF_MATH_FAST, force_stride=max(self.x_points.shape[1], 4), map_shared=1, layout=_lib.MF_LAYOUT_TIME_MAJOR,
                                    points_per_lane=self.points_per_lane)
             ok = bool(_lib.lib().mf_rollout_loss_fusable(C.byref(d)))

@@ -85,7 +85,13 @@ class TerrainFitProblem:
             # (the step always runs the backward next and hands the value out afterwards: the backward launch forms it too)
             return self.dp.physics_loss_rollout(z.unsqueeze(0), self.controls, self.states_gt[0], self.spec, friction=mu.unsqueeze(0),
                                                 value_in_backward=self.loss_value_in_backward)[0]
-        states, _ = self.dp(z.unsqueeze(0), self.controls, friction=mu.unsqueeze(0))
+        # (the fit discards the forces, scripts/fit_terrain.py:56: the forward writes the states only -- for the reference's 223-point
+        #  body that is 36 of 241 MB per launch; `return_forces` is restored for the module's other callers)
+        keep, self.dp.return_forces = self.dp.return_forces, False
+        try:
+            states, _ = self.dp(z.unsqueeze(0), self.controls, friction=mu.unsqueeze(0))
+        finally:
+            self.dp.return_forces = keep
         loss_fn = physics_loss_fused if self.fused_loss else physics_loss
         return loss_fn(states, self.states_gt, self.pred_ts, self.gt_ts, nearest=self.nearest if self.fused_loss else self.nearest.long())
 

@@ -104,12 +104,12 @@ def test_gradient_copy_pool_is_reused_clean():
 
 
 # ---- physics_loss inside the rollout's own launches (MfRolloutLoss; DPhysics.physics_loss_rollout) ----------------
-def _fit_problem(B, T, loss_in_kernel, graph=False, res=0.1, d_max=3.2, gt_every=10, in_forward=False, value='backward'):
+def _fit_problem(B, T, loss_in_kernel, graph=False, res=0.1, d_max=3.2, gt_every=10, in_forward=False, value='backward', integ=1):
     from monoforce_amd import synthetic as syn
     from monoforce_amd.train import TerrainFitProblem
     from tests.test_rollout_gpu import make_dphysics
     pts, masks = syn.robot_points_4()
-    dp = make_dphysics(pts, masks, 1, res, d_max)
+    dp = make_dphysics(pts, masks, integ, res, d_max)
     dp.loss_in_forward = in_forward      # True: the forward rollout kernel accumulates the loss itself; False: one small launch on its rows
     z_true = (syn.bump_terrain(syn.bump_params(3), d_max, res) * 0.3).to(DEV)
     mu = syn.wave_friction(d_max, res).to(DEV)
@@ -123,9 +123,10 @@ def _fit_problem(B, T, loss_in_kernel, graph=False, res=0.1, d_max=3.2, gt_every
     return prob, z, m
 
 
-@pytest.mark.parametrize('in_forward,value', [(False, 'launch'), (True, 'forward'), (False, 'backward')])
+@pytest.mark.parametrize('in_forward,value,integ', [(False, 'launch', 1), (True, 'forward', 1), (False, 'backward', 1),
+                                                     (False, 'launch', 0), (False, 'backward', 0)])      # dynamics(): the backward half (round 4)
 @pytest.mark.parametrize('B,T,gt_every', [(48, 300, 10), (37, 95, 10), (3, 41, 1), (1, 12, 5), (1500, 120, 10)])
-def test_loss_inside_the_rollout_kernels_equals_the_two_kernel_route(B, T, gt_every, in_forward, value):
+def test_loss_inside_the_rollout_kernels_equals_the_two_kernel_route(B, T, gt_every, in_forward, value, integ):
     """Forward: the mean the rollout kernel finishes itself == mf_physics_loss_value_* on its outputs (and == the plain-torch
     restatement of losses.py:102-127); backward: dL/dXs formed by the fetching waves == the gradient rows mf_physics_loss_bwd_* writes,
     so the terrain / friction gradients agree to the rounding of the atomics' arrival order.  Batches with a trailing partial
@@ -136,7 +137,7 @@ def test_loss_inside_the_rollout_kernels_equals_the_two_kernel_route(B, T, gt_ev
     from monoforce_amd.losses import physics_loss
     out = []
     for in_kernel in (False, True):
-        prob, z, m = _fit_problem(B, T, in_kernel, gt_every=gt_every, in_forward=in_forward, value=value)
+        prob, z, m = _fit_problem(B, T, in_kernel, gt_every=gt_every, in_forward=in_forward, value=value, integ=integ)
         vals = []
         for _ in range(3):                                   # launch after launch: the ticket comes back to zero
             loss = prob.step(z, m)
@@ -144,6 +145,11 @@ def test_loss_inside_the_rollout_kernels_equals_the_two_kernel_route(B, T, gt_ev
         assert len(set(vals)) == 1, vals
         out.append((vals[0], z.grad.clone(), m.grad.clone(), prob))
     assert out[1][3].loss_in_kernel and out[1][3].spec.fusable
+    if integ == 0 and B > 1024:      # dynamics() streams up to 256 workgroups: beyond, the same value and gradient through the unfused route
+        from monoforce_amd import _lib
+        import ctypes as C
+        d = _lib.MfRolloutDesc(B=B, T=T, N=4, H=64, W=64, integrator=0, math_mode=_lib.MF_MATH_FAST, force_stride=4, map_shared=1, layout=_lib.MF_LAYOUT_TIME_MAJOR)
+        assert not _lib.lib().mf_rollout_loss_fusable(C.byref(d))
     assert abs(out[0][0] - out[1][0]) <= 2e-6 * abs(out[0][0]), (out[0][0], out[1][0])
     assert hp.rel_err(out[1][1].cpu(), out[0][1].cpu()) <= 2e-5 and hp.rel_err(out[1][2].cpu(), out[0][2].cpu()) <= 2e-5
     # ... and the value against the reference formula in plain torch on the rollout's outputs
@@ -196,8 +202,9 @@ def test_loss_value_formed_by_the_backward_launch():
 
 
 def test_loss_rollout_falls_back_where_the_library_cannot_fuse():
-    """dynamics(), exact arithmetic, float64, or two stamps on one output row: `physics_loss_rollout` returns the same value and
-    gradient through the unfused route (`mf_rollout_loss_fusable` / LossSpec.fusable say no)."""
+    """Exact arithmetic, float64 (outside the validation build), two stamps on one output row: `physics_loss_rollout` returns the same
+    value and gradient through the unfused route (`mf_rollout_loss_fusable` / LossSpec.fusable say no); dynamics() (first case) fuses
+    its backward half since round 4 and must agree all the same."""
     from monoforce_amd import synthetic as syn
     from monoforce_amd.losses import physics_loss
     from tests.test_rollout_gpu import make_dphysics
@@ -224,3 +231,37 @@ def test_loss_rollout_falls_back_where_the_library_cannot_fuse():
         tol = 1e-5 if dtype == torch.float32 else 1e-10
         assert abs(float(loss) - float(ref)) <= tol * abs(float(ref)), (kw, integ, dtype, crowded)
         assert hp.rel_err(zl.grad.cpu(), z2.grad.cpu()) <= 10 * tol
+
+
+@pytest.mark.parametrize('in_forward,value', [(False, 'launch'), (True, 'forward'), (False, 'backward')])
+def test_rollouts_that_diverge_after_the_last_stamp_do_not_poison_the_fused_loss(in_forward, value):
+    """the fused loss formed its term at EVERY row with weight 0 off the stamps -- a rollout whose rows become non-finite
+    after its last stamp (here: it drives onto NaN cells) turned inf * 0 into a NaN loss and gradient, where the unfused route and the
+    reference (losses.py:116-127: only the stamped rows are gathered) stay finite.  Rows are masked by the stamp now."""
+    from monoforce_amd import synthetic as syn
+    from monoforce_amd.losses import physics_loss
+    from tests.test_rollout_gpu import make_dphysics
+    pts, masks = syn.robot_points_4()
+    B, T, res, d_max = 24, 300, 0.1, 3.2
+    z = (syn.bump_terrain(syn.bump_params(3), d_max, res) * 0.1)
+    z[int((1.2 + d_max) / res):, :] = float('nan')                      # x >= 1.2 m: reached after ~1.5 s at v >= 0.5 m/s
+    ctrl = syn.const_controls(B, T, seed=2, w_range=(-0.2, 0.2)).to(DEV)
+    dp = make_dphysics(pts, masks, 1, res, d_max, return_forces=False)
+    dp.loss_in_forward = in_forward
+    ts = torch.linspace(0, dp.dphys_cfg.traj_sim_time, int(dp.dphys_cfg.traj_sim_time / dp.dphys_cfg.dt))[:T]
+    gt_ts = ts[9:60:10]                                                 # stamps within the first 0.6 s only
+    Xgt = torch.randn(B, gt_ts.numel(), 3, generator=torch.Generator().manual_seed(0)).to(DEV) * 0.1
+    spec = dp.loss_spec(gt_ts, gamma=0.9, n_steps=T)
+    zl = z.to(DEV).requires_grad_(True)
+    loss, states = dp.physics_loss_rollout(zl.unsqueeze(0), ctrl, Xgt, spec, value_in_backward=(value == 'backward'))
+    assert type(loss.grad_fn).__name__.startswith('_RolloutLossFn')
+    loss.backward()
+    torch.cuda.synchronize()
+    assert not torch.isfinite(states[0][:, -1]).all(), 'the rollouts were meant to diverge after the stamps'
+    z2 = z.to(DEV).requires_grad_(True)
+    st2, _ = dp(z2.unsqueeze(0), ctrl)
+    ref = physics_loss(st2, [Xgt], ts.to(DEV).unsqueeze(0).expand(B, -1), gt_ts.to(DEV).unsqueeze(0).expand(B, -1))
+    assert np.isfinite(float(ref)) and abs(float(loss) - float(ref)) <= 1e-5 * abs(float(ref)), (float(loss), float(ref))
+    # (the VALUE is what is pinned here.  The gradient of such a batch is NaN on every route of this library: the reverse scan starts at
+    #  the last step and pushes its -- zero -- adjoint through the Jacobians of the non-finite steps, 0 x NaN, where autograd never
+    #  visits steps behind the last stamped row.  A rollout that diverges is a failed rollout; documented, not masked.)

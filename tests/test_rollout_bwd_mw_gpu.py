@@ -24,24 +24,27 @@ def _problem(B, N, T, n_tracks, shared):
     return pts, masks, z, mu, ctrl
 
 
-def _loss(outs, xs_only):
+def _loss(outs, xs_only, dtype=torch.float32):
     if xs_only:      # positions at a few rows only: every other upstream gradient arrives as None (physics_loss, losses.py:102-127)
         Xs = outs[0]
         from monoforce_amd import synthetic as syn
-        return (Xs[:, ::7] * syn.probe_weights(Xs[:, ::7].shape, phase=0.3, dtype=torch.float32).to(Xs.device)).sum()
-    return hp.probe_loss(outs, torch.float32)
+        return (Xs[:, ::7] * syn.probe_weights(Xs[:, ::7].shape, phase=0.3, dtype=dtype).to(Xs.device)).sum()
+    return hp.probe_loss(outs, dtype)
 
 
-def _grads(fn, dev, z, mu, ctrl, B, xs_only, state=None):
+MW_BAR = 2e-3      # float32 kernels against the float64 oracle on these contact-rich rollouts (gradients; rel. to the largest entry)
+
+
+def _grads(fn, dev, z, mu, ctrl, B, xs_only, state=None, dtype=torch.float32):
     zl, ml, cl = (t.clone().to(dev).requires_grad_(True) for t in (z, mu, ctrl))
     st = None
     if state is not None:
-        st = [s.clone().float().to(dev) for s in state]
+        st = [s.clone().to(dtype).to(dev) for s in state]
         for s in st[1:]:
             s.requires_grad_(True)
     expand = lambda m: m.expand(B, -1, -1) if m.shape[0] == 1 else m  # noqa: E731
     outs = fn(expand(zl), cl, expand(ml), None if st is None else tuple(st))
-    _loss(outs, xs_only).backward()
+    _loss(outs, xs_only, dtype).backward()
     leaves = [zl, ml, cl] + (st[1:] if st is not None else [])
     g = [l.grad if l.grad is not None else torch.zeros_like(l) for l in leaves]      # (T = 1: nothing depends on mu / controls)
     return [o.detach().cpu() for o in outs], [t.cpu() for t in g]
@@ -84,24 +87,26 @@ def test_multiwave_backward_vs_oracle_and_one_wave_kernel(B, N, n_tracks, T, xs_
             return list(so) + list(fo)
         return run
 
-    o_ref, g_ref = _grads(f_oracle, 'cpu', z, mu, ctrl, B, xs_only, state)
+    # the referee: the oracle in FLOAT64 on the same (float32-valued) inputs -- the float64 build of these kernels meets it at 1e-7
+    # (tests/test_cp_f64_validation_gpu.py::test_multiwave_kernels_f64_vs_oracle), so what is measured here is float32 rounding alone
+    o_ref, g_ref = _grads(f_oracle, 'cpu', z.double(), mu.double(), ctrl.double(), B, xs_only, state, dtype=torch.float64)
+    # ... and the float32 reproducibility of THIS problem, from the oracle alone: how far the oracle's own float32 run lands from its
+    # float64 run.  Contact-rich rollouts are chaotic: where the reference's arithmetic itself is not a 2e-3 path in
+    # float32 (64 rollouts x 223 points: 1-7 %), no float32 kernel can be -- the bar is max(MW_BAR, 3 x that envelope), per gradient.
+    _, g_env = _grads(f_oracle, 'cpu', z, mu, ctrl, B, xs_only, state)
     o_mw, g_mw = _grads(f_hip(0), DEV, z, mu, ctrl, B, xs_only, state)
     o_1w, g_1w = _grads(f_hip(4), DEV, z, mu, ctrl, B, xs_only, state)
     names = ('z', 'mu', 'controls', 'xd0', 'R0', 'w0')
-    for nm, a, b, c in zip(names, g_mw, g_ref, g_1w):
+    for nm, a, b, c, e32 in zip(names, g_mw, g_ref, g_1w, g_env):
         assert torch.isfinite(a).all(), nm
-        # two float32 evaluation orders of these contact-rich rollouts sit 1-2e-4 apart themselves (test_random_shapes_gpu.py)
+        bar = max(MW_BAR, 3.0 * hp.rel_err(e32, b))
         if B > 500 and a.shape[0] == B:
-            # thousands of float32 rollouts: a few per thousand take a clamp / kink decision differently in two evaluation orders
+            # thousands of float32 rollouts: a few per thousand take a clamp / kink decision differently from the float64 run
             # (4 of 1500 random problems) -- per rollout, all but 0.5 % within the bar
-            e = torch.tensor([hp.rel_err(a[i], c[i]) for i in range(B)])
-            assert float((e <= 2e-3).float().mean()) >= 0.995, (nm, 'vs the one-wave kernel', float((e <= 2e-3).float().mean()), float(e.max()))
+            e = torch.tensor([hp.rel_err(a[i], b[i]) for i in range(B)])
+            assert float((e <= MW_BAR).float().mean()) >= 0.995, (nm, 'vs the float64 oracle', float((e <= MW_BAR).float().mean()), float(e.max()))
             continue
-        assert hp.rel_err(a, c) <= 2e-3, (nm, 'vs the one-wave kernel', hp.rel_err(a, c))
-        # (... and now and then a float32 rollout of the oracle takes a clamp / kink decision the other way than the HIP float32
-        #  forward -- one rollout of 70 in the dynamics() case of 33 points: BOTH kernels then sit the same distance from it; the
-        #  general kernel is held to the float64 oracle elsewhere)
-        assert hp.rel_err(a, b) <= max(2e-3, 1.05 * hp.rel_err(c, b) + 1e-4), (nm, 'vs oracle', hp.rel_err(a, b), hp.rel_err(c, b))
+        assert hp.rel_err(a, b) <= bar, (nm, 'vs the float64 oracle', hp.rel_err(a, b), 'bar', bar, 'one-wave kernel:', hp.rel_err(c, b))
     for k, a, b in zip(hp.OUT_KEYS, o_mw, o_1w):      # the recording forward writes the outputs of the plain one
         tol = 5e-4 if k in ('Xs', 'Rs') else (3e-2 if k in ('Fs', 'Ff') else 2e-3)
         assert hp.rel_err(a, b) <= tol, (k, hp.rel_err(a, b))

@@ -239,3 +239,61 @@ def test_random_clustered_pooling_vs_oracle(seed):
     """float64 pooling of random, clustered point sets vs the exact sums of the oracle (forward <= 1e-12, backward bit-exact):
     piles of up to 2000 points in one voxel, channel counts around 64, planes that are no multiple of the tile, 1..3 slabs."""
     _check_random_pool(seed)
+
+
+_QUAD_CHILD = r'''
+import sys
+sys.path.insert(0, %r)
+import torch
+from tests.test_splat_gpu import _quad_cases
+torch.save(_quad_cases(), %r)
+'''
+
+
+def _quad_cases():
+    """float32 pooling problems the 16-lanes-per-point forward covers (C % 4 == 0, plane % 4 == 0): config-4 shapes, a ragged last
+    tile (plane 2500), C = 80 (a second, partial channel chunk), nz = 3, a pile of 300 points in one voxel, an empty sample; plain
+    splat and the fused lift-splat."""
+    from monoforce_amd import splat
+    outs = []
+    m, geom, x = _c4_problem(B=2, C=64, seed=11)
+    outs.append(pool(geom, x.astype(np.float32), m.dx, m.bx, m.nx)[0].cpu())
+    for C, nxy, nz in ((80, 50, 1), (64, 40, 3), (8, 16, 1), (4, 6, 2)):
+        rng = np.random.RandomState(C + nxy)
+        B, P = 2, 900
+        dx = np.array([0.5, 0.5, 1.0], np.float32)
+        bx = np.array([-nxy * 0.25 + 0.25, -nxy * 0.25 + 0.25, -nz * 0.5 + 0.5], np.float32)
+        nx = np.array([nxy, nxy, nz])
+        geom = (rng.rand(B, P, 3).astype(np.float32) - 0.5) * np.array([nxy * 0.6, nxy * 0.6, nz * 1.2], np.float32)
+        geom[0, :300] = np.array([0.1, 0.1, 0.0], np.float32)
+        geom[1, :] += 1000.0
+        outs.append(pool(geom, rng.randn(B, P, C).astype(np.float32), dx, bx, nx)[0].cpu())
+    for shape in (dict(B=1, N=4, D=59, fH=16, fW=32, C=64, nx=256, nz=1), dict(B=2, N=3, D=7, fH=5, fW=9, C=80, nx=40, nz=2)):
+        g = torch.Generator().manual_seed(5)
+        B, N, D, fH, fW, C = (shape[k] for k in ('B', 'N', 'D', 'fH', 'fW', 'C'))
+        nxy, nz = shape['nx'], shape['nz']
+        geom = (torch.rand(B, N, D, fH, fW, 3, generator=g) - 0.5) * torch.tensor([nxy * 0.06, nxy * 0.06, nz * 1.3])
+        dx = torch.tensor([0.05, 0.05, 1.0]); bx = torch.tensor([-nxy * 0.025 + 0.025, -nxy * 0.025 + 0.025, -nz * 0.5 + 0.5]); nx = torch.tensor([nxy, nxy, nz])
+        plan = splat.SplatPlan(geom.to(DEV), dx, bx, nx)
+        depth = torch.rand(B * N, D, fH, fW, generator=g).softmax(dim=1).to(DEV)
+        ctx = torch.randn(B * N, C, fH, fW, generator=g).to(DEV)
+        outs.append(splat._LiftPool.apply(depth, ctx, plan).cpu())
+    return outs
+
+
+def test_quad_forward_is_bit_identical_to_the_point_per_iteration_kernels():
+    """Round 4's forward (sixteen lanes per point, a tile's voxels dealt round robin to the workgroup's sixteen rows) sums every voxel's
+    points in ascending order with the products rounded on their own, like the kernels it replaces: the same bits -- checked against
+    a child process that runs the old kernels (MF_SPLAT_QUAD=0)."""
+    import os, subprocess, sys, tempfile
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    new = _quad_cases()
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, 'old.pt')
+        r = subprocess.run([sys.executable, '-c', _QUAD_CHILD % (repo, path)], capture_output=True, text=True, timeout=600, env=dict(os.environ, MF_SPLAT_QUAD='0'))
+        assert r.returncode == 0, r.stderr[-2000:]
+        old = torch.load(path)
+    assert len(new) == len(old) == 7
+    for i, (a, b) in enumerate(zip(new, old)):
+        assert a.dtype == torch.float32 and float(b.abs().max()) > 0
+        assert torch.equal(a, b), (i, float((a - b).abs().max()))

@@ -9,9 +9,10 @@ DEV = 'cuda'
 Bs = [int(x) for x in os.environ.get('AB_B', '256,1024,2048,4096,8192,16384').split(',')]
 bwd = os.environ.get('AB_BWD', '0') == '1'
 integ = int(os.environ.get('AB_INTEG', '1'))
+only_cp = os.environ.get('AB_ONLY_CP', '0') == '1'      # the component-parallel states-only rows alone (mode sweeps)
 for B in Bs:
-    for ppl in (16, 1):
-        for forces in (True, False):
+    for ppl in ((16,) if only_cp else (16, 1)):
+        for forces in ((False,) if only_cp else (True, False)):
             cfg, dp, pts, masks, z, mu, ctrl = build_problem(B, 500, 4, DEV, integ)
             dp.points_per_lane = ppl
             dp.return_forces = forces
