@@ -306,24 +306,26 @@ __global__ void __launch_bounds__(256) splat_fwd_quad_kernel(const float* __rest
         if (cc < nch) {
           float* o = out + ((size_t)bz * C + c0 + cc) * plane + vid0 + 4 * q;
           if (nvox == kTileVox) __builtin_nontemporal_store(zero4, reinterpret_cast<f4*>(o));
-          else { for (int j = 0; j < 4; ++j) if (4 * q + j < nvox) o[j] = 0.f; }
+          else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (4 * q + j < nvox) o[j] = 0.f;
+          }
         }
       }
     }
     return;
   }
-  // this row's four voxels: bounds through the LDS crossbar (ds_bpermute), prefix counts of its virtual point stream
-  int ob[4], pre[5];
-  pre[0] = 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int v = gid + 16 * j;
-    const int o = __shfl(off_l, min(v, 63), 64);
-    const int e = v + 1 < 64 ? __shfl(off_l, min(v + 1, 63), 64) : off_end;
-    ob[j] = o;
-    pre[j + 1] = pre[j] + (v < nvox ? e - o : 0);
-  }
-  const int n_row = pre[4];
+  // this row's four voxels: prefix counts of its virtual point stream
+  // (the bounds go through LDS -- one wave's LDS operations execute in order, no barrier: lane l's off_l, then the tile's end)
+  __shared__ int offs_sh[4][kTileVox + 1];
+  offs_sh[wave][lane] = off_l;
+  offs_sh[wave][kTileVox] = off_end;
+  const int o0 = offs_sh[wave][gid], o1 = offs_sh[wave][gid + 16], o2 = offs_sh[wave][gid + 32], o3 = offs_sh[wave][gid + 48];
+  const int p1 = gid < nvox ? offs_sh[wave][gid + 1] - o0 : 0;
+  const int p2 = p1 + (gid + 16 < nvox ? offs_sh[wave][gid + 17] - o1 : 0);
+  const int p3 = p2 + (gid + 32 < nvox ? offs_sh[wave][gid + 33] - o2 : 0);
+  const int p4 = p3 + (gid + 48 < nvox ? offs_sh[wave][gid + 49] - o3 : 0);
+  const int n_row = p4;
   // chunks of sixteen stream slots until the busiest row of the wave is through
   int n_max = max(n_row, __shfl_xor(n_row, 16, 64));
   n_max = __builtin_amdgcn_readfirstlane(max(n_max, __shfl_xor(n_max, 32, 64)));
@@ -333,15 +335,27 @@ __global__ void __launch_bounds__(256) splat_fwd_quad_kernel(const float* __rest
 #pragma unroll
     for (int j = 0; j < 4; ++j) *reinterpret_cast<f4*>(&tile[(gid + 16 * j) * kQPitch + 4 * q]) = zero4;
     f4 acc = zero4;
+    // this lane's stream slot of the chunk at K0: its point id (slots past the end read a valid id and are masked) and flags.  Which
+    // of the row's four voxels the slot falls into is decided by nested selects on scalars (indexing prefix / offset arrays with a
+    // computed j -- or a lambda capturing them -- made the compiler keep them in scratch memory).
+#define MF_SPLAT_SLOT(K0, PID, META)                                                                       \
+    {                                                                                                      \
+      const int sl = (K0) + q;                                                                             \
+      const bool valid = sl < n_row;                                                                       \
+      const bool c1 = sl >= p1, c2 = sl >= p2, c3 = sl >= p3;                                              \
+      const int pj = c3 ? p3 : (c2 ? p2 : (c1 ? p1 : 0));                                                  \
+      const int pn = c3 ? p4 : (c2 ? p3 : (c1 ? p2 : p1));                                                 \
+      const int oj = c3 ? o3 : (c2 ? o2 : (c1 ? o1 : o0));                                                 \
+      const int vj = gid + (c3 ? 48 : (c2 ? 32 : (c1 ? 16 : 0)));                                          \
+      META = vj | (valid ? 0x100 : 0) | (sl + 1 == pn ? 0x400 : 0);                                        \
+      PID = list[valid ? oj + (sl - pj) : off_beg];                                                        \
+    }
+    // (measured and not kept: the point ids of chunk k + 1 requested behind the row loads of chunk k -- one dependent round trip per
+    //  chunk instead of two, but 138 registers instead of 122, i.e. three workgroups per CU instead of four: 25 -> 29 us at B = 1,
+    //  71 -> 88 us at B = 8.  The kernel is bound by its instruction issue, which more resident waves fill better.)
     for (int k0 = 0; k0 < n_max; k0 += 16) {
-      const int sl = k0 + q;                                     // this lane's stream slot
-      const bool valid = sl < n_row;
-      const int j = (sl >= pre[1] ? 1 : 0) + (sl >= pre[2] ? 1 : 0) + (sl >= pre[3] ? 1 : 0);
-      const int pj = j == 0 ? 0 : (j == 1 ? pre[1] : (j == 2 ? pre[2] : pre[3]));
-      const int pn = j == 0 ? pre[1] : (j == 1 ? pre[2] : (j == 2 ? pre[3] : pre[4]));
-      const int oj = j == 0 ? ob[0] : (j == 1 ? ob[1] : (j == 2 ? ob[2] : ob[3]));
-      const int pid = list[valid ? oj + (sl - pj) : off_beg];    // (slots past the end read a valid id and are masked)
-      int meta_l = (gid + 16 * j) | (valid ? 0x100 : 0) | (sl == pj ? 0x200 : 0) | (sl + 1 == pn ? 0x400 : 0);
+      int pid, meta_l;
+      MF_SPLAT_SLOT(k0, pid, meta_l)
       float w_l = 1.0f;
       int row_l = pid;
       if constexpr (WEIGHTED) { w_l = weight[pid]; row_l = (pid / d_hw) * hw + pid % hw; }
@@ -359,11 +373,11 @@ __global__ void __launch_bounds__(256) splat_fwd_quad_kernel(const float* __rest
         if (meta & 0x100) {                                  /* row-uniform: all sixteen lanes of the row agree */  \
           f4 pr = val[I];                                                                                          \
           if constexpr (WEIGHTED) { pr.x = mul_rounded(wi, pr.x); pr.y = mul_rounded(wi, pr.y); pr.z = mul_rounded(wi, pr.z); pr.w = mul_rounded(wi, pr.w); } \
-          const f4 sum = acc + pr;                                                                                 \
-          acc = (meta & 0x200) ? (zero4 + pr) : sum;         /* first point of its voxel: 0 + x, as the kernels above */ \
-          if (meta & 0x400) {                                /* last point of its voxel: its sum goes to the tile */ \
+          acc = acc + pr;                                    /* (a voxel's first point: 0 + x, as the kernels above) */ \
+          if (meta & 0x400) {                                /* last point of its voxel: its sum goes to the tile, the next starts at 0 */ \
             const int v = meta & 0xff;                                                                             \
             *reinterpret_cast<f4*>(&tile[v * kQPitch + ((4 * q + 4 * (v >> 2)) & 63)]) = acc;                      \
+            acc = zero4;                                                                                           \
           }                                                                                                        \
         }                                                                                                          \
       }
@@ -374,12 +388,12 @@ __global__ void __launch_bounds__(256) splat_fwd_quad_kernel(const float* __rest
         const float wi = row_share_f<0>(w_l);
         f4 pr = val[0];
         if constexpr (WEIGHTED) { pr.x = mul_rounded(wi, pr.x); pr.y = mul_rounded(wi, pr.y); pr.z = mul_rounded(wi, pr.z); pr.w = mul_rounded(wi, pr.w); }
-        const f4 sum = acc + pr;
-        const f4 cand = (meta & 0x200) ? (zero4 + pr) : sum;
-        acc = (meta & 0x100) ? cand : acc;
+        const f4 sum = acc + pr;                             // (a voxel's first point: acc is 0, the sum is 0 + x as in the kernels above)
+        acc = (meta & 0x100) ? sum : acc;
         if ((meta & 0x500) == 0x500) {
           const int v = meta & 0xff;
           *reinterpret_cast<f4*>(&tile[v * kQPitch + ((4 * q + 4 * (v >> 2)) & 63)]) = acc;
+          acc = zero4;
         }
       }
       MF_SPLAT_POINT(1) MF_SPLAT_POINT(2) MF_SPLAT_POINT(3) MF_SPLAT_POINT(4) MF_SPLAT_POINT(5) MF_SPLAT_POINT(6) MF_SPLAT_POINT(7)
@@ -399,7 +413,12 @@ __global__ void __launch_bounds__(256) splat_fwd_quad_kernel(const float* __rest
       if (cc < nch) {
         float* o = out + ((size_t)bz * C + c0 + cc) * plane + vid0 + 4 * q;
         if (nvox == kTileVox) __builtin_nontemporal_store(r, reinterpret_cast<f4*>(o));
-        else { const float rr[4] = {r.x, r.y, r.z, r.w}; for (int j = 0; j < 4; ++j) if (4 * q + j < nvox) o[j] = rr[j]; }
+        else {      // a ragged last tile: element by element (no indexed copy of r: that would live in scratch memory)
+          if (4 * q + 0 < nvox) o[0] = r.x;
+          if (4 * q + 1 < nvox) o[1] = r.y;
+          if (4 * q + 2 < nvox) o[2] = r.z;
+          if (4 * q + 3 < nvox) o[3] = r.w;
+        }
       }
     }
     __syncthreads();
@@ -616,13 +635,14 @@ __global__ void __launch_bounds__(256) lift_splat_bwd_rows_quad_kernel(const flo
   const int off_end = offsets[key0 + nvox];
   if (__builtin_amdgcn_readfirstlane(off_end) == __builtin_amdgcn_readfirstlane(off_l)) return;      // no points: the gather never reads this tile
   const int q = lane & 15, g = lane >> 4, gid = wave * 4 + g;
+  __shared__ int offs_sh[4][kTileVox + 1];      // (one wave's LDS operations execute in order: no barrier)
+  offs_sh[wave][lane] = off_l;
+  offs_sh[wave][kTileVox] = off_end;
   bool occ[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int v = gid + 16 * j;
-    const int o = __shfl(off_l, min(v, 63), 64);
-    const int e = v + 1 < 64 ? __shfl(off_l, min(v + 1, 63), 64) : off_end;
-    occ[j] = v < nvox && e > o;
+    occ[j] = v < nvox && offs_sh[wave][v + 1] > offs_sh[wave][v];
   }
   for (int c0 = 0; c0 < C; c0 += 64) {
     const int nch = min(64, C - c0);
@@ -633,7 +653,7 @@ __global__ void __launch_bounds__(256) lift_splat_bwd_rows_quad_kernel(const flo
       if (cc < nch) {
         const float* o = gout + ((size_t)bz * C + c0 + cc) * plane + vid0 + 4 * q;
         if (nvox == kTileVox) r = *reinterpret_cast<const f4*>(o);
-        else { float rr[4] = {0.f, 0.f, 0.f, 0.f}; for (int j = 0; j < 4; ++j) if (4 * q + j < nvox) rr[j] = o[j]; r = f4{rr[0], rr[1], rr[2], rr[3]}; }
+        else { r.x = 4 * q + 0 < nvox ? o[0] : 0.f; r.y = 4 * q + 1 < nvox ? o[1] : 0.f; r.z = 4 * q + 2 < nvox ? o[2] : 0.f; r.w = 4 * q + 3 < nvox ? o[3] : 0.f; }
       }
       const int col = (cc + 4 * q) & 63;                         // rotation of voxel rows 4 q .. 4 q + 3 (v >> 2 = q)
       tile[(4 * q + 0) * kQPitch + col] = r.x; tile[(4 * q + 1) * kQPitch + col] = r.y;

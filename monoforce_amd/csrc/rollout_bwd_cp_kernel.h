@@ -1017,38 +1017,61 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
         uA = uZ; uB = uZ;                             // (the epilogue reads whichever the last iteration would have requested into)
     } else {
       // MODE = kCpSaved: ONE wave reads the record itself (either integrator; launches the streaming form does not cover, and the
-      // A/B leg of the parity tests).  Three stages again, in one instruction stream: the rows and the record of step n - 2 are
-      // requested, the cells of step n - 1 gathered at the top of the iteration; the vector-Jacobian chain of step n (~1000
-      // cycles) runs; then step n - 1 is rebuilt from what has arrived meanwhile.  Two register sets, unrolled by two.
+      // A/B leg of the parity tests).  Three stages in one instruction stream: rows, record and upstream row are requested THREE / TWO
+      // iterations before they are used, the cells of step n - 1 gathered at the top of the iteration; the vector-Jacobian chain of
+      // step n (~1000 cycles) runs; then step n - 1 is rebuilt from what has arrived meanwhile.  (Round 3 requested one iteration
+      // ahead: with every SIMD of the chip holding such a wave -- 4096 rollouts -- an HBM round trip is longer than an iteration,
+      // and the gather at the top, which needs the record's cell coordinate, waited for it: 268 instructions at ~9.8 cycles each.)
+      // Three register sets, rotated by iteration count: iteration i (step n0 - i) runs on K[i % 3] / U[i % 3], gathers from and
+      // rebuilds S[(i + 1) % 3] into K[(i + 1) % 3], requests step n - 3 into S[i % 3] and the upstream row of step n - 2 into
+      // U[(i + 2) % 3]; unrolled by three, so every index is a constant.
       struct Raw { StateIn st; Saved sv; };
-      auto run = [&](int n, const Rec& kc, const UpIn& up, Raw& X, Raw& Y, Rec& k_next, UpIn& up_next) {
-        add_upstream_state(up);
-        gather_cells(X.sv);                                   // step n - 1 (n = 0: a harmless repeat of step 0)
-        load_state(max(n - 2, 0), Y.st);
-        load_saved(max(n - 2, 0), Y.sv);
-        load_upstream(ODE ? n : max(n - 1, 0), up_next);      // the row step n - 1 produced (ODEINT's row 0: added after the loop)
+      Raw S_[3];
+      Rec K_[3];
+      UpIn U_[3];
+      auto up_row = [&](int m) { return ODE ? max(m + 1, 0) : max(m, 0); };      // the output row step m produced (ODEINT's "step -1": row 0)
+      auto run = [&](auto rtag, int n) {
+        constexpr int R = decltype(rtag)::value, R1 = (R + 1) % 3, R2 = (R + 2) % 3;
+        add_upstream_state(U_[R]);
+        gather_cells(S_[R1].sv);                                // step n - 1 (n = 0: a harmless repeat of step 0)
+        load_state(max(n - 3, 0), S_[R].st);
+        load_saved(max(n - 3, 0), S_[R].sv);
+        load_upstream(min(up_row(n - 2), a.T - 1), U_[R2]);
         flush_stash();
         if constexpr (GCTRL) bstore2(rGctrl, v_ctrl, gctrl_pending, gv_pending, gwc_pending);
-        vjp(n, kc, up);
+        vjp(n, K_[R], U_[R]);
         // (the gathered values pass through an empty asm that also reads the adjoint the chain ends in: their consumers stay behind it)
-        asm("" : "+v"(X.sv.zc), "+v"(X.sv.mc) : "v"(lR0));
-        rebuild(X.st, X.sv, k_next);
+        asm("" : "+v"(S_[R1].sv.zc), "+v"(S_[R1].sv.mc) : "v"(lR0));
+        rebuild(S_[R1].st, S_[R1].sv, K_[R1]);
       };
-      Raw rA, rB;
-      Rec kA, kB;
-      load_state(max(n, 0), rA.st);
-      load_saved(max(n, 0), rA.sv);
-      load_upstream(min(max(n, 0) + (ODE ? 1 : 0), a.T - 1), uA);
-      load_state(max(n - 1, 0), rB.st);
-      load_saved(max(n - 1, 0), rB.sv);
-      gather_cells(rA.sv);
-      rebuild(rA.st, rA.sv, kA);
+      const int n0 = max(n, 0);
+      load_state(n0, S_[0].st);
+      load_saved(n0, S_[0].sv);
+      load_upstream(min(up_row(n0), a.T - 1), U_[0]);
+      load_state(max(n0 - 1, 0), S_[1].st);
+      load_saved(max(n0 - 1, 0), S_[1].sv);
+      load_upstream(min(up_row(n0 - 1), a.T - 1), U_[1]);
+      load_state(max(n0 - 2, 0), S_[2].st);
+      load_saved(max(n0 - 2, 0), S_[2].sv);
+      gather_cells(S_[0].sv);
+      rebuild(S_[0].st, S_[0].sv, K_[0]);
       __builtin_amdgcn_s_waitcnt(0);
-      for (; n >= 1; n -= 2) {
-        run(n, kA, uA, rB, rA, kB, uB);
-        run(n - 1, kB, uB, rA, rB, kA, uA);
+      using std::integral_constant;
+      int i = 0;
+      for (; i + 2 < n_steps; i += 3) {
+        run(integral_constant<int, 0>{}, n0 - i);
+        run(integral_constant<int, 1>{}, n0 - i - 1);
+        run(integral_constant<int, 2>{}, n0 - i - 2);
       }
-      if (n == 0) run(0, kA, uA, rB, rA, kB, uB);
+      if (i < n_steps) run(integral_constant<int, 0>{}, n0 - i);
+      if (i + 1 < n_steps) run(integral_constant<int, 1>{}, n0 - i - 1);
+      // the upstream gradient of output row 0 ("step -1") went into U[(n0 + 1) % 3]; the epilogue below reads it from uA / uB
+      {
+        const int r0 = (n0 + 1) % 3;
+        uA = r0 == 0 ? U_[0] : (r0 == 1 ? U_[1] : U_[2]);
+        uB = uA;
+      }
+      n = -1;
     }
   } else {
   load_state(max(n, 0), sA);
