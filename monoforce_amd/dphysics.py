@@ -546,7 +546,9 @@ class DPhysics(torch.nn.Module):
         scripts use: scripts/train.py:399-406, scripts/fit_terrain.py:53-62) with the loss INSIDE the rollout's two launches (SURVEY.md
         8f rank 1): the forward kernel accumulates the time-weighted squared error at the stamped rows while it writes them, the
         backward forms dL/dXs there itself -- no loss launches, no [B,T,3] gradient tensor.  X_gt [B,T2,3]; `spec` = self.loss_spec(gt_ts).
-        Returns (loss, (Xs, Xds, Rs, Omegas)); the states come back detached from the graph (only the loss is differentiable).
+        Returns (loss, (Xs, Xds, Rs, Omegas)); the states come back detached from the graph (only the loss is differentiable) and are
+        READ-ONLY until `loss.backward()` has run: the backward launch re-reads the Xs rows to form dL/dXs (they are not copied, and an
+        in-place edit would not be noticed by autograd's version check).
         `value_in_backward` (MF_LOSS_VALUE_IN_BACKWARD): for a caller that ALWAYS calls `loss.backward()` next and reads the value
         only afterwards (a fit loop): the backward launch forms the value too -- the returned scalar is NaN until then -- and the
         step loses its one remaining loss launch.

@@ -372,6 +372,7 @@ def test_component_parallel_backward_positions_only_loss(B, integ):
     zd, md, cd = z.to(DEV).requires_grad_(True), mu.to(DEV).requires_grad_(True), ctrl.to(DEV).requires_grad_(True)
     (Xs, _, _, _), _ = dp(zd, cd, friction=md)
     (Xs[sel.to(DEV)] * wts.to(DEV)).sum().backward()
+    spec = hp.spec_from(pts, masks, integ, 0.05, 6.4)
     zc, mc = z.double().requires_grad_(True), mu.double().requires_grad_(True)
     cc = ctrl[sel].double().requires_grad_(True)
     zin = zc.expand(len(sel), -1, -1) if shared else zc[sel]

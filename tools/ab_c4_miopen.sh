@@ -9,10 +9,10 @@ R=$OUT/${TAG}_ab_c4_miopen.txt
 : > $R
 run() {      # name, env assignments...
   name=$1; shift
-  rm -rf $OUT/prof_$name
-  env "$@" timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$name -o c4 -- python bench.py --workload c4 --steps 10 --warmup 4 --no-cpu-baseline > $OUT/c4_$name.json 2> $OUT/c4_$name.err
-  f=$(find $OUT/prof_$name -name "*kernel_stats.csv" | head -1)
-  python - "$name" "$OUT/c4_$name.json" "$f" >> $R <<'PY'
+  rm -rf /tmp/prof_$name      # (traces stay on the box: gpurun_out/ is capped at 64 MiB)
+  env "$@" timeout ${AB_TIMEOUT:-300} rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$name -o c4 -- python bench.py --workload c4 --steps 6 --warmup 4 --no-cpu-baseline > /tmp/c4_$name.json 2> /tmp/c4_$name.err
+  f=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1)
+  python - "$name" "/tmp/c4_$name.json" "$f" >> $R <<'PY'
 import csv, json, sys
 name, jf, kf = sys.argv[1:4]
 try:
@@ -39,7 +39,6 @@ PY
 }
 run base
 run benchmark MF_MIOPEN_BENCHMARK=1
-run find_normal MF_MIOPEN_BENCHMARK=1 MIOPEN_FIND_MODE=NORMAL
 run channels_last MF_MIOPEN_BENCHMARK=1 MF_CHANNELS_LAST=1
-run find_enforce MF_MIOPEN_BENCHMARK=1 MIOPEN_FIND_ENFORCE=SEARCH MIOPEN_FIND_MODE=NORMAL
+[ -n "$AB_MORE" ] && run find_normal MF_MIOPEN_BENCHMARK=1 MIOPEN_FIND_MODE=NORMAL
 cat $R

@@ -3,19 +3,19 @@
 # Every step has its own timeout; PMC passes are separate from the kernel-trace passes (and from each other).
 TAG=${1:-rX}
 OUT=gpurun_out/$TAG
-mkdir -p $OUT
+mkdir -p $OUT /tmp/mfprof      # (raw traces stay on the box under /tmp: gpurun_out/ is capped at 64 MiB; only summaries are written to $OUT)
 export TMPDIR=/tmp
 B="--no-cpu-baseline --no-others"
 timeout 900 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err
-for w in c3f c3 c4; do
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$w -o $w -- python bench.py --steps 20 --warmup 3 --workload $w $B > $OUT/${TAG}_${w}_bench_under_rocprof.json 2> $OUT/prof_$w.err
-  f=$(find $OUT/prof_$w -name "*kernel_stats.csv" | head -1)
+for w in c3f c3 c4 ref_nb; do
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/mfprof/prof_$w -o $w -- python bench.py --steps 20 --warmup 3 --workload $w $B > $OUT/${TAG}_${w}_bench_under_rocprof.json 2> $OUT/prof_$w.err
+  f=$(find /tmp/mfprof/prof_$w -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && head -40 "$f" > $OUT/${TAG}_${w}_kernel_stats.csv
 done
 for c in FETCH_SIZE WRITE_SIZE; do
-  for w in c3f c3 c4; do
-    timeout 240 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_${c}_$w -o $w -- python bench.py --steps 4 --warmup 1 --workload $w $B > /dev/null 2> $OUT/pmc_${c}_$w.err
-    f=$(find $OUT/pmc_${c}_$w -name "*counter_collection.csv" | head -1)
+  for w in c3f c3; do      # (c4's PMC passes -- ~1000 dispatches per step, serialised by the counters -- run into the timeout: no c4 row)
+    timeout 240 rocprofv3 --pmc $c --output-format csv -d /tmp/mfprof/pmc_${c}_$w -o $w -- python bench.py --steps 4 --warmup 1 --workload $w $B > /dev/null 2> $OUT/pmc_${c}_$w.err
+    f=$(find /tmp/mfprof/pmc_${c}_$w -name "*counter_collection.csv" | head -1)
     [ -n "$f" ] && python tools/pmc_summary.py "$f" > $OUT/${TAG}_pmc_${c}_$w.txt
   done
 done
@@ -27,7 +27,7 @@ out, tag = sys.argv[1], sys.argv[2]
 names = {'rollout_fwd': 'rollout_fwd_kernel', 'rollout_bwd': 'rollout_bwd_kernel', 'lift_splat_fwd': 'lift_splat_fwd_kernel',
          'lift_splat_bwd': 'lift_splat_bwd_kernel'}
 res = {}
-for w in ('c3f', 'c3', 'c4'):
+for w in ('c3f', 'c3'):
     per, calls = {}, {}
     for c, mult in (('FETCH_SIZE', 2), ('WRITE_SIZE', 1)):
         try:
@@ -56,6 +56,9 @@ AB_BWD=1 AB_B=256,1024,2048,4096,8192 timeout 300 python tools/ab_cp.py 2> /dev/
 AB_INTEG=0 AB_BWD=1 AB_B=1024,4096,8192 timeout 300 python tools/ab_cp.py 2> /dev/null | grep "^B " | sed 's/^B /dynamics() B /' >> $OUT/${TAG}_ab_lane_mappings.txt
 AB_B=1024,16384,65536 timeout 300 python tools/bench_planner.py > $OUT/${TAG}_bench_planner.jsonl 2> $OUT/bench_planner.err
 timeout 300 python tools/bench_lift_splat.py 2> $OUT/bench_lift_splat.err | grep '^B=' > $OUT/${TAG}_bench_lift_splat.txt
+timeout 300 bash tools/prof_splat.sh $TAG > /dev/null 2>&1
+timeout 500 bash tools/ab_midrange.sh $TAG > /dev/null 2>&1
+AB_TIMEOUT=240 timeout 800 bash tools/ab_c4_miopen.sh $TAG > /dev/null 2>&1
 timeout 300 python tools/bench_graphed.py 2> $OUT/bench_graphed.err | grep n_trajs > $OUT/${TAG}_bench_graphed.txt
 AB_B=4 AB_N=100,175,223,400 timeout 300 python tools/ab_points.py 2> /dev/null | grep forces > $OUT/${TAG}_large_body_small_batch.txt
 AB_B=64 AB_N=100,175,223,400 timeout 300 python tools/ab_points.py 2> /dev/null | grep forces >> $OUT/${TAG}_large_body_small_batch.txt
