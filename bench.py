@@ -294,7 +294,9 @@ class Runner:
             gc = dict(xbound=[-6.4, 6.4, 0.05], ybound=[-6.4, 6.4, 0.05], zbound=[-3.2, 3.2, 6.4], dbound=[0.6, 6.4, 0.1])
             enc = LiftSplatShoot(gc, dict(final_dim=(256, 512))).to(dev).train()
             if os.environ.get('MF_CHANNELS_LAST'):      # A/B (tools/ab_c4_miopen.sh): NHWC weights -> MIOpen's NHWC solvers
-                enc = enc.to(memory_format=torch.channels_last)
+                for m_ in enc.modules():      # (conv weights only: the module also holds 4-D non-conv parameters, e.g. the frustum table)
+                    if isinstance(m_, torch.nn.Conv2d):
+                        m_.weight.data = m_.weight.data.contiguous(memory_format=torch.channels_last)
             ebatch = synthetic_encoder_batch(enc, dp, n_rollouts=B, device=dev, seed=rank)    # the encoder batch is sharded too
             estep = EncoderTrainStep(enc, dp, lr=1e-4, graph=not os.environ.get('MF_BENCH_NO_GRAPH'))
         elif wl['backward']:

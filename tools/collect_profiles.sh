@@ -58,7 +58,6 @@ AB_B=1024,16384,65536 timeout 300 python tools/bench_planner.py > $OUT/${TAG}_be
 timeout 300 python tools/bench_lift_splat.py 2> $OUT/bench_lift_splat.err | grep '^B=' > $OUT/${TAG}_bench_lift_splat.txt
 timeout 300 bash tools/prof_splat.sh $TAG > /dev/null 2>&1
 timeout 500 bash tools/ab_midrange.sh $TAG > /dev/null 2>&1
-AB_TIMEOUT=240 timeout 800 bash tools/ab_c4_miopen.sh $TAG > /dev/null 2>&1
 timeout 300 python tools/bench_graphed.py 2> $OUT/bench_graphed.err | grep n_trajs > $OUT/${TAG}_bench_graphed.txt
 AB_B=4 AB_N=100,175,223,400 timeout 300 python tools/ab_points.py 2> /dev/null | grep forces > $OUT/${TAG}_large_body_small_batch.txt
 AB_B=64 AB_N=100,175,223,400 timeout 300 python tools/ab_points.py 2> /dev/null | grep forces >> $OUT/${TAG}_large_body_small_batch.txt
