@@ -10,6 +10,11 @@
 namespace mf {
 
 void set_error(const std::string& msg);  // capi.hip
+// Compute units / SIMDs of the device the launch goes to (hipDeviceProp_t::multiProcessorCount; MI355X: 256 CUs x 4 SIMDs).  The
+// dispatch thresholds of the rollout kernels are expressed in these (waves per SIMD, workgroups per CU), not in literals tuned on one
+// box.  Where no device answers -- the policy queries of a CPU-only process, e.g. mf_rollout_record_bytes -- an MI355X is assumed.
+int device_cus();   // capi.hip
+inline long long device_simds() { return 4ll * device_cus(); }
 
 #define MF_REQUIRE(cond, code, msg)        \
   do {                                     \

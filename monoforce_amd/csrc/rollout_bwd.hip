@@ -113,7 +113,7 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
     // accumulator carry-over between adjacent cells (rollout_bwd_kernel.h): ~55 more instructions per step, half the atomics --
     // a gain from ~3 waves per 4 CUs upwards (B = 4096 at N = 4: 1.00 -> 0.94 ms; B = 65536: 9.5 -> 5.5 ms), a loss below
     const RolloutBwdArgs<float>& af = *reinterpret_cast<const RolloutBwdArgs<float>*>(&a);
-    if ((long long)d->B * m.G >= 192 * 64) return launch_rollout_bwd_carry_fast_f32(af, m, d->integrator, block, st);
+    if ((long long)d->B * m.G >= 3ll * device_cus() / 4 * 64) return launch_rollout_bwd_carry_fast_f32(af, m, d->integrator, block, st);
     return launch_rollout_bwd_fast_f32(af, m, d->integrator, block, st);
   }
   return launch_rollout_bwd<S, false>(a, m, d->integrator, block, st);

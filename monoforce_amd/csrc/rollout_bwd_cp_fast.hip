@@ -10,8 +10,8 @@ namespace mf {
 // owns one footprint cell here: its gradient accumulator flushes with one atomic per map, which is what bounds the one-point-
 // per-lane kernel once the chip is full); MF_CP_BWD_MAX_WAVES overrides (0 disables)
 static long long cp_bwd_max_waves() {
-  static const long long v = getenv("MF_CP_BWD_MAX_WAVES") ? atoll(getenv("MF_CP_BWD_MAX_WAVES")) : 2048;
-  return v;
+  static const long long v = getenv("MF_CP_BWD_MAX_WAVES") ? atoll(getenv("MF_CP_BWD_MAX_WAVES")) : -1;
+  return v >= 0 ? v : 2 * device_simds();      // two waves per SIMD (MI355X: 2048)
 }
 
 static bool cp_bwd_covers(const MfRolloutDesc* d, bool joints, int scalar_bytes = 4) {
@@ -36,7 +36,8 @@ bool use_component_parallel_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* 
 // backward), so beyond its streaming range it keeps no record (MF_CP_RECORD_DYNAMICS=1 forces one: A/B runs, parity tests of that
 // kernel).  MF_CP_RECORD_MAX_WAVES overrides the size limit (0 disables).
 long long cp_record_bytes(const MfRolloutDesc* d, int scalar_bytes) {
-  static const long long max_waves = getenv("MF_CP_RECORD_MAX_WAVES") ? atoll(getenv("MF_CP_RECORD_MAX_WAVES")) : 1024;
+  static const long long max_waves_env = getenv("MF_CP_RECORD_MAX_WAVES") ? atoll(getenv("MF_CP_RECORD_MAX_WAVES")) : -1;
+  const long long max_waves = max_waves_env >= 0 ? max_waves_env : device_simds();      // one wave per SIMD
   if (!d || d->B <= 0 || d->T <= 0) return 0;
   MfRolloutFwdBufs f{};
   static const bool dyn = getenv("MF_CP_RECORD_DYNAMICS") && atoi(getenv("MF_CP_RECORD_DYNAMICS")) != 0;

@@ -1143,8 +1143,10 @@ void launch_rollout_bwd_cp_stream_dynamics_f32(const RolloutBwdArgs<float>& a, b
 // (2 x 60 / 72 KB of the CU's 160 KB), one with twelve; dynamics() carries six more planes per slot (96 / 108 KB with six slots: one
 // workgroup per CU).  MF_CP_STREAM_MAX_GRID overrides the default integrator's limit (A/B runs).
 inline unsigned cp_stream_max_grid(int integ = MF_INTEG_ODEINT_EULER) {
-  static const unsigned v = getenv("MF_CP_STREAM_MAX_GRID") ? (unsigned)atoi(getenv("MF_CP_STREAM_MAX_GRID")) : 512u;
-  return integ == MF_INTEG_ODEINT_EULER ? v : (v < 256u ? v : 256u);
+  static const int env = getenv("MF_CP_STREAM_MAX_GRID") ? atoi(getenv("MF_CP_STREAM_MAX_GRID")) : -1;
+  const unsigned cus = (unsigned)device_cus();
+  const unsigned v = env >= 0 ? (unsigned)env : 2u * cus;      // two workgroups per CU (MI355X: 512); dynamics(): one
+  return integ == MF_INTEG_ODEINT_EULER ? v : (v < cus ? v : cus);
 }
 
 // one launch of the variant (positions-only loss?, control gradient?, late recompute?) the arguments call for
@@ -1172,7 +1174,7 @@ int launch_rollout_bwd_cp_variant(const RolloutBwdArgs<S>& a, bool xs_only, hipS
   // the forward's record when there is one: a second wave per workgroup streams it through LDS (default integrator, while the
   // rings fit the CUs' LDS), else one wave reads it itself; without a record at most one wave per SIMD: late recompute
   const int saved_mode = grid <= cp_stream_max_grid_of<S>(INTEG) && forced != kCpSaved ? kCpStream : kCpSaved;
-  const int mode = a.rec ? saved_mode : (forced >= 0 && forced < kCpSaved ? forced : (grid <= 1024u ? kCpLate : kCpEarly));
+  const int mode = a.rec ? saved_mode : (forced >= 0 && forced < kCpSaved ? forced : ((long long)grid <= device_simds() ? kCpLate : kCpEarly));
 #define MF_BCP(XS_, GC_, M_) hipLaunchKernelGGL((rollout_bwd_cp_kernel<S, INTEG, XS_, GC_, M_>), dim3(grid), dim3(64), 0, st, a)
 #define MF_BCP_L(XS_, GC_) do { if (mode == kCpStream) launch_rollout_bwd_cp_stream_any(a, INTEG, xs_only, grid, st); else if (mode == kCpSaved) MF_BCP(XS_, GC_, kCpSaved); else if (mode == kCpLate) MF_BCP(XS_, GC_, kCpLate); else MF_BCP(XS_, GC_, kCpEarly); } while (0)
   if (xs_only) { if (gc) MF_BCP_L(true, true); else MF_BCP_L(true, false); }

@@ -18,7 +18,7 @@ static bool mw_shape(const MfRolloutDesc* d) {
   if (d->points_per_lane == 4) return false;
   const LaneMap m = choose_lane_map(d->B, d->N, d->points_per_lane == MF_LANES_COMPONENT ? 0 : d->points_per_lane);
   if (m.PPL != 1 || m.G < 8) return false;
-  return m.G > 64 || (long long)d->B * m.G <= 2048ll * 64;
+  return m.G > 64 || (long long)d->B * m.G <= 2 * device_simds() * 64;      // two waves per SIMD
 }
 long long mw_record_bytes(const MfRolloutDesc* d, int scalar_bytes) {
   if (!mw_shape(d)) return 0;

@@ -683,7 +683,7 @@ int launch_rollout_bwd_mw_t(const RolloutBwdArgs<S>& a, int G, int integ, bool x
     constexpr int TE = mw_tile_edge(G_);                                                                         \
     constexpr long long lds = (long long)(G_ > 64 ? 1 : 64 / G_) * 2 * (TE + 1) * TE * (long long)sizeof(S) + 4096;                       \
     const unsigned grid = (unsigned)(((long long)a.B * G_ + blk - 1) / blk);                                     \
-    const bool tile = TE > 0 && !tile_off && (long long)((grid + 255) / 256) * lds <= 160 * 1024 && (long long)a.H * a.W < (1ll << 30); \
+    const bool tile = TE > 0 && !tile_off && (long long)((grid + (unsigned)device_cus() - 1) / (unsigned)device_cus()) * lds <= 160 * 1024 && (long long)a.H * a.W < (1ll << 30); \
     const bool dyn = integ == MF_INTEG_DYNAMICS;                                                                 \
     if (tile) {                                                                                                  \
       if constexpr (TE > 0) {                                                                                    \

@@ -102,7 +102,7 @@ static bool use_interleaved_maps(const MfRolloutDesc* d, const MfRolloutFwdBufs*
   // Below ~half a wave per SIMD the launch is bound by the instruction stream of its waves; the extra pass (a second launch in
   // front of the rollout, ~10 us) then costs what the two saved gathers bring (measured: B = 1024 path costs 0.306 -> 0.323 ms)
   // (the float64 validation build takes the pass whenever it is offered: its purpose is to run the ZMU kernels)
-  if (sizeof(S) == 4 && (long long)d->B * m.G < 512ll * 64) return false;
+  if (sizeof(S) == 4 && (long long)d->B * m.G < device_simds() / 2 * 64) return false;      // (half a wave per SIMD)
   const int n = d->H * d->W;
   hipLaunchKernelGGL((interleave_maps_kernel<S>), dim3((n + 255) / 256), dim3(256), 0, st, a->z, a->mu, n, (cp::Pk2<S>*)p->zmu_scratch);
   a->zmu = (const S*)p->zmu_scratch;
@@ -174,8 +174,8 @@ extern "C" int mf_rollout_fwd_f32(const MfRolloutDesc* d, const MfRolloutFwdBufs
       return mf::rollout_fwd_cp<float>(d, p, a, (hipStream_t)s);
     MF_REQUIRE(!p->loss, MF_ERR_UNSUPPORTED, "rollout_fwd: this launch cannot carry the fused physics loss (mf_rollout_loss_fusable)");
     if (!forces && m.PPL == 4 && m.G < 64) m = mf::choose_lane_map(d->B, d->N, 1);
-    // >= one wave per SIMD (1024) and a one-point-per-lane mapping within a wave: the split-store kernels (rollout_fwd_kernel.h)
-    const bool split = m.PPL == 1 && m.G <= 64 && (long long)d->B * m.G >= 1024ll * 64;
+    // >= one wave per SIMD and a one-point-per-lane mapping within a wave: the split-store kernels (rollout_fwd_kernel.h)
+    const bool split = m.PPL == 1 && m.G <= 64 && (long long)d->B * m.G >= mf::device_simds() * 64;
     if (p->rec && mf::mw_record_bytes(d, 4) > 0) {      // the 16-byte record of rollout_bwd_mw_kernel.h
       MF_REQUIRE(((uintptr_t)p->rec & 15) == 0, MF_ERR_INVALID, "rollout_fwd: rec must be 16-byte aligned");
       a.rec = (float*)p->rec;

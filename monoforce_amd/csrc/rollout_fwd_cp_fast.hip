@@ -10,8 +10,8 @@ namespace mf {
 // 1024 0.16 / 0.29, 2048 0.17 / 0.29, 4096 0.18 / 0.30 (43 % of the HBM roofline), 8192 0.41 / 0.32 -- so up to 1024 waves, one per
 // SIMD.  MF_CP_MAX_WAVES overrides (tuning / A-B runs; 0 disables the mapping).
 static long long cp_max_waves() {
-  static const long long v = getenv("MF_CP_MAX_WAVES") ? atoll(getenv("MF_CP_MAX_WAVES")) : 1024;
-  return v;
+  static const long long v = getenv("MF_CP_MAX_WAVES") ? atoll(getenv("MF_CP_MAX_WAVES")) : -1;
+  return v >= 0 ? v : device_simds();      // one wave per SIMD (MI355X: 1024)
 }
 
 bool use_component_parallel(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, int scalar_bytes) {

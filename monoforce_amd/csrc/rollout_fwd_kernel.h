@@ -1049,7 +1049,7 @@ static inline LaneMap choose_lane_map(int B, int N, int points_per_lane) {
   // 1.38 / 4.4 ms at B = 512 (2 waves per SIMD); a tie at B = 1024 -- so up to 2048 waves per launch.
   if (points_per_lane != 4) {
     const int g = N <= 128 ? 128 : (N <= 256 ? 256 : 512);
-    if ((long long)B * (g / 64) <= 2048) return LaneMap{g, 1};
+    if ((long long)B * (g / 64) <= 2 * device_simds()) return LaneMap{g, 1};      // two waves per SIMD (MI355X: 2048)
   }
   if (N <= 128) return points_per_lane != 4 ? LaneMap{64, 2} : LaneMap{32, 4};
   if (N <= 256) return LaneMap{64, 4};
@@ -1064,7 +1064,8 @@ int launch_rollout_fwd(const RolloutArgs<S>& a, LaneMap m, int integ, int block,
   // More than two waves per SIMD do not help these kernels -- their gathers then miss the CU's L1 more often -- so a very
   // large batch goes out as consecutive launches of <= kChunkWaves waves on the same stream (measured: B = 65536 1.81 -> 1.73 ms,
   // B = 131072 4.23 -> 3.90 ms; MF_CHUNK_WAVES=0 disables).  The chunk is a whole number of workgroups; results do not depend on it.
-  static const long long kChunkWaves = getenv("MF_CHUNK_WAVES") ? atoll(getenv("MF_CHUNK_WAVES")) : 2048;
+  static const long long kChunkEnv = getenv("MF_CHUNK_WAVES") ? atoll(getenv("MF_CHUNK_WAVES")) : -1;
+  const long long kChunkWaves = kChunkEnv >= 0 ? kChunkEnv : 2 * device_simds();      // two waves per SIMD (MI355X: 2048)
   int chunk_B = a.B;
   if (m.G <= 64 && kChunkWaves > 0 && (long long)a.B * m.G > kChunkWaves * 64) chunk_B = (int)(kChunkWaves * 64 / m.G);
   bool launched = false;
