@@ -432,6 +432,8 @@ class Runner:
                        'parallelism': f'rollout-sharded x{world}', **({'launch': launch} if launch else {})},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic,
+                         # the PMC-measured HBM bytes per launch over the kernel's measured duration: what the memory system really sustained
+                         'frac_traffic': (traffic / (kern[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                          **({'record_bytes_per_launch': rec_bytes,
                              'traffic_note': 'traffic includes the per-step record the forward writes and the backward reads instead of '
                                              'recomputing it (record_bytes_per_launch; DESIGN.md 4.2b) -- not re-reads'} if rec_bytes else {}),

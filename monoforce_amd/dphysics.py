@@ -568,7 +568,13 @@ class DPhysics(torch.nn.Module):
                                    points_per_lane=self.points_per_lane)
             ok = bool(_lib.lib().mf_rollout_loss_fusable(C.byref(d)))
         if not ok:
-            states, _ = self.dphysics(z_grid, controls, state=state, friction=friction)
+            # (the loss reads the positions only: the forward writes the states, not the 24 N bytes of force rows per rollout-step -- for the
+            #  reference's 223-point body 36 of 241 MB per launch; `return_forces` is restored for the module's other callers)
+            keep, self.return_forces = self.return_forces, False
+            try:
+                states, _ = self.dphysics(z_grid, controls, state=state, friction=friction)
+            finally:
+                self.return_forces = keep
             B_, T2 = X_gt.shape[:2]
             gt_ts = spec.gt_ts.unsqueeze(0).expand(B_, -1)
             return physics_loss_fused(states, [X_gt], None, gt_ts, gamma=spec.gamma, nearest=spec.near.unsqueeze(0).expand(B_, -1)), states
