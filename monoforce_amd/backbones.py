@@ -10,6 +10,8 @@ They are restated from the published architectures with the SAME module / parame
 "unpinned": neither the packages nor any weights are available offline; only names/shapes are tested.
 """
 import math
+import os
+import types
 
 import torch
 from torch import nn
@@ -27,18 +29,58 @@ class Swish(nn.Module):
         return torch.nn.functional.silu(x)
 
 
+def lean():
+    """The launch diet below (same arithmetic, fewer / better kernels) is on unless MF_BACKBONE_LEAN=0 -- kept switchable for
+    the A/B in profiles/ (tools/ab_c4_backbone.sh)."""
+    return os.environ.get('MF_BACKBONE_LEAN', '1') != '0'
+
+
+class _DepthwiseNative(torch.autograd.Function):
+    """Depthwise convolution through ATen's own depthwise kernels.  MIOpen's immediate mode has no tuned solver for these
+    shapes on gfx950 without a find-db and falls back to `naive_conv_*` (8.9 % of the encoder step's kernel time,
+    profiles/r4e_c4_kernel_stats.csv); the backend is chosen again in the backward, hence a Function and not just a
+    context manager around the forward."""
+
+    @staticmethod
+    def forward(ctx, x, w, stride, padding):
+        ctx.save_for_backward(x, w)
+        ctx.conf = (stride, padding)
+        with torch.backends.cudnn.flags(enabled=False):
+            return F.conv2d(x, w, None, stride, padding, 1, w.shape[0])
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        stride, padding = ctx.conf
+        with torch.backends.cudnn.flags(enabled=False):
+            gx, gw, _ = torch.ops.aten.convolution_backward(g.contiguous(), x, w, None, list(stride), list(padding), [1, 1], False, [0, 0],
+                                                            w.shape[0], [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        return gx, gw, None, None
+
+
 class Conv2dStaticSame(nn.Conv2d):
     """Conv with TensorFlow-style "same" padding fixed at construction for even feature maps: total pad k - stride,
-    the extra pixel on the bottom/right (k3 s2 -> (0,1), k5 s2 -> (1,2), stride 1 -> symmetric)."""
+    the extra pixel on the bottom/right (k3 s2 -> (0,1), k5 s2 -> (1,2), stride 1 -> symmetric).  A symmetric pad is
+    handed to the convolution itself (no pad kernel, no slice in the backward); `static_padding` stays as a member
+    because the package the reference uses has it."""
 
     def __init__(self, cin, cout, k, stride=1, groups=1, bias=False):
         super().__init__(cin, cout, k, stride=stride, groups=groups, bias=bias)
         total = max(k - stride, 0)
         lo = total // 2
         self.static_padding = nn.ZeroPad2d((lo, total - lo, lo, total - lo)) if total > 0 else nn.Identity()
+        self._sym = lo if total == 2 * lo else None
 
     def forward(self, x):
-        return F.conv2d(self.static_padding(x), self.weight, self.bias, self.stride, 0, self.dilation, self.groups)
+        fast = lean()
+        pad = 0
+        if fast and self._sym is not None:
+            pad = self._sym
+        else:
+            x = self.static_padding(x)
+        if fast and x.is_cuda and self.groups > 1 and self.groups == self.in_channels == self.out_channels and self.bias is None:
+            return _DepthwiseNative.apply(x, self.weight, tuple(self.stride), (pad, pad))
+        return F.conv2d(x, self.weight, self.bias, self.stride, pad, self.dilation, self.groups)
 
 
 def drop_connect(x, p, training):
@@ -47,6 +89,15 @@ def drop_connect(x, p, training):
     keep = 1.0 - p
     mask = torch.floor(keep + torch.rand(x.shape[0], 1, 1, 1, dtype=x.dtype, device=x.device))
     return x / keep * mask
+
+
+def drop_connect_add(x, inputs, p, training):
+    """`drop_connect(x) + inputs` as one elementwise kernel each way: the same uniform draw, floor(keep + r) == 1 iff r >= p."""
+    if not training or not p:
+        return x + inputs
+    keep = 1.0 - p
+    scale = torch.floor(keep + torch.rand(x.shape[0], 1, 1, 1, dtype=x.dtype, device=x.device)) / keep
+    return torch.addcmul(inputs, x, scale)
 
 
 class MBConvBlock(nn.Module):
@@ -73,13 +124,63 @@ class MBConvBlock(nn.Module):
         if self.expand != 1:
             x = self._swish(self._bn0(self._expand_conv(x)))
         x = self._swish(self._bn1(self._depthwise_conv(x)))
-        s = F.adaptive_avg_pool2d(x, 1)
-        s = self._se_expand(self._swish(self._se_reduce(s)))
-        x = torch.sigmoid(s) * x
+        if lean():
+            # squeeze-excitation on the pooled (B, C) rows: the two 1x1 convolutions of a 1x1 map are two small GEMMs
+            s = x.mean((2, 3))
+            s = F.linear(F.silu(F.linear(s, self._se_reduce.weight.flatten(1), self._se_reduce.bias)),
+                         self._se_expand.weight.flatten(1), self._se_expand.bias)
+            x = torch.sigmoid(s)[:, :, None, None] * x
+        else:
+            s = F.adaptive_avg_pool2d(x, 1)
+            s = self._se_expand(self._swish(self._se_reduce(s)))
+            x = torch.sigmoid(s) * x
         x = self._bn2(self._project_conv(x))
         if self.stride == 1 and self.cin == self.cout:
+            if lean():
+                return drop_connect_add(x, inputs, drop_connect_rate, self.training)
             x = drop_connect(x, drop_connect_rate, self.training) + inputs
         return x
+
+
+def _bn_forward_without_counter(self, x):
+    return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, self.training or self.running_mean is None,
+                        self.momentum, self.eps)
+
+
+class _CounterBank:
+    """All `num_batches_tracked` buffers of a model as views of ONE int64 row, bumped by one kernel per training forward
+    instead of one per batch-norm layer (70 launches per encoder step).  `.to()` / `.cuda()` re-create the buffers one by
+    one: the bank notices (device or base changed) and gathers them again, outside any stream capture."""
+
+    def __init__(self, mods):
+        self.mods, self.flat = mods, None
+
+    def _gather(self):
+        vals = torch.stack([m.num_batches_tracked.reshape(()) for m in self.mods])
+        self.flat = vals.clone()
+        for i, m in enumerate(self.mods):
+            m._buffers['num_batches_tracked'] = self.flat[i]
+
+    def __call__(self, root, args):
+        if not root.training or not self.mods:
+            return
+        m0 = self.mods[0].num_batches_tracked
+        if self.flat is None or m0._base is not self.flat or any(m.num_batches_tracked._base is not self.flat for m in self.mods[1:]):
+            self._gather()
+        self.flat.add_(1)
+
+
+def fuse_batchnorm_counters(root):
+    """Batch-norm layers with a fixed momentum do not read `num_batches_tracked`; they only count.  Count for all of them
+    at once in a forward pre-hook of `root` (every layer runs once per forward of the encoder).  State dicts keep the keys."""
+    if not lean():
+        return root
+    mods = [m for m in root.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.track_running_stats
+            and m.momentum is not None and m.num_batches_tracked is not None]
+    for m in mods:
+        m.forward = types.MethodType(_bn_forward_without_counter, m)
+    root.register_forward_pre_hook(_CounterBank(mods))
+    return root
 
 
 class _GlobalParams:

@@ -11,7 +11,7 @@ backbones are the plain-torch restatements in `backbones.py` (MIOpen / rocBLAS).
 import torch
 from torch import nn
 
-from .backbones import EfficientNetB0, resnet18
+from .backbones import EfficientNetB0, resnet18, fuse_batchnorm_counters
 from .lss_utils import gen_dx_bx
 from . import splat
 
@@ -136,6 +136,7 @@ class LiftSplatShoot(nn.Module):
         if build_backbones:
             self.camencode = CamEncode(self.D, self.camC)
             self.bevencode = BevEncode(inC=self.camC, outC=outC)
+            fuse_batchnorm_counters(self)   # one `num_batches_tracked` bump per training forward() instead of one per layer
         self.use_quickcumsum = True      # accepted for compatibility; both reference paths compute the same sums
         self.fuse_lift = True            # lift (depth x context) inside the splat kernels; False: get_cam_feats + voxel_pooling
         self.fuse_geometry = True        # with fuse_lift: get_geometry inside the splat's key pass (no [B,N,D,fH,fW,3] tensor)

@@ -231,3 +231,24 @@ def EncoderTrainStepRef(enc, dp, b9):
     (inputs, hm_geom, hm_terrain, controls, pose0, states_gt, pred_ts, gt_ts, _) = b9
     with torch.no_grad():
         return float(fresh.losses((inputs, hm_geom, hm_terrain, controls, pose0, states_gt, pred_ts, gt_ts, nearest_steps(pred_ts, gt_ts).to(torch.int32)))[2])
+
+
+@pytest.mark.parametrize('k,stride', [(3, 1), (5, 1), (3, 2), (5, 2)])
+def test_depthwise_convolution_off_miopen_matches_the_library_route(k, stride, monkeypatch):
+    """backbones.Conv2dStaticSame sends depthwise convolutions to ATen's depthwise kernels (MIOpen's immediate mode answers
+    these shapes with naive_conv): values and both gradients against the MIOpen route of the same module."""
+    from monoforce_amd import backbones as bb
+    torch.manual_seed(k * 10 + stride)
+    conv = bb.Conv2dStaticSame(48, 48, k, stride=stride, groups=48).cuda()
+    x = torch.randn(4, 48, 32, 64, device='cuda')
+    out = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('MF_BACKBONE_LEAN', flag)
+        xi = x.clone().requires_grad_(True)
+        conv.zero_grad()
+        y = conv(xi)
+        (y * torch.linspace(-1, 1, y.numel(), device='cuda').view_as(y)).sum().backward()
+        out[flag] = (y.detach(), xi.grad.clone(), conv.weight.grad.clone())
+    for a, b in zip(out['1'], out['0']):
+        assert a.shape == b.shape
+        assert torch.allclose(a, b, rtol=2e-4, atol=2e-4 * float(b.abs().max()))

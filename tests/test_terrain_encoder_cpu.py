@@ -108,3 +108,62 @@ def test_missing_mesh_warns_about_the_standin(monkeypatch):
         warnings.simplefilter('always')
         cfg = DPhysConfig(robot='tradr')
     assert any('STAND-IN' in str(w.message) for w in rec) and cfg.robot_points.shape[1] == 3
+
+
+def test_backbone_launch_diet_is_the_same_arithmetic(monkeypatch):
+    """MF_BACKBONE_LEAN (symmetric pad inside the convolution, squeeze-excitation as two small GEMMs, drop-connect + residual as
+    one addcmul) against the plain module graph: same draws, same values and gradients."""
+    from monoforce_amd import backbones as bb
+
+    def run(flag):
+        monkeypatch.setenv('MF_BACKBONE_LEAN', flag)
+        torch.manual_seed(1)
+        blocks = [bb.MBConvBlock(16, 16, 3, 1, 6), bb.MBConvBlock(16, 24, 5, 2, 6), bb.MBConvBlock(24, 24, 5, 1, 6)]
+        torch.manual_seed(2)
+        x = torch.randn(6, 16, 12, 10, requires_grad=True)
+        y = x
+        for b in blocks:
+            y = b(y, 0.3)
+        y.square().sum().backward()
+        return [y.detach(), x.grad] + [p.grad for b in blocks for p in b.parameters()]
+
+    for a, b in zip(run('1'), run('0')):
+        assert float(b.abs().max()) > 0 and torch.allclose(a, b, rtol=1e-5, atol=2e-6 * float(b.abs().max()))
+
+
+def test_batchnorm_counters_count_once_per_forward_and_survive_moves():
+    import copy
+    from monoforce_amd.terrain_encoder import LiftSplatShoot
+    m = LiftSplatShoot(LSS_SMALL['grid_conf'], LSS_SMALL['data_aug_conf'])
+    g = hp.load('lss')
+    cal = [torch.as_tensor(g[k]) for k in ('rots', 'trans', 'intrins', 'post_rots', 'post_trans')]
+    x = torch.randn(cal[0].shape[0], cal[0].shape[1], 3, 64, 96)
+
+    def voxels_without_the_splat(self, x, *cal, plan=None):     # the splat needs the GPU; every layer still runs once
+        B, N, C, H, W = x.shape
+        self.camencode.get_depth_and_context(x.view(B * N, C, H, W))
+        return torch.randn(B, self.camC, int(self.nx[0]), int(self.nx[1]), dtype=x.dtype)
+
+    LiftSplatShoot.get_voxels, keep = voxels_without_the_splat, LiftSplatShoot.get_voxels
+    try:
+        _counter_checks(m, x, cal)
+    finally:
+        LiftSplatShoot.get_voxels = keep
+
+
+def _counter_checks(m, x, cal):
+    import copy
+    m.train()
+    for _ in range(2):
+        m(x, *cal)
+    counters = {k: int(v) for k, v in m.state_dict().items() if k.endswith('num_batches_tracked')}
+    assert len(counters) > 60 and set(counters.values()) == {2}
+    m2 = copy.deepcopy(m).double()            # buffers re-created one by one: the bank gathers them again
+    m2(x.double(), *(c.double() for c in cal))
+    assert {int(v) for k, v in m2.state_dict().items() if k.endswith('num_batches_tracked')} == {3}
+    assert {int(v) for k, v in m.state_dict().items() if k.endswith('num_batches_tracked')} == {2}
+    m.eval()
+    m(x, *cal)
+    assert {int(v) for k, v in m.state_dict().items() if k.endswith('num_batches_tracked')} == {2}
+    m.load_state_dict(m2.float().state_dict())
+    assert int(m.camencode.trunk._bn0.num_batches_tracked) == 3
