@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 #include <string>
 
 #include "../../include/monoforce_hip.h"
@@ -15,6 +16,21 @@ void set_error(const std::string& msg);  // capi.hip
 // box.  Where no device answers -- the policy queries of a CPU-only process, e.g. mf_rollout_record_bytes -- an MI355X is assumed.
 int device_cus();   // capi.hip
 inline long long device_simds() { return 4ll * device_cus(); }
+// Workgroup size of the kernels whose unit of work is ONE wave (four component-parallel rollouts) with nothing shared between waves.
+// Measured (profiles/r4_ab_block.txt, twice, on different boxes): with three or four waves per CU the same launch is 20-30 % faster
+// as 256-thread workgroups (ONE per CU) than as 64-thread ones -- record-reading backward at 4096 rollouts 0.54 -> 0.44 ms, recording
+// forward 0.265 -> 0.193 ms, and 0.373 -> 0.248 ms for an A/B build of the backward with every memory operation compiled out
+// (profiles/r4_ab_saved_variants.txt).  The cause is NOT identified: the dispatcher spreads the waves evenly over the SIMDs either way
+// (tools/microbench/wave_placement.hip, also with 208 registers and LDS), they start within 2 us of each other, and a plain 8 / 32 KB
+// FMA loop runs equally fast in both forms (tools/microbench/ifetch_lockstep.hip).  Below two waves per CU 64-thread workgroups reach
+// more CUs; from two waves per SIMD up the forms measure the same.  So the rule is the measured one: 256 threads between two and four
+// waves per CU, 64 elsewhere.
+inline unsigned wave_unit_block(unsigned waves) {
+  static const int env = getenv("MF_CP_BLOCK") ? atoi(getenv("MF_CP_BLOCK")) : 0;      // A/B (tools/ab_block.sh): 64 / 128 / 256
+  if (env == 64 || env == 128 || env == 256) return (unsigned)env;
+  const unsigned cus = (unsigned)device_cus();
+  return waves > 2u * cus && waves <= 4u * cus ? 256u : 64u;
+}
 
 #define MF_REQUIRE(cond, code, msg)        \
   do {                                     \

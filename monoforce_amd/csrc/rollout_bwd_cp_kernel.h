@@ -57,7 +57,7 @@ extern __device__ unsigned long long mf_stream_prof[16];
 #endif
 template <typename S, int INTEG, bool XS_ONLY, bool GCTRL, int MODE, int SLOTS = 6, int BATCH = 3>
 // (streaming, positions-only loss: at most 256 registers, so that two workgroups -- six waves -- share a CU's four SIMDs)
-__global__ void __launch_bounds__(MODE == kCpStream ? 192 : 64) MF_STREAM_WPE
+__global__ void __launch_bounds__(MODE == kCpStream ? 192 : 256) MF_STREAM_WPE
 rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
   constexpr bool ODE = INTEG == MF_INTEG_ODEINT_EULER;
   constexpr bool LATE = MODE == kCpLate, STREAM = MODE == kCpStream, SAVED = MODE == kCpSaved || STREAM;
@@ -465,6 +465,9 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
       v.zc = S(0.1) * (S)q; v.mc = S(0.8);
       return;
 #endif
+      // (Measured and dropped, round 4: lanes q and q ^ 2 hold neighbouring cells and could share ONE two-element load per map, as
+      //  gather4 does for one point per lane -- 32 addresses per wave instead of 64.  4096 rollouts: 0.446 -> 0.49 ms; a dwordx2 at a
+      //  4-byte-aligned address costs the L1 more than the two lane accesses it replaces.)
       v.zc = ld32(zmap, moff + (unsigned)v.idx);
       v.mc = ld32(mumap, moff + (unsigned)v.idx);
     };
@@ -1033,16 +1036,31 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
       auto run = [&](auto rtag, int n) {
         constexpr int R = decltype(rtag)::value, R1 = (R + 1) % 3, R2 = (R + 2) % 3;
         add_upstream_state(U_[R]);
-        gather_cells(S_[R1].sv);                                // step n - 1 (n = 0: a harmless repeat of step 0)
+        // (MF_SAVED_NO_*: A/B builds of tools/ab_saved_variants.sh -- what each stage costs where every SIMD holds such a wave; wrong results)
+        gather_cells(S_[R1].sv);                                // step n - 1 (n = 0: a harmless repeat of step 0; MF_STREAM_NO_GATHER: constants)
+#ifndef MF_SAVED_NO_STATE
         load_state(max(n - 3, 0), S_[R].st);
+#endif
+#ifndef MF_SAVED_NO_REC
         load_saved(max(n - 3, 0), S_[R].sv);
+#endif
+#ifndef MF_SAVED_NO_UP
         load_upstream(min(up_row(n - 2), a.T - 1), U_[R2]);
+#endif
+#ifndef MF_SAVED_NO_ATOMIC
         flush_stash();
+#endif
         if constexpr (GCTRL) bstore2(rGctrl, v_ctrl, gctrl_pending, gv_pending, gwc_pending);
+#ifndef MF_SAVED_NO_VJP
         vjp(n, K_[R], U_[R]);
+#endif
         // (the gathered values pass through an empty asm that also reads the adjoint the chain ends in: their consumers stay behind it)
+#ifndef MF_SAVED_NO_VJP
         asm("" : "+v"(S_[R1].sv.zc), "+v"(S_[R1].sv.mc) : "v"(lR0));
+#endif
+#ifndef MF_SAVED_NO_REBUILD
         rebuild(S_[R1].st, S_[R1].sv, K_[R1]);
+#endif
       };
       const int n0 = max(n, 0);
       load_state(n0, S_[0].st);
@@ -1168,14 +1186,15 @@ inline unsigned cp_stream_max_grid_of(int integ) {
 template <typename S, int INTEG>
 int launch_rollout_bwd_cp_variant(const RolloutBwdArgs<S>& a, bool xs_only, hipStream_t st) {
   const long long threads = (long long)a.B * 16;
-  const unsigned grid = (unsigned)((threads + 63) / 64);
+  const unsigned grid = (unsigned)((threads + 63) / 64);      // waves of rollouts
+  const unsigned block = wave_unit_block(grid), wgs = (unsigned)((threads + block - 1) / block);      // (the streaming form: 192 threads, its own)
   const bool gc = a.gcontrols != nullptr;
   static const int forced = getenv("MF_CP_BWD_MODE") ? atoi(getenv("MF_CP_BWD_MODE")) : -1;      // A/B (tools/ab_cp.py): 0 early, 1 late, 2 record read by one wave
   // the forward's record when there is one: a second wave per workgroup streams it through LDS (default integrator, while the
   // rings fit the CUs' LDS), else one wave reads it itself; without a record at most one wave per SIMD: late recompute
   const int saved_mode = grid <= cp_stream_max_grid_of<S>(INTEG) && forced != kCpSaved ? kCpStream : kCpSaved;
   const int mode = a.rec ? saved_mode : (forced >= 0 && forced < kCpSaved ? forced : ((long long)grid <= device_simds() ? kCpLate : kCpEarly));
-#define MF_BCP(XS_, GC_, M_) hipLaunchKernelGGL((rollout_bwd_cp_kernel<S, INTEG, XS_, GC_, M_>), dim3(grid), dim3(64), 0, st, a)
+#define MF_BCP(XS_, GC_, M_) hipLaunchKernelGGL((rollout_bwd_cp_kernel<S, INTEG, XS_, GC_, M_>), dim3(wgs), dim3(block), 0, st, a)
 #define MF_BCP_L(XS_, GC_) do { if (mode == kCpStream) launch_rollout_bwd_cp_stream_any(a, INTEG, xs_only, grid, st); else if (mode == kCpSaved) MF_BCP(XS_, GC_, kCpSaved); else if (mode == kCpLate) MF_BCP(XS_, GC_, kCpLate); else MF_BCP(XS_, GC_, kCpEarly); } while (0)
   if (xs_only) { if (gc) MF_BCP_L(true, true); else MF_BCP_L(true, false); }
   else         { if (gc) MF_BCP_L(false, true); else MF_BCP_L(false, false); }

@@ -377,8 +377,10 @@ long long cp_record_bytes(const MfRolloutDesc* d, int scalar_bytes = 4);      //
 // rollout_fwd_cp_f64.hip)
 template <typename S>
 int launch_rollout_fwd_cp_t(const RolloutArgs<S>& a, int integ, bool forces, bool zmu, hipStream_t st) {
-  const int block = 64;   // one wave = 4 rollouts per workgroup: B = 1024 puts one wave on each of the 256 CUs
+  // one wave = 4 rollouts: B = 1024 puts one wave on each of the 256 CUs; workgroups of one wave, or of four where the dispatcher would
+  // otherwise stack waves on a SIMD (wave_unit_block; the kernels that carry the fused loss -- <= two waves per CU -- are one-wave workgroups)
   const long long threads = (long long)a.B * 16;
+  const int block = a.loss_gt ? 64 : (int)wave_unit_block((unsigned)((threads + 63) / 64));
   const unsigned grid = (unsigned)((threads + block - 1) / block);
   const bool rec = a.rec != nullptr;
   if (a.loss_gt) {      // fused physics loss: default integrator, states only (the host checked)
