@@ -624,6 +624,9 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
       };
       if (threadIdx.x >= 64) {
         // ---------------- the two fetching waves ----------------
+        // (Measured and dropped, round 4: handing the computing role to the wave that has its SIMD to itself where two workgroups share a
+        //  CU -- by the hardware SIMD ids, tools/microbench/wave_placement.hip shows the pattern -- made 1536 / 2048 rollouts slower:
+        //  0.274 / 0.292 -> 0.296 / 0.304 ms.)
         // The steps go out in batches of three; fetching wave k (0 / 1) takes every other batch -- one wave's instruction
         // stream (~150 instructions per step: rebuild, gates, coefficient products, ten LDS writes) could not stay ahead of the
         // computing wave's ~1000 cycles per step once the cell gathers had joined it (measured: 0.221 ms alone at B = 1024

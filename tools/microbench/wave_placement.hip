@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <map>
+#include <string>
 #include <vector>
 #define K_PLACE_BODY \
   const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);     /* HW_ID: wave[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13] */ \
@@ -25,7 +26,9 @@ int main(int argc, char** argv) {
   const int block = argc > 1 ? atoi(argv[1]) : 64;
   const int big = argc > 2 ? atoi(argv[2]) : 0;
   const int lds = argc > 3 ? atoi(argv[3]) : 0;      // dynamic LDS bytes per workgroup (nobody uses them)
-  for (int waves0 : {256, 512, 768, 1024, 1536, 2048, 4096}) {
+  for (int waves0_ : {256, 512, 768, 1024, 1536, 2048, 4096}) {
+    int waves0 = waves0_;
+    if (block == 192 && waves0 == 2048) waves0 = 1536;      // 512 workgroups of three waves
     const int waves = waves0 / (block / 64) * (block / 64);
     unsigned* ids; float* sink; unsigned long long* starts; hipMalloc(&ids, 8 * waves); hipMalloc(&sink, 4); hipMalloc(&starts, 16 * waves);
     if (big) hipLaunchKernelGGL(k_place<1>, dim3(waves * 64 / block), dim3(block), lds, 0, ids, sink, 200000, starts);
@@ -55,6 +58,22 @@ int main(int argc, char** argv) {
       shared_simd += same; split_cu += other_cu;
     }
     if (wpb > 1) printf("      workgroups of %d waves: %d of %d have two waves on one SIMD (%d span CUs)\n", wpb, shared_simd, waves / wpb, split_cu);
+    if (wpb == 3 && waves / wpb <= 512) {      // two 3-wave workgroups per CU (the streaming backward at 2048 rollouts): which SIMDs, in wave order?
+      std::map<unsigned, std::vector<int>> by_cu;      // CU -> workgroup ids
+      for (int g = 0; g + wpb <= waves; g += wpb) {
+        const unsigned hw = h[2 * g], xcc = h[2 * g + 1] & 0xf;
+        by_cu[(xcc << 12) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 0xf)].push_back(g / wpb);
+      }
+      std::map<std::string, int> pat;
+      for (auto& kv : by_cu) {
+        std::string k;
+        for (int wg : kv.second) { k += "("; for (int i = 0; i < wpb; ++i) k += char('0' + ((h[2 * (wg * wpb + i)] >> 4) & 3)); k += ")"; }
+        pat[k]++;
+      }
+      printf("      SIMDs of the waves, per CU, workgroups in id order:");
+      for (auto& kv : pat) printf("  %s x%d", kv.first.c_str(), kv.second);
+      printf("\n");
+    }
     std::map<int, int> hs, hc;
     for (auto& kv : per_simd) hs[kv.second]++;
     for (auto& kv : per_cu) hc[kv.second]++;
