@@ -280,10 +280,30 @@ __device__ __forceinline__ float row_share_f(float v) { return __builtin_bit_cas
 
 constexpr int kQPitch = 68;      // words per voxel row of the LDS tile (64 channels + 4: rows stay 16-byte aligned)
 
-template <bool WEIGHTED>
-__global__ void __launch_bounds__(256) splat_fwd_quad_kernel(const float* __restrict__ x, const float* __restrict__ weight,
+// n / d for any 32-bit n by a multiply-high and two shifts (Granlund & Montgomery 1994, fig. 4.1): the fused kernels turn a frustum
+// point id into (camera, pixel) with two divisions by launch constants -- ~35 instructions each as a hardware-less u32 division,
+// four here.  The host forms (m, sh1, sh2) per launch.
+struct FastDiv { unsigned m, sh1, sh2; };
+static FastDiv fast_div_make(unsigned d) {
+  unsigned s = 0;
+  while ((1ull << s) < d) ++s;                                  // ceil(log2 d)
+  FastDiv f;
+  f.m = (unsigned)((((1ull << s) - d) << 32) / d + 1);
+  f.sh1 = s < 1 ? s : 1;
+  f.sh2 = s > 0 ? s - 1 : 0;
+  return f;
+}
+__device__ __forceinline__ unsigned fast_div(unsigned n, const FastDiv& f) {
+  const unsigned t = __umulhi(f.m, n);
+  return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+
+// PIPE (round 4, second form of the point loop: eight rows in flight, eight waves per SIMD): see the comment at the loop.
+template <bool WEIGHTED, bool PIPE>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE ? 8 : 4, PIPE ? 8 : 4))) splat_fwd_quad_kernel(const float* __restrict__ x, const float* __restrict__ weight,
                                                             const int* __restrict__ offsets, const int* __restrict__ list, int C,
-                                                            int plane, int tiles_per_plane, int d_hw, int hw, float* __restrict__ out) {
+                                                            int plane, int tiles_per_plane, FastDiv div_dhw, FastDiv div_hw, int hw,
+                                                            float* __restrict__ out) {
   typedef float f4 __attribute__((ext_vector_type(4)));
   __shared__ __attribute__((aligned(16))) float tile[kTileVox * kQPitch];
   const int bz = blockIdx.x / tiles_per_plane;
@@ -329,6 +349,14 @@ __global__ void __launch_bounds__(256) splat_fwd_quad_kernel(const float* __rest
   // chunks of sixteen stream slots until the busiest row of the wave is through
   int n_max = max(n_row, __shfl_xor(n_row, 16, 64));
   n_max = __builtin_amdgcn_readfirstlane(max(n_max, __shfl_xor(n_max, 32, 64)));
+  // (PIPE, registers: with the sixteen rows of a chunk alive all the time, the row's eight prefix counts / list offsets live in ONE
+  //  register spread over lanes 0..7 of the row and come back through row_share operands -- the kernel stays at four waves per SIMD)
+  const int tab = q == 0 ? p1 : q == 1 ? p2 : q == 2 ? p3 : q == 3 ? p4 : q == 4 ? o0 : q == 5 ? o1 : q == 6 ? o2 : o3;
+  // fused lift: frustum point id ((cam * D + d) * hw + pixel) -> context row cam * hw + pixel
+  auto lift_row = [&](int pid) {
+    const unsigned cam = fast_div((unsigned)pid, div_dhw), pq = fast_div((unsigned)pid, div_hw);
+    return (int)(cam * (unsigned)hw + ((unsigned)pid - pq * (unsigned)hw));
+  };
   for (int c0 = 0; c0 < C; c0 += 64) {
     const int cq = min(c0 + 4 * q, C - 4);                      // channel quad of this lane (chunks beyond C: clamped, not stored)
     // the row's own voxel rows start at zero (LDS executes a wave's operations in order: no barrier between these and the sums)
@@ -353,12 +381,82 @@ __global__ void __launch_bounds__(256) splat_fwd_quad_kernel(const float* __rest
     // (measured and not kept: the point ids of chunk k + 1 requested behind the row loads of chunk k -- one dependent round trip per
     //  chunk instead of two, but 138 registers instead of 122, i.e. three workgroups per CU instead of four: 25 -> 29 us at B = 1,
     //  71 -> 88 us at B = 8.  The kernel is bound by its instruction issue, which more resident waves fill better.)
+    const char* const xrow = reinterpret_cast<const char*>(x) + (size_t)cq * 4;
+    const unsigned xstride = (unsigned)C * 4u;
+    if constexpr (PIPE) {
+      // Round 4, second form of the point loop.  tools/ab_splat_fill.py: a plain fill of the B = 8 output takes 21 us, this kernel on
+      // an EMPTY plan 28 us, on the rig's plan 61 us -- the stores are not the bound; a workgroup lives ~9 us, most of it the three to
+      // five dependent round trips of its one or two chunks (CSR bounds -> point ids -> weights / rows), with four workgroups on a CU.
+      // (Measured and dropped first: the three loads of a slot as three pipeline stages across chunks -- ids two chunks ahead,
+      // every row register re-requested as soon as it is used, `vmcnt(17)` throughout: 60.4 -> 63.1 us at B = 8; rows hold one
+      // or two chunks, there is nothing to overlap.)  What the kernel responds to is workgroups in flight (three instead of four per
+      // CU: 25 -> 29 us, see above), so this form holds EIGHT rows of a chunk in registers instead of sixteen -- the register of
+      // point i is re-requested for point i + 8 as soon as it has been used -- and fits eight waves per SIMD.
+      // Instruction diet of the same round (the waves of a tile run at ~45 % slot occupancy, so what a slot costs matters): slots
+      // past a row's end need NO masking -- they come after the row's last voxel has been stored, what they add to `acc` is never
+      // written -- so they read the tile's first point (a valid row) and nothing is selected per point; the slot's row OFFSET is
+      // formed once per chunk and reaches the sixteen lanes as the DPP operand of one add with the lane's own channel offset
+      // (before: an id through a DPP move, then a quarter-rate v_mul_lo per point); "last point of its voxel" is the sign bit of
+      // the slot's word.
+      const unsigned xstride = (unsigned)C * 4u, cq4 = (unsigned)cq * 4u;
+      for (int k0 = 0; k0 < n_max; k0 += 16) {
+        int pid, meta_l;
+        {
+          const int sl = k0 + q;
+          const int t1 = row_share_i<0>(tab), t2 = row_share_i<1>(tab), t3 = row_share_i<2>(tab), t4 = row_share_i<3>(tab);
+          const int u0 = row_share_i<4>(tab), u1 = row_share_i<5>(tab), u2 = row_share_i<6>(tab), u3 = row_share_i<7>(tab);
+          const bool valid = sl < t4;
+          const bool c1 = sl >= t1, c2 = sl >= t2, c3 = sl >= t3;
+          const int pj = c3 ? t3 : (c2 ? t2 : (c1 ? t1 : 0));
+          const int pn = c3 ? t4 : (c2 ? t3 : (c1 ? t2 : t1));
+          const int oj = c3 ? u3 : (c2 ? u2 : (c1 ? u1 : u0));
+          const int vj = gid + (c3 ? 48 : (c2 ? 32 : (c1 ? 16 : 0)));
+          meta_l = vj | (sl + 1 == pn ? (int)0x80000000 : 0);      // (sl + 1 == pn implies a slot inside the row's stream)
+          pid = list[valid ? oj + (sl - pj) : off_beg];
+        }
+        float w_l = 1.0f;
+        int row_l = pid;
+        if constexpr (WEIGHTED) { w_l = weight[pid]; row_l = lift_row(pid); }
+        const int roff_l = (int)((unsigned)row_l * xstride);
+        f4 val[8];
+        // (loads pinned in program order: the scheduler issues independent loads last-first, and the first wait then covers them all)
+#define MF_SPLAT_LOAD(R, I) val[R] = *reinterpret_cast<const f4*>(reinterpret_cast<const char*>(x) + (size_t)((unsigned)row_share_i<I>(roff_l) + cq4)); \
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);
+        MF_SPLAT_LOAD(0, 0) MF_SPLAT_LOAD(1, 1) MF_SPLAT_LOAD(2, 2) MF_SPLAT_LOAD(3, 3) MF_SPLAT_LOAD(4, 4) MF_SPLAT_LOAD(5, 5) MF_SPLAT_LOAD(6, 6) MF_SPLAT_LOAD(7, 7)
+        // point I of the chunk from register R (nothing conditional in front of the store of a finished voxel: a load inside a
+        // branch makes the wait-count pass wait for everything), then -- NEXT -- the register goes to point I + 8
+#define MF_SPLAT_POINT8(R, I, NEXT)                                                                                \
+        {                                                                                                          \
+          const int meta = row_share_i<I>(meta_l);                                                                 \
+          f4 pr = val[R];                                                                                          \
+          if constexpr (WEIGHTED) {                                                                                \
+            const float wi = row_share_f<I>(w_l);                                                                  \
+            pr.x = mul_rounded(wi, pr.x); pr.y = mul_rounded(wi, pr.y); pr.z = mul_rounded(wi, pr.z); pr.w = mul_rounded(wi, pr.w); \
+          }                                                                                                        \
+          acc = acc + pr;                                    /* (a voxel's first point: 0 + x, as the kernels above) */ \
+          NEXT                                                                                                     \
+          if (meta < 0) {                                    /* last point of its voxel: its sum goes to the tile */ \
+            const int v = meta & 0xff;                                                                             \
+            *reinterpret_cast<f4*>(&tile[v * kQPitch + ((4 * q + 4 * (v >> 2)) & 63)]) = acc;                      \
+            acc = zero4;                                                                                           \
+          }                                                                                                        \
+        }
+        MF_SPLAT_POINT8(0, 0, MF_SPLAT_LOAD(0, 8)) MF_SPLAT_POINT8(1, 1, MF_SPLAT_LOAD(1, 9)) MF_SPLAT_POINT8(2, 2, MF_SPLAT_LOAD(2, 10))
+        MF_SPLAT_POINT8(3, 3, MF_SPLAT_LOAD(3, 11)) MF_SPLAT_POINT8(4, 4, MF_SPLAT_LOAD(4, 12)) MF_SPLAT_POINT8(5, 5, MF_SPLAT_LOAD(5, 13))
+        MF_SPLAT_POINT8(6, 6, MF_SPLAT_LOAD(6, 14)) MF_SPLAT_POINT8(7, 7, MF_SPLAT_LOAD(7, 15))
+        MF_SPLAT_POINT8(0, 8, ) MF_SPLAT_POINT8(1, 9, ) MF_SPLAT_POINT8(2, 10, ) MF_SPLAT_POINT8(3, 11, )
+        MF_SPLAT_POINT8(4, 12, ) MF_SPLAT_POINT8(5, 13, ) MF_SPLAT_POINT8(6, 14, ) MF_SPLAT_POINT8(7, 15, )
+#undef MF_SPLAT_POINT8
+#undef MF_SPLAT_LOAD
+      }
+    } else
     for (int k0 = 0; k0 < n_max; k0 += 16) {
       int pid, meta_l;
       MF_SPLAT_SLOT(k0, pid, meta_l)
       float w_l = 1.0f;
       int row_l = pid;
-      if constexpr (WEIGHTED) { w_l = weight[pid]; row_l = (pid / d_hw) * hw + pid % hw; }
+      if constexpr (WEIGHTED) { w_l = weight[pid]; row_l = lift_row(pid); }
       const char* xb = reinterpret_cast<const char*>(x) + (size_t)cq * 4;
       const unsigned rstride = (unsigned)C * 4u;
       f4 val[16];
@@ -402,9 +500,14 @@ __global__ void __launch_bounds__(256) splat_fwd_quad_kernel(const float* __rest
     }
     __syncthreads();
     // out[(bz * C + c) * plane + vid]: lane (g, q) = channel row wave * 16 + 4 i + g, voxels 4 q .. 4 q + 3 -> one 16-byte store
+    // (the lane's coordinates pass through an empty asm: the output addresses are invariant in this loop over the channel chunks,
+    //  the compiler hoisted all of them above the point loop and -- at 64 registers -- spilled them there)
+    int qo = q, go = g;
+    if constexpr (PIPE) asm volatile("" : "+v"(qo), "+v"(go));
     const int nch = min(64, C - c0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+      const int q = qo, g = go;
       const int cc = wave * 16 + 4 * i + g;
       const int col = (cc + 4 * q) & 63;                         // rotation of voxel rows 4 q .. 4 q + 3: (v >> 2) = q
       f4 r;
@@ -777,6 +880,10 @@ static int splat_prepare(const MfSplatDesc* d, const float* geom, const float* f
 
 // the 16-lanes-per-point forward: float32 rows of whole channel quads, 16-byte aligned output rows; MF_SPLAT_QUAD=0 keeps the
 // one-point-per-iteration kernels (A/B runs, bit-equality tests of the two)
+static bool quad_pipe() {      // MF_SPLAT_PIPE=0: the two-round-trips-per-chunk point loop (A/B runs)
+  static const bool off = getenv("MF_SPLAT_PIPE") && atoi(getenv("MF_SPLAT_PIPE")) == 0;
+  return !off;
+}
 static bool quad_forward_ok(const MfSplatDesc* d, int plane) {
   static const bool off = getenv("MF_SPLAT_QUAD") && atoi(getenv("MF_SPLAT_QUAD")) == 0;
   return !off && d->C % 4 == 0 && plane % 4 == 0 && (long long)d->C * 4 * ((long long)d->B * d->n_per_sample) < (1ll << 32);
@@ -790,8 +897,13 @@ static int splat_fwd(const MfSplatDesc* d, const S* x, const void* workspace, S*
   const int tpp = (plane + kTileVox - 1) / kTileVox;
   if constexpr (sizeof(S) == 4) {
     if (quad_forward_ok(d, plane)) {      // sixteen lanes per point (splat_fwd_quad_kernel)
-      hipLaunchKernelGGL((splat_fwd_quad_kernel<false>), dim3(d->B * d->nz * tpp), dim3(256), 0, st, x, (const float*)nullptr, ws.offsets, ws.list,
-                         d->C, plane, tpp, 1, 1, out);
+      const FastDiv one = fast_div_make(1);
+      if (quad_pipe())
+        hipLaunchKernelGGL((splat_fwd_quad_kernel<false, true>), dim3(d->B * d->nz * tpp), dim3(256), 0, st, x, (const float*)nullptr, ws.offsets,
+                           ws.list, d->C, plane, tpp, one, one, 1, out);
+      else
+        hipLaunchKernelGGL((splat_fwd_quad_kernel<false, false>), dim3(d->B * d->nz * tpp), dim3(256), 0, st, x, (const float*)nullptr, ws.offsets,
+                           ws.list, d->C, plane, tpp, one, one, 1, out);
       MF_LAUNCH_OK("splat_fwd");
       return MF_OK;
     }
@@ -831,8 +943,13 @@ static int lift_splat_fwd(const MfSplatDesc* d, const S* depth, const S* ctx, co
   const int tpp = (plane + kTileVox - 1) / kTileVox;
   if constexpr (sizeof(S) == 4) {
     if (quad_forward_ok(d, plane)) {
-      hipLaunchKernelGGL((splat_fwd_quad_kernel<true>), dim3(d->B * d->nz * tpp), dim3(256), 0, st, ctx, depth, ws.offsets, ws.list, d->C, plane, tpp,
-                         d->lift_D * d->lift_hw, d->lift_hw, out);
+      const FastDiv div_dhw = fast_div_make((unsigned)(d->lift_D * d->lift_hw)), div_hw = fast_div_make((unsigned)d->lift_hw);
+      if (quad_pipe())
+        hipLaunchKernelGGL((splat_fwd_quad_kernel<true, true>), dim3(d->B * d->nz * tpp), dim3(256), 0, st, ctx, depth, ws.offsets, ws.list, d->C, plane,
+                           tpp, div_dhw, div_hw, d->lift_hw, out);
+      else
+        hipLaunchKernelGGL((splat_fwd_quad_kernel<true, false>), dim3(d->B * d->nz * tpp), dim3(256), 0, st, ctx, depth, ws.offsets, ws.list, d->C, plane,
+                           tpp, div_dhw, div_hw, d->lift_hw, out);
       MF_LAUNCH_OK("lift_splat_fwd");
       return MF_OK;
     }
