@@ -340,18 +340,40 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE ?
   __shared__ int offs_sh[4][kTileVox + 1];
   offs_sh[wave][lane] = off_l;
   offs_sh[wave][kTileVox] = off_end;
-  const int o0 = offs_sh[wave][gid], o1 = offs_sh[wave][gid + 16], o2 = offs_sh[wave][gid + 32], o3 = offs_sh[wave][gid + 48];
-  const int p1 = gid < nvox ? offs_sh[wave][gid + 1] - o0 : 0;
-  const int p2 = p1 + (gid + 16 < nvox ? offs_sh[wave][gid + 17] - o1 : 0);
-  const int p3 = p2 + (gid + 32 < nvox ? offs_sh[wave][gid + 33] - o2 : 0);
-  const int p4 = p3 + (gid + 48 < nvox ? offs_sh[wave][gid + 49] - o3 : 0);
+  int o0, o1, o2, o3, p1, p2, p3, p4, v0 = gid, v1 = gid + 16, v2 = gid + 32, v3 = gid + 48;
+  unsigned long long occ = ~0ull;                                  // voxels whose LDS rows are written by their sums (PIPE)
+  if constexpr (PIPE) {
+    // The OCCUPIED voxels of the tile are dealt to the sixteen rows by rank (row r: the r-th, (r + 16)-th ... occupied voxel): a
+    // camera rig fills ~9 of a tile's 64 voxels, sixteen points each, usually neighbours -- dealt by voxel index (the form below)
+    // two of them meet in one row (a second chunk for the whole wave) while other waves idle: 1.77 chunks per tile on the slowest
+    // wave at the config-4 rig, ~45 % of the slots in use.  Which voxel a row sums does not change any sum.
+    const int cnt_l = lane < nvox ? offs_sh[wave][lane + 1] - off_l : 0;
+    occ = __ballot(cnt_l > 0);
+    const int n_occ = __popcll(occ);
+    __shared__ int vox_sh[4][kTileVox];
+    if (cnt_l > 0) vox_sh[wave][__popcll(occ & ((1ull << lane) - 1ull))] = lane;
+    const bool h0 = gid < n_occ, h1 = gid + 16 < n_occ, h2 = gid + 32 < n_occ, h3 = gid + 48 < n_occ;
+    v0 = h0 ? vox_sh[wave][gid] : 0; v1 = h1 ? vox_sh[wave][gid + 16] : 0; v2 = h2 ? vox_sh[wave][gid + 32] : 0; v3 = h3 ? vox_sh[wave][gid + 48] : 0;
+    o0 = offs_sh[wave][v0]; o1 = offs_sh[wave][v1]; o2 = offs_sh[wave][v2]; o3 = offs_sh[wave][v3];
+    p1 = h0 ? offs_sh[wave][v0 + 1] - o0 : 0;
+    p2 = p1 + (h1 ? offs_sh[wave][v1 + 1] - o1 : 0);
+    p3 = p2 + (h2 ? offs_sh[wave][v2 + 1] - o2 : 0);
+    p4 = p3 + (h3 ? offs_sh[wave][v3 + 1] - o3 : 0);
+  } else {
+    o0 = offs_sh[wave][gid]; o1 = offs_sh[wave][gid + 16]; o2 = offs_sh[wave][gid + 32]; o3 = offs_sh[wave][gid + 48];
+    p1 = gid < nvox ? offs_sh[wave][gid + 1] - o0 : 0;
+    p2 = p1 + (gid + 16 < nvox ? offs_sh[wave][gid + 17] - o1 : 0);
+    p3 = p2 + (gid + 32 < nvox ? offs_sh[wave][gid + 33] - o2 : 0);
+    p4 = p3 + (gid + 48 < nvox ? offs_sh[wave][gid + 49] - o3 : 0);
+  }
   const int n_row = p4;
   // chunks of sixteen stream slots until the busiest row of the wave is through
   int n_max = max(n_row, __shfl_xor(n_row, 16, 64));
   n_max = __builtin_amdgcn_readfirstlane(max(n_max, __shfl_xor(n_max, 32, 64)));
-  // (PIPE, registers: with the sixteen rows of a chunk alive all the time, the row's eight prefix counts / list offsets live in ONE
-  //  register spread over lanes 0..7 of the row and come back through row_share operands -- the kernel stays at four waves per SIMD)
-  const int tab = q == 0 ? p1 : q == 1 ? p2 : q == 2 ? p3 : q == 3 ? p4 : q == 4 ? o0 : q == 5 ? o1 : q == 6 ? o2 : o3;
+  // (PIPE, registers: the row's prefix counts / list offsets / voxels live in ONE register spread over lanes 0..11 of the row and
+  //  come back through row_share operands)
+  const int tab = q == 0 ? p1 : q == 1 ? p2 : q == 2 ? p3 : q == 3 ? p4 : q == 4 ? o0 : q == 5 ? o1 : q == 6 ? o2 : q == 7 ? o3
+                : q == 8 ? v0 : q == 9 ? v1 : q == 10 ? v2 : v3;
   // fused lift: frustum point id ((cam * D + d) * hw + pixel) -> context row cam * hw + pixel
   auto lift_row = [&](int pid) {
     const unsigned cam = fast_div((unsigned)pid, div_dhw), pq = fast_div((unsigned)pid, div_hw);
@@ -360,8 +382,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE ?
   for (int c0 = 0; c0 < C; c0 += 64) {
     const int cq = min(c0 + 4 * q, C - 4);                      // channel quad of this lane (chunks beyond C: clamped, not stored)
     // the row's own voxel rows start at zero (LDS executes a wave's operations in order: no barrier between these and the sums)
+    // (PIPE: the rows of occupied voxels are written by whichever row sums them -- only the others are cleared here)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<f4*>(&tile[(gid + 16 * j) * kQPitch + 4 * q]) = zero4;
+    for (int j = 0; j < 4; ++j)
+      if (!PIPE || !((occ >> (gid + 16 * j)) & 1ull)) *reinterpret_cast<f4*>(&tile[(gid + 16 * j) * kQPitch + 4 * q]) = zero4;
     f4 acc = zero4;
     // this lane's stream slot of the chunk at K0: its point id (slots past the end read a valid id and are masked) and flags.  Which
     // of the row's four voxels the slot falls into is decided by nested selects on scalars (indexing prefix / offset arrays with a
@@ -410,7 +434,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PIPE ?
           const int pj = c3 ? t3 : (c2 ? t2 : (c1 ? t1 : 0));
           const int pn = c3 ? t4 : (c2 ? t3 : (c1 ? t2 : t1));
           const int oj = c3 ? u3 : (c2 ? u2 : (c1 ? u1 : u0));
-          const int vj = gid + (c3 ? 48 : (c2 ? 32 : (c1 ? 16 : 0)));
+          const int w0 = row_share_i<8>(tab), w1 = row_share_i<9>(tab), w2 = row_share_i<10>(tab), w3 = row_share_i<11>(tab);
+          const int vj = c3 ? w3 : (c2 ? w2 : (c1 ? w1 : w0));
           meta_l = vj | (sl + 1 == pn ? (int)0x80000000 : 0);      // (sl + 1 == pn implies a slot inside the row's stream)
           pid = list[valid ? oj + (sl - pj) : off_beg];
         }
