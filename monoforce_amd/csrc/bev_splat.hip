@@ -11,12 +11,13 @@
 //     scan      exclusive prefix sum of the histogram -> CSR offsets
 //     fill      CSR lists of point ids per voxel
 //     rank      order each voxel's CSR segment by point id (thread per point: rank inside its short segment)
-//   forward   one workgroup per tile of 64 consecutive voxels of one BEV plane, 16 voxels per wave, lane = channel:
-//             the wave's points are one contiguous sorted range of the CSR list; their feature rows (C contiguous floats
-//             = one coalesced 256 B access per point) stream through a 16-deep, branch-free load pipeline and are accumulated in
-//             ascending point order (deterministic, bit-reproducible); the
-//             [channel][voxel] tile is transposed through LDS so every output row segment (64 voxels of one channel
-//             plane) is written as one contiguous 256 B store.  Empty voxels cost one offsets read.
+//   forward   one workgroup per tile of 64 consecutive voxels of one BEV plane.  float32 rows of whole channel quads (the reference's
+//             shapes): splat_fwd_quad_kernel -- sixteen lanes per point, the tile's OCCUPIED voxels dealt to the workgroup's sixteen
+//             rows by rank, eight feature rows in flight per row and eight waves per SIMD (the comment at the kernel has the
+//             measurements that led there); other shapes / float64: splat_fwd_kernel -- 16 voxels per wave, lane = channel, a
+//             16-deep branch-free load pipeline.  Every voxel is summed in ascending point order (deterministic, bit-reproducible,
+//             the same bits from both kernels); the [voxel][channel] tile is transposed through LDS so every output row segment
+//             (64 voxels of one channel plane) leaves as one contiguous 256 B store.  Tiles without points store zeros.
 //   backward  the same tiling in reverse: the grad tile is loaded coalesced per channel plane, and each kept point's
 //             feature-gradient row is written as one coalesced row (QuickCumsum.backward is exactly this gather);
 //             rows of dropped points are zero-filled by the keys pass of the backward.

@@ -57,7 +57,8 @@ AB_INTEG=0 AB_BWD=1 AB_B=1024,4096,8192 timeout 300 python tools/ab_cp.py 2> /de
 AB_B=1024,16384,65536 timeout 300 python tools/bench_planner.py > $OUT/${TAG}_bench_planner.jsonl 2> $OUT/bench_planner.err
 timeout 300 python tools/bench_lift_splat.py 2> $OUT/bench_lift_splat.err | grep '^B=' > $OUT/${TAG}_bench_lift_splat.txt
 timeout 300 bash tools/prof_splat.sh $TAG > /dev/null 2>&1
-timeout 500 bash tools/ab_midrange.sh $TAG > /dev/null 2>&1
+timeout 200 python tools/ab_splat_fill.py 2> /dev/null | grep '^B=' > $OUT/${TAG}_ab_splat_fill.txt
+[ -n "$MF_COLLECT_MIDRANGE" ] && timeout 500 bash tools/ab_midrange.sh $TAG > /dev/null 2>&1      # (the backward's forms at 2048 .. 8192 rollouts: ~6 minutes, on request)
 timeout 300 python tools/bench_graphed.py 2> $OUT/bench_graphed.err | grep n_trajs > $OUT/${TAG}_bench_graphed.txt
 AB_B=4 AB_N=100,175,223,400 timeout 300 python tools/ab_points.py 2> /dev/null | grep forces > $OUT/${TAG}_large_body_small_batch.txt
 AB_B=64 AB_N=100,175,223,400 timeout 300 python tools/ab_points.py 2> /dev/null | grep forces >> $OUT/${TAG}_large_body_small_batch.txt
