@@ -307,11 +307,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
       x = mf_fma(xd, h, x);
       w = mf_fma(wd, h, w);
       const S th2 = dot3(w, w);
-      const S kc = w * M::inv_len(th2);                            // K = [w]x / max(|w|, eps)
+      const S il = M::inv_len(th2);
+      const S kc = w * il;                                         // K = [w]x / max(|w|, eps)
       const S k1 = dpp<kRot1>(kc), k2 = dpp<kRot2>(kc);
       S sn_, oc;
-      M::sincos_small(M::sqrt(th2) * h, &sn_, &oc);
-      const S kk = dot3(kc, kc);
+      M::sincos_small(M::len_of(th2, il) * h, &sn_, &oc);
+      // |k|^2 (1 above the eps floor): fast math from the scalars at hand -- two multiplies, no second cross-lane sum in the step's chain
+      const S kk = M::kReciprocalNorm ? th2 * (il * il) : dot3(kc, kc);
       // row c of M = I + K sin + K^2 (1 - cos), stored relative to the diagonal: m0 = M[c][c], m1 = M[c][c+1], m2 = M[c][c+2]
       // (K[c][c+1] = -k_{c+2}, K[c][c+2] = k_{c+1}, K^2 = k k^T - |k|^2 I)
       const S ock = oc * kc;

@@ -77,6 +77,7 @@ struct Mth {
   static __device__ __forceinline__ S sigmoid_m10(S dh) { return (S)1 / ((S)1 + mf_exp((S)10 * dh)); }
   // v / max(|v|, eps) given |v|^2
   static __device__ __forceinline__ S inv_len(S len2) { return (S)1 / mf_max(mf_sqrt(len2), (S)1e-6); }
+  static __device__ __forceinline__ S len_of(S len2, S) { return mf_sqrt(len2); }      // |v| given |v|^2 (and inv_len(|v|^2), unused here)
   static constexpr bool kReciprocalNorm = false;
   static __device__ __forceinline__ void sincos_small(S v, S* s, S* omc) { S c; mf_sincos(v, s, &c); *omc = (S)1 - c; }
   static __device__ __forceinline__ S clamp(S v, S lo, S hi) { return mf_clamp(v, lo, hi); }   // torch.clamp, NaN propagates
@@ -101,20 +102,24 @@ struct Mth<float, true> {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(14.426950408889634f * dh));  // exp(10 dh) = 2^(10 log2(e) dh)
   }
   static __device__ __forceinline__ float inv_len(float len2) { return __builtin_amdgcn_rsqf(fmaxf(len2, 1e-12f)); }
+  // |v| = |v|^2 / |v| from the reciprocal at hand: a multiply instead of a second transcendental (below the 1e-6 floor of inv_len
+  // the product is |v|^2 1e6 < |v|: an angle of < 1e-8 rad per step either way)
+  static __device__ __forceinline__ float len_of(float len2, float il) { return len2 * il; }
   static constexpr bool kReciprocalNorm = true;
   static __device__ __forceinline__ float clamp(float v, float lo, float hi) { return __builtin_amdgcn_fmed3f(v, lo, hi); }  // 1 instr
   // joint angles (|a| of a few radians at most): hardware sin / cos after the 1 / 2pi scaling, ~1e-6 absolute
   static __device__ __forceinline__ void sincos(float v, float* sn, float* cs) { *sn = __sinf(v); *cs = __cosf(v); }
   // sin(v), 1 - cos(v) of the Rodrigues step, v = |w| dt ~ 1e-2.  Branch-free (a branch here splits the basic block the
-  // backward's two instruction streams are interleaved in): |v| < 1 -- Taylor series to v^11 / v^12 (< 2e-10), and 1 - cos
-  // without the cancellation; a body spinning faster than 1 rad per step gets the hardware sin / cos (~1e-6 absolute on
-  // values of order 1).
+  // backward's two instruction streams are interleaved in): |v| < 1 / 4 -- Taylor series to v^7 / v^8 (truncation < 1e-11
+  // relative), and 1 - cos without the cancellation; a body spinning faster than 25 rad/s at dt = 0.01 gets the hardware
+  // sin / cos (~1e-6 absolute on values of order 1).  (Round 4: the series ran to v^11 / v^12 below |v| < 1 -- four more FMAs
+  // in a loop that runs at its issue bound.)
   static __device__ __forceinline__ void sincos_small(float v, float* s, float* omc) {
     const float v2 = v * v;
-    const float ts = v * (1.0f + v2 * (-1.0f / 6 + v2 * (1.0f / 120 + v2 * (-1.0f / 5040 + v2 * (1.0f / 362880 - v2 * (1.0f / 39916800))))));
-    const float tc = v2 * (0.5f + v2 * (-1.0f / 24 + v2 * (1.0f / 720 + v2 * (-1.0f / 40320 + v2 * (1.0f / 3628800 - v2 * (1.0f / 479001600))))));
+    const float ts = v * (1.0f + v2 * (-1.0f / 6 + v2 * (1.0f / 120 - v2 * (1.0f / 5040))));
+    const float tc = v2 * (0.5f + v2 * (-1.0f / 24 + v2 * (1.0f / 720 - v2 * (1.0f / 40320))));
     const float rev = __builtin_amdgcn_fractf(v * 0.15915494309189535f);
-    const bool small = fabsf(v) < 1.0f;
+    const bool small = fabsf(v) < 0.25f;
     *s = small ? ts : __builtin_amdgcn_sinf(rev);
     *omc = small ? tc : 1.0f - __builtin_amdgcn_cosf(rev);
   }
