@@ -118,7 +118,10 @@ def test_plan_reuse():
 
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
 @pytest.mark.parametrize('shape', [dict(B=1, N=4, D=59, fH=16, fW=32, C=64, nx=256, nz=1), dict(B=2, N=3, D=7, fH=5, fW=9, C=80, nx=40, nz=2),
-                                   dict(B=1, N=1, D=70, fH=3, fW=4, C=5, nx=24, nz=1)])
+                                   dict(B=1, N=1, D=70, fH=3, fW=4, C=5, nx=24, nz=1),
+                                   # (round 4: the fused forward turns a point id into (camera, pixel) by multiply-high -- odd divisors, 1, a prime)
+                                   dict(B=2, N=2, D=59, fH=7, fW=11, C=64, nx=48, nz=1), dict(B=1, N=5, D=3, fH=1, fW=1, C=8, nx=16, nz=1),
+                                   dict(B=1, N=2, D=13, fH=1, fW=97, C=12, nx=32, nz=2)])
 def test_fused_lift_splat_equals_lift_then_splat(dtype, shape):
     """mf_bev_lift_splat_* (depth x context inside the splat) vs the materialised lift followed by the plain splat: forward,
     and the gradients w.r.t. depth and context, incl. C not a multiple of 64, D > 64, nz > 1 and dropped points."""
@@ -239,6 +242,36 @@ def test_random_clustered_pooling_vs_oracle(seed):
     """float64 pooling of random, clustered point sets vs the exact sums of the oracle (forward <= 1e-12, backward bit-exact):
     piles of up to 2000 points in one voxel, channel counts around 64, planes that are no multiple of the tile, 1..3 slabs."""
     _check_random_pool(seed)
+
+
+@pytest.mark.parametrize('seed', range(12))
+def test_random_clustered_pooling_float32_rows_in_flight_vs_oracle(seed):
+    """The float32 forward of round 4 (sixteen lanes per point, a tile's occupied voxels dealt to its rows by rank, eight rows in flight)
+    on random clustered problems -- piles of up to 2000 points in one voxel, one to three chunks per row and many, ragged last tiles,
+    C = 4 ... 132, empty samples -- against the oracle's exact (float64) sums: float32 accumulation of a pile in ascending point order
+    stays within 1e-5 of the largest sum; a dropped or doubled point would be 1e-2."""
+    rng = np.random.RandomState(7000 + seed)
+    B = int(rng.randint(1, 4))
+    C = int(rng.choice([4, 16, 64, 68, 132]))
+    nxy, nz = 2 * int(rng.randint(3, 36)), int(rng.randint(1, 4))                      # plane % 4 == 0: the sixteen-lane kernels' shapes
+    P = int(rng.choice([1, 63, 64, 65, 128, 500, 1500, 4000]))
+    dx = np.array([0.5, 0.5, 1.0], np.float32)
+    bx = np.array([-nxy * 0.25 + 0.25, -nxy * 0.25 + 0.25, -nz * 0.5 + 0.5], np.float32)
+    nx = np.array([nxy, nxy, nz])
+    spread = float(rng.choice([0.02, 0.1, 0.6]))
+    centre = (rng.rand(1, 1, 3).astype(np.float32) - 0.5) * np.array([nxy * 0.3, nxy * 0.3, nz * 0.5], np.float32)
+    geom = centre + (rng.rand(B, P, 3).astype(np.float32) - 0.5) * np.array([nxy * 0.5 * spread, nxy * 0.5 * spread, nz * 1.2], np.float32)
+    if P >= 128:
+        geom[0, :P // 2] = geom[0, 0]                                                  # half of sample 0 piled into ONE voxel
+    if B > 1 and seed % 3 == 0:
+        geom[-1] += 1000.0                                                             # an empty sample
+    x = rng.randn(B, P, C).astype(np.float32)
+    out, _ = pool(geom, x, dx, bx, nx)
+    assert out.dtype == torch.float32
+    ref, kept = so.voxel_pooling(geom, x.astype(np.float64), dx, bx, nx)
+    assert hp.rel_err(out, ref) <= 1e-5, (seed, hp.rel_err(out, ref))
+    out2, _ = pool(geom, x, dx, bx, nx)
+    assert torch.equal(out, out2)
 
 
 _QUAD_CHILD = r'''
