@@ -629,12 +629,20 @@ __global__ void __launch_bounds__(256) splat_bwd_kernel(const S* __restrict__ go
 }
 
 // rows of dropped points get zero gradient (x[kept] in the reference: no gradient reaches the others)
+// (a wave looks at 64 keys with one coalesced load and writes the rows of the few dropped ones; one wave per POINT -- a quarter of a
+//  million workgroups at B = 8, 94 % of which leave at once -- was 67 us there, more than half of the backward kernel itself)
 template <typename S>
 __global__ void __launch_bounds__(256) splat_bwd_zero_kernel(const int* __restrict__ keys, int P, int C, S* __restrict__ gx) {
   const int lane = threadIdx.x & 63;
-  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (p >= P || keys[p] >= 0) return;
-  for (int c = lane; c < C; c += 64) gx[(size_t)p * C + c] = (S)0;
+  const int p0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+  const int p = p0 + lane;
+  unsigned long long dropped = __ballot(p < P && keys[min(p, P - 1)] < 0);
+  while (dropped) {
+    const int k = __ffsll((long long)dropped) - 1;
+    dropped &= dropped - 1;
+    S* row = gx + (size_t)(p0 + k) * C;
+    for (int c = lane; c < C; c += 64) row[c] = (S)0;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -802,6 +810,63 @@ __global__ void __launch_bounds__(256) lift_splat_bwd_rows_quad_kernel(const flo
   }
 }
 
+// The plain splat's backward (QuickCumsum.backward: every kept point receives the gradient row of its voxel), sixteen lanes per point
+// (round 4; float32, C % 4 == 0, plane % 4 == 0).  splat_bwd_kernel above walks ONE point per wave iteration with 16 voxels per
+// wave -- at the config-4 rig a tile's ~140 points sit in ~9 neighbouring voxels, i.e. in one or two of its four waves (122 us at
+// B = 8 for 247 MB of rows).  Here the tile comes in through the rotated [voxel][channel] LDS tile of the kernel above, and the tile's
+// point list -- ONE contiguous CSR range -- is dealt to the waves in chunks of 64 whatever the voxels: a wave reads 64 point ids
+// and their voxels (the key array of the plan) with two coalesced loads, then four points per instruction: a 16-byte LDS read of
+// the voxel's row and a 16-byte store per lane.  A pure gather: no summation order to keep.
+__global__ void __launch_bounds__(256) splat_bwd_quad_kernel(const float* __restrict__ gout, const int* __restrict__ offsets,
+                                                            const int* __restrict__ list, const int* __restrict__ keys, int C, int plane,
+                                                            int tiles_per_plane, float* __restrict__ gx) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  __shared__ __attribute__((aligned(16))) float tile[kTileVox * kQPitch];
+  const int bz = blockIdx.x / tiles_per_plane;
+  const int vid0 = (blockIdx.x % tiles_per_plane) * kTileVox;
+  const int nvox = min(kTileVox, plane - vid0);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int key0 = bz * plane + vid0;
+  const int off_beg = offsets[key0], off_end = offsets[key0 + nvox];      // (scalar loads: the tile's CSR range)
+  if (off_end == off_beg) return;
+  const int n = off_end - off_beg;
+  const int q = lane & 15, g = lane >> 4;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    const int nch = min(64, C - c0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int cc = wave * 16 + 4 * i + g;
+      f4 r = {0.f, 0.f, 0.f, 0.f};
+      if (cc < nch) {
+        const float* o = gout + ((size_t)bz * C + c0 + cc) * plane + vid0 + 4 * q;
+        if (nvox == kTileVox) r = *reinterpret_cast<const f4*>(o);
+        else { r.x = 4 * q + 0 < nvox ? o[0] : 0.f; r.y = 4 * q + 1 < nvox ? o[1] : 0.f; r.z = 4 * q + 2 < nvox ? o[2] : 0.f; r.w = 4 * q + 3 < nvox ? o[3] : 0.f; }
+      }
+      const int col = (cc + 4 * q) & 63;                         // rotation of voxel rows 4 q .. 4 q + 3 (v >> 2 = q)
+      tile[(4 * q + 0) * kQPitch + col] = r.x; tile[(4 * q + 1) * kQPitch + col] = r.y;
+      tile[(4 * q + 2) * kQPitch + col] = r.z; tile[(4 * q + 3) * kQPitch + col] = r.w;
+    }
+    __syncthreads();
+    const int cq = c0 + 4 * q;
+    for (int k0 = wave * 64; k0 < n; k0 += 256) {
+      const int m = min(64, n - k0);
+      const int pid_l = list[off_beg + k0 + min(lane, m - 1)];
+      const int v_l = keys[pid_l] - key0;                        // the point's voxel inside the tile
+#pragma unroll 4
+      for (int i = 0; i < 16; ++i) {
+        const int idx = 4 * i + g;                               // this row's point of the chunk
+        const int pid = __shfl(pid_l, idx, 64), v = __shfl(v_l, idx, 64);
+        if (idx < m && cq < C) {
+          const f4 r = *reinterpret_cast<const f4*>(&tile[v * kQPitch + ((4 * q + 4 * (v >> 2)) & 63)]);
+          __builtin_nontemporal_store(r, reinterpret_cast<f4*>(gx + (size_t)pid * C + cq));
+        }
+        if (4 * i + 4 >= m) break;                               // (wave-uniform)
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // Step 2, sixteen lanes per (camera, pixel), lane q = channels 4 q .. 4 q + 3: along the pixel's D depth bins
 //   g_depth[p] = <ctx[pixel], gT[voxel(p)]>  (four products per lane, a 16-lane DPP sum),  g_ctx[pixel] += depth[p] * gT[voxel(p)];
 // a wave instruction covers four pixels (the one-pixel-per-wave kernel above spends ~25 instructions per point, 6 of them the 64-lane
@@ -946,7 +1011,14 @@ static int splat_bwd(const MfSplatDesc* d, const S* gout, const void* workspace,
   const int P = d->B * d->n_per_sample;
   const int plane = d->nx * d->ny;
   const int tpp = (plane + kTileVox - 1) / kTileVox;
-  hipLaunchKernelGGL((splat_bwd_zero_kernel<S>), dim3((P + 3) / 4), dim3(256), 0, st, ws.keys, P, d->C, gx);
+  hipLaunchKernelGGL((splat_bwd_zero_kernel<S>), dim3((P + 255) / 256), dim3(256), 0, st, ws.keys, P, d->C, gx);
+  if constexpr (sizeof(S) == 4) {
+    if (quad_forward_ok(d, plane)) {      // sixteen lanes per point (splat_bwd_quad_kernel)
+      hipLaunchKernelGGL(splat_bwd_quad_kernel, dim3(d->B * d->nz * tpp), dim3(256), 0, st, gout, ws.offsets, ws.list, ws.keys, d->C, plane, tpp, gx);
+      MF_LAUNCH_OK("splat_bwd");
+      return MF_OK;
+    }
+  }
   hipLaunchKernelGGL((splat_bwd_kernel<S>), dim3(d->B * d->nz * tpp), dim3(256), 0, st, gout, ws.offsets, ws.list, d->C, plane, tpp, gx);
   MF_LAUNCH_OK("splat_bwd");
   return MF_OK;
