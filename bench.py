@@ -14,7 +14,7 @@ max over ranks), inputs resident in HBM, outputs allocated inside the timed regi
 the step is replayed as a hipGraph, owned by the captured graph.  Launch mode (`config.launch`): after the warm-up the step is
 timed both ways on the host at hand -- launched call by call, and captured once and replayed as ONE hipGraph launch per step
 (same kernels, same work) -- and the timed region runs in the faster mode; MF_BENCH_NO_GRAPH=1 keeps it launch by launch.
-Kernel durations for `roofline` come from HIP events around the C-ABI launches of every 8th timed step (those steps run
+Kernel durations for `roofline` come from HIP events around the C-ABI launches of every 32nd timed step and of four steps run right after the region (those steps run
 launch by launch in either mode).
 Rollouts are independent: ranks shard the batch with no data-path collective (weak scaling: B rollouts per GPU); the
 backward all-reduces the gradient of what the ranks SHARE -- one terrain / friction map pair, the same on every rank
@@ -57,7 +57,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s HBM3E peak (~6.3 TB/s achievable)
-EVENT_EVERY = 8              # kernel durations: HIP events around the launches of every 8th step of the timed region
+EVENT_EVERY = 32             # kernel durations: HIP events around the launches of every 32nd step of the timed region (+ sampled steps after it)
 
 WORKLOADS = {
     'c1': dict(B=1, T=200, N=4, backward=True, grid_res=0.1, desc='BASELINE configs[0]: 1 rollout x 200 steps, 128x128 terrain, forward + backward'),
@@ -360,7 +360,7 @@ class Runner:
             launch = {'mode': ('two hipGraph replays around the exchange' if split else 'one hipGraph replay per step') if mode['graph'] else 'launch by launch',
                       'calibration_ms_per_step': {'graph': t_graph, 'eager': t_eager}}
         self.barrier()
-        # HIP events around the C-ABI launches of every 8th step of the timed region, on the stream the kernel is launched on
+        # HIP events around the C-ABI launches of every 32nd step of the timed region, on the stream the kernel is launched on
         # (around all of them they cost 33 us of a 0.55 ms step: each record is a packet of its own between two kernels)
         # (`events_after`, the side workloads of the default line -- a handful of steps each: a step bracketed with events runs launch by
         #  launch, and one such step among five replays of a 16 ms graph IS the average on a host that is slow at launching -- c4 read
@@ -373,12 +373,16 @@ class Runner:
             step()
         self.barrier()
         elapsed = time.perf_counter() - t0
+        # more samples of the kernel durations from steps run right after the region (untimed; a bracketed step runs launch by launch,
+        # which is why the region itself carries few of them: at K = 20 every 8th step was 3 of 20 steps at 0.45-0.58 instead of 0.385 ms)
         if events_after:
             _timing.start(every=1)
-            for _ in range(max(2, min(steps // 2, 6))):
-                _timing.next_step()
-                step()
-            self.barrier()
+        else:
+            _timing.set_every(1)
+        for _ in range(max(2, min(steps // 2, 6)) if events_after else 4):
+            _timing.next_step()
+            step()
+        self.barrier()
         kern = {k: float(np.mean(v)) for k, v in _timing.stop().items()}       # average launch duration per kernel, ms
         elapsed_min, elapsed = self.max_over_ranks(elapsed, 'MIN'), self.max_over_ranks(elapsed)
         # the exchange step on its own (the backward's one collective), so that a scaling curve can be read
@@ -453,7 +457,7 @@ class Runner:
                          'frac_note': '`frac` = SURVEY 8d algorithmic bytes (map cells counted even when cache-served) / kernel time / 8 TB/s; '
                                       '`frac_hbm` = the same model without the cache-served bytes; `traffic` = PMC-measured HBM bytes',
                          'kernel': dom, 'kernel_ms': kern[dom], 'kernel_ms_from': ('HIP events around the launches of sampled steps run right after the timed region (the region itself: replays only)'
-                                                           if events_after else f'HIP events around the launches of every {EVENT_EVERY}th timed step'),
+                                                           if events_after else f'HIP events around the launches of every {EVENT_EVERY}th timed step and of four steps run right after the region'),
                          'algorithmic_bytes_per_launch': alg[dom], 'bytes_per_rollout_step': alg[dom] // (B * T),
                          'per_kernel': per_kernel},
         }

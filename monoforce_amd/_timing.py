@@ -19,6 +19,12 @@ def start(capacity=4096, every=1):
     _every, _step = max(int(every), 1), -1
 
 
+def set_every(every):
+    """Change the sampling period of a running recording (the records so far are kept)."""
+    global _every, _step
+    _every, _step = max(int(every), 1), -1
+
+
 def next_step():
     global _step
     _step += 1
