@@ -213,6 +213,10 @@ int mf_rollout_loss_fusable(const MfRolloutDesc* desc);
  * body (forward +5 %, backward -17 % at 1024 rollouts x 4 points), and bodies of 5..512 points up to two waves per SIMD
  * (16 bytes per rollout-step; backward 2.05 -> 1.04 ms at 64 rollouts x 223 points, 1.38 -> 0.97 ms at 1024 x 32). */
 long long mf_rollout_record_bytes(const MfRolloutDesc* desc);
+/* 1 where mf_rollout_fwd_f32, given `zmu_scratch` and no `zmu`, fills the scratch with the interleaved (z, mu) pair (few-point bodies on the
+ * component-parallel kernels from half a wave per SIMD up): the caller may hand that buffer to mf_rollout_bwd_f32 as `zmu` for the same
+ * step and maps -- the backward then runs no interleave pass of its own. */
+int mf_rollout_fwd_stages_zmu(const MfRolloutDesc* desc);
 /* The same for the _f64 entry points: non-zero only for the float64 VALIDATION build of the component-parallel kernels
  * (points_per_lane = MF_LANES_COMPONENT: the float32 kernels' source instantiated on double, 32-byte quads), which exists so that the
  * code the BASELINE configurations run can be held to the float64 oracle (dphysics.py:172-272, 467-528 under float64) over the full
@@ -269,6 +273,10 @@ typedef struct MfRolloutBwdBufs {
   const void* rec;          /* the record the forward wrote (MfRolloutFwdBufs.rec of the same desc), or NULL: recompute */
   const MfRolloutLoss* loss; /* the forward's fused physics loss (then all six upstream pointers are NULL: the kernel forms dL/dXs
                                itself from loss->Xs, gt, w and gloss), or NULL */
+  void* zmu_scratch;        /* optional scratch, 2*H*W floats (8-byte aligned), as MfRolloutFwdBufs.zmu_scratch: with a SHARED float32 map
+                               pair the record-reading backward (two to four waves of rollouts per CU) re-gathers a cell's (z, mu)
+                               with ONE 8-byte load from an interleaved copy it stages here (B = 4096: 0.45 -> 0.40 ms) */
+  const void* zmu;          /* optional, float32: the SHARED maps already interleaved (MfRolloutFwdBufs.zmu of the same step) */
 } MfRolloutBwdBufs;
 
 /* 1 if the backward kernels chosen for this descriptor always write the control gradient (gcontrols must then be a buffer), 0 if

@@ -4,6 +4,12 @@
 #include "rollout_bwd_mw_kernel.h"
 
 namespace mf {
+// (z, mu) of the shared maps interleaved (as rollout_fwd.hip's pass for the forward's ZMU kernels)
+template <typename S>
+__global__ void __launch_bounds__(256) interleave_maps_bwd_kernel(const S* __restrict__ z, const S* __restrict__ mu, int n, cp::Pk2<S>* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = cp::Pk2<S>{z[i], mu[i]};
+}
 
 template <typename S>
 static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* stream) {
@@ -40,6 +46,7 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
   a.joint_angles = (const S*)p->joint_angles;
   a.gjoint = (S*)p->gjoint_angles;
   a.rec = nullptr;
+  a.zmu = nullptr;
   a.loss_T2 = 0; a.loss_gt = nullptr; a.loss_row_stamp = nullptr; a.loss_row_w = nullptr; a.loss_gloss = nullptr; a.loss_inv_count = (S)0;
   a.loss_partial = nullptr; a.loss_ticket = nullptr; a.loss_out = nullptr;
   MF_REQUIRE(!p->gjoint_angles || p->joint_angles, MF_ERR_INVALID, "rollout_bwd: gjoint_angles without joint_angles");
@@ -97,7 +104,18 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
       a.rec = (const S*)p->rec;
     }
     const bool xs_only = (p->gXs || p->loss) && !p->gXds && !p->gRs && !p->gOmegas && !p->gFs && !p->gFf;
-    if constexpr (sizeof(S) == 4) return launch_rollout_bwd_cp_f32(a, d->integrator, xs_only, st);
+    if constexpr (sizeof(S) == 4) {
+      if ((p->zmu || p->zmu_scratch) && cp_bwd_wants_zmu(d, a.rec != nullptr, p->mu != nullptr)) {      // interleaved (z, mu) for the record-reading kernel
+        MF_REQUIRE((((uintptr_t)p->zmu_scratch | (uintptr_t)p->zmu) & 7) == 0, MF_ERR_INVALID, "rollout_bwd: zmu_scratch / zmu must be 8-byte aligned");
+        if (p->zmu) a.zmu = (const S*)p->zmu;
+        else {
+          const int n = d->H * d->W;
+          hipLaunchKernelGGL((interleave_maps_bwd_kernel<S>), dim3((n + 255) / 256), dim3(256), 0, st, a.z, a.mu, n, (cp::Pk2<S>*)p->zmu_scratch);
+          a.zmu = (const S*)p->zmu_scratch;
+        }
+      }
+      return launch_rollout_bwd_cp_f32(a, d->integrator, xs_only, st);
+    }
     else return launch_rollout_bwd_cp_f64(a, d->integrator, xs_only, st);
   }
   const LaneMap m = choose_lane_map(d->B, d->N, d->points_per_lane == MF_LANES_COMPONENT ? 0 : d->points_per_lane);

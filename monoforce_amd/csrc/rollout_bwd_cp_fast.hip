@@ -64,6 +64,16 @@ bool cp_loss_fusable(const MfRolloutDesc* d) {
   const long long grid = ((long long)d->B * 16 + 63) / 64;
   return grid <= (long long)cp_stream_max_grid(d->integrator);
 }
+// The record-reading kernel (kCpSaved: beyond the streaming form's grid, up to one wave per SIMD) re-gathers every cell's (z, mu); with
+// a shared float32 pair it reads them interleaved.  MF_CP_BWD_ZMU=0: two 4-byte loads per cell (A/B runs, parity of the two).
+bool cp_bwd_wants_zmu(const MfRolloutDesc* d, bool has_rec, bool has_mu) {
+  static const bool off = getenv("MF_CP_BWD_ZMU") && atoi(getenv("MF_CP_BWD_ZMU")) == 0;
+  static const int forced = getenv("MF_CP_BWD_MODE") ? atoi(getenv("MF_CP_BWD_MODE")) : -1;
+  if (off || !d || !d->map_shared || !has_rec || !has_mu || d->integrator != MF_INTEG_ODEINT_EULER || d->math_mode != MF_MATH_FAST) return false;
+  if ((long long)d->H * d->W * 8 >= (1ll << 31)) return false;      // 32-bit byte offsets into the (z, mu) cells
+  const long long grid = ((long long)d->B * 16 + 63) / 64;
+  return forced == kCpSaved || grid > (long long)cp_stream_max_grid(d->integrator);
+}
 bool cp_loss_in_forward(const MfRolloutDesc* d) { return cp_loss_fusable(d) && d->integrator == MF_INTEG_ODEINT_EULER; }
 
 }  // namespace mf

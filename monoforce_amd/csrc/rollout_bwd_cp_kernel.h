@@ -55,7 +55,7 @@ extern __device__ unsigned long long mf_stream_prof[16];
 #else
 #define MF_STREAM_WPE __attribute__((amdgpu_waves_per_eu((MODE == kCpStream && XS_ONLY && sizeof(S) == 4) ? 2 : 1)))
 #endif
-template <typename S, int INTEG, bool XS_ONLY, bool GCTRL, int MODE, int SLOTS = 6, int BATCH = 3>
+template <typename S, int INTEG, bool XS_ONLY, bool GCTRL, int MODE, int SLOTS = 6, int BATCH = 3, bool ZMU = false>
 // (streaming, positions-only loss: at most 256 registers, so that two workgroups -- six waves -- share a CU's four SIMDs)
 __global__ void __launch_bounds__(MODE == kCpStream ? 192 : 256) MF_STREAM_WPE
 rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
@@ -468,6 +468,12 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
       // (Measured and dropped, round 4: lanes q and q ^ 2 hold neighbouring cells and could share ONE two-element load per map, as
       //  gather4 does for one point per lane -- 32 addresses per wave instead of 64.  4096 rollouts: 0.446 -> 0.49 ms; a dwordx2 at a
       //  4-byte-aligned address costs the L1 more than the two lane accesses it replaces.)
+      if constexpr (ZMU) {      // the shared maps interleaved: the cell's (z, mu) as ONE aligned 8-byte load -- half the address lookups of
+                                // the step's gathers where four such waves share a CU's L1 (B = 4096: 0.45 -> 0.40 ms)
+        const Pk2<S> zm = *reinterpret_cast<const Pk2<S>*>(reinterpret_cast<const char*>(a.zmu) + (size_t)((unsigned)v.idx * (unsigned)(2 * sizeof(S))));
+        v.zc = zm.a; v.mc = zm.b;
+        return;
+      }
       v.zc = ld32(zmap, moff + (unsigned)v.idx);
       v.mc = ld32(mumap, moff + (unsigned)v.idx);
     };
@@ -1155,6 +1161,7 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
 bool use_component_parallel_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, int scalar_bytes = 4);
 long long cp_record_bytes(const MfRolloutDesc* d, int scalar_bytes);      // bytes of the forward's per-step record for this launch shape (0: none)
 bool cp_loss_fusable(const MfRolloutDesc* d);           // both directions of this launch can carry the fused physics loss
+bool cp_bwd_wants_zmu(const MfRolloutDesc* d, bool has_rec, bool has_mu);      // the launch will run the record-reading kernel on interleaved maps if it gets them
 int launch_rollout_bwd_cp_f32(const RolloutBwdArgs<float>& a, int integ, bool xs_only, hipStream_t st);   // a.gcontrols may be NULL
 int launch_rollout_bwd_cp_dynamics_f32(const RolloutBwdArgs<float>& a, bool xs_only, hipStream_t st);      // rollout_bwd_dyn_cp_fast.hip
 void launch_rollout_bwd_cp_stream_f32(const RolloutBwdArgs<float>& a, bool xs_only, unsigned grid, hipStream_t st);   // rollout_bwd_cp_stream_fast.hip
@@ -1198,10 +1205,14 @@ int launch_rollout_bwd_cp_variant(const RolloutBwdArgs<S>& a, bool xs_only, hipS
   const int saved_mode = grid <= cp_stream_max_grid_of<S>(INTEG) && forced != kCpSaved ? kCpStream : kCpSaved;
   const int mode = a.rec ? saved_mode : (forced >= 0 && forced < kCpSaved ? forced : ((long long)grid <= device_simds() ? kCpLate : kCpEarly));
 #define MF_BCP(XS_, GC_, M_) hipLaunchKernelGGL((rollout_bwd_cp_kernel<S, INTEG, XS_, GC_, M_>), dim3(wgs), dim3(block), 0, st, a)
-#define MF_BCP_L(XS_, GC_) do { if (mode == kCpStream) launch_rollout_bwd_cp_stream_any(a, INTEG, xs_only, grid, st); else if (mode == kCpSaved) MF_BCP(XS_, GC_, kCpSaved); else if (mode == kCpLate) MF_BCP(XS_, GC_, kCpLate); else MF_BCP(XS_, GC_, kCpEarly); } while (0)
+  // (the record-reading mode on the interleaved maps the host staged: cp_bwd_wants_zmu)
+  constexpr bool kZmu = std::is_same<S, float>::value && INTEG == MF_INTEG_ODEINT_EULER;
+#define MF_BCP_Z(XS_, GC_) do { if constexpr (kZmu) { if (a.zmu) { hipLaunchKernelGGL((rollout_bwd_cp_kernel<S, INTEG, XS_, GC_, kCpSaved, 6, 3, kZmu>), dim3(wgs), dim3(block), 0, st, a); break; } } MF_BCP(XS_, GC_, kCpSaved); } while (0)
+#define MF_BCP_L(XS_, GC_) do { if (mode == kCpStream) launch_rollout_bwd_cp_stream_any(a, INTEG, xs_only, grid, st); else if (mode == kCpSaved) MF_BCP_Z(XS_, GC_); else if (mode == kCpLate) MF_BCP(XS_, GC_, kCpLate); else MF_BCP(XS_, GC_, kCpEarly); } while (0)
   if (xs_only) { if (gc) MF_BCP_L(true, true); else MF_BCP_L(true, false); }
   else         { if (gc) MF_BCP_L(false, true); else MF_BCP_L(false, false); }
 #undef MF_BCP_L
+#undef MF_BCP_Z
 #undef MF_BCP
   hipError_t e = hipGetLastError();
   MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("rollout_bwd (component-parallel) launch: ") + hipGetErrorString(e));

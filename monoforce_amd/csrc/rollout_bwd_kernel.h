@@ -31,6 +31,7 @@ struct RolloutBwdArgs {
   S joint_xyz[12];
   S* gjoint;               // [B,T,4] out: gradient of the flipper angles, or NULL
   const S* rec;            // component-parallel kernels: the forward's per-step record (rollout_fwd_cp_kernel.h), or NULL
+  const S* zmu;            // record-reading component-parallel kernel (ZMU): the shared maps interleaved, S[H*W][2] = (z, mu), or NULL
   // fused physics loss (MfRolloutLoss; streaming component-parallel backward): gXs points at the forward's Xs rows then
   int loss_T2;
   const S* loss_gt;        // NULL: no fused loss

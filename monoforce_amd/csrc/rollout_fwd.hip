@@ -90,19 +90,27 @@ __global__ void __launch_bounds__(256) interleave_maps_kernel(const S* __restric
   if (i < n) out[i] = cp::Pk2<S>{z[i], mu ? mu[i] : (S)1};
 }
 // true (and a.zmu set, the interleave pass launched) when this launch can read the interleaved copy
+// the launch shapes whose kernels read the shared maps interleaved ...
+static bool zmu_shape(const MfRolloutDesc* d, bool joints, const LaneMap& m, int scalar_bytes) {
+  if (!d->map_shared || d->math_mode != MF_MATH_FAST || joints || m.PPL != 1 || m.G > 64) return false;
+  return (long long)d->H * d->W * (long long)scalar_bytes < (1ll << 31);   // 32-bit byte offsets into the (z, mu) cells
+}
+// ... and those that run the interleave pass into a scratch they are offered:
+// below ~half a wave per SIMD the launch is bound by the instruction stream of its waves; the extra pass (a second launch in
+// front of the rollout, ~10 us) then costs what the two saved gathers bring (measured: B = 1024 path costs 0.306 -> 0.323 ms)
+// (the float64 validation build takes the pass whenever it is offered: its purpose is to run the ZMU kernels)
+static bool zmu_pass(const MfRolloutDesc* d, const LaneMap& m, int scalar_bytes) {
+  return scalar_bytes != 4 || (long long)d->B * m.G >= device_simds() / 2 * 64;      // (half a wave per SIMD)
+}
 template <typename S>
 static bool use_interleaved_maps(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, RolloutArgs<S>* a, const LaneMap& m, hipStream_t st) {
-  if ((!p->zmu_scratch && !p->zmu) || !d->map_shared || d->math_mode != MF_MATH_FAST || p->joint_angles || m.PPL != 1 || m.G > 64) return false;
-  if ((long long)d->H * d->W * (long long)sizeof(S) >= (1ll << 31)) return false;   // 32-bit byte offsets into the (z, mu) cells
+  if ((!p->zmu_scratch && !p->zmu) || !zmu_shape(d, p->joint_angles != nullptr, m, (int)sizeof(S))) return false;
   if (p->zmu && p->mu) {   // the caller staged the interleaved pair itself (mf_terrain_stage_fwd_f32): no pass, no batch-size condition
     a->zmu = (const S*)p->zmu;
     return true;
   }
   if (!p->zmu_scratch) return false;
-  // Below ~half a wave per SIMD the launch is bound by the instruction stream of its waves; the extra pass (a second launch in
-  // front of the rollout, ~10 us) then costs what the two saved gathers bring (measured: B = 1024 path costs 0.306 -> 0.323 ms)
-  // (the float64 validation build takes the pass whenever it is offered: its purpose is to run the ZMU kernels)
-  if (sizeof(S) == 4 && (long long)d->B * m.G < device_simds() / 2 * 64) return false;      // (half a wave per SIMD)
+  if (!zmu_pass(d, m, (int)sizeof(S))) return false;
   const int n = d->H * d->W;
   hipLaunchKernelGGL((interleave_maps_kernel<S>), dim3((n + 255) / 256), dim3(256), 0, st, a->z, a->mu, n, (cp::Pk2<S>*)p->zmu_scratch);
   a->zmu = (const S*)p->zmu_scratch;
@@ -141,6 +149,15 @@ static int rollout_fwd_cp(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, Rol
   return launch_rollout_fwd_cp_any(a, d->integrator, forces, zmu, st);
 }
 }  // namespace mf
+
+// 1 where mf_rollout_fwd_f32 given `zmu_scratch` (and no `zmu`) fills it with the interleaved (z, mu) pair on the component-parallel route:
+// the caller may then hand the same buffer to mf_rollout_bwd_f32 as `zmu` (same step, same maps) and spare the backward its own pass
+extern "C" int mf_rollout_fwd_stages_zmu(const MfRolloutDesc* d) {
+  if (!d || d->B <= 0 || d->T <= 0 || d->has_joints) return 0;
+  MfRolloutFwdBufs none{};
+  const mf::LaneMap m{16, 1};
+  return mf::use_component_parallel(d, &none) && mf::zmu_shape(d, false, m, 4) && mf::zmu_pass(d, m, 4) ? 1 : 0;
+}
 
 extern "C" int mf_rollout_fwd_f32(const MfRolloutDesc* d, const MfRolloutFwdBufs* p, void* s) {
   mf::RolloutArgs<float> a;

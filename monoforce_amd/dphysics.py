@@ -243,13 +243,14 @@ def _rollout_forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_gra
         nbytes = int(rb(C.byref(desc)))
         if nbytes > 0:
             rec = torch.empty(nbytes // dt.itemsize, dtype=dt, device=dev)
+    zmu_scratch, zmu_staged = _zmu_scratch(mod, desc, keep['z']), mod._staged_zmu(desc, z, mu)
     bufs = _lib.MfRolloutFwdBufs(
         z=_lib.ptr(keep['z']), mu=_lib.ptr(keep['mu']), controls=_lib.ptr(controls), ts=_lib.ptr(ts),
         points=_lib.ptr(keep['points']), part=_lib.ptr(mod._part_dev(dev)),
         x0=_lib.ptr(x0), xd0=_lib.ptr(xd0), R0=_lib.ptr(R0), w0=_lib.ptr(w0),
         Xs=_lib.ptr(Xs), Xds=_lib.ptr(Xds), Rs=_lib.ptr(Rs), Omegas=_lib.ptr(Om), Fs=_lib.ptr(Fs), Ff=_lib.ptr(Ff),
         Xraw=_lib.ptr(Xraw), joint_angles=_lib.ptr(joint_angles),
-        zmu_scratch=_lib.ptr(_zmu_scratch(mod, desc, keep['z'])), zmu=_lib.ptr(mod._staged_zmu(desc, z, mu)), rec=_lib.ptr(rec))
+        zmu_scratch=_lib.ptr(zmu_scratch), zmu=_lib.ptr(zmu_staged), rec=_lib.ptr(rec))
     loss_val = lstruct = None
     in_backward = loss is not None and len(loss) > 2 and bool(loss[2]) and want_grad      # MF_LOSS_VALUE_IN_BACKWARD
     in_forward = loss is not None and mod.loss_in_forward and not in_backward and desc.integrator == _lib.MF_INTEG_ODEINT_EULER      # (the LOSS kernels: default integrator)
@@ -295,6 +296,10 @@ def _rollout_forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_gra
     ctx.set_materialize_grads(False)
     if want_grad:
         ctx.mod, ctx.desc, ctx.keep = mod, desc, keep
+        # (the backward's record-reading kernel reads the shared maps interleaved too: the staged pair, or this scratch, which it fills itself)
+        ctx.zmu = (zmu_scratch, zmu_staged) if keep['mu'] is not None else (None, None)
+        if ctx.zmu[1] is None and zmu_scratch is not None and dt == torch.float32 and _lib.lib().mf_rollout_fwd_stages_zmu(C.byref(desc)):
+            ctx.zmu = (None, zmu_scratch)       # this launch filled the scratch: the backward reads it as it is
         ctx.z_shape, ctx.mu_shape, ctx.mu_given = z.shape, (mu.shape if mu is not None else None), mu is not None
         ctx.z_expanded = z.stride(0) == 0 and z.shape[0] > 1
         ctx.mu_expanded = mu is not None and mu.stride(0) == 0 and mu.shape[0] > 1

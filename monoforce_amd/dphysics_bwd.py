@@ -144,7 +144,7 @@ def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf, gloss=None):
         gFs=_lib.ptr(ups[4]), gFf=_lib.ptr(ups[5]), zeros=_lib.ptr(zero_row),
         gz=_lib.ptr(gz), gmu=_lib.ptr(gmu), gcontrols=_lib.ptr(gcontrols), gx0=_lib.ptr(gx0),
         gxd0=_lib.ptr(gxd0), gR0=_lib.ptr(gR0), gw0=_lib.ptr(gw0), joint_angles=_lib.ptr(ja), gjoint_angles=_lib.ptr(gja),
-        rec=_lib.ptr(getattr(ctx, 'rec', None)))
+        rec=_lib.ptr(getattr(ctx, 'rec', None)), zmu_scratch=_lib.ptr(getattr(ctx, 'zmu', (None, None))[0]), zmu=_lib.ptr(getattr(ctx, 'zmu', (None, None))[1]))
     if gloss is not None:       # the forward carried physics_loss itself (MfRolloutLoss): the kernel forms dL/dXs from Xs and the ground truth
         spec, X_gt, Xs_rows, loss_out = ctx.loss
         gl = gloss.to(dt).reshape(1).contiguous()
