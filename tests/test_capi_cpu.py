@@ -121,3 +121,20 @@ def test_control_tensor_classification_on_the_host():
     assert t.is_contiguous() and (sb, st) == (0, 0) and torch.equal(t, dense)
     t, sb, st = _kernel_controls(c, allow_view=False)
     assert t.is_contiguous() and (sb, st) == (0, 0)
+
+
+def test_forward_reports_where_it_stages_the_interleaved_maps(built_lib):
+    """mf_rollout_fwd_stages_zmu: the component-parallel forward fills `zmu_scratch` from half a wave per SIMD up, for a SHARED float32 map
+    pair of a rigid body of <= 4 points -- the buffer the record-reading backward may then be handed as `zmu` (no GPU needed: the query
+    uses the MI355X's geometry when no device is present)."""
+    from monoforce_amd import _lib
+    def stages(**kw):  # noqa: E306
+        base = dict(B=4096, T=500, N=4, H=256, W=256, n_tracks=2, integrator=1, math_mode=_lib.MF_MATH_FAST, force_stride=4, map_shared=1,
+                    layout=_lib.MF_LAYOUT_TIME_MAJOR)
+        base.update(kw)
+        return built_lib.mf_rollout_fwd_stages_zmu(ctypes.byref(_lib.MfRolloutDesc(**base)))
+    assert stages() == 1 and stages(B=2048) == 1
+    assert stages(B=1024) == 0                      # below half a wave per SIMD the pass costs what it brings
+    assert stages(map_shared=0) == 0 and stages(math_mode=0) == 0 and stages(N=32, force_stride=32) == 0 and stages(has_joints=1) == 0
+    assert stages(B=100000) == 0                    # beyond the component-parallel kernels' range
+    assert built_lib.mf_rollout_fwd_stages_zmu(None) == 0
