@@ -612,9 +612,9 @@ def main():
                     args.integrator = 1
             others['c4'] = brief(r.run('c4', 5, 4, events_after=True)[0])
         else:
-            others['strong_c3'] = brief(r.run('c3', short, 3, batch=max(8192 // r.world, 1))[0])
+            others['strong_c3'] = brief(r.run('c3', short, 3, batch=max(8192 // r.world, 1), events_after=True)[0])
             others['strong_c3']['scaling'] = 'strong (8192 rollouts in total)'
-            others['c5'] = brief(r.run('c5', 5, 4)[0])
+            others['c5'] = brief(r.run('c5', 5, 4, events_after=True)[0])
     if r.rank == 0:
         out = {'metric': 'rollout-steps/sec (batch x horizon) on 256x256 terrain', 'value': res['value'], 'unit': 'rollout-steps/s',
                'n_gpus': r.world, 'world_size': r.dist_world, 'backend': ('rccl' if r.backend == 'nccl' else r.backend) if r.dist_on else None,
