@@ -405,8 +405,15 @@ int mf_interpolate_grid_f32(const MfInterpDesc* desc, const float* grid, const f
 int mf_interpolate_grid_f64(const MfInterpDesc* desc, const double* grid, const double* xq, const double* yq, double* z_out, double* n_out,
                             int32_t* cells_out, double* frac_out, void* hip_stream);
 
-/* Text of the calling thread's last error ("" if none). */
+/* Text of the calling thread's last error ("" if none).  THREAD-LOCAL: host threads driving different streams each read the message
+ * of their own failed call (the reference raises a Python exception in the calling thread, dphysics.py:575,579 asserts). */
 const char* mf_last_error(void);
+/* Which rollout kernel the calling thread's last mf_rollout_fwd_* / mf_rollout_bwd_* call launched: the demangled kernel template
+ * with its parameters (lane mapping, integrator, arithmetic, record / streaming mode ...), grid, workgroup size and the thread's
+ * launch count, e.g. "mf::rollout_bwd_cp_kernel<float, 1, true, false, 3, 12, 3, false> grid=256 block=192 launches=7"; "" before
+ * the first launch.  Diagnostic only (bench.py reports it as config.launch; the reference has one code path, dphysics.py:530-594,
+ * this library has a dispatcher).  Thread-local. */
+const char* mf_last_launch(void);
 /* Library version, e.g. "monoforce_hip 0.1 gfx950". */
 const char* mf_version(void);
 /* sizeof() of an ABI struct by name ("MfRolloutDesc", ...), -1 if unknown: lets bindings verify their mirrors. */

@@ -41,17 +41,24 @@ class _DepthwiseNative(torch.autograd.Function):
     profiles/r4e_c4_kernel_stats.csv); the backend is chosen again in the backward, hence a Function and not just a
     context manager around the forward."""
 
+    # (under autocast the forward runs in the autocast dtype and the backward sees the same dtypes: without these decorators the
+    #  saved half-precision input met a float32 weight in `convolution_backward`.  ADVICE r4.)
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda')
     def forward(ctx, x, w, stride, padding):
+        if w.dtype != x.dtype:
+            w = w.to(x.dtype)
         ctx.save_for_backward(x, w)
         ctx.conf = (stride, padding)
         with torch.backends.cudnn.flags(enabled=False):
             return F.conv2d(x, w, None, stride, padding, 1, w.shape[0])
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, g):
         x, w = ctx.saved_tensors
         stride, padding = ctx.conf
+        g = g.to(x.dtype)
         with torch.backends.cudnn.flags(enabled=False):
             gx, gw, _ = torch.ops.aten.convolution_backward(g.contiguous(), x, w, None, list(stride), list(padding), [1, 1], False, [0, 0],
                                                             w.shape[0], [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
@@ -142,9 +149,14 @@ class MBConvBlock(nn.Module):
         return x
 
 
-def _bn_forward_without_counter(self, x):
-    return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, self.training or self.running_mean is None,
-                        self.momentum, self.eps)
+class BatchNorm2dCounted(nn.BatchNorm2d):
+    """BatchNorm2d whose `num_batches_tracked` is bumped by its owner's `_CounterBank` (one kernel for all layers) instead of by
+    its own forward.  A class, not a per-instance `forward` patch: `torch.save(model)` pickles it, `copy.deepcopy` keeps it, and
+    `SyncBatchNorm.convert_sync_batchnorm` replaces it like any other batch norm (the converted layers count for themselves)."""
+
+    def forward(self, x):
+        return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, self.training or self.running_mean is None,
+                            self.momentum, self.eps)
 
 
 class _CounterBank:
@@ -161,7 +173,7 @@ class _CounterBank:
         for i, m in enumerate(self.mods):
             m._buffers['num_batches_tracked'] = self.flat[i]
 
-    def __call__(self, root, args):
+    def __call__(self, root, args=None):
         if not root.training or not self.mods:
             return
         m0 = self.mods[0].num_batches_tracked
@@ -170,17 +182,28 @@ class _CounterBank:
         self.flat.add_(1)
 
 
-def fuse_batchnorm_counters(root):
-    """Batch-norm layers with a fixed momentum do not read `num_batches_tracked`; they only count.  Count for all of them
-    at once in a forward pre-hook of `root` (every layer runs once per forward of the encoder).  State dicts keep the keys."""
+def fuse_batchnorm_counters(root, owners=None):
+    """Batch-norm layers with a fixed momentum do not read `num_batches_tracked`; they only count.  Count for all layers of an
+    OWNER with one kernel: the owner calls `bump_batchnorm_counters(self)` where its batch norms run (CamEncode.get_eff_depth,
+    BevEncode.forward) -- not a forward hook of the root: training code that calls the sub-modules directly (`get_cam_feats`,
+    `camencode.get_depth_and_context`, `get_voxels` + `bevencode`; the fused lift does, and the reference's notebooks do) then
+    advances the counters exactly like a forward of the root.  State dicts keep the keys."""
     if not lean():
         return root
-    mods = [m for m in root.modules() if isinstance(m, nn.modules.batchnorm._BatchNorm) and m.track_running_stats
-            and m.momentum is not None and m.num_batches_tracked is not None]
-    for m in mods:
-        m.forward = types.MethodType(_bn_forward_without_counter, m)
-    root.register_forward_pre_hook(_CounterBank(mods))
+    for owner in (owners if owners is not None else [root]):
+        mods = [m for m in owner.modules() if type(m) in (nn.BatchNorm2d, BatchNorm2dCounted) and m.track_running_stats
+                and m.momentum is not None and m.num_batches_tracked is not None]
+        for m in mods:
+            m.__class__ = BatchNorm2dCounted
+        object.__setattr__(owner, '_bn_counter_bank', _CounterBank(mods))
     return root
+
+
+def bump_batchnorm_counters(owner):
+    """One `num_batches_tracked` bump for every batch norm of `owner` (training mode only); no-op without a bank."""
+    bank = owner.__dict__.get('_bn_counter_bank')
+    if bank is not None:
+        bank(owner)
 
 
 class _GlobalParams:

@@ -32,6 +32,17 @@ inline unsigned wave_unit_block(unsigned waves) {
   return waves > 2u * cus && waves <= 4u * cus ? 256u : 64u;
 }
 
+// Which kernel an entry point launched (mf_last_launch, capi.hip): the rollout dispatchers note the host stub, grid and workgroup
+// of every launch in thread-local storage -- two stores, no formatting; the name is looked up (hipKernelNameRefByPtr) and demangled
+// only when somebody asks.
+void note_launch(const void* kernel_stub, unsigned grid, unsigned block);
+#define MF_KLAUNCH(kernel, grid, block, shmem, stream, ...)                                             \
+  do {                                                                                                  \
+    const dim3 mf_g_ = (grid), mf_b_ = (block);                                                         \
+    ::mf::note_launch(reinterpret_cast<const void*>(&kernel), mf_g_.x, mf_b_.x);                         \
+    hipLaunchKernelGGL(kernel, mf_g_, mf_b_, shmem, stream, __VA_ARGS__);                               \
+  } while (0)
+
 #define MF_REQUIRE(cond, code, msg)        \
   do {                                     \
     if (!(cond)) {                         \

@@ -1204,10 +1204,10 @@ int launch_rollout_bwd_cp_variant(const RolloutBwdArgs<S>& a, bool xs_only, hipS
   // rings fit the CUs' LDS), else one wave reads it itself; without a record at most one wave per SIMD: late recompute
   const int saved_mode = grid <= cp_stream_max_grid_of<S>(INTEG) && forced != kCpSaved ? kCpStream : kCpSaved;
   const int mode = a.rec ? saved_mode : (forced >= 0 && forced < kCpSaved ? forced : ((long long)grid <= device_simds() ? kCpLate : kCpEarly));
-#define MF_BCP(XS_, GC_, M_) hipLaunchKernelGGL((rollout_bwd_cp_kernel<S, INTEG, XS_, GC_, M_>), dim3(wgs), dim3(block), 0, st, a)
+#define MF_BCP(XS_, GC_, M_) MF_KLAUNCH((rollout_bwd_cp_kernel<S, INTEG, XS_, GC_, M_>), dim3(wgs), dim3(block), 0, st, a)
   // (the record-reading mode on the interleaved maps the host staged: cp_bwd_wants_zmu)
   constexpr bool kZmu = std::is_same<S, float>::value && INTEG == MF_INTEG_ODEINT_EULER;
-#define MF_BCP_Z(XS_, GC_) do { if constexpr (kZmu) { if (a.zmu) { hipLaunchKernelGGL((rollout_bwd_cp_kernel<S, INTEG, XS_, GC_, kCpSaved, 6, 3, kZmu>), dim3(wgs), dim3(block), 0, st, a); break; } } MF_BCP(XS_, GC_, kCpSaved); } while (0)
+#define MF_BCP_Z(XS_, GC_) do { if constexpr (kZmu) { if (a.zmu) { MF_KLAUNCH((rollout_bwd_cp_kernel<S, INTEG, XS_, GC_, kCpSaved, 6, 3, kZmu>), dim3(wgs), dim3(block), 0, st, a); break; } } MF_BCP(XS_, GC_, kCpSaved); } while (0)
 #define MF_BCP_L(XS_, GC_) do { if (mode == kCpStream) launch_rollout_bwd_cp_stream_any(a, INTEG, xs_only, grid, st); else if (mode == kCpSaved) MF_BCP_Z(XS_, GC_); else if (mode == kCpLate) MF_BCP(XS_, GC_, kCpLate); else MF_BCP(XS_, GC_, kCpEarly); } while (0)
   if (xs_only) { if (gc) MF_BCP_L(true, true); else MF_BCP_L(true, false); }
   else         { if (gc) MF_BCP_L(false, true); else MF_BCP_L(false, false); }

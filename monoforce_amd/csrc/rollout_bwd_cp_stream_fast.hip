@@ -21,8 +21,8 @@ void launch_rollout_bwd_cp_stream_f32(const RolloutBwdArgs<float>& a, bool xs_on
   const bool gc = a.gcontrols != nullptr;
   static const int big_ring_env = getenv("MF_CP_STREAM_BIG_RING_MAX_GRID") ? atoi(getenv("MF_CP_STREAM_BIG_RING_MAX_GRID")) : -1;
   const unsigned big_ring_max = big_ring_env >= 0 ? (unsigned)big_ring_env : (unsigned)device_cus();      // one workgroup per CU
-#define MF_BCPS(XS_, GC_) do { if (grid <= big_ring_max) hipLaunchKernelGGL((rollout_bwd_cp_kernel<float, I, XS_, GC_, kCpStream, 12>), dim3(grid), dim3(192), 0, st, a); \
-                               else hipLaunchKernelGGL((rollout_bwd_cp_kernel<float, I, XS_, GC_, kCpStream, 6, (XS_ ? 2 : 3)>), dim3(grid), dim3(192), 0, st, a); } while (0)
+#define MF_BCPS(XS_, GC_) do { if (grid <= big_ring_max) MF_KLAUNCH((rollout_bwd_cp_kernel<float, I, XS_, GC_, kCpStream, 12>), dim3(grid), dim3(192), 0, st, a); \
+                               else MF_KLAUNCH((rollout_bwd_cp_kernel<float, I, XS_, GC_, kCpStream, 6, (XS_ ? 2 : 3)>), dim3(grid), dim3(192), 0, st, a); } while (0)
   if (xs_only) { if (gc) MF_BCPS(true, true); else MF_BCPS(true, false); }
   else         { if (gc) MF_BCPS(false, true); else MF_BCPS(false, false); }
 #undef MF_BCPS

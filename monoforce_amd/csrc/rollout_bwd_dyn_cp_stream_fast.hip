@@ -9,7 +9,7 @@ namespace mf {
 void launch_rollout_bwd_cp_stream_dynamics_f32(const RolloutBwdArgs<float>& a, bool xs_only, unsigned grid, hipStream_t st) {
   constexpr int I = MF_INTEG_DYNAMICS;
   const bool gc = a.gcontrols != nullptr;
-#define MF_BCPS(XS_, GC_) hipLaunchKernelGGL((rollout_bwd_cp_kernel<float, I, XS_, GC_, kCpStream, 6>), dim3(grid), dim3(192), 0, st, a)
+#define MF_BCPS(XS_, GC_) MF_KLAUNCH((rollout_bwd_cp_kernel<float, I, XS_, GC_, kCpStream, 6>), dim3(grid), dim3(192), 0, st, a)
   if (xs_only) { if (gc) MF_BCPS(true, true); else MF_BCPS(true, false); }
   else         { if (gc) MF_BCPS(false, true); else MF_BCPS(false, false); }
 #undef MF_BCPS

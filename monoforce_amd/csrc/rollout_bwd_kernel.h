@@ -768,9 +768,9 @@ int launch_rollout_bwd(const RolloutBwdArgs<S>& a, LaneMap m, int integ, int blo
   if (!launched && m.G == G_ && m.PPL == P_) {                                                                                     \
     launched = true;                                                                                                               \
     if (integ == MF_INTEG_DYNAMICS)                                                                                                \
-      hipLaunchKernelGGL((rollout_bwd_kernel<S, G_, P_, MF_INTEG_DYNAMICS, FAST, JOINTS, CARRY>), dim3(grid), dim3(block), 0, st, a);      \
+      MF_KLAUNCH((rollout_bwd_kernel<S, G_, P_, MF_INTEG_DYNAMICS, FAST, JOINTS, CARRY>), dim3(grid), dim3(block), 0, st, a);      \
     else                                                                                                                           \
-      hipLaunchKernelGGL((rollout_bwd_kernel<S, G_, P_, MF_INTEG_ODEINT_EULER, FAST, JOINTS, CARRY>), dim3(grid), dim3(block), 0, st, a);  \
+      MF_KLAUNCH((rollout_bwd_kernel<S, G_, P_, MF_INTEG_ODEINT_EULER, FAST, JOINTS, CARRY>), dim3(grid), dim3(block), 0, st, a);  \
   }
   MF_CASE(4, 1) MF_CASE(8, 1) MF_CASE(16, 1) MF_CASE(32, 1) MF_CASE(64, 1) MF_CASE(64, 2) MF_CASE(64, 4) MF_CASE(64, 8)
   MF_CASE(128, 1) MF_CASE(256, 1) MF_CASE(512, 1)

@@ -675,7 +675,7 @@ int launch_rollout_bwd_mw_t(const RolloutBwdArgs<S>& a, int G, int integ, bool x
   // 256 CUs.  MF_MW_TILE=0 keeps the register accumulators (A/B runs, parity of the two routes).
   static const bool tile_off = getenv("MF_MW_TILE") && atoi(getenv("MF_MW_TILE")) == 0;
   bool launched = false;
-#define MF_LAUNCH(G_, XS_, T_, I_) hipLaunchKernelGGL((rollout_bwd_mw_kernel<S, G_, XS_, T_, I_>), dim3(grid), dim3(blk), 0, st, a)
+#define MF_LAUNCH(G_, XS_, T_, I_) MF_KLAUNCH((rollout_bwd_mw_kernel<S, G_, XS_, T_, I_>), dim3(grid), dim3(blk), 0, st, a)
 #define MF_CASE(G_)                                                                                              \
   if (!launched && G == G_) {                                                                                    \
     launched = true;                                                                                             \

@@ -387,16 +387,16 @@ int launch_rollout_fwd_cp_t(const RolloutArgs<S>& a, int integ, bool forces, boo
   const bool rec = a.rec != nullptr;
   if (a.loss_gt) {      // fused physics loss: default integrator, states only (the host checked)
     constexpr int I = MF_INTEG_ODEINT_EULER;
-    if (rec) { if (zmu) hipLaunchKernelGGL((rollout_fwd_cp_kernel<S, I, false, true, true, true>), dim3(grid), dim3(block), 0, st, a);
-               else hipLaunchKernelGGL((rollout_fwd_cp_kernel<S, I, false, false, true, true>), dim3(grid), dim3(block), 0, st, a); }
-    else     { if (zmu) hipLaunchKernelGGL((rollout_fwd_cp_kernel<S, I, false, true, false, true>), dim3(grid), dim3(block), 0, st, a);
-               else hipLaunchKernelGGL((rollout_fwd_cp_kernel<S, I, false, false, false, true>), dim3(grid), dim3(block), 0, st, a); }
+    if (rec) { if (zmu) MF_KLAUNCH((rollout_fwd_cp_kernel<S, I, false, true, true, true>), dim3(grid), dim3(block), 0, st, a);
+               else MF_KLAUNCH((rollout_fwd_cp_kernel<S, I, false, false, true, true>), dim3(grid), dim3(block), 0, st, a); }
+    else     { if (zmu) MF_KLAUNCH((rollout_fwd_cp_kernel<S, I, false, true, false, true>), dim3(grid), dim3(block), 0, st, a);
+               else MF_KLAUNCH((rollout_fwd_cp_kernel<S, I, false, false, false, true>), dim3(grid), dim3(block), 0, st, a); }
     hipError_t e = hipGetLastError();
     MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("rollout_fwd (component-parallel, fused loss) launch: ") + hipGetErrorString(e));
     return MF_OK;
   }
-#define MF_CP(INTEG_, FORCES_, ZMU_) do { if (rec) hipLaunchKernelGGL((rollout_fwd_cp_kernel<S, INTEG_, FORCES_, ZMU_, true>), dim3(grid), dim3(block), 0, st, a); \
-                                          else hipLaunchKernelGGL((rollout_fwd_cp_kernel<S, INTEG_, FORCES_, ZMU_, false>), dim3(grid), dim3(block), 0, st, a); } while (0)
+#define MF_CP(INTEG_, FORCES_, ZMU_) do { if (rec) MF_KLAUNCH((rollout_fwd_cp_kernel<S, INTEG_, FORCES_, ZMU_, true>), dim3(grid), dim3(block), 0, st, a); \
+                                          else MF_KLAUNCH((rollout_fwd_cp_kernel<S, INTEG_, FORCES_, ZMU_, false>), dim3(grid), dim3(block), 0, st, a); } while (0)
 #define MF_CP_F(INTEG_)                                          \
   do {                                                           \
     if (forces) { if (zmu) MF_CP(INTEG_, true, true); else MF_CP(INTEG_, true, false); }    \

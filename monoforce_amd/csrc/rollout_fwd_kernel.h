@@ -1084,9 +1084,9 @@ int launch_rollout_fwd(const RolloutArgs<S>& a, LaneMap m, int integ, int block,
   if (!launched && m.G == G_ && m.PPL == P_) {                                                                                             \
     launched = true;                                                                                                                       \
     if (integ == MF_INTEG_DYNAMICS)                                                                                                        \
-      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_DYNAMICS, FAST, JOINTS, FORCES, COST, SPLIT, ZMU>), dim3(grid), dim3(block), 0, st, ac);     \
+      MF_KLAUNCH((rollout_fwd_kernel<S, G_, P_, MF_INTEG_DYNAMICS, FAST, JOINTS, FORCES, COST, SPLIT, ZMU>), dim3(grid), dim3(block), 0, st, ac);     \
     else                                                                                                                                   \
-      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, P_, MF_INTEG_ODEINT_EULER, FAST, JOINTS, FORCES, COST, SPLIT, ZMU>), dim3(grid), dim3(block), 0, st, ac); \
+      MF_KLAUNCH((rollout_fwd_kernel<S, G_, P_, MF_INTEG_ODEINT_EULER, FAST, JOINTS, FORCES, COST, SPLIT, ZMU>), dim3(grid), dim3(block), 0, st, ac); \
   }
   if (!JOINTS) { MF_CASE(4, 1) MF_CASE(8, 1) MF_CASE(16, 1) MF_CASE(32, 1) MF_CASE(64, 1) }
   if constexpr (!SPLIT && !ZMU) {   // SPLIT / ZMU kernels: the one-point-per-lane mappings up to a wave only
@@ -1114,10 +1114,10 @@ int launch_rollout_fwd_mw_rec(const RolloutArgs<S>& a, LaneMap m, int integ, hip
     const int blk = G_ > 64 ? G_ : 64;                                                                                       \
     const unsigned grid = (unsigned)(((long long)a.B * G_ + blk - 1) / blk);                                                 \
     if (integ == MF_INTEG_DYNAMICS)                                                                                          \
-      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, 1, MF_INTEG_DYNAMICS, true, false, FORCES, 0, SPLIT, ZMU, true>),    \
+      MF_KLAUNCH((rollout_fwd_kernel<S, G_, 1, MF_INTEG_DYNAMICS, true, false, FORCES, 0, SPLIT, ZMU, true>),    \
                          dim3(grid), dim3(blk), 0, st, a);                                                                   \
     else                                                                                                                     \
-      hipLaunchKernelGGL((rollout_fwd_kernel<S, G_, 1, MF_INTEG_ODEINT_EULER, true, false, FORCES, 0, SPLIT, ZMU, true>), \
+      MF_KLAUNCH((rollout_fwd_kernel<S, G_, 1, MF_INTEG_ODEINT_EULER, true, false, FORCES, 0, SPLIT, ZMU, true>), \
                          dim3(grid), dim3(blk), 0, st, a);                                                                   \
   }
   MF_CASE(8) MF_CASE(16) MF_CASE(32) MF_CASE(64)

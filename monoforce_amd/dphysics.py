@@ -211,6 +211,15 @@ class LossSpec:
 def _rollout_forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_grad, joint_angles=None, want_forces=True,
                      x0_buf=None, x0_private=False, default_state=False, loss=None):
     """One `mf_rollout_fwd_*` launch; `loss` = (LossSpec, X_gt[B,T2,3]) fuses physics_loss into it (outs then start with the loss)."""
+    # (the library's policy queries -- record bytes, force stride, who stages the interleaved maps -- read the CU count of the CURRENT
+    #  device: everything runs with the tensors' device current, not only the launch itself.  ADVICE r4.)
+    with torch.cuda.device(z.device):
+        return _rollout_forward_on_device(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_grad, joint_angles, want_forces,
+                                          x0_buf, x0_private, default_state, loss)
+
+
+def _rollout_forward_on_device(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_grad, joint_angles, want_forces,
+                               x0_buf, x0_private, default_state, loss):
     # x_arg is the autograd input (the caller's start position when it requires grad); the kernel works on x0_buf, the
     # detached contiguous buffer that receives the snapped height.  x0_private: nobody else sees that buffer.
     x0 = x0_buf if x0_buf is not None else x_arg
@@ -517,7 +526,16 @@ class DPhysics(torch.nn.Module):
         xd0, R0, w0 = (s.to(device=dev, dtype=dtype).contiguous() for s in state[1:])
         want_grad = torch.is_grad_enabled() and any(
             t is not None and t.requires_grad for t in (z_grid, friction, controls, x_in, xd0, R0, w0, ja_dev))
-        cp64 = dtype == torch.float64 and self.points_per_lane == _lib.MF_LANES_COMPONENT      # the validation build of the fast kernels
+        # the float64 validation build of the fast kernels: a states-only forward exists where the component-parallel kernels run
+        # (N <= 4) or a multi-wave record is kept for a backward (mf_rollout_record_bytes_f64 > 0) -- elsewhere float64 needs the force
+        # buffers (mf_rollout_fwd_f64), so they stay (N > 4 under no_grad, or B beyond the record range)
+        cp64 = dtype == torch.float64 and self.points_per_lane == _lib.MF_LANES_COMPONENT and ja_dev is None
+        if cp64 and self.x_points.shape[1] > 4:
+            dq = _lib.MfRolloutDesc(B=B, T=N_ts, N=self.x_points.shape[1], H=z_grid.shape[-2], W=z_grid.shape[-1], n_tracks=len(cfg.driving_parts),
+                                    integrator=_lib.MF_INTEG_ODEINT_EULER if cfg.use_odeint else _lib.MF_INTEG_DYNAMICS,
+                                    points_per_lane=self.points_per_lane, math_mode=_lib.MF_MATH_FAST)
+            with torch.cuda.device(dev):
+                cp64 = want_grad and int(_lib.lib().mf_rollout_record_bytes_f64(C.byref(dq))) > 0
         want_forces = self.return_forces or self.precise or (dtype != torch.float32 and not cp64) or ja_dev is not None
         # a start position that requires grad is the autograd input itself (its gradient: x and y through the contact geometry,
         # z none -- the snap overwrites it); the kernel works on the detached buffer x0 either way
@@ -571,7 +589,8 @@ class DPhysics(torch.nn.Module):
                                    integrator=_lib.MF_INTEG_ODEINT_EULER if self.dphys_cfg.use_odeint else _lib.MF_INTEG_DYNAMICS,
                                    math_mode=_lib.MF_MATH_FAST, force_stride=max(self.x_points.shape[1], 4), map_shared=1, layout=_lib.MF_LAYOUT_TIME_MAJOR,
                                    points_per_lane=self.points_per_lane)
-            ok = bool(_lib.lib().mf_rollout_loss_fusable(C.byref(d)))
+            with torch.cuda.device(torch.device(self.device)):
+                ok = bool(_lib.lib().mf_rollout_loss_fusable(C.byref(d)))
         if not ok:
             # (the loss reads the positions only: the forward writes the states, not the 24 N bytes of force rows per rollout-step -- for the
             #  reference's 223-point body 36 of 241 MB per launch; `return_forces` is restored for the module's other callers)

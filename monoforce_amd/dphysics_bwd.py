@@ -96,6 +96,12 @@ def grad_pool(owner, n_maps, copies, n, dt, dev):
     return p
 
 def rollout_backward(ctx, gXs, gXds, gRs, gOm, gFs, gFf, gloss=None):
+    # (policy queries -- mf_rollout_bwd_wants_gcontrols -- read the CU count of the CURRENT device: the tensors' device, throughout)
+    with torch.cuda.device(ctx.saved_tensors[0].device):
+        return _rollout_backward_on_device(ctx, gXs, gXds, gRs, gOm, gFs, gFf, gloss)
+
+
+def _rollout_backward_on_device(ctx, gXs, gXds, gRs, gOm, gFs, gFf, gloss):
     from .dphysics import _scalar_suffix, _stream_ptr
     controls, x_init, xd0, R0, w0, ts, Xraw, Xds, Rs, Om = ctx.saved_tensors
     desc, keep, mod = ctx.desc, ctx.keep, ctx.mod

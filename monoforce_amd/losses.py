@@ -66,6 +66,7 @@ def rotation_difference(R1, R2, reduction='mean'):
 
 
 _TICKETS = {}
+_CAPTURED_TICKETS = []      # counters whose ADDRESS a captured hipGraph replays into: never freed (4 bytes each), whatever the LRU / reset does
 
 
 def _ticket(device, stream):
@@ -78,6 +79,8 @@ def _ticket(device, stream):
             _TICKETS.pop(next(iter(_TICKETS)))
         t = torch.zeros(1, dtype=torch.int32, device=device)
     _TICKETS[key] = t                              # re-inserted last = most recently used
+    if torch.cuda.is_current_stream_capturing() and not any(t is c for c in _CAPTURED_TICKETS):
+        _CAPTURED_TICKETS.append(t)                # a replay ticks this address long after the LRU dropped the entry
     return t
 
 

@@ -127,13 +127,14 @@ def _rollout_fwd(z, mu, controls, x0, xd0, R0, w0, pts, part_id, Iinv, consts, i
         d.math_mode = _lib.MF_MATH_EXACT
     B, T, N = d.B, d.T, d.N
     x0 = x0.to(dt).contiguous().clone()          # the kernel moves its z component onto the terrain: returned, not written in place
-    Np = _lib.lib().mf_rollout_force_stride(C.byref(d))
+    with torch.cuda.device(dev):      # (the policy queries read the CU count of the CURRENT device)
+        Np = _lib.lib().mf_rollout_force_stride(C.byref(d))
+        # the component-parallel kernels' per-step record for the backward (MfRolloutFwdBufs.rec), where the library keeps one
+        nrec = int(_lib.lib().mf_rollout_record_bytes(C.byref(d))) // 4 if (save_for_bwd and dt == torch.float32) else 0
     d.force_stride = Np
     new = lambda *tail: torch.empty(T, B, *tail, dtype=dt, device=dev)  # noqa: E731
     Xs, Xds, Rs, Om, Fs, Ff = new(3), new(3), new(3, 3), new(3), new(Np, 3), new(Np, 3)
     Xraw = new(3) if save_for_bwd else torch.empty(0, dtype=dt, device=dev)
-    # the component-parallel kernels' per-step record for the backward (MfRolloutFwdBufs.rec), where the library keeps one
-    nrec = int(_lib.lib().mf_rollout_record_bytes(C.byref(d))) // 4 if (save_for_bwd and dt == torch.float32) else 0
     rec = torch.empty(nrec, dtype=dt, device=dev)
     ts = _time_grid(consts, T, dt, dev)
     bufs = _lib.MfRolloutFwdBufs(z=_lib.ptr(zc), mu=_lib.ptr(muc), controls=_lib.ptr(cc), ts=_lib.ptr(ts), points=_lib.ptr(pc),

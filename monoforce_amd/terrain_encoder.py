@@ -11,7 +11,7 @@ backbones are the plain-torch restatements in `backbones.py` (MIOpen / rocBLAS).
 import torch
 from torch import nn
 
-from .backbones import EfficientNetB0, resnet18, fuse_batchnorm_counters
+from .backbones import EfficientNetB0, resnet18, fuse_batchnorm_counters, bump_batchnorm_counters
 from .lss_utils import gen_dx_bx
 from . import splat
 
@@ -57,6 +57,7 @@ class CamEncode(nn.Module):
     def get_eff_depth(self, x):
         """Walk the trunk keeping the last feature map of every resolution; fuse reductions 5 (1/32) and 4 (1/16)."""
         t = self.trunk
+        bump_batchnorm_counters(self)      # (every batch norm of this module runs once below)
         x = t._swish(t._bn0(t._conv_stem(x)))
         endpoints, prev = [], x
         n = len(t._blocks)
@@ -109,6 +110,7 @@ class BevEncode(nn.Module):
         return self.up1(self.layer3(self.layer2(x1)), x1)
 
     def forward(self, x, stage_k=None):
+        bump_batchnorm_counters(self)
         x = self.backbone(x)
         geom, diff = self.up_geom(x), self.up_diff(x)
         friction = self.up_friction(x)
@@ -136,7 +138,8 @@ class LiftSplatShoot(nn.Module):
         if build_backbones:
             self.camencode = CamEncode(self.D, self.camC)
             self.bevencode = BevEncode(inC=self.camC, outC=outC)
-            fuse_batchnorm_counters(self)   # one `num_batches_tracked` bump per training forward() instead of one per layer
+            # one `num_batches_tracked` bump per training forward of each backbone instead of one per batch-norm layer
+            fuse_batchnorm_counters(self, owners=[self.camencode, self.bevencode])
         self.use_quickcumsum = True      # accepted for compatibility; both reference paths compute the same sums
         self.fuse_lift = True            # lift (depth x context) inside the splat kernels; False: get_cam_feats + voxel_pooling
         self.fuse_geometry = True        # with fuse_lift: get_geometry inside the splat's key pass (no [B,N,D,fH,fW,3] tensor)

@@ -252,7 +252,13 @@ class EncoderTrainStep:
         spec = e['spec']
         if spec is None:
             return None
-        if torch.cuda.is_current_stream_capturing() or not self._same_tensor(e, gt_ts):
+        capturing = torch.cuda.is_current_stream_capturing()
+        if capturing or not self._same_tensor(e, gt_ts):
+            if not capturing and not structural and not bool((gt_ts == gt_ts[:1]).all()):
+                # a later batch of this shape whose rollouts carry DIFFERENT stamps (the reference's per-sample stamps,
+                # datasets/rough.py:261-296): the unfused loss, like the per-tensor check of round 3 -- not a NaN.  (One host round
+                # trip per new batch of a non-expanded stamp tensor; inside a capture the decision is frozen and the poison stands.)
+                return None
             spec.refresh_(gt_ts)
             e['src'] = [(gt_ts, gt_ts._version)]
         return spec
@@ -320,11 +326,18 @@ class EncoderTrainStep:
             except RuntimeError as e:
                 import warnings
                 warnings.warn(f'EncoderTrainStep: hipGraph capture failed ({str(e).splitlines()[0][:160]}); running launch by launch')
-                self.graph, self.buckets.defer = False, False
+                # (several ranks: the others may have captured and will call `buckets.exchange()` -- bucket-INDEX order -- between
+                #  their two replays; this rank keeps the deferred exchange too, so every rank issues the same collectives in the same
+                #  order.  The hook-launched exchange orders them by gradient readiness: mixed with the above it can pair different
+                #  buckets across ranks.  ADVICE r4.)
+                self.graph, self.buckets.defer = False, split
                 torch.cuda.synchronize(dev)
                 self._restore(snap)
                 return self._step_eager(batch)
-            cap = self._cap = dict(graph=g, apply=g2, batch=batch, out=out, split=split)
+            # (the captured launches read the device tables of the LossSpecs in use by address: pinned here, so that the eviction
+            #  in `_loss_spec` cannot free them under a live graph)
+            cap = self._cap = dict(graph=g, apply=g2, batch=batch, out=out, split=split,
+                                   pinned_specs=[e['spec'] for e in self._specs.values() if e['spec'] is not None])
         cap['graph'].replay()
         if cap['split']:
             self.buckets.exchange()

@@ -515,9 +515,59 @@ def gen_heightmap(out):
     out['points'] = pts
 
 
+# ----------------------------------------------------------------------------------------------------------
+# fixture 10: the reference's REAL tradr body (config/meshes/tradr.obj) through its own robot_geometry, and rollouts on it
+# ----------------------------------------------------------------------------------------------------------
+def _o3d_voxel_down_sample(vertices, voxel_size):
+    """Restatement of open3d==0.13.0 `PointCloud.voxel_down_sample` (third-party, absent here -> UNPINNED; SURVEY 8c iii):
+    voxel index floor((p - (min_bound - voxel_size / 2)) / voxel_size), one output point per occupied voxel = the mean of its
+    points.  open3d returns the voxels in hash-map order; here they come in lexicographic order of the index (a permutation of the
+    same set: the rollout sums over the points, the masks are per point)."""
+    v = np.asarray(vertices, np.float64)
+    origin = v.min(0) - 0.5 * voxel_size
+    key = np.floor((v - origin) / voxel_size).astype(np.int64)
+    _, inv = np.unique(key, axis=0, return_inverse=True)
+    inv = inv.reshape(-1)
+    cnt = np.bincount(inv).astype(np.float64)
+    return np.stack([np.bincount(inv, weights=v[:, k]) / cnt for k in range(3)], 1)
+
+
+def gen_tradr(out):
+    mesh = '/root/reference/monoforce/config/meshes/tradr.obj'
+    verts = np.asarray([[float(t) for t in l.split()[1:4]] for l in open(mesh) if l.startswith('v ')], np.float64)
+    keep = ref_cfg.get_points_from_robot_mesh
+    ref_cfg.get_points_from_robot_mesh = lambda robot, voxel_size=0.1, return_mesh=False: torch.as_tensor(
+        _o3d_voxel_down_sample(verts, voxel_size), dtype=torch.float32)
+    try:
+        pts, masks, size = ref_cfg.robot_geometry('tradr')      # the reference's own split rules (dphys_config.py:38-74)
+    finally:
+        ref_cfg.get_points_from_robot_mesh = keep
+    out['n_vertices'] = np.int64(len(verts))
+    out['points'] = npy(pts)
+    out['masks'] = np.stack([npy(m) for m in masks])
+    out['robot_size'] = np.array([float(size[0]), float(size[1])], np.float64)
+    print(f'tradr: {len(verts)} vertices -> {pts.shape[0]} points, masks {[int(m.sum()) for m in masks]}, size {out["robot_size"]}')
+    # rollouts of the real body through the reference (both integrators, float32 + float64, gradients): B = 2, T = 48, 64 x 64 map;
+    # the float32 force rows are not kept (size)
+    B, T, d_max, res = 2, 48, 3.2, 0.1
+    z = torch.stack([syn.bump_terrain(syn.bump_params(70 + b), d_max, res, torch.float64) * 0.5 for b in range(B)])
+    mu = torch.stack([syn.wave_friction(d_max, res, 0.5, 1.0, 1.3 + b, 2.1, torch.float64) for b in range(B)])
+    ctrl = syn.varying_controls(B, T, seed=11, dtype=torch.float64)
+    out['z'] = npy(z); out['mu'] = npy(mu); out['ctrl'] = npy(ctrl)
+    out['meta'] = np.array([d_max, res, T], np.float64)
+    pn, mn = npy(pts), [npy(m) for m in masks]
+    for dtype, tag in ((torch.float32, 'f32'), (torch.float64, 'f64')):
+        for integ in (0, 1):
+            r = run_ref(pn, mn, dtype, integ, z, ctrl, None, mu, res, d_max, grads=True, n_tracks_robot='tradr')
+            for k, v in r.items():
+                if not (tag == 'f32' and k in ('Fs', 'Ff')):
+                    out[f'{tag}/i{integ}/{k}'] = v
+            print(f'tradr {tag} integ={integ}: |Xs|max={np.abs(r["Xs"]).max():.3f} |g_z|max={np.abs(r["g_z"]).max():.3e}')
+
+
 def main():
     jobs = dict(interp=gen_interp, rollout_small=gen_small, step=gen_step, rollout_full=gen_full, lss=gen_lss,
-                physics_loss=gen_loss, rollout_joints=gen_joints, img_utils=gen_img_utils, heightmap=gen_heightmap)
+                physics_loss=gen_loss, rollout_joints=gen_joints, img_utils=gen_img_utils, heightmap=gen_heightmap, tradr_body=gen_tradr)
     only = sys.argv[1:]
     for name, fn in jobs.items():
         if only and name not in only:

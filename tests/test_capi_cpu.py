@@ -138,3 +138,30 @@ def test_forward_reports_where_it_stages_the_interleaved_maps(built_lib):
     assert stages(map_shared=0) == 0 and stages(math_mode=0) == 0 and stages(N=32, force_stride=32) == 0 and stages(has_joints=1) == 0
     assert stages(B=100000) == 0                    # beyond the component-parallel kernels' range
     assert built_lib.mf_rollout_fwd_stages_zmu(None) == 0
+
+
+def test_last_error_and_last_launch_are_thread_local(built_lib):
+    """VERDICT r4 / housekeeping: two host threads (two streams) each read the message of THEIR failed call; a thread that never
+    failed reads "".  mf_last_launch: "" for a thread that launched nothing."""
+    import threading
+    from monoforce_amd import _lib
+    seen = {}
+
+    def worker(name, n_tracks, barrier):
+        d = _lib.MfRolloutDesc(B=1 if n_tracks else 0, T=1, N=4, H=8, W=8, n_tracks=n_tracks or 2)
+        b = _lib.MfRolloutFwdBufs()
+        rc = built_lib.mf_rollout_fwd_f32(ctypes.byref(d), ctypes.byref(b), None)
+        barrier.wait()                      # both calls have failed before either thread reads its text
+        seen[name] = (rc, built_lib.mf_last_error().decode(), built_lib.mf_last_launch().decode())
+
+    bar = threading.Barrier(2)
+    ts = [threading.Thread(target=worker, args=('a', 3, bar)), threading.Thread(target=worker, args=('b', 0, bar))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert seen['a'][0] == 1 and 'n_tracks' in seen['a'][1] and 'positive' not in seen['a'][1]
+    assert seen['b'][0] == 1 and 'positive' in seen['b'][1] and 'n_tracks' not in seen['b'][1]
+    assert seen['a'][2] == '' and seen['b'][2] == ''
+    quiet = {}
+    t = threading.Thread(target=lambda: quiet.setdefault('e', built_lib.mf_last_error().decode()))
+    t.start(); t.join()
+    assert quiet['e'] == ''

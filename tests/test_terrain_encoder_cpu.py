@@ -167,3 +167,25 @@ def _counter_checks(m, x, cal):
     assert {int(v) for k, v in m.state_dict().items() if k.endswith('num_batches_tracked')} == {2}
     m.load_state_dict(m2.float().state_dict())
     assert int(m.camencode.trunk._bn0.num_batches_tracked) == 3
+
+
+def test_batchnorm_counters_follow_direct_submodule_calls_and_the_model_pickles(tmp_path):
+    """a training forward that calls the sub-modules directly (the fused lift, the reference's notebooks) advances the
+    counters of the batch norms that ran -- and only those; the counted batch norm is a class, so `torch.save(model)` works."""
+    from monoforce_amd.terrain_encoder import LiftSplatShoot
+    from monoforce_amd.backbones import BatchNorm2dCounted
+    m = LiftSplatShoot(LSS_SMALL['grid_conf'], LSS_SMALL['data_aug_conf']).train()
+    x = torch.randn(2, 3, 64, 96)
+    m.camencode.get_depth_and_context(x)
+    m.camencode(x)
+    cam = {int(v) for k, v in m.state_dict().items() if k.endswith('num_batches_tracked') and k.startswith('camencode')}
+    bev = {int(v) for k, v in m.state_dict().items() if k.endswith('num_batches_tracked') and k.startswith('bevencode')}
+    assert cam == {2} and bev == {0}
+    m.bevencode(torch.randn(1, m.camC, int(m.nx[0]), int(m.nx[1])))
+    assert {int(v) for k, v in m.state_dict().items() if k.endswith('num_batches_tracked') and k.startswith('bevencode')} == {1}
+    assert sum(isinstance(b, BatchNorm2dCounted) for b in m.modules()) > 60
+    path = tmp_path / 'model.pt'
+    torch.save(m, path)
+    m2 = torch.load(path, weights_only=False)
+    m2.train().camencode(x)
+    assert int(m2.camencode.trunk._bn0.num_batches_tracked) == 3 and int(m.camencode.trunk._bn0.num_batches_tracked) == 2

@@ -1,0 +1,89 @@
+"""The HIP rollout on the reference's REAL 175-point tradr body (config/meshes/tradr.obj through the reference's own
+`robot_geometry`; fixture tests/golden/tradr_body.npz, see gen_golden.py::gen_tradr) -- every other large-body test runs a synthetic
+box.  Outputs and gradients against the REFERENCE's own rollouts of that body (float64 at 1e-9 / 1e-7; float32 fast math at the
+north_star bar), for the general kernels, the recording forward + record-reading backward (the default route at this size) and the
+float64 validation build of the latter; and the bench's n175 launch shape (64 rollouts, shared map) against the float64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+from tests import helpers as hp
+from tests.test_rollout_gpu import make_dphysics
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+def _fixture(dt):
+    g = hp.load('tradr_body')
+    d_max, res, _ = (float(v) for v in g['meta'])
+    z, mu, ctrl = (torch.as_tensor(g[k]).to(dt) for k in ('z', 'mu', 'ctrl'))
+    return g, g['points'], list(g['masks']), z, mu, ctrl, d_max, res
+
+
+def _run(dp, z, mu, ctrl, dt):
+    zl, ml, cl = (t.clone().to(DEV).requires_grad_(True) for t in (z, mu, ctrl))
+    states, forces = dp(zl, cl, friction=ml)
+    outs = list(states) + list(forces)
+    hp.probe_loss(outs, dt).backward()
+    torch.cuda.synchronize()
+    return [o.detach().cpu() for o in outs], [t.grad.cpu() for t in (zl, ml, cl)]
+
+
+@pytest.mark.parametrize('integ', [0, 1])
+@pytest.mark.parametrize('ppl', [0, 4, 16])      # 0: the library's choice; 4: several points per lane; 16: MF_LANES_COMPONENT = the validation build
+def test_real_tradr_body_f64_vs_reference(integ, ppl):
+    g, pts, masks, z, mu, ctrl, d_max, res = _fixture(torch.float64)
+    dp = make_dphysics(pts, masks, integ, res, d_max, points_per_lane=ppl)
+    outs, grads = _run(dp, z, mu, ctrl, torch.float64)
+    for k, o in zip(hp.OUT_KEYS, outs):
+        assert hp.rel_err(o, g[f'f64/i{integ}/{k}']) <= 1e-9, (k, hp.rel_err(o, g[f'f64/i{integ}/{k}']))
+    for k, a in zip(('g_z', 'g_mu', 'g_ctrl'), grads):
+        assert hp.rel_err(a, g[f'f64/i{integ}/{k}']) <= 1e-7, (k, hp.rel_err(a, g[f'f64/i{integ}/{k}']))
+
+
+@pytest.mark.parametrize('integ', [0, 1])
+@pytest.mark.parametrize('ppl', [0, 4])
+def test_real_tradr_body_f32_vs_reference(integ, ppl):
+    """float32 fast math (ppl = 0: recording forward over 4 waves + record-reading backward): states within north_star's 1e-4 of the
+    reference's float64 rollout over these 48 steps, forces 2e-3 (|F| ~ 1e2..1e3 N impulses), gradients at the bar derived from the
+    reference alone: max(2e-3, 3 x the distance between ITS float32 and float64 gradients)."""
+    g, pts, masks, z, mu, ctrl, d_max, res = _fixture(torch.float32)
+    dp = make_dphysics(pts, masks, integ, res, d_max, points_per_lane=ppl)
+    outs, grads = _run(dp, z, mu, ctrl, torch.float32)
+    for k, o in zip(hp.OUT_KEYS, outs):
+        tol = 1e-4 if k in ('Xs', 'Rs') else (2e-3 if k in ('Fs', 'Ff') else 1e-3)
+        assert hp.rel_err(o, g[f'f64/i{integ}/{k}']) <= tol, (k, hp.rel_err(o, g[f'f64/i{integ}/{k}']))
+    for k, a in zip(('g_z', 'g_mu', 'g_ctrl'), grads):
+        ref64, ref32 = g[f'f64/i{integ}/{k}'], g[f'f32/i{integ}/{k}']
+        bar = max(2e-3, 3.0 * hp.rel_err(ref32, ref64))
+        assert torch.isfinite(a).all(), k
+        assert hp.rel_err(a, ref64) <= bar, (k, hp.rel_err(a, ref64), 'bar', bar)
+
+
+@pytest.mark.parametrize('integ', [1, 0])
+def test_n175_launch_shape_f64_build_vs_oracle(integ):
+    """The bench's n175 shape in small: 64 rollouts of the real body on ONE shared map pair (the launch shape that picks one rollout per
+    workgroup of four waves and the LDS gradient tile), 40 steps, float64 validation build against the float64 oracle."""
+    from monoforce_amd import synthetic as syn
+    from oracle import dphysics_oracle as orc      # checker only
+    g = hp.load('tradr_body')
+    pts, masks = g['points'], list(g['masks'])
+    B, T, d_max, res = 64, 40, 6.4, 0.1
+    z = (syn.bump_terrain(syn.bump_params(3), d_max, res, torch.float64) * 0.5).unsqueeze(0)
+    mu = syn.wave_friction(d_max, res, 0.5, 1.0, 1.1, 0.7, torch.float64).unsqueeze(0)
+    ctrl = syn.varying_controls(B, T, seed=5, dtype=torch.float64)
+    spec = hp.spec_from(pts, masks, integ, res, d_max)
+    zo, mo, co = (t.clone().requires_grad_(True) for t in (z, mu, ctrl))
+    so, fo = orc.rollout(spec, zo.expand(B, -1, -1), co, friction=mo.expand(B, -1, -1))
+    Xo = so[0]
+    w = syn.probe_weights(Xo[:, ::5].shape, phase=0.3, dtype=torch.float64)
+    (Xo[:, ::5] * w).sum().backward()
+    dp = make_dphysics(pts, masks, integ, res, d_max, points_per_lane=16)
+    zl, ml, cl = (t.clone().to(DEV).requires_grad_(True) for t in (z, mu, ctrl))
+    sh, fh = dp(zl, cl, friction=ml)
+    (sh[0][:, ::5] * w.to(DEV)).sum().backward()
+    for k, a, b in zip(hp.OUT_KEYS, list(sh) + list(fh), list(so) + list(fo)):
+        assert hp.rel_err(a.detach().cpu(), b.detach()) <= 1e-9, (k, hp.rel_err(a.detach().cpu(), b.detach()))
+    for k, a, b in (('z', zl.grad, zo.grad), ('mu', ml.grad, mo.grad), ('controls', cl.grad, co.grad)):
+        assert hp.rel_err(a.cpu(), b) <= 1e-7, (k, hp.rel_err(a.cpu(), b))
