@@ -147,9 +147,12 @@ def _time_cpu(fn, budget_s, max_runs=12):
     return float(np.median(kept)), len(kept)
 
 
-def cpu_baseline(N, integ, T, budget_s=12.0):
-    """Time the CPU oracle on bounded samples, host threads as torch sees them: the forward (no_grad) at B=256, the autograd
-    forward + backward of config 3 at B=32, and config 1 (one rollout, 200 steps, 128x128)."""
+def cpu_baseline(N, integ, T, budget_s=12.0, headline='c3'):
+    """Time the CPU oracle on bounded samples, host threads as torch sees them.  `value` is the leg that does the SAME work as the
+    GPU headline beside it: for c3 the autograd forward + backward of config 3 on a B = 32 sample of its 1024 rollouts
+    (rollout-steps/s of that sample; its cost per rollout GROWS with B -- every gather's autograd node materialises a [B,H,W]
+    gradient, as in the reference -- so the sample flatters the CPU); for a forward-only headline the no_grad forward at B = 256.
+    The other legs stay under `legs`: `c2_forward`, `c3_autograd`, `c1_forward` (config 1 at its own size)."""
     from oracle import dphysics_oracle as orc      # checker / baseline only -- never on the product path
     from monoforce_amd import synthetic as syn
     cores = torch.get_num_threads()
@@ -164,10 +167,9 @@ def cpu_baseline(N, integ, T, budget_s=12.0):
         with torch.no_grad():
             orc.rollout(spec, zb, ctrl, friction=mb)
     t, n = _time_cpu(fwd, budget_s)
-    head = dict(value=Bs * T / t, unit='rollout-steps/s', cores=cores, kind='port',
-                sample=f'oracle/dphysics_oracle.py (torch-CPU port), B={Bs} x T={T} x N={N}, 256x256 shared map, forward '
-                       f'no_grad, median of {n} runs; os.cpu_count()={os.cpu_count()}.  (legs: the autograd forward + backward of '
-                       f'config 3 is timed on a B=32 sample -- its cost grows with B^2 -- and config 1 at its own size)')
+    legs['c2_forward'] = dict(value=Bs * T / t, unit='rollout-steps/s', cores=cores, kind='port',
+                              sample=f'oracle/dphysics_oracle.py (torch-CPU port), B={Bs} x T={T} x N={N}, 256x256 shared map, forward '
+                                     f'no_grad, median of {n} runs')
     # forward + autograd backward to the terrain (C3), loss on every 10th pose like physics_loss
     Ba = 32       # every gather's autograd node materialises a [B,H,W] gradient (as in the reference): time grows with B^2
     ctrl_a = syn.const_controls(Ba, T, seed=0)
@@ -179,8 +181,9 @@ def cpu_baseline(N, integ, T, budget_s=12.0):
         (Xs[:, 9::10] ** 2).mean().backward()
     t, n = _time_cpu(fwd_bwd, 3.2 * budget_s, max_runs=5)       # (one run is ~7 s: a warm-up and >= 3 timed ones)
     legs['c3_autograd'] = dict(value=Ba * T / t, unit='rollout-steps/s', cores=cores, kind='port',
-                               sample=f'B={Ba} x T={T} x N={N}, 256x256 shared map, forward + torch autograd backward to '
-                                      f'terrain and friction, median of {n} runs')
+                               sample=f'oracle/dphysics_oracle.py (torch-CPU port), B={Ba} (a sample of config 3\'s 1024 rollouts: the autograd graph of one '
+                                      f'run holds a [B,H,W] gradient per gather, time per rollout grows with B) x T={T} x N={N}, 256x256 shared map, forward + torch '
+                                      f'autograd backward to terrain and friction, median of {n} runs')
     # config 1: ONE rollout, 200 steps, 128x128 map (the reference's own CPU-runnable case)
     cfg1, _, pts1, masks1, z1, mu1, ctrl1 = build_problem(1, 200, N, None, integ, seed=0, grid_res=0.1)
     spec1 = _oracle_spec(cfg1, pts1, masks1, integ, 0.1)
@@ -191,6 +194,10 @@ def cpu_baseline(N, integ, T, budget_s=12.0):
     t, n = _time_cpu(c1, 4.0, max_runs=8)
     legs['c1_forward'] = dict(value=200 / t, unit='rollout-steps/s', cores=cores, kind='port',
                               sample=f'B=1 x T=200 x N={N}, 128x128 map (res 0.1), forward no_grad, median of {n} runs')
+    same = 'c3_autograd' if WORKLOADS[headline]['backward'] else 'c2_forward'
+    head = dict(legs[same])
+    head['same_workload_as_headline'] = same
+    head['sample'] += f'; os.cpu_count()={os.cpu_count()}'
     head['legs'] = legs
     return head
 
@@ -384,6 +391,7 @@ class Runner:
             step()
         self.barrier()
         kern = {k: float(np.mean(v)) for k, v in _timing.stop().items()}       # average launch duration per kernel, ms
+        kernels_run = _timing.launches()      # which kernel template the library's dispatcher picked (mf_last_launch), per sampled launch
         elapsed_min, elapsed = self.max_over_ranks(elapsed, 'MIN'), self.max_over_ranks(elapsed)
         # the exchange step on its own (the backward's one collective), so that a scaling curve can be read
         comm_ms = None
@@ -443,7 +451,8 @@ class Runner:
             'config': {'workload': f'{name}: B={B}/GPU x T={T} x N={N} contact points, {H}x{H} grid (res {res} m), one shared '
                                    f'terrain+friction map (the same on every rank), integrator={integ}, {mode}; {wl["desc"]}',
                        'rollouts_per_gpu': B, 'rollouts_total': B_total, 'horizon': T, 'contact_points': N, 'grid': [H, H],
-                       'parallelism': f'rollout-sharded x{world}', **({'launch': launch} if launch else {})},
+                       'parallelism': f'rollout-sharded x{world}',
+                       'launch': {**(launch or {'mode': 'launch by launch'}), 'kernels': kernels_run}},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS,
                          'traffic': traffic,
                          # the PMC-measured HBM bytes per launch over the kernel's measured duration: what the memory system really sustained
@@ -464,13 +473,25 @@ class Runner:
         del dp
         return out, (N, T)
 
-    def batch_sweep(self, N, T, batches=(1024, 4096, 8192, 16384)):
-        """Forward and backward rollout kernels at a few batch sizes (kernel time from HIP events; not part of `value`)."""
+    def batch_sweep(self, N, T, batches=(256, 1024, 4096, 8192, 16384, 32768, 65536), private_batches=(256, 1024)):
+        """Forward and backward rollout kernels over the batch (256 ... 65 536 rollouts; kernel time from HIP events; not part
+        of `value`), one shared map pair; and the per-rollout-map variant (`per_rollout_maps`: one 256 x 256 height + friction pair PER
+        rollout -- 512 KiB each, so 1024 rollouts hold 512 MB of maps and as much again of map gradients; beyond that the variant is
+        memory for its own sake and is not swept)."""
         from monoforce_amd import _timing
         from monoforce_amd.train import TerrainFitProblem
         from monoforce_amd import synthetic as syn
         dev = self.dev
-        sweep = {}
+        sweep, private = {}, {}
+
+        def row(Bs, f_ms, b_ms, launches):
+            fg = fwd_bytes_per_rollout_step(N) * Bs * T / (f_ms * 1e-3) / 1e9
+            bg = bwd_bytes_per_rollout_step(N) * Bs * T / (b_ms * 1e-3) / 1e9
+            return {'fwd_ms': f_ms, 'fwd_frac': fg / HBM_PEAK_GBS, 'fwd_rollout_steps_per_s': Bs * T / (f_ms * 1e-3),
+                    'fwd_frac_hbm': fwd_hbm_bytes_per_rollout_step(N) * Bs * T / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    'bwd_ms': b_ms, 'bwd_frac': bg / HBM_PEAK_GBS, 'bwd_rollout_steps_per_s': Bs * T / (b_ms * 1e-3),
+                    'bwd_frac_hbm': bwd_hbm_bytes_per_rollout_step(N) * Bs * T / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'kernels': launches}
+
         for Bs in batches:
             _, dps, _, _, z, mu, cs = build_problem(Bs, T, N, dev, self.args.integrator, seed=0)
             cs = cs.to(dev)
@@ -482,24 +503,100 @@ class Runner:
             _timing.start()
             for _ in range(3):
                 prob.step(zl, ml)
+            launches = {'rollout_bwd_kernel': _timing.launches().get('rollout_bwd_kernel')}
             k = _timing.stop()
             with torch.no_grad():       # the plain forward (all six outputs, no saved rows for a backward)
                 dps(zd, cs, friction=md)
                 _timing.start()
                 for _ in range(3):
                     dps(zd, cs, friction=md)
+                launches['rollout_fwd_kernel'] = _timing.launches().get('rollout_fwd_kernel')
                 kf = _timing.stop()
-            f_ms, b_ms = float(np.mean(kf['rollout_fwd_kernel'])), float(np.mean(k['rollout_bwd_kernel']))
-            fg = fwd_bytes_per_rollout_step(N) * Bs * T / (f_ms * 1e-3) / 1e9
-            bg = bwd_bytes_per_rollout_step(N) * Bs * T / (b_ms * 1e-3) / 1e9
-            sweep[str(Bs)] = {'fwd_ms': f_ms, 'fwd_frac': fg / HBM_PEAK_GBS, 'fwd_rollout_steps_per_s': Bs * T / (f_ms * 1e-3),
-                              'fwd_frac_hbm': fwd_hbm_bytes_per_rollout_step(N) * Bs * T / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                              'bwd_ms': b_ms, 'bwd_frac': bg / HBM_PEAK_GBS,
-                              'bwd_frac_hbm': bwd_hbm_bytes_per_rollout_step(N) * Bs * T / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            sweep[str(Bs)] = row(Bs, float(np.mean(kf['rollout_fwd_kernel'])), float(np.mean(k['rollout_bwd_kernel'])), launches)
             del dps, prob, cs, zl, ml
             torch.cuda.empty_cache()      # return the sweep's multi-GB blocks now, not inside a later workload's timed region
+        for Bs in private_batches:      # one map pair PER ROLLOUT: [B,H,W] leaves, the loss on every 10th pose (the rows physics_loss stamps)
+            _, dps, _, _, z, mu, cs = build_problem(Bs, T, N, dev, self.args.integrator, seed=0)
+            cs = cs.to(dev)
+            zb = z.to(dev).unsqueeze(0).repeat(Bs, 1, 1).requires_grad_(True)
+            mb = mu.to(dev).unsqueeze(0).repeat(Bs, 1, 1).requires_grad_(True)
+
+            def fb():
+                zb.grad = mb.grad = None
+                (Xs, _, _, _), _ = dps(zb, cs, friction=mb)
+                (Xs[:, 9::10] ** 2).mean().backward()
+            for _ in range(2):
+                fb()
+            _timing.start()
+            for _ in range(3):
+                fb()
+            launches = _timing.launches()
+            k = _timing.stop()
+            private[str(Bs)] = row(Bs, float(np.mean(k['rollout_fwd_kernel'])), float(np.mean(k['rollout_bwd_kernel'])), launches)
+            private[str(Bs)]['note'] = ('forward = the autograd forward of this route (all six outputs + the rows kept for the backward); backward reads '
+                                        'dL/dXs rows and writes [B,H,W] gradients of both maps')
+            del dps, cs, zb, mb
+            torch.cuda.empty_cache()
         first = {leg: next((int(b) for b in sweep if sweep[b][leg + '_frac'] >= 0.4), None) for leg in ('fwd', 'bwd')}
-        return {'batches': sweep, 'first_B_at_40pct': first}
+        return {'batches': sweep, 'per_rollout_maps': private, 'first_B_at_40pct': first}
+
+
+def api_workload(r, T, N, integ, B=1024, iters=24):
+    """`c3_api`: the DROP-IN route a user of the unchanged scripts gets (scripts/fit_terrain.py:53-62,
+    scripts/train.py:399-406): `DPhysics.forward` -- six outputs, fresh tensors, launch by launch --, `monoforce.losses.physics_loss`
+    (plain torch ops on the returned states) and `loss.backward()` through autograd into the rollout's backward entry point (which
+    then READS upstream-gradient rows).  No fused loss, no hipGraph, no states-only forward: what the headline's `TerrainFitProblem`
+    route adds on top of the a1 API is exactly the difference between the two lines."""
+    from monoforce_amd import _timing
+    from monoforce.losses import physics_loss      # the reference's import path (the shim re-exports monoforce_amd.losses)
+    from monoforce_amd import synthetic as syn
+    dev = r.dev
+    cfg, dp, _, _, z, mu, ctrl = build_problem(B, T, N, dev, integ, seed=0)
+    cd = ctrl.to(dev)
+    with torch.no_grad():
+        (Xg, Xdg, Rg, Og), _ = dp(syn.bump_terrain(syn.bump_params(100), 6.4, 0.05).to(dev).unsqueeze(0), cd, friction=mu.to(dev).unsqueeze(0))
+    full_ts = torch.linspace(0, cfg.traj_sim_time, int(cfg.traj_sim_time / cfg.dt), device=dev)[:T]
+    sel = torch.arange(9, T, 10, device=dev)                      # 10 Hz ground-truth poses (datasets/rough.py:217,238)
+    pred_ts, gt_ts = full_ts.unsqueeze(0).expand(B, -1), full_ts[sel].unsqueeze(0).expand(B, -1).contiguous()
+    states_gt = [t[:, sel].contiguous() for t in (Xg, Xdg, Rg, Og)]
+    zl, ml = z.to(dev).clone().requires_grad_(True), mu.to(dev).clone().requires_grad_(True)
+    host = {'forward_call_us': [], 'loss_us': [], 'backward_call_us': []}
+
+    def step(record=False):
+        zl.grad = ml.grad = None
+        t0 = time.perf_counter()
+        states, forces = dp(z_grid=zl.unsqueeze(0), controls=cd, friction=ml.unsqueeze(0))
+        t1 = time.perf_counter()
+        loss = physics_loss(states_pred=states, states_gt=states_gt, pred_ts=pred_ts, gt_ts=gt_ts, gamma=0.9)
+        t2 = time.perf_counter()
+        loss.backward()
+        t3 = time.perf_counter()
+        if record:
+            host['forward_call_us'].append((t1 - t0) * 1e6); host['loss_us'].append((t2 - t1) * 1e6); host['backward_call_us'].append((t3 - t2) * 1e6)
+        return loss
+
+    for _ in range(4):
+        step()
+    r.barrier()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        step(record=True)
+    torch.cuda.synchronize(dev)
+    ms = (time.perf_counter() - t0) / iters * 1e3
+    _timing.start()
+    for _ in range(4):
+        _timing.next_step()
+        step()
+    launches = _timing.launches()
+    kern = {k: float(np.mean(v)) for k, v in _timing.stop().items()}
+    alg = {'rollout_fwd_kernel': fwd_bytes_per_rollout_step(N) * B * T, 'rollout_bwd_kernel': bwd_bytes_per_rollout_step(N) * B * T}
+    per_kernel = {k: {'ms': v, 'algorithmic_bytes': alg[k], 'frac': alg[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS} for k, v in kern.items() if k in alg}
+    return {'value': B * T / (ms * 1e-3), 'unit': 'rollout-steps/s', 'ms_per_step': ms,
+            'workload': f'c3_api: B={B} x T={T} x N={N}, one shared 256x256 map pair, DPhysics.forward (six outputs, fresh tensors, eager) + '
+                        f'monoforce.losses.physics_loss (torch ops, 50 stamps) + loss.backward(); launch by launch, no hipGraph',
+            'launch': {'mode': 'launch by launch', 'kernels': launches},
+            'host_us_per_call': {k: float(np.median(v)) for k, v in host.items()},
+            'kernel_ms_sum': float(sum(kern.get(k, 0.0) for k in alg)), 'per_kernel': per_kernel}
 
 
 def shoot_workload(r, T, N, integ, B=16384, iters=8):
@@ -603,6 +700,7 @@ def main():
             for name in ('c1', 'c2', 'ref_nb', 'n32', 'n175'):
                 others[name] = brief(r.run(name, short if name in ('c1', 'c2') else 6, 3, events_after=True)[0])
             others['shoot'] = shoot_workload(r, T, N, args.integrator)
+            others['c3_api'] = api_workload(r, T, N, args.integrator)
             if args.integrator == 1:      # the other integrator side by side -- dynamics() (use_odeint=False), same shapes
                 args.integrator = 0
                 try:
@@ -626,7 +724,7 @@ def main():
         if others:
             out['other_workloads'] = others
         if not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(N, args.integrator, T) if not r.dist_on else None      # timed at N=1 only
+            out['cpu_baseline'] = cpu_baseline(N, args.integrator, T, headline=args.workload) if not r.dist_on else None      # timed at N=1 only
         print(json.dumps(out))
     if r.dist_on:
         import torch.distributed as dist

@@ -346,6 +346,11 @@ int mf_physics_loss_fwd_f32(const MfLossDesc* desc, const float* Xs, const float
 int mf_physics_loss_fwd_f64(const MfLossDesc* desc, const double* Xs, const double* Xgt, const double* gt_ts, const int32_t* nearest, double* partial, void* hip_stream);
 int mf_physics_loss_bwd_f32(const MfLossDesc* desc, const float* Xs, const float* Xgt, const float* gt_ts, const int32_t* nearest, const float* gloss, float* gXs, void* hip_stream);
 int mf_physics_loss_bwd_f64(const MfLossDesc* desc, const double* Xs, const double* Xgt, const double* gt_ts, const int32_t* nearest, const double* gloss, double* gXs, void* hip_stream);
+/* nearest[b][j] = argmin_t |pred_ts[b][t] - gt_ts[b][j]|, the first minimum (losses.py:116 `torch.argmin(torch.abs(pred_ts.unsqueeze(1) -
+ * gt_ts.unsqueeze(2)), dim=2)`): the index table the entry points above take, without the two [B,T2,T1] temporaries of the reference's
+ * form.  pred_ts rows of T1, gt_ts rows of T2 stamps, row strides in elements (0 = one row shared by all rollouts); nearest int32[B][T2]. */
+int mf_nearest_steps_f32(int32_t B, int32_t T1, int32_t T2, const float* pred_ts, long long pred_stride_b, const float* gt_ts, long long gt_stride_b, int32_t* nearest, void* hip_stream);
+int mf_nearest_steps_f64(int32_t B, int32_t T1, int32_t T2, const double* pred_ts, long long pred_stride_b, const double* gt_ts, long long gt_stride_b, int32_t* nearest, void* hip_stream);
 /* The same loss, finished inside the launch: `loss[0]` receives the mean (what `partial.sum() / (3 B T2)` gives, summed in block
  * order).  `partial` holds ceil(B*T2/256) scalars of scratch; `ticket` is ONE zero-initialised uint32 the library resets itself --
  * reusable launch after launch by calls ordered on one stream (two streams need two tickets).  `zero_fill` (may be NULL): a buffer

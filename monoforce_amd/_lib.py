@@ -73,7 +73,7 @@ class MfHeightmapDesc(C.Structure):
 SYMBOLS = ['mf_rollout_force_stride', 'mf_rollout_fwd_f32', 'mf_rollout_fwd_f64', 'mf_rollout_default_state_f32', 'mf_rollout_default_state_f64', 'mf_rollout_bwd_f32', 'mf_rollout_bwd_f64', 'mf_rollout_bwd_wants_gcontrols', 'mf_rollout_record_bytes', 'mf_rollout_record_bytes_f64', 'mf_rollout_fwd_stages_zmu', 'mf_rollout_loss_fusable', 'mf_bev_splat_workspace_bytes', 'mf_bev_splat_prepare', 'mf_bev_splat_prepare_cameras',
            'mf_bev_splat_fwd_f32', 'mf_bev_splat_fwd_f64', 'mf_bev_splat_bwd_f32', 'mf_bev_splat_bwd_f64',
            'mf_bev_lift_splat_fwd_f32', 'mf_bev_lift_splat_fwd_f64', 'mf_bev_lift_splat_bwd_f32', 'mf_bev_lift_splat_bwd_f64',
-           'mf_physics_loss_fwd_f32', 'mf_physics_loss_fwd_f64', 'mf_physics_loss_bwd_f32', 'mf_physics_loss_bwd_f64', 'mf_physics_loss_value_f32', 'mf_physics_loss_value_f64', 'mf_reduce_grad_copies_f32', 'mf_reduce_grad_copies_f64', 'mf_estimate_heightmap_f32', 'mf_interpolate_grid_f32', 'mf_interpolate_grid_f64', 'mf_terrain_stage_fwd_f32', 'mf_terrain_stage_bwd_f32', 'mf_last_error', 'mf_last_launch', 'mf_version', 'mf_sizeof']
+           'mf_physics_loss_fwd_f32', 'mf_physics_loss_fwd_f64', 'mf_physics_loss_bwd_f32', 'mf_physics_loss_bwd_f64', 'mf_physics_loss_value_f32', 'mf_physics_loss_value_f64', 'mf_nearest_steps_f32', 'mf_nearest_steps_f64', 'mf_reduce_grad_copies_f32', 'mf_reduce_grad_copies_f64', 'mf_estimate_heightmap_f32', 'mf_interpolate_grid_f32', 'mf_interpolate_grid_f64', 'mf_terrain_stage_fwd_f32', 'mf_terrain_stage_bwd_f32', 'mf_last_error', 'mf_last_launch', 'mf_version', 'mf_sizeof']
 
 _lib = None
 _lock = threading.Lock()
@@ -98,7 +98,7 @@ def lib():
                 L.mf_last_launch.restype = C.c_char_p
                 for name in SYMBOLS:
                     fn = getattr(L, name)   # AttributeError if the build is stale
-                    if name.startswith(('mf_rollout', 'mf_bev', 'mf_physics', 'mf_estimate', 'mf_terrain', 'mf_reduce', 'mf_interpolate')):
+                    if name.startswith(('mf_rollout', 'mf_bev', 'mf_physics', 'mf_estimate', 'mf_terrain', 'mf_reduce', 'mf_interpolate', 'mf_nearest')):
                         fn.restype = C.c_int
                 L.mf_bev_splat_workspace_bytes.restype = C.c_size_t
                 L.mf_rollout_record_bytes.restype = C.c_longlong

@@ -6,6 +6,7 @@ import torch
 _records = None     # None = off; else list of (name, start_event, end_event)
 _pool = []          # pre-created events (creating them inside a timed region costs host time)
 _every, _step = 1, 0
+_launches = {}      # name -> text of mf_last_launch() for the sampled launches since the last start()
 
 
 def start(capacity=4096, every=1):
@@ -17,6 +18,7 @@ def start(capacity=4096, every=1):
         _pool.append(torch.cuda.Event(enable_timing=True))
     _records = []
     _every, _step = max(int(every), 1), -1
+    _launches.clear()
 
 
 def set_every(every):
@@ -61,3 +63,17 @@ def timed(name, device):
     yield
     b.record(torch.cuda.current_stream(device))
     _records.append((name, a, b))
+
+
+def note_launch(name):
+    """Called right after a sampled C-ABI rollout launch, on the launching thread (mf_last_launch is thread-local and the backward
+    runs on autograd's thread): remember which kernel template the library's dispatcher picked."""
+    if _records is None or (_every > 1 and _step % _every != 0):
+        return
+    from . import _lib
+    _launches[name] = _lib.lib().mf_last_launch().decode()
+
+
+def launches():
+    """{name: 'kernel<template parameters> grid=.. block=.. launches=..'} of the sampled launches since the last start()."""
+    return dict(_launches)

@@ -162,6 +162,43 @@ static int loss_bwd(const MfLossDesc* d, const S* Xs, const S* Xgt, const S* gt_
 
 }  // namespace mf
 
+namespace mf {
+// nearest[b][j] = argmin_t |pred_ts[b][t] - gt_ts[b][j]| (losses.py:116: `torch.argmin(torch.abs(pred_ts.unsqueeze(1) - gt_ts.unsqueeze(2)), dim=2)`),
+// the FIRST minimum like torch.argmin; NaN differences are skipped unless every one is NaN (then 0).  One thread per (rollout, stamp)
+// scanning its rollout's T1 predicted stamps (a 2 KB row the 50 threads of a rollout share in L1): the reference's form materialises
+// two [B,T2,T1] tensors -- 25.6 M elements at the BASELINE shape, 76 us of three ATen launches -- for 51 200 indices.
+template <typename S>
+__global__ void __launch_bounds__(256) nearest_steps_kernel(const S* __restrict__ pred_ts, long long pred_sb, const S* __restrict__ gt_ts, long long gt_sb,
+                                                           int B, int T1, int T2, int* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;        // = b * T2 + j
+  if (i >= B * T2) return;
+  const int b = i / T2, j = i - b * T2;
+  const S g = gt_ts[b * gt_sb + j];
+  const S* p = pred_ts + b * pred_sb;
+  S best = (S)INFINITY;
+  int arg = 0;
+  bool any = false;
+  for (int t = 0; t < T1; ++t) {
+    const S d = fabs(p[t] - g);
+    if (d < best || (!any && d == d)) { best = d; arg = t; any = true; }      // strict <: the first minimum
+  }
+  out[i] = arg;
+}
+template <typename S>
+static int nearest_steps(int B, int T1, int T2, const S* pred_ts, long long pred_sb, const S* gt_ts, long long gt_sb, int32_t* out, hipStream_t st) {
+  MF_REQUIRE(B > 0 && T1 > 0 && T2 > 0 && pred_ts && gt_ts && out && pred_sb >= 0 && gt_sb >= 0, MF_ERR_INVALID, "nearest_steps: bad argument");
+  const long long n = (long long)B * T2;
+  MF_REQUIRE(n < (1ll << 31), MF_ERR_UNSUPPORTED, "nearest_steps: B * T2 must be below 2^31");
+  hipLaunchKernelGGL((nearest_steps_kernel<S>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, pred_ts, pred_sb, gt_ts, gt_sb, B, T1, T2, out);
+  hipError_t e = hipGetLastError();
+  MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("nearest_steps launch: ") + hipGetErrorString(e));
+  return MF_OK;
+}
+}  // namespace mf
+extern "C" int mf_nearest_steps_f32(int32_t B, int32_t T1, int32_t T2, const float* pred_ts, long long pred_stride_b, const float* gt_ts, long long gt_stride_b,
+                                    int32_t* nearest, void* s) { return mf::nearest_steps<float>(B, T1, T2, pred_ts, pred_stride_b, gt_ts, gt_stride_b, nearest, (hipStream_t)s); }
+extern "C" int mf_nearest_steps_f64(int32_t B, int32_t T1, int32_t T2, const double* pred_ts, long long pred_stride_b, const double* gt_ts, long long gt_stride_b,
+                                    int32_t* nearest, void* s) { return mf::nearest_steps<double>(B, T1, T2, pred_ts, pred_stride_b, gt_ts, gt_stride_b, nearest, (hipStream_t)s); }
 extern "C" int mf_physics_loss_fwd_f32(const MfLossDesc* d, const float* Xs, const float* Xgt, const float* gt_ts, const int32_t* nearest,
                                        float* partial, void* s) { return mf::loss_fwd<float>(d, Xs, Xgt, gt_ts, nearest, partial, (hipStream_t)s); }
 extern "C" int mf_physics_loss_fwd_f64(const MfLossDesc* d, const double* Xs, const double* Xgt, const double* gt_ts, const int32_t* nearest,

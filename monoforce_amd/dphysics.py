@@ -277,6 +277,7 @@ def _rollout_forward_on_device(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts
     fn = getattr(_lib.lib(), 'mf_rollout_fwd_' + _scalar_suffix(dt))
     with torch.cuda.device(dev), _timing.timed('rollout_fwd_kernel', dev):
         _lib.check(fn(C.byref(desc), C.byref(bufs), _stream_ptr(dev)), 'mf_rollout_fwd')
+    _timing.note_launch('rollout_fwd_kernel')
     outs = (Xs, Xds, Rs, Om) + ((Fs[..., :N, :], Ff[..., :N, :]) if want_forces else ())
     if tm:
         outs = tuple(o.transpose(0, 1) for o in outs)

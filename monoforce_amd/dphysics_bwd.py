@@ -163,6 +163,7 @@ def _rollout_backward_on_device(ctx, gXs, gXds, gRs, gOm, gFs, gFf, gloss):
     fn = getattr(_lib.lib(), 'mf_rollout_bwd_' + _scalar_suffix(dt))
     with torch.cuda.device(dev), _timing.timed('rollout_bwd_kernel', dev):
         _lib.check(fn(C.byref(desc), C.byref(bufs), _stream_ptr(dev)), 'mf_rollout_bwd')
+    _timing.note_launch('rollout_bwd_kernel')
 
     if desc.map_shared:
         summed = pool.reduce(z.shape)          # one launch: both maps summed over their copies, the pool left zeroed

@@ -4,7 +4,9 @@ tensors are on).  Semantics of `/root/reference/monoforce/src/monoforce/losses.p
 """
 import torch
 
-__all__ = ['nearest_steps', 'physics_loss', 'physics_loss_fused', 'hm_loss', 'total_variation', 'rotation_difference']
+_HIP_LOSS = True      # physics_loss on GPU tensors runs on the mf_physics_loss_* kernels (False: the reference's ATen form)
+
+__all__ = ['nearest_steps', 'nearest_steps_hip', 'physics_loss', 'physics_loss_aten', 'physics_loss_fused', 'hm_loss', 'total_variation', 'rotation_difference']
 
 
 def total_variation(heightmap):
@@ -35,11 +37,53 @@ def nearest_steps(pred_ts, gt_ts):
     return (pred_ts.unsqueeze(1) - gt_ts.unsqueeze(2)).abs().argmin(dim=2)
 
 
+def nearest_steps_hip(pred_ts, gt_ts):
+    """`nearest_steps` as ONE launch (`mf_nearest_steps_*`: a thread per (rollout, stamp) scans its rollout's predicted stamps) instead
+    of sub / abs / argmin over two [N,T2,T1] temporaries -- 25.6 M elements and 76 us of GPU time at the BASELINE shape for 51 200
+    indices.  Same indices (the first minimum, like torch.argmin); int32 [N,T2].  Expanded (stride-0) stamp rows are read as they are."""
+    import ctypes as C
+    from . import _lib
+    _lib.require_hip_tensor(pred_ts, 'pred_ts')
+    dt = torch.promote_types(pred_ts.dtype, gt_ts.dtype)
+    if dt not in (torch.float32, torch.float64):
+        dt = torch.float32
+    N, T2 = gt_ts.shape
+    T1 = pred_ts.shape[1]
+    assert pred_ts.shape[0] == N and pred_ts.dim() == 2, f'pred_ts {tuple(pred_ts.shape)} and gt_ts {tuple(gt_ts.shape)} disagree'
+
+    def rows(t):      # dtype, unit stride inside a row; the row stride may be 0 (one row expanded over the rollouts)
+        t = t.detach().to(dt)
+        return t if t.stride(1) == 1 or t.shape[1] == 1 else t.contiguous()
+    p, g = rows(pred_ts), rows(gt_ts)
+    out = torch.empty(N, T2, dtype=torch.int32, device=pred_ts.device)
+    fn = getattr(_lib.lib(), 'mf_nearest_steps_' + ('f32' if dt == torch.float32 else 'f64'))
+    with torch.cuda.device(pred_ts.device):
+        _lib.check(fn(C.c_int32(N), C.c_int32(T1), C.c_int32(T2), _lib.ptr(p), C.c_longlong(p.stride(0)), _lib.ptr(g), C.c_longlong(g.stride(0)),
+                      _lib.ptr(out), C.c_void_p(torch.cuda.current_stream(pred_ts.device).cuda_stream)), 'mf_nearest_steps')
+    return out
+
+
 def physics_loss(states_pred, states_gt, pred_ts, gt_ts, gamma=0.9, rotation_loss=False, nearest=None):
     """Time-discounted position MSE at the predicted steps closest to the ground-truth stamps (losses.py:102-138).
 
     states_*[0]: positions [N,T1,3] / [N,T2,3]; pred_ts [N,T1]; gt_ts [N,T2]; weight 1 / (1 + gamma t).
-    """
+    Tensors on the MI355X: the same value and gradient from the hand-written kernels (`physics_loss_fused`: one gather-reduce launch
+    forward, one scatter launch backward, the index table from `mf_nearest_steps_*`) instead of ~25 ATen launches -- the reference's
+    own form (`physics_loss_aten`) costs 0.29 ms of GPU time per call at the BASELINE shape, as much as the rollout's forward and
+    half its backward (a sort inside `index_put_`'s backward, two 25.6 M-element temporaries for the argmin).
+    `monoforce_amd.losses._HIP_LOSS = False` keeps the ATen form everywhere."""
+    X_gt, X_pred = states_gt[0], states_pred[0]
+    if (_HIP_LOSS and not rotation_loss and X_pred.is_cuda and X_pred.dtype in (torch.float32, torch.float64) and X_pred.dim() == 3
+            and X_pred.stride(2) == 1 and X_gt.is_cuda and gt_ts.is_cuda and (nearest is not None or pred_ts.is_cuda)):
+        if nearest is None:
+            nearest = nearest_steps_hip(pred_ts, gt_ts)
+        return _FusedPhysicsLoss.apply(X_pred, X_gt, gt_ts, nearest, gamma)
+    return physics_loss_aten(states_pred, states_gt, pred_ts, gt_ts, gamma=gamma, rotation_loss=rotation_loss, nearest=nearest)
+
+
+def physics_loss_aten(states_pred, states_gt, pred_ts, gt_ts, gamma=0.9, rotation_loss=False, nearest=None):
+    """The reference's formulation (losses.py:102-138) in plain torch ops, on whatever device the tensors are on -- what `physics_loss`
+    runs on CPU tensors and for the rotation term, and what the tests hold the HIP loss kernels to."""
     X_gt, X_pred = states_gt[0], states_pred[0]
     if nearest is None:     # callers with fixed time stamps may pass the cached result of nearest_steps()
         nearest = nearest_steps(pred_ts, gt_ts)

@@ -153,7 +153,7 @@ def _stamp_rig(graph=False, n_rollouts=32):
 
 def _plain_physics_loss(dp, enc, b16):
     """The physics term through the module's plain entry points: `DPhysics.forward` + the torch `physics_loss` -- no fused tables."""
-    from monoforce_amd.losses import physics_loss
+    from monoforce_amd.losses import physics_loss_aten as physics_loss      # (the reference formulation in ATen ops: the referee)
     (imgs, rots, trans, intrins, post_rots, post_trans, hm_geom, hm_terrain, control_ts, controls, pose0, traj_ts, Xs, Xds, Rs, Om) = b16
     with torch.no_grad():
         out = enc(imgs, rots, trans, intrins, post_rots, post_trans)

@@ -23,7 +23,7 @@ def test_fused_loss_matches_reference_golden():
 @pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
 def test_fused_loss_on_time_major_views_with_duplicate_stamps(dtype):
     """The rollout's outputs are [B,T,3] views of time-major buffers; several ground-truth stamps may share the nearest step."""
-    from monoforce_amd.losses import physics_loss, physics_loss_fused
+    from monoforce_amd.losses import physics_loss_aten as physics_loss, physics_loss_fused
     B, T1, T2 = 37, 120, 11
     gen = torch.Generator().manual_seed(0)
     base = torch.randn(T1, B, 3, generator=gen, dtype=dtype).to(DEV)
@@ -65,7 +65,7 @@ def test_terrain_fit_step_same_gradients_with_fused_loss():
 def test_loss_value_is_finished_inside_the_launch_and_reusable(B, T2):
     """`mf_physics_loss_value_*`: the block taking the last ticket turns the per-block partial sums into the mean and resets the
     ticket -- the same value launch after launch (1 .. 587 blocks), equal to the plain-torch restatement of losses.py:102-127."""
-    from monoforce_amd.losses import physics_loss, physics_loss_fused
+    from monoforce_amd.losses import physics_loss_aten as physics_loss, physics_loss_fused
     T1 = 10 * T2
     gen = torch.Generator().manual_seed(B)
     X = torch.randn(B, T1, 3, generator=gen).to(DEV)
@@ -134,7 +134,7 @@ def test_loss_inside_the_rollout_kernels_equals_the_two_kernel_route(B, T, gt_ev
     the rollout kernel accumulating the loss itself (`loss_in_forward`, the LOSS kernels) and one small launch on the rows it wrote; the
     backward half is the same -- and, third form (the fit step's default), the backward launch forming the VALUE as well
     (MF_LOSS_VALUE_IN_BACKWARD)."""
-    from monoforce_amd.losses import physics_loss
+    from monoforce_amd.losses import physics_loss_aten as physics_loss      # (the reference formulation in ATen ops: the referee)
     out = []
     for in_kernel in (False, True):
         prob, z, m = _fit_problem(B, T, in_kernel, gt_every=gt_every, in_forward=in_forward, value=value, integ=integ)
@@ -206,7 +206,7 @@ def test_loss_rollout_falls_back_where_the_library_cannot_fuse():
     value and gradient through the unfused route (`mf_rollout_loss_fusable` / LossSpec.fusable say no); dynamics() (first case) fuses
     its backward half since round 4 and must agree all the same."""
     from monoforce_amd import synthetic as syn
-    from monoforce_amd.losses import physics_loss
+    from monoforce_amd.losses import physics_loss_aten as physics_loss      # (the reference formulation in ATen ops: the referee)
     from tests.test_rollout_gpu import make_dphysics
     pts, masks = syn.robot_points_4()
     B, T = 16, 60
@@ -266,3 +266,39 @@ def test_non_finite_rows_behind_the_last_stamp_do_not_poison_the_fused_loss(in_f
     assert np.isfinite(res_[True][0]) and abs(res_[True][0] - res_[False][0]) <= 1e-6 * abs(res_[False][0]), (res_[True][0], res_[False][0])
     assert torch.isfinite(res_[True][1]).all()
     assert hp.rel_err(res_[True][1].cpu(), res_[False][1].cpu()) <= 1e-5
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.float64])
+@pytest.mark.parametrize('expanded', [True, False])
+def test_public_physics_loss_on_gpu_tensors_is_the_hip_loss_and_equals_the_aten_form(dtype, expanded):
+    """`monoforce.losses.physics_loss` (the reference's import path) on GPU tensors: value and gradient of the reference formulation
+    (`physics_loss_aten`, losses.py:102-127), through `mf_nearest_steps_*` + `mf_physics_loss_*` -- including irregular stamps, ties
+    between two predicted steps (the first minimum wins, like torch.argmin) and stamps outside the predicted range."""
+    from monoforce.losses import physics_loss
+    from monoforce_amd import losses as L
+    B, T1, T2 = 37, 120, 23
+    g = torch.Generator().manual_seed(5)
+    pred_row = torch.cumsum(torch.rand(T1, generator=g, dtype=torch.float64) * 0.02 + 0.001, 0)
+    pred = (pred_row.unsqueeze(0).expand(B, -1) if expanded else pred_row.unsqueeze(0) + torch.rand(B, 1, generator=g, dtype=torch.float64) * 0.01)
+    gt = torch.sort(torch.rand(B, T2, generator=g, dtype=torch.float64) * float(pred_row[-1]) * 1.1 - 0.05, dim=1).values
+    gt[:, 3] = (pred[:, 10] + pred[:, 11]) / 2                      # a tie (exact in float64; float32 rounds it to one side or the other)
+    gt[:, 4] = pred[:, 40]                                          # exactly on a step
+    pred, gt = pred.to(DEV, dtype), gt.to(DEV, dtype)
+    X = torch.randn(B, T1, 3, generator=g, dtype=torch.float64).to(DEV, dtype)
+    Xgt = torch.randn(B, T2, 3, generator=g, dtype=torch.float64).to(DEV, dtype)
+    assert torch.equal(L.nearest_steps_hip(pred, gt).long(), L.nearest_steps(pred, gt))
+    out = []
+    for fn in (physics_loss, L.physics_loss_aten):
+        Xl = X.clone().transpose(0, 1).contiguous().transpose(0, 1).requires_grad_(True)      # the rollout's time-major layout as a [B,T,3] view
+        loss = fn([Xl], [Xgt], pred, gt, gamma=0.9)
+        loss.backward()
+        out.append((float(loss), Xl.grad.clone()))
+    tol = 1e-5 if dtype == torch.float32 else 1e-12
+    assert abs(out[0][0] - out[1][0]) <= tol * abs(out[1][0])
+    assert hp.rel_err(out[0][1].cpu(), out[1][1].cpu()) <= tol
+    assert type(physics_loss([X.requires_grad_(True)], [Xgt], pred, gt).grad_fn).__name__.startswith('_FusedPhysicsLoss')
+    keep, L._HIP_LOSS = L._HIP_LOSS, False
+    try:
+        assert not type(physics_loss([X], [Xgt], pred, gt).grad_fn).__name__.startswith('_FusedPhysicsLoss')
+    finally:
+        L._HIP_LOSS = keep

@@ -45,20 +45,36 @@ def test_real_tradr_body_f64_vs_reference(integ, ppl):
 @pytest.mark.parametrize('integ', [0, 1])
 @pytest.mark.parametrize('ppl', [0, 4])
 def test_real_tradr_body_f32_vs_reference(integ, ppl):
-    """float32 fast math (ppl = 0: recording forward over 4 waves + record-reading backward): states within north_star's 1e-4 of the
-    reference's float64 rollout over these 48 steps, forces 2e-3 (|F| ~ 1e2..1e3 N impulses), gradients at the bar derived from the
-    reference alone: max(2e-3, 3 x the distance between ITS float32 and float64 gradients)."""
+    """float32 fast math (ppl = 0: recording forward over 4 waves + record-reading backward) against the reference's own FLOAT32
+    rollout of the same float32 inputs: poses within north_star's 1e-4 over these 48 steps, velocities 1e-3.  (The fixture's float64
+    rollout started from the float64 inputs: its distance to ANY float32 run is the input rounding, 1.0e-3 on Xs -- not a kernel
+    property.)  Gradients against the float64 oracle on the float32-valued inputs, at the bar derived from the oracle alone:
+    max(2e-3, 3 x the distance between ITS float32 and float64 gradients)."""
+    from oracle import dphysics_oracle as orc      # checker only
     g, pts, masks, z, mu, ctrl, d_max, res = _fixture(torch.float32)
     dp = make_dphysics(pts, masks, integ, res, d_max, points_per_lane=ppl)
     outs, grads = _run(dp, z, mu, ctrl, torch.float32)
     for k, o in zip(hp.OUT_KEYS, outs):
-        tol = 1e-4 if k in ('Xs', 'Rs') else (2e-3 if k in ('Fs', 'Ff') else 1e-3)
-        assert hp.rel_err(o, g[f'f64/i{integ}/{k}']) <= tol, (k, hp.rel_err(o, g[f'f64/i{integ}/{k}']))
-    for k, a in zip(('g_z', 'g_mu', 'g_ctrl'), grads):
-        ref64, ref32 = g[f'f64/i{integ}/{k}'], g[f'f32/i{integ}/{k}']
-        bar = max(2e-3, 3.0 * hp.rel_err(ref32, ref64))
+        key = f'f32/i{integ}/{k}'
+        if key in g.files:
+            tol = 1e-4 if k in ('Xs', 'Rs') else 1e-3
+            assert hp.rel_err(o, g[key]) <= tol, (k, hp.rel_err(o, g[key]))
+    spec = hp.spec_from(pts, masks, integ, res, d_max)
+
+    def oracle_grads(dt):
+        zo, mo, co = (t.clone().to(dt).requires_grad_(True) for t in (z, mu, ctrl))
+        so, fo = orc.rollout(spec, zo, co, friction=mo)
+        hp.probe_loss(list(so) + list(fo), dt).backward()
+        return [zo.grad, mo.grad, co.grad], list(so) + list(fo)
+    g64, o64 = oracle_grads(torch.float64)
+    g32, _ = oracle_grads(torch.float32)
+    for k, o, b in zip(hp.OUT_KEYS, outs, o64):      # forces: vs the float64 oracle on the same float32-valued inputs
+        if k in ('Fs', 'Ff'):
+            assert hp.rel_err(o, b.detach()) <= 2e-3, (k, hp.rel_err(o, b.detach()))
+    for k, a, b64, b32 in zip(('g_z', 'g_mu', 'g_ctrl'), grads, g64, g32):
+        bar = max(2e-3, 3.0 * hp.rel_err(b32, b64))
         assert torch.isfinite(a).all(), k
-        assert hp.rel_err(a, ref64) <= bar, (k, hp.rel_err(a, ref64), 'bar', bar)
+        assert hp.rel_err(a, b64) <= bar, (k, hp.rel_err(a, b64), 'bar', bar)
 
 
 @pytest.mark.parametrize('integ', [1, 0])
