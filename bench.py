@@ -66,6 +66,10 @@ WORKLOADS = {
     'c3': dict(B=1024, T=500, N=4, backward=True, desc='BASELINE configs[2]: 1024 rollouts x 500 steps, forward + physics loss + backward to terrain'),
     'c4': dict(B=1024, T=500, N=4, backward=True, encoder=True,
                desc='BASELINE configs[3]: TerrainEncoder (4 cams 3x256x512 -> 256x256 BEV) + 1024 rollouts per GPU, end-to-end train step'),
+    # the same step as a real train.py loop sees it: a NEW image augmentation every step (terrain_encoder/utils.py:110-133 samples
+    # resize / crop per sample), so the voxel plan of the splat is rebuilt in every forward instead of being served from the rig cache
+    'c4_aug': dict(B=1024, T=500, N=4, backward=True, encoder=True, augment=True,
+                   desc='BASELINE configs[3] with a fresh image augmentation (post_rots, post_trans) every step: the splat plan is rebuilt per forward'),
     # the reference's own operating point (examples/diff_physics.ipynb:199-226: 64 rollouts x 600 steps of the 223-point `marv` body on a
     # 128 x 128 grid -- the only timing the reference records) and two more body sizes of its robots
     'ref_nb': dict(B=64, T=600, N=223, backward=True, grid_res=0.1,
@@ -306,6 +310,20 @@ class Runner:
                         m_.weight.data = m_.weight.data.contiguous(memory_format=torch.channels_last)
             ebatch = synthetic_encoder_batch(enc, dp, n_rollouts=B, device=dev, seed=rank)    # the encoder batch is sharded too
             estep = EncoderTrainStep(enc, dp, lr=1e-4, graph=not os.environ.get('MF_BENCH_NO_GRAPH'))
+            aug_pool = None
+            if wl.get('augment'):      # eight pre-sampled resize + crop augmentations, copied into the batch's tensors before every step
+                enc.cache_plan = False
+                ga = torch.Generator().manual_seed(1234)
+                post_rots, post_trans = ebatch[0][4], ebatch[0][5]
+                aug_pool = []
+                for _ in range(8):
+                    sc = 0.9 + 0.2 * torch.rand(post_rots.shape[:2], generator=ga)
+                    pr = torch.eye(3).repeat(*post_rots.shape[:2], 1, 1)
+                    pr[..., 0, 0] = sc; pr[..., 1, 1] = sc
+                    pt = torch.zeros(post_trans.shape)
+                    pt[..., :2] = (torch.rand(*post_trans.shape[:2], 2, generator=ga) - 0.5) * 30.0
+                    aug_pool.append((pr.to(dev), pt.to(dev)))
+                aug_i = [0]
         elif wl['backward']:
             from monoforce_amd.train import TerrainFitProblem
             from monoforce_amd import synthetic as syn
@@ -326,6 +344,10 @@ class Runner:
         def step():
             eager = _timing.sampled() or not mode['graph']       # steps bracketed with HIP events run launch by launch
             if wl.get('encoder'):
+                if aug_pool is not None:      # the data loader's part: this step's augmentation, in place (two small copies)
+                    pr, pt = aug_pool[aug_i[0] % len(aug_pool)]
+                    aug_i[0] += 1
+                    ebatch[0][4].copy_(pr); ebatch[0][5].copy_(pt)
                 return estep.step(ebatch, eager=eager)
             if wl['backward']:
                 return prob.step(zleaf, mleaf, eager=eager)
@@ -709,6 +731,7 @@ def main():
                 finally:
                     args.integrator = 1
             others['c4'] = brief(r.run('c4', 5, 4, events_after=True)[0])
+            others['c4_aug'] = brief(r.run('c4_aug', 5, 4, events_after=True)[0])
         else:
             others['strong_c3'] = brief(r.run('c3', short, 3, batch=max(8192 // r.world, 1), events_after=True)[0])
             others['strong_c3']['scaling'] = 'strong (8192 rollouts in total)'

@@ -311,6 +311,16 @@ int mf_bev_splat_prepare(const MfSplatDesc* desc, const float* geom /* [B*n_per_
  * cams[B*cameras][24] = post_trans[3], inverse(post_rots)[9], (rots x inverse(intrins))[9], trans[3], matrices row-major. */
 int mf_bev_splat_prepare_cameras(const MfSplatDesc* desc, const float* frustum, int32_t pts_per_cam, const float* cams,
                                  void* workspace, void* hip_stream);
+/* The same plan straight from the calibration tensors LiftSplatShoot.forward receives (lss.py:282-296): rots, intrins, post_rots
+ * [B*cameras][3][3] and trans, post_trans [B*cameras][3], float32 row-major -- BOTH 3 x 3 inversions of get_geometry (lss.py:212, 218:
+ * torch.inverse(post_rots), torch.inverse(intrins)) and the product rots x inverse(intrins) are formed inside the key kernel (float64
+ * adjugate rounded once to float32), so a data loader with per-sample augmentation (terrain_encoder/utils.py:110-133) pays no
+ * torch.inverse -- two LU launches and a host synchronisation -- per step.  For diagonal-plus-translation intrinsics and scale / flip /
+ * crop augmentations the inverse is exact up to one rounding per entry and the keys equal mf_bev_splat_prepare_cameras' bit for bit;
+ * an in-plane rotation (rot_lim) makes the two differ in the last bit of some entries, which moves a point only if it lies within
+ * ~1e-6 voxel of a voxel face (tests/test_splat_gpu.py). */
+int mf_bev_splat_prepare_rig(const MfSplatDesc* desc, const float* frustum, int32_t pts_per_cam, const float* rots, const float* trans,
+                             const float* intrins, const float* post_rots, const float* post_trans, void* workspace, void* hip_stream);
 /* out[B][nz*C][nx][ny] = per-voxel sums of x[B*n_per_sample][C]; every output element is written (zeros where empty) */
 int mf_bev_splat_fwd_f32(const MfSplatDesc* desc, const float* x, const void* workspace, float* out, void* hip_stream);
 int mf_bev_splat_fwd_f64(const MfSplatDesc* desc, const double* x, const void* workspace, double* out, void* hip_stream);

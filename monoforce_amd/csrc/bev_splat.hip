@@ -198,6 +198,168 @@ __global__ void __launch_bounds__(256) splat_rank_kernel(const int* __restrict__
   sorted[s + rank] = p;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// round 5: the plan pass as memset + FOUR launches (keys + histogram + arrival slot | single-pass scan | fill | rank) instead of
+// memset + seven -- at the config-4 shapes the pass is launch latency, not work (121 k points, 65 k voxels: ~25 us of kernels inside
+// 180 us per call, profiles/r4j_bench_lift_splat.txt) -- and, for a camera rig, with both 3 x 3 inversions of get_geometry
+// (lss.py:212, 218) inside the key kernel: no torch.inverse (two LU launches and a host synchronisation per plan) on the host side.
+//   * the histogram atomic RETURNS the point's arrival slot inside its voxel: the CSR fill needs no second atomic pass;
+//   * the exclusive scan is one kernel (decoupled look-back: a block publishes its aggregate, then its inclusive prefix; a wave of
+//     the next block inspects 64 predecessors at once; block ids come from a ticket, so no dispatch order is assumed).
+// Same keys, same CSR lists (ascending point ids inside a voxel) as the round-4 pass: every consumer kernel is unchanged.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void emit_key(int p, int key, int* __restrict__ keys, int* __restrict__ count, int* __restrict__ slot) {
+  keys[p] = key;
+  if (key >= 0) slot[p] = atomicAdd(count + key, 1);      // arrival order inside the voxel (any order: the rank pass sorts by point id)
+}
+
+__global__ void __launch_bounds__(256) plan_keys_geom_kernel(const float* __restrict__ geom, int P, int n_per_sample, int nx, int ny, int nz,
+                                                            float ox, float oy, float oz, float dx, float dy, float dz,
+                                                            int* __restrict__ keys, int* __restrict__ count, int* __restrict__ slot) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  emit_key(p, voxel_key(geom[(size_t)p * 3 + 0], geom[(size_t)p * 3 + 1], geom[(size_t)p * 3 + 2], p / n_per_sample, nx, ny, nz, ox, oy, oz,
+                        dx, dy, dz), keys, count, slot);
+}
+
+__device__ __forceinline__ int frustum_point_key(const float* __restrict__ frustum, const float* cam, int p, int f, int n_per_sample, int nx, int ny,
+                                                 int nz, float ox, float oy, float oz, float dx, float dy, float dz) {
+#pragma clang fp contract(off)
+  const float q0 = frustum[(size_t)f * 3 + 0] - cam[0], q1 = frustum[(size_t)f * 3 + 1] - cam[1], q2 = frustum[(size_t)f * 3 + 2] - cam[2];
+  float a[3], g[3];
+  mat_apply(cam + 3, q0, q1, q2, a);
+  mat_apply(cam + 12, a[0] * a[2], a[1] * a[2], a[2], g);
+  return voxel_key(g[0] + cam[21], g[1] + cam[22], g[2] + cam[23], p / n_per_sample, nx, ny, nz, ox, oy, oz, dx, dy, dz);
+}
+
+__global__ void __launch_bounds__(256) plan_keys_cams_kernel(const float* __restrict__ frustum, const float* __restrict__ cams, int P, int n_per_sample,
+                                                            int pts_per_cam, int nx, int ny, int nz, float ox, float oy, float oz, float dx,
+                                                            float dy, float dz, int* __restrict__ keys, int* __restrict__ count,
+                                                            int* __restrict__ slot) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  emit_key(p, frustum_point_key(frustum, cams + (size_t)(p / pts_per_cam) * 24, p, p % pts_per_cam, n_per_sample, nx, ny, nz, ox, oy, oz, dx, dy, dz),
+           keys, count, slot);
+}
+
+// inverse of a 3 x 3 float32 matrix, formed in float64 (adjugate over the determinant) and rounded ONCE: within half an ulp of the
+// exact inverse's entries.  The reference takes torch.inverse (an LU factorisation in float32 whose last bits differ between its CPU
+// (LAPACK) and GPU (MAGMA / rocSOLVER) back ends); for the matrices a rig produces -- diagonal-plus-translation intrinsics, scale /
+// flip / crop augmentations -- every such inverse is exact up to one rounding per entry and all of them agree.
+__device__ __forceinline__ void inverse3_f32(const float* __restrict__ m, float* __restrict__ o) {
+  const double a = m[0], b = m[1], c = m[2], d = m[3], e = m[4], f = m[5], g = m[6], h = m[7], i = m[8];
+  const double A = e * i - f * h, B = c * h - b * i, C = b * f - c * e;
+  const double D = f * g - d * i, E = a * i - c * g, F = c * d - a * f;
+  const double G = d * h - e * g, H = b * g - a * h, I = a * e - b * d;
+  const double idet = 1.0 / (a * A + b * D + c * G);
+  o[0] = (float)(A * idet); o[1] = (float)(B * idet); o[2] = (float)(C * idet);
+  o[3] = (float)(D * idet); o[4] = (float)(E * idet); o[5] = (float)(F * idet);
+  o[6] = (float)(G * idet); o[7] = (float)(H * idet); o[8] = (float)(I * idet);
+}
+// the 24 coefficients of camera k as splat_keys_frustum_kernel reads them: post_trans, inv(post_rots), rots inv(intrins), trans
+// (the 3 x 3 product in float32 with every product and sum rounded on its own, like a float32 matmul without FMA)
+__device__ __forceinline__ void camera_coefficients(const float* __restrict__ rots, const float* __restrict__ trans, const float* __restrict__ intrins,
+                                                    const float* __restrict__ post_rots, const float* __restrict__ post_trans, int k, float* __restrict__ cam) {
+#pragma clang fp contract(off)
+  float kinv[9];
+  inverse3_f32(post_rots + (size_t)k * 9, cam + 3);
+  inverse3_f32(intrins + (size_t)k * 9, kinv);
+  const float* r = rots + (size_t)k * 9;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) cam[12 + i * 3 + j] = (r[i * 3 + 0] * kinv[0 * 3 + j] + r[i * 3 + 1] * kinv[1 * 3 + j]) + r[i * 3 + 2] * kinv[2 * 3 + j];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) { cam[c] = post_trans[(size_t)k * 3 + c]; cam[21 + c] = trans[(size_t)k * 3 + c]; }
+}
+
+__global__ void __launch_bounds__(256) plan_keys_rig_kernel(const float* __restrict__ frustum, const float* __restrict__ rots, const float* __restrict__ trans,
+                                                           const float* __restrict__ intrins, const float* __restrict__ post_rots,
+                                                           const float* __restrict__ post_trans, int P, int n_per_sample, int pts_per_cam, int nx, int ny,
+                                                           int nz, float ox, float oy, float oz, float dx, float dy, float dz, int* __restrict__ keys,
+                                                           int* __restrict__ count, int* __restrict__ slot) {
+  __shared__ float cam_s[2][24];
+  const int p0 = blockIdx.x * blockDim.x, p1 = min(p0 + (int)blockDim.x - 1, P - 1);
+  const int k0 = p0 / pts_per_cam, k1 = p1 / pts_per_cam;
+  const int p = p0 + threadIdx.x;
+  const bool two = k1 - k0 <= 1;      // the block's points belong to at most two cameras (always, for >= 256 points per camera)
+  if (two) {
+    if (threadIdx.x == 0) camera_coefficients(rots, trans, intrins, post_rots, post_trans, k0, cam_s[0]);
+    if (threadIdx.x == 64) camera_coefficients(rots, trans, intrins, post_rots, post_trans, k1, cam_s[1]);
+    __syncthreads();
+  }
+  if (p >= P) return;
+  const int k = p / pts_per_cam;
+  float own[24];
+  const float* cam = cam_s[k - k0 > 0 ? 1 : 0];
+  if (!two) { camera_coefficients(rots, trans, intrins, post_rots, post_trans, k, own); cam = own; }
+  emit_key(p, frustum_point_key(frustum, cam, p, p - k * pts_per_cam, n_per_sample, nx, ny, nz, ox, oy, oz, dx, dy, dz), keys, count, slot);
+}
+
+// exclusive scan of `in[0 .. n)` into `out[0 .. n]` (out[n] = the total) in ONE launch.  2048 elements per 256-thread block; `state` =
+// zero-filled words: state[0] = the block-id ticket, then one 64-bit word per block: flag (1 = aggregate, 2 = inclusive prefix) << 62 | value.
+constexpr int kScanItems = 8;
+__global__ void __launch_bounds__(256) plan_scan_kernel(const int* __restrict__ in, int n, int* __restrict__ out, unsigned long long* __restrict__ state) {
+  __shared__ int wave_tot[4];
+  __shared__ int bid_s, prev_s;
+  if (threadIdx.x == 0) bid_s = (int)atomicAdd((unsigned*)state, 1u);
+  __syncthreads();
+  const int bid = bid_s;
+  unsigned long long* st = state + 1;      // (64-bit words from state[1]; the host leaves 8 bytes for the ticket)
+  const int base = bid * (256 * kScanItems) + threadIdx.x * kScanItems;
+  int v[kScanItems], sum = 0;
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i) { v[i] = (base + i < n) ? in[base + i] : 0; sum += v[i]; }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+  if (lane == 63) wave_tot[wave] = inc;
+  __syncthreads();
+  int wave_off = 0;
+  for (int w = 0; w < wave; ++w) wave_off += wave_tot[w];
+  const int block_total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+  if (threadIdx.x < 64) {      // wave 0: publish the aggregate, look back, publish the inclusive prefix
+    if (lane == 0) __hip_atomic_store(st + bid, (bid == 0 ? 2ull : 1ull) << 62 | (unsigned long long)(unsigned)block_total, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    int prev = 0;
+    int hi = bid - 1;            // nearest predecessor not yet accounted for
+    while (hi >= 0) {
+      const int j = hi - lane;
+      unsigned long long w = 0;
+      do {
+        w = j >= 0 ? __hip_atomic_load(st + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);      // (before block 0: prefix 0)
+      } while (__any((w >> 62) == 0));
+      const unsigned long long has_prefix = __ballot((w >> 62) == 2);
+      const int first = __ffsll((long long)has_prefix) - 1;      // nearest lane holding an inclusive prefix (-1: none in this window)
+      const int take = first < 0 ? 64 : first + 1;               // lanes 0 .. take - 1 contribute (aggregates, then the prefix)
+      int c = lane < take ? (int)(unsigned)(w & 0xffffffffull) : 0;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d, 64);
+      prev += c;
+      if (first >= 0) break;
+      hi -= 64;
+    }
+    if (lane == 0) {
+      if (bid > 0) __hip_atomic_store(st + bid, 2ull << 62 | (unsigned long long)(unsigned)(prev + block_total), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      prev_s = prev;
+    }
+  }
+  __syncthreads();
+  int run = prev_s + wave_off + inc - sum;
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i) { if (base + i < n) out[base + i] = run; run += v[i]; }
+  if (base <= n - 1 && n - 1 < base + kScanItems) out[n] = run;      // the thread that holds the last element writes the total
+}
+
+// CSR fill without atomics: the key pass already gave every kept point its arrival slot inside its voxel
+__global__ void __launch_bounds__(256) plan_fill_kernel(const int* __restrict__ keys, int P, const int* __restrict__ offsets, const int* __restrict__ slot,
+                                                       int* __restrict__ list) {
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int key = keys[p];
+  if (key >= 0) list[offsets[key] + slot[p]] = p;
+}
+
 template <typename S>
 __device__ __forceinline__ S mul_rounded(S a, S b) {
 #pragma clang fp contract(off)
@@ -941,14 +1103,47 @@ static int check_desc(const MfSplatDesc* d) {
     MF_REQUIRE(e_ == hipSuccess, MF_ERR_LAUNCH, std::string(what) + ": " + hipGetErrorString(e_));     \
   } while (0)
 
+struct RigPtrs { const float *rots, *trans, *intrins, *post_rots, *post_trans; };
+
+// MF_SPLAT_PLAN=0: the round-4 pass (seven launches; A/B runs, equality tests of the two)
+static bool plan_v2() {
+  static const bool off = getenv("MF_SPLAT_PLAN") && atoi(getenv("MF_SPLAT_PLAN")) == 0;
+  return !off;
+}
+
 static int splat_prepare(const MfSplatDesc* d, const float* geom, const float* frustum, const float* cams, int pts_per_cam,
-                         void* workspace, hipStream_t st) {
+                         void* workspace, hipStream_t st, const RigPtrs* rig = nullptr) {
   SplatWs ws;
   carve(d, workspace, &ws);
   const int P = d->B * d->n_per_sample;
   const int V = d->B * d->nz * d->nx * d->ny;
-  hipError_t e = hipMemsetAsync(ws.count, 0, (char*)ws.offsets - (char*)ws.count, st);   // count + cursor
+  hipError_t e = hipMemsetAsync(ws.count, 0, (char*)ws.offsets - (char*)ws.count, st);   // count + cursor (v2: cursor = the scan's ticket and block states)
   MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("bev_splat memset: ") + hipGetErrorString(e));
+  const dim3 gp((P + 255) / 256), blk(256);
+  if (plan_v2() || rig) {
+    // keys + histogram + arrival slots (slots kept in `list` until the rank pass overwrites it with the sorted ids)
+    if (geom)
+      hipLaunchKernelGGL(plan_keys_geom_kernel, gp, blk, 0, st, geom, P, d->n_per_sample, d->nx, d->ny, d->nz, d->off[0], d->off[1], d->off[2],
+                         d->dx[0], d->dx[1], d->dx[2], ws.keys, ws.count, ws.list);
+    else if (rig)
+      hipLaunchKernelGGL(plan_keys_rig_kernel, gp, blk, 0, st, frustum, rig->rots, rig->trans, rig->intrins, rig->post_rots, rig->post_trans, P,
+                         d->n_per_sample, pts_per_cam, d->nx, d->ny, d->nz, d->off[0], d->off[1], d->off[2], d->dx[0], d->dx[1], d->dx[2], ws.keys,
+                         ws.count, ws.list);
+    else
+      hipLaunchKernelGGL(plan_keys_cams_kernel, gp, blk, 0, st, frustum, cams, P, d->n_per_sample, pts_per_cam, d->nx, d->ny, d->nz, d->off[0],
+                         d->off[1], d->off[2], d->dx[0], d->dx[1], d->dx[2], ws.keys, ws.count, ws.list);
+    MF_LAUNCH_OK("splat_keys");
+    const int nblk = (V + 256 * kScanItems - 1) / (256 * kScanItems);
+    // the scan's state lives in the (zeroed) cursor region: 8 bytes of ticket + one 64-bit word per block
+    MF_REQUIRE((size_t)(nblk + 1) * 8 <= (size_t)((char*)ws.offsets - (char*)ws.cursor), MF_ERR_UNSUPPORTED, "bev_splat: scan state does not fit the workspace");
+    hipLaunchKernelGGL(plan_scan_kernel, dim3(nblk), blk, 0, st, ws.count, V, ws.offsets, (unsigned long long*)ws.cursor);
+    MF_LAUNCH_OK("splat_scan");
+    hipLaunchKernelGGL(plan_fill_kernel, gp, blk, 0, st, ws.keys, P, ws.offsets, ws.list, ws.scratch);
+    MF_LAUNCH_OK("splat_fill");
+    hipLaunchKernelGGL(splat_rank_kernel, gp, blk, 0, st, ws.keys, ws.offsets, V, ws.scratch, ws.list);
+    MF_LAUNCH_OK("splat_sort");
+    return MF_OK;
+  }
   if (geom)
     hipLaunchKernelGGL(splat_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, st, geom, P, d->n_per_sample, d->nx, d->ny, d->nz,
                        d->off[0], d->off[1], d->off[2], d->dx[0], d->dx[1], d->dx[2], ws.keys, ws.count);
@@ -1121,6 +1316,15 @@ extern "C" int mf_bev_splat_prepare_cameras(const MfSplatDesc* d, const float* f
   MF_REQUIRE(pts_per_cam > 0 && d->n_per_sample % pts_per_cam == 0, MF_ERR_INVALID,
              "bev_splat_prepare_cameras: n_per_sample must be cameras * pts_per_cam");
   return mf::splat_prepare(d, nullptr, frustum, cams, pts_per_cam, ws, (hipStream_t)s);
+}
+extern "C" int mf_bev_splat_prepare_rig(const MfSplatDesc* d, const float* frustum, int32_t pts_per_cam, const float* rots, const float* trans,
+                                        const float* intrins, const float* post_rots, const float* post_trans, void* ws, void* s) {
+  int rc = mf::check_desc(d);
+  if (rc != MF_OK) return rc;
+  MF_REQUIRE(frustum && rots && trans && intrins && post_rots && post_trans && ws, MF_ERR_INVALID, "bev_splat_prepare_rig: null buffer");
+  MF_REQUIRE(pts_per_cam > 0 && d->n_per_sample % pts_per_cam == 0, MF_ERR_INVALID, "bev_splat_prepare_rig: n_per_sample must be cameras * pts_per_cam");
+  const mf::RigPtrs rig{rots, trans, intrins, post_rots, post_trans};
+  return mf::splat_prepare(d, nullptr, frustum, nullptr, pts_per_cam, ws, (hipStream_t)s, &rig);
 }
 #define MF_SPLAT_ENTRY(name, S, impl)                                                           \
   extern "C" int name(const MfSplatDesc* d, const S* in, const void* ws, S* out, void* s) {     \

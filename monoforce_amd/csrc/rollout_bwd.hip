@@ -131,6 +131,27 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
     // accumulator carry-over between adjacent cells (rollout_bwd_kernel.h): ~55 more instructions per step, half the atomics --
     // a gain from ~3 waves per 4 CUs upwards (B = 4096 at N = 4: 1.00 -> 0.94 ms; B = 65536: 9.5 -> 5.5 ms), a loss below
     const RolloutBwdArgs<float>& af = *reinterpret_cast<const RolloutBwdArgs<float>*>(&a);
+    // positions-only upstream (physics_loss) on a one-point-per-lane mapping inside a wave, from one wave per SIMD up: the XS_ONLY
+    // kernels -- and, for ONE shared map pair with a friction map, the interleaved (z, mu) copy (the caller's staged pair, or the
+    // scratch it offers, refilled here: one 65 536-cell pass in front of a launch of >= 1 ms).  MF_BWD_XS=0 / MF_BWD_XS_ZMU=0: A/B.
+    static const bool xs_off = getenv("MF_BWD_XS") && atoi(getenv("MF_BWD_XS")) == 0;
+    static const bool xs_zmu_off = getenv("MF_BWD_XS_ZMU") && atoi(getenv("MF_BWD_XS_ZMU")) == 0;
+    const bool xs_only = p->gXs && !p->gXds && !p->gRs && !p->gOmegas && !p->gFs && !p->gFf;
+    if (!xs_off && xs_only && m.PPL == 1 && m.G <= 64 && (long long)d->B * m.G >= device_simds() * 64) {
+      RolloutBwdArgs<float> ax = af;
+      bool zmu = false;
+      if (!xs_zmu_off && d->map_shared && p->mu && (p->zmu || p->zmu_scratch) && (long long)d->H * d->W * 8 < (1ll << 31)) {
+        MF_REQUIRE((((uintptr_t)p->zmu_scratch | (uintptr_t)p->zmu) & 7) == 0, MF_ERR_INVALID, "rollout_bwd: zmu_scratch / zmu must be 8-byte aligned");
+        if (p->zmu) ax.zmu = (const float*)p->zmu;
+        else {
+          const int n = d->H * d->W;
+          hipLaunchKernelGGL((interleave_maps_bwd_kernel<float>), dim3((n + 255) / 256), dim3(256), 0, st, ax.z, ax.mu, n, (cp::Pk2<float>*)p->zmu_scratch);
+          ax.zmu = (const float*)p->zmu_scratch;
+        }
+        zmu = true;
+      }
+      return launch_rollout_bwd_xs_fast_f32(ax, m, d->integrator, block, zmu, st);
+    }
     if ((long long)d->B * m.G >= 3ll * device_cus() / 4 * 64) return launch_rollout_bwd_carry_fast_f32(af, m, d->integrator, block, st);
     return launch_rollout_bwd_fast_f32(af, m, d->integrator, block, st);
   }

@@ -65,7 +65,12 @@ __device__ __forceinline__ S* at32(S* base, unsigned elem) {
     (o)[2] = (a)[0] * (b)[1] - (a)[1] * (b)[0]; \
   } while (0)
 
-template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS = false, bool CARRY = true>
+// XS_ONLY (round 5): the only upstream gradient is dL/dXs (physics_loss, losses.py:102-127: positions at the stamped rows) -- the
+// other five row loads per step, their adds and the impulse adjoints are compiled out.  ZMU: ONE shared (z, mu) pair read interleaved,
+// two 16-byte loads per footprint instead of eight 4-byte ones (gather4x2, rollout_fwd_kernel.h).  Both serve the saturated launches of
+// <= 4-point bodies (B > 8192), which PMC shows bound by the CU's L1 address path, not by VALU issue
+// (profiles/r5_pmc_backward_B16384.txt): the distinct addresses per wave-step drop from ~1060 to ~650.
+template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS = false, bool CARRY = true, bool XS_ONLY = false, bool ZMU = false>
 __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_bwd_kernel(const RolloutBwdArgs<S> a) {
   using M = Mth<S, FAST>;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -185,21 +190,27 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_bwd_kernel(const Ro
   auto load_upstream = [&](const Ptrs& p, UpIn& u) {
     // absent upstream gradients point at a zero row with stride 0 (host side), so these loads are unconditional
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { u.gXs[c] = p.g1[c]; u.gXds[c] = p.g2[c]; u.gOm[c] = p.g3[c]; }
+    for (int c = 0; c < 3; ++c) u.gXs[c] = p.g1[c];
+    if constexpr (!XS_ONLY) {
 #pragma unroll
-    for (int c = 0; c < 9; ++c) u.gRs[c] = p.g4[c];
+      for (int c = 0; c < 3; ++c) { u.gXds[c] = p.g2[c]; u.gOm[c] = p.g3[c]; }
 #pragma unroll
-    for (int j = 0; j < PPL; ++j)
+      for (int c = 0; c < 9; ++c) u.gRs[c] = p.g4[c];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) { u.gFs[j][c] = p.f1[j][c]; u.gFf[j][c] = p.f2[j][c]; }   // masked by act[] where they are consumed
+      for (int j = 0; j < PPL; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { u.gFs[j][c] = p.f1[j][c]; u.gFf[j][c] = p.f2[j][c]; }   // masked by act[] where they are consumed
+    }
   };
   auto add_upstream_state = [&](const UpIn& u) {
     lx[0] += u.gXs[0]; lx[1] += u.gXs[1]; lx[2] += u.gXs[2];
     lR[2] += u.gXs[0] * a.sink; lR[5] += u.gXs[1] * a.sink; lR[8] += u.gXs[2] * a.sink;   // Xs = x + R[:,2] * sink
-    lxd[0] += u.gXds[0]; lxd[1] += u.gXds[1]; lxd[2] += u.gXds[2];
+    if constexpr (!XS_ONLY) {
+      lxd[0] += u.gXds[0]; lxd[1] += u.gXds[1]; lxd[2] += u.gXds[2];
 #pragma unroll
-    for (int c = 0; c < 9; ++c) lR[c] += u.gRs[c];
-    lw[0] += u.gOm[0]; lw[1] += u.gOm[1]; lw[2] += u.gOm[2];
+      for (int c = 0; c < 9; ++c) lR[c] += u.gRs[c];
+      lw[0] += u.gOm[0]; lw[1] += u.gOm[1]; lw[2] += u.gOm[2];
+    }
   };
 
   if (INTEG == MF_INTEG_ODEINT_EULER) {
@@ -290,10 +301,14 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_bwd_kernel(const Ro
       vp[j][2] = xd[2] + (w[0] * r[j][1] - w[1] * r[j][0]);
       cell[j] = locate_m<S, FAST>(px, py, a.d_max, a.res, a.inv_res, a.H, last);
       const Cell<S>& c = cell[j];
+      if constexpr (ZMU) {      // the footprint in both maps as two 16-byte loads of the interleaved (z, mu) pair
+        gather4x2(a.zmu, c, last, zc4[j], mc4[j]);
+      } else {
       zc4[j][0] = ld32(zmap, moff + (unsigned)c.ic); zc4[j][1] = ld32(zmap, moff + (unsigned)c.i_f); zc4[j][2] = ld32(zmap, moff + (unsigned)c.il); zc4[j][3] = ld32(zmap, moff + (unsigned)c.ifl);
       // unconditional (mumap aliases z when there is no friction map; the select follows the blend): one basic block, and
       // no consumer of the gathers ahead of the loads and atomics issued below
       mc4[j][0] = ld32(mumap, moff + (unsigned)c.ic); mc4[j][1] = ld32(mumap, moff + (unsigned)c.i_f); mc4[j][2] = ld32(mumap, moff + (unsigned)c.il); mc4[j][3] = ld32(mumap, moff + (unsigned)c.ifl);
+      }
     }
     // Issue order of a step's memory operations (vmcnt retires loads, stores and atomics in order, so a wait for a load is
     // a wait for everything issued before it): gathers of this step | map-gradient atomics and control-gradient store
@@ -376,7 +391,7 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_bwd_kernel(const Ro
 #pragma unroll
       for (int j = 0; j < PPL; ++j)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { laFs[j][c] += act[j] ? up.gFs[j][c] : zero; laFf[j][c] += act[j] ? up.gFf[j][c] : zero; }
+        for (int c = 0; c < 3; ++c) { if constexpr (!XS_ONLY) { laFs[j][c] += act[j] ? up.gFs[j][c] : zero; laFf[j][c] += act[j] ? up.gFf[j][c] : zero; } }
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         gxdd[c] = h * lxd[c];
@@ -386,7 +401,7 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_bwd_kernel(const Ro
 #pragma unroll
       for (int j = 0; j < PPL; ++j)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { gFr[j][c] = h * laFs[j][c]; gFf[j][c] = h * laFf[j][c]; }
+        for (int c = 0; c < 3; ++c) { gFr[j][c] = XS_ONLY ? zero : h * laFs[j][c]; gFf[j][c] = XS_ONLY ? zero : h * laFf[j][c]; }
       // R' = R + h [w]x R : column-wise dR_c = w x R_c
       S lRn[9];
 #pragma unroll
@@ -409,7 +424,7 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_bwd_kernel(const Ro
 #pragma unroll
       for (int j = 0; j < PPL; ++j)
 #pragma unroll
-        for (int c = 0; c < 3; ++c) { gFr[j][c] = act[j] ? up.gFs[j][c] : zero; gFf[j][c] = act[j] ? up.gFf[j][c] : zero; }
+        for (int c = 0; c < 3; ++c) { gFr[j][c] = (!XS_ONLY && act[j]) ? up.gFs[j][c] : zero; gFf[j][c] = (!XS_ONLY && act[j]) ? up.gFf[j][c] : zero; }
       // R' = R M(w'),  w' = w + wd h,  M = I + K sin(th h) + K^2 (1 - cos(th h)),  K = [w']x / max(|w'|, eps)
       S wn[3] = {w[0] + wd[0] * h, w[1] + wd[1] * h, w[2] + wd[2] * h};
       S th = M::sqrt(wn[0] * wn[0] + wn[1] * wn[1] + wn[2] * wn[2]);
@@ -492,8 +507,8 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_bwd_kernel(const Ro
       S gFr_[3], gG[3];
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-        gFr_[c] = gFr[j][c] + gsum[c] + gf[c];
-        S gFf_ = gFf[j][c] + gsum[c] + gf[c];
+        gFr_[c] = XS_ONLY ? gsum[c] + gf[c] : gFr[j][c] + gsum[c] + gf[c];
+        S gFf_ = XS_ONLY ? gsum[c] + gf[c] : gFf[j][c] + gsum[c] + gf[c];
         gG[c] = inside(Gf[j][c], -a.mg, a.mg) ? gFf_ : zero;
       }
       S gNn = gG[0] * st[j][0] + gG[1] * st[j][1] + gG[2] * st[j][2];
@@ -783,6 +798,30 @@ int launch_rollout_bwd(const RolloutBwdArgs<S>& a, LaneMap m, int integ, int blo
   MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("rollout_bwd launch: ") + hipGetErrorString(e));
   return MF_OK;
 }
+
+// the positions-only (XS_ONLY) instantiations with accumulator carry-over, one point per lane inside a wave (G = 4 .. 64), plain or
+// interleaved maps: the saturated launches of small bodies (rollout_bwd_xs_fast.hip)
+template <typename S, bool ZMU>
+int launch_rollout_bwd_xs(const RolloutBwdArgs<S>& a, LaneMap m, int integ, int block, hipStream_t st) {
+  const long long threads = (long long)a.B * m.G;
+  const unsigned grid = (unsigned)((threads + block - 1) / block);
+  bool launched = false;
+#define MF_CASE(G_)                                                                                                                       \
+  if (!launched && m.G == G_ && m.PPL == 1) {                                                                                              \
+    launched = true;                                                                                                                       \
+    if (integ == MF_INTEG_DYNAMICS)                                                                                                        \
+      MF_KLAUNCH((rollout_bwd_kernel<S, G_, 1, MF_INTEG_DYNAMICS, true, false, true, true, ZMU>), dim3(grid), dim3(block), 0, st, a);      \
+    else                                                                                                                                   \
+      MF_KLAUNCH((rollout_bwd_kernel<S, G_, 1, MF_INTEG_ODEINT_EULER, true, false, true, true, ZMU>), dim3(grid), dim3(block), 0, st, a);  \
+  }
+  MF_CASE(4) MF_CASE(8) MF_CASE(16) MF_CASE(32) MF_CASE(64)
+#undef MF_CASE
+  MF_REQUIRE(launched, MF_ERR_UNSUPPORTED, "rollout_bwd: no positions-only kernel for this lane mapping");
+  hipError_t e = hipGetLastError();
+  MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("rollout_bwd (positions only) launch: ") + hipGetErrorString(e));
+  return MF_OK;
+}
+int launch_rollout_bwd_xs_fast_f32(const RolloutBwdArgs<float>& a, LaneMap m, int integ, int block, bool zmu, hipStream_t st);      // rollout_bwd_xs_fast.hip
 
 // defined in rollout_bwd_fast.hip (plain flush) and rollout_bwd_carry_fast.hip (accumulator carry-over)
 int launch_rollout_bwd_fast_f32(const RolloutBwdArgs<float>& a, LaneMap m, int integ, int block, hipStream_t st);

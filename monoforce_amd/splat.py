@@ -11,6 +11,10 @@ import torch
 from . import _lib, _timing
 
 
+import os as _os
+_HOST_INVERSE = bool(int(_os.environ.get('MF_SPLAT_HOST_INVERSE', '0')))      # round 4's plan route for camera rigs (torch.inverse on the device)
+
+
 def _stream_ptr(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
@@ -24,17 +28,20 @@ def grid_host(dx, bx, nx):
 
 
 class SplatPlan:
-    def __init__(self, geom, dx, bx, nx, _cameras=None, grid=None):
-        """geom [B, ..., 3] float32 on the GPU; dx, bx (float32 tensors), nx (int64 tensor) as produced by gen_dx_bx."""
+    def __init__(self, geom, dx, bx, nx, _cameras=None, grid=None, workspace=None):
+        """geom [B, ..., 3] float32 on the GPU; dx, bx (float32 tensors), nx (int64 tensor) as produced by gen_dx_bx.
+        `workspace`: a uint8 tensor of at least mf_bev_splat_workspace_bytes() to build the plan in (a caller that rebuilds the plan
+        every step reuses one buffer: stream order keeps step i's kernels ahead of step i + 1's rebuild)."""
         if _cameras is None:
             _lib.require_hip_tensor(geom, 'geom')
             B = geom.shape[0]
             g = geom.detach().to(torch.float32).contiguous().view(-1, 3)
             device, n_per_sample = geom.device, g.shape[0] // B
         else:
-            frustum, cams, B = _cameras
-            _lib.require_hip_tensor(cams, 'camera models')
-            device, n_per_sample = cams.device, (cams.shape[0] // B) * frustum.shape[0]
+            frustum, cams, B = _cameras      # cams: [B*N,24] coefficient rows, or the five raw calibration tensors (the rig entry point)
+            rig = isinstance(cams, (tuple, list))
+            _lib.require_hip_tensor(cams[0] if rig else cams, 'camera models')
+            device, n_per_sample = (cams[0] if rig else cams).device, ((cams[0] if rig else cams).shape[0] // B) * frustum.shape[0]
         off, dxl, n = grid if grid is not None else grid_host(dx, bx, nx)
         self.B, self.n_per_sample = B, n_per_sample
         self.nx, self.ny, self.nz = n
@@ -45,12 +52,19 @@ class SplatPlan:
         nbytes = _lib.lib().mf_bev_splat_workspace_bytes(C.byref(d))
         if nbytes == 0:
             raise RuntimeError('mf_bev_splat_workspace_bytes: ' + _lib.lib().mf_last_error().decode())
-        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        if workspace is not None and workspace.numel() >= nbytes and workspace.device == device and workspace.dtype == torch.uint8:
+            self.workspace = workspace
+        else:
+            self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=device)
         with torch.cuda.device(device), _timing.timed('splat_prepare', device):
             if _cameras is None:
                 _lib.check(_lib.lib().mf_bev_splat_prepare(C.byref(d), _lib.ptr(g), _lib.ptr(self.workspace), _stream_ptr(device)),
                            'mf_bev_splat_prepare')
                 self._keepalive = g
+            elif rig:
+                _lib.check(_lib.lib().mf_bev_splat_prepare_rig(C.byref(d), _lib.ptr(frustum), C.c_int32(frustum.shape[0]), *(_lib.ptr(t) for t in cams),
+                                                               _lib.ptr(self.workspace), _stream_ptr(device)), 'mf_bev_splat_prepare_rig')
+                self._keepalive = (frustum, cams)
             else:
                 _lib.check(_lib.lib().mf_bev_splat_prepare_cameras(C.byref(d), _lib.ptr(frustum), C.c_int32(frustum.shape[0]),
                                                                    _lib.ptr(cams), _lib.ptr(self.workspace), _stream_ptr(device)),
@@ -58,19 +72,28 @@ class SplatPlan:
                 self._keepalive = (frustum, cams)
 
     @classmethod
-    def from_cameras(cls, frustum, rots, trans, intrins, post_rots, post_trans, dx, bx, nx, grid=None):
+    def from_cameras(cls, frustum, rots, trans, intrins, post_rots, post_trans, dx, bx, nx, grid=None, host_inverse=None, workspace=None):
         """The plan of `SplatPlan(get_geometry(rots, trans, intrins, post_rots, post_trans), ...)` without the geometry
-        tensor: frustum [D,fH,fW,3] (create_frustum), camera models [B,N,3(,3)] as LiftSplatShoot.forward takes them.  The two
-        3x3-by-3x3 products of get_geometry (lss.py:212, 218) stay here; the per-point part runs inside the key kernel."""
+        tensor: frustum [D,fH,fW,3] (create_frustum), camera models [B,N,3(,3)] as LiftSplatShoot.forward takes them.
+        Default (round 5): `mf_bev_splat_prepare_rig` -- the five tensors go to the key kernel as they are, which inverts post_rots and
+        intrins itself: no `torch.inverse` (two LU launches + a host synchronisation), no concatenations, nothing on the host but one
+        C call; a per-sample augmentation (new tensors every step) costs the plan's five launches.  `host_inverse=True` (or
+        MF_SPLAT_HOST_INVERSE=1): round 4's route, torch.inverse on the device and `mf_bev_splat_prepare_cameras` -- torch's own LU
+        bits (A/B runs, parity tests of the two)."""
         B, N = trans.shape[:2]
         f32 = lambda t: t.detach().to(torch.float32)
+        fr = f32(frustum).contiguous().view(-1, 3)
+        if host_inverse is None:
+            host_inverse = _HOST_INVERSE
+        if not host_inverse:
+            rig = tuple(f32(t).reshape(B * N, -1).contiguous() for t in (rots, trans, intrins, post_rots, post_trans))
+            return cls(None, dx, bx, nx, _cameras=(fr, rig, B), grid=grid, workspace=workspace)
         # both 3x3 inverses of get_geometry (lss.py:212, 218) in ONE batched call: the batched LU treats every matrix on its own, so
         # the results are the reference's, bit for bit, at half the launches
         inv = torch.inverse(torch.cat((f32(post_rots).reshape(B * N, 3, 3), f32(intrins).reshape(B * N, 3, 3))))
         cams = torch.cat((f32(post_trans).reshape(B * N, 3), inv[:B * N].reshape(B * N, 9),
                           f32(rots).reshape(B * N, 3, 3).matmul(inv[B * N:]).reshape(B * N, 9), f32(trans).reshape(B * N, 3)), 1).contiguous()
-        fr = f32(frustum).contiguous().view(-1, 3)
-        return cls(None, dx, bx, nx, _cameras=(fr, cams, B), grid=grid)
+        return cls(None, dx, bx, nx, _cameras=(fr, cams, B), grid=grid, workspace=workspace)
 
     def keys(self):
         """Linear voxel id of every point ([B * n_per_sample] int32, -1 = dropped): the first array of the workspace."""

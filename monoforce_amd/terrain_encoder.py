@@ -145,6 +145,9 @@ class LiftSplatShoot(nn.Module):
         self.fuse_geometry = True        # with fuse_lift: get_geometry inside the splat's key pass (no [B,N,D,fH,fW,3] tensor)
         self._grid_host = None
         self._plan_cache = None          # (the five calibration tensors, their versions, plan): see splat_plan_cached
+        # False: build the plan in EVERY forward (a data loader with per-sample augmentation refills the calibration tensors in place;
+        # inside a captured train step the plan's launches are then part of the graph -- the rig plan has no host synchronisation)
+        self.cache_plan = True
 
     def create_frustum(self):
         """(u, v, d) of every lifted point: pixel centres on the /16 feature grid x depth bins (lss.py:191-202)."""
@@ -190,14 +193,19 @@ class LiftSplatShoot(nn.Module):
         versions = (self.dx._version, self.bx._version, self.nx._version, self.dx.device)
         if self._grid_host is None or self._grid_host[0] != versions:
             self._grid_host = (versions, splat.grid_host(self.dx, self.bx, self.nx))
-        return splat.SplatPlan.from_cameras(self.frustum, rots, trans, intrins, post_rots, post_trans, self.dx, self.bx, self.nx,
-                                            grid=self._grid_host[1])
+        # (`cache_plan = False`: the plan is rebuilt every forward, in ONE persistent workspace -- no allocation per step, none inside a capture)
+        ws = None if self.cache_plan else self.__dict__.get('_plan_ws')
+        plan = splat.SplatPlan.from_cameras(self.frustum, rots, trans, intrins, post_rots, post_trans, self.dx, self.bx, self.nx,
+                                            grid=self._grid_host[1], workspace=ws)
+        if not self.cache_plan:
+            self.__dict__['_plan_ws'] = plan.workspace
+        return plan
 
     def splat_plan_cached(self, rots, trans, intrins, post_rots, post_trans):
         """`splat_plan` for the SAME five tensor objects, unmodified since the last call (identity + version counters; the cache holds
         the tensors, so their storage cannot be recycled under it): a fixed camera rig -- a frame loop, a synthetic benchmark batch, a
-        captured train step -- pays the two 3x3 inversions (`torch.inverse` synchronises) and the key / scan / CSR passes once instead of
-        every forward.  New tensors every step (a data loader with augmentation) simply miss."""
+        captured train step -- pays the key / scan / CSR passes once instead of every forward.  New tensors every step (a data loader with
+        augmentation) simply miss: the plan is then five launches with no host synchronisation (`mf_bev_splat_prepare_rig`)."""
         cal = (rots, trans, intrins, post_rots, post_trans)
         c = self._plan_cache
         if c is not None and all(a is b for a, b in zip(c[0], cal)) and c[1] == tuple(t._version for t in cal):
@@ -212,7 +220,7 @@ class LiftSplatShoot(nn.Module):
             B, N, C, imH, imW = x.shape
             depth, context = self.camencode.get_depth_and_context(x.view(B * N, C, imH, imW))
             if plan is None and self.fuse_geometry:
-                plan = self.splat_plan_cached(rots, trans, intrins, post_rots, post_trans)
+                plan = (self.splat_plan_cached if self.cache_plan else self.splat_plan)(rots, trans, intrins, post_rots, post_trans)
             geom = None if plan is not None else self.get_geometry(rots, trans, intrins, post_rots, post_trans)
             return splat.lift_voxel_pooling(geom, depth, context, self.dx, self.bx, self.nx, plan=plan)
         geom = self.get_geometry(rots, trans, intrins, post_rots, post_trans)

@@ -325,6 +325,9 @@ class EncoderTrainStep:
                         self._apply()
             except RuntimeError as e:
                 import warnings
+                if os.environ.get('MF_DEBUG_CAPTURE'):
+                    import traceback
+                    traceback.print_exc()
                 warnings.warn(f'EncoderTrainStep: hipGraph capture failed ({str(e).splitlines()[0][:160]}); running launch by launch')
                 # (several ranks: the others may have captured and will call `buckets.exchange()` -- bucket-INDEX order -- between
                 #  their two replays; this rank keeps the deferred exchange too, so every rank issues the same collectives in the same

@@ -23,12 +23,21 @@ def test_get_voxels_matches_oracle_on_lifted_features():
     with torch.no_grad():
         geom = m.get_geometry(*rig)
         feats = m.get_cam_feats(x)
-        bev = m.get_voxels(x, *rig)
+        # the plan of THIS geometry tensor (get_geometry ran torch.inverse + matmul on the device), so that get_voxels and the oracle
+        # pool the same indices
+        from monoforce_amd import splat
+        bev = m.get_voxels(x, *rig, plan=splat.SplatPlan(geom, m.dx, m.bx, m.nx))
+        bev_rig = m.get_voxels(x, *rig)       # the default route: the plan straight from the calibration tensors (in-kernel inverses)
         out = m(x, *rig)
     assert feats.shape == (B, 3, m.D, 4, 6, 64) and bev.shape == (B, 64, 64, 64)
     ref, kept = so.voxel_pooling(geom.cpu().numpy(), feats.cpu().numpy(), m.dx.cpu().numpy(), m.bx.cpu().numpy(), m.nx.cpu().numpy())
     assert kept.mean() > 0.3
     assert hp.rel_err(bev.cpu(), ref) <= 1e-6
+    # this synthetic rig puts frustum points EXACTLY on voxel faces (focal 40, depths in multiples of 0.2, 0.1 m voxels: (76 - 48) / 40 * 2.0
+    # = 1.4); the in-kernel 3 x 3 product rounds like torch's CPU matmul (unfused), the device matmul of get_geometry does not, so a
+    # handful of such points land in the neighbouring voxel: a few voxel columns differ, everything else is the same sum
+    cols = (bev_rig.cpu() - torch.as_tensor(ref)).abs().amax(dim=1) > 1e-6 * float(np.abs(ref).max())
+    assert float(cols.float().mean()) <= 5e-3, float(cols.float().mean())
     assert set(out) == {'geom', 'terrain', 'diff', 'friction'} and out['terrain'].shape == (B, 1, 64, 64)
     assert all(torch.isfinite(v).all() for v in out.values())
 

@@ -194,6 +194,51 @@ def test_large_batch_shared_map_backward_vs_oracle(B, ppl, integ):
     assert float(cd.grad[rest.to(DEV)].abs().max()) == 0.0          # rollouts the loss does not touch get exactly nothing
 
 
+@pytest.mark.parametrize('integ', [1, 0])
+@pytest.mark.parametrize('friction', [True, False])
+def test_saturated_positions_only_backward_vs_oracle(integ, friction):
+    """B = 16 384 rollouts of the 4-point body (one wave of sixteen rollouts on every SIMD), loss on the positions only: the XS_ONLY
+    instantiations of the general backward (round 5), reading the shared pair interleaved when there is a friction map (ZMU) --
+    against the float64 ORACLE on the 32 rollouts the loss touches, at the bar derived from the oracle alone."""
+    from monoforce_amd import synthetic as syn, _timing
+    B, T, sub = 16384, 60, 32
+    pts, masks = syn.robot_points_4()
+    z = syn.bump_terrain(syn.bump_params(5), 6.4, 0.05)
+    mu = syn.wave_friction(6.4, 0.05) if friction else None
+    ctrl = syn.const_controls(B, T, seed=2)
+    sel = torch.arange(0, B, B // sub)[:sub]
+    spec = hp.spec_from(pts, masks, integ, 0.05, 6.4)
+    wts = syn.probe_weights((sub, T, 3), phase=0.3)
+    dp = make_dphysics(pts, masks, integ, 0.05, 6.4)
+    dp.dphys_cfg.traj_sim_time = 5.0
+    zd = z.to(DEV).requires_grad_(True)
+    md = mu.to(DEV).requires_grad_(True) if friction else None
+    cd = ctrl.to(DEV).requires_grad_(True)
+    _timing.start()
+    (Xs, Xds, Rs, Om), _ = dp(zd.unsqueeze(0), cd, friction=md.unsqueeze(0) if friction else None)
+    (Xs[sel.to(DEV)] * wts.to(DEV)).sum().backward()
+    ran = _timing.launches()
+    _timing.stop()
+    name = ran['rollout_bwd_kernel']
+    # rollout_bwd_kernel<float, 4, 1, INTEG, FAST, JOINTS, CARRY, XS_ONLY, ZMU>
+    assert 'rollout_bwd_kernel<float, 4, 1, %d, true, false, true, true, %s>' % (integ, 'true' if friction else 'false') in name, name
+
+    def oracle_grads(dtype):
+        zc = z.to(dtype).requires_grad_(True)
+        mc = mu.to(dtype).requires_grad_(True) if friction else None
+        cc = ctrl[sel].to(dtype).requires_grad_(True)
+        (rX, _, _, _), _ = orc.rollout(spec, zc.unsqueeze(0).expand(sub, -1, -1), cc, friction=mc.unsqueeze(0).expand(sub, -1, -1) if friction else None)
+        (rX * wts.to(dtype)).sum().backward()
+        return (zc.grad, mc.grad, cc.grad) if friction else (zc.grad, cc.grad)
+    ref, env = oracle_grads(torch.float64), oracle_grads(torch.float32)
+    got = (zd.grad, md.grad, cd.grad[sel.to(DEV)]) if friction else (zd.grad, cd.grad[sel.to(DEV)])
+    for nm, g_, r64, r32 in zip(('z', 'mu', 'controls') if friction else ('z', 'controls'), got, ref, env):
+        bar = max(2e-4, 3.0 * hp.rel_err(r32, r64))
+        assert hp.rel_err(g_, r64) <= bar, (nm, hp.rel_err(g_, r64), 'bar', bar)
+    rest = torch.ones(B, dtype=torch.bool); rest[sel] = False
+    assert float(cd.grad[rest.to(DEV)].abs().max()) == 0.0
+
+
 def test_config4_full_size_step_vs_oracles():
     """BASELINE configs[3] at full size, one step: 4 cameras x 3x256x512 -> 256x256 BEV, 1024 rollouts x 500 steps on the
     predicted terrain.  BEV vs the splat oracle on the lifted features; rollout states vs the rollout oracle on the

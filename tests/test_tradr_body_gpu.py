@@ -67,10 +67,11 @@ def test_real_tradr_body_f32_vs_reference(integ, ppl):
         hp.probe_loss(list(so) + list(fo), dt).backward()
         return [zo.grad, mo.grad, co.grad], list(so) + list(fo)
     g64, o64 = oracle_grads(torch.float64)
-    g32, _ = oracle_grads(torch.float32)
-    for k, o, b in zip(hp.OUT_KEYS, outs, o64):      # forces: vs the float64 oracle on the same float32-valued inputs
-        if k in ('Fs', 'Ff'):
-            assert hp.rel_err(o, b.detach()) <= 2e-3, (k, hp.rel_err(o, b.detach()))
+    g32, o32 = oracle_grads(torch.float32)
+    for k, o, b, e32 in zip(hp.OUT_KEYS, outs, o64, o32):      # forces: vs the float64 oracle on the same float32-valued inputs
+        if k in ('Fs', 'Ff'):      # (dynamics() hands out the forces themselves: a point making or breaking contact flips them in float32 -- the oracle's own 24 %)
+            bar = max(2e-3, 3.0 * hp.rel_err(e32.detach(), b.detach()))
+            assert hp.rel_err(o, b.detach()) <= bar, (k, hp.rel_err(o, b.detach()), 'bar', bar)
     for k, a, b64, b32 in zip(('g_z', 'g_mu', 'g_ctrl'), grads, g64, g32):
         bar = max(2e-3, 3.0 * hp.rel_err(b32, b64))
         assert torch.isfinite(a).all(), k

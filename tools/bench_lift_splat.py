@@ -57,3 +57,31 @@ for B in (1, 8):
             fn()
         e1.record(); torch.cuda.synchronize()
         print(f'B={B} {name:20s} {e0.elapsed_time(e1) / 20 * 1e3:7.1f} us on the device, {(time.perf_counter() - t0) / 20 * 1e6:7.1f} us wall', flush=True)
+    # the same plan rebuilt in ONE persistent workspace (LiftSplatShoot.cache_plan = False: what a train loop with per-sample augmentation
+    # runs), launch by launch and as a hipGraph replay (the plan has no host synchronisation: inside a captured train step its five
+    # launches are graph nodes) -- the replay is the device-side cost of the pass without the host's launch pacing
+    enc.cache_plan = False
+    for _ in range(3):
+        enc.splat_plan(*calib)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter(); e0.record()
+    for _ in range(20):
+        enc.splat_plan(*calib)
+    e1.record(); torch.cuda.synchronize()
+    print(f'B={B} plan, one workspace     {e0.elapsed_time(e1) / 20 * 1e3:7.1f} us on the device, {(time.perf_counter() - t0) / 20 * 1e6:7.1f} us wall', flush=True)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        enc.splat_plan(*calib)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
+        enc.splat_plan(*calib)
+    g.replay(); torch.cuda.synchronize()
+    e0.record()
+    for _ in range(20):
+        g.replay()
+    e1.record(); torch.cuda.synchronize()
+    print(f'B={B} plan, hipGraph replay   {e0.elapsed_time(e1) / 20 * 1e3:7.1f} us on the device per replay (memset + 4 kernels)', flush=True)
+    enc.cache_plan = True
