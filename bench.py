@@ -600,11 +600,15 @@ def api_workload(r, T, N, integ, B=1024, iters=24):
     for _ in range(4):
         step()
     r.barrier()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    e0.record()
     for _ in range(iters):
         step(record=True)
+    e1.record()
     torch.cuda.synchronize(dev)
     ms = (time.perf_counter() - t0) / iters * 1e3
+    gpu_ms = e0.elapsed_time(e1) / iters
     _timing.start()
     for _ in range(4):
         _timing.next_step()
@@ -618,7 +622,7 @@ def api_workload(r, T, N, integ, B=1024, iters=24):
                         f'monoforce.losses.physics_loss (torch ops, 50 stamps) + loss.backward(); launch by launch, no hipGraph',
             'launch': {'mode': 'launch by launch', 'kernels': launches},
             'host_us_per_call': {k: float(np.median(v)) for k, v in host.items()},
-            'kernel_ms_sum': float(sum(kern.get(k, 0.0) for k in alg)), 'per_kernel': per_kernel}
+            'device_ms_per_step': gpu_ms, 'kernel_ms_sum': float(sum(kern.get(k, 0.0) for k in alg)), 'per_kernel': per_kernel}
 
 
 def shoot_workload(r, T, N, integ, B=16384, iters=8):

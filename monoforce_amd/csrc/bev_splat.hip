@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(256) splat_rank_kernel(const int* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// round 5: the plan pass as memset + FOUR launches (keys + histogram + arrival slot | single-pass scan | fill | rank) instead of
+// round 5: the plan pass as FIVE launches (clear | keys + histogram + arrival slot | single-pass scan | fill | rank) instead of
 // memset + seven -- at the config-4 shapes the pass is launch latency, not work (121 k points, 65 k voxels: ~25 us of kernels inside
 // 180 us per call, profiles/r4j_bench_lift_splat.txt) -- and, for a camera rig, with both 3 x 3 inversions of get_geometry
 // (lss.py:212, 218) inside the key kernel: no torch.inverse (two LU launches and a host synchronisation per plan) on the host side.
@@ -208,6 +208,13 @@ __global__ void __launch_bounds__(256) splat_rank_kernel(const int* __restrict__
 //     the next block inspects 64 predecessors at once; block ids come from a ticket, so no dispatch order is assumed).
 // Same keys, same CSR lists (ascending point ids inside a voxel) as the round-4 pass: every consumer kernel is unchanged.
 // ---------------------------------------------------------------------------------------------------------
+// count + scan state back to zero: a kernel, not hipMemsetAsync -- the pass also runs INSIDE captured train steps (a plan per forward under
+// per-sample augmentation), and a memset node replayed by hipGraphLaunch did not clear the buffer (ROCm 7.2: the second replay ran on
+// the first one's histogram and ticket -- out-of-range CSR slots, a look-back that never ends; found with tools/debug_c4_aug.py)
+__global__ void __launch_bounds__(256) plan_clear_kernel(int4* __restrict__ p, int n4) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += gridDim.x * blockDim.x) p[i] = int4{0, 0, 0, 0};
+}
+
 __device__ __forceinline__ void emit_key(int p, int key, int* __restrict__ keys, int* __restrict__ count, int* __restrict__ slot) {
   keys[p] = key;
   if (key >= 0) slot[p] = atomicAdd(count + key, 1);      // arrival order inside the voxel (any order: the rank pass sorts by point id)
@@ -326,9 +333,10 @@ __global__ void __launch_bounds__(256) plan_scan_kernel(const int* __restrict__ 
     while (hi >= 0) {
       const int j = hi - lane;
       unsigned long long w = 0;
+      int polls = 0;      // (bounded: a predecessor that never publishes -- a corrupted state buffer -- must not hang the GPU; the plan is then garbage, not a strike)
       do {
         w = j >= 0 ? __hip_atomic_load(st + j, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) : (2ull << 62);      // (before block 0: prefix 0)
-      } while (__any((w >> 62) == 0));
+      } while (__any((w >> 62) == 0) && ++polls < (1 << 22));
       const unsigned long long has_prefix = __ballot((w >> 62) == 2);
       const int first = __ffsll((long long)has_prefix) - 1;      // nearest lane holding an inclusive prefix (-1: none in this window)
       const int take = first < 0 ? 64 : first + 1;               // lanes 0 .. take - 1 contribute (aggregates, then the prefix)
@@ -1117,10 +1125,13 @@ static int splat_prepare(const MfSplatDesc* d, const float* geom, const float* f
   carve(d, workspace, &ws);
   const int P = d->B * d->n_per_sample;
   const int V = d->B * d->nz * d->nx * d->ny;
-  hipError_t e = hipMemsetAsync(ws.count, 0, (char*)ws.offsets - (char*)ws.count, st);   // count + cursor (v2: cursor = the scan's ticket and block states)
-  MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("bev_splat memset: ") + hipGetErrorString(e));
   const dim3 gp((P + 255) / 256), blk(256);
   if (plan_v2() || rig) {
+    {      // count + cursor (= the scan's ticket and block states) to zero; both regions are 256-byte multiples
+      const int n4 = (int)(((char*)ws.offsets - (char*)ws.count) / 16);
+      hipLaunchKernelGGL(plan_clear_kernel, dim3(std::min((n4 + 255) / 256, 1024)), blk, 0, st, (int4*)ws.count, n4);
+      MF_LAUNCH_OK("splat_clear");
+    }
     // keys + histogram + arrival slots (slots kept in `list` until the rank pass overwrites it with the sorted ids)
     if (geom)
       hipLaunchKernelGGL(plan_keys_geom_kernel, gp, blk, 0, st, geom, P, d->n_per_sample, d->nx, d->ny, d->nz, d->off[0], d->off[1], d->off[2],
@@ -1143,6 +1154,11 @@ static int splat_prepare(const MfSplatDesc* d, const float* geom, const float* f
     hipLaunchKernelGGL(splat_rank_kernel, gp, blk, 0, st, ws.keys, ws.offsets, V, ws.scratch, ws.list);
     MF_LAUNCH_OK("splat_sort");
     return MF_OK;
+  }
+  {      // count + cursor to zero (a kernel: see plan_clear_kernel)
+    const int n4 = (int)(((char*)ws.offsets - (char*)ws.count) / 16);
+    hipLaunchKernelGGL(plan_clear_kernel, dim3(std::min((n4 + 255) / 256, 1024)), blk, 0, st, (int4*)ws.count, n4);
+    MF_LAUNCH_OK("splat_clear");
   }
   if (geom)
     hipLaunchKernelGGL(splat_keys_kernel, dim3((P + 255) / 256), dim3(256), 0, st, geom, P, d->n_per_sample, d->nx, d->ny, d->nz,

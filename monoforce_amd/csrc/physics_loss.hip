@@ -178,9 +178,20 @@ __global__ void __launch_bounds__(256) nearest_steps_kernel(const S* __restrict_
   S best = (S)INFINITY;
   int arg = 0;
   bool any = false;
-  for (int t = 0; t < T1; ++t) {
+  int t = 0;
+  for (; t + 8 <= T1; t += 8) {      // eight stamps per trip: their loads are issued together (the chain of compares is what is serial)
+    S v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = p[t + k];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const S d = fabs(v[k] - g);
+      if (d < best || (!any && d == d)) { best = d; arg = t + k; any = true; }      // strict <: the first minimum
+    }
+  }
+  for (; t < T1; ++t) {
     const S d = fabs(p[t] - g);
-    if (d < best || (!any && d == d)) { best = d; arg = t; any = true; }      // strict <: the first minimum
+    if (d < best || (!any && d == d)) { best = d; arg = t; any = true; }
   }
   out[i] = arg;
 }

@@ -191,7 +191,9 @@ class LiftSplatShoot(nn.Module):
         """Voxel plan of a camera rig without the geometry tensor (the reference's get_geometry + the index part of
         voxel_pooling, lss.py:204-224, 246-262); reusable across frames while calibration and augmentation are unchanged."""
         versions = (self.dx._version, self.bx._version, self.nx._version, self.dx.device)
-        if self._grid_host is None or self._grid_host[0] != versions:
+        # (read back once per version of the three grid tensors -- a host synchronisation -- and never inside a stream capture: a captured
+        #  train step restores its snapshot into every state-dict tensor first, which bumps the versions of these constants too)
+        if self._grid_host is None or (self._grid_host[0] != versions and not torch.cuda.is_current_stream_capturing()):
             self._grid_host = (versions, splat.grid_host(self.dx, self.bx, self.nx))
         # (`cache_plan = False`: the plan is rebuilt every forward, in ONE persistent workspace -- no allocation per step, none inside a capture)
         ws = None if self.cache_plan else self.__dict__.get('_plan_ws')

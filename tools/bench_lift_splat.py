@@ -83,5 +83,5 @@ for B in (1, 8):
     for _ in range(20):
         g.replay()
     e1.record(); torch.cuda.synchronize()
-    print(f'B={B} plan, hipGraph replay   {e0.elapsed_time(e1) / 20 * 1e3:7.1f} us on the device per replay (memset + 4 kernels)', flush=True)
+    print(f'B={B} plan, hipGraph replay   {e0.elapsed_time(e1) / 20 * 1e3:7.1f} us on the device per replay (clear + 4 kernels)', flush=True)
     enc.cache_plan = True
