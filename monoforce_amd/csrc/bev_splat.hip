@@ -297,10 +297,13 @@ __global__ void __launch_bounds__(256) plan_keys_rig_kernel(const float* __restr
   }
   if (p >= P) return;
   const int k = p / pts_per_cam;
-  float own[24];
-  const float* cam = cam_s[k - k0 > 0 ? 1 : 0];
-  if (!two) { camera_coefficients(rots, trans, intrins, post_rots, post_trans, k, own); cam = own; }
-  emit_key(p, frustum_point_key(frustum, cam, p, p - k * pts_per_cam, n_per_sample, nx, ny, nz, ox, oy, oz, dx, dy, dz), keys, count, slot);
+  if (two) {
+    emit_key(p, frustum_point_key(frustum, cam_s[k - k0 > 0 ? 1 : 0], p, p - k * pts_per_cam, n_per_sample, nx, ny, nz, ox, oy, oz, dx, dy, dz), keys, count, slot);
+  } else {      // (its own call: one pointer that is LDS or a private array would put the array in scratch)
+    float own[24];
+    camera_coefficients(rots, trans, intrins, post_rots, post_trans, k, own);
+    emit_key(p, frustum_point_key(frustum, own, p, p - k * pts_per_cam, n_per_sample, nx, ny, nz, ox, oy, oz, dx, dy, dz), keys, count, slot);
+  }
 }
 
 // exclusive scan of `in[0 .. n)` into `out[0 .. n]` (out[n] = the total) in ONE launch.  2048 elements per 256-thread block; `state` =
