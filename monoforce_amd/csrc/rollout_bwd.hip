@@ -137,7 +137,8 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
     static const bool xs_off = getenv("MF_BWD_XS") && atoi(getenv("MF_BWD_XS")) == 0;
     static const bool xs_zmu_off = getenv("MF_BWD_XS_ZMU") && atoi(getenv("MF_BWD_XS_ZMU")) == 0;
     const bool xs_only = p->gXs && !p->gXds && !p->gRs && !p->gOmegas && !p->gFs && !p->gFf;
-    if (!xs_off && xs_only && m.PPL == 1 && m.G <= 64 && (long long)d->B * m.G >= device_simds() * 64) {
+    static const long long xs_min_waves = getenv("MF_BWD_XS_MIN_WAVES") ? atoll(getenv("MF_BWD_XS_MIN_WAVES")) : device_simds();      // (A/B: lower it to run them on fewer rollouts)
+    if (!xs_off && xs_only && m.PPL == 1 && m.G <= 64 && (long long)d->B * m.G >= xs_min_waves * 64) {
       RolloutBwdArgs<float> ax = af;
       bool zmu = false;
       if (!xs_zmu_off && d->map_shared && p->mu && (p->zmu || p->zmu_scratch) && (long long)d->H * d->W * 8 < (1ll << 31)) {
@@ -149,6 +150,13 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
           ax.zmu = (const float*)p->zmu_scratch;
         }
         zmu = true;
+      }
+      // ... and, four lanes per rollout on ONE shared map pair: the accumulators' writes go to a 128 x 128-cell LDS window per workgroup
+      // (rollout_bwd_kernel.h WIN; 128 KB of LDS = one workgroup per CU: 256 threads at one wave per SIMD, 512 from two up).  MF_BWD_WIN=0: A/B.
+      static const bool win_off = getenv("MF_BWD_WIN") && atoi(getenv("MF_BWD_WIN")) == 0;
+      if (!win_off && d->map_shared && m.G == 4 && d->H == d->W && (d->H & (d->H - 1)) == 0) {      // (power-of-two side: cell -> window row / column by shift and mask)
+        const long long waves = ((long long)d->B * m.G + 63) / 64;
+        return launch_rollout_bwd_xs_win_fast_f32(ax, m, d->integrator, waves >= 2ll * device_simds() ? 512 : 256, zmu, st);
       }
       return launch_rollout_bwd_xs_fast_f32(ax, m, d->integrator, block, zmu, st);
     }

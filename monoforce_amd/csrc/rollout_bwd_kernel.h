@@ -51,6 +51,11 @@ __device__ __forceinline__ void atomic_add(float* p, float v) { unsafeAtomicAdd(
 #endif
 __device__ __forceinline__ void atomic_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 
+// LDS float add without return (ds_add_f32); `p` must point into __shared__ memory
+__device__ __forceinline__ void lds_add(float* p, float v) {
+  __builtin_amdgcn_ds_faddf((__attribute__((address_space(3))) float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP, false);
+}
+__device__ __forceinline__ void lds_add(double* p, double v) { unsafeAtomicAdd(p, v); }
 template <typename S>
 __device__ __forceinline__ bool inside(S v, S lo, S hi) { return v >= lo && v <= hi; }
 template <typename S>
@@ -70,8 +75,17 @@ __device__ __forceinline__ S* at32(S* base, unsigned elem) {
 // two 16-byte loads per footprint instead of eight 4-byte ones (gather4x2, rollout_fwd_kernel.h).  Both serve the saturated launches of
 // <= 4-point bodies (B > 8192), which PMC shows bound by the CU's L1 address path, not by VALU issue
 // (profiles/r5_pmc_backward_B16384.txt): the distinct addresses per wave-step drop from ~1060 to ~650.
-template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS = false, bool CARRY = true, bool XS_ONLY = false, bool ZMU = false>
-__global__ void __launch_bounds__(G > 256 ? G : 256) rollout_bwd_kernel(const RolloutBwdArgs<S> a) {
+// WIN (round 5, saturated launches of a shared map pair): what the register accumulators write when a point changes cell goes to a
+// kWinW x kWinW-cell window of both gradient maps in LDS instead of out as device-scope float atomics -- those execute at the memory
+// side and sit in the in-order vmcnt queue in front of the next step's row loads (a 64-lane wave flushes somebody's cells on nearly
+// every step): with the atomics compiled out the backward of 32 768 rollouts takes 1.33 ms instead of 2.57 (profiles/r5_ab_bwd_win.txt).
+// ds_add_f32 costs ~12 cycles per ACTIVE lane (tools/microbench/lds_atomics.hip: 768 cycles for a full wave, whatever the addresses;
+// ds_add_u32 / _u64: ~30) -- affordable for the ~50 cell changes per wave-step, not for eight adds per lane and step (measured: no gain),
+// so the accumulators and their carry-over stay.  The window is centred on the start of the workgroup's first rollout; a cell outside
+// it takes the global atomic as before.  One pass at the end adds the non-zero window cells to gradient copy blockIdx % grad_copies.
+constexpr int kWinW = 128;
+template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS, bool CARRY, bool XS_ONLY, bool ZMU, bool WIN>
+__device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* win, const unsigned win_flat0, const unsigned win_shift) {
   using M = Mth<S, FAST>;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = tid / G;
@@ -237,23 +251,30 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_bwd_kernel(const Ro
 #pragma unroll
     for (int q = 0; q < 4; ++q) { acc_idx[j][q] = st_idx[j][q] = 0u; acc_z[j][q] = acc_m[j][q] = st_z[j][q] = st_m[j][q] = zero; }
   }
+  // one cell's accumulated pair goes out: WIN -- into the workgroup's LDS window when the cell lies inside it (flat index -> window
+  // row / column by shift and mask: the host takes this kernel for power-of-two H only), else (and without WIN) device-scope atomics
+  auto emit = [&](unsigned idx, S vz, S vm) {
+    if constexpr (WIN) {
+      const unsigned d = idx - win_flat0, rx = d >> win_shift, ry = d & (unsigned)(a.H - 1);
+      if ((rx < (unsigned)kWinW) & (ry < (unsigned)kWinW)) {
+        S* wz = win + (rx * kWinW + ry);
+        lds_add(wz, vz);
+        if (want_gmu) lds_add(wz + kWinW * kWinW, vm);
+        return;
+      }
+    }
+    atomic_add(at32(gzmap, goff + idx), vz);
+    if (want_gmu) atomic_add(at32(gmumap, goff + idx), vm);
+  };
   auto flush_stash = [&]() {
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
       if (st_pending[j]) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) atomic_add(at32(gzmap, goff + st_idx[j][q]), st_z[j][q]);
-        if (want_gmu) {
-#pragma unroll
-          for (int q = 0; q < 2; ++q) atomic_add(at32(gmumap, goff + st_idx[j][q]), st_m[j][q]);
-        }
+        for (int q = 0; q < 2; ++q) emit(st_idx[j][q], st_z[j][q], st_m[j][q]);
         if (st_all[j]) {
 #pragma unroll
-          for (int q = 2; q < 4; ++q) atomic_add(at32(gzmap, goff + st_idx[j][q]), st_z[j][q]);
-          if (want_gmu) {
-#pragma unroll
-            for (int q = 2; q < 4; ++q) atomic_add(at32(gmumap, goff + st_idx[j][q]), st_m[j][q]);
-          }
+          for (int q = 2; q < 4; ++q) emit(st_idx[j][q], st_z[j][q], st_m[j][q]);
         }
       }
       st_pending[j] = st_all[j] = false;
@@ -713,11 +734,7 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_bwd_kernel(const Ro
   for (int j = 0; j < PPL; ++j) {          // what is still accumulated in registers
     if (act[j]) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) atomic_add(at32(gzmap, goff + acc_idx[j][q]), acc_z[j][q]);
-      if (want_gmu) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) atomic_add(at32(gmumap, goff + acc_idx[j][q]), acc_m[j][q]);
-      }
+      for (int q = 0; q < 4; ++q) emit(acc_idx[j][q], acc_z[j][q], acc_m[j][q]);
     }
   }
 
@@ -773,6 +790,43 @@ __global__ void __launch_bounds__(G > 256 ? G : 256) rollout_bwd_kernel(const Ro
   }
 }
 
+template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS = false, bool CARRY = true, bool XS_ONLY = false, bool ZMU = false, bool WIN = false>
+__global__ void __launch_bounds__(WIN ? 512 : (G > 256 ? G : 256)) rollout_bwd_kernel(const RolloutBwdArgs<S> a) {
+  if constexpr (WIN) {
+    static_assert(G <= 64 && sizeof(S) == 4, "the LDS gradient window serves float32 rollouts inside a wave");
+    __shared__ S win[2 * kWinW * kWinW];
+    // window origin: centred on the start of the workgroup's first rollout, inside the map (workgroup-uniform)
+    const int b0 = min((int)((blockIdx.x * blockDim.x) / G), a.B - 1);
+    const int cx = (int)mf_clamp(Mth<S, FAST>::cell_coord(a.x_init[b0 * 3 + 0], a.d_max, a.res, a.inv_res), (S)-262144.0, (S)262144.0);
+    const int cy = (int)mf_clamp(Mth<S, FAST>::cell_coord(a.x_init[b0 * 3 + 1], a.d_max, a.res, a.inv_res), (S)-262144.0, (S)262144.0);
+    const int wx0 = __builtin_amdgcn_readfirstlane(max(min(cx - kWinW / 2, a.H - kWinW), 0));
+    const int wy0 = __builtin_amdgcn_readfirstlane(max(min(cy - kWinW / 2, a.H - kWinW), 0));
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    for (int i = threadIdx.x; i < 2 * kWinW * kWinW / 4; i += blockDim.x) reinterpret_cast<f4*>(win)[i] = f4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    const unsigned sh = 31u - (unsigned)__builtin_clz((unsigned)a.H);      // H = 2^sh (host-checked)
+    rollout_bwd_body<S, G, PPL, INTEG, FAST, JOINTS, CARRY, XS_ONLY, ZMU, true>(a, win, (unsigned)wy0 + ((unsigned)wx0 << sh), sh);
+    __syncthreads();
+    const unsigned HW = (unsigned)a.H * (unsigned)a.W;
+    const unsigned coff = (a.map_shared ? (unsigned)(blockIdx.x % a.grad_copies) : 0u) * HW;
+    const bool want_gmu = a.gmu != nullptr && a.mu != nullptr;
+    for (int i = threadIdx.x; i < kWinW * kWinW; i += blockDim.x) {
+      const int ix = wx0 + i / kWinW, iy = wy0 + i % kWinW;
+      if (ix < a.H && iy < a.H) {
+        const unsigned cell = (unsigned)iy + (unsigned)a.H * (unsigned)ix;
+        const S vz = win[i];
+        if (vz != (S)0) atomic_add(at32(a.gz, coff + cell), vz);
+        if (want_gmu) {
+          const S vm = win[kWinW * kWinW + i];
+          if (vm != (S)0) atomic_add(at32(a.gmu, coff + cell), vm);
+        }
+      }
+    }
+  } else {
+    rollout_bwd_body<S, G, PPL, INTEG, FAST, JOINTS, CARRY, XS_ONLY, ZMU, false>(a, nullptr, 0, 0);
+  }
+}
+
 template <typename S, bool FAST, bool JOINTS = false, bool CARRY = true>
 int launch_rollout_bwd(const RolloutBwdArgs<S>& a, LaneMap m, int integ, int block, hipStream_t st) {
   if (m.G > 64) block = m.G;   // a rollout spread over several waves: exactly one rollout per workgroup (LDS + barrier)
@@ -801,20 +855,21 @@ int launch_rollout_bwd(const RolloutBwdArgs<S>& a, LaneMap m, int integ, int blo
 
 // the positions-only (XS_ONLY) instantiations with accumulator carry-over, one point per lane inside a wave (G = 4 .. 64), plain or
 // interleaved maps: the saturated launches of small bodies (rollout_bwd_xs_fast.hip)
-template <typename S, bool ZMU>
+template <typename S, bool ZMU, bool WIN = false>
 int launch_rollout_bwd_xs(const RolloutBwdArgs<S>& a, LaneMap m, int integ, int block, hipStream_t st) {
   const long long threads = (long long)a.B * m.G;
   const unsigned grid = (unsigned)((threads + block - 1) / block);
   bool launched = false;
-#define MF_CASE(G_)                                                                                                                       \
-  if (!launched && m.G == G_ && m.PPL == 1) {                                                                                              \
-    launched = true;                                                                                                                       \
-    if (integ == MF_INTEG_DYNAMICS)                                                                                                        \
-      MF_KLAUNCH((rollout_bwd_kernel<S, G_, 1, MF_INTEG_DYNAMICS, true, false, true, true, ZMU>), dim3(grid), dim3(block), 0, st, a);      \
-    else                                                                                                                                   \
-      MF_KLAUNCH((rollout_bwd_kernel<S, G_, 1, MF_INTEG_ODEINT_EULER, true, false, true, true, ZMU>), dim3(grid), dim3(block), 0, st, a);  \
+#define MF_CASE(G_)                                                                                                                            \
+  if (!launched && m.G == G_ && m.PPL == 1) {                                                                                                   \
+    launched = true;                                                                                                                            \
+    if (integ == MF_INTEG_DYNAMICS)                                                                                                             \
+      MF_KLAUNCH((rollout_bwd_kernel<S, G_, 1, MF_INTEG_DYNAMICS, true, false, true, true, ZMU, WIN>), dim3(grid), dim3(block), 0, st, a);      \
+    else                                                                                                                                        \
+      MF_KLAUNCH((rollout_bwd_kernel<S, G_, 1, MF_INTEG_ODEINT_EULER, true, false, true, true, ZMU, WIN>), dim3(grid), dim3(block), 0, st, a);  \
   }
-  MF_CASE(4) MF_CASE(8) MF_CASE(16) MF_CASE(32) MF_CASE(64)
+  MF_CASE(4)
+  if constexpr (!WIN) { MF_CASE(8) MF_CASE(16) MF_CASE(32) MF_CASE(64) }
 #undef MF_CASE
   MF_REQUIRE(launched, MF_ERR_UNSUPPORTED, "rollout_bwd: no positions-only kernel for this lane mapping");
   hipError_t e = hipGetLastError();
@@ -822,6 +877,7 @@ int launch_rollout_bwd_xs(const RolloutBwdArgs<S>& a, LaneMap m, int integ, int 
   return MF_OK;
 }
 int launch_rollout_bwd_xs_fast_f32(const RolloutBwdArgs<float>& a, LaneMap m, int integ, int block, bool zmu, hipStream_t st);      // rollout_bwd_xs_fast.hip
+int launch_rollout_bwd_xs_win_fast_f32(const RolloutBwdArgs<float>& a, LaneMap m, int integ, int block, bool zmu, hipStream_t st);  // rollout_bwd_xs_win_fast.hip
 
 // defined in rollout_bwd_fast.hip (plain flush) and rollout_bwd_carry_fast.hip (accumulator carry-over)
 int launch_rollout_bwd_fast_f32(const RolloutBwdArgs<float>& a, LaneMap m, int integ, int block, hipStream_t st);

@@ -196,12 +196,17 @@ def test_large_batch_shared_map_backward_vs_oracle(B, ppl, integ):
 
 @pytest.mark.parametrize('integ', [1, 0])
 @pytest.mark.parametrize('friction', [True, False])
-def test_saturated_positions_only_backward_vs_oracle(integ, friction):
+@pytest.mark.parametrize('scattered', [False, True])
+def test_saturated_positions_only_backward_vs_oracle(integ, friction, scattered):
     """B = 16 384 rollouts of the 4-point body (one wave of sixteen rollouts on every SIMD), loss on the positions only: the XS_ONLY
-    instantiations of the general backward (round 5), reading the shared pair interleaved when there is a friction map (ZMU) --
-    against the float64 ORACLE on the 32 rollouts the loss touches, at the bar derived from the oracle alone."""
+    instantiations of the general backward (round 5), reading the shared pair interleaved when there is a friction map (ZMU), cell
+    gradients through the workgroup's 128 x 128-cell LDS window (WIN; MF_BWD_WIN=0: register accumulators + atomics) -- against the
+    float64 ORACLE on the 32 rollouts the loss touches, at the bar derived from the oracle alone.  `scattered`: given start poses all
+    over the map, so that most rollouts of a workgroup lie OUTSIDE its window (centred on its first rollout) and take the atomics."""
+    import os
     from monoforce_amd import synthetic as syn, _timing
     B, T, sub = 16384, 60, 32
+    win = os.environ.get('MF_BWD_WIN', '1') != '0'
     pts, masks = syn.robot_points_4()
     z = syn.bump_terrain(syn.bump_params(5), 6.4, 0.05)
     mu = syn.wave_friction(6.4, 0.05) if friction else None
@@ -211,23 +216,35 @@ def test_saturated_positions_only_backward_vs_oracle(integ, friction):
     wts = syn.probe_weights((sub, T, 3), phase=0.3)
     dp = make_dphysics(pts, masks, integ, 0.05, 6.4)
     dp.dphys_cfg.traj_sim_time = 5.0
+    state = None
+    if scattered:
+        g = torch.Generator().manual_seed(11)
+        x0 = torch.zeros(B, 3); x0[:, :2] = (torch.rand(B, 2, generator=g) - 0.5) * 12.6      # up to the map's edge (+-6.3 of +-6.4 m) and past the window
+        yaw = torch.rand(B, generator=g) * 6.2831853
+        R0 = torch.zeros(B, 3, 3); R0[:, 0, 0] = yaw.cos(); R0[:, 0, 1] = -yaw.sin(); R0[:, 1, 0] = yaw.sin(); R0[:, 1, 1] = yaw.cos(); R0[:, 2, 2] = 1.0
+        xd0 = torch.zeros(B, 3); xd0[:, 0] = ctrl[:, 0, 0] * yaw.cos(); xd0[:, 1] = ctrl[:, 0, 0] * yaw.sin()
+        w0 = torch.zeros(B, 3); w0[:, 2] = ctrl[:, 0, 1]
+        state = (x0, xd0, R0, w0)
     zd = z.to(DEV).requires_grad_(True)
     md = mu.to(DEV).requires_grad_(True) if friction else None
     cd = ctrl.to(DEV).requires_grad_(True)
     _timing.start()
-    (Xs, Xds, Rs, Om), _ = dp(zd.unsqueeze(0), cd, friction=md.unsqueeze(0) if friction else None)
+    (Xs, Xds, Rs, Om), _ = dp(zd.unsqueeze(0), cd, friction=md.unsqueeze(0) if friction else None,
+                              state=tuple(t.clone().to(DEV) for t in state) if scattered else None)
     (Xs[sel.to(DEV)] * wts.to(DEV)).sum().backward()
     ran = _timing.launches()
     _timing.stop()
     name = ran['rollout_bwd_kernel']
-    # rollout_bwd_kernel<float, 4, 1, INTEG, FAST, JOINTS, CARRY, XS_ONLY, ZMU>
-    assert 'rollout_bwd_kernel<float, 4, 1, %d, true, false, true, true, %s>' % (integ, 'true' if friction else 'false') in name, name
+    # rollout_bwd_kernel<float, 4, 1, INTEG, FAST, JOINTS, CARRY, XS_ONLY, ZMU, WIN>
+    assert 'rollout_bwd_kernel<float, 4, 1, %d, true, false, true, true, %s, %s>' % (integ, 'true' if friction else 'false', 'true' if win else 'false') in name, name
 
     def oracle_grads(dtype):
         zc = z.to(dtype).requires_grad_(True)
         mc = mu.to(dtype).requires_grad_(True) if friction else None
         cc = ctrl[sel].to(dtype).requires_grad_(True)
-        (rX, _, _, _), _ = orc.rollout(spec, zc.unsqueeze(0).expand(sub, -1, -1), cc, friction=mc.unsqueeze(0).expand(sub, -1, -1) if friction else None)
+        st = tuple(t[sel].clone().to(dtype) for t in state) if scattered else None
+        (rX, _, _, _), _ = orc.rollout(spec, zc.unsqueeze(0).expand(sub, -1, -1), cc, state=st,
+                                       friction=mc.unsqueeze(0).expand(sub, -1, -1) if friction else None)
         (rX * wts.to(dtype)).sum().backward()
         return (zc.grad, mc.grad, cc.grad) if friction else (zc.grad, cc.grad)
     ref, env = oracle_grads(torch.float64), oracle_grads(torch.float32)
@@ -237,6 +254,19 @@ def test_saturated_positions_only_backward_vs_oracle(integ, friction):
         assert hp.rel_err(g_, r64) <= bar, (nm, hp.rel_err(g_, r64), 'bar', bar)
     rest = torch.ones(B, dtype=torch.bool); rest[sel] = False
     assert float(cd.grad[rest.to(DEV)].abs().max()) == 0.0
+
+
+def test_saturated_backward_without_the_lds_window_vs_oracle():
+    """The same cases on the register-accumulator kernels (MF_BWD_WIN=0 is read once per process: a child runs them)."""
+    import os, subprocess, sys
+    if os.environ.get('MF_BWD_WIN') == '0':
+        pytest.skip('this IS the child')
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(repo, 'tests', 'test_parity_net_gpu.py'), '-x', '-q', '-m', 'gpu', '-k',
+                        'test_saturated_positions_only_backward_vs_oracle'], env=dict(os.environ, MF_BWD_WIN='0'), capture_output=True, text=True,
+                       timeout=1200, cwd=repo)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert '8 passed' in r.stdout, r.stdout[-500:]
 
 
 def test_config4_full_size_step_vs_oracles():
