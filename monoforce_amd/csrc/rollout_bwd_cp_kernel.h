@@ -55,9 +55,12 @@ extern __device__ unsigned long long mf_stream_prof[16];
 #else
 #define MF_STREAM_WPE __attribute__((amdgpu_waves_per_eu((MODE == kCpStream && XS_ONLY && sizeof(S) == 4) ? 2 : 1)))
 #endif
-template <typename S, int INTEG, bool XS_ONLY, bool GCTRL, int MODE, int SLOTS = 6, int BATCH = 3, bool ZMU = false>
+// WIN (round 5; early recompute from two waves per SIMD up): the accumulators' cell writes go to the workgroup's LDS window
+// (rollout_bwd_kernel.h: win_open / win_emit / win_close) -- the host launches it only when every lane of every workgroup owns a rollout
+// (no early exit in front of the barriers) on power-of-two maps.
+template <typename S, int INTEG, bool XS_ONLY, bool GCTRL, int MODE, int SLOTS = 6, int BATCH = 3, bool ZMU = false, bool WIN = false>
 // (streaming, positions-only loss: at most 256 registers, so that two workgroups -- six waves -- share a CU's four SIMDs)
-__global__ void __launch_bounds__(MODE == kCpStream ? 192 : 256) MF_STREAM_WPE
+__global__ void __launch_bounds__(MODE == kCpStream ? 192 : (WIN ? 512 : 256)) MF_STREAM_WPE
 rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
   constexpr bool ODE = INTEG == MF_INTEG_ODEINT_EULER;
   constexpr bool LATE = MODE == kCpLate, STREAM = MODE == kCpStream, SAVED = MODE == kCpSaved || STREAM;
@@ -68,7 +71,17 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
   const int lane = threadIdx.x & 63;
   const int tid = STREAM ? blockIdx.x * 64 + lane : blockIdx.x * blockDim.x + threadIdx.x;
   const int b = tid >> 4;
-  if (b >= a.B) return;
+  __shared__ S win[WIN ? 2 * kWinW * kWinW : 1];
+  int wx0 = 0, wy0 = 0;
+  unsigned win_flat0 = 0u, win_shift = 0u;
+  if constexpr (WIN) {
+    static_assert(MODE != kCpStream && sizeof(S) == 4, "the LDS gradient window serves the float32 one-wave forms");
+    win_open<S, true>(a, win, (int)((blockIdx.x * blockDim.x) >> 4), &wx0, &wy0);
+    __syncthreads();
+    win_shift = 31u - (unsigned)__builtin_clz((unsigned)a.H);
+    win_flat0 = (unsigned)wy0 + ((unsigned)wx0 << win_shift);
+  }
+  if (b >= a.B) return;      // (WIN: never taken -- host-checked)
   const int p = (tid >> 2) & 3, q = tid & 3, cc = q < 3 ? q : 2;
   const S one = S(1.0), zero = S(0.0);
   const int HW = a.H * a.W, last = HW - 1;
@@ -194,11 +207,15 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
   unsigned acc_idx = 0u, st_idx = 0u;
   S acc_z = zero, acc_m = zero, st_z = zero, st_m = zero;
   bool st_pending = false;
-  auto flush_stash = [&]() {
-    if (st_pending) {
-      atomic_add(at32(gzmap, goff + st_idx), st_z);
-      if (want_gmu) atomic_add(at32(gmumap, goff + st_idx), st_m);
+  auto emit = [&](unsigned idx, S vz, S vm) {
+    if constexpr (WIN) {
+      if (win_emit(win, win_flat0, win_shift, (unsigned)(a.H - 1), idx, vz, vm, want_gmu)) return;
     }
+    atomic_add(at32(gzmap, goff + idx), vz);
+    if (want_gmu) atomic_add(at32(gmumap, goff + idx), vm);
+  };
+  auto flush_stash = [&]() {
+    if (st_pending) emit(st_idx, st_z, st_m);
     st_pending = false;
   };
 
@@ -1117,10 +1134,7 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
   UpIn up = (n_steps & 1) ? uB : uA;
   flush_stash();
   if constexpr (GCTRL) bstore2(rGctrl, v_ctrl, gctrl_pending, gv_pending, gwc_pending);
-  if (act) {                               // what is still accumulated in registers
-    atomic_add(at32(gzmap, goff + acc_idx), acc_z);
-    if (want_gmu) atomic_add(at32(gmumap, goff + acc_idx), acc_m);
-  }
+  if (act) emit(acc_idx, acc_z, acc_m);      // what is still accumulated in registers
   if constexpr (ODE) {                         // output 0 is the initial state itself (its forces are constant zeros)
     if (n_steps == 0) load_upstream(0, up);    // T == 1: the loop never ran
     add_upstream_state(up);
@@ -1155,6 +1169,10 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
     a.gxd0[b * 3 + cc] = lxd;
     a.gw0[b * 3 + cc] = lw;
     a.gR0[b * 9 + cc * 3 + 0] = lR0; a.gR0[b * 9 + cc * 3 + 1] = lR1; a.gR0[b * 9 + cc * 3 + 2] = lR2;
+  }
+  if constexpr (WIN) {
+    __syncthreads();
+    win_close(a, win, wx0, wy0);
   }
 }
 
@@ -1207,11 +1225,19 @@ int launch_rollout_bwd_cp_variant(const RolloutBwdArgs<S>& a, bool xs_only, hipS
 #define MF_BCP(XS_, GC_, M_) MF_KLAUNCH((rollout_bwd_cp_kernel<S, INTEG, XS_, GC_, M_>), dim3(wgs), dim3(block), 0, st, a)
   // (the record-reading mode on the interleaved maps the host staged: cp_bwd_wants_zmu)
   constexpr bool kZmu = std::is_same<S, float>::value && INTEG == MF_INTEG_ODEINT_EULER;
+  // (measured and dropped, round 5: the LDS gradient window in this record-reading form -- 3072 / 4096 rollouts: 0.382 / 0.406 ms with or without)
 #define MF_BCP_Z(XS_, GC_) do { if constexpr (kZmu) { if (a.zmu) { MF_KLAUNCH((rollout_bwd_cp_kernel<S, INTEG, XS_, GC_, kCpSaved, 6, 3, kZmu>), dim3(wgs), dim3(block), 0, st, a); break; } } MF_BCP(XS_, GC_, kCpSaved); } while (0)
-#define MF_BCP_L(XS_, GC_) do { if (mode == kCpStream) launch_rollout_bwd_cp_stream_any(a, INTEG, xs_only, grid, st); else if (mode == kCpSaved) MF_BCP_Z(XS_, GC_); else if (mode == kCpLate) MF_BCP(XS_, GC_, kCpLate); else MF_BCP(XS_, GC_, kCpEarly); } while (0)
+  // early recompute beyond one wave per SIMD on ONE shared power-of-two map pair: the cell writes through an LDS window per workgroup of
+  // eight waves (one workgroup per CU: 128 KB); every workgroup must be full (no early exit in front of its barriers).  MF_BWD_WIN=0: A/B.
+  static const bool win_off = getenv("MF_BWD_WIN") && atoi(getenv("MF_BWD_WIN")) == 0;
+  constexpr bool kWin = std::is_same<S, float>::value;
+  const bool win = kWin && !win_off && mode == kCpEarly && a.map_shared && a.H == a.W && (a.H & (a.H - 1)) == 0 && threads % 512 == 0;
+#define MF_BCP_W(XS_, GC_) do { if constexpr (kWin) { if (win) { MF_KLAUNCH((rollout_bwd_cp_kernel<S, INTEG, XS_, GC_, kCpEarly, 6, 3, false, kWin>), dim3((unsigned)(threads / 512)), dim3(512), 0, st, a); break; } } MF_BCP(XS_, GC_, kCpEarly); } while (0)
+#define MF_BCP_L(XS_, GC_) do { if (mode == kCpStream) launch_rollout_bwd_cp_stream_any(a, INTEG, xs_only, grid, st); else if (mode == kCpSaved) MF_BCP_Z(XS_, GC_); else if (mode == kCpLate) MF_BCP(XS_, GC_, kCpLate); else MF_BCP_W(XS_, GC_); } while (0)
   if (xs_only) { if (gc) MF_BCP_L(true, true); else MF_BCP_L(true, false); }
   else         { if (gc) MF_BCP_L(false, true); else MF_BCP_L(false, false); }
 #undef MF_BCP_L
+#undef MF_BCP_W
 #undef MF_BCP_Z
 #undef MF_BCP
   hipError_t e = hipGetLastError();

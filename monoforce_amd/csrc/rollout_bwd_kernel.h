@@ -84,6 +84,49 @@ __device__ __forceinline__ S* at32(S* base, unsigned elem) {
 // so the accumulators and their carry-over stay.  The window is centred on the start of the workgroup's first rollout; a cell outside
 // it takes the global atomic as before.  One pass at the end adds the non-zero window cells to gradient copy blockIdx % grad_copies.
 constexpr int kWinW = 128;
+// (workgroup-uniform) origin of the window: centred on the start of the workgroup's first rollout `b0`, inside the map; zero-fills the
+// window; a barrier follows in the caller
+template <typename S, bool FAST>
+__device__ __forceinline__ void win_open(const RolloutBwdArgs<S>& a, S* win, int b0, int* wx0, int* wy0) {
+  b0 = min(b0, a.B - 1);
+  const int cx = (int)mf_clamp(Mth<S, FAST>::cell_coord(a.x_init[b0 * 3 + 0], a.d_max, a.res, a.inv_res), (S)-262144.0, (S)262144.0);
+  const int cy = (int)mf_clamp(Mth<S, FAST>::cell_coord(a.x_init[b0 * 3 + 1], a.d_max, a.res, a.inv_res), (S)-262144.0, (S)262144.0);
+  *wx0 = __builtin_amdgcn_readfirstlane(max(min(cx - kWinW / 2, a.H - kWinW), 0));
+  *wy0 = __builtin_amdgcn_readfirstlane(max(min(cy - kWinW / 2, a.H - kWinW), 0));
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  for (int i = threadIdx.x; i < 2 * kWinW * kWinW / 4; i += blockDim.x) reinterpret_cast<f4*>(win)[i] = f4{0.f, 0.f, 0.f, 0.f};
+}
+// one cell's pair into the window if the cell (flat map index `idx`, H = 2^shift) lies inside it; false: the caller takes the atomics
+template <typename S>
+__device__ __forceinline__ bool win_emit(S* win, unsigned win_flat0, unsigned win_shift, unsigned h_mask, unsigned idx, S vz, S vm, bool want_gmu) {
+  const unsigned d = idx - win_flat0, rx = d >> win_shift, ry = d & h_mask;
+  if ((rx < (unsigned)kWinW) & (ry < (unsigned)kWinW)) {
+    S* wz = win + (rx * kWinW + ry);
+    lds_add(wz, vz);
+    if (want_gmu) lds_add(wz + kWinW * kWinW, vm);
+    return true;
+  }
+  return false;
+}
+// after the workgroup's last emit and a barrier: the non-zero window cells to gradient copy blockIdx % grad_copies, coalesced
+template <typename S>
+__device__ __forceinline__ void win_close(const RolloutBwdArgs<S>& a, const S* win, int wx0, int wy0) {
+  const unsigned HW = (unsigned)a.H * (unsigned)a.W;
+  const unsigned coff = (a.map_shared ? (unsigned)(blockIdx.x % a.grad_copies) : 0u) * HW;
+  const bool want_gmu = a.gmu != nullptr && a.mu != nullptr;
+  for (int i = threadIdx.x; i < kWinW * kWinW; i += blockDim.x) {
+    const int ix = wx0 + i / kWinW, iy = wy0 + i % kWinW;
+    if (ix < a.H && iy < a.H) {
+      const unsigned cell = (unsigned)iy + (unsigned)a.H * (unsigned)ix;
+      const S vz = win[i];
+      if (vz != (S)0) atomic_add(at32(a.gz, coff + cell), vz);
+      if (want_gmu) {
+        const S vm = win[kWinW * kWinW + i];
+        if (vm != (S)0) atomic_add(at32(a.gmu, coff + cell), vm);
+      }
+    }
+  }
+}
 template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS, bool CARRY, bool XS_ONLY, bool ZMU, bool WIN>
 __device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* win, const unsigned win_flat0, const unsigned win_shift) {
   using M = Mth<S, FAST>;
@@ -255,13 +298,7 @@ __device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* 
   // row / column by shift and mask: the host takes this kernel for power-of-two H only), else (and without WIN) device-scope atomics
   auto emit = [&](unsigned idx, S vz, S vm) {
     if constexpr (WIN) {
-      const unsigned d = idx - win_flat0, rx = d >> win_shift, ry = d & (unsigned)(a.H - 1);
-      if ((rx < (unsigned)kWinW) & (ry < (unsigned)kWinW)) {
-        S* wz = win + (rx * kWinW + ry);
-        lds_add(wz, vz);
-        if (want_gmu) lds_add(wz + kWinW * kWinW, vm);
-        return;
-      }
+      if (win_emit(win, win_flat0, win_shift, (unsigned)(a.H - 1), idx, vz, vm, want_gmu)) return;
     }
     atomic_add(at32(gzmap, goff + idx), vz);
     if (want_gmu) atomic_add(at32(gmumap, goff + idx), vm);
@@ -795,33 +832,13 @@ __global__ void __launch_bounds__(WIN ? 512 : (G > 256 ? G : 256)) rollout_bwd_k
   if constexpr (WIN) {
     static_assert(G <= 64 && sizeof(S) == 4, "the LDS gradient window serves float32 rollouts inside a wave");
     __shared__ S win[2 * kWinW * kWinW];
-    // window origin: centred on the start of the workgroup's first rollout, inside the map (workgroup-uniform)
-    const int b0 = min((int)((blockIdx.x * blockDim.x) / G), a.B - 1);
-    const int cx = (int)mf_clamp(Mth<S, FAST>::cell_coord(a.x_init[b0 * 3 + 0], a.d_max, a.res, a.inv_res), (S)-262144.0, (S)262144.0);
-    const int cy = (int)mf_clamp(Mth<S, FAST>::cell_coord(a.x_init[b0 * 3 + 1], a.d_max, a.res, a.inv_res), (S)-262144.0, (S)262144.0);
-    const int wx0 = __builtin_amdgcn_readfirstlane(max(min(cx - kWinW / 2, a.H - kWinW), 0));
-    const int wy0 = __builtin_amdgcn_readfirstlane(max(min(cy - kWinW / 2, a.H - kWinW), 0));
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    for (int i = threadIdx.x; i < 2 * kWinW * kWinW / 4; i += blockDim.x) reinterpret_cast<f4*>(win)[i] = f4{0.f, 0.f, 0.f, 0.f};
+    int wx0, wy0;
+    win_open<S, FAST>(a, win, (int)((blockIdx.x * blockDim.x) / G), &wx0, &wy0);
     __syncthreads();
     const unsigned sh = 31u - (unsigned)__builtin_clz((unsigned)a.H);      // H = 2^sh (host-checked)
     rollout_bwd_body<S, G, PPL, INTEG, FAST, JOINTS, CARRY, XS_ONLY, ZMU, true>(a, win, (unsigned)wy0 + ((unsigned)wx0 << sh), sh);
     __syncthreads();
-    const unsigned HW = (unsigned)a.H * (unsigned)a.W;
-    const unsigned coff = (a.map_shared ? (unsigned)(blockIdx.x % a.grad_copies) : 0u) * HW;
-    const bool want_gmu = a.gmu != nullptr && a.mu != nullptr;
-    for (int i = threadIdx.x; i < kWinW * kWinW; i += blockDim.x) {
-      const int ix = wx0 + i / kWinW, iy = wy0 + i % kWinW;
-      if (ix < a.H && iy < a.H) {
-        const unsigned cell = (unsigned)iy + (unsigned)a.H * (unsigned)ix;
-        const S vz = win[i];
-        if (vz != (S)0) atomic_add(at32(a.gz, coff + cell), vz);
-        if (want_gmu) {
-          const S vm = win[kWinW * kWinW + i];
-          if (vm != (S)0) atomic_add(at32(a.gmu, coff + cell), vm);
-        }
-      }
-    }
+    win_close(a, win, wx0, wy0);
   } else {
     rollout_bwd_body<S, G, PPL, INTEG, FAST, JOINTS, CARRY, XS_ONLY, ZMU, false>(a, nullptr, 0, 0);
   }

@@ -14,7 +14,7 @@ sys.path.insert(0, os.path.join(REPO, 'tools'))
 
 DEFAULT_PATH_OBJECTS = {
     'rollout_fwd_cp_fast.o', 'rollout_bwd_cp_fast.o', 'rollout_bwd_cp_stream_fast.o', 'rollout_bwd_dyn_cp_fast.o', 'rollout_bwd_dyn_cp_stream_fast.o',
-    'rollout_fwd_fast.o', 'rollout_fwd_split_fast.o', 'rollout_fwd_zmu_fast.o', 'rollout_fwd_cost.o', 'rollout_bwd_mw_fast.o',
+    'rollout_bwd_xs_fast.o', 'rollout_bwd_xs_win_fast.o', 'rollout_fwd_fast.o', 'rollout_fwd_split_fast.o', 'rollout_fwd_zmu_fast.o', 'rollout_fwd_cost.o', 'rollout_bwd_mw_fast.o',
     'bev_splat.o', 'physics_loss.o', 'terrain_stage.o', 'heightmap.o', 'interp_grid_fast.o',
 }
 

@@ -197,7 +197,8 @@ def test_large_batch_shared_map_backward_vs_oracle(B, ppl, integ):
 @pytest.mark.parametrize('integ', [1, 0])
 @pytest.mark.parametrize('friction', [True, False])
 @pytest.mark.parametrize('scattered', [False, True])
-def test_saturated_positions_only_backward_vs_oracle(integ, friction, scattered):
+@pytest.mark.parametrize('B', [16384, 8192])
+def test_saturated_positions_only_backward_vs_oracle(integ, friction, scattered, B):
     """B = 16 384 rollouts of the 4-point body (one wave of sixteen rollouts on every SIMD), loss on the positions only: the XS_ONLY
     instantiations of the general backward (round 5), reading the shared pair interleaved when there is a friction map (ZMU), cell
     gradients through the workgroup's 128 x 128-cell LDS window (WIN; MF_BWD_WIN=0: register accumulators + atomics) -- against the
@@ -205,7 +206,7 @@ def test_saturated_positions_only_backward_vs_oracle(integ, friction, scattered)
     over the map, so that most rollouts of a workgroup lie OUTSIDE its window (centred on its first rollout) and take the atomics."""
     import os
     from monoforce_amd import synthetic as syn, _timing
-    B, T, sub = 16384, 60, 32
+    T, sub = 60, 32      # (B = 8192: two waves per SIMD of the component-parallel early-recompute kernel, the same window)
     win = os.environ.get('MF_BWD_WIN', '1') != '0'
     pts, masks = syn.robot_points_4()
     z = syn.bump_terrain(syn.bump_params(5), 6.4, 0.05)
@@ -235,8 +236,10 @@ def test_saturated_positions_only_backward_vs_oracle(integ, friction, scattered)
     ran = _timing.launches()
     _timing.stop()
     name = ran['rollout_bwd_kernel']
-    # rollout_bwd_kernel<float, 4, 1, INTEG, FAST, JOINTS, CARRY, XS_ONLY, ZMU, WIN>
-    assert 'rollout_bwd_kernel<float, 4, 1, %d, true, false, true, true, %s, %s>' % (integ, 'true' if friction else 'false', 'true' if win else 'false') in name, name
+    if B == 16384:      # rollout_bwd_kernel<float, 4, 1, INTEG, FAST, JOINTS, CARRY, XS_ONLY, ZMU, WIN>
+        assert 'rollout_bwd_kernel<float, 4, 1, %d, true, false, true, true, %s, %s>' % (integ, 'true' if friction else 'false', 'true' if win else 'false') in name, name
+    else:               # rollout_bwd_cp_kernel<float, INTEG, XS_ONLY, GCTRL, MODE = early, SLOTS, BATCH, ZMU, WIN>
+        assert 'rollout_bwd_cp_kernel<float, %d, true, true, 0, 6, 3, false%s>' % (integ, ', true' if win else ', false') in name, name
 
     def oracle_grads(dtype):
         zc = z.to(dtype).requires_grad_(True)
@@ -266,7 +269,7 @@ def test_saturated_backward_without_the_lds_window_vs_oracle():
                         'test_saturated_positions_only_backward_vs_oracle'], env=dict(os.environ, MF_BWD_WIN='0'), capture_output=True, text=True,
                        timeout=1200, cwd=repo)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert '8 passed' in r.stdout, r.stdout[-500:]
+    assert '16 passed' in r.stdout, r.stdout[-500:]
 
 
 def test_config4_full_size_step_vs_oracles():
