@@ -344,8 +344,8 @@ int mf_bev_lift_splat_bwd_f64(const MfSplatDesc* desc, const double* depth, cons
 /* ---- fused physics loss (losses.py:102-127) -------------------------------------------------------------------
  * loss = mean_{b,j,c} ((Xs[b, nearest[b,j], c] - Xgt[b,j,c]) * w[b,j])^2,  w = 1 / (1 + gamma * gt_ts[b,j]).
  * Xs is addressed as Xs[b*x_stride_b + t*x_stride_t + c] (elements), so both rollout output layouts work in place.
- * _fwd writes ceil(B*T2/256) per-workgroup partial sums (loss = sum(partial) / (B*T2*3)); _bwd ACCUMULATES d loss/d Xs into gXs (same
- * strides as Xs, zero it first) given the upstream scalar gradient gloss[0]. */
+ * _fwd writes ceil(B*T2/256) per-workgroup partial sums (loss = sum(partial) / (B*T2*3)); _bwd writes d loss/d Xs into a gXs that is ZERO on entry (same
+ * strides as Xs; stamps of one rollout that share a step add up, a step one stamp has to itself is stored) given the upstream scalar gradient gloss[0]. */
 typedef struct MfLossDesc {
   int32_t B, T1, T2;            /* rollouts, predicted steps, ground-truth stamps */
   int32_t reserved;

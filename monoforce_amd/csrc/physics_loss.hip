@@ -50,7 +50,14 @@ __global__ void __launch_bounds__(256) physics_loss_value_kernel(const S* __rest
   __shared__ bool last;
   const int i = blockIdx.x * blockDim.x + threadIdx.x;        // = b * T2 + j
   // the buffer the backward will scatter d loss / d Xs into is cleared here (one launch fewer in front of the rollout backward)
-  for (long long k = i; k < zero_count; k += (long long)gridDim.x * blockDim.x) zero_fill[k] = (S)0;
+  {   // (16-byte stores: the scalar form filled config 3's 98 MB at 16 384 rollouts at 0.6 TB/s -- 0.16 ms in front of a 1 ms backward)
+    const long long head = min(zero_count, (long long)(((16u - (unsigned)((uintptr_t)zero_fill & 15u)) & 15u) / sizeof(S)));
+    const long long n16 = (zero_count - head) * (long long)sizeof(S) / 16, tail0 = head + n16 * (16 / (long long)sizeof(S));
+    int4* z16 = reinterpret_cast<int4*>(zero_fill + head);
+    for (long long k = i; k < n16; k += (long long)gridDim.x * blockDim.x) z16[k] = make_int4(0, 0, 0, 0);
+    if (i < head) zero_fill[i] = (S)0;
+    if (tail0 + i < zero_count) zero_fill[tail0 + i] = (S)0;
+  }
   S acc = (S)0;
   if (i < B * T2) {
     const int b = i / T2;
@@ -101,15 +108,26 @@ __global__ void __launch_bounds__(256) physics_loss_bwd_kernel(const S* __restri
                                                               const S* __restrict__ Xgt, const S* __restrict__ gt_ts,
                                                               const int* __restrict__ nearest, int B, int T2, S gamma,
                                                               const S* __restrict__ gloss, S inv_count, S* __restrict__ gXs) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= B * T2) return;
-  const int b = i / T2;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= B * T2) return;
+  // time-major rows (sb < st): neighbouring threads take neighbouring ROLLOUTS of one stamp -- their Xs / gXs rows are neighbours in
+  // memory when the rollouts share their stamps (the common case); batch-major rows: neighbouring stamps of one rollout
+  const bool jm = sb < st;
+  const int b = jm ? t % B : t / T2, j = jm ? t / B : t % T2;
+  const int i = b * T2 + j;
   const S scale = (S)2 * gloss[0] * inv_count;
   const S w = (S)1 / ((S)1 + gamma * gt_ts[i]);
-  const long long o = b * sb + (long long)nearest[i] * st;
+  const int nr = nearest[i];
+  const long long o = b * sb + (long long)nr * st;
   const S* g = Xgt + (size_t)i * 3;
+  // stamps of a rollout may share a step (then the contributions add up: atomics); a step this stamp has to itself is stored
+  bool shared = false;
+  for (int k = 0; k < T2; ++k) shared |= (k != j) & (nearest[b * T2 + k] == nr);
 #pragma unroll
-  for (int c = 0; c < 3; ++c) atomic_add_s(gXs + o + c, scale * w * (Xs[o + c] * w - g[c] * w));   // stamps may share a step
+  for (int c = 0; c < 3; ++c) {
+    const S v = scale * w * (Xs[o + c] * w - g[c] * w);
+    if (shared) atomic_add_s(gXs + o + c, v); else gXs[o + c] = v;
+  }
 }
 
 template <typename S>
