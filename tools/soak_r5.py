@@ -66,6 +66,7 @@ for seed in range(n_cp):
     loss_of(list(so) + list(fo), torch.float32).backward()
     got = [zl.grad.cpu(), cl.grad.cpu()] + ([ml.grad.cpu()] if ml is not None else [])
     spec = hp.spec_from(pts, masks, info['integ'], info['res'], d_max)
+    spec.robot_size_y = float(pts4[:, 1].max() - pts4[:, 1].min())      # (as the inertia: the HIP side keeps the 4-point body's robot_size; a 1-point body's own y-extent is 0)
     _pi = orc.point_inertia          # (the soak runs the N-point body with the 4-point body's inertia: same for the oracle)
     P4 = torch.as_tensor(pts4, dtype=torch.float32)
     orc.point_inertia = lambda mass, P: _pi(mass, P4.to(P).unsqueeze(0))
@@ -116,7 +117,7 @@ for seed in range(n_mw):
         outs = fn(ex(zl), cl, ex(ml), tuple(st))
         loss = (outs[0][:, ::3] * syn.probe_weights(outs[0][:, ::3].shape, 0.3, dtype=dt).to(dev)).sum() if xs_only else hp.probe_loss(outs, dt)
         loss.backward()
-        return [g.grad.cpu() for g in [zl, cl] + ([ml] if use_mu else []) + st[1:]]
+        return [(torch.zeros_like(g) if g.grad is None else g.grad).cpu() for g in [zl, cl] + ([ml] if use_mu else []) + st[1:]]      # (an input the loss does not reach: autograd leaves None)
     dp = make_dphysics(pts, masks, integ, rs_, d_max)
     spec = hp.spec_from(pts, masks, integ, rs_, d_max)
 
