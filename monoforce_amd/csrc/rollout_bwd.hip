@@ -156,7 +156,8 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
       static const bool win_off = getenv("MF_BWD_WIN") && atoi(getenv("MF_BWD_WIN")) == 0;
       if (!win_off && d->map_shared && m.G == 4 && d->H == d->W && (d->H & (d->H - 1)) == 0) {      // (power-of-two side: cell -> window row / column by shift and mask)
         const long long waves = ((long long)d->B * m.G + 63) / 64;
-        return launch_rollout_bwd_xs_win_fast_f32(ax, m, d->integrator, waves >= 2ll * device_simds() ? 512 : 256, zmu, st);
+        const bool two = waves >= 2ll * device_simds();      // (two waves per SIMD: eight-wave workgroups, accumulator carry-over)
+        return launch_rollout_bwd_xs_win_fast_f32(ax, m, d->integrator, two ? 512 : 256, zmu, two, st);
       }
       return launch_rollout_bwd_xs_fast_f32(ax, m, d->integrator, block, zmu, st);
     }

@@ -872,18 +872,18 @@ int launch_rollout_bwd(const RolloutBwdArgs<S>& a, LaneMap m, int integ, int blo
 
 // the positions-only (XS_ONLY) instantiations with accumulator carry-over, one point per lane inside a wave (G = 4 .. 64), plain or
 // interleaved maps: the saturated launches of small bodies (rollout_bwd_xs_fast.hip)
-template <typename S, bool ZMU, bool WIN = false>
+template <typename S, bool ZMU, bool WIN = false, bool CARRY = true>
 int launch_rollout_bwd_xs(const RolloutBwdArgs<S>& a, LaneMap m, int integ, int block, hipStream_t st) {
   const long long threads = (long long)a.B * m.G;
   const unsigned grid = (unsigned)((threads + block - 1) / block);
   bool launched = false;
-#define MF_CASE(G_)                                                                                                                            \
-  if (!launched && m.G == G_ && m.PPL == 1) {                                                                                                   \
-    launched = true;                                                                                                                            \
-    if (integ == MF_INTEG_DYNAMICS)                                                                                                             \
-      MF_KLAUNCH((rollout_bwd_kernel<S, G_, 1, MF_INTEG_DYNAMICS, true, false, true, true, ZMU, WIN>), dim3(grid), dim3(block), 0, st, a);      \
-    else                                                                                                                                        \
-      MF_KLAUNCH((rollout_bwd_kernel<S, G_, 1, MF_INTEG_ODEINT_EULER, true, false, true, true, ZMU, WIN>), dim3(grid), dim3(block), 0, st, a);  \
+#define MF_CASE(G_)                                                                                                                              \
+  if (!launched && m.G == G_ && m.PPL == 1) {                                                                                                     \
+    launched = true;                                                                                                                              \
+    if (integ == MF_INTEG_DYNAMICS)                                                                                                               \
+      MF_KLAUNCH((rollout_bwd_kernel<S, G_, 1, MF_INTEG_DYNAMICS, true, false, CARRY, true, ZMU, WIN>), dim3(grid), dim3(block), 0, st, a);       \
+    else                                                                                                                                          \
+      MF_KLAUNCH((rollout_bwd_kernel<S, G_, 1, MF_INTEG_ODEINT_EULER, true, false, CARRY, true, ZMU, WIN>), dim3(grid), dim3(block), 0, st, a);   \
   }
   MF_CASE(4)
   if constexpr (!WIN) { MF_CASE(8) MF_CASE(16) MF_CASE(32) MF_CASE(64) }
@@ -894,7 +894,7 @@ int launch_rollout_bwd_xs(const RolloutBwdArgs<S>& a, LaneMap m, int integ, int 
   return MF_OK;
 }
 int launch_rollout_bwd_xs_fast_f32(const RolloutBwdArgs<float>& a, LaneMap m, int integ, int block, bool zmu, hipStream_t st);      // rollout_bwd_xs_fast.hip
-int launch_rollout_bwd_xs_win_fast_f32(const RolloutBwdArgs<float>& a, LaneMap m, int integ, int block, bool zmu, hipStream_t st);  // rollout_bwd_xs_win_fast.hip
+int launch_rollout_bwd_xs_win_fast_f32(const RolloutBwdArgs<float>& a, LaneMap m, int integ, int block, bool zmu, bool carry, hipStream_t st);  // rollout_bwd_xs_win_fast.hip
 
 // defined in rollout_bwd_fast.hip (plain flush) and rollout_bwd_carry_fast.hip (accumulator carry-over)
 int launch_rollout_bwd_fast_f32(const RolloutBwdArgs<float>& a, LaneMap m, int integ, int block, hipStream_t st);
