@@ -260,6 +260,44 @@ def test_saturated_positions_only_backward_vs_oracle(integ, friction, scattered,
     assert float(cd.grad[rest.to(DEV)].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('res,B', [(0.2, 16384 + 37), (0.1, 16384 + 4)])
+def test_saturated_backward_small_maps_and_ragged_batches_vs_oracle(res, B):
+    """The LDS-window kernel where its window is LARGER than the map (64 x 64 cells) or exactly the map (128 x 128), with a batch that
+    leaves the last wave and the last workgroup partly empty -- the loss touches the last rollouts too -- against the float64 oracle."""
+    from monoforce_amd import synthetic as syn, _timing
+    T, sub = 40, 32
+    pts, masks = syn.robot_points_4()
+    z = syn.bump_terrain(syn.bump_params(7), 6.4, res)
+    mu = syn.wave_friction(6.4, res)
+    assert z.shape[-1] == int(round(12.8 / res))
+    ctrl = syn.const_controls(B, T, seed=3)
+    sel = torch.cat([torch.arange(0, B, B // (sub - 4))[:sub - 4], torch.arange(B - 4, B)])
+    spec = hp.spec_from(pts, masks, 1, res, 6.4)
+    wts = syn.probe_weights((sel.numel(), T, 3), phase=0.7)
+    dp = make_dphysics(pts, masks, 1, res, 6.4)
+    dp.dphys_cfg.traj_sim_time = 5.0
+    zd, md, cd = z.to(DEV).requires_grad_(True), mu.to(DEV).requires_grad_(True), ctrl.to(DEV).requires_grad_(True)
+    _timing.start()
+    (Xs, _, _, _), _ = dp(zd.unsqueeze(0), cd, friction=md.unsqueeze(0))
+    (Xs[sel.to(DEV)] * wts.to(DEV)).sum().backward()
+    name = _timing.launches()['rollout_bwd_kernel']
+    _timing.stop()
+    import os
+    if os.environ.get('MF_BWD_WIN', '1') != '0':
+        assert name.split(' grid')[0].endswith('true, true>'), name      # ZMU, WIN
+
+    def oracle_grads(dtype):
+        zc, mc, cc = z.to(dtype).requires_grad_(True), mu.to(dtype).requires_grad_(True), ctrl[sel].to(dtype).requires_grad_(True)
+        n = sel.numel()
+        (rX, _, _, _), _ = orc.rollout(spec, zc.unsqueeze(0).expand(n, -1, -1), cc, friction=mc.unsqueeze(0).expand(n, -1, -1))
+        (rX * wts.to(dtype)).sum().backward()
+        return zc.grad, mc.grad, cc.grad
+    ref, env = oracle_grads(torch.float64), oracle_grads(torch.float32)
+    for nm, g_, r64, r32 in zip(('z', 'mu', 'controls'), (zd.grad, md.grad, cd.grad[sel.to(DEV)]), ref, env):
+        bar = max(2e-4, 3.0 * hp.rel_err(r32, r64))
+        assert hp.rel_err(g_, r64) <= bar, (nm, hp.rel_err(g_, r64), 'bar', bar)
+
+
 def test_saturated_backward_without_the_lds_window_vs_oracle():
     """The same cases on the register-accumulator kernels (MF_BWD_WIN=0 is read once per process: a child runs them)."""
     import os, subprocess, sys
