@@ -131,13 +131,15 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
     // accumulator carry-over between adjacent cells (rollout_bwd_kernel.h): ~55 more instructions per step, half the atomics --
     // a gain from ~3 waves per 4 CUs upwards (B = 4096 at N = 4: 1.00 -> 0.94 ms; B = 65536: 9.5 -> 5.5 ms), a loss below
     const RolloutBwdArgs<float>& af = *reinterpret_cast<const RolloutBwdArgs<float>*>(&a);
-    // positions-only upstream (physics_loss) on a one-point-per-lane mapping inside a wave, from one wave per SIMD up: the XS_ONLY
+    // positions-only upstream (physics_loss) on a one-point-per-lane mapping inside a wave, from half a wave per SIMD up: the XS_ONLY
     // kernels -- and, for ONE shared map pair with a friction map, the interleaved (z, mu) copy (the caller's staged pair, or the
     // scratch it offers, refilled here: one 65 536-cell pass in front of a launch of >= 1 ms).  MF_BWD_XS=0 / MF_BWD_XS_ZMU=0: A/B.
     static const bool xs_off = getenv("MF_BWD_XS") && atoi(getenv("MF_BWD_XS")) == 0;
     static const bool xs_zmu_off = getenv("MF_BWD_XS_ZMU") && atoi(getenv("MF_BWD_XS_ZMU")) == 0;
     const bool xs_only = p->gXs && !p->gXds && !p->gRs && !p->gOmegas && !p->gFs && !p->gFf;
-    static const long long xs_min_waves = getenv("MF_BWD_XS_MIN_WAVES") ? atoll(getenv("MF_BWD_XS_MIN_WAVES")) : device_simds();      // (A/B: lower it to run them on fewer rollouts)
+    // (from half a wave per SIMD: right above the component-parallel kernels' range -- 10 240 / 12 288 / 14 336 rollouts of the 4-point body
+    //  1.14 / 1.39 / 1.60 ms on the general kernels, 0.91 / 0.90 / 0.93 here, tools/ab_between.sh; MF_BWD_XS_MIN_WAVES overrides)
+    static const long long xs_min_waves = getenv("MF_BWD_XS_MIN_WAVES") ? atoll(getenv("MF_BWD_XS_MIN_WAVES")) : device_simds() / 2;
     if (!xs_off && xs_only && m.PPL == 1 && m.G <= 64 && (long long)d->B * m.G >= xs_min_waves * 64) {
       RolloutBwdArgs<float> ax = af;
       bool zmu = false;
