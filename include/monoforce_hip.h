@@ -89,7 +89,7 @@ typedef struct MfRolloutDesc {
   int32_t force_stride; /* point slots per row of the Fs / Ff buffers, >= mf_rollout_force_stride(desc); 0 means N
                            (only valid when N is a multiple of the lane tile, e.g. N = 4).  Padding slots get zeros. */
   int32_t grad_copies;  /* backward, shared map only: number of private copies of the gz / gmu maps (rollout b scatters into
-                           copy b % grad_copies; the caller sums the copies).  Thousands of rollouts of one batch cross the
+                           copy b % grad_copies -- the LDS-window kernels: a workgroup's window into copy workgroup % grad_copies; the caller sums the copies).  Thousands of rollouts of one batch cross the
                            same cells, and same-address float atomics serialise in L2 at ~20 ns each; 0 or 1 = one copy.
                            Measured: 32 copies for bodies of up to 4 points (~64 rollouts per copy beyond 2048 rollouts), at least
                            64 for larger bodies, whose points sit on nearly the same cells in every rollout of a batch
