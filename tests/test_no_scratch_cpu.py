@@ -49,3 +49,16 @@ def test_streaming_backward_fits_two_workgroups_per_cu(metadata):
     assert len(rows) == 2, rows
     for n, m in rows:
         assert m['vgpr'] + m['agpr'] <= 256 and m['lds'] <= 80 * 1024 and m['scratch'] == 0, (n, m)
+
+
+def test_lds_window_kernels_fit_one_workgroup_of_eight_waves_per_cu(metadata):
+    """The LDS-window backward kernels (round 5) hold a 128 x 128-cell window of both gradient maps (128 KB of the CU's 160 KB: one workgroup
+    per CU) and run as workgroups of up to eight waves -- two per SIMD: at most 256 registers per lane, no scratch."""
+    rows = [(n, m) for o, n, m in metadata if m['lds'] == 2 * 128 * 128 * 4]
+    names = ' '.join(n for n, _ in rows)
+    assert 'rollout_bwd_kernel<float, 4, 1, 1, true, false, true, true, true, true>' in names       # positions-only, interleaved maps, carry-over
+    assert 'rollout_bwd_kernel<float, 4, 1, 0, true, false, false, true, false, true>' in names     # dynamics(), plain maps, no carry-over
+    assert 'rollout_bwd_cp_kernel<float, 1, true, false, 0, 6, 3, false, true>' in names            # component-parallel early recompute
+    assert len(rows) >= 12, names
+    for n, m in rows:
+        assert m['scratch'] == 0 and m['vgpr'] + m['agpr'] <= 256, (n, m)
