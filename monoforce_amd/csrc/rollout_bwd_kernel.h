@@ -175,6 +175,12 @@ __device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* 
   S* gctrl = a.gcontrols + (size_t)b * a.T * 2;
 
   // adjoint of the state (x, xd, R, w) [+ the impulse accumulators of the ODEINT extended state]
+  // UNSUM (round 5; the positions-only kernels of rollouts inside a wave): the adjoint state is kept UN-SUMMED over the lanes of a rollout
+  // -- every lane holds the part its own points contributed, the state is the sum of the parts.  Every use of it is linear, and only
+  // the two parts met by per-point data -- the adjoints of the linear and angular velocity -- are summed every step, with the control
+  // gradient that is stored: 8 + 5 lane sums per step instead of 23 + 5 (the saturated launches are VALU-bound: r5h_pmc_backward_sat_B32768.txt).
+  constexpr bool UNSUM = XS_ONLY && G <= 64 && !JOINTS;
+  const S up_lane = (!UNSUM || gl == 0) ? one : zero;      // upstream gradients of the body state enter ONE lane's part
   S lx[3] = {zero, zero, zero}, lxd[3] = {zero, zero, zero}, lw[3] = {zero, zero, zero}, lR[9];
 #pragma unroll
   for (int c = 0; c < 9; ++c) lR[c] = zero;
@@ -260,8 +266,14 @@ __device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* 
     }
   };
   auto add_upstream_state = [&](const UpIn& u) {
+    if constexpr (UNSUM) {
+      const S ms = up_lane * a.sink;
+      lx[0] += up_lane * u.gXs[0]; lx[1] += up_lane * u.gXs[1]; lx[2] += up_lane * u.gXs[2];
+      lR[2] += u.gXs[0] * ms; lR[5] += u.gXs[1] * ms; lR[8] += u.gXs[2] * ms;
+    } else {
     lx[0] += u.gXs[0]; lx[1] += u.gXs[1]; lx[2] += u.gXs[2];
     lR[2] += u.gXs[0] * a.sink; lR[5] += u.gXs[1] * a.sink; lR[8] += u.gXs[2] * a.sink;   // Xs = x + R[:,2] * sink
+    }
     if constexpr (!XS_ONLY) {
       lxd[0] += u.gXds[0]; lxd[1] += u.gXds[1]; lxd[2] += u.gXds[2];
 #pragma unroll
@@ -450,11 +462,22 @@ __device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* 
       for (int j = 0; j < PPL; ++j)
 #pragma unroll
         for (int c = 0; c < 3; ++c) { if constexpr (!XS_ONLY) { laFs[j][c] += act[j] ? up.gFs[j][c] : zero; laFf[j][c] += act[j] ? up.gFf[j][c] : zero; } }
+      if constexpr (UNSUM) {
+        S tot6[6] = {lxd[0], lxd[1], lxd[2], lw[0], lw[1], lw[2]};      // the velocity adjoints proper
+        gs.sum_n(tot6);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          gxdd[c] = h * tot6[c];
+          gwd[c] = h * tot6[3 + c];
+          lxd[c] += h * lx[c];
+        }
+      } else {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         gxdd[c] = h * lxd[c];
         gwd[c] = h * lw[c];
         lxd[c] += h * lx[c];               // x' = x + h xd
+      }
       }
 #pragma unroll
       for (int j = 0; j < PPL; ++j)
@@ -529,12 +552,27 @@ __device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* 
 #pragma unroll
         for (int c = 0; c < 3; ++c) gwn[c] += M::div(gth * wn[c], th);
       }
+      if constexpr (UNSUM) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          lw[c] += gwn[c];
+          lxd[c] += h * lx[c];
+        }
+        S tot6[6] = {lxd[0], lxd[1], lxd[2], lw[0], lw[1], lw[2]};
+        gs.sum_n(tot6);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          gwd[c] = h * tot6[3 + c];
+          gxdd[c] = h * tot6[c];
+        }
+      } else {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         lw[c] += gwn[c];
         gwd[c] = h * lw[c];                // w' = w + wd h
         lxd[c] += h * lx[c];               // x' = x + xd' h
         gxdd[c] = h * lxd[c];              // xd' = xd + xdd h
+      }
       }
 #pragma unroll
       for (int c = 0; c < 9; ++c) lR[c] = lRn[c];
@@ -736,25 +774,35 @@ __device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* 
         }
       }
     }
+    if constexpr (UNSUM) {      // the lane's own parts, no sums -- but for the control gradient this step stores
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { lx[c] += gx_[c]; lxd[c] += gxd_[c]; lw[c] += gw_[c]; }
+#pragma unroll
+      for (int c = 0; c < 9; ++c) lR[c] += gR_[c];
+      S red2[2] = {gv, gwc};
+      gs.sum_n(red2);
+      gv = red2[0]; gwc = red2[1];
+    } else {
     S red[JOINTS ? 27 : 23];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) { red[c] = gx_[c]; red[3 + c] = gxd_[c]; red[6 + c] = gw_[c]; red[9 + c] = ge[c]; }
+      for (int c = 0; c < 3; ++c) { red[c] = gx_[c]; red[3 + c] = gxd_[c]; red[6 + c] = gw_[c]; red[9 + c] = ge[c]; }
 #pragma unroll
-    for (int c = 0; c < 9; ++c) red[12 + c] = gR_[c];
-    red[21] = gv; red[22] = gwc;
-    if constexpr (JOINTS) { red[23] = gja_[0]; red[24] = gja_[1]; red[25] = gja_[2]; red[26] = gja_[3]; }
-    gs.sum_n(red);       // the step's 23 adjoint sums in one batched reduction (multi-wave groups: one LDS exchange)
-    if constexpr (JOINTS) {
-      if (a.gjoint != nullptr && gl == 0) {
-        S* o = a.gjoint + ((size_t)b * a.T + n) * 4;
-        o[0] = red[23]; o[1] = red[24]; o[2] = red[25]; o[3] = red[26];
+      for (int c = 0; c < 9; ++c) red[12 + c] = gR_[c];
+      red[21] = gv; red[22] = gwc;
+      if constexpr (JOINTS) { red[23] = gja_[0]; red[24] = gja_[1]; red[25] = gja_[2]; red[26] = gja_[3]; }
+      gs.sum_n(red);       // the step's 23 adjoint sums in one batched reduction (multi-wave groups: one LDS exchange)
+      if constexpr (JOINTS) {
+        if (a.gjoint != nullptr && gl == 0) {
+          S* o = a.gjoint + ((size_t)b * a.T + n) * 4;
+          o[0] = red[23]; o[1] = red[24]; o[2] = red[25]; o[3] = red[26];
+        }
       }
+#pragma unroll
+      for (int c = 0; c < 3; ++c) { lx[c] += red[c]; lxd[c] += red[3 + c]; lw[c] += red[6 + c]; ge[c] = red[9 + c]; }
+#pragma unroll
+      for (int c = 0; c < 9; ++c) lR[c] += red[12 + c];
+      gv = red[21]; gwc = red[22];
     }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) { lx[c] += red[c]; lxd[c] += red[3 + c]; lw[c] += red[6 + c]; ge[c] = red[9 + c]; }
-#pragma unroll
-    for (int c = 0; c < 9; ++c) lR[c] += red[12 + c];
-    gv = red[21]; gwc = red[22];
     {   // e = col0(R) / max(|col0|, eps): through |col0| only when it is >= eps
       const S dote = (coln >= (S)1e-6) ? ge[0] * e[0] + ge[1] * e[1] + ge[2] * e[2] : zero;
       lR[0] += M::div(ge[0] - dote * e[0], el);
@@ -781,6 +829,18 @@ __device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* 
     add_upstream_state(up);
   }
 
+  if constexpr (UNSUM) {      // the adjoint of the initial state proper
+    S tot[18];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { tot[c] = lx[c]; tot[3 + c] = lxd[c]; tot[6 + c] = lw[c]; }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) tot[9 + c] = lR[c];
+    gs.sum_n(tot);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) { lx[c] = tot[c]; lxd[c] = tot[3 + c]; lw[c] = tot[6 + c]; }
+#pragma unroll
+    for (int c = 0; c < 9; ++c) lR[c] = tot[9 + c];
+  }
   // terrain snap of the initial height: x.z = mean_i blend(z; cell((R0 P_i + x0).xy))   (dphysics.py:567-571)
   S gx0[3] = {lx[0], lx[1], lx[2]};
   if (!a.skip_snap) {

@@ -298,6 +298,39 @@ def test_saturated_backward_small_maps_and_ragged_batches_vs_oracle(res, B):
         assert hp.rel_err(g_, r64) <= bar, (nm, hp.rel_err(g_, r64), 'bar', bar)
 
 
+def test_saturated_positions_only_backward_of_an_eight_point_body_vs_oracle():
+    """Beyond the multi-wave record kernels' range (two waves per SIMD) an 8-point body runs the positions-only general backward at eight lanes
+    per rollout (XS_ONLY, un-summed adjoint state, device-scope atomics: no window beyond four lanes) -- against the float64 oracle."""
+    from monoforce_amd import synthetic as syn, _timing
+    B, T, sub, N = 16384 + 256, 40, 24, 8
+    pts, masks = syn.robot_points_box(N, seed=5, n_tracks=2)
+    z = syn.bump_terrain(syn.bump_params(9), 6.4, 0.05)
+    mu = syn.wave_friction(6.4, 0.05)
+    ctrl = syn.const_controls(B, T, seed=4)
+    sel = torch.arange(0, B, B // sub)[:sub]
+    spec = hp.spec_from(pts, masks, 1, 0.05, 6.4)
+    wts = syn.probe_weights((sub, T, 3), phase=0.2)
+    dp = make_dphysics(pts, masks, 1, 0.05, 6.4)
+    dp.dphys_cfg.traj_sim_time = 5.0
+    zd, md, cd = z.to(DEV).requires_grad_(True), mu.to(DEV).requires_grad_(True), ctrl.to(DEV).requires_grad_(True)
+    _timing.start()
+    (Xs, _, _, _), _ = dp(zd.unsqueeze(0), cd, friction=md.unsqueeze(0))
+    (Xs[sel.to(DEV)] * wts.to(DEV)).sum().backward()
+    name = _timing.launches()['rollout_bwd_kernel']
+    _timing.stop()
+    assert 'rollout_bwd_kernel<float, 8, 1, 1, true, false, true, true, true, false>' in name, name      # CARRY, XS_ONLY, ZMU, no WIN
+
+    def oracle_grads(dtype):
+        zc, mc, cc = z.to(dtype).requires_grad_(True), mu.to(dtype).requires_grad_(True), ctrl[sel].to(dtype).requires_grad_(True)
+        (rX, _, _, _), _ = orc.rollout(spec, zc.unsqueeze(0).expand(sub, -1, -1), cc, friction=mc.unsqueeze(0).expand(sub, -1, -1))
+        (rX * wts.to(dtype)).sum().backward()
+        return zc.grad, mc.grad, cc.grad
+    ref, env = oracle_grads(torch.float64), oracle_grads(torch.float32)
+    for nm, g_, r64, r32 in zip(('z', 'mu', 'controls'), (zd.grad, md.grad, cd.grad[sel.to(DEV)]), ref, env):
+        bar = max(2e-4, 3.0 * hp.rel_err(r32, r64))
+        assert hp.rel_err(g_, r64) <= bar, (nm, hp.rel_err(g_, r64), 'bar', bar)
+
+
 def test_saturated_backward_without_the_lds_window_vs_oracle():
     """The same cases on the register-accumulator kernels (MF_BWD_WIN=0 is read once per process: a child runs them)."""
     import os, subprocess, sys
