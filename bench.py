@@ -28,7 +28,14 @@ Workloads (`--workload`; the default, c3, is BASELINE configs[2], the shape nort
   c4   BASELINE configs[3]   TerrainEncoder (4 cams 3x256x512 -> 256x256 BEV) + 1024 rollouts, end-to-end train step
   c5   BASELINE configs[4]   8192 rollouts in total + encoder, sharded over the ranks (STRONG scaling: 8192 / N per GPU)
 
-The JSON line (rank 0) carries, besides the contract's keys:
+OUTPUT.  The LAST stdout line (rank 0) is ONE compact JSON object, < 4 KB (`compact_line`): the contract's keys, `config`, `roofline`
+(bound, achieved, peak, unit, frac, traffic, frac_traffic, frac_model, kernel, kernel_ms, ...), `cpu_baseline` (value, unit, cores,
+kind, sample), `forward_only` and one ms-per-step number per side workload.  Everything else -- per-kernel tables, the batch sweep,
+side workloads, CPU legs, kernel-instance strings -- goes to the DETAIL file (`--detail`, default bench_detail.json next to this
+script, copied to gpurun_out/ when that directory exists); the line names it under `detail`.  (Round 5 printed all of it as one
+28.8 KB line, which the driver could not parse: tests/test_bench_line_cpu.py holds the line to its size now.)
+
+The detail record carries, besides the contract's keys:
   roofline      dominant hand-written kernel of the headline step -- algorithmic bytes per launch (80 + 56 N
                 bytes per rollout-step forward, 160 + 120 N backward) / its average launch duration, measured live with HIP
                 events on the launch stream, against the 8 TB/s HBM peak -- plus `per_kernel` (forward AND backward
@@ -109,6 +116,85 @@ def fwd_states_only_bytes_per_rollout_step(N):
     """A states-only forward (FORCES = false: the fit / train steps discard the forces) is asked to move
     controls 8 + states 72 + map cells 32 N -- NOT the 24 N of forces: its `algorithmic_bytes` is 80 + 32 N (208 B at N = 4)."""
     return 80 + 32 * N
+
+
+def parse_instance(text):
+    """'mf::rollout_bwd_kernel<float, 4, 1, 1, true, ...> grid=.. block=.. launches=..' -> ('rollout_bwd_kernel', ['float', '4', ...], {'grid': .., 'block': ..})."""
+    import re
+    m = re.match(r'\s*(?:mf::)?(\w+)<(.*?)>(.*)$', text or '')
+    if not m:
+        return None, [], {}
+    kv = {k: int(v) for k, v in re.findall(r'(\w+)=(\d+)', m.group(3))}
+    return m.group(1), [t.strip() for t in m.group(2).split(',')], kv
+
+
+def instance_bytes_per_rollout_step(instance, N, T=500, T2=50):
+    """The bytes THIS kernel instantiation is asked to move per rollout-step -- SURVEY 8d's figure with the rows the
+    instantiation never touches taken out and the ones it adds (the forward's record) put in -- and the terms, as text.  Returns
+    (bytes, text, flags) or (None, reason, {}) for an unknown kernel.  Template parameter order: the kernels' headers
+    (rollout_bwd_kernel.h:890, rollout_bwd_cp_kernel.h:61, rollout_bwd_mw_kernel.h:62, rollout_fwd_kernel.h:226, rollout_fwd_cp_kernel.h:16)."""
+    name, t, _ = parse_instance(instance)
+    if name is None:
+        return None, 'no kernel instance recorded', {}
+    b = lambda i, default=False: (t[i] == 'true') if i < len(t) else default      # noqa: E731
+    terms, flags = [], {}
+    if name in ('rollout_bwd_kernel', 'rollout_bwd_cp_kernel', 'rollout_bwd_mw_kernel'):
+        if name == 'rollout_bwd_kernel':       # <S, G, PPL, INTEG, FAST, JOINTS, CARRY, XS_ONLY, ZMU, WIN, LOSS>
+            xs, win, loss, rec, gctrl = b(7), b(9), b(10), 0, True
+        elif name == 'rollout_bwd_cp_kernel':  # <S, INTEG, XS_ONLY, GCTRL, MODE, SLOTS, BATCH, ZMU, WIN>
+            xs, gctrl, mode, win, loss = b(2), b(3), int(t[4]), b(8), False
+            rec = 256 if mode >= 2 else 0      # kCpSaved / kCpStream read the forward's 16-byte quad per lane, 16 lanes per rollout
+        else:                                  # <S, G, XS_ONLY, TILE, INTEG>
+            xs, gctrl, win, loss, rec = b(2), True, int(t[3]) > 0, False, 16
+        total = 0
+        if xs:
+            total += 12; terms.append('positions-only upstream: one 12-B row (dL/dXs, or the Xs row a fused loss reads)')
+        else:
+            total += 72 + 24 * N; terms.append(f'upstream rows 72 + 24 N = {72 + 24 * N}')
+        if loss:
+            total += 12 * T2 / T; terms.append(f'ground-truth rows 12 B x {T2}/{T} stamped steps')
+        total += 8 + 72; terms.append('controls 8 + saved state 72')
+        total += 32 * N; terms.append(f're-gathered cells 32 N = {32 * N} (L2 / LDS-served)')
+        total += 64 * N; terms.append(f'cell-gradient read-modify-write 64 N = {64 * N}' + (' (LDS window first)' if win else ' (L2 atomics)'))
+        if gctrl:
+            total += 8; terms.append('control gradient 8')
+        if rec:
+            total += rec; terms.append(f"the forward's record {rec}")
+        flags = dict(xs_only=xs, win=win, fused_loss=loss, record=rec)
+        return total, ' + '.join(terms), flags
+    if name in ('rollout_fwd_kernel', 'rollout_fwd_cp_kernel'):
+        if name == 'rollout_fwd_kernel':       # <S, G, PPL, INTEG, FAST, JOINTS, FORCES, COST, SPLIT, ZMU, REC>
+            forces, cost, rec = b(6, True), int(t[7]) if len(t) > 7 else 0, 16 if b(10) else 0
+        else:                                  # <S, INTEG, FORCES, ZMU, REC, LOSS>
+            forces, cost, rec = b(2, True), 0, 256 if b(4) else 0
+        if cost:
+            return 8 + 16 + 32 * N, f'path-cost mode: controls 8 + cost row 16 + cells 32 N = {32 * N}', dict(cost=True)
+        total = 8 + 72 + 32 * N
+        terms = ['controls 8 + states 72', f'gathered cells 32 N = {32 * N} (L2-served)']
+        if forces:
+            total += 24 * N; terms.append(f'force rows 24 N = {24 * N}')
+        if rec:
+            total += rec; terms.append(f'the record kept for the backward {rec}')
+        return total, ' + '.join(terms), dict(forces=forces, record=rec)
+    return None, f'no byte model for {name}', {}
+
+
+def regime_of(instance, B, N):
+    """What bounds this launch, from its occupancy (MI355X: 1024 SIMDs) and the counters on file -- stated, not inferred from `frac`:
+    below one wave per SIMD a launch costs what ONE wave's dependent chain issues (profiles/r3_critical_path.txt); the saturated
+    positions-only backward is VALU-bound (profiles/r5h_pmc_backward_sat_B32768.txt: VALUs ~92 % busy, 1.5 TB/s at the HBM counters)."""
+    name, t, kv = parse_instance(instance)
+    if name is None:
+        return None
+    waves = kv.get('grid', 0) * max(kv.get('block', 64) // 64, 1)
+    per_simd = waves / 1024.0
+    if name in ('rollout_bwd_cp_kernel', 'rollout_fwd_cp_kernel') or per_simd < 1.0:
+        return f'issue-bound: {per_simd:.2f} waves per SIMD, a step costs what one wave\'s dependent chain issues'
+    if name == 'rollout_bwd_kernel' and len(t) > 7 and t[7] == 'true':
+        return f'VALU-bound ({per_simd:.1f} waves per SIMD; PMC: VALUs ~92 % busy at two waves per SIMD); cells and RMW are cache / LDS-served'
+    if name == 'rollout_fwd_kernel':
+        return f'{per_simd:.1f} waves per SIMD: bound by the CU\'s L1 address path (gathers) and the output stores'
+    return f'{per_simd:.1f} waves per SIMD'
 
 
 def build_problem(B, T, N, device, integ, seed=0, grid_res=0.05, terrain_seed=0):
@@ -449,6 +535,15 @@ class Runner:
                           # the bytes of the model that must cross HBM (no cache-served map cells / scatter RMW); splat: all of them
                           'hbm_bytes_model': hbm.get(k, alg[k]), 'frac_hbm': hbm.get(k, alg[k]) / (v * 1e-3) / 1e9 / HBM_PEAK_GBS}
                       for k, v in kern.items()}
+        for k in ('rollout_fwd_kernel', 'rollout_bwd_kernel'):      # what THIS instantiation is asked to move, beside SURVEY 8d's figure
+            if k in per_kernel:
+                mb, terms, _ = instance_bytes_per_rollout_step(kernels_run.get(k), N, T=T)
+                per_kernel[k].update({'instance': kernels_run.get(k), 'model_bytes_per_rollout_step': mb, 'model_terms': terms,
+                                      'frac_model': (mb * B * T / (kern[k] * 1e-3) / 1e9 / HBM_PEAK_GBS) if mb else None,
+                                      'regime': regime_of(kernels_run.get(k), B, N)})
+                tr = self.traffic.get(name if not batch else f'{name}_B{B}', {}).get(k)
+                per_kernel[k]['traffic'] = tr
+                per_kernel[k]['frac_traffic'] = (tr / (kern[k] * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr else None
         if 'rollout_fwd_kernel' in per_kernel:
             per_kernel['rollout_fwd_kernel']['bytes_model'] = (
                 f'states only (no force rows): controls 8 + states 72 + map cells 32 N = {fwd_states_only_bytes_per_rollout_step(N)} B per rollout-step'
@@ -461,7 +556,7 @@ class Runner:
         mode = 'encoder train step (fwd+bwd+Adam)' if wl.get('encoder') else 'forward+backward' if wl['backward'] else 'forward'
         integ = 'odeint-euler (reference default)' if args.integrator == 1 else 'dynamics()'
         H = int(round(12.8 / res))
-        traffic = self.traffic.get(name, {}).get(dom)
+        traffic = self.traffic.get(name if not batch else f'{name}_B{B}', {}).get(dom)
         # the per-step record small default-integrator launches keep in the forward for the backward (MfRolloutFwdBufs.rec): real
         # bytes on top of the algorithmic ones -- a recompute-for-storage trade, reported so that `traffic` reads right
         rec_bytes = 0
@@ -490,8 +585,12 @@ class Runner:
                          'traffic_source': ('profiles/hbm_traffic.json (rocprofv3 PMC passes of this command on THIS library build -- sha256 checked; '
                                             'not re-measured in this run)' if traffic else self.traffic_stale),
                          'frac_hbm': per_kernel[dom]['frac_hbm'], 'hbm_bytes_model_per_launch': per_kernel[dom]['hbm_bytes_model'],
-                         'frac_note': '`frac` = SURVEY 8d algorithmic bytes (map cells counted even when cache-served) / kernel time / 8 TB/s; '
-                                      '`frac_hbm` = the same model without the cache-served bytes; `traffic` = PMC-measured HBM bytes',
+                         'frac_model': per_kernel[dom].get('frac_model'), 'model_bytes_per_rollout_step': per_kernel[dom].get('model_bytes_per_rollout_step'),
+                         'model_terms': per_kernel[dom].get('model_terms'), 'regime': per_kernel[dom].get('regime'),
+                         'frac_note': '`frac` = SURVEY 8d algorithmic bytes (the contract figure: map cells counted even when cache-served, upstream rows '
+                                      'counted even when the instantiation never reads them) / kernel time / 8 TB/s; `frac_model` = the bytes THIS '
+                                      'instantiation is asked to move (model_terms); `frac_hbm` = SURVEY 8d without the cache-served bytes; `traffic` / '
+                                      '`frac_traffic` = HBM bytes at the PMC counters -- the only one of the four that is HBM bandwidth',
                          'kernel': dom, 'kernel_ms': kern[dom], 'kernel_ms_from': ('HIP events around the launches of sampled steps run right after the timed region (the region itself: replays only)'
                                                            if events_after else f'HIP events around the launches of every {EVENT_EVERY}th timed step and of four steps run right after the region'),
                          'algorithmic_bytes_per_launch': alg[dom], 'bytes_per_rollout_step': alg[dom] // (B * T),
@@ -511,27 +610,53 @@ class Runner:
         dev = self.dev
         sweep, private = {}, {}
 
-        def row(Bs, f_ms, b_ms, launches):
+        def row(Bs, f_ms, b_ms, launches, step_ms=None):
             fg = fwd_bytes_per_rollout_step(N) * Bs * T / (f_ms * 1e-3) / 1e9
             bg = bwd_bytes_per_rollout_step(N) * Bs * T / (b_ms * 1e-3) / 1e9
-            return {'fwd_ms': f_ms, 'fwd_frac': fg / HBM_PEAK_GBS, 'fwd_rollout_steps_per_s': Bs * T / (f_ms * 1e-3),
-                    'fwd_frac_hbm': fwd_hbm_bytes_per_rollout_step(N) * Bs * T / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                    'bwd_ms': b_ms, 'bwd_frac': bg / HBM_PEAK_GBS, 'bwd_rollout_steps_per_s': Bs * T / (b_ms * 1e-3),
-                    'bwd_frac_hbm': bwd_hbm_bytes_per_rollout_step(N) * Bs * T / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'kernels': launches}
+            out = {'fwd_ms': f_ms, 'fwd_frac': fg / HBM_PEAK_GBS, 'fwd_rollout_steps_per_s': Bs * T / (f_ms * 1e-3),
+                   'fwd_frac_hbm': fwd_hbm_bytes_per_rollout_step(N) * Bs * T / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   'bwd_ms': b_ms, 'bwd_frac': bg / HBM_PEAK_GBS, 'bwd_rollout_steps_per_s': Bs * T / (b_ms * 1e-3),
+                   'bwd_frac_hbm': bwd_hbm_bytes_per_rollout_step(N) * Bs * T / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 'kernels': launches}
+            # three fractions per leg: SURVEY 8d's figure (`*_frac`), the bytes the instantiation that RAN is asked to
+            # move (`*_frac_model`), and HBM bytes at the PMC counters where a pass is on file (`*_frac_traffic`, profiles/hbm_traffic.json)
+            for leg, ms in (('fwd', f_ms), ('bwd', b_ms)):
+                inst = launches.get(f'rollout_{leg}_kernel')
+                mb, terms, _ = instance_bytes_per_rollout_step(inst, N, T=T)
+                tr = self.traffic.get(f'c3_B{Bs}', {}).get(f'rollout_{leg}_kernel') if leg == 'bwd' else self.traffic.get(f'c3f_B{Bs}', {}).get('rollout_fwd_kernel')
+                out.update({f'{leg}_model_bytes_per_rollout_step': mb, f'{leg}_model_terms': terms,
+                            f'{leg}_frac_model': (mb * Bs * T / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if mb else None,
+                            f'{leg}_traffic': tr, f'{leg}_frac_traffic': (tr / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if tr else None,
+                            f'{leg}_bound': regime_of(inst, Bs, N)})
+                if out[f'{leg}_frac'] > 0.79 or (out[f'{leg}_frac_model'] or 0) > 0.79:      # beyond what HBM can deliver (~6.3 of 8 TB/s): not HBM bandwidth
+                    out[f'{leg}_note'] = ('cache-served: a model fraction above 0.79 exceeds what HBM delivers -- the gathered cells and the '
+                                          'cell-gradient read-modify-writes of the model stay in L2 / LDS; read `frac_traffic` / `frac_hbm` for HBM')
+            if step_ms is not None:
+                out['step_ms'] = step_ms      # forward + loss + backward + gradient reduction of one fit step, HIP events around the step
+            return out
 
         for Bs in batches:
             _, dps, _, _, z, mu, cs = build_problem(Bs, T, N, dev, self.args.integrator, seed=0)
             cs = cs.to(dev)
-            prob = TerrainFitProblem(dps, syn.bump_terrain(syn.bump_params(100), 6.4, 0.05).to(dev), mu.to(dev), cs)
+            prob = TerrainFitProblem(dps, syn.bump_terrain(syn.bump_params(100), 6.4, 0.05).to(dev), mu.to(dev), cs, graph=not os.environ.get('MF_BENCH_NO_GRAPH'))
             zl, ml = z.to(dev).clone().requires_grad_(True), mu.to(dev).clone().requires_grad_(True)
             zd, md = z.to(dev).unsqueeze(0), mu.to(dev).unsqueeze(0)
             for _ in range(2):
-                prob.step(zl, ml)
+                prob.step(zl, ml, eager=True)
             _timing.start()
             for _ in range(3):
-                prob.step(zl, ml)
+                prob.step(zl, ml, eager=True)
             launches = {'rollout_bwd_kernel': _timing.launches().get('rollout_bwd_kernel')}
             k = _timing.stop()
+            # the whole fit step (forward + loss + backward + reduction of the gradient copies), replayed as one hipGraph: HIP events around 6 steps
+            prob.step(zl, ml)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(6):
+                prob.step(zl, ml)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            step_ms = e0.elapsed_time(e1) / 6
+            launches['step'] = {kk: float(np.mean(v)) for kk, v in k.items()}      # every hand-written launch of the step, ms
             with torch.no_grad():       # the plain forward (all six outputs, no saved rows for a backward)
                 dps(zd, cs, friction=md)
                 _timing.start()
@@ -539,7 +664,7 @@ class Runner:
                     dps(zd, cs, friction=md)
                 launches['rollout_fwd_kernel'] = _timing.launches().get('rollout_fwd_kernel')
                 kf = _timing.stop()
-            sweep[str(Bs)] = row(Bs, float(np.mean(kf['rollout_fwd_kernel'])), float(np.mean(k['rollout_bwd_kernel'])), launches)
+            sweep[str(Bs)] = row(Bs, float(np.mean(kf['rollout_fwd_kernel'])), float(np.mean(k['rollout_bwd_kernel'])), launches, step_ms=step_ms)
             del dps, prob, cs, zl, ml
             torch.cuda.empty_cache()      # return the sweep's multi-GB blocks now, not inside a later workload's timed region
         for Bs in private_batches:      # one map pair PER ROLLOUT: [B,H,W] leaves, the loss on every 10th pose (the rows physics_loss stamps)
@@ -564,8 +689,11 @@ class Runner:
                                         'dL/dXs rows and writes [B,H,W] gradients of both maps')
             del dps, cs, zb, mb
             torch.cuda.empty_cache()
-        first = {leg: next((int(b) for b in sweep if sweep[b][leg + '_frac'] >= 0.4), None) for leg in ('fwd', 'bwd')}
-        return {'batches': sweep, 'per_rollout_maps': private, 'first_B_at_40pct': first}
+        first = {kind or 'survey_8d': {leg: next((int(b) for b in sweep if (sweep[b].get(f'{leg}_frac{kind}') or 0) >= 0.4), None) for leg in ('fwd', 'bwd')}
+                 for kind in ('', '_model', '_hbm', '_traffic')}
+        return {'batches': sweep, 'per_rollout_maps': private, 'first_B_at_40pct': first,
+                'first_B_at_40pct_note': 'per fraction: survey_8d = SURVEY 8d bytes; _model = the instantiation\'s own bytes; _hbm = SURVEY 8d without '
+                                         'cache-served bytes; _traffic = PMC-measured HBM bytes (None: no batch with a PMC pass reaches 40 % of HBM)'}
 
 
 def api_workload(r, T, N, integ, B=1024, iters=24):
@@ -655,6 +783,67 @@ def shoot_workload(r, T, N, integ, B=16384, iters=8):
                                                   'GB/s': (8 + 16 + 32 * N) * B * T / (kms * 1e-3) / 1e9}}}
 
 
+COMPACT_LIMIT = 4096        # bytes: the driver parses the LAST stdout line and holds only a few KB of it (BENCH_r05: a 28.8 KB line was unparseable)
+
+
+def _short(text, n):
+    text = str(text)
+    return text if len(text) <= n else text[:n - 3] + '...'
+
+
+def _r(v, sig=6):
+    """Round floats to `sig` significant digits (the compact line only; the detail file keeps every digit)."""
+    if isinstance(v, float) and v == v and v not in (float('inf'), float('-inf')) and v != 0.0:
+        return float(f'%.{sig}g' % v)
+    return v
+
+
+def compact_line(out, detail_file=None):
+    """The ONE line the driver parses: the contract's keys + `roofline` + `cpu_baseline`, every value a number or a short string.
+    Sweeps, side workloads, per-kernel tables, kernel-name strings and CPU legs live in the detail file (`detail`)."""
+    cfg, roof = out['config'], out['roofline']
+    c = {k: _r(out.get(k)) for k in ('metric', 'value', 'unit', 'n_gpus', 'world_size', 'backend', 'steps', 'warmup', 'ms_per_step')}
+    if out.get('ms_per_step_ranks'):
+        c['ms_per_step_ranks'] = {k: _r(v) for k, v in out['ms_per_step_ranks'].items()}
+    c['comm_ms'] = _r(out.get('comm_ms'))
+    c.update({k: out.get(k) for k in ('higher_is_better', 'scaling', 'vs_baseline', 'dtype', 'data')})
+    c['config'] = {'workload': _short(cfg['workload'], 200),
+                   **{k: cfg.get(k) for k in ('rollouts_per_gpu', 'rollouts_total', 'horizon', 'contact_points', 'grid', 'parallelism')},
+                   'launch': {'mode': (cfg.get('launch') or {}).get('mode')}}
+    c['roofline'] = {k: _r(roof.get(k)) for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'frac_traffic', 'frac_hbm', 'frac_model', 'kernel', 'kernel_ms',
+                                                  'algorithmic_bytes_per_launch', 'bytes_per_rollout_step', 'model_bytes_per_rollout_step',
+                                                  'record_bytes_per_launch')
+                     if k in roof}
+    c['roofline']['kernel_instance'] = _short(((cfg.get('launch') or {}).get('kernels') or {}).get(roof.get('kernel'), ''), 120)
+    if roof.get('regime'):
+        c['roofline']['regime'] = _short(roof['regime'], 160)
+    pk = roof.get('per_kernel') or {}
+    c['roofline']['per_kernel_ms'] = {k: _r(v['ms'], 4) for k, v in pk.items() if isinstance(v, dict) and 'ms' in v and not k.endswith('_all_outputs')}
+    if out.get('forward_only'):
+        f = out['forward_only']
+        c['forward_only'] = {'value': _r(f['value']), 'ms_per_step': _r(f['ms_per_step']), 'kernel_ms': _r(f['roofline'].get('kernel_ms')),
+                             'frac': _r(f['roofline'].get('frac'))}
+    if 'cpu_baseline' in out:
+        cb = out['cpu_baseline']
+        c['cpu_baseline'] = None if cb is None else {**{k: _r(cb.get(k)) for k in ('value', 'unit', 'cores', 'kind')},
+                                                    'sample': _short(cb.get('sample', ''), 420)}
+    ow = out.get('other_workloads') or {}
+    if ow:      # one number per side workload; everything else about them is in the detail file
+        c['other_ms_per_step'] = {k: _r(v.get('ms_per_step'), 4) for k, v in ow.items()}
+    c['detail'] = detail_file
+    line = json.dumps(c, separators=(',', ':'))
+    if len(line) >= COMPACT_LIMIT:      # never let an over-long string cost the round its measurement again
+        for k in ('other_ms_per_step', 'forward_only'):
+            c.pop(k, None)
+        c['roofline'].pop('per_kernel_ms', None)
+        c['config']['workload'] = _short(c['config']['workload'], 80)
+        if c.get('cpu_baseline'):
+            c['cpu_baseline']['sample'] = _short(c['cpu_baseline']['sample'], 120)
+        line = json.dumps(c, separators=(',', ':'))
+    assert len(line) < COMPACT_LIMIT, len(line)
+    return line
+
+
 def library_sha256():
     import hashlib
     from monoforce_amd import _lib
@@ -698,6 +887,8 @@ def main():
     ap.add_argument('--block', type=int, default=0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-others', action='store_true', help='headline workload only (no forward_only / sweep / side workloads)')
+    ap.add_argument('--detail', default=os.path.join(REPO, 'bench_detail.json'),
+                    help='where rank 0 writes the full record (per-kernel tables, batch sweep, side workloads, CPU legs); the stdout line stays < 4 KB')
     args = ap.parse_args()
 
     world_env = os.environ.get('WORLD_SIZE')
@@ -758,7 +949,19 @@ def main():
             out['other_workloads'] = others
         if not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(N, args.integrator, T, headline=args.workload) if not r.dist_on else None      # timed at N=1 only
-        print(json.dumps(out))
+        detail_file = None
+        try:
+            with open(args.detail, 'w') as f:
+                json.dump(out, f)
+            detail_file = os.path.relpath(args.detail, REPO) if os.path.abspath(args.detail).startswith(REPO + os.sep) else args.detail
+            scratch = os.path.join(REPO, 'gpurun_out')      # a copy where a gpurun call merges files back from
+            if os.path.isdir(scratch) and os.path.dirname(os.path.abspath(args.detail)) != scratch:
+                with open(os.path.join(scratch, os.path.basename(args.detail)), 'w') as f:
+                    json.dump(out, f)
+        except OSError as e:
+            print(f'bench.py: could not write {args.detail}: {e}', file=sys.stderr)
+        sys.stdout.flush()
+        print(compact_line(out, detail_file), flush=True)      # the LAST stdout line, < 4 KB: what the driver parses
     if r.dist_on:
         import torch.distributed as dist
         dist.destroy_process_group()

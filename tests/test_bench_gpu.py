@@ -19,16 +19,24 @@ def _run_bench(args, env_extra=None, drop=()):
     return subprocess.run([sys.executable, os.path.join(REPO, 'bench.py')] + args, env=env, capture_output=True, text=True, timeout=900)
 
 
+def _last_line_and_detail(r):
+    last = r.stdout.rstrip('\n').splitlines()[-1]              # the driver parses the LAST stdout line: compact, < 4 KB
+    line = json.loads(last)
+    assert len(last) < 4096
+    return line, json.load(open(line['detail'] if os.path.isabs(line['detail']) else os.path.join(REPO, line['detail'])))
+
+
 def test_bench_spawns_its_own_ranks():
     """`bench.py --gpus 2` with no launcher around it starts two ranks itself and says so in the JSON line."""
-    r = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '64', '--no-others', '--no-cpu-baseline'],
-                   {'MF_BENCH_SINGLE_DEVICE': '1', 'MF_BENCH_BACKEND': 'gloo'})
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = [ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1]
-    out = json.loads(line)
+    with tempfile.TemporaryDirectory() as td:
+        r = _run_bench(['--gpus', '2', '--steps', '2', '--warmup', '1', '--batch', '64', '--no-others', '--no-cpu-baseline',
+                        '--detail', os.path.join(td, 'd.json')], {'MF_BENCH_SINGLE_DEVICE': '1', 'MF_BENCH_BACKEND': 'gloo'})
+        assert r.returncode == 0, r.stderr[-2000:]
+        out, full = _last_line_and_detail(r)
     assert out['n_gpus'] == 2 and out['world_size'] == 2 and out['backend'] == 'gloo'
     assert out['scaling'] == 'weak' and out['config']['rollouts_per_gpu'] == 64 and out['config']['rollouts_total'] == 128
-    assert out['value'] > 0 and set(out['roofline']['per_kernel']) >= {'rollout_fwd_kernel', 'rollout_bwd_kernel'}
+    assert out['value'] > 0 and set(out['roofline']['per_kernel_ms']) >= {'rollout_fwd_kernel', 'rollout_bwd_kernel'}
+    assert set(full['roofline']['per_kernel']) >= {'rollout_fwd_kernel', 'rollout_bwd_kernel'} and 'cpu_baseline' not in out
 
 
 def test_bench_refuses_a_different_rank_count():

@@ -20,9 +20,21 @@ def _bench(args, env_extra, timeout=1500):
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_PORT')}
     env.update({'HSA_ENABLE_IPC_MODE_LEGACY': '0'})
     env.update(env_extra)
-    r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py')] + args, env=env, capture_output=True, text=True, timeout=timeout)
-    assert r.returncode == 0, r.stderr[-3000:]
-    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    with tempfile.TemporaryDirectory() as td:
+        detail = os.path.join(td, 'detail.json')
+        r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py')] + args + ['--detail', detail], env=env, capture_output=True, text=True,
+                           timeout=timeout)
+        assert r.returncode == 0, r.stderr[-3000:]
+        last = r.stdout.rstrip('\n').splitlines()[-1]          # what the driver parses: the LAST stdout line, compact
+        line = json.loads(last)
+        assert len(last) < 4096 and line['detail'] == detail and 'roofline' in line
+        full = json.load(open(detail))                         # tables, side workloads, kernel names: the detail file
+    for k in ('value', 'n_gpus', 'world_size', 'backend', 'scaling', 'steps', 'warmup'):
+        assert line[k] == (float('%.6g' % full[k]) if isinstance(full[k], float) else full[k]), k
+    assert line['comm_ms'] is None or line['comm_ms'] > 0
+    if 'other_workloads' in full:
+        assert set(line['other_ms_per_step']) == set(full['other_workloads'])
+    return full
 
 
 def _check_c5(out, world, backend):

@@ -117,7 +117,9 @@ def test_bench_through_its_multi_rank_code_on_one_gpu():
     r = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '4', '--warmup', '2', '--batch', '256',
                         '--no-others', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
-    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    last = r.stdout.rstrip('\n').splitlines()[-1]
+    out = json.loads(last)
+    assert len(last) < 4096
     assert out['backend'] == 'rccl' and out['world_size'] == 1 and out['n_gpus'] == 1
     assert out['comm_ms'] is not None and 0 < out['comm_ms'] < float('inf')      # (positive and finite; no timing bar: the host of a box can be slow)
     assert out['ms_per_step_ranks']['min'] <= out['ms_per_step_ranks']['max'] and out['value'] > 0

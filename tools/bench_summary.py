@@ -1,4 +1,4 @@
-"""One-screen summary of a bench.py JSON line: python tools/bench_summary.py gpurun_out/<tag>/bench.json"""
+"""One-screen summary of a bench.py DETAIL record (`--detail`, default bench_detail.json): python tools/bench_summary.py bench_detail.json"""
 import json, sys
 d = json.load(open(sys.argv[1]))
 print('c3: value %.4g  ms/step %.4f  roofline frac %.4f (%s %.4f ms)  launch %s' % (d['value'], d['ms_per_step'], d['roofline']['frac'], d['roofline']['kernel'], d['roofline']['kernel_ms'], (d['config'].get('launch') or {}).get('mode')))

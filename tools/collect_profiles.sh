@@ -6,17 +6,28 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT /tmp/mfprof      # (raw traces stay on the box under /tmp: gpurun_out/ is capped at 64 MiB; only summaries are written to $OUT)
 export TMPDIR=/tmp
 B="--no-cpu-baseline --no-others"
-timeout 900 python bench.py > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err
+timeout 900 python bench.py --detail $OUT/${TAG}_bench_default_detail.json > $OUT/${TAG}_bench_default.json 2> $OUT/bench_default.err      # (stdout: the compact line the driver parses; --detail: tables, sweep, side workloads)
 for w in c3f c3 c4 ref_nb; do
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/mfprof/prof_$w -o $w -- python bench.py --steps 20 --warmup 3 --workload $w $B > $OUT/${TAG}_${w}_bench_under_rocprof.json 2> $OUT/prof_$w.err
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/mfprof/prof_$w -o $w -- python bench.py --steps 20 --warmup 3 --workload $w $B --detail $OUT/${TAG}_${w}_bench_under_rocprof_detail.json > $OUT/${TAG}_${w}_bench_under_rocprof.json 2> $OUT/prof_$w.err
   f=$(find /tmp/mfprof/prof_$w -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && head -40 "$f" > $OUT/${TAG}_${w}_kernel_stats.csv
 done
 for c in FETCH_SIZE WRITE_SIZE; do
   for w in c3f c3; do      # (c4's PMC passes -- ~1000 dispatches per step, serialised by the counters -- run into the timeout: no c4 row)
-    timeout 240 rocprofv3 --pmc $c --output-format csv -d /tmp/mfprof/pmc_${c}_$w -o $w -- python bench.py --steps 4 --warmup 1 --workload $w $B > /dev/null 2> $OUT/pmc_${c}_$w.err
+    timeout 240 rocprofv3 --pmc $c --output-format csv -d /tmp/mfprof/pmc_${c}_$w -o $w -- python bench.py --steps 4 --warmup 1 --workload $w $B --detail /tmp/mfprof/d.json > /dev/null 2> $OUT/pmc_${c}_$w.err
     f=$(find /tmp/mfprof/pmc_${c}_$w -name "*counter_collection.csv" | head -1)
     [ -n "$f" ] && python tools/pmc_summary.py "$f" > $OUT/${TAG}_pmc_${c}_$w.txt
+  done
+done
+# ... and the saturated batches of the sweep (`batch_sweep` rows carry frac_traffic at 8192 / 16 384 / 32 768): the c3 step and
+# the plain forward (c3f) at those batches, same two counters
+for Bn in ${MF_SWEEP_PMC:-8192 16384 32768}; do
+  for c in FETCH_SIZE WRITE_SIZE; do
+    for w in c3f c3; do
+      timeout 240 rocprofv3 --pmc $c --output-format csv -d /tmp/mfprof/pmc_${c}_${w}_B$Bn -o $w -- python bench.py --steps 3 --warmup 1 --workload $w --batch $Bn $B --detail /tmp/mfprof/d.json > /dev/null 2> $OUT/pmc_${c}_${w}_B$Bn.err
+      f=$(find /tmp/mfprof/pmc_${c}_${w}_B$Bn -name "*counter_collection.csv" | head -1)
+      [ -n "$f" ] && python tools/pmc_summary.py "$f" > $OUT/${TAG}_pmc_${c}_${w}_B$Bn.txt
+    done
   done
 done
 # HBM bytes per launch of the hand-written kernels for bench.py's `roofline.traffic`: WRITE_SIZE + 2 x FETCH_SIZE (KiB; on
@@ -27,7 +38,8 @@ out, tag = sys.argv[1], sys.argv[2]
 names = {'rollout_fwd': 'rollout_fwd_kernel', 'rollout_bwd': 'rollout_bwd_kernel', 'lift_splat_fwd': 'lift_splat_fwd_kernel',
          'lift_splat_bwd': 'lift_splat_bwd_kernel'}
 res = {}
-for w in ('c3f', 'c3'):
+import os
+for w in ['c3f', 'c3'] + [f'{w}_B{b}' for b in os.environ.get('MF_SWEEP_PMC', '8192 16384 32768').split() for w in ('c3f', 'c3')]:
     per, calls = {}, {}
     for c, mult in (('FETCH_SIZE', 2), ('WRITE_SIZE', 1)):
         try:
