@@ -960,11 +960,13 @@ def main():
                     json.dump(out, f)
         except OSError as e:
             print(f'bench.py: could not write {args.detail}: {e}', file=sys.stderr)
-        sys.stdout.flush()
-        print(compact_line(out, detail_file), flush=True)      # the LAST stdout line, < 4 KB: what the driver parses
+        line = compact_line(out, detail_file)
     if r.dist_on:
         import torch.distributed as dist
-        dist.destroy_process_group()
+        dist.destroy_process_group()      # (before the line: whatever the collective library says on its way out must not follow it)
+    if r.rank == 0:
+        sys.stdout.flush()
+        print(line, flush=True)      # the LAST stdout line, < 4 KB: what the driver parses
 
 
 if __name__ == '__main__':

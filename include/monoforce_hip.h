@@ -203,10 +203,23 @@ typedef struct MfRolloutFwdBufs {
                            MF_LAYOUT_TIME_MAJOR): fills loss->loss.  NULL = plain rollout. */
 } MfRolloutFwdBufs;
 
-/* 1 where BOTH directions of this launch can carry the fused physics loss (MfRolloutLoss): float32 MF_MATH_FAST, default
- * integrator, rigid body of <= 4 points, time-major outputs, and few enough rollouts for the streaming backward; else 0 (run
- * mf_physics_loss_* on the outputs instead). */
+/* Can this launch carry the fused physics loss (MfRolloutLoss)?
+ *   1  BOTH directions, on the component-parallel kernels with the streaming backward: float32 MF_MATH_FAST, rigid body of <= 4 points,
+ *      time-major outputs, few enough rollouts (<= 2048; dynamics(): <= 1024).  The value: from the forward launch (default integrator),
+ *      from the backward launch (MF_LOSS_VALUE_IN_BACKWARD), or from mf_physics_loss_value_* on the written rows.
+ *   2  the BACKWARD of a saturated launch (round 6): the positions-only one-point-per-lane kernels (float32 MF_MATH_FAST, rigid body of <= 64
+ *      points, time-major, beyond the component-parallel / record-reading ranges: > 8192 rollouts of a 4-point body) form dL/dXs at the
+ *      stamped rows themselves -- pass MfRolloutBwdBufs.loss with flags = 0 and NO MfRolloutFwdBufs.loss; the value comes from
+ *      mf_physics_loss_value_* on the forward's rows.  The step loses the loss-gradient launch and the dense [T][B][3] gradient (98 MB at
+ *      16 384 rollouts, a tenth of its rows non-zero).
+ *   0  neither: run mf_physics_loss_* on the outputs. */
 int mf_rollout_loss_fusable(const MfRolloutDesc* desc);
+
+/* 1 where mf_rollout_bwd_f32 with a positions-only upstream (gXs or a fused loss; the other five NULL) sends the cell gradients of this
+ * launch through per-workgroup LDS windows (saturated launches of a <= 4-point body on ONE shared power-of-two map pair): a workgroup
+ * adds its window to gradient copy blockIdx % grad_copies once, at its end, so desc->grad_copies may stay small (32) -- the caller's
+ * reduction over the copies (mf_reduce_grad_copies_*) is what grows with them: 0.125 ms at 256 copies of a 256 x 256 pair. */
+int mf_rollout_bwd_window(const MfRolloutDesc* desc);
 
 /* Bytes of MfRolloutFwdBufs.rec / MfRolloutBwdBufs.rec for this launch shape; 0 where the kernels chosen for it keep no record
  * (then pass NULL).  The record pays while the launch is bound by the instruction stream of its waves: few rollouts of a small

@@ -70,7 +70,7 @@ class MfHeightmapDesc(C.Structure):
 
 
 # every symbol include/monoforce_hip.h declares; tests check the library exports all of them
-SYMBOLS = ['mf_rollout_force_stride', 'mf_rollout_fwd_f32', 'mf_rollout_fwd_f64', 'mf_rollout_default_state_f32', 'mf_rollout_default_state_f64', 'mf_rollout_bwd_f32', 'mf_rollout_bwd_f64', 'mf_rollout_bwd_wants_gcontrols', 'mf_rollout_record_bytes', 'mf_rollout_record_bytes_f64', 'mf_rollout_fwd_stages_zmu', 'mf_rollout_loss_fusable', 'mf_bev_splat_workspace_bytes', 'mf_bev_splat_prepare', 'mf_bev_splat_prepare_cameras', 'mf_bev_splat_prepare_rig',
+SYMBOLS = ['mf_rollout_force_stride', 'mf_rollout_fwd_f32', 'mf_rollout_fwd_f64', 'mf_rollout_default_state_f32', 'mf_rollout_default_state_f64', 'mf_rollout_bwd_f32', 'mf_rollout_bwd_f64', 'mf_rollout_bwd_wants_gcontrols', 'mf_rollout_record_bytes', 'mf_rollout_record_bytes_f64', 'mf_rollout_fwd_stages_zmu', 'mf_rollout_loss_fusable', 'mf_rollout_bwd_window', 'mf_bev_splat_workspace_bytes', 'mf_bev_splat_prepare', 'mf_bev_splat_prepare_cameras', 'mf_bev_splat_prepare_rig',
            'mf_bev_splat_fwd_f32', 'mf_bev_splat_fwd_f64', 'mf_bev_splat_bwd_f32', 'mf_bev_splat_bwd_f64',
            'mf_bev_lift_splat_fwd_f32', 'mf_bev_lift_splat_fwd_f64', 'mf_bev_lift_splat_bwd_f32', 'mf_bev_lift_splat_bwd_f64',
            'mf_physics_loss_fwd_f32', 'mf_physics_loss_fwd_f64', 'mf_physics_loss_bwd_f32', 'mf_physics_loss_bwd_f64', 'mf_physics_loss_value_f32', 'mf_physics_loss_value_f64', 'mf_nearest_steps_f32', 'mf_nearest_steps_f64', 'mf_reduce_grad_copies_f32', 'mf_reduce_grad_copies_f64', 'mf_estimate_heightmap_f32', 'mf_interpolate_grid_f32', 'mf_interpolate_grid_f64', 'mf_terrain_stage_fwd_f32', 'mf_terrain_stage_bwd_f32', 'mf_last_error', 'mf_last_launch', 'mf_version', 'mf_sizeof']

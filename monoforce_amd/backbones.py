@@ -162,22 +162,35 @@ class BatchNorm2dCounted(nn.BatchNorm2d):
 class _CounterBank:
     """All `num_batches_tracked` buffers of a model as views of ONE int64 row, bumped by one kernel per training forward
     instead of one per batch-norm layer (70 launches per encoder step).  `.to()` / `.cuda()` re-create the buffers one by
-    one: the bank notices (device or base changed) and gathers them again, outside any stream capture."""
+    one: the bank notices (device or base changed) and gathers them again, outside any stream capture.
+    A tracked layer that is no longer its parent's child -- `SyncBatchNorm.convert_sync_batchnorm` replaced it; the replacement shares
+    the old buffer tensor and counts for itself -- leaves the bank (it was bumped twice per step), as do layers that never
+    run (`sites` lists (parent, name, module): the owner's live batch norms)."""
 
-    def __init__(self, mods):
-        self.mods, self.flat = mods, None
+    def __init__(self, sites):
+        self.sites, self.flat = list(sites), None
+
+    @property
+    def mods(self):
+        return [m for _, _, m in self.sites]
 
     def _gather(self):
-        vals = torch.stack([m.num_batches_tracked.reshape(()) for m in self.mods])
+        mods = self.mods
+        vals = torch.stack([m.num_batches_tracked.reshape(()) for m in mods])
         self.flat = vals.clone()
-        for i, m in enumerate(self.mods):
+        for i, m in enumerate(mods):
             m._buffers['num_batches_tracked'] = self.flat[i]
 
     def __call__(self, root, args=None):
-        if not root.training or not self.mods:
+        if not root.training or not self.sites:
             return
-        m0 = self.mods[0].num_batches_tracked
-        if self.flat is None or m0._base is not self.flat or any(m.num_batches_tracked._base is not self.flat for m in self.mods[1:]):
+        live = [st for st in self.sites if st[0]._modules.get(st[1]) is st[2] and type(st[2]) is BatchNorm2dCounted]
+        if len(live) != len(self.sites):      # some layers were replaced: they keep their (old) buffer and count for themselves
+            self.sites, self.flat = live, None
+            if not live:
+                return
+        mods = self.mods
+        if self.flat is None or any(m.num_batches_tracked._base is not self.flat for m in mods):
             self._gather()
         self.flat.add_(1)
 
@@ -191,11 +204,19 @@ def fuse_batchnorm_counters(root, owners=None):
     if not lean():
         return root
     for owner in (owners if owners is not None else [root]):
-        mods = [m for m in owner.modules() if type(m) in (nn.BatchNorm2d, BatchNorm2dCounted) and m.track_running_stats
-                and m.momentum is not None and m.num_batches_tracked is not None]
-        for m in mods:
+        # layers that never run keep their own counter at 0, like the reference's (lss.py:78-92 walks the EfficientNet trunk up to its
+        # blocks: the head's `_bn1` is loaded from the checkpoint and never called)
+        idle = {id(getattr(e, '_bn1', None)) for e in owner.modules() if isinstance(e, EfficientNetB0)}
+        sites, seen = [], set(idle)
+        for parent in owner.modules():
+            for name, m in parent._modules.items():
+                if (type(m) in (nn.BatchNorm2d, BatchNorm2dCounted) and m.track_running_stats and m.momentum is not None
+                        and m.num_batches_tracked is not None and id(m) not in seen):      # (a layer shared by two parents counts once)
+                    seen.add(id(m))
+                    sites.append((parent, name, m))
+        for _, _, m in sites:
             m.__class__ = BatchNorm2dCounted
-        object.__setattr__(owner, '_bn_counter_bank', _CounterBank(mods))
+        object.__setattr__(owner, '_bn_counter_bank', _CounterBank(sites))
     return root
 
 

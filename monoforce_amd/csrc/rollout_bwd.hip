@@ -11,6 +11,46 @@ __global__ void __launch_bounds__(256) interleave_maps_bwd_kernel(const S* __res
   if (i < n) out[i] = cp::Pk2<S>{z[i], mu[i]};
 }
 
+long long mw_record_bytes(const MfRolloutDesc* d, int scalar_bytes);   // rollout_bwd_mw_fast.hip
+
+// The launches of a positions-only upstream that go to the XS_ONLY one-point-per-lane kernels (rollout_bwd_kernel.h): float32 fast math, rigid
+// body, beyond the component-parallel range (N <= 4: > two waves per SIMD) and the record-reading multi-wave range (5..64 points: > two waves per
+// SIMD), one point per lane inside a wave, from half a wave per SIMD up.  These kernels carry the fused physics loss (LOSS) as well.
+static bool xs_bwd_off() { static const bool off = getenv("MF_BWD_XS") && atoi(getenv("MF_BWD_XS")) == 0; return off; }
+static long long xs_bwd_min_waves() {
+  static const long long v = getenv("MF_BWD_XS_MIN_WAVES") ? atoll(getenv("MF_BWD_XS_MIN_WAVES")) : device_simds() / 2;
+  return v;
+}
+static bool xs_bwd_shape(const MfRolloutDesc* d, const LaneMap& m) {
+  return !xs_bwd_off() && m.PPL == 1 && m.G <= 64 && (long long)d->B * m.G >= xs_bwd_min_waves() * 64;
+}
+bool xs_loss_fusable(const MfRolloutDesc* d) {
+  static const bool off = getenv("MF_BWD_XS_LOSS") && atoi(getenv("MF_BWD_XS_LOSS")) == 0;      // A/B: the unfused route (dense dL/dXs rows)
+  if (off || !d || d->B <= 0 || d->T <= 0 || d->N <= 0 || d->N > 64 || d->has_joints) return false;
+  if (d->math_mode != MF_MATH_FAST || d->layout != MF_LAYOUT_TIME_MAJOR) return false;
+  if (d->integrator != MF_INTEG_ODEINT_EULER && d->integrator != MF_INTEG_DYNAMICS) return false;
+  if (d->points_per_lane == MF_LANES_COMPONENT || d->points_per_lane == 4) return false;
+  MfRolloutBwdBufs none{};
+  if (use_component_parallel_bwd(d, &none, 4)) return false;      // the component-parallel kernels' range
+  if (mw_record_bytes(d, 4) > 0) return false;                     // the record-reading multi-wave kernels' range
+  return xs_bwd_shape(d, choose_lane_map(d->B, d->N, d->points_per_lane));
+}
+
+// the positions-only launches whose cell gradients leave through the workgroup's LDS window (rollout_bwd_kernel.h WIN): four lanes per rollout
+// on ONE shared map pair with a power-of-two side
+static bool xs_win_off() { static const bool off = getenv("MF_BWD_WIN") && atoi(getenv("MF_BWD_WIN")) == 0; return off; }
+static bool xs_win_shape(const MfRolloutDesc* d, const LaneMap& m) {
+  return !xs_win_off() && d->map_shared && m.G == 4 && d->H == d->W && (d->H & (d->H - 1)) == 0;
+}
+bool xs_bwd_window(const MfRolloutDesc* d) {
+  if (!d || d->B <= 0 || d->N <= 0 || d->N > 4 || d->has_joints || d->math_mode != MF_MATH_FAST) return false;
+  if (d->points_per_lane == MF_LANES_COMPONENT || d->points_per_lane == 4) return false;
+  MfRolloutBwdBufs none{};
+  if (use_component_parallel_bwd(d, &none, 4)) return false;
+  const LaneMap m = choose_lane_map(d->B, d->N, d->points_per_lane);
+  return xs_bwd_shape(d, m) && xs_win_shape(d, m);
+}
+
 template <typename S>
 static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* stream) {
   MF_REQUIRE(d && p, MF_ERR_INVALID, "rollout_bwd: null descriptor");
@@ -48,7 +88,7 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
   a.rec = nullptr;
   a.zmu = nullptr;
   a.loss_T2 = 0; a.loss_gt = nullptr; a.loss_row_stamp = nullptr; a.loss_row_w = nullptr; a.loss_gloss = nullptr; a.loss_inv_count = (S)0;
-  a.loss_partial = nullptr; a.loss_ticket = nullptr; a.loss_out = nullptr;
+  a.loss_partial = nullptr; a.loss_ticket = nullptr; a.loss_out = nullptr; a.loss_near = nullptr; a.loss_w = nullptr;
   MF_REQUIRE(!p->gjoint_angles || p->joint_angles, MF_ERR_INVALID, "rollout_bwd: gjoint_angles without joint_angles");
   MF_REQUIRE(!d->has_joints == !p->joint_angles, MF_ERR_INVALID, "rollout_bwd: joint_angles must be given exactly when desc->has_joints is set");
   MF_REQUIRE(!p->joint_angles || d->n_tracks == 4, MF_ERR_INVALID, "rollout_bwd: joint angles need the 4 driving parts of robot 'marv'");
@@ -58,13 +98,19 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
   a.Xraw = (const S*)p->Xraw; a.Xds = (const S*)p->Xds; a.Rs = (const S*)p->Rs; a.Om = (const S*)p->Omegas;
   if (p->loss) {      // the forward's fused physics loss: dL/dXs is formed inside the kernel from Xs, the ground truth and gloss
     const MfRolloutLoss* L = p->loss;
-    MF_REQUIRE((sizeof(S) == 4 || d->points_per_lane == MF_LANES_COMPONENT) && cp_loss_fusable(d) && p->rec && !p->joint_angles, MF_ERR_UNSUPPORTED,
-               "rollout_bwd: this launch cannot carry the fused physics loss (mf_rollout_loss_fusable; the forward's record is required)");
+    const bool loss_cp = (sizeof(S) == 4 || d->points_per_lane == MF_LANES_COMPONENT) && cp_loss_fusable(d) && p->rec && !p->joint_angles;
+    const bool loss_xs = !loss_cp && sizeof(S) == 4 && xs_loss_fusable(d) && !p->joint_angles && !(L->flags & MF_LOSS_VALUE_IN_BACKWARD);
+    MF_REQUIRE(loss_cp || loss_xs, MF_ERR_UNSUPPORTED,
+               "rollout_bwd: this launch cannot carry the fused physics loss (mf_rollout_loss_fusable: 1 = the streaming component-parallel backward, "
+               "the forward's record required; 2 = the saturated positions-only kernels, no MF_LOSS_VALUE_IN_BACKWARD)");
+    MF_REQUIRE((long long)d->B * L->T2 * 3 * (long long)sizeof(S) < (1ll << 32), MF_ERR_UNSUPPORTED, "rollout_bwd: ground truth of 4 GiB or more");
     MF_REQUIRE(!p->gXs && !p->gXds && !p->gRs && !p->gOmegas && !p->gFs && !p->gFf, MF_ERR_INVALID,
                "rollout_bwd: with a fused loss the six upstream gradients must be NULL");
     MF_REQUIRE(L->T2 > 0 && L->gt && L->row_stamp && L->row_w && L->gloss && L->Xs, MF_ERR_INVALID, "rollout_bwd: incomplete MfRolloutLoss");
     a.loss_T2 = L->T2; a.loss_gt = (const S*)L->gt; a.loss_row_stamp = L->row_stamp; a.loss_row_w = (const S*)L->row_w; a.loss_gloss = (const S*)L->gloss;
     a.loss_inv_count = (S)(1.0 / ((double)d->B * L->T2 * 3));
+    MF_REQUIRE(!loss_xs || (L->near && L->w), MF_ERR_INVALID, "rollout_bwd: the saturated fused loss reads MfRolloutLoss.near and .w");
+    a.loss_near = L->near; a.loss_w = (const S*)L->w;
     if (L->flags & MF_LOSS_VALUE_IN_BACKWARD) {      // the fetching waves also form the loss value
       MF_REQUIRE(L->partial && L->ticket && L->loss, MF_ERR_INVALID, "rollout_bwd: MF_LOSS_VALUE_IN_BACKWARD needs MfRolloutLoss.partial / ticket / loss");
       a.loss_partial = (S*)L->partial; a.loss_ticket = L->ticket; a.loss_out = (S*)L->loss;
@@ -134,13 +180,12 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
     // positions-only upstream (physics_loss) on a one-point-per-lane mapping inside a wave, from half a wave per SIMD up: the XS_ONLY
     // kernels -- and, for ONE shared map pair with a friction map, the interleaved (z, mu) copy (the caller's staged pair, or the
     // scratch it offers, refilled here: one 65 536-cell pass in front of a launch of >= 1 ms).  MF_BWD_XS=0 / MF_BWD_XS_ZMU=0: A/B.
-    static const bool xs_off = getenv("MF_BWD_XS") && atoi(getenv("MF_BWD_XS")) == 0;
     static const bool xs_zmu_off = getenv("MF_BWD_XS_ZMU") && atoi(getenv("MF_BWD_XS_ZMU")) == 0;
-    const bool xs_only = p->gXs && !p->gXds && !p->gRs && !p->gOmegas && !p->gFs && !p->gFf;
+    const bool xs_only = (p->gXs || p->loss) && !p->gXds && !p->gRs && !p->gOmegas && !p->gFs && !p->gFf;
+    const bool fused = p->loss != nullptr;      // LOSS instantiations: dL/dXs formed from the Xs rows, the ground truth and the stamp tables
     // (from half a wave per SIMD: right above the component-parallel kernels' range -- 10 240 / 12 288 / 14 336 rollouts of the 4-point body
     //  1.14 / 1.39 / 1.60 ms on the general kernels, 0.91 / 0.90 / 0.93 here, tools/ab_between.sh; MF_BWD_XS_MIN_WAVES overrides)
-    static const long long xs_min_waves = getenv("MF_BWD_XS_MIN_WAVES") ? atoll(getenv("MF_BWD_XS_MIN_WAVES")) : device_simds() / 2;
-    if (!xs_off && xs_only && m.PPL == 1 && m.G <= 64 && (long long)d->B * m.G >= xs_min_waves * 64) {
+    if (xs_only && xs_bwd_shape(d, m)) {
       RolloutBwdArgs<float> ax = af;
       bool zmu = false;
       if (!xs_zmu_off && d->map_shared && p->mu && (p->zmu || p->zmu_scratch) && (long long)d->H * d->W * 8 < (1ll << 31)) {
@@ -155,22 +200,32 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
       }
       // ... and, four lanes per rollout on ONE shared map pair: the accumulators' writes go to a 128 x 128-cell LDS window per workgroup
       // (rollout_bwd_kernel.h WIN; 128 KB of LDS = one workgroup per CU: 256 threads at one wave per SIMD, 512 from two up).  MF_BWD_WIN=0: A/B.
-      static const bool win_off = getenv("MF_BWD_WIN") && atoi(getenv("MF_BWD_WIN")) == 0;
-      if (!win_off && d->map_shared && m.G == 4 && d->H == d->W && (d->H & (d->H - 1)) == 0) {      // (power-of-two side: cell -> window row / column by shift and mask)
+      if (xs_win_shape(d, m)) {      // (power-of-two side: cell -> window row / column by shift and mask)
         const long long waves = ((long long)d->B * m.G + 63) / 64;
         const bool two = waves >= 2ll * device_simds();      // (two waves per SIMD: eight-wave workgroups, accumulator carry-over)
+        if (fused) return launch_rollout_bwd_xs_win_loss_fast_f32(ax, m, d->integrator, two ? 512 : 256, zmu, two, st);
         return launch_rollout_bwd_xs_win_fast_f32(ax, m, d->integrator, two ? 512 : 256, zmu, two, st);
       }
+      if (fused) return launch_rollout_bwd_xs_loss_fast_f32(ax, m, d->integrator, block, zmu, st);
       return launch_rollout_bwd_xs_fast_f32(ax, m, d->integrator, block, zmu, st);
     }
+    MF_REQUIRE(!fused, MF_ERR_UNSUPPORTED, "rollout_bwd: this launch cannot carry the fused physics loss (mf_rollout_loss_fusable)");
     if ((long long)d->B * m.G >= 3ll * device_cus() / 4 * 64) return launch_rollout_bwd_carry_fast_f32(af, m, d->integrator, block, st);
     return launch_rollout_bwd_fast_f32(af, m, d->integrator, block, st);
   }
+  MF_REQUIRE(!p->loss, MF_ERR_UNSUPPORTED, "rollout_bwd: this launch cannot carry the fused physics loss (mf_rollout_loss_fusable)");
   return launch_rollout_bwd<S, false>(a, m, d->integrator, block, st);
 }
 
 }  // namespace mf
 
+// 0 = no; 1 = both directions on the component-parallel kernels with the streaming backward (value in the forward launch, in the backward
+// launch -- MF_LOSS_VALUE_IN_BACKWARD -- or from mf_physics_loss_value_*); 2 = the BACKWARD of a saturated launch (positions-only one-point-
+// per-lane kernels): pass MfRolloutBwdBufs.loss with flags = 0, take the value from mf_physics_loss_value_* on the forward's rows
+extern "C" int mf_rollout_loss_fusable(const MfRolloutDesc* d) { return mf::cp_loss_fusable(d) ? 1 : (mf::xs_loss_fusable(d) ? 2 : 0); }
+// 1 where a positions-only backward of this shape (float32) sends its cell gradients through the workgroups' LDS windows: a workgroup then adds
+// its window to gradient copy blockIdx % grad_copies ONCE, at its end -- few copies suffice (the caller's reduction over them is what grows)
+extern "C" int mf_rollout_bwd_window(const MfRolloutDesc* d) { return mf::xs_bwd_window(d) ? 1 : 0; }
 extern "C" int mf_rollout_bwd_f32(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* s) {
   return mf::rollout_bwd<float>(d, p, s);
 }

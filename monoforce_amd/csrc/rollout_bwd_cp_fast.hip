@@ -77,7 +77,6 @@ bool cp_bwd_wants_zmu(const MfRolloutDesc* d, bool has_rec, bool has_mu) {
 bool cp_loss_in_forward(const MfRolloutDesc* d) { return cp_loss_fusable(d) && d->integrator == MF_INTEG_ODEINT_EULER; }
 
 }  // namespace mf
-extern "C" int mf_rollout_loss_fusable(const MfRolloutDesc* d) { return mf::cp_loss_fusable(d) ? 1 : 0; }
 extern "C" int mf_rollout_bwd_wants_gcontrols(const MfRolloutDesc* d) { return (d && mf::cp_bwd_covers(d, d->has_joints != 0)) ? 0 : 1; }
 namespace mf { long long mw_record_bytes(const MfRolloutDesc* d, int scalar_bytes); }   // rollout_bwd_mw_fast.hip
 extern "C" long long mf_rollout_record_bytes(const MfRolloutDesc* d) {

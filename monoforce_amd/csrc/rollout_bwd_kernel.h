@@ -42,6 +42,10 @@ struct RolloutBwdArgs {
   S* loss_partial;         // MF_LOSS_VALUE_IN_BACKWARD (NULL otherwise): per-workgroup partial sums, the ticket, the mean
   unsigned* loss_ticket;
   S* loss_out;
+  // (round 6, appended: the offsets of everything above are those of round 5) the per-STAMP tables of the fused loss, for the one-point-per-
+  // lane LOSS kernels: near[j] = output row of stamp j (strictly increasing), w[j] = its weight
+  const int* loss_near;
+  const S* loss_w;
 };
 
 #ifdef MF_NO_ATOMICS
@@ -127,7 +131,16 @@ __device__ __forceinline__ void win_close(const RolloutBwdArgs<S>& a, const S* w
     }
   }
 }
-template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS, bool CARRY, bool XS_ONLY, bool ZMU, bool WIN>
+// LOSS (round 6; XS_ONLY launches): `physics_loss` (losses.py:102-127) inside the launch -- a.gXs points at the forward's own Xs rows and the
+// kernel forms dL/dXs at the stamped rows itself from Xs, the ground truth and the stamp's weight (the formula of physics_loss.hip,
+// same rounding): no [T][B][3] gradient tensor to clear, fill and read (98 MB at 16 384 rollouts, 10 % of its rows non-zero), no loss-
+// gradient launch.  The row tables are indexed by the (wave-uniform) output row: scalar loads.
+template <typename S>
+__device__ __forceinline__ S xs_loss_grad(S scale, S xs, S g, S w) {      // scale = 2 gloss / (B T2 3)
+#pragma clang fp contract(off)
+  return scale * w * (xs * w - g * w);
+}
+template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS, bool CARRY, bool XS_ONLY, bool ZMU, bool WIN, bool LOSS = false>
 __device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* win, const unsigned win_flat0, const unsigned win_shift) {
   using M = Mth<S, FAST>;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -204,7 +217,19 @@ __device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* 
   struct UpIn {
     S gXs[3], gXds[3], gRs[9], gOm[3];
     S gFs[PPL][3], gFf[PPL][3];
+    S lg[3], lw;        // LOSS: ground truth of the row's stamp, its weight (raw loads; the gradient is formed where the row is consumed)
+    bool stamped;       // LOSS: the row carries a stamp (wave-uniform)
   };
+  static_assert(!LOSS || XS_ONLY, "the fused physics loss is a positions-only upstream");
+  const S loss_scale = LOSS ? (S)2 * a.loss_gloss[0] * a.loss_inv_count : zero;      // as csrc/physics_loss.hip: (2 gloss) / count
+  const S* const loss_gt_b = LOSS ? a.loss_gt + (size_t)b * (size_t)a.loss_T2 * 3u : nullptr;
+  // The rows are visited from the last one down and the stamps' rows increase with the stamp: ONE current stamp (index, row, weight -- wave-
+  // uniform, in scalar registers) is compared with the row at hand and stepped down when it is met.  Its successor's row and weight are
+  // scalar loads issued a whole iteration before their first use, and the ground-truth address depends on no load at all (first attempt:
+  // row_stamp[row] -> address, a dependent scalar load in front of the step's vector loads: 0.93 -> 1.13 ms at 16 384 rollouts).
+  int l_j = LOSS ? a.loss_T2 - 1 : 0;
+  int l_row = LOSS ? a.loss_near[l_j] : -1;
+  S l_w = LOSS ? a.loss_w[l_j] : zero;
   const int n_steps = (INTEG == MF_INTEG_ODEINT_EULER) ? a.T - 1 : a.T;
   // Running pointers to the rows of the step being prefetched: stepping them back by wave-uniform deltas replaces a dozen
   // 64-bit row * stride multiplications per iteration.
@@ -212,6 +237,7 @@ __device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* 
     const S *x, *xd, *w, *R, *c, *t, *g1, *g2, *g3, *g4;
     const S* f1[PPL];
     const S* f2[PPL];
+    int trow;           // LOSS: time index of the output row g1 points at (wave-uniform)
   };
   auto make_ptrs = [&](int m, Ptrs& p) {       // rows of step m: the state it started from, the upstream of the row it produced
     const size_t in_row = row0 + (size_t)(INTEG == MF_INTEG_ODEINT_EULER ? m : m - 1) * row_stride;   // (m - 1 unused for m = 0)
@@ -221,6 +247,7 @@ __device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* 
     p.x = a.Xraw + in_row * 3; p.xd = a.Xds + in_row * 3; p.w = a.Om + in_row * 3; p.R = a.Rs + in_row * 9;
     p.c = ctrl + (size_t)m * 2; p.t = a.ts + m;
     p.g1 = a.gXs + out_row * a.sXs; p.g2 = a.gXds + out_row * a.sXds; p.g3 = a.gOm + out_row * a.sOm; p.g4 = a.gRs + out_row * a.sRs;
+    p.trow = INTEG == MF_INTEG_ODEINT_EULER ? min(m + 1, a.T - 1) : m;
 #pragma unroll
     for (int j = 0; j < PPL; ++j) {
       const size_t pt = out_row * a.N + min(gl * PPL + j, a.N - 1);   // clamped: inactive slots read a valid row, masked at use
@@ -233,6 +260,7 @@ __device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* 
   auto step_back = [&](Ptrs& p, size_t k) {    // k = 1: one step earlier; k = 0: stay (the prefetch of step 0 repeats itself)
     p.x -= k * d3; p.xd -= k * d3; p.w -= k * d3; p.R -= k * d9; p.c -= k * 2; p.t -= k;
     p.g1 -= k * dg1; p.g2 -= k * dg2; p.g3 -= k * dg3; p.g4 -= k * dg4;
+    p.trow -= (int)k;
 #pragma unroll
     for (int j = 0; j < PPL; ++j) { p.f1[j] -= k * df1; p.f2[j] -= k * df2; }
   };
@@ -254,6 +282,18 @@ __device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* 
     // absent upstream gradients point at a zero row with stride 0 (host side), so these loads are unconditional
 #pragma unroll
     for (int c = 0; c < 3; ++c) u.gXs[c] = p.g1[c];
+    if constexpr (LOSS) {      // (unconditional loads: an unstamped row reads the current stamp's ground truth -- the same line again -- masked at use)
+      const int tr = __builtin_amdgcn_readfirstlane(p.trow);
+      u.stamped = tr == l_row;
+      u.lw = l_w;
+      const S* g = loss_gt_b + (size_t)(unsigned)max(l_j, 0) * 3u;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) u.lg[c] = g[c];
+      l_j = __builtin_amdgcn_readfirstlane(l_j - (u.stamped ? 1 : 0));
+      const int jn = max(l_j, 0);
+      l_row = l_j >= 0 ? a.loss_near[jn] : -1;      // (first used by the NEXT call: a whole iteration for the scalar loads to land)
+      l_w = a.loss_w[jn];
+    }
     if constexpr (!XS_ONLY) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) { u.gXds[c] = p.g2[c]; u.gOm[c] = p.g3[c]; }
@@ -266,13 +306,18 @@ __device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* 
     }
   };
   auto add_upstream_state = [&](const UpIn& u) {
+    S g[3] = {u.gXs[0], u.gXs[1], u.gXs[2]};
+    if constexpr (LOSS) {      // dL/dXs of this row: masked by the stamp, not by a zero weight (an unstamped row of a diverged rollout may hold inf / NaN)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) g[c] = u.stamped ? xs_loss_grad(loss_scale, u.gXs[c], u.lg[c], u.lw) : zero;
+    }
     if constexpr (UNSUM) {
       const S ms = up_lane * a.sink;
-      lx[0] += up_lane * u.gXs[0]; lx[1] += up_lane * u.gXs[1]; lx[2] += up_lane * u.gXs[2];
-      lR[2] += u.gXs[0] * ms; lR[5] += u.gXs[1] * ms; lR[8] += u.gXs[2] * ms;
+      lx[0] += up_lane * g[0]; lx[1] += up_lane * g[1]; lx[2] += up_lane * g[2];
+      lR[2] += g[0] * ms; lR[5] += g[1] * ms; lR[8] += g[2] * ms;
     } else {
-    lx[0] += u.gXs[0]; lx[1] += u.gXs[1]; lx[2] += u.gXs[2];
-    lR[2] += u.gXs[0] * a.sink; lR[5] += u.gXs[1] * a.sink; lR[8] += u.gXs[2] * a.sink;   // Xs = x + R[:,2] * sink
+    lx[0] += g[0]; lx[1] += g[1]; lx[2] += g[2];
+    lR[2] += g[0] * a.sink; lR[5] += g[1] * a.sink; lR[8] += g[2] * a.sink;   // Xs = x + R[:,2] * sink
     }
     if constexpr (!XS_ONLY) {
       lxd[0] += u.gXds[0]; lxd[1] += u.gXds[1]; lxd[2] += u.gXds[2];
@@ -887,7 +932,7 @@ __device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* 
   }
 }
 
-template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS = false, bool CARRY = true, bool XS_ONLY = false, bool ZMU = false, bool WIN = false>
+template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS = false, bool CARRY = true, bool XS_ONLY = false, bool ZMU = false, bool WIN = false, bool LOSS = false>
 __global__ void __launch_bounds__(WIN ? 512 : (G > 256 ? G : 256)) rollout_bwd_kernel(const RolloutBwdArgs<S> a) {
   if constexpr (WIN) {
     static_assert(G <= 64 && sizeof(S) == 4, "the LDS gradient window serves float32 rollouts inside a wave");
@@ -896,11 +941,11 @@ __global__ void __launch_bounds__(WIN ? 512 : (G > 256 ? G : 256)) rollout_bwd_k
     win_open<S, FAST>(a, win, (int)((blockIdx.x * blockDim.x) / G), &wx0, &wy0);
     __syncthreads();
     const unsigned sh = 31u - (unsigned)__builtin_clz((unsigned)a.H);      // H = 2^sh (host-checked)
-    rollout_bwd_body<S, G, PPL, INTEG, FAST, JOINTS, CARRY, XS_ONLY, ZMU, true>(a, win, (unsigned)wy0 + ((unsigned)wx0 << sh), sh);
+    rollout_bwd_body<S, G, PPL, INTEG, FAST, JOINTS, CARRY, XS_ONLY, ZMU, true, LOSS>(a, win, (unsigned)wy0 + ((unsigned)wx0 << sh), sh);
     __syncthreads();
     win_close(a, win, wx0, wy0);
   } else {
-    rollout_bwd_body<S, G, PPL, INTEG, FAST, JOINTS, CARRY, XS_ONLY, ZMU, false>(a, nullptr, 0, 0);
+    rollout_bwd_body<S, G, PPL, INTEG, FAST, JOINTS, CARRY, XS_ONLY, ZMU, false, LOSS>(a, nullptr, 0, 0);
   }
 }
 
@@ -932,7 +977,7 @@ int launch_rollout_bwd(const RolloutBwdArgs<S>& a, LaneMap m, int integ, int blo
 
 // the positions-only (XS_ONLY) instantiations with accumulator carry-over, one point per lane inside a wave (G = 4 .. 64), plain or
 // interleaved maps: the saturated launches of small bodies (rollout_bwd_xs_fast.hip)
-template <typename S, bool ZMU, bool WIN = false, bool CARRY = true>
+template <typename S, bool ZMU, bool WIN = false, bool CARRY = true, bool LOSS = false>
 int launch_rollout_bwd_xs(const RolloutBwdArgs<S>& a, LaneMap m, int integ, int block, hipStream_t st) {
   const long long threads = (long long)a.B * m.G;
   const unsigned grid = (unsigned)((threads + block - 1) / block);
@@ -941,9 +986,9 @@ int launch_rollout_bwd_xs(const RolloutBwdArgs<S>& a, LaneMap m, int integ, int 
   if (!launched && m.G == G_ && m.PPL == 1) {                                                                                                     \
     launched = true;                                                                                                                              \
     if (integ == MF_INTEG_DYNAMICS)                                                                                                               \
-      MF_KLAUNCH((rollout_bwd_kernel<S, G_, 1, MF_INTEG_DYNAMICS, true, false, CARRY, true, ZMU, WIN>), dim3(grid), dim3(block), 0, st, a);       \
+      MF_KLAUNCH((rollout_bwd_kernel<S, G_, 1, MF_INTEG_DYNAMICS, true, false, CARRY, true, ZMU, WIN, LOSS>), dim3(grid), dim3(block), 0, st, a);       \
     else                                                                                                                                          \
-      MF_KLAUNCH((rollout_bwd_kernel<S, G_, 1, MF_INTEG_ODEINT_EULER, true, false, CARRY, true, ZMU, WIN>), dim3(grid), dim3(block), 0, st, a);   \
+      MF_KLAUNCH((rollout_bwd_kernel<S, G_, 1, MF_INTEG_ODEINT_EULER, true, false, CARRY, true, ZMU, WIN, LOSS>), dim3(grid), dim3(block), 0, st, a);   \
   }
   MF_CASE(4)
   if constexpr (!WIN) { MF_CASE(8) MF_CASE(16) MF_CASE(32) MF_CASE(64) }
@@ -955,6 +1000,9 @@ int launch_rollout_bwd_xs(const RolloutBwdArgs<S>& a, LaneMap m, int integ, int 
 }
 int launch_rollout_bwd_xs_fast_f32(const RolloutBwdArgs<float>& a, LaneMap m, int integ, int block, bool zmu, hipStream_t st);      // rollout_bwd_xs_fast.hip
 int launch_rollout_bwd_xs_win_fast_f32(const RolloutBwdArgs<float>& a, LaneMap m, int integ, int block, bool zmu, bool carry, hipStream_t st);  // rollout_bwd_xs_win_fast.hip
+// ... the same with the fused physics loss (LOSS; a.loss_gt set): rollout_bwd_xs_loss_fast.hip, rollout_bwd_xs_win_loss_fast.hip
+int launch_rollout_bwd_xs_loss_fast_f32(const RolloutBwdArgs<float>& a, LaneMap m, int integ, int block, bool zmu, hipStream_t st);
+int launch_rollout_bwd_xs_win_loss_fast_f32(const RolloutBwdArgs<float>& a, LaneMap m, int integ, int block, bool zmu, bool carry, hipStream_t st);
 
 // defined in rollout_bwd_fast.hip (plain flush) and rollout_bwd_carry_fast.hip (accumulator carry-over)
 int launch_rollout_bwd_fast_f32(const RolloutBwdArgs<float>& a, LaneMap m, int integ, int block, hipStream_t st);

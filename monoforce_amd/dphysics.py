@@ -576,8 +576,9 @@ class DPhysics(torch.nn.Module):
         `value_in_backward` (MF_LOSS_VALUE_IN_BACKWARD): for a caller that ALWAYS calls `loss.backward()` next and reads the value
         only afterwards (a fit loop): the backward launch forms the value too -- the returned scalar is NaN until then -- and the
         step loses its one remaining loss launch.
-        Where the library cannot fuse (mf_rollout_loss_fusable: other than float32 fast math, a rigid body of <= 4 points, <= 2048
-        rollouts -- dynamics(): <= 1024; several stamps on one row) the same value and gradient come from the unfused route."""
+        Where the library cannot fuse (mf_rollout_loss_fusable: 1 = float32 fast math, a rigid body of <= 4 points, <= 2048 rollouts --
+        dynamics(): <= 1024; 2 = the saturated positions-only backward, > 8192 rollouts of a <= 4-point body, whose forward takes the value
+        from one small launch on its rows; several stamps on one row: never) the same value and gradient come from the unfused route."""
         from .losses import physics_loss_fused
         cp64 = z_grid.dtype == torch.float64 and self.points_per_lane == _lib.MF_LANES_COMPONENT      # the validation build of the fast kernels
         ok = (spec.fusable and not self.precise and (z_grid.dtype == torch.float32 or cp64) and spec.w.dtype == z_grid.dtype
@@ -591,7 +592,10 @@ class DPhysics(torch.nn.Module):
                                    math_mode=_lib.MF_MATH_FAST, force_stride=max(self.x_points.shape[1], 4), map_shared=1, layout=_lib.MF_LAYOUT_TIME_MAJOR,
                                    points_per_lane=self.points_per_lane)
             with torch.cuda.device(torch.device(self.device)):
-                ok = bool(_lib.lib().mf_rollout_loss_fusable(C.byref(d)))
+                fus = int(_lib.lib().mf_rollout_loss_fusable(C.byref(d)))
+            ok = fus == 1 or (fus == 2 and z_grid.dtype == torch.float32)
+            if fus == 2:       # the saturated positions-only backward forms dL/dXs itself; the value: one small launch on the forward's rows
+                value_in_backward = False
         if not ok:
             # (the loss reads the positions only: the forward writes the states, not the 24 N bytes of force rows per rollout-step -- for the
             #  reference's 223-point body 36 of 241 MB per launch; `return_forces` is restored for the module's other callers)

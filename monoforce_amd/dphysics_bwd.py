@@ -15,6 +15,7 @@ import os
 # (c3, 1024 rollouts x 4 points, streaming backward: 16 / 32 / 64 copies -> kernel 0.218 / 0.210 / 0.207 ms, step 0.3865 / 0.3831 /
 #  0.3887 ms -- the reduction over the copies grows with them: 32)
 GRAD_COPIES = int(os.environ.get('MF_GRAD_COPIES', '32'))
+WIN_GRAD_COPIES = int(os.environ.get('MF_GRAD_COPIES_WIN', '32'))      # LDS-window launches (0: as everywhere else); tools/ab_grad_copies.py
 
 
 def grad_copies_for(B, N):
@@ -122,6 +123,11 @@ def _rollout_backward_on_device(ctx, gXs, gXds, gRs, gOm, gFs, gFf, gloss):
         # private gradient copies: rollout b scatters into copy b % copies, summed below (same-address atomics serialise)
         # ~64 rollouts per copy (same-address atomics serialise), between GRAD_COPIES and 256 copies
         copies = grad_copies_for(B, desc.N)
+        # ... unless the launch sends its cell gradients through per-workgroup LDS windows (mf_rollout_bwd_window: saturated positions-only
+        # launches): a workgroup adds its window to ONE copy once, at its end -- 256 copies bought nothing there and cost a 0.125 ms reduction
+        if (WIN_GRAD_COPIES and dt == torch.float32 and (gloss is not None or ups[0] is not None) and all(u is None for u in ups[1:])
+                and _lib.lib().mf_rollout_bwd_window(C.byref(desc))):
+            copies = min(copies, WIN_GRAD_COPIES)
         desc.grad_copies = copies
         # one zero fill for [gz copies | gmu copies | the zero row absent upstream gradients point at]
         n_maps = 2 if want_gmu else 1

@@ -8,6 +8,8 @@ parameter names (`camencode.trunk._blocks...`, `bevencode.up_friction`, non-grad
 `mf_bev_splat_*` (exact per-voxel sums, coalesced reads and writes) instead of argsort + prefix-sum trick; the
 backbones are the plain-torch restatements in `backbones.py` (MIOpen / rocBLAS).
 """
+import weakref
+
 import torch
 from torch import nn
 
@@ -195,12 +197,24 @@ class LiftSplatShoot(nn.Module):
         #  train step restores its snapshot into every state-dict tensor first, which bumps the versions of these constants too)
         if self._grid_host is None or (self._grid_host[0] != versions and not torch.cuda.is_current_stream_capturing()):
             self._grid_host = (versions, splat.grid_host(self.dx, self.bx, self.nx))
-        # (`cache_plan = False`: the plan is rebuilt every forward, in ONE persistent workspace -- no allocation per step, none inside a capture)
-        ws = None if self.cache_plan else self.__dict__.get('_plan_ws')
+        if self.cache_plan:
+            return splat.SplatPlan.from_cameras(self.frustum, rots, trans, intrins, post_rots, post_trans, self.dx, self.bx, self.nx, grid=self._grid_host[1])
+        # `cache_plan = False`: the plan is rebuilt every forward in a PERSISTENT workspace -- no allocation per step, none inside a capture.
+        # A workspace is reused only once nothing references the plan last built in it: `lift_voxel_pooling` saves the plan for its
+        # backward, so a second forward before the first one's backward (two views summed into one loss, an evaluation forward inside the step)
+        # must not overwrite that plan's keys / offsets / lists -- it takes another slot.  The slot knows through a weak reference: the plan
+        # lives exactly as long as an autograd graph (or the caller) holds it.
+        slots = self.__dict__.setdefault('_plan_ws_slots', [])
+        slot = next((sl for sl in slots if sl['plan'] is None or sl['plan']() is None), None)
+        if slot is None:
+            if slots and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('LiftSplatShoot(cache_plan=False): a stream capture needs a second splat-plan workspace (an earlier forward\'s plan is '
+                                   'still referenced by an autograd graph); run one such step launch by launch first, or release that graph')
+            slot = dict(ws=None, plan=None)
+            slots.append(slot)
         plan = splat.SplatPlan.from_cameras(self.frustum, rots, trans, intrins, post_rots, post_trans, self.dx, self.bx, self.nx,
-                                            grid=self._grid_host[1], workspace=ws)
-        if not self.cache_plan:
-            self.__dict__['_plan_ws'] = plan.workspace
+                                            grid=self._grid_host[1], workspace=slot['ws'])
+        slot['ws'], slot['plan'] = plan.workspace, weakref.ref(plan)
         return plan
 
     def splat_plan_cached(self, rots, trans, intrins, post_rots, post_trans):

@@ -118,8 +118,8 @@ def test_bench_through_its_multi_rank_code_on_one_gpu():
                         '--no-others', '--no-cpu-baseline'], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     last = r.stdout.rstrip('\n').splitlines()[-1]
+    assert last.startswith('{') and len(last) < 4096, r.stdout[-600:]
     out = json.loads(last)
-    assert len(last) < 4096
     assert out['backend'] == 'rccl' and out['world_size'] == 1 and out['n_gpus'] == 1
     assert out['comm_ms'] is not None and 0 < out['comm_ms'] < float('inf')      # (positive and finite; no timing bar: the host of a box can be slow)
     assert out['ms_per_step_ranks']['min'] <= out['ms_per_step_ranks']['max'] and out['value'] > 0

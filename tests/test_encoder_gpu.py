@@ -261,3 +261,42 @@ def test_depthwise_convolution_off_miopen_matches_the_library_route(k, stride, m
     for a, b in zip(out['1'], out['0']):
         assert a.shape == b.shape
         assert torch.allclose(a, b, rtol=2e-4, atol=2e-4 * float(b.abs().max()))
+
+
+def test_two_forwards_before_one_backward_without_the_plan_cache():
+    """`cache_plan = False` rebuilds the splat plan every forward in a persistent workspace: a SECOND forward with another
+    camera rig before the first forward's backward must not overwrite the plan that backward will scatter with.  Two views summed into one
+    loss: gradients equal the cached-plan run's; the two plans live in different workspaces; the slot is reused once its graph is gone."""
+    from monoforce_amd import synthetic as syn
+    from monoforce_amd.terrain_encoder import LiftSplatShoot
+    torch.manual_seed(0)
+    m = LiftSplatShoot(SMALL['grid_conf'], SMALL['data_aug_conf']).to(DEV).eval()
+    x1, x2 = torch.randn(1, 3, 3, 64, 96, device=DEV), torch.randn(1, 3, 3, 64, 96, device=DEV)
+    rig1 = [t.to(DEV) for t in syn.lss_camera_rig(1, 3, 64, 96, 40.0)]
+    rig2 = [t.clone() for t in rig1]
+    rig2[1] = rig2[1] + torch.tensor([0.35, -0.2, 0.0], device=DEV)          # the second view: the rig moved -> other voxels
+    w1, w2 = torch.randn(1, 64, 64, 64, device=DEV), torch.randn(1, 64, 64, 64, device=DEV)
+    params = [p for p in m.camencode.parameters() if p.requires_grad]
+
+    def grads(cache):
+        m.cache_plan = cache
+        m._plan_cache = None
+        for p in params:
+            p.grad = None
+        b1 = m.get_voxels(x1, *rig1)
+        b2 = m.get_voxels(x2, *rig2)                                          # before b1's backward
+        ((b1 * w1).sum() + (b2 * w2).sum()).backward()
+        return [p.grad.clone() for p in params]
+    ref = grads(True)
+    got = grads(False)
+    slots = m._plan_ws_slots
+    assert len(slots) == 2 and slots[0]['ws'].data_ptr() != slots[1]['ws'].data_ptr()
+    scale = max(float(g.abs().max()) for g in ref)
+    assert scale > 0
+    for a, b in zip(got, ref):
+        assert float((a - b).abs().max()) <= 1e-6 * scale
+    assert all(sl['plan']() is None for sl in slots)                          # the graph is gone: both slots are free again
+    got2 = grads(False)
+    assert len(m._plan_ws_slots) == 2
+    for a, b in zip(got2, ref):
+        assert float((a - b).abs().max()) <= 1e-6 * scale

@@ -56,9 +56,10 @@ def test_lds_window_kernels_fit_one_workgroup_of_eight_waves_per_cu(metadata):
     per CU) and run as workgroups of up to eight waves -- two per SIMD: at most 256 registers per lane, no scratch."""
     rows = [(n, m) for o, n, m in metadata if m['lds'] == 2 * 128 * 128 * 4]
     names = ' '.join(n for n, _ in rows)
-    assert 'rollout_bwd_kernel<float, 4, 1, 1, true, false, true, true, true, true>' in names       # positions-only, interleaved maps, carry-over
-    assert 'rollout_bwd_kernel<float, 4, 1, 0, true, false, false, true, false, true>' in names     # dynamics(), plain maps, no carry-over
+    assert 'rollout_bwd_kernel<float, 4, 1, 1, true, false, true, true, true, true, false>' in names       # positions-only, interleaved maps, carry-over
+    assert 'rollout_bwd_kernel<float, 4, 1, 1, true, false, true, true, true, true, true>' in names        # ... with the fused physics loss (round 6)
+    assert 'rollout_bwd_kernel<float, 4, 1, 0, true, false, false, true, false, true, false>' in names     # dynamics(), plain maps, no carry-over
     assert 'rollout_bwd_cp_kernel<float, 1, true, false, 0, 6, 3, false, true>' in names            # component-parallel early recompute
-    assert len(rows) >= 12, names
+    assert len(rows) >= 20, names
     for n, m in rows:
         assert m['scratch'] == 0 and m['vgpr'] + m['agpr'] <= 256, (n, m)

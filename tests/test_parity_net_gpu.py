@@ -236,9 +236,9 @@ def test_saturated_positions_only_backward_vs_oracle(integ, friction, scattered,
     ran = _timing.launches()
     _timing.stop()
     name = ran['rollout_bwd_kernel']
-    if B >= 16384:      # rollout_bwd_kernel<float, 4, 1, INTEG, FAST, JOINTS, CARRY, XS_ONLY, ZMU, WIN>
+    if B >= 16384:      # rollout_bwd_kernel<float, 4, 1, INTEG, FAST, JOINTS, CARRY, XS_ONLY, ZMU, WIN, LOSS>
         # (with the window the accumulator carry-over runs from two waves per SIMD up only: 32 768 rollouts, eight-wave workgroups)
-        assert 'rollout_bwd_kernel<float, 4, 1, %d, true, false, %s, true, %s, %s>' % (integ, 'false' if (win and B < 32768) else 'true', 'true' if friction else 'false', 'true' if win else 'false') in name, name
+        assert 'rollout_bwd_kernel<float, 4, 1, %d, true, false, %s, true, %s, %s, false>' % (integ, 'false' if (win and B < 32768) else 'true', 'true' if friction else 'false', 'true' if win else 'false') in name, name
     else:               # rollout_bwd_cp_kernel<float, INTEG, XS_ONLY, GCTRL, MODE = early, SLOTS, BATCH, ZMU, WIN>
         assert 'rollout_bwd_cp_kernel<float, %d, true, true, 0, 6, 3, false%s>' % (integ, ', true' if win else ', false') in name, name
 
@@ -284,7 +284,7 @@ def test_saturated_backward_small_maps_and_ragged_batches_vs_oracle(res, B):
     _timing.stop()
     import os
     if os.environ.get('MF_BWD_WIN', '1') != '0':
-        assert name.split(' grid')[0].endswith('true, true>'), name      # ZMU, WIN
+        assert name.split(' grid')[0].endswith('true, true, false>'), name      # ZMU, WIN, no fused loss
 
     def oracle_grads(dtype):
         zc, mc, cc = z.to(dtype).requires_grad_(True), mu.to(dtype).requires_grad_(True), ctrl[sel].to(dtype).requires_grad_(True)
@@ -318,7 +318,7 @@ def test_saturated_positions_only_backward_of_an_eight_point_body_vs_oracle():
     (Xs[sel.to(DEV)] * wts.to(DEV)).sum().backward()
     name = _timing.launches()['rollout_bwd_kernel']
     _timing.stop()
-    assert 'rollout_bwd_kernel<float, 8, 1, 1, true, false, true, true, true, false>' in name, name      # CARRY, XS_ONLY, ZMU, no WIN
+    assert 'rollout_bwd_kernel<float, 8, 1, 1, true, false, true, true, true, false, false>' in name, name      # CARRY, XS_ONLY, ZMU, no WIN, no fused loss
 
     def oracle_grads(dtype):
         zc, mc, cc = z.to(dtype).requires_grad_(True), mu.to(dtype).requires_grad_(True), ctrl[sel].to(dtype).requires_grad_(True)

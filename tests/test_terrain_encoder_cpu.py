@@ -156,15 +156,20 @@ def _counter_checks(m, x, cal):
     m.train()
     for _ in range(2):
         m(x, *cal)
-    counters = {k: int(v) for k, v in m.state_dict().items() if k.endswith('num_batches_tracked')}
+    def counts(mod):      # every batch norm that RUNS; the EfficientNet head's `_bn1` never does (lss.py:78-92) and stays at 0, like the reference's
+        sd = mod.state_dict()
+        idle = [k for k in sd if k.endswith('trunk._bn1.num_batches_tracked')]
+        assert len(idle) == 1 and int(sd[idle[0]]) == 0, idle
+        return {k: int(v) for k, v in sd.items() if k.endswith('num_batches_tracked') and k not in idle}
+    counters = counts(m)
     assert len(counters) > 60 and set(counters.values()) == {2}
     m2 = copy.deepcopy(m).double()            # buffers re-created one by one: the bank gathers them again
     m2(x.double(), *(c.double() for c in cal))
-    assert {int(v) for k, v in m2.state_dict().items() if k.endswith('num_batches_tracked')} == {3}
-    assert {int(v) for k, v in m.state_dict().items() if k.endswith('num_batches_tracked')} == {2}
+    assert set(counts(m2).values()) == {3}
+    assert set(counts(m).values()) == {2}
     m.eval()
     m(x, *cal)
-    assert {int(v) for k, v in m.state_dict().items() if k.endswith('num_batches_tracked')} == {2}
+    assert set(counts(m).values()) == {2}
     m.load_state_dict(m2.float().state_dict())
     assert int(m.camencode.trunk._bn0.num_batches_tracked) == 3
 
@@ -178,9 +183,9 @@ def test_batchnorm_counters_follow_direct_submodule_calls_and_the_model_pickles(
     x = torch.randn(2, 3, 64, 96)
     m.camencode.get_depth_and_context(x)
     m.camencode(x)
-    cam = {int(v) for k, v in m.state_dict().items() if k.endswith('num_batches_tracked') and k.startswith('camencode')}
+    cam = {int(v) for k, v in m.state_dict().items() if k.endswith('num_batches_tracked') and k.startswith('camencode') and 'trunk._bn1.' not in k}
     bev = {int(v) for k, v in m.state_dict().items() if k.endswith('num_batches_tracked') and k.startswith('bevencode')}
-    assert cam == {2} and bev == {0}
+    assert cam == {2} and bev == {0} and int(m.camencode.trunk._bn1.num_batches_tracked) == 0
     m.bevencode(torch.randn(1, m.camC, int(m.nx[0]), int(m.nx[1])))
     assert {int(v) for k, v in m.state_dict().items() if k.endswith('num_batches_tracked') and k.startswith('bevencode')} == {1}
     assert sum(isinstance(b, BatchNorm2dCounted) for b in m.modules()) > 60
@@ -189,3 +194,20 @@ def test_batchnorm_counters_follow_direct_submodule_calls_and_the_model_pickles(
     m2 = torch.load(path, weights_only=False)
     m2.train().camencode(x)
     assert int(m2.camencode.trunk._bn0.num_batches_tracked) == 3 and int(m.camencode.trunk._bn0.num_batches_tracked) == 2
+
+
+def test_batchnorm_counters_after_a_syncbatchnorm_conversion():
+    """`SyncBatchNorm.convert_sync_batchnorm` replaces the counted layers; the replacements share the old buffer tensors and count
+    for themselves.  The bank drops what it no longer owns -- a converted layer advanced by TWO per step before -- and keeps bumping the rest."""
+    from monoforce_amd.terrain_encoder import LiftSplatShoot
+    from monoforce_amd.backbones import bump_batchnorm_counters, BatchNorm2dCounted
+    m = LiftSplatShoot(LSS_SMALL['grid_conf'], LSS_SMALL['data_aug_conf']).train()
+    bump_batchnorm_counters(m.camencode); bump_batchnorm_counters(m.bevencode)
+    assert int(m.camencode.trunk._bn0.num_batches_tracked) == 1 and int(m.camencode.trunk._bn1.num_batches_tracked) == 0
+    m.camencode = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m.camencode)          # (the bank object stays on the same owner module)
+    sync = [b for b in m.camencode.modules() if isinstance(b, torch.nn.SyncBatchNorm)]
+    assert len(sync) > 40 and not any(isinstance(b, BatchNorm2dCounted) for b in m.camencode.modules())
+    before = [int(b.num_batches_tracked) for b in sync]
+    bump_batchnorm_counters(m.camencode); bump_batchnorm_counters(m.bevencode)
+    assert [int(b.num_batches_tracked) for b in sync] == before                        # theirs to bump now (their own forward does it)
+    assert {int(v) for k, v in m.state_dict().items() if k.endswith('num_batches_tracked') and k.startswith('bevencode')} == {2}

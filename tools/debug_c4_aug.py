@@ -29,7 +29,7 @@ a256 = lambda n: (n * 4 + 255) // 256 * 256
 
 def check(i):
     torch.cuda.synchronize()
-    w = enc._plan_ws.cpu().numpy()
+    w = enc._plan_ws_slots[0]['ws'].cpu().numpy()
     keys = w[0:4 * P].view(np.int32)
     count = w[a256(P):a256(P) + 4 * V].view(np.int32)
     off = w[a256(P) + 2 * a256(V):a256(P) + 2 * a256(V) + 4 * (V + 1)].view(np.int32)
