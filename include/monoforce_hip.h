@@ -209,15 +209,15 @@ typedef struct MfRolloutFwdBufs {
  *      from the backward launch (MF_LOSS_VALUE_IN_BACKWARD), or from mf_physics_loss_value_* on the written rows.
  *   2  the BACKWARD of a saturated launch (round 6): the positions-only one-point-per-lane kernels (float32 MF_MATH_FAST, rigid body of <= 64
  *      points, time-major, beyond the component-parallel / record-reading ranges: > 8192 rollouts of a 4-point body) form dL/dXs at the
- *      stamped rows themselves -- pass MfRolloutBwdBufs.loss with flags = 0 and NO MfRolloutFwdBufs.loss; the value comes from
- *      mf_physics_loss_value_* on the forward's rows.  The step loses the loss-gradient launch and the dense [T][B][3] gradient (98 MB at
+ *      stamped rows themselves -- pass MfRolloutBwdBufs.loss and NO MfRolloutFwdBufs.loss; the value comes from mf_physics_loss_value_* on
+ *      the forward's rows or, with MF_LOSS_VALUE_IN_BACKWARD, from the backward launch (partial: S[B], near and w required).  The step loses the loss-gradient launch and the dense [T][B][3] gradient (98 MB at
  *      16 384 rollouts, a tenth of its rows non-zero).
  *   0  neither: run mf_physics_loss_* on the outputs. */
 int mf_rollout_loss_fusable(const MfRolloutDesc* desc);
 
 /* 1 where mf_rollout_bwd_f32 with a positions-only upstream (gXs or a fused loss; the other five NULL) sends the cell gradients of this
  * launch through per-workgroup LDS windows (saturated launches of a <= 4-point body on ONE shared power-of-two map pair): a workgroup
- * adds its window to gradient copy blockIdx % grad_copies once, at its end, so desc->grad_copies may stay small (32) -- the caller's
+ * adds its window to gradient copy blockIdx % grad_copies once, at its end, so desc->grad_copies may stay small (64) -- the caller's
  * reduction over the copies (mf_reduce_grad_copies_*) is what grows with them: 0.125 ms at 256 copies of a 256 x 256 pair. */
 int mf_rollout_bwd_window(const MfRolloutDesc* desc);
 
@@ -274,7 +274,8 @@ typedef struct MfRolloutBwdBufs {
   const void* zeros;    /* >= 9 zero scalars of type S; required when any of the six upstream pointers is NULL */
   void* gz;             /* out (atomic accumulate): dL/dz, S[map_shared ? max(grad_copies,1) : B][H][W] */
   void* gmu;            /* out (atomic accumulate): dL/dmu, same shape; NULL to skip */
-  void* gcontrols;      /* out: S[B][T][2]; may be NULL (gradient not wanted) where mf_rollout_bwd_wants_gcontrols(desc) returns 0 */
+  void* gcontrols;      /* out: S[B][T][2]; may be NULL = gradient not wanted (round 6: every kernel; before, only where
+                           mf_rollout_bwd_wants_gcontrols(desc) returned 0) -- 8 B per rollout-step of stores less */
   void* gx0;            /* out: S[B][3] (z component is 0 unless skip_snap); NULL to skip */
   void* gxd0;           /* out: S[B][3] */
   void* gR0;            /* out: S[B][3][3] */
@@ -293,7 +294,8 @@ typedef struct MfRolloutBwdBufs {
 } MfRolloutBwdBufs;
 
 /* 1 if the backward kernels chosen for this descriptor always write the control gradient (gcontrols must then be a buffer), 0 if
- * they can skip it (gcontrols may be NULL: saves its dot product, sums and stores per step). */
+ * they can skip it (gcontrols may be NULL).  Round 6: 0 for every descriptor -- the component-parallel kernels compile the gradient out
+ * (its dot product, sums and stores), the others keep their instruction stream and drop the stores' traffic. */
 int mf_rollout_bwd_wants_gcontrols(const MfRolloutDesc* desc);
 int mf_rollout_bwd_f32(const MfRolloutDesc* desc, const MfRolloutBwdBufs* bufs, void* hip_stream);
 int mf_rollout_bwd_f64(const MfRolloutDesc* desc, const MfRolloutBwdBufs* bufs, void* hip_stream);

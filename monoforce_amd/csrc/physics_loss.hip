@@ -60,12 +60,9 @@ __global__ void __launch_bounds__(256) physics_loss_value_kernel(const S* __rest
   }
   S acc = (S)0;
   if (i < B * T2) {
-    // time-major rows (sb < st: the rollout's own outputs): neighbouring threads take neighbouring ROLLOUTS of one stamp -- a wave reads ONE
-    // 768-byte stretch of an Xs row and 64 ground-truth rows 12 T2 bytes apart, instead of 50 Xs rows megabytes apart (round 6: 819 200
-    // (rollout, stamp) pairs at 16 384 rollouts took 85 us that way, most of it address translation); batch-major rows: neighbouring stamps
-    const bool jm = sb < st;
-    const int b = jm ? i % B : i / T2, j = jm ? i / B : i % T2;
-    const int k = b * T2 + j;
+    // (round 6: neighbouring threads = neighbouring ROLLOUTS of one stamp, so that a wave reads one stretch of an Xs row, measured SLOWER --
+    //  0.085 -> 0.136 ms at 16 384 rollouts x 50 stamps: the ground truth, its stamps and the index table are [B][T2] and became strided)
+    const int k = i, b = i / T2;
     const S w = (S)1 / ((S)1 + gamma * gt_ts[k]);
     const S* x = Xs + b * sb + (long long)nearest[k] * st;
     const S* g = Xgt + (size_t)k * 3;

@@ -99,10 +99,10 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
   if (p->loss) {      // the forward's fused physics loss: dL/dXs is formed inside the kernel from Xs, the ground truth and gloss
     const MfRolloutLoss* L = p->loss;
     const bool loss_cp = (sizeof(S) == 4 || d->points_per_lane == MF_LANES_COMPONENT) && cp_loss_fusable(d) && p->rec && !p->joint_angles;
-    const bool loss_xs = !loss_cp && sizeof(S) == 4 && xs_loss_fusable(d) && !p->joint_angles && !(L->flags & MF_LOSS_VALUE_IN_BACKWARD);
+    const bool loss_xs = !loss_cp && sizeof(S) == 4 && xs_loss_fusable(d) && !p->joint_angles;
     MF_REQUIRE(loss_cp || loss_xs, MF_ERR_UNSUPPORTED,
                "rollout_bwd: this launch cannot carry the fused physics loss (mf_rollout_loss_fusable: 1 = the streaming component-parallel backward, "
-               "the forward's record required; 2 = the saturated positions-only kernels, no MF_LOSS_VALUE_IN_BACKWARD)");
+               "the forward's record required; 2 = the saturated positions-only kernels)");
     MF_REQUIRE((long long)d->B * L->T2 * 3 * (long long)sizeof(S) < (1ll << 32), MF_ERR_UNSUPPORTED, "rollout_bwd: ground truth of 4 GiB or more");
     MF_REQUIRE(!p->gXs && !p->gXds && !p->gRs && !p->gOmegas && !p->gFs && !p->gFf, MF_ERR_INVALID,
                "rollout_bwd: with a fused loss the six upstream gradients must be NULL");
@@ -128,6 +128,8 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
   a.gFs = p->gFs ? (const S*)p->gFs : zr;       a.sFs = p->gFs ? 3 : 0;
   a.gFf = p->gFf ? (const S*)p->gFf : zr;       a.sFf = p->gFf ? 3 : 0;
   a.gz = (S*)p->gz; a.gmu = (S*)p->gmu; a.gcontrols = (S*)p->gcontrols;
+  a.gc_sb = 2 * d->T; a.gc_st = 2;
+  if (!p->gcontrols) { a.gcontrols = (S*)p->gw0; a.gc_sb = 3; a.gc_st = 0; }      // one-point-per-lane kernels (RolloutBwdArgs.gc_sb); the others test for NULL
   a.gx0 = (S*)p->gx0; a.gxd0 = (S*)p->gxd0; a.gR0 = (S*)p->gR0; a.gw0 = (S*)p->gw0;
 
   hipStream_t st = (hipStream_t)stream;
@@ -142,9 +144,8 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
   // float32: the dispatcher's choice for few rollouts of a small body; float64: the VALIDATION build of the same kernels, on explicit
   // request only (points_per_lane = MF_LANES_COMPONENT; rollout_bwd_cp_f64.hip)
   const bool cp = (sizeof(S) == 4 || d->points_per_lane == MF_LANES_COMPONENT) && use_component_parallel_bwd(d, p, (int)sizeof(S));
-  MF_REQUIRE(p->gcontrols || cp, MF_ERR_INVALID, "rollout_bwd: gcontrols may be NULL only where the component-parallel kernels run "
-             "(float32 MF_MATH_FAST, rigid body of N <= 4 points, either integrator, B <= 8192: mf_rollout_bwd_wants_gcontrols() == 0)");
   if (cp) {   // few rollouts of a small body: a rollout over 16 lanes
+    a.gcontrols = (S*)p->gcontrols;      // (these kernels compile the control gradient out instead: GCTRL)
     if (p->rec && cp_record_bytes(d, (int)sizeof(S)) > 0) {      // the forward kept its per-step record: read it instead of recomputing
       MF_REQUIRE(((uintptr_t)p->rec & 15) == 0, MF_ERR_INVALID, "rollout_bwd: rec must be 16-byte aligned");
       a.rec = (const S*)p->rec;
@@ -169,6 +170,7 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
   if ((sizeof(S) == 4 || d->points_per_lane == MF_LANES_COMPONENT) && use_multiwave_bwd(d, p)) {
     MF_REQUIRE(((uintptr_t)p->rec & (4 * sizeof(S) - 1)) == 0, MF_ERR_INVALID, "rollout_bwd: rec must be aligned to its quads");
     a.rec = (const S*)p->rec;
+    a.gcontrols = (S*)p->gcontrols;      // (tested for NULL by the kernel)
     const bool xs_only = !p->gXds && !p->gRs && !p->gOmegas && !p->gFs && !p->gFf;
     if constexpr (sizeof(S) == 4) return launch_rollout_bwd_mw_f32(a, m.G, d->integrator, xs_only, st);
     else return launch_rollout_bwd_mw_f64(a, m.G, d->integrator, xs_only, st);

@@ -77,7 +77,9 @@ bool cp_bwd_wants_zmu(const MfRolloutDesc* d, bool has_rec, bool has_mu) {
 bool cp_loss_in_forward(const MfRolloutDesc* d) { return cp_loss_fusable(d) && d->integrator == MF_INTEG_ODEINT_EULER; }
 
 }  // namespace mf
-extern "C" int mf_rollout_bwd_wants_gcontrols(const MfRolloutDesc* d) { return (d && mf::cp_bwd_covers(d, d->has_joints != 0)) ? 0 : 1; }
+// (round 6: no kernel needs the buffer any more -- the component-parallel kernels compile the control gradient out, the multi-wave ones test
+//  for NULL, the one-point-per-lane ones send the rows to a 3-float dump per rollout; kept for callers that ask)
+extern "C" int mf_rollout_bwd_wants_gcontrols(const MfRolloutDesc* d) { (void)d; return 0; }
 namespace mf { long long mw_record_bytes(const MfRolloutDesc* d, int scalar_bytes); }   // rollout_bwd_mw_fast.hip
 extern "C" long long mf_rollout_record_bytes(const MfRolloutDesc* d) {
   const long long cp = mf::cp_record_bytes(d, 4);

@@ -46,6 +46,10 @@ struct RolloutBwdArgs {
   // lane LOSS kernels: near[j] = output row of stamp j (strictly increasing), w[j] = its weight
   const int* loss_near;
   const S* loss_w;
+  // element strides of the control-gradient rows over rollouts / over steps: (2 T, 2) = the caller's [B][T][2]; (3, 0) = nobody wants the
+  // control gradient -- gcontrols then points at gw0 and every step's pair lands on the rollout's own gw0 row, which the kernel's final
+  // store overwrites (same lanes, program order): the same instruction stream without 8 B per rollout-step of stores (65 MB at 16 384 x 500)
+  int gc_sb, gc_st;
 };
 
 #ifdef MF_NO_ATOMICS
@@ -140,8 +144,54 @@ __device__ __forceinline__ S xs_loss_grad(S scale, S xs, S g, S w) {      // sca
 #pragma clang fp contract(off)
   return scale * w * (xs * w - g * w);
 }
+template <typename S>
+__device__ __forceinline__ S xs_loss_term(S xs, S g, S w) {
+#pragma clang fp contract(off)
+  const S d = xs * w - g * w;
+  return d * d;
+}
+// MF_LOSS_VALUE_IN_BACKWARD on the one-point-per-lane LOSS kernels: every thread of the workgroup arrives with its share (0 for lanes that
+// count nothing); one partial sum per workgroup in a fixed order, and the workgroup that takes the last ticket adds the partial sums in index
+// order and writes the mean (as physics_loss_value_kernel does): deterministic for a given launch shape.
+template <typename S>
+__device__ __forceinline__ void xs_loss_value_finish(const RolloutBwdArgs<S>& a, S acc) {
+  if (a.loss_out == nullptr) return;      // (workgroup-uniform)
+#ifdef MF_XS_LOSS_NOFINISH      // A/B hook: what does the cross-workgroup finish (fences, ticket) cost?
+  if (a.B > 0) return;
+#endif
+  __shared__ S wave_sum[8];
+  __shared__ unsigned last_wg;
+  const int nw = (int)((blockDim.x + 63) >> 6), lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if (lane == 0) wave_sum[wv] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    S tot = (S)0;
+    for (int k = 0; k < nw; ++k) tot += wave_sum[k];
+    __builtin_nontemporal_store(tot, a.loss_partial + blockIdx.x);
+    __threadfence();
+    last_wg = atomicAdd(a.loss_ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!last_wg) return;
+  __threadfence();
+  S tot = (S)0;
+  for (unsigned k = threadIdx.x; k < gridDim.x; k += blockDim.x) tot += __builtin_nontemporal_load(a.loss_partial + k);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d, 64);
+  __syncthreads();
+  if (lane == 0) wave_sum[wv] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    S sum = (S)0;
+    for (int k = 0; k < nw; ++k) sum += wave_sum[k];
+    a.loss_out[0] = sum * a.loss_inv_count;
+    *a.loss_ticket = 0u;
+  }
+}
 template <typename S, int G, int PPL, int INTEG, bool FAST, bool JOINTS, bool CARRY, bool XS_ONLY, bool ZMU, bool WIN, bool LOSS = false>
-__device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* win, const unsigned win_flat0, const unsigned win_shift) {
+__device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* win, const unsigned win_flat0, const unsigned win_shift, S* l_acc = nullptr) {
   using M = Mth<S, FAST>;
   const int tid = blockIdx.x * blockDim.x + threadIdx.x;
   const int b = tid / G;
@@ -185,7 +235,7 @@ __device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* 
   const size_t row_stride = (a.layout == MF_LAYOUT_TIME_MAJOR) ? (size_t)a.B : 1;
   const size_t row0 = (a.layout == MF_LAYOUT_TIME_MAJOR) ? (size_t)b : (size_t)b * a.T;
   const S* ctrl = a.controls + (size_t)b * a.T * 2;
-  S* gctrl = a.gcontrols + (size_t)b * a.T * 2;
+  S* gctrl = a.gcontrols + (size_t)b * (size_t)a.gc_sb;
 
   // adjoint of the state (x, xd, R, w) [+ the impulse accumulators of the ODEINT extended state]
   // UNSUM (round 5; the positions-only kernels of rollouts inside a wave): the adjoint state is kept UN-SUMMED over the lanes of a rollout
@@ -223,13 +273,24 @@ __device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* 
   static_assert(!LOSS || XS_ONLY, "the fused physics loss is a positions-only upstream");
   const S loss_scale = LOSS ? (S)2 * a.loss_gloss[0] * a.loss_inv_count : zero;      // as csrc/physics_loss.hip: (2 gloss) / count
   const S* const loss_gt_b = LOSS ? a.loss_gt + (size_t)b * (size_t)a.loss_T2 * 3u : nullptr;
-  // The rows are visited from the last one down and the stamps' rows increase with the stamp: ONE current stamp (index, row, weight -- wave-
-  // uniform, in scalar registers) is compared with the row at hand and stepped down when it is met.  Its successor's row and weight are
-  // scalar loads issued a whole iteration before their first use, and the ground-truth address depends on no load at all (first attempt:
-  // row_stamp[row] -> address, a dependent scalar load in front of the step's vector loads: 0.93 -> 1.13 ms at 16 384 rollouts).
-  int l_j = LOSS ? a.loss_T2 - 1 : 0;
+  // The rows are visited from the last one down and the stamps' rows increase with the stamp: ONE current stamp l_j (its row and weight in
+  // registers) is compared with the row at hand and stepped down when it is met; its successor's row and weight are loaded right then -- a
+  // whole iteration before their first use, from an address that depends on no load of this iteration -- and the ground-truth address
+  // depends on l_j alone.  No branch, no wait of its own.  (First attempt: row_stamp[row] -> ground-truth address, a dependent load in front
+  // of the step's requests: 0.93 -> 1.13 ms at 16 384 rollouts.  Second: the successor's loads behind a `l_j >= 0 ?` -- the compiler made it
+  // a branch with an s_waitcnt vmcnt(0) inside the loop: 1.21 ms.)
+  S l_val = zero;      // LOSS: this lane's share of the loss value (sum of the weighted squared errors of its rollout's stamped rows)
+  // (the stamp index lives in a VECTOR register on purpose -- an opaque per-lane zero is added to it: left to itself the compiler sees a
+  //  uniform address, keeps the loaded row in a scalar register and puts the v_readfirstlane -- and with it an s_waitcnt for nearly the
+  //  whole prefetch group -- right behind the load: 0.93 -> 1.21 ms at 16 384 rollouts, profiles/r6_ab_fused_loss_sat.txt)
+  int l_opaque_zero = 0;
+  if constexpr (LOSS) asm volatile("v_mov_b32 %0, 0" : "=v"(l_opaque_zero));
+  int l_j = LOSS ? a.loss_T2 - 1 + l_opaque_zero : 0;
   int l_row = LOSS ? a.loss_near[l_j] : -1;
   S l_w = LOSS ? a.loss_w[l_j] : zero;
+  const S* l_gt = LOSS ? loss_gt_b + (size_t)(unsigned)l_j * 3u : nullptr;
+  const int* const l_near_tab = LOSS ? a.loss_near : nullptr;
+  const S* const l_w_tab = LOSS ? a.loss_w : nullptr;
   const int n_steps = (INTEG == MF_INTEG_ODEINT_EULER) ? a.T - 1 : a.T;
   // Running pointers to the rows of the step being prefetched: stepping them back by wave-uniform deltas replaces a dozen
   // 64-bit row * stride multiplications per iteration.
@@ -283,16 +344,15 @@ __device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* 
 #pragma unroll
     for (int c = 0; c < 3; ++c) u.gXs[c] = p.g1[c];
     if constexpr (LOSS) {      // (unconditional loads: an unstamped row reads the current stamp's ground truth -- the same line again -- masked at use)
-      const int tr = __builtin_amdgcn_readfirstlane(p.trow);
-      u.stamped = tr == l_row;
+      u.stamped = (p.trow == l_row) & (l_j >= 0);
       u.lw = l_w;
-      const S* g = loss_gt_b + (size_t)(unsigned)max(l_j, 0) * 3u;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) u.lg[c] = g[c];
-      l_j = __builtin_amdgcn_readfirstlane(l_j - (u.stamped ? 1 : 0));
-      const int jn = max(l_j, 0);
-      l_row = l_j >= 0 ? a.loss_near[jn] : -1;      // (first used by the NEXT call: a whole iteration for the scalar loads to land)
-      l_w = a.loss_w[jn];
+      for (int c = 0; c < 3; ++c) u.lg[c] = l_gt[c];
+      l_j -= u.stamped ? 1 : 0;
+      l_gt -= (u.stamped & (l_j >= 0)) ? 3 : 0;      // (running pointer to the current stamp's ground truth; it stays on stamp 0 at the end)
+      const unsigned jn = (unsigned)max(l_j, 0);
+      l_row = l_near_tab[jn];      // (first used by the NEXT call: a whole iteration for the two loads to land)
+      l_w = l_w_tab[jn];
     }
     if constexpr (!XS_ONLY) {
 #pragma unroll
@@ -308,8 +368,23 @@ __device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* 
   auto add_upstream_state = [&](const UpIn& u) {
     S g[3] = {u.gXs[0], u.gXs[1], u.gXs[2]};
     if constexpr (LOSS) {      // dL/dXs of this row: masked by the stamp, not by a zero weight (an unstamped row of a diverged rollout may hold inf / NaN)
+#ifdef MF_XS_LOSS_BRANCH      // A/B hook (tools/build_variant.sh): a wave-uniform branch around the stamped rows' arithmetic instead of selects
+      g[0] = g[1] = g[2] = zero;
+      if (__builtin_amdgcn_ballot_w64(u.stamped) != 0) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) g[c] = xs_loss_grad(loss_scale, u.gXs[c], u.lg[c], u.lw);
+        const S e2 = xs_loss_term(u.gXs[0], u.lg[0], u.lw) + xs_loss_term(u.gXs[1], u.lg[1], u.lw) + xs_loss_term(u.gXs[2], u.lg[2], u.lw);
+        l_val += gl == 0 ? e2 : zero;
+      }
+#else
 #pragma unroll
       for (int c = 0; c < 3; ++c) g[c] = u.stamped ? xs_loss_grad(loss_scale, u.gXs[c], u.lg[c], u.lw) : zero;
+#ifndef MF_XS_LOSS_NOVALUE    // A/B hook: no value accumulation
+      // MF_LOSS_VALUE_IN_BACKWARD: the weighted squared error of the row as well (one lane of the rollout's group counts it)
+      const S e2 = xs_loss_term(u.gXs[0], u.lg[0], u.lw) + xs_loss_term(u.gXs[1], u.lg[1], u.lw) + xs_loss_term(u.gXs[2], u.lg[2], u.lw);
+      l_val += (u.stamped & (gl == 0)) ? e2 : zero;
+#endif
+#endif
     }
     if constexpr (UNSUM) {
       const S ms = up_lane * a.sink;
@@ -329,7 +404,7 @@ __device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* 
 
   if (INTEG == MF_INTEG_ODEINT_EULER) {
     // the last control of the grid is never used by the explicit scheme
-    if (gl == 0) { gctrl[(a.T - 1) * 2 + 0] = zero; gctrl[(a.T - 1) * 2 + 1] = zero; }
+    if (gl == 0) { gctrl[(a.T - 1) * a.gc_st + 0] = zero; gctrl[(a.T - 1) * a.gc_st + 1] = zero; }
   }
 
   // Scatter-add of the cell gradients.  Device-scope float atomics execute at the memory side (the per-XCD L2s are not
@@ -377,7 +452,7 @@ __device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* 
 
   // control gradient of the previous iteration, stored one iteration late; before the first one it rewrites the last row with
   // zeros (ODEINT: that row IS zero; DYNAMICS: the first iteration's own result overwrites it, same lanes, program order)
-  S* gctrl_pending = gctrl + (size_t)(a.T - 1) * 2;
+  S* gctrl_pending = gctrl + (size_t)(a.T - 1) * (size_t)a.gc_st;
   S gv_pending = zero, gwc_pending = zero;
   StateIn cur;
   UpIn up;
@@ -854,7 +929,7 @@ __device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* 
       lR[3] += M::div(ge[1] - dote * e[1], el);
       lR[6] += M::div(ge[2] - dote * e[2], el);
     }
-    gctrl_pending = gctrl + n * 2; gv_pending = gv; gwc_pending = gwc;   // stored by the next iteration (or after the loop)
+    gctrl_pending = gctrl + n * a.gc_st; gv_pending = gv; gwc_pending = gwc;   // stored by the next iteration (or after the loop)
     cur = nxt;
     up = up_next;
   }
@@ -920,6 +995,7 @@ __device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* 
 #pragma unroll
     for (int q = 0; q < 6; ++q) lR[q] += gs.sum(sR[q]);
   }
+  if constexpr (LOSS) { if (l_acc) *l_acc = l_val; }
   if (gl == 0) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -941,11 +1017,18 @@ __global__ void __launch_bounds__(WIN ? 512 : (G > 256 ? G : 256)) rollout_bwd_k
     win_open<S, FAST>(a, win, (int)((blockIdx.x * blockDim.x) / G), &wx0, &wy0);
     __syncthreads();
     const unsigned sh = 31u - (unsigned)__builtin_clz((unsigned)a.H);      // H = 2^sh (host-checked)
-    rollout_bwd_body<S, G, PPL, INTEG, FAST, JOINTS, CARRY, XS_ONLY, ZMU, true, LOSS>(a, win, (unsigned)wy0 + ((unsigned)wx0 << sh), sh);
+    S l_acc = (S)0;
+    rollout_bwd_body<S, G, PPL, INTEG, FAST, JOINTS, CARRY, XS_ONLY, ZMU, true, LOSS>(a, win, (unsigned)wy0 + ((unsigned)wx0 << sh), sh, &l_acc);
     __syncthreads();
     win_close(a, win, wx0, wy0);
+    if constexpr (LOSS) xs_loss_value_finish(a, l_acc);
   } else {
-    rollout_bwd_body<S, G, PPL, INTEG, FAST, JOINTS, CARRY, XS_ONLY, ZMU, false, LOSS>(a, nullptr, 0, 0);
+    S l_acc = (S)0;
+    rollout_bwd_body<S, G, PPL, INTEG, FAST, JOINTS, CARRY, XS_ONLY, ZMU, false, LOSS>(a, nullptr, 0, 0, &l_acc);
+    if constexpr (LOSS) {
+      static_assert(G <= 64, "the fused loss serves rollouts inside a wave");
+      xs_loss_value_finish(a, l_acc);
+    }
   }
 }
 

@@ -262,11 +262,15 @@ def _rollout_forward_on_device(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts
         zmu_scratch=_lib.ptr(zmu_scratch), zmu=_lib.ptr(zmu_staged), rec=_lib.ptr(rec))
     loss_val = lstruct = None
     in_backward = loss is not None and len(loss) > 2 and bool(loss[2]) and want_grad      # MF_LOSS_VALUE_IN_BACKWARD
-    in_forward = loss is not None and mod.loss_in_forward and not in_backward and desc.integrator == _lib.MF_INTEG_ODEINT_EULER      # (the LOSS kernels: default integrator)
+    saturated = loss is not None and len(loss) > 3 and loss[3] == 2      # mf_rollout_loss_fusable = 2: the fusion lives in the BACKWARD launch alone
+    in_forward = (loss is not None and mod.loss_in_forward and not in_backward and not saturated
+                  and desc.integrator == _lib.MF_INTEG_ODEINT_EULER)      # (the LOSS kernels: default integrator, component-parallel)
     if loss is not None:
         spec, X_gt = loss[:2]
         loss_val = torch.empty((), dtype=dt, device=dev)
-    if in_backward:     # the launch only marks the value as not yet known (NaN); mf_rollout_bwd_* fills it
+    if in_backward and saturated:      # (the saturated forward kernels carry no loss at all: the value is marked as not yet known here)
+        loss_val.fill_(float('nan'))
+    elif in_backward:     # the launch only marks the value as not yet known (NaN); mf_rollout_bwd_* fills it
         lstruct = _lib.MfRolloutLoss(T2=spec.T2, flags=_lib.MF_LOSS_VALUE_IN_BACKWARD, loss=_lib.ptr(loss_val))
         bufs.loss = C.cast(C.pointer(lstruct), C.c_void_p)
     if in_forward:
@@ -300,7 +304,8 @@ def _rollout_forward_on_device(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts
         # (the backward launch's scratch is allocated HERE: under a hipGraph capture the autograd thread must not allocate)
         # (... and the scalar is held through an ALIAS: the tensor handed out gets this node as its grad_fn, and a node holding its own
         #  output is a reference cycle -- garbage that the collector then frees whenever it runs, e.g. in the middle of a later capture)
-        ctx.loss = (spec, X_gt, Xs, (loss_val.detach(), torch.empty((B + 3) // 4, dtype=dt, device=dev)) if in_backward else None) if want_grad else None
+        # (partial sums of the direction that forms the value: one per workgroup -- B / 4 component-parallel, at most B one point per lane)
+        ctx.loss = (spec, X_gt, Xs, (loss_val.detach(), torch.empty(B if saturated else (B + 3) // 4, dtype=dt, device=dev)) if in_backward else None) if want_grad else None
     ctx.n_force_outs = 2 if want_forces else 0
     # outputs the loss does not touch arrive as None in backward (= NULL upstream pointers), not as zero-filled tensors
     ctx.set_materialize_grads(False)
@@ -341,9 +346,9 @@ class _RolloutLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_grad, x0_buf, x0_private, default_state, spec, X_gt,
-                value_in_backward=False):
+                value_in_backward=False, route=1):
         outs = _rollout_forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_grad, None, False, x0_buf, x0_private,
-                                default_state, loss=(spec, X_gt, value_in_backward))
+                                default_state, loss=(spec, X_gt, value_in_backward, route))
         ctx.mark_non_differentiable(*outs[1:])
         return outs
 
@@ -351,9 +356,9 @@ class _RolloutLossFn(torch.autograd.Function):
     def backward(ctx, gloss, *_unused):
         from .dphysics_bwd import rollout_backward
         if gloss is None:
-            return (None,) * 16
+            return (None,) * 17
         grads = rollout_backward(ctx, None, None, None, None, None, None, gloss=gloss)      # (mod, z, mu, controls, x, xd0, R0, w0, ts, want_grad, ja)
-        return grads[:10] + (None, None, None, None, None, None)
+        return grads[:10] + (None, None, None, None, None, None, None)
 
 
 class DPhysics(torch.nn.Module):
@@ -545,7 +550,7 @@ class DPhysics(torch.nn.Module):
         if _loss is not None:       # physics_loss inside the launches (physics_loss_rollout)
             spec, X_gt = _loss[:2]
             outs = _RolloutLossFn.apply(self, z_grid, friction, controls, x_arg, xd0, R0, w0, ts, want_grad, x0, own_state,
-                                        state_in_kernel, spec, X_gt, len(_loss) > 2 and bool(_loss[2]))
+                                        state_in_kernel, spec, X_gt, len(_loss) > 2 and bool(_loss[2]), _loss[3] if len(_loss) > 3 else 1)
             loss_val, outs = outs[0], outs[1:]
         else:
             outs = _RolloutFn.apply(self, z_grid, friction, controls, x_arg, xd0, R0, w0, ts, want_grad, ja_dev, want_forces,
@@ -593,9 +598,9 @@ class DPhysics(torch.nn.Module):
                                    points_per_lane=self.points_per_lane)
             with torch.cuda.device(torch.device(self.device)):
                 fus = int(_lib.lib().mf_rollout_loss_fusable(C.byref(d)))
+            # (2: the saturated positions-only backward forms dL/dXs itself -- and the value, with `value_in_backward`; else the value comes
+            #  from one small launch on the forward's rows)
             ok = fus == 1 or (fus == 2 and z_grid.dtype == torch.float32)
-            if fus == 2:       # the saturated positions-only backward forms dL/dXs itself; the value: one small launch on the forward's rows
-                value_in_backward = False
         if not ok:
             # (the loss reads the positions only: the forward writes the states, not the 24 N bytes of force rows per rollout-step -- for the
             #  reference's 223-point body 36 of 241 MB per launch; `return_forces` is restored for the module's other callers)
@@ -609,7 +614,7 @@ class DPhysics(torch.nn.Module):
             return physics_loss_fused(states, [X_gt], None, gt_ts, gamma=spec.gamma, nearest=spec.near.unsqueeze(0).expand(B_, -1)), states
         Xg = X_gt.detach().to(device=torch.device(self.device), dtype=z_grid.dtype).contiguous()
         assert Xg.shape == (B, spec.T2, 3), f'X_gt shape {tuple(Xg.shape)} != {(B, spec.T2, 3)}'
-        return self.dphysics(z_grid, controls, state=state, friction=friction, _loss=(spec, Xg, bool(value_in_backward)))
+        return self.dphysics(z_grid, controls, state=state, friction=friction, _loss=(spec, Xg, bool(value_in_backward), fus))
 
     @torch.no_grad()
     def rollout_costs(self, z_grid, controls, state=None, friction=None, pose_stride=None, project=True):

@@ -15,7 +15,10 @@ import os
 # (c3, 1024 rollouts x 4 points, streaming backward: 16 / 32 / 64 copies -> kernel 0.218 / 0.210 / 0.207 ms, step 0.3865 / 0.3831 /
 #  0.3887 ms -- the reduction over the copies grows with them: 32)
 GRAD_COPIES = int(os.environ.get('MF_GRAD_COPIES', '32'))
-WIN_GRAD_COPIES = int(os.environ.get('MF_GRAD_COPIES_WIN', '32'))      # LDS-window launches (0: as everywhere else); tools/ab_grad_copies.py
+# LDS-window launches (0: as everywhere else).  Fit step at 16 384 / 32 768 rollouts, backward kernel at 256 / 64 / 32 copies: 0.969 / 1.004 /
+# 1.059 and 1.524 / 1.536 / 1.632 ms (the windows' final adds meet in fewer copies) against 0.125 / 0.035 / 0.02 ms of reduction: 64
+# (profiles/r6c_ab_step_copies.txt)
+WIN_GRAD_COPIES = int(os.environ.get('MF_GRAD_COPIES_WIN', '64'))
 
 
 def grad_copies_for(B, N):
@@ -124,7 +127,7 @@ def _rollout_backward_on_device(ctx, gXs, gXds, gRs, gOm, gFs, gFf, gloss):
         # ~64 rollouts per copy (same-address atomics serialise), between GRAD_COPIES and 256 copies
         copies = grad_copies_for(B, desc.N)
         # ... unless the launch sends its cell gradients through per-workgroup LDS windows (mf_rollout_bwd_window: saturated positions-only
-        # launches): a workgroup adds its window to ONE copy once, at its end -- 256 copies bought nothing there and cost a 0.125 ms reduction
+        # launches): a workgroup adds its window to ONE copy once, at its end -- 256 copies cost a 0.125 ms reduction for 0.035 ms of kernel time
         if (WIN_GRAD_COPIES and dt == torch.float32 and (gloss is not None or ups[0] is not None) and all(u is None for u in ups[1:])
                 and _lib.lib().mf_rollout_bwd_window(C.byref(desc))):
             copies = min(copies, WIN_GRAD_COPIES)
@@ -140,8 +143,7 @@ def _rollout_backward_on_device(ctx, gXs, gXds, gRs, gOm, gFs, gFf, gloss):
         gmu = torch.zeros_like(mu) if want_gmu else None
         zero_row = torch.zeros(16, dtype=dt, device=dev)
     # the control gradient is skipped where nobody wants it and the chosen kernels can leave it out (mf_rollout_bwd_wants_gcontrols)
-    need_gc = (ctx.needs_input_grad[3] or bool(_lib.lib().mf_rollout_bwd_wants_gcontrols(C.byref(desc)))
-               or (dt != torch.float32 and desc.points_per_lane != _lib.MF_LANES_COMPONENT))      # (float64 + component lanes: the validation build)
+    need_gc = ctx.needs_input_grad[3] or bool(_lib.lib().mf_rollout_bwd_wants_gcontrols(C.byref(desc)))      # (round 6: never forced by the library)
     gcontrols = torch.empty_like(controls) if need_gc else None
     gxd0, gR0, gw0 = torch.empty_like(xd0), torch.empty_like(R0), torch.empty_like(w0)
     gx0 = torch.empty_like(xd0) if ctx.needs_input_grad[4] else None

@@ -286,7 +286,7 @@ def test_two_forwards_before_one_backward_without_the_plan_cache():
         b1 = m.get_voxels(x1, *rig1)
         b2 = m.get_voxels(x2, *rig2)                                          # before b1's backward
         ((b1 * w1).sum() + (b2 * w2).sum()).backward()
-        return [p.grad.clone() for p in params]
+        return [p.grad.clone() for p in params if p.grad is not None]
     ref = grads(True)
     got = grads(False)
     slots = m._plan_ws_slots

@@ -110,11 +110,13 @@ def test_fused_loss_equals_the_unfused_hip_route(integ, B, N):
     gen = torch.Generator().manual_seed(3)
     X_gt = (torch.rand(B, stamps.numel(), 3, generator=gen) - 0.5).to(DEV)
     out = {}
-    for route in ('fused', 'unfused'):
+    for route in ('fused', 'fused_value_in_backward', 'unfused'):
         zd, md = z.to(DEV).requires_grad_(True), mu.to(DEV).requires_grad_(True)
         _timing.start()
-        if route == 'fused':
-            loss = dp.physics_loss_rollout(zd.unsqueeze(0), ctrl, X_gt, lspec, friction=md.unsqueeze(0))[0]
+        if route.startswith('fused'):
+            vib = route.endswith('backward')      # MF_LOSS_VALUE_IN_BACKWARD: NaN until the backward launch has formed it
+            loss = dp.physics_loss_rollout(zd.unsqueeze(0), ctrl, X_gt, lspec, friction=md.unsqueeze(0), value_in_backward=vib)[0]
+            assert bool(torch.isnan(loss.detach())) == vib
         else:
             keep, dp.return_forces = dp.return_forces, False
             states, _ = dp(zd.unsqueeze(0), ctrl, friction=md.unsqueeze(0))
@@ -124,17 +126,18 @@ def test_fused_loss_equals_the_unfused_hip_route(integ, B, N):
         loss.backward()
         name = _timing.launches()['rollout_bwd_kernel'].split(' grid')[0]
         ks = _timing.stop()
-        assert name.endswith(', true>' if route == 'fused' else ', false>'), (route, name)
-        assert ('physics_loss_bwd' in ks) == (route == 'unfused')
-        out[route] = (float(loss), zd.grad.clone(), md.grad.clone())
-    assert abs(out['fused'][0] - out['unfused'][0]) <= 1e-6 * abs(out['unfused'][0])
-    for k in (1, 2):
-        assert hp.rel_err(out['fused'][k], out['unfused'][k]) <= 2e-5, (k, hp.rel_err(out['fused'][k], out['unfused'][k]))
+        assert name.endswith(', true>' if route.startswith('fused') else ', false>'), (route, name)
+        assert ('physics_loss_bwd' in ks) == (route == 'unfused') and ('physics_loss_fwd' in ks) == (route != 'fused_value_in_backward')
+        out[route] = (float(loss.detach()), zd.grad.clone(), md.grad.clone())
+    for route in ('fused', 'fused_value_in_backward'):
+        assert abs(out[route][0] - out['unfused'][0]) <= 2e-6 * abs(out['unfused'][0]), (route, out[route][0], out['unfused'][0])
+        for k in (1, 2):
+            assert hp.rel_err(out[route][k], out['unfused'][k]) <= 2e-5, (route, k, hp.rel_err(out[route][k], out['unfused'][k]))
 
 
 def test_fit_step_at_16384_rollouts_takes_the_fused_route_and_drops_the_dense_gradient():
-    """`TerrainFitProblem` (bench.py's sweep, scripts/fit_terrain.py:53-62 at scale): one value launch + the fused backward; launch by launch
-    and replayed as a hipGraph give the same loss and gradients."""
+    """`TerrainFitProblem` (bench.py's sweep, scripts/fit_terrain.py:53-62 at scale): forward + the fused backward (which forms the loss value
+    too) + the reduction of the gradient copies -- no loss launch at all; launch by launch and replayed as a hipGraph give the same loss and gradients."""
     from monoforce_amd import synthetic as syn, _timing
     from monoforce_amd.train import TerrainFitProblem
     from bench import build_problem
@@ -147,7 +150,7 @@ def test_fit_step_at_16384_rollouts_takes_the_fused_route_and_drops_the_dense_gr
     name = _timing.launches()['rollout_bwd_kernel'].split(' grid')[0]
     ks = _timing.stop()
     assert name.endswith('true, true, true, true>'), name      # XS_ONLY, ZMU, WIN, LOSS
-    assert 'physics_loss_bwd' not in ks and 'physics_loss_fwd' in ks
+    assert 'physics_loss_bwd' not in ks and 'physics_loss_fwd' not in ks and l0 == l0 and l0 > 0
     g0 = (zl.grad.clone(), ml.grad.clone())
     assert float(g0[0].abs().max()) > 0 and float(g0[1].abs().max()) > 0
     for _ in range(3):

@@ -54,7 +54,7 @@ def test_streaming_backward_fits_two_workgroups_per_cu(metadata):
 def test_lds_window_kernels_fit_one_workgroup_of_eight_waves_per_cu(metadata):
     """The LDS-window backward kernels (round 5) hold a 128 x 128-cell window of both gradient maps (128 KB of the CU's 160 KB: one workgroup
     per CU) and run as workgroups of up to eight waves -- two per SIMD: at most 256 registers per lane, no scratch."""
-    rows = [(n, m) for o, n, m in metadata if m['lds'] == 2 * 128 * 128 * 4]
+    rows = [(n, m) for o, n, m in metadata if 2 * 128 * 128 * 4 <= m['lds'] <= 2 * 128 * 128 * 4 + 256]      # (+ the fused loss's eight wave sums)
     names = ' '.join(n for n, _ in rows)
     assert 'rollout_bwd_kernel<float, 4, 1, 1, true, false, true, true, true, true, false>' in names       # positions-only, interleaved maps, carry-over
     assert 'rollout_bwd_kernel<float, 4, 1, 1, true, false, true, true, true, true, true>' in names        # ... with the fused physics loss (round 6)

@@ -48,5 +48,16 @@ for B in [int(x) for x in os.environ.get('AB_B', '16384,32768').split(',')]:
                      ('whole fit step', lambda: prob.step(zl, ml, eager=True)), ('all outputs again', plain)):
         k, inst = timed(fn)
         print(f'B={B} {name:42s} {k}  {inst}', flush=True)
-    del prob, dp
+    # the whole step end to end, replayed as one hipGraph: HIP events around 8 replays
+    probg = TerrainFitProblem(dp, syn.bump_terrain(syn.bump_params(100), 6.4, 0.05).to(DEV), mu.to(DEV), cd, graph=True)
+    for _ in range(3):
+        probg.step(zl, ml)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(8):
+        probg.step(zl, ml)
+    e1.record()
+    torch.cuda.synchronize()
+    print(f'B={B} step replayed as one hipGraph: {e0.elapsed_time(e1) / 8:.4f} ms', flush=True)
+    del prob, probg, dp
     torch.cuda.empty_cache()
