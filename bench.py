@@ -696,66 +696,114 @@ class Runner:
                                          'cache-served bytes; _traffic = PMC-measured HBM bytes (None: no batch with a PMC pass reaches 40 % of HBM)'}
 
 
-def api_workload(r, T, N, integ, B=1024, iters=24):
-    """`c3_api`: the DROP-IN route a user of the unchanged scripts gets (scripts/fit_terrain.py:53-62,
-    scripts/train.py:399-406): `DPhysics.forward` -- six outputs, fresh tensors, launch by launch --, `monoforce.losses.physics_loss`
-    (plain torch ops on the returned states) and `loss.backward()` through autograd into the rollout's backward entry point (which
-    then READS upstream-gradient rows).  No fused loss, no hipGraph, no states-only forward: what the headline's `TerrainFitProblem`
-    route adds on top of the a1 API is exactly the difference between the two lines."""
+def points_sweep(r, T, integ, points=(32, 175, 223), batches=(64, 1024, 4096)):
+    """SURVEY 8d's secondary sweep -- N in {32, 175 (tradr), 223 (marv, the reference notebook's body)} -- over the batch, so that the reference's
+    body sizes have a saturation curve and not only the B = 64 latency point: the fit step's states-only forward and its
+    backward, kernel times from HIP events, SURVEY 8d's bytes and the instantiation's own."""
     from monoforce_amd import _timing
+    from monoforce_amd.train import TerrainFitProblem
+    from monoforce_amd import synthetic as syn
+    dev, rows = r.dev, {}
+    for Np in points:
+        for Bs in batches:
+            _, dps, _, _, z, mu, cs = build_problem(Bs, T, Np, dev, integ, seed=0)
+            cs = cs.to(dev)
+            prob = TerrainFitProblem(dps, syn.bump_terrain(syn.bump_params(100), 6.4, 0.05).to(dev), mu.to(dev), cs)
+            zl, ml = z.to(dev).clone().requires_grad_(True), mu.to(dev).clone().requires_grad_(True)
+            prob.step(zl, ml)
+            _timing.start()
+            for _ in range(2):
+                prob.step(zl, ml)
+            inst = _timing.launches()
+            k = {a: float(np.mean(v)) for a, v in _timing.stop().items()}
+            f_ms, b_ms = k['rollout_fwd_kernel'], k['rollout_bwd_kernel']
+            row = {'fwd_ms': f_ms, 'bwd_ms': b_ms, 'kernels': {a: inst.get(a) for a in ('rollout_fwd_kernel', 'rollout_bwd_kernel')},
+                   'fwd_rollout_steps_per_s': Bs * T / (f_ms * 1e-3), 'bwd_rollout_steps_per_s': Bs * T / (b_ms * 1e-3),
+                   'fwd_frac': fwd_states_only_bytes_per_rollout_step(Np) * Bs * T / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                   'bwd_frac': bwd_bytes_per_rollout_step(Np) * Bs * T / (b_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            for leg, ms in (('fwd', f_ms), ('bwd', b_ms)):
+                mb, _, _ = instance_bytes_per_rollout_step(inst.get(f'rollout_{leg}_kernel'), Np, T=T)
+                row[f'{leg}_frac_model'] = (mb * Bs * T / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if mb else None
+            rows[f'N{Np}_B{Bs}'] = row
+            del dps, prob, cs, zl, ml
+            torch.cuda.empty_cache()
+    return {'rows': rows, 'bytes_model': 'fwd_frac: states-only forward 80 + 32 N B per rollout-step; bwd_frac: SURVEY 8d 160 + 120 N; *_frac_model: the '
+                                           'instantiation that ran (positions-only upstream, 16-byte record)'}
+
+
+def api_workload(r, T, N, integ, B=1024, iters=24):
+    """`c3_api`: the DROP-IN route a user of the unchanged scripts gets (scripts/fit_terrain.py:53-62, scripts/train.py:399-406): `DPhysics.forward`
+    (six outputs), `monoforce.losses.physics_loss` on the returned states, `loss.backward()`.  Timed twice: as it runs by default -- after three
+    identical cycles the module replays the whole step as ONE hipGraph (monoforce_amd/api_cache.py: rollout with force rows + the loss inside
+    the launches + backward; `physics_loss` returns the graph's loss, its backward hands out the graph's gradients) -- and launch by launch
+    (MF_API_GRAPH=0: forward kernel, mf_nearest_steps + mf_physics_loss_value / _bwd, backward kernel reading dense dL/dXs rows), with the
+    host time of each of the three calls."""
+    from monoforce_amd import _timing, api_cache
     from monoforce.losses import physics_loss      # the reference's import path (the shim re-exports monoforce_amd.losses)
     from monoforce_amd import synthetic as syn
     dev = r.dev
-    cfg, dp, _, _, z, mu, ctrl = build_problem(B, T, N, dev, integ, seed=0)
-    cd = ctrl.to(dev)
-    with torch.no_grad():
-        (Xg, Xdg, Rg, Og), _ = dp(syn.bump_terrain(syn.bump_params(100), 6.4, 0.05).to(dev).unsqueeze(0), cd, friction=mu.to(dev).unsqueeze(0))
-    full_ts = torch.linspace(0, cfg.traj_sim_time, int(cfg.traj_sim_time / cfg.dt), device=dev)[:T]
-    sel = torch.arange(9, T, 10, device=dev)                      # 10 Hz ground-truth poses (datasets/rough.py:217,238)
-    pred_ts, gt_ts = full_ts.unsqueeze(0).expand(B, -1), full_ts[sel].unsqueeze(0).expand(B, -1).contiguous()
-    states_gt = [t[:, sel].contiguous() for t in (Xg, Xdg, Rg, Og)]
-    zl, ml = z.to(dev).clone().requires_grad_(True), mu.to(dev).clone().requires_grad_(True)
-    host = {'forward_call_us': [], 'loss_us': [], 'backward_call_us': []}
+    out = {}
+    for mode in ('cached', 'launch_by_launch'):
+        keep, api_cache.ENABLED = api_cache.ENABLED, mode == 'cached'
+        try:
+            cfg, dp, _, _, z, mu, ctrl = build_problem(B, T, N, dev, integ, seed=0)
+            cd = ctrl.to(dev)
+            with torch.no_grad():
+                (Xg, Xdg, Rg, Og), _ = dp(syn.bump_terrain(syn.bump_params(100), 6.4, 0.05).to(dev).unsqueeze(0), cd, friction=mu.to(dev).unsqueeze(0))
+            full_ts = torch.linspace(0, cfg.traj_sim_time, int(cfg.traj_sim_time / cfg.dt), device=dev)[:T]
+            sel = torch.arange(9, T, 10, device=dev)                      # 10 Hz ground-truth poses (datasets/rough.py:217,238)
+            pred_ts, gt_ts = full_ts.unsqueeze(0).expand(B, -1), full_ts[sel].unsqueeze(0).expand(B, -1).contiguous()
+            states_gt = [t[:, sel].contiguous() for t in (Xg, Xdg, Rg, Og)]
+            zl, ml = z.to(dev).clone().unsqueeze(0).requires_grad_(True), mu.to(dev).clone().unsqueeze(0).requires_grad_(True)
+            host = {'forward_call_us': [], 'loss_us': [], 'backward_call_us': []}
 
-    def step(record=False):
-        zl.grad = ml.grad = None
-        t0 = time.perf_counter()
-        states, forces = dp(z_grid=zl.unsqueeze(0), controls=cd, friction=ml.unsqueeze(0))
-        t1 = time.perf_counter()
-        loss = physics_loss(states_pred=states, states_gt=states_gt, pred_ts=pred_ts, gt_ts=gt_ts, gamma=0.9)
-        t2 = time.perf_counter()
-        loss.backward()
-        t3 = time.perf_counter()
-        if record:
-            host['forward_call_us'].append((t1 - t0) * 1e6); host['loss_us'].append((t2 - t1) * 1e6); host['backward_call_us'].append((t3 - t2) * 1e6)
-        return loss
+            def step(record=False):
+                zl.grad = ml.grad = None
+                t0 = time.perf_counter()
+                states, forces = dp(z_grid=zl, controls=cd, friction=ml)
+                t1 = time.perf_counter()
+                loss = physics_loss(states_pred=states, states_gt=states_gt, pred_ts=pred_ts, gt_ts=gt_ts, gamma=0.9)
+                t2 = time.perf_counter()
+                loss.backward()
+                t3 = time.perf_counter()
+                if record:
+                    host['forward_call_us'].append((t1 - t0) * 1e6); host['loss_us'].append((t2 - t1) * 1e6); host['backward_call_us'].append((t3 - t2) * 1e6)
+                return loss
 
-    for _ in range(4):
-        step()
-    r.barrier()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(iters):
-        step(record=True)
-    e1.record()
-    torch.cuda.synchronize(dev)
-    ms = (time.perf_counter() - t0) / iters * 1e3
-    gpu_ms = e0.elapsed_time(e1) / iters
-    _timing.start()
-    for _ in range(4):
-        _timing.next_step()
-        step()
-    launches = _timing.launches()
-    kern = {k: float(np.mean(v)) for k, v in _timing.stop().items()}
-    alg = {'rollout_fwd_kernel': fwd_bytes_per_rollout_step(N) * B * T, 'rollout_bwd_kernel': bwd_bytes_per_rollout_step(N) * B * T}
-    per_kernel = {k: {'ms': v, 'algorithmic_bytes': alg[k], 'frac': alg[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS} for k, v in kern.items() if k in alg}
+            for _ in range(6):      # (the cached step is captured in the fourth call)
+                step()
+            r.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record()
+            for _ in range(iters):
+                step(record=True)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            ms = (time.perf_counter() - t0) / iters * 1e3
+            row = {'ms_per_step': ms, 'device_ms_per_step': e0.elapsed_time(e1) / iters, 'host_us_per_call': {k: float(np.median(v)) for k, v in host.items()},
+                   'replays': getattr(dp.__dict__.get('_api_step_cache'), 'replays', 0)}
+            if mode == 'launch_by_launch':
+                _timing.start()
+                for _ in range(4):
+                    _timing.next_step()
+                    step()
+                row['kernels'] = _timing.launches()
+                kern = {k: float(np.mean(v)) for k, v in _timing.stop().items()}
+                alg = {'rollout_fwd_kernel': fwd_bytes_per_rollout_step(N) * B * T, 'rollout_bwd_kernel': bwd_bytes_per_rollout_step(N) * B * T}
+                row['per_kernel'] = {k: {'ms': v, 'algorithmic_bytes': alg[k], 'frac': alg[k] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS} for k, v in kern.items() if k in alg}
+                row['kernel_ms_sum'] = float(sum(kern.values()))
+            out[mode] = row
+            del dp
+        finally:
+            api_cache.ENABLED = keep
+    ms = out['cached']['ms_per_step']
     return {'value': B * T / (ms * 1e-3), 'unit': 'rollout-steps/s', 'ms_per_step': ms,
-            'workload': f'c3_api: B={B} x T={T} x N={N}, one shared 256x256 map pair, DPhysics.forward (six outputs, fresh tensors, eager) + '
-                        f'monoforce.losses.physics_loss (torch ops, 50 stamps) + loss.backward(); launch by launch, no hipGraph',
-            'launch': {'mode': 'launch by launch', 'kernels': launches},
-            'host_us_per_call': {k: float(np.median(v)) for k, v in host.items()},
-            'device_ms_per_step': gpu_ms, 'kernel_ms_sum': float(sum(kern.get(k, 0.0) for k in alg)), 'per_kernel': per_kernel}
+            'workload': f'c3_api: B={B} x T={T} x N={N}, one shared 256x256 map pair, DPhysics.forward (six outputs) + monoforce.losses.physics_loss (50 stamps) + '
+                        f'loss.backward() as the reference\'s scripts write them; default behaviour: the step replayed as one hipGraph after three identical cycles',
+            'launch': {'mode': 'one hipGraph replay per step (api_cache)' if out['cached']['replays'] >= iters else 'launch by launch'},
+            'cached': out['cached'], 'launch_by_launch': out['launch_by_launch'],
+            'per_kernel': out['launch_by_launch'].get('per_kernel', {})}
 
 
 def shoot_workload(r, T, N, integ, B=16384, iters=8):
@@ -919,6 +967,7 @@ def main():
                     'workload': o['config']['workload'], 'launch': o['config'].get('launch'), 'per_kernel': o['roofline']['per_kernel']}
         if r.world == 1 and not r.force_dist:
             res['roofline']['batch_sweep'] = r.batch_sweep(N, T)
+            res['roofline']['points_sweep'] = points_sweep(r, T, args.integrator)
             for name in ('c1', 'c2', 'ref_nb', 'n32', 'n175'):
                 others[name] = brief(r.run(name, short if name in ('c1', 'c2') else 6, 3, events_after=True)[0])
             others['shoot'] = shoot_workload(r, T, N, args.integrator)

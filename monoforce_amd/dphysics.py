@@ -263,7 +263,7 @@ def _rollout_forward_on_device(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts
     loss_val = lstruct = None
     in_backward = loss is not None and len(loss) > 2 and bool(loss[2]) and want_grad      # MF_LOSS_VALUE_IN_BACKWARD
     saturated = loss is not None and len(loss) > 3 and loss[3] == 2      # mf_rollout_loss_fusable = 2: the fusion lives in the BACKWARD launch alone
-    in_forward = (loss is not None and mod.loss_in_forward and not in_backward and not saturated
+    in_forward = (loss is not None and mod.loss_in_forward and not in_backward and not saturated and not want_forces
                   and desc.integrator == _lib.MF_INTEG_ODEINT_EULER)      # (the LOSS kernels: default integrator, component-parallel)
     if loss is not None:
         spec, X_gt = loss[:2]
@@ -346,8 +346,8 @@ class _RolloutLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_grad, x0_buf, x0_private, default_state, spec, X_gt,
-                value_in_backward=False, route=1):
-        outs = _rollout_forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_grad, None, False, x0_buf, x0_private,
+                value_in_backward=False, route=1, want_forces=False):
+        outs = _rollout_forward(ctx, mod, z, mu, controls, x_arg, xd0, R0, w0, ts, want_grad, None, bool(want_forces), x0_buf, x0_private,
                                 default_state, loss=(spec, X_gt, value_in_backward, route))
         ctx.mark_non_differentiable(*outs[1:])
         return outs
@@ -356,9 +356,9 @@ class _RolloutLossFn(torch.autograd.Function):
     def backward(ctx, gloss, *_unused):
         from .dphysics_bwd import rollout_backward
         if gloss is None:
-            return (None,) * 17
+            return (None,) * 18
         grads = rollout_backward(ctx, None, None, None, None, None, None, gloss=gloss)      # (mod, z, mu, controls, x, xd0, R0, w0, ts, want_grad, ja)
-        return grads[:10] + (None, None, None, None, None, None, None)
+        return grads[:10] + (None, None, None, None, None, None, None, None)
 
 
 class DPhysics(torch.nn.Module):
@@ -485,6 +485,19 @@ class DPhysics(torch.nn.Module):
         cfg = self.dphys_cfg
         dev = torch.device(self.device)
         dt_, T_ = cfg.dt, cfg.traj_sim_time
+        # the drop-in step at the fused step's speed (api_cache.py): after a few identical forward -> physics_loss cycles the whole step is
+        # ONE hipGraph replay; every other call runs launch by launch below (and is observed)
+        api_key = None
+        if _loss is None:
+            cache = self.__dict__.get('_api_step_cache')
+            if cache is None:
+                from .api_cache import ApiStepCache
+                cache = self.__dict__['_api_step_cache'] = ApiStepCache(self)
+            api_key = cache.forward_key(z_grid, controls, friction, joint_angles, state)
+            if api_key is not None:
+                hit = cache.try_forward(api_key, z_grid, controls, friction)
+                if hit is not None:
+                    return hit
         # extension over the reference: a [1,H,W] map with B > 1 controls is ONE terrain shared by all rollouts
         batch_size = z_grid.shape[0] if z_grid.shape[0] != 1 else controls.shape[0]
         z_grid = z_grid.to(dev)
@@ -550,7 +563,8 @@ class DPhysics(torch.nn.Module):
         if _loss is not None:       # physics_loss inside the launches (physics_loss_rollout)
             spec, X_gt = _loss[:2]
             outs = _RolloutLossFn.apply(self, z_grid, friction, controls, x_arg, xd0, R0, w0, ts, want_grad, x0, own_state,
-                                        state_in_kernel, spec, X_gt, len(_loss) > 2 and bool(_loss[2]), _loss[3] if len(_loss) > 3 else 1)
+                                        state_in_kernel, spec, X_gt, len(_loss) > 2 and bool(_loss[2]), _loss[3] if len(_loss) > 3 else 1,
+                                        len(_loss) > 4 and bool(_loss[4]))
             loss_val, outs = outs[0], outs[1:]
         else:
             outs = _RolloutFn.apply(self, z_grid, friction, controls, x_arg, xd0, R0, w0, ts, want_grad, ja_dev, want_forces,
@@ -561,7 +575,11 @@ class DPhysics(torch.nn.Module):
         Xs, Xds, Rs, Omegas = outs[:4]
         F_springs, F_frictions = outs[4:] if len(outs) == 6 else (None, None)
         if _loss is not None:
+            if len(_loss) > 4 and _loss[4]:
+                return loss_val, (Xs, Xds, Rs, Omegas), (F_springs, F_frictions)
             return loss_val, (Xs, Xds, Rs, Omegas)
+        if api_key is not None:
+            cache.tag_eager_outputs(Xs, api_key, None)
         return (Xs, Xds, Rs, Omegas), (F_springs, F_frictions)
 
     def loss_spec(self, gt_ts, gamma=0.9, n_steps=None, dtype=torch.float32):
@@ -570,7 +588,7 @@ class DPhysics(torch.nn.Module):
         n = len(self.ts) if n_steps is None else int(n_steps)
         return LossSpec(self._time_grid(n, dtype, torch.device('cpu')), gt_ts, gamma, torch.device(self.device), dtype=dtype)
 
-    def physics_loss_rollout(self, z_grid, controls, X_gt, spec, state=None, friction=None, value_in_backward=False):
+    def physics_loss_rollout(self, z_grid, controls, X_gt, spec, state=None, friction=None, value_in_backward=False, want_forces=False):
         """`physics_loss(self(z_grid, controls, ...), [X_gt], pred_ts, gt_ts, gamma)` (losses.py:102-127, the position term the training
         scripts use: scripts/train.py:399-406, scripts/fit_terrain.py:53-62) with the loss INSIDE the rollout's two launches (SURVEY.md
         8f rank 1): the forward kernel accumulates the time-weighted squared error at the stamped rows while it writes them, the
@@ -578,6 +596,8 @@ class DPhysics(torch.nn.Module):
         Returns (loss, (Xs, Xds, Rs, Omegas)); the states come back detached from the graph (only the loss is differentiable) and are
         READ-ONLY until `loss.backward()` has run: the backward launch re-reads the Xs rows to form dL/dXs (they are not copied, and an
         in-place edit would not be noticed by autograd's version check).
+        `want_forces`: also write and return the force rows, (loss, states, (F_springs, F_frictions)) -- what `forward` hands out (the cached
+        drop-in step, `_ApiStepCache`).
         `value_in_backward` (MF_LOSS_VALUE_IN_BACKWARD): for a caller that ALWAYS calls `loss.backward()` next and reads the value
         only afterwards (a fit loop): the backward launch forms the value too -- the returned scalar is NaN until then -- and the
         step loses its one remaining loss launch.
@@ -604,17 +624,18 @@ class DPhysics(torch.nn.Module):
         if not ok:
             # (the loss reads the positions only: the forward writes the states, not the 24 N bytes of force rows per rollout-step -- for the
             #  reference's 223-point body 36 of 241 MB per launch; `return_forces` is restored for the module's other callers)
-            keep, self.return_forces = self.return_forces, False
+            keep, self.return_forces = self.return_forces, bool(want_forces)
             try:
-                states, _ = self.dphysics(z_grid, controls, state=state, friction=friction)
+                states, forces = self.dphysics(z_grid, controls, state=state, friction=friction)
             finally:
                 self.return_forces = keep
             B_, T2 = X_gt.shape[:2]
             gt_ts = spec.gt_ts.unsqueeze(0).expand(B_, -1)
-            return physics_loss_fused(states, [X_gt], None, gt_ts, gamma=spec.gamma, nearest=spec.near.unsqueeze(0).expand(B_, -1)), states
+            loss = physics_loss_fused(states, [X_gt], None, gt_ts, gamma=spec.gamma, nearest=spec.near.unsqueeze(0).expand(B_, -1))
+            return (loss, states, forces) if want_forces else (loss, states)
         Xg = X_gt.detach().to(device=torch.device(self.device), dtype=z_grid.dtype).contiguous()
         assert Xg.shape == (B, spec.T2, 3), f'X_gt shape {tuple(Xg.shape)} != {(B, spec.T2, 3)}'
-        return self.dphysics(z_grid, controls, state=state, friction=friction, _loss=(spec, Xg, bool(value_in_backward), fus))
+        return self.dphysics(z_grid, controls, state=state, friction=friction, _loss=(spec, Xg, bool(value_in_backward), fus, bool(want_forces)))
 
     @torch.no_grad()
     def rollout_costs(self, z_grid, controls, state=None, friction=None, pose_stride=None, project=True):

@@ -73,12 +73,37 @@ def physics_loss(states_pred, states_gt, pred_ts, gt_ts, gamma=0.9, rotation_los
     half its backward (a sort inside `index_put_`'s backward, two 25.6 M-element temporaries for the argmin).
     `monoforce_amd.losses._HIP_LOSS = False` keeps the ATen form everywhere."""
     X_gt, X_pred = states_gt[0], states_pred[0]
+    # the cached drop-in step (api_cache.py): these ARE the states a replayed step handed out and this IS the call it was captured with ->
+    # the graph's loss, whose backward hands out the graph's gradients; a launch-by-launch forward's states are observed instead
+    tag = getattr(X_pred, '_mf_step', None)
+    if tag is not None:
+        hit = tag[0].cached_loss(tag, states_pred, states_gt, pred_ts, gt_ts, gamma, rotation_loss, nearest)
+        if hit is not None:
+            return hit
+    else:
+        tag = getattr(X_pred, '_mf_obs', None)
+        if tag is not None:
+            tag[0].observe_loss(tag, states_pred, states_gt, pred_ts, gt_ts, gamma, rotation_loss, nearest)
+    # (the HIP route returns the loss in X_pred's dtype, sends no gradient to X_gt / gt_ts and stores -- not adds -- a row's gradient: it takes
+    #  the call only where that IS the reference's result -- same dtypes, constants that do not require grad, a non-empty batch, rows of
+    #  X_pred that do not alias each other -- and leaves the rest to the ATen form.  ADVICE r5.)
     if (_HIP_LOSS and not rotation_loss and X_pred.is_cuda and X_pred.dtype in (torch.float32, torch.float64) and X_pred.dim() == 3
-            and X_pred.stride(2) == 1 and X_gt.is_cuda and gt_ts.is_cuda and (nearest is not None or pred_ts.is_cuda)):
+            and X_pred.stride(2) == 1 and X_gt.is_cuda and gt_ts.is_cuda and (nearest is not None or pred_ts.is_cuda)
+            and X_gt.dtype == X_pred.dtype and gt_ts.dtype == X_pred.dtype and not X_gt.requires_grad and not gt_ts.requires_grad
+            and X_pred.numel() > 0 and X_gt.numel() > 0 and _rows_do_not_overlap(X_pred)):
         if nearest is None:
             nearest = nearest_steps_hip(pred_ts, gt_ts)
         return _FusedPhysicsLoss.apply(X_pred, X_gt, gt_ts, nearest, gamma)
     return physics_loss_aten(states_pred, states_gt, pred_ts, gt_ts, gamma=gamma, rotation_loss=rotation_loss, nearest=nearest)
+
+
+def _rows_do_not_overlap(X):
+    """True when no two (rollout, step) rows of X[B,T,3] share memory (an `expand`ed / stride-0 X_pred aliases rows: the scatter kernel's
+    plain stores would then drop contributions that the reference's index_put_ adds up)."""
+    (lo, nlo), (hi, nhi) = sorted([(abs(X.stride(0)), X.shape[0]), (abs(X.stride(1)), X.shape[1])])
+    if nlo > 1 and lo < 3:
+        return False
+    return not (nhi > 1 and hi < lo * (nlo - 1) + 3)
 
 
 def physics_loss_aten(states_pred, states_gt, pred_ts, gt_ts, gamma=0.9, rotation_loss=False, nearest=None):
