@@ -1014,6 +1014,13 @@ def main():
         import torch.distributed as dist
         dist.destroy_process_group()      # (before the line: whatever the collective library says on its way out must not follow it)
     if r.rank == 0:
+        # (RCCL announces itself with a C printf -- 'Librccl path : ...' -- that sits in the C library's buffer while stdout is a pipe and would
+        #  come out at exit, BEHIND the line: flush every C stream first)
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         sys.stdout.flush()
         print(line, flush=True)      # the LAST stdout line, < 4 KB: what the driver parses
 

@@ -1,0 +1,152 @@
+"""The soak problems that landed outside the oracle-derived bar in round 5 (profiles/r5i_soak_win.txt: LDS-window problem 53; profiles/r5h_soak.txt:
+multi-wave problems 118 and 146), rebuilt from their seeds with the generators of tools/soak_win.py and tools/soak_r5.py, so that
+tests/test_soak_outliers_gpu.py can hold each one to its EXPLANATION instead of a text file.  Test infrastructure (imports oracle/).
+
+    python -m tests.soak_cases <kind> <seed> <out.pt>      dumps the float32 HIP gradients of the case (the child process of the route-equality test:
+                                                            MF_BWD_WIN / MF_MW_BWD are read once per process)"""
+import sys
+
+import numpy as np
+import torch
+
+from oracle import dphysics_oracle as orc
+from tests import helpers as hp
+from tests.test_rollout_gpu import make_dphysics
+
+DEV = 'cuda'
+SINK = 40.0 * 9.81 / (5e4 + 1e-6)      # m g / (k + 1e-6): Xs = x + R[:, 2] * sink (dphysics.py:587-589), tradr mass, default stiffness
+
+
+class Case:
+    pass
+
+
+def build(kind, seed):
+    from monoforce_amd import synthetic as syn
+    c = Case()
+    c.kind, c.seed = kind, seed
+    if kind == 'win':      # tools/soak_win.py
+        rng = np.random.RandomState(9000 + seed)
+        B = int(rng.choice([4608, 6144, 8192, 8192 + 512, 12288, 16384, 16384 + 37, 24576, 32768, 32768 + 4]))
+        T = int(rng.randint(20, 121)); H = int(rng.choice([64, 128, 256, 512])); res = 12.8 / H
+        N = int(rng.choice([3, 4])); integ = int(rng.randint(0, 2)); friction = bool(rng.randint(0, 4)); scattered = bool(rng.randint(0, 2))
+        pts4, _ = syn.robot_points_4()
+        pts = pts4[:N].copy(); masks = [pts[:, 1] > 0, pts[:, 1] <= 0]
+        z = (syn.bump_terrain(syn.bump_params(seed + 3), 6.4, res) * float(rng.choice([0.3, 1.0]))).unsqueeze(0)
+        mu = syn.wave_friction(6.4, res).unsqueeze(0) if friction else None
+        ctrl = syn.const_controls(B, T, seed=seed)
+        sub = 24
+        sel = torch.cat([torch.arange(0, B, B // (sub - 3))[:sub - 3], torch.arange(B - 3, B)])
+        state = None
+        if scattered:
+            g = torch.Generator().manual_seed(seed)
+            x0 = torch.zeros(B, 3); x0[:, :2] = (torch.rand(B, 2, generator=g) - 0.5) * 12.4
+            yaw = torch.rand(B, generator=g) * 6.2831853
+            R0 = torch.zeros(B, 3, 3); R0[:, 0, 0] = yaw.cos(); R0[:, 0, 1] = -yaw.sin(); R0[:, 1, 0] = yaw.sin(); R0[:, 1, 1] = yaw.cos(); R0[:, 2, 2] = 1.0
+            xd0 = torch.zeros(B, 3); xd0[:, 0] = ctrl[:, 0, 0] * yaw.cos(); xd0[:, 1] = ctrl[:, 0, 0] * yaw.sin()
+            w0 = torch.zeros(B, 3); w0[:, 2] = ctrl[:, 0, 1]
+            state = (x0, xd0, R0, w0)
+        c.B, c.T, c.H, c.res, c.d_max, c.N, c.integ, c.shared = B, T, H, res, 6.4, N, integ, True
+        c.pts, c.masks, c.z, c.mu, c.ctrl, c.sel, c.state = pts, masks, z, mu, ctrl, sel, state
+        c.wts = syn.probe_weights((sel.numel(), T, 3), phase=0.1 * seed)
+        c.all_outputs = False
+    else:                  # tools/soak_r5.py, the multi-wave generator
+        rng = np.random.RandomState(seed)
+        N = int(rng.choice([5, 7, 8, 9, 16, 17, 32, 33, 50, 64, 65, 100, 128, 129, 175, 223, 256, 257, 300]))
+        B = int(rng.randint(1, 41)); T = int(rng.choice([2, 3, 5, 17, 40, 80, 120]))
+        nt = int(rng.choice([2, 4])); integ = int(rng.randint(0, 2)); shared = bool(rng.randint(0, 2)); use_mu = bool(rng.randint(0, 3))
+        rs_ = float(rng.choice([0.05, 0.1])); d_max = 3.2; xs_only = bool(rng.randint(0, 2))
+        pts, masks = syn.robot_points_box(N, seed=seed, n_tracks=nt)
+        nb = 1 if shared else B
+        z = torch.stack([syn.bump_terrain(syn.bump_params(seed + b, smooth=bool(rng.randint(0, 2))), d_max, rs_, torch.float64) * 0.3 for b in range(nb)]).float()
+        mu = torch.stack([syn.wave_friction(d_max, rs_, 0.5, 1.0, 1.0 + 0.1 * b, 0.8, torch.float64) for b in range(nb)]).float()
+        ctrl = syn.varying_controls(B, T, seed=seed, dtype=torch.float64).float()
+        where = rng.choice(['centre', 'edge', 'off'])
+        x0 = torch.zeros(B, 3); x0[:, 0] = {'centre': 0.0, 'edge': d_max - 0.3, 'off': d_max + 0.5}[where]; x0[:, 1] = torch.from_numpy(rng.uniform(-1, 1, B)).float()
+        yaw = torch.from_numpy(rng.uniform(-3.1, 3.1, B)).float()
+        R0 = torch.zeros(B, 3, 3); R0[:, 0, 0] = yaw.cos(); R0[:, 0, 1] = -yaw.sin(); R0[:, 1, 0] = yaw.sin(); R0[:, 1, 1] = yaw.cos(); R0[:, 2, 2] = 1
+        xd0 = torch.stack([yaw.cos(), yaw.sin(), torch.zeros(B)], 1) * 0.8
+        c.B, c.T, c.H, c.res, c.d_max, c.N, c.integ, c.shared = B, T, z.shape[-1], rs_, d_max, N, integ, shared
+        c.pts, c.masks, c.z, c.mu, c.ctrl, c.sel = pts, masks, z, (mu if use_mu else None), ctrl, torch.arange(B)
+        c.state = (x0, xd0, R0, torch.zeros(B, 3))
+        c.all_outputs, c.where = not xs_only, str(where)
+        c.wts = None
+    c.spec = hp.spec_from(c.pts, c.masks, c.integ, c.res, c.d_max)
+    return c
+
+
+def _loss(c, outs, dt, dev, rows_mask):
+    """The soak's probe loss over the selected rollouts; `rows_mask` [n_sel] switches rollouts off."""
+    from monoforce_amd import synthetic as syn
+    m = rows_mask.to(dt).to(dev)
+    if c.kind == 'win':
+        return (outs[0] * c.wts.to(dt).to(dev) * m.view(-1, 1, 1)).sum()
+    if not c.all_outputs:
+        X = outs[0][:, ::3]
+        return (X * syn.probe_weights(X.shape, 0.3, dtype=dt).to(dev) * m.view(-1, 1, 1)).sum()
+    scales = [1.0, 1.0, 1.0, 1.0, 1e-3, 1e-3]
+    loss = 0
+    for i, (o, s) in enumerate(zip(outs, scales)):
+        mm = m.view(-1, *([1] * (o.dim() - 1)))
+        loss = loss + (o * syn.probe_weights(o.shape, phase=0.5 + i, dtype=dt).to(o.device) * mm).sum() * s
+    return loss
+
+
+def _maps(c, t, n, rows):
+    if t is None:
+        return None
+    if t.shape[0] == 1:
+        return t.expand(n, -1, -1) if c.kind != 'win' else t
+    return t if rows is None else t[rows]
+
+
+def run_hip(c, dt=torch.float32, rows=None, rows_mask=None, points_per_lane=0):
+    """Gradients (z, mu, controls of the selected rollouts) and outputs of the HIP route.  `rows`: run ONLY these rollouts as their own small
+    batch (other kernels: what the float64 check uses)."""
+    from monoforce_amd import _timing
+    dp = make_dphysics(c.pts, c.masks, c.integ, c.res, c.d_max, points_per_lane=points_per_lane)
+    dp.dphys_cfg.traj_sim_time = 5.0
+    idx = c.sel if rows is None else rows
+    ctrl = c.ctrl if rows is None else c.ctrl[rows]
+    n = ctrl.shape[0]
+    leaf = lambda t: t.to(dt).to(DEV).detach().clone().requires_grad_(True)      # noqa: E731
+    per_rollout_maps = c.z.shape[0] > 1
+    zsrc = c.z if (rows is None or not per_rollout_maps) else c.z[rows]
+    msrc = None if c.mu is None else (c.mu if (rows is None or not per_rollout_maps) else c.mu[rows])
+    zd, md, cd = leaf(zsrc), (leaf(msrc) if msrc is not None else None), leaf(ctrl)
+    ex = lambda m: None if m is None else (m.expand(n, -1, -1) if (m.shape[0] == 1 and c.kind != 'win') else m)      # noqa: E731
+    st = None
+    if c.state is not None:
+        st = tuple((t if rows is None else t[rows]).clone().to(dt).to(DEV) for t in c.state)
+    _timing.start()
+    states, forces = dp(ex(zd), cd, friction=ex(md), state=st)
+    outs = list(states) + list(forces)
+    sel_local = idx.to(DEV) if rows is None else torch.arange(n, device=DEV)
+    mask = torch.ones(sel_local.numel()) if rows_mask is None else rows_mask
+    _loss(c, [o[sel_local] for o in outs], dt, DEV, mask).backward()
+    name = _timing.launches().get('rollout_bwd_kernel', '?').split(' grid')[0]
+    _timing.stop()
+    return dict(gz=zd.grad.cpu(), gmu=(md.grad.cpu() if md is not None else None), gc=cd.grad[sel_local].cpu(),
+                Xs=outs[0][sel_local].detach().cpu(), Rs=outs[2][sel_local].detach().cpu(), kernel=name)
+
+
+def run_oracle(c, dt, rows=None, rows_mask=None):
+    idx = c.sel if rows is None else rows
+    n = idx.numel()
+    per_rollout_maps = c.z.shape[0] > 1
+    zc = (c.z if not per_rollout_maps else c.z[idx]).to(dt).requires_grad_(True)
+    mc = None if c.mu is None else (c.mu if not per_rollout_maps else c.mu[idx]).to(dt).requires_grad_(True)
+    cc = c.ctrl[idx].to(dt).requires_grad_(True)
+    st = tuple(t[idx].clone().to(dt) for t in c.state) if c.state is not None else None
+    ex = lambda m: None if m is None else (m.expand(n, -1, -1) if m.shape[0] == 1 else m)      # noqa: E731
+    states, forces = orc.rollout(c.spec, ex(zc), cc, state=st, friction=ex(mc))
+    outs = list(states) + list(forces)
+    mask = torch.ones(n) if rows_mask is None else rows_mask
+    _loss(c, outs, dt, 'cpu', mask).backward()
+    return dict(gz=zc.grad, gmu=(mc.grad if mc is not None else None), gc=cc.grad, Xs=outs[0].detach(), Rs=outs[2].detach())
+
+
+if __name__ == '__main__':
+    kind, seed, out = sys.argv[1], int(sys.argv[2]), sys.argv[3]
+    r = run_hip(build(kind, seed))
+    torch.save(r, out)
