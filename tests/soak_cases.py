@@ -75,20 +75,23 @@ def build(kind, seed):
     return c
 
 
-def _loss(c, outs, dt, dev, rows_mask):
-    """The soak's probe loss over the selected rollouts; `rows_mask` [n_sel] switches rollouts off."""
+def _loss(c, outs, dt, dev, rows_mask, widx=None):
+    """The soak's probe loss over the selected rollouts; `rows_mask` [n] switches rollouts off; `widx`: positions (in the full selection) of
+    the rollouts at hand, so that a subset is weighted like the same rollouts of the full problem."""
     from monoforce_amd import synthetic as syn
     m = rows_mask.to(dt).to(dev)
+    n_full = c.sel.numel()
+    pick = (lambda w: w) if widx is None else (lambda w: w[widx.to(w.device)])
     if c.kind == 'win':
-        return (outs[0] * c.wts.to(dt).to(dev) * m.view(-1, 1, 1)).sum()
+        return (outs[0] * pick(c.wts.to(dt).to(dev)) * m.view(-1, 1, 1)).sum()
     if not c.all_outputs:
         X = outs[0][:, ::3]
-        return (X * syn.probe_weights(X.shape, 0.3, dtype=dt).to(dev) * m.view(-1, 1, 1)).sum()
+        return (X * pick(syn.probe_weights((n_full,) + tuple(X.shape[1:]), 0.3, dtype=dt).to(dev)) * m.view(-1, 1, 1)).sum()
     scales = [1.0, 1.0, 1.0, 1.0, 1e-3, 1e-3]
     loss = 0
     for i, (o, s) in enumerate(zip(outs, scales)):
         mm = m.view(-1, *([1] * (o.dim() - 1)))
-        loss = loss + (o * syn.probe_weights(o.shape, phase=0.5 + i, dtype=dt).to(o.device) * mm).sum() * s
+        loss = loss + (o * pick(syn.probe_weights((n_full,) + tuple(o.shape[1:]), phase=0.5 + i, dtype=dt).to(o.device)) * mm).sum() * s
     return loss
 
 
@@ -101,11 +104,13 @@ def _maps(c, t, n, rows):
 
 
 def run_hip(c, dt=torch.float32, rows=None, rows_mask=None, points_per_lane=0):
-    """Gradients (z, mu, controls of the selected rollouts) and outputs of the HIP route.  `rows`: run ONLY these rollouts as their own small
-    batch (other kernels: what the float64 check uses)."""
+    """Gradients (z, mu, controls of the selected rollouts) and outputs of the HIP route.  `rows` (positions in the selection): run ONLY these
+    rollouts as their own small batch (other kernels: what the float64 check uses)."""
     from monoforce_amd import _timing
     dp = make_dphysics(c.pts, c.masks, c.integ, c.res, c.d_max, points_per_lane=points_per_lane)
     dp.dphys_cfg.traj_sim_time = 5.0
+    widx = rows                                   # positions in the selection (weights); `rows` below: rollout indices
+    rows = None if rows is None else c.sel[rows]
     idx = c.sel if rows is None else rows
     ctrl = c.ctrl if rows is None else c.ctrl[rows]
     n = ctrl.shape[0]
@@ -123,7 +128,7 @@ def run_hip(c, dt=torch.float32, rows=None, rows_mask=None, points_per_lane=0):
     outs = list(states) + list(forces)
     sel_local = idx.to(DEV) if rows is None else torch.arange(n, device=DEV)
     mask = torch.ones(sel_local.numel()) if rows_mask is None else rows_mask
-    _loss(c, [o[sel_local] for o in outs], dt, DEV, mask).backward()
+    _loss(c, [o[sel_local] for o in outs], dt, DEV, mask, widx).backward()
     name = _timing.launches().get('rollout_bwd_kernel', '?').split(' grid')[0]
     _timing.stop()
     return dict(gz=zd.grad.cpu(), gmu=(md.grad.cpu() if md is not None else None), gc=cd.grad[sel_local].cpu(),
@@ -131,18 +136,20 @@ def run_hip(c, dt=torch.float32, rows=None, rows_mask=None, points_per_lane=0):
 
 
 def run_oracle(c, dt, rows=None, rows_mask=None):
-    idx = c.sel if rows is None else rows
+    widx = rows
+    idx = c.sel if rows is None else c.sel[rows]
     n = idx.numel()
     per_rollout_maps = c.z.shape[0] > 1
-    zc = (c.z if not per_rollout_maps else c.z[idx]).to(dt).requires_grad_(True)
-    mc = None if c.mu is None else (c.mu if not per_rollout_maps else c.mu[idx]).to(dt).requires_grad_(True)
-    cc = c.ctrl[idx].to(dt).requires_grad_(True)
+    leaf = lambda t: t.detach().clone().to(dt).requires_grad_(True)      # noqa: E731  (a copy: .to(float32) of a float32 tensor is the tensor itself)
+    zc = leaf(c.z if not per_rollout_maps else c.z[idx])
+    mc = None if c.mu is None else leaf(c.mu if not per_rollout_maps else c.mu[idx])
+    cc = leaf(c.ctrl[idx])
     st = tuple(t[idx].clone().to(dt) for t in c.state) if c.state is not None else None
     ex = lambda m: None if m is None else (m.expand(n, -1, -1) if m.shape[0] == 1 else m)      # noqa: E731
     states, forces = orc.rollout(c.spec, ex(zc), cc, state=st, friction=ex(mc))
     outs = list(states) + list(forces)
     mask = torch.ones(n) if rows_mask is None else rows_mask
-    _loss(c, outs, dt, 'cpu', mask).backward()
+    _loss(c, outs, dt, 'cpu', mask, widx).backward()
     return dict(gz=zc.grad, gmu=(mc.grad if mc is not None else None), gc=cc.grad, Xs=outs[0].detach(), Rs=outs[2].detach())
 
 

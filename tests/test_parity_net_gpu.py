@@ -208,6 +208,8 @@ def test_saturated_positions_only_backward_vs_oracle(integ, friction, scattered,
     from monoforce_amd import synthetic as syn, _timing
     T, sub = 60, 32      # (B = 8192: two waves per SIMD of the component-parallel early-recompute kernel, the same window)
     win = os.environ.get('MF_BWD_WIN', '1') != '0'
+    if not win and not (friction and B in (8192, 16384)):
+        pytest.skip('the register-accumulator child runs the eight cases with a friction map at 8192 / 16 384 rollouts (VERDICT r5 item 9)')
     pts, masks = syn.robot_points_4()
     z = syn.bump_terrain(syn.bump_params(5), 6.4, 0.05)
     mu = syn.wave_friction(6.4, 0.05) if friction else None
@@ -341,7 +343,7 @@ def test_saturated_backward_without_the_lds_window_vs_oracle():
                         'test_saturated_positions_only_backward_vs_oracle'], env=dict(os.environ, MF_BWD_WIN='0'), capture_output=True, text=True,
                        timeout=1200, cwd=repo)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert '24 passed' in r.stdout, r.stdout[-500:]
+    assert '8 passed' in r.stdout and '16 skipped' in r.stdout, r.stdout[-500:]
 
 
 def test_config4_full_size_step_vs_oracles():
