@@ -1063,6 +1063,34 @@ static inline LaneMap choose_lane_map(int B, int N, int points_per_lane) {
 
 // Instantiated mappings: one point per lane (G = 4..64) and (64, 2/4/8) always; the 4-points-per-lane mappings with G < 64
 // only for the full-output rigid-body kernels (they are a tuning / test option, see choose_lane_map).
+// Round 6: the controls of a saturated launch read ONCE in front of it.  A step loads the next step's (v, w) one step ahead (~0.7 us at
+// 16 384 rollouts) inside its dependent chain, and vmcnt retires loads in order: while the [B][T][2] array sits in the memory-side cache
+// (forward after forward) that is free, but the forward of a fit / train step follows a backward that has streamed ~700 MB through the
+// caches, and every 64-byte line of controls then costs an HBM round trip in front of the step's gathers -- forward 0.34 -> 0.43 ms at
+// 16 384 rollouts, 0.35 again with this 16 us pass (tools/ab_step_fwd2.py, profiles/r6_ab_step_fwd.txt).  A deeper in-kernel prefetch does
+// not help: a load that misses stalls the younger gathers behind it wherever it is issued.  MF_FWD_TOUCH_CONTROLS=0: A/B.
+template <int UNUSED = 0>      // (a template: one definition across the translation units that include this header)
+__global__ void __launch_bounds__(256) touch_lines_kernel(const float4* __restrict__ p, long long n16, float4* __restrict__ sink) {
+  float4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (long long)gridDim.x * blockDim.x) {
+    const float4 v = p[i];
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  if (acc.x == 1.2345e-30f && acc.y == 5.4321e-30f) *sink = acc;      // (never: keeps the loads)
+}
+template <typename S>
+static inline void touch_controls(const RolloutArgs<S>& a, const LaneMap& m, int b0, int nb, hipStream_t st) {
+  static const bool off = getenv("MF_FWD_TOUCH_CONTROLS") && atoi(getenv("MF_FWD_TOUCH_CONTROLS")) == 0;
+  if (off || a.ctrl_st == 0 || a.ctrl_sb != a.T * 2 || m.G > 64) return;      // (one pair per rollout, or rows that are not adjacent: nothing to stream)
+  if ((long long)nb * m.G < device_simds() / 2 * 64) return;                   // (below half a wave per SIMD a step is longer than the round trip)
+  const long long bytes = (long long)nb * a.T * 2 * (long long)sizeof(S);
+  if (bytes < (8ll << 20) || bytes > (192ll << 20)) return;                    // (a few MB stay resident anyway; more than the cache holds is futile)
+  const char* base = reinterpret_cast<const char*>(a.controls + (size_t)b0 * a.ctrl_sb);
+  const char* al = reinterpret_cast<const char*>(((uintptr_t)base + 15) & ~(uintptr_t)15);
+  const long long n16 = (bytes - (al - base)) / 16;
+  hipLaunchKernelGGL((touch_lines_kernel<0>), dim3(2048), dim3(256), 0, st, reinterpret_cast<const float4*>(al), n16, reinterpret_cast<float4*>(const_cast<char*>(al)));
+}
+
 template <typename S, bool FAST, bool JOINTS = false, bool FORCES = true, int COST = 0, bool SPLIT = false, bool ZMU = false>
 int launch_rollout_fwd(const RolloutArgs<S>& a, LaneMap m, int integ, int block, hipStream_t st) {
   if (m.G > 64) block = m.G;   // a rollout spread over several waves: exactly one rollout per workgroup (LDS + barrier)
@@ -1079,6 +1107,7 @@ int launch_rollout_fwd(const RolloutArgs<S>& a, LaneMap m, int integ, int block,
   ac.b0 = b0;
   const long long threads = (long long)((a.B - b0 < chunk_B) ? a.B - b0 : chunk_B) * m.G;
   const unsigned grid = (unsigned)((threads + block - 1) / block);
+  touch_controls(a, m, b0, (a.B - b0 < chunk_B) ? a.B - b0 : chunk_B, st);
   launched = false;
 #define MF_CASE(G_, P_)                                                                                                                   \
   if (!launched && m.G == G_ && m.PPL == P_) {                                                                                             \

@@ -59,6 +59,14 @@ def seq_e():      # a 256 MB fill between the step and the next forward (flushes
     prob.step(zl, ml, eager=True); big.zero_(); fwd()
 
 
-for name, s in (('A fwd fwd fwd', seq_a), ('B step fwd fwd', seq_b), ('C step sleep fwd', seq_c), ('E step fill256MB fwd', seq_e)):
+def seq_f():      # the controls (65 MB at 16 384 x 500) read once between the step and the forward: back in the memory-side cache?
+    prob.step(zl, ml, eager=True); cd.sum(); fwd()
+
+
+def seq_g():      # ... and the other way round: the fill evicts them in front of an otherwise 'alone' forward
+    fwd(); big.zero_(); fwd(); cd.sum(); fwd()
+
+
+for name, s in (('F step read-controls fwd', seq_f), ('G fwd fill fwd read-controls fwd', seq_g), ('A fwd fwd fwd', seq_a), ('B step fwd fwd', seq_b), ('C step sleep fwd', seq_c), ('E step fill256MB fwd', seq_e)):
     f, rest = fwd_times(s)
     print(f'B={B} {name:24s} forwards in order {f}  others {rest}', flush=True)
