@@ -24,6 +24,15 @@ static long long xs_bwd_min_waves() {
 static bool xs_bwd_shape(const MfRolloutDesc* d, const LaneMap& m) {
   return !xs_bwd_off() && m.PPL == 1 && m.G <= 64 && (long long)d->B * m.G >= xs_bwd_min_waves() * 64;
 }
+// the component-parallel backward in its ONE-WAVE forms (beyond the streaming form's grid, up to two waves per SIMD): dL/dXs formed where the
+// row is consumed (rollout_bwd_cp_kernel.h ONE1); the value comes from mf_physics_loss_value_* on the forward's rows
+bool cp_loss_one_wave(const MfRolloutDesc* d, int scalar_bytes) {
+  static const bool off = getenv("MF_CP_LOSS_ONE_WAVE") && atoi(getenv("MF_CP_LOSS_ONE_WAVE")) == 0;      // A/B: the unfused route
+  if (off || !d || d->layout != MF_LAYOUT_TIME_MAJOR || d->has_joints || cp_loss_fusable(d)) return false;
+  if (scalar_bytes != 4 && d->points_per_lane != MF_LANES_COMPONENT) return false;
+  MfRolloutBwdBufs none{};
+  return use_component_parallel_bwd(d, &none, scalar_bytes);
+}
 bool xs_loss_fusable(const MfRolloutDesc* d) {
   static const bool off = getenv("MF_BWD_XS_LOSS") && atoi(getenv("MF_BWD_XS_LOSS")) == 0;      // A/B: the unfused route (dense dL/dXs rows)
   if (off || !d || d->B <= 0 || d->T <= 0 || d->N <= 0 || d->N > 64 || d->has_joints) return false;
@@ -100,7 +109,10 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
     const MfRolloutLoss* L = p->loss;
     const bool loss_cp = (sizeof(S) == 4 || d->points_per_lane == MF_LANES_COMPONENT) && cp_loss_fusable(d) && p->rec && !p->joint_angles;
     const bool loss_xs = !loss_cp && sizeof(S) == 4 && xs_loss_fusable(d) && !p->joint_angles;
-    MF_REQUIRE(loss_cp || loss_xs, MF_ERR_UNSUPPORTED,
+    // (3: the one-wave forms of the component-parallel backward -- record read by the computing wave, early / late recompute)
+    const bool loss_cp1 = !loss_cp && !loss_xs && cp_loss_one_wave(d, (int)sizeof(S)) && !p->joint_angles && !(L->flags & MF_LOSS_VALUE_IN_BACKWARD);
+    MF_REQUIRE(!(loss_cp1 || loss_xs) || (L->near && L->w), MF_ERR_INVALID, "rollout_bwd: this fused loss reads MfRolloutLoss.near and .w");
+    MF_REQUIRE(loss_cp || loss_xs || loss_cp1, MF_ERR_UNSUPPORTED,
                "rollout_bwd: this launch cannot carry the fused physics loss (mf_rollout_loss_fusable: 1 = the streaming component-parallel backward, "
                "the forward's record required; 2 = the saturated positions-only kernels)");
     MF_REQUIRE((long long)d->B * L->T2 * 3 * (long long)sizeof(S) < (1ll << 32), MF_ERR_UNSUPPORTED, "rollout_bwd: ground truth of 4 GiB or more");
@@ -109,7 +121,6 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
     MF_REQUIRE(L->T2 > 0 && L->gt && L->row_stamp && L->row_w && L->gloss && L->Xs, MF_ERR_INVALID, "rollout_bwd: incomplete MfRolloutLoss");
     a.loss_T2 = L->T2; a.loss_gt = (const S*)L->gt; a.loss_row_stamp = L->row_stamp; a.loss_row_w = (const S*)L->row_w; a.loss_gloss = (const S*)L->gloss;
     a.loss_inv_count = (S)(1.0 / ((double)d->B * L->T2 * 3));
-    MF_REQUIRE(!loss_xs || (L->near && L->w), MF_ERR_INVALID, "rollout_bwd: the saturated fused loss reads MfRolloutLoss.near and .w");
     a.loss_near = L->near; a.loss_w = (const S*)L->w;
     if (L->flags & MF_LOSS_VALUE_IN_BACKWARD) {      // the fetching waves also form the loss value
       MF_REQUIRE(L->partial && L->ticket && L->loss, MF_ERR_INVALID, "rollout_bwd: MF_LOSS_VALUE_IN_BACKWARD needs MfRolloutLoss.partial / ticket / loss");
@@ -224,7 +235,10 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
 // 0 = no; 1 = both directions on the component-parallel kernels with the streaming backward (value in the forward launch, in the backward
 // launch -- MF_LOSS_VALUE_IN_BACKWARD -- or from mf_physics_loss_value_*); 2 = the BACKWARD of a saturated launch (positions-only one-point-
 // per-lane kernels): pass MfRolloutBwdBufs.loss with flags = 0, take the value from mf_physics_loss_value_* on the forward's rows
-extern "C" int mf_rollout_loss_fusable(const MfRolloutDesc* d) { return mf::cp_loss_fusable(d) ? 1 : (mf::xs_loss_fusable(d) ? 2 : 0); }
+// 3 = the BACKWARD of a component-parallel launch beyond the streaming form (one-wave forms): as 2, without MF_LOSS_VALUE_IN_BACKWARD
+extern "C" int mf_rollout_loss_fusable(const MfRolloutDesc* d) {
+  return mf::cp_loss_fusable(d) ? 1 : (mf::xs_loss_fusable(d) ? 2 : (mf::cp_loss_one_wave(d, 4) ? 3 : 0));
+}
 // 1 where a positions-only backward of this shape (float32) sends its cell gradients through the workgroups' LDS windows: a workgroup then adds
 // its window to gradient copy blockIdx % grad_copies ONCE, at its end -- few copies suffice (the caller's reduction over them is what grows)
 extern "C" int mf_rollout_bwd_window(const MfRolloutDesc* d) { return mf::xs_bwd_window(d) ? 1 : 0; }

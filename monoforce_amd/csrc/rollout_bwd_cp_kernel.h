@@ -132,7 +132,12 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
   const unsigned u_ff = ((row0 * (unsigned)a.N + pcl) * (unsigned)a.sFf + (unsigned)cc) * kS;
 
   struct StateIn { S x, xd, w, R0, R1, R2, cv, cw, t0, t1; };
-  struct UpIn { S gXs, gXds, gOm, gR0, gR1, gR2, gFs, gFf; };
+  // (a positions-only launch carries ONE upstream value per row -- and, for the fused loss of the one-wave forms (ONE1 below), the row's ground
+  //  truth and weight, -1 = no stamp.  Two types, not one with ten members: the record-reading form keeps three of them in an array the
+  //  compiler must be able to promote out of scratch)
+  struct UpFull { S gXs, gXds, gOm, gR0, gR1, gR2, gFs, gFf; };
+  struct UpXs { S gXs, lg, lw; };
+  using UpIn = std::conditional_t<XS_ONLY, UpXs, UpFull>;
   // ODEINT: output row 0 is the initial state and step m maps row m -> row m + 1 (the last control is unused); DYNAMICS: step m
   // maps row m - 1 (the initial state for m = 0) -> row m
   const int n_steps = ODE ? a.T - 1 : a.T;
@@ -166,8 +171,39 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
     }
     bload2(rCtrl, v_ctrl, um * kC, &s.cv, &s.cw);
   };
+  // ONE1 (round 6): `physics_loss` inside the ONE-WAVE forms of this kernel (record read by the computing wave, early / late recompute:
+  // 2049 .. 8192 rollouts) -- a.gXs points at the forward's own Xs rows, dL/dXs is formed where the row is consumed, as the streaming form's
+  // fetching waves and the saturated one-point-per-lane kernels (rollout_bwd_kernel.h LOSS) do.  The rows are requested from the last one
+  // down (never up, sometimes twice): the stamp at or below the row at hand -- index, row, weight, all in VECTOR registers through an
+  // opaque zero, so that the compiler does not pull a v_readfirstlane and its wait up to the loads -- steps down when the row passes it;
+  // its predecessor's row and weight are requested a call ahead; the ground-truth address depends on the index alone.  Runtime switch with
+  // dummy tables when off (no branch in the loop), like the streaming form.
+  const bool one1 = (MODE != kCpStream) && XS_ONLY && a.loss_gt != nullptr;      // wave-uniform
+  const Msk one1_mask = one1 ? ~(Msk)0 : (Msk)0;
+  const S one1_scale = one1 ? S(2.0) * a.loss_gloss[0] * a.loss_inv_count : zero;
+  const int* const o_near = one1 ? a.loss_near : reinterpret_cast<const int*>(a.ts);      // (dummies: >= 1 valid word)
+  const S* const o_w = one1 ? a.loss_w : a.ts;
+  const S* const o_gt = one1 ? a.loss_gt + ((size_t)b * (size_t)a.loss_T2) * 3u + (unsigned)cc : a.z;
+  // (the stamp state lives in VECTOR registers through an opaque zero: as scalars it took ~20 SGPRs the one-wave forms do not have -- 88 -> 106
+  //  and 128 bytes of scratch --, and left to itself the compiler keeps a uniform load's result scalar with a v_readfirstlane, and its wait,
+  //  right behind the load)
+  int o_zero = 0;
+  if constexpr (XS_ONLY && MODE != kCpStream) asm volatile("v_mov_b32 %0, 0" : "=v"(o_zero));
+  int o_j = (one1 ? a.loss_T2 - 1 : 0) + o_zero;           // largest stamp whose row is <= the row last requested (starts at the last row)
+  int o_near_cur = o_near[o_j], o_near_prev = o_near[max(o_j - 1, 0)];
+  S o_w_cur = o_w[o_j], o_w_prev = o_w[max(o_j - 1, 0)];
   auto load_upstream = [&](int orow, UpIn& u) {         // upstream gradients of output row `orow`
     const unsigned uo = __builtin_amdgcn_readfirstlane((unsigned)orow);
+    if constexpr (XS_ONLY && MODE != kCpStream) {
+      const bool dec = (o_near_cur > (int)uo) & (o_j >= 0);      // the row has passed the current stamp: its predecessor takes over
+      o_j -= dec ? 1 : 0;
+      o_near_cur = dec ? o_near_prev : o_near_cur;
+      o_w_cur = dec ? o_w_prev : o_w_cur;
+      const int jp = max(o_j - 1, 0);
+      o_near_prev = o_near[jp]; o_w_prev = o_w[jp];            // (first used by a later call)
+      u.lw = ((o_near_cur == (int)uo) & (o_j >= 0)) ? o_w_cur : -one;      // (a weight is positive: -1 marks a row without a stamp)
+      u.lg = o_gt[(size_t)(unsigned)max(o_j, 0) * 3u];
+    }
     u.gXs = bload1<S>(rgXs, u_xs, uo * sg_xs);
     if constexpr (!XS_ONLY) {
       u.gXds = bload1<S>(rgXds, u_xds, uo * sg_xds); u.gOm = bload1<S>(rgOm, u_om, uo * sg_om);
@@ -192,7 +228,12 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
   };
   auto add_upstream_state = [&](const UpIn& u) {
     UpIn m = u;
-    m.gXs = first * u.gXs;
+    S gXs_row = u.gXs;
+    if constexpr (XS_ONLY && MODE != kCpStream) {      // ONE1: the row's slot holds Xs itself; a bitwise merge, not a select on `one1` (no branch)
+      const Msk smask = u.lw > zero ? ~(Msk)0 : (Msk)0;
+      gXs_row = bfi(one1_mask, bfi(smask, cp_loss_grad(one1_scale, u.gXs, u.lg, u.lw), zero), u.gXs);
+    }
+    m.gXs = first * gXs_row;
     if constexpr (!XS_ONLY) { m.gXds = first * u.gXds; m.gR0 = first * u.gR0; m.gR1 = first * u.gR1; m.gR2 = first * u.gR2; m.gOm = first * u.gOm; }
     add_upstream_masked(m);
   };

@@ -620,7 +620,9 @@ class DPhysics(torch.nn.Module):
                 fus = int(_lib.lib().mf_rollout_loss_fusable(C.byref(d)))
             # (2: the saturated positions-only backward forms dL/dXs itself -- and the value, with `value_in_backward`; else the value comes
             #  from one small launch on the forward's rows)
-            ok = fus == 1 or (fus == 2 and z_grid.dtype == torch.float32)
+            ok = fus == 1 or (fus in (2, 3) and z_grid.dtype == torch.float32)
+            if fus == 3:       # (the one-wave component-parallel backward forms dL/dXs; the value: one small launch on the forward's rows)
+                value_in_backward = False
         if not ok:
             # (the loss reads the positions only: the forward writes the states, not the 24 N bytes of force rows per rollout-step -- for the
             #  reference's 223-point body 36 of 241 MB per launch; `return_forces` is restored for the module's other callers)

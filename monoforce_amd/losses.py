@@ -40,7 +40,9 @@ def nearest_steps(pred_ts, gt_ts):
 def nearest_steps_hip(pred_ts, gt_ts):
     """`nearest_steps` as ONE launch (`mf_nearest_steps_*`: a thread per (rollout, stamp) scans its rollout's predicted stamps) instead
     of sub / abs / argmin over two [N,T2,T1] temporaries -- 25.6 M elements and 76 us of GPU time at the BASELINE shape for 51 200
-    indices.  Same indices (the first minimum, like torch.argmin); int32 [N,T2].  Expanded (stride-0) stamp rows are read as they are."""
+    indices.  Same indices (the first minimum, like torch.argmin); int32 [N,T2].  Expanded (stride-0) stamp rows are read as they are.
+    One documented difference: a NaN among the differences is SKIPPED here (index 0 only when every difference is NaN), where
+    torch.argmin returns the first NaN's index -- stamps are finite in every caller of the reference."""
     import ctypes as C
     from . import _lib
     _lib.require_hip_tensor(pred_ts, 'pred_ts')
@@ -232,4 +234,7 @@ def physics_loss_fused(states_pred, states_gt, pred_ts, gt_ts, gamma=0.9, neares
     """`physics_loss` (position term) on the HIP kernels `mf_physics_loss_*`; same value and gradient."""
     if nearest is None:
         nearest = nearest_steps(pred_ts, gt_ts)
-    return _FusedPhysicsLoss.apply(states_pred[0], states_gt[0], gt_ts, nearest, gamma)
+    X_pred = states_pred[0]
+    if X_pred.dim() != 3 or X_pred.numel() == 0 or not _rows_do_not_overlap(X_pred):      # (aliased rows: the scatter kernel stores, the reference adds)
+        return physics_loss_aten(states_pred, states_gt, pred_ts, gt_ts, gamma=gamma, nearest=nearest.long())
+    return _FusedPhysicsLoss.apply(X_pred, states_gt[0], gt_ts, nearest, gamma)

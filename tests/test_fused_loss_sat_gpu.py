@@ -91,6 +91,74 @@ def test_fused_loss_in_the_saturated_backward_vs_float64_oracle(integ, scattered
 
 
 @pytest.mark.parametrize('integ', [1, 0])
+@pytest.mark.parametrize('B', [4096, 8192, 2304])
+def test_fused_loss_in_the_one_wave_component_parallel_backward(integ, B):
+    """2049 .. 8192 rollouts: the component-parallel backward in its one-wave forms (record read by the computing wave up to 4096 rollouts,
+    early recompute with the LDS window beyond) forms dL/dXs itself (mf_rollout_loss_fusable = 3) -- against the float64 ORACLE on a subset
+    (every other rollout's ground truth = its own prediction) and against the unfused HIP route on random ground truth for all rollouts."""
+    from monoforce_amd import synthetic as syn, _timing
+    from monoforce_amd.losses import physics_loss_fused
+    T, sub, every = 60, 16, 10
+    pts, masks = syn.robot_points_4()
+    z, mu = syn.bump_terrain(syn.bump_params(6), 6.4, 0.05), syn.wave_friction(6.4, 0.05)
+    ctrl = syn.const_controls(B, T, seed=3)
+    dp = make_dphysics(pts, masks, integ, 0.05, 6.4)
+    dp.dphys_cfg.traj_sim_time = 5.0
+    assert _fusable(dp, B, T, 256) == 3
+    sel = torch.cat([torch.arange(0, B, B // (sub - 2))[:sub - 2], torch.tensor([B - 2, B - 1])])
+    n = sel.numel()
+    spec = hp.spec_from(pts, masks, integ, 0.05, 6.4)
+    stamps = torch.arange(every - 1, T, every)
+    full_ts = torch.linspace(0, 5.0, 500)[:T]
+    lspec = dp.loss_spec(full_ts[stamps], gamma=0.9, n_steps=T)
+    with torch.no_grad():
+        (X0, _, _, _), _ = dp(z.to(DEV).unsqueeze(0), ctrl.to(DEV), friction=mu.to(DEV).unsqueeze(0))
+    gen = torch.Generator().manual_seed(7)
+    X_own = X0[:, stamps.to(DEV)].contiguous()
+    tgt = X_own[sel.to(DEV)].cpu() + 0.2 * (torch.rand(n, stamps.numel(), 3, generator=gen) - 0.5)
+    X_sub = X_own.clone(); X_sub[sel.to(DEV)] = tgt.to(DEV)
+    X_rand = (torch.rand(B, stamps.numel(), 3, generator=gen) - 0.5).to(DEV)
+    count = B * stamps.numel() * 3
+
+    def run(X_gt, route):
+        zd, md, cd = z.to(DEV).requires_grad_(True), mu.to(DEV).requires_grad_(True), ctrl.to(DEV).requires_grad_(True)
+        _timing.start()
+        if route == 'fused':
+            loss = dp.physics_loss_rollout(zd.unsqueeze(0), cd, X_gt, lspec, friction=md.unsqueeze(0))[0]
+        else:
+            keep, dp.return_forces = dp.return_forces, False
+            states, _ = dp(zd.unsqueeze(0), cd, friction=md.unsqueeze(0))
+            dp.return_forces = keep
+            loss = physics_loss_fused(states, [X_gt], None, lspec.gt_ts.unsqueeze(0).expand(B, -1), gamma=0.9, nearest=lspec.near.unsqueeze(0).expand(B, -1))
+        loss.backward()
+        name = _timing.launches()['rollout_bwd_kernel'].split(' grid')[0]
+        ks = _timing.stop()
+        assert 'rollout_bwd_cp_kernel<float, %d, true,' % integ in name, name
+        assert ('physics_loss_bwd' in ks) == (route != 'fused'), (route, list(ks))
+        return float(loss.detach()), zd.grad.clone(), md.grad.clone(), cd.grad.clone()
+    a, b = run(X_rand, 'fused'), run(X_rand, 'unfused')
+    assert abs(a[0] - b[0]) <= 2e-6 * abs(b[0])
+    for k in (1, 2, 3):
+        assert hp.rel_err(a[k], b[k]) <= 2e-5, (k, hp.rel_err(a[k], b[k]))
+    got = run(X_sub, 'fused')
+
+    def oracle(dtype):
+        zc, mc, cc = z.to(dtype).requires_grad_(True), mu.to(dtype).requires_grad_(True), ctrl[sel].to(dtype).requires_grad_(True)
+        (rX, _, _, _), _ = orc.rollout(spec, zc.unsqueeze(0).expand(n, -1, -1), cc, friction=mc.unsqueeze(0).expand(n, -1, -1))
+        w = (1. / (1. + 0.9 * full_ts[stamps].to(dtype))).view(1, -1, 1)
+        lo = (((rX[:, stamps] * w - tgt.to(dtype) * w) ** 2).sum() / count)
+        lo.backward()
+        return lo.detach(), zc.grad, mc.grad, cc.grad
+    ref, env = oracle(torch.float64), oracle(torch.float32)
+    assert abs(got[0] - float(ref[0])) <= max(2e-4, 3.0 * abs(float(env[0]) - float(ref[0])) / abs(float(ref[0]))) * abs(float(ref[0]))
+    for nm, g_, r64, r32 in zip(('z', 'mu', 'controls'), (got[1], got[2], got[3][sel.to(DEV)]), ref[1:], env[1:]):
+        bar = max(2e-4, 3.0 * hp.rel_err(r32, r64))
+        assert hp.rel_err(g_, r64) <= bar, (nm, hp.rel_err(g_, r64), 'bar', bar)
+    rest = torch.ones(B, dtype=torch.bool); rest[sel] = False
+    assert float(got[3][rest.to(DEV)].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('integ', [1, 0])
 @pytest.mark.parametrize('B,N', [(16384, 4), (20480, 4), (16384 + 256, 8)])
 def test_fused_loss_equals_the_unfused_hip_route(integ, B, N):
     """Random ground truth for ALL rollouts: the fused launch against forward + mf_physics_loss_value / _bwd + the backward reading dense rows
