@@ -188,8 +188,11 @@ def regime_of(instance, B, N):
         return None
     waves = kv.get('grid', 0) * max(kv.get('block', 64) // 64, 1)
     per_simd = waves / 1024.0
-    if name in ('rollout_bwd_cp_kernel', 'rollout_fwd_cp_kernel') or per_simd < 1.0:
+    if per_simd < 1.0:
         return f'issue-bound: {per_simd:.2f} waves per SIMD, a step costs what one wave\'s dependent chain issues'
+    if name in ('rollout_bwd_cp_kernel', 'rollout_fwd_cp_kernel'):
+        return (f'{per_simd:.1f} waves per SIMD of the component-parallel kernel: ' +
+                ('VALU-bound (the recomputing form at two waves per SIMD)' if per_simd >= 2.0 else 'one dependent chain per SIMD + the CU\'s shared L1 address path (DESIGN 8)'))
     if name == 'rollout_bwd_kernel' and len(t) > 7 and t[7] == 'true':
         return f'VALU-bound ({per_simd:.1f} waves per SIMD; PMC: VALUs ~92 % busy at two waves per SIMD); cells and RMW are cache / LDS-served'
     if name == 'rollout_fwd_kernel':
@@ -237,6 +240,25 @@ def _time_cpu(fn, budget_s, max_runs=12):
     return float(np.median(kept)), len(kept)
 
 
+def _best_threads(fn, candidates):
+    """The torch intra-op thread count at which `fn` runs fastest on this host (one run each after a warm-up): the oracle's tensors are small
+    ([B, N, 3] at a few hundred rollouts), and all 128 threads of a GPU box's host run it several times SLOWER than 8 do (round 6: the GPU
+    test tier's oracle calls 91 s -> 18 s).  The baseline is timed at the best count found, and says which."""
+    keep = torch.get_num_threads()
+    best = (float('inf'), keep)
+    try:
+        for i, n in enumerate(candidates):
+            torch.set_num_threads(n)
+            if i == 0:
+                fn()
+            t0 = time.perf_counter()
+            fn()
+            best = min(best, (time.perf_counter() - t0, n))
+    finally:
+        torch.set_num_threads(keep)
+    return best[1]
+
+
 def cpu_baseline(N, integ, T, budget_s=12.0, headline='c3'):
     """Time the CPU oracle on bounded samples, host threads as torch sees them.  `value` is the leg that does the SAME work as the
     GPU headline beside it: for c3 the autograd forward + backward of config 3 on a B = 32 sample of its 1024 rollouts
@@ -245,7 +267,8 @@ def cpu_baseline(N, integ, T, budget_s=12.0, headline='c3'):
     The other legs stay under `legs`: `c2_forward`, `c3_autograd`, `c1_forward` (config 1 at its own size)."""
     from oracle import dphysics_oracle as orc      # checker / baseline only -- never on the product path
     from monoforce_amd import synthetic as syn
-    cores = torch.get_num_threads()
+    all_threads = torch.get_num_threads()
+    cand = sorted({min(8, all_threads), min(32, all_threads), all_threads})
     legs = {}
     # forward, no_grad (SURVEY 8d: C2)
     Bs = 256
@@ -256,6 +279,8 @@ def cpu_baseline(N, integ, T, budget_s=12.0, headline='c3'):
     def fwd():
         with torch.no_grad():
             orc.rollout(spec, zb, ctrl, friction=mb)
+    cores = _best_threads(fwd, cand)
+    torch.set_num_threads(cores)
     t, n = _time_cpu(fwd, budget_s)
     legs['c2_forward'] = dict(value=Bs * T / t, unit='rollout-steps/s', cores=cores, kind='port',
                               sample=f'oracle/dphysics_oracle.py (torch-CPU port), B={Bs} x T={T} x N={N}, 256x256 shared map, forward '
@@ -269,7 +294,9 @@ def cpu_baseline(N, integ, T, budget_s=12.0, headline='c3'):
         ml = mu.clone().requires_grad_(True)
         (Xs, _, _, _), _ = orc.rollout(spec, zl.unsqueeze(0).expand(Ba, -1, -1), ctrl_a, friction=ml.unsqueeze(0).expand(Ba, -1, -1))
         (Xs[:, 9::10] ** 2).mean().backward()
-    t, n = _time_cpu(fwd_bwd, 3.2 * budget_s, max_runs=5)       # (one run is ~7 s: a warm-up and >= 3 timed ones)
+    cores = _best_threads(fwd_bwd, cand)
+    torch.set_num_threads(cores)
+    t, n = _time_cpu(fwd_bwd, 2.0 * budget_s, max_runs=5)       # (one run is 2 .. 7 s depending on the thread count)
     legs['c3_autograd'] = dict(value=Ba * T / t, unit='rollout-steps/s', cores=cores, kind='port',
                                sample=f'oracle/dphysics_oracle.py (torch-CPU port), B={Ba} (a sample of config 3\'s 1024 rollouts: the autograd graph of one '
                                       f'run holds a [B,H,W] gradient per gather, time per rollout grows with B) x T={T} x N={N}, 256x256 shared map, forward + torch '
@@ -281,13 +308,16 @@ def cpu_baseline(N, integ, T, budget_s=12.0, headline='c3'):
     def c1():
         with torch.no_grad():
             orc.rollout(spec1, z1.unsqueeze(0), ctrl1, friction=mu1.unsqueeze(0))
+    cores = _best_threads(c1, cand)
+    torch.set_num_threads(cores)
     t, n = _time_cpu(c1, 4.0, max_runs=8)
+    torch.set_num_threads(all_threads)
     legs['c1_forward'] = dict(value=200 / t, unit='rollout-steps/s', cores=cores, kind='port',
                               sample=f'B=1 x T=200 x N={N}, 128x128 map (res 0.1), forward no_grad, median of {n} runs')
     same = 'c3_autograd' if WORKLOADS[headline]['backward'] else 'c2_forward'
     head = dict(legs[same])
     head['same_workload_as_headline'] = same
-    head['sample'] += f'; os.cpu_count()={os.cpu_count()}'
+    head['sample'] += f'; {head["cores"]} torch threads = the fastest of {cand} on this host; os.cpu_count()={os.cpu_count()}'
     head['legs'] = legs
     return head
 

@@ -10,6 +10,14 @@ if REPO not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with `-m gpu` on the GPU box)')
+    # The CPU oracle's tensors are small ([B, N, 3] at a handful of rollouts): with all 128 intra-op threads of a GPU box's host every ATen
+    # call is mostly thread hand-off -- the oracle calls of the `-m gpu` tier took 5 x longer than with 8 threads (round 6, same box: 91 s ->
+    # 18 s for 32 multi-wave cases; the whole tier 805 s -> see DESIGN 2).  The referee's arithmetic does not depend on the thread count.
+    try:
+        import torch
+        torch.set_num_threads(min(8, torch.get_num_threads()))
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope='session')
