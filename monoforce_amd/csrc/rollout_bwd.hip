@@ -223,6 +223,10 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
       return launch_rollout_bwd_xs_fast_f32(ax, m, d->integrator, block, zmu, st);
     }
     MF_REQUIRE(!fused, MF_ERR_UNSUPPORTED, "rollout_bwd: this launch cannot carry the fused physics loss (mf_rollout_loss_fusable)");
+    // ... and one rollout per wave with several points per lane (65 .. 512 points beyond the multi-wave range), positions-only upstream
+    static const bool xs_ppl_off = getenv("MF_BWD_XS_PPL") && atoi(getenv("MF_BWD_XS_PPL")) == 0;      // A/B: the general kernel
+    if (!xs_ppl_off && !xs_bwd_off() && xs_only && !fused && m.G == 64 && (m.PPL == 2 || m.PPL == 4 || m.PPL == 8) && (long long)d->B >= xs_bwd_min_waves())
+      return launch_rollout_bwd_xs_ppl_fast_f32(af, m, d->integrator, block, st);
     if ((long long)d->B * m.G >= 3ll * device_cus() / 4 * 64) return launch_rollout_bwd_carry_fast_f32(af, m, d->integrator, block, st);
     return launch_rollout_bwd_fast_f32(af, m, d->integrator, block, st);
   }

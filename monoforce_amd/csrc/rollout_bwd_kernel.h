@@ -1081,6 +1081,29 @@ int launch_rollout_bwd_xs(const RolloutBwdArgs<S>& a, LaneMap m, int integ, int 
   MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("rollout_bwd (positions only) launch: ") + hipGetErrorString(e));
   return MF_OK;
 }
+// ... and for one rollout per wave with 2 / 4 / 8 points per lane (bodies of 65 .. 512 points beyond the record-reading multi-wave range):
+// a positions-only upstream compiles out 6 PPL row loads and the impulse adjoints per lane and step (rollout_bwd_xs_ppl_fast.hip; round 6)
+template <typename S>
+int launch_rollout_bwd_xs_ppl(const RolloutBwdArgs<S>& a, LaneMap m, int integ, int block, hipStream_t st) {
+  const long long threads = (long long)a.B * m.G;
+  const unsigned grid = (unsigned)((threads + block - 1) / block);
+  bool launched = false;
+#define MF_CASE(P_)                                                                                                                              \
+  if (!launched && m.G == 64 && m.PPL == P_) {                                                                                                    \
+    launched = true;                                                                                                                              \
+    if (integ == MF_INTEG_DYNAMICS)                                                                                                               \
+      MF_KLAUNCH((rollout_bwd_kernel<S, 64, P_, MF_INTEG_DYNAMICS, true, false, true, true, false, false>), dim3(grid), dim3(block), 0, st, a);       \
+    else                                                                                                                                          \
+      MF_KLAUNCH((rollout_bwd_kernel<S, 64, P_, MF_INTEG_ODEINT_EULER, true, false, true, true, false, false>), dim3(grid), dim3(block), 0, st, a);   \
+  }
+  MF_CASE(2) MF_CASE(4) MF_CASE(8)
+#undef MF_CASE
+  MF_REQUIRE(launched, MF_ERR_UNSUPPORTED, "rollout_bwd: no positions-only kernel for this lane mapping");
+  hipError_t e = hipGetLastError();
+  MF_REQUIRE(e == hipSuccess, MF_ERR_LAUNCH, std::string("rollout_bwd (positions only, several points per lane) launch: ") + hipGetErrorString(e));
+  return MF_OK;
+}
+int launch_rollout_bwd_xs_ppl_fast_f32(const RolloutBwdArgs<float>& a, LaneMap m, int integ, int block, hipStream_t st);      // rollout_bwd_xs_ppl_fast.hip
 int launch_rollout_bwd_xs_fast_f32(const RolloutBwdArgs<float>& a, LaneMap m, int integ, int block, bool zmu, hipStream_t st);      // rollout_bwd_xs_fast.hip
 int launch_rollout_bwd_xs_win_fast_f32(const RolloutBwdArgs<float>& a, LaneMap m, int integ, int block, bool zmu, bool carry, hipStream_t st);  // rollout_bwd_xs_win_fast.hip
 // ... the same with the fused physics loss (LOSS; a.loss_gt set): rollout_bwd_xs_loss_fast.hip, rollout_bwd_xs_win_loss_fast.hip

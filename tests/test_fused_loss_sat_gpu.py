@@ -226,3 +226,42 @@ def test_fit_step_at_16384_rollouts_takes_the_fused_route_and_drops_the_dense_gr
         assert abs(l1 - l0) <= 1e-6 * abs(l0)
         for a, b in zip((zl.grad, ml.grad), g0):
             assert hp.rel_err(a, b) <= 2e-5
+
+
+@pytest.mark.parametrize('integ', [1, 0])
+@pytest.mark.parametrize('N,B,ppl', [(100, 1100, 2), (223, 600, 4), (300, 520, 8)])
+def test_positions_only_backward_with_several_points_per_lane_vs_oracle(integ, N, B, ppl):
+    """Bodies of 65 .. 512 points beyond the record-reading multi-wave range (more than two waves per SIMD at one rollout over 2 / 4 / 8
+    waves): one rollout per wave with 2 / 4 / 8 points per lane.  Round 6: a positions-only upstream (what `physics_loss` sends) runs the
+    XS_ONLY instantiation there too (bench.py's points_sweep had these launches at 3.8 x their forward's time on the general kernel) --
+    against the float64 ORACLE on the rollouts the loss touches."""
+    from monoforce_amd import synthetic as syn, _timing
+    T, sub = 24, 6
+    pts, masks = syn.robot_points_box(N, seed=7, n_tracks=2)
+    z, mu = syn.bump_terrain(syn.bump_params(4), 6.4, 0.1) * 0.5, syn.wave_friction(6.4, 0.1)
+    ctrl = syn.const_controls(B, T, seed=6)
+    sel = torch.cat([torch.arange(0, B, B // (sub - 1))[:sub - 1], torch.tensor([B - 1])])
+    spec = hp.spec_from(pts, masks, integ, 0.1, 6.4)
+    wts = syn.probe_weights((sel.numel(), T, 3), phase=0.4)
+    dp = make_dphysics(pts, masks, integ, 0.1, 6.4)
+    dp.dphys_cfg.traj_sim_time = 5.0
+    zd, md, cd = z.to(DEV).requires_grad_(True), mu.to(DEV).requires_grad_(True), ctrl.to(DEV).requires_grad_(True)
+    _timing.start()
+    (Xs, _, _, _), _ = dp(zd.unsqueeze(0), cd, friction=md.unsqueeze(0))
+    (Xs[sel.to(DEV)] * wts.to(DEV)).sum().backward()
+    name = _timing.launches()['rollout_bwd_kernel'].split(' grid')[0]
+    _timing.stop()
+    assert 'rollout_bwd_kernel<float, 64, %d, %d, true, false, true, true, false, false, false>' % (ppl, integ) in name, name      # CARRY, XS_ONLY
+
+    def oracle_grads(dtype):
+        zc, mc, cc = z.to(dtype).requires_grad_(True), mu.to(dtype).requires_grad_(True), ctrl[sel].to(dtype).requires_grad_(True)
+        n = sel.numel()
+        (rX, _, _, _), _ = orc.rollout(spec, zc.unsqueeze(0).expand(n, -1, -1), cc, friction=mc.unsqueeze(0).expand(n, -1, -1))
+        (rX * wts.to(dtype)).sum().backward()
+        return zc.grad, mc.grad, cc.grad
+    ref, env = oracle_grads(torch.float64), oracle_grads(torch.float32)
+    for nm, g_, r64, r32 in zip(('z', 'mu', 'controls'), (zd.grad, md.grad, cd.grad[sel.to(DEV)]), ref, env):
+        bar = max(2e-3, 3.0 * hp.rel_err(r32, r64))      # (large bodies: the multi-wave tests' bar)
+        assert hp.rel_err(g_, r64) <= bar, (nm, hp.rel_err(g_, r64), 'bar', bar)
+    rest = torch.ones(B, dtype=torch.bool); rest[sel] = False
+    assert float(cd.grad[rest.to(DEV)].abs().max()) == 0.0
