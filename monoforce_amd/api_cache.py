@@ -139,6 +139,16 @@ class ApiStepCache:
         # (ONE map expanded over the batch with stride 0 gets its gradient as a stride-0 expand too: scaling that would materialise [B,H,W])
         if any(t is not None and t.shape[0] > 1 and t.stride(0) == 0 for t in (z_grid, friction)):
             return None
+        # The graph reads its inputs WHERE THEY LIE: anything the launch-by-launch route would first copy -- rows that are not contiguous,
+        # one shared map beside per-rollout ones (expanded for real by `_make_desc`), tensors on another device than the module's -- would
+        # freeze that copy into the graph.  Such calls are not candidates.
+        if not (controls.is_contiguous() and z_grid.is_contiguous() and (friction is None or friction.is_contiguous())):
+            return None
+        if friction is not None and friction.shape[0] != z_grid.shape[0]:
+            return None
+        mdev = torch.device(m.device)
+        if mdev.type != 'cuda' or (mdev.index is not None and mdev.index != z_grid.device.index) or (mdev.index is None and z_grid.device.index != torch.cuda.current_device()):
+            return None
         return (_tkey(z_grid), _tkey(controls), _tkey(friction), self._config_key())
 
     @staticmethod
@@ -147,6 +157,8 @@ class ApiStepCache:
             return None
         X_gt = states_gt[0]
         if not (X_gt.is_cuda and gt_ts.is_cuda and pred_ts.is_cuda) or X_gt.requires_grad or gt_ts.requires_grad or pred_ts.requires_grad:
+            return None
+        if not (X_gt.is_contiguous() and X_gt.dtype == torch.float32 and X_gt.dim() == 3):      # (read where it lies: no converted / compacted copy)
             return None
         return (_tkey(X_gt), _tkey(gt_ts), gt_ts._version, _tkey(pred_ts), pred_ts._version, float(gamma))
 
@@ -228,7 +240,7 @@ class ApiStepCache:
         rows = gt_ts if gt_ts.dim() == 2 else gt_ts.unsqueeze(0)
         prow = pred_ts if pred_ts.dim() == 2 else pred_ts.unsqueeze(0)
         grid = m._time_grid(T, z_grid.dtype, dev)
-        if rows.shape[0] not in (1, B) or prow.shape[0] not in (1, B) or prow.shape[1] != T or X_gt.shape[:2] != (B, rows.shape[1]) or X_gt.shape[-1] != 3:
+        if X_gt.device != dev or rows.shape[0] not in (1, B) or prow.shape[0] not in (1, B) or prow.shape[1] != T or X_gt.shape[:2] != (B, rows.shape[1]) or X_gt.shape[-1] != 3:
             raise ValueError('shapes the cached step does not carry')
         if not (bool((rows == rows[:1]).all()) and bool((prow == prow[:1]).all()) and bool(torch.allclose(prow[0].to(grid.dtype), grid, rtol=0, atol=1e-7))):
             raise ValueError('stamps differ between the rollouts, or pred_ts is not the module\'s time grid')

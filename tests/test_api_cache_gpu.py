@@ -132,3 +132,24 @@ def test_inference_and_other_callers_are_untouched():
         for _ in range(6):
             dp(z_grid=z0.unsqueeze(0), controls=ctrl, friction=mu0.unsqueeze(0))
     assert dp._api_step_cache.replays == 0 and dp._api_step_cache.entry is None
+
+
+def test_every_row_stamped_like_fit_terrain_and_non_contiguous_inputs_stay_launch_by_launch():
+    """`scripts/fit_terrain.py:53-62` passes `gt_ts = pred_ts` (every output row carries a stamp): cached, equal to launch by launch.  Controls
+    that are a strided view of a larger tensor would have to be compacted into a copy first -- the graph would read that copy for ever: such
+    calls never arm the cache."""
+    args = _problem(B=64, T=60, every=1, seed=3)
+    ref, _ = _fit(*args, iters=8, enabled=False)
+    got, n = _fit(*_problem(B=64, T=60, every=1, seed=3), iters=8, enabled=True)
+    assert n >= 4
+    _same(got, ref)
+    dp, z0, mu0, ctrl, states_gt, pred_ts, gt_ts = _problem(B=64, T=60, seed=4)
+    wide = torch.zeros(64, 60, 4, device=DEV)
+    wide[..., :2] = ctrl
+    strided = wide[..., :2]                                   # same values, rows 16 bytes apart
+    assert not strided.is_contiguous()
+    ref, _ = _fit(dp, z0, mu0, ctrl, states_gt, pred_ts, gt_ts, iters=7, enabled=False)
+    dp2, *_ = _problem(B=64, T=60, seed=4)
+    got, n = _fit(dp2, z0, mu0, strided, states_gt, pred_ts, gt_ts, iters=7, enabled=True)
+    assert n == 0
+    _same(got, ref)
