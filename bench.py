@@ -141,8 +141,8 @@ def instance_bytes_per_rollout_step(instance, N, T=500, T2=50):
     if name in ('rollout_bwd_kernel', 'rollout_bwd_cp_kernel', 'rollout_bwd_mw_kernel'):
         if name == 'rollout_bwd_kernel':       # <S, G, PPL, INTEG, FAST, JOINTS, CARRY, XS_ONLY, ZMU, WIN, LOSS>
             xs, win, loss, rec, gctrl = b(7), b(9), b(10), 0, True
-        elif name == 'rollout_bwd_cp_kernel':  # <S, INTEG, XS_ONLY, GCTRL, MODE, SLOTS, BATCH, ZMU, WIN>
-            xs, gctrl, mode, win, loss = b(2), b(3), int(t[4]), b(8), False
+        elif name == 'rollout_bwd_cp_kernel':  # <S, INTEG, XS_ONLY, GCTRL, MODE, SLOTS, BATCH, ZMU, WIN, ONE1>
+            xs, gctrl, mode, win, loss = b(2), b(3), int(t[4]), b(8), b(9)      # (kCpStream's fused loss is a launch argument, not an instantiation)
             rec = 256 if mode >= 2 else 0      # kCpSaved / kCpStream read the forward's 16-byte quad per lane, 16 lanes per rollout
         else:                                  # <S, G, XS_ONLY, TILE, INTEG>
             xs, gctrl, win, loss, rec = b(2), True, int(t[3]) > 0, False, 16

@@ -212,8 +212,10 @@ typedef struct MfRolloutFwdBufs {
  *      stamped rows themselves -- pass MfRolloutBwdBufs.loss and NO MfRolloutFwdBufs.loss; the value comes from mf_physics_loss_value_* on
  *      the forward's rows or, with MF_LOSS_VALUE_IN_BACKWARD, from the backward launch (partial: S[B], near and w required).  The step loses the loss-gradient launch and the dense [T][B][3] gradient (98 MB at
  *      16 384 rollouts, a tenth of its rows non-zero).
- *   3  the BACKWARD of a component-parallel launch beyond the streaming form (2049 .. 8192 rollouts of a <= 4-point body; round 6): as 2 --
- *      MfRolloutBwdBufs.loss with near and w, no MfRolloutFwdBufs.loss -- without MF_LOSS_VALUE_IN_BACKWARD (the value: mf_physics_loss_value_*).
+ *   3  the BACKWARD of a component-parallel launch in its early-recompute form (no record, more than one wave per SIMD: 4097 .. 8192
+ *      rollouts of a <= 4-point body, either integrator; round 6): as 2 -- MfRolloutBwdBufs.loss with near and w, no MfRolloutFwdBufs.loss --
+ *      without MF_LOSS_VALUE_IN_BACKWARD (the value: mf_physics_loss_value_*).  The other one-wave launches (2049 .. 4096 rollouts;
+ *      dynamics() from 1025) answer 0: there the fused kernel loses what the two loss launches cost (profiles/r6_ab_one_wave_loss.txt).
  *   0  neither: run mf_physics_loss_* on the outputs. */
 int mf_rollout_loss_fusable(const MfRolloutDesc* desc);
 

@@ -24,12 +24,15 @@ static long long xs_bwd_min_waves() {
 static bool xs_bwd_shape(const MfRolloutDesc* d, const LaneMap& m) {
   return !xs_bwd_off() && m.PPL == 1 && m.G <= 64 && (long long)d->B * m.G >= xs_bwd_min_waves() * 64;
 }
-// the component-parallel backward in its ONE-WAVE forms (beyond the streaming form's grid, up to two waves per SIMD): dL/dXs formed where the
-// row is consumed (rollout_bwd_cp_kernel.h ONE1); the value comes from mf_physics_loss_value_* on the forward's rows
+// the component-parallel backward in its EARLY-RECOMPUTE form (no record, more than one wave per SIMD: 4097 .. 8192 rollouts of a <= 4-point
+// body, either integrator): dL/dXs formed where the row is consumed (rollout_bwd_cp_kernel.h ONE1 -- instantiations
+// of their own, the kernels without the loss are untouched); the value comes from mf_physics_loss_value_* on the forward's rows
 bool cp_loss_one_wave(const MfRolloutDesc* d, int scalar_bytes) {
   static const bool off = getenv("MF_CP_LOSS_ONE_WAVE") && atoi(getenv("MF_CP_LOSS_ONE_WAVE")) == 0;      // A/B: the unfused route
   if (off || !d || d->layout != MF_LAYOUT_TIME_MAJOR || d->has_joints || cp_loss_fusable(d)) return false;
   if (scalar_bytes != 4 && d->points_per_lane != MF_LANES_COMPONENT) return false;
+  // the record-reading form and late recompute (up to one wave per SIMD): no gain (profiles/r6_ab_one_wave_loss.txt)
+  if (cp_record_bytes(d, scalar_bytes) > 0 || ((long long)d->B * 16 + 63) / 64 <= (long long)device_simds()) return false;
   MfRolloutBwdBufs none{};
   return use_component_parallel_bwd(d, &none, scalar_bytes);
 }
@@ -239,7 +242,7 @@ static int rollout_bwd(const MfRolloutDesc* d, const MfRolloutBwdBufs* p, void* 
 // 0 = no; 1 = both directions on the component-parallel kernels with the streaming backward (value in the forward launch, in the backward
 // launch -- MF_LOSS_VALUE_IN_BACKWARD -- or from mf_physics_loss_value_*); 2 = the BACKWARD of a saturated launch (positions-only one-point-
 // per-lane kernels): pass MfRolloutBwdBufs.loss with flags = 0, take the value from mf_physics_loss_value_* on the forward's rows
-// 3 = the BACKWARD of a component-parallel launch beyond the streaming form (one-wave forms): as 2, without MF_LOSS_VALUE_IN_BACKWARD
+// 3 = the BACKWARD of a component-parallel launch in its early-recompute form (4097 .. 8192 rollouts): as 2, without MF_LOSS_VALUE_IN_BACKWARD
 extern "C" int mf_rollout_loss_fusable(const MfRolloutDesc* d) {
   return mf::cp_loss_fusable(d) ? 1 : (mf::xs_loss_fusable(d) ? 2 : (mf::cp_loss_one_wave(d, 4) ? 3 : 0));
 }

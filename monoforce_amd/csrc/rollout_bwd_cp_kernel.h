@@ -58,7 +58,11 @@ extern __device__ unsigned long long mf_stream_prof[16];
 // WIN (round 5; early recompute from two waves per SIMD up): the accumulators' cell writes go to the workgroup's LDS window
 // (rollout_bwd_kernel.h: win_open / win_emit / win_close) -- the host launches it only when every lane of every workgroup owns a rollout
 // (no early exit in front of the barriers) on power-of-two maps.
-template <typename S, int INTEG, bool XS_ONLY, bool GCTRL, int MODE, int SLOTS = 6, int BATCH = 3, bool ZMU = false, bool WIN = false>
+// ONE1 (round 6): the fused physics loss in the early-recompute form -- its OWN instantiations: as a runtime switch with dummy tables (the
+// streaming form's way) the three extra loads per row and 18 more registers cost every launch of the one-wave forms 6-10 % (2304 .. 8192
+// rollouts: backward 0.36 -> 0.40, 0.38 -> 0.43, 0.65 -> 0.70 ms, profiles/r6_ab_one_wave_loss.txt), more than the fusion returned below
+// 6144 rollouts.  Launched for early recompute only (more than one wave per SIMD): below, the loss's own two launches are cheaper.
+template <typename S, int INTEG, bool XS_ONLY, bool GCTRL, int MODE, int SLOTS = 6, int BATCH = 3, bool ZMU = false, bool WIN = false, bool ONE1 = false>
 // (streaming, positions-only loss: at most 256 registers, so that two workgroups -- six waves -- share a CU's four SIMDs)
 __global__ void __launch_bounds__(MODE == kCpStream ? 192 : (WIN ? 512 : 256)) MF_STREAM_WPE
 rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
@@ -136,8 +140,9 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
   //  truth and weight, -1 = no stamp.  Two types, not one with ten members: the record-reading form keeps three of them in an array the
   //  compiler must be able to promote out of scratch)
   struct UpFull { S gXs, gXds, gOm, gR0, gR1, gR2, gFs, gFf; };
-  struct UpXs { S gXs, lg, lw; };
-  using UpIn = std::conditional_t<XS_ONLY, UpXs, UpFull>;
+  struct UpOne1 { S gXs, lg, lw; };
+  using UpIn = std::conditional_t<ONE1, UpOne1, UpFull>;
+  static_assert(!ONE1 || (XS_ONLY && MODE != kCpStream), "ONE1: a positions-only upstream in the one-wave forms");
   // ODEINT: output row 0 is the initial state and step m maps row m -> row m + 1 (the last control is unused); DYNAMICS: step m
   // maps row m - 1 (the initial state for m = 0) -> row m
   const int n_steps = ODE ? a.T - 1 : a.T;
@@ -171,30 +176,30 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
     }
     bload2(rCtrl, v_ctrl, um * kC, &s.cv, &s.cw);
   };
-  // ONE1 (round 6): `physics_loss` inside the ONE-WAVE forms of this kernel (record read by the computing wave, early / late recompute:
-  // 2049 .. 8192 rollouts) -- a.gXs points at the forward's own Xs rows, dL/dXs is formed where the row is consumed, as the streaming form's
+  // ONE1 (round 6): `physics_loss` inside the early-recompute form of this kernel (4097 .. 8192 rollouts) -- a.gXs points at the forward's own Xs rows, dL/dXs is formed where the row is consumed, as the streaming form's
   // fetching waves and the saturated one-point-per-lane kernels (rollout_bwd_kernel.h LOSS) do.  The rows are requested from the last one
   // down (never up, sometimes twice): the stamp at or below the row at hand -- index, row, weight, all in VECTOR registers through an
   // opaque zero, so that the compiler does not pull a v_readfirstlane and its wait up to the loads -- steps down when the row passes it;
-  // its predecessor's row and weight are requested a call ahead; the ground-truth address depends on the index alone.  Runtime switch with
-  // dummy tables when off (no branch in the loop), like the streaming form.
-  const bool one1 = (MODE != kCpStream) && XS_ONLY && a.loss_gt != nullptr;      // wave-uniform
-  const Msk one1_mask = one1 ? ~(Msk)0 : (Msk)0;
-  const S one1_scale = one1 ? S(2.0) * a.loss_gloss[0] * a.loss_inv_count : zero;
-  const int* const o_near = one1 ? a.loss_near : reinterpret_cast<const int*>(a.ts);      // (dummies: >= 1 valid word)
-  const S* const o_w = one1 ? a.loss_w : a.ts;
-  const S* const o_gt = one1 ? a.loss_gt + ((size_t)b * (size_t)a.loss_T2) * 3u + (unsigned)cc : a.z;
+  // its predecessor's row and weight are requested a call ahead; the ground-truth address depends on the index alone.
+  const S one1_scale = ONE1 ? S(2.0) * a.loss_gloss[0] * a.loss_inv_count : zero;
+  const int* const o_near = ONE1 ? a.loss_near : nullptr;
+  const S* const o_w = ONE1 ? a.loss_w : nullptr;
+  const S* const o_gt = ONE1 ? a.loss_gt + ((size_t)b * (size_t)a.loss_T2) * 3u + (unsigned)cc : nullptr;
   // (the stamp state lives in VECTOR registers through an opaque zero: as scalars it took ~20 SGPRs the one-wave forms do not have -- 88 -> 106
   //  and 128 bytes of scratch --, and left to itself the compiler keeps a uniform load's result scalar with a v_readfirstlane, and its wait,
   //  right behind the load)
   int o_zero = 0;
-  if constexpr (XS_ONLY && MODE != kCpStream) asm volatile("v_mov_b32 %0, 0" : "=v"(o_zero));
-  int o_j = (one1 ? a.loss_T2 - 1 : 0) + o_zero;           // largest stamp whose row is <= the row last requested (starts at the last row)
-  int o_near_cur = o_near[o_j], o_near_prev = o_near[max(o_j - 1, 0)];
-  S o_w_cur = o_w[o_j], o_w_prev = o_w[max(o_j - 1, 0)];
+  int o_j = 0, o_near_cur = 0, o_near_prev = 0;           // o_j: largest stamp whose row is <= the row last requested (starts at the last row)
+  S o_w_cur = zero, o_w_prev = zero;
+  if constexpr (ONE1) {
+    asm volatile("v_mov_b32 %0, 0" : "=v"(o_zero));
+    o_j = a.loss_T2 - 1 + o_zero;
+    o_near_cur = o_near[o_j]; o_near_prev = o_near[max(o_j - 1, 0)];
+    o_w_cur = o_w[o_j]; o_w_prev = o_w[max(o_j - 1, 0)];
+  }
   auto load_upstream = [&](int orow, UpIn& u) {         // upstream gradients of output row `orow`
     const unsigned uo = __builtin_amdgcn_readfirstlane((unsigned)orow);
-    if constexpr (XS_ONLY && MODE != kCpStream) {
+    if constexpr (ONE1) {
       const bool dec = (o_near_cur > (int)uo) & (o_j >= 0);      // the row has passed the current stamp: its predecessor takes over
       o_j -= dec ? 1 : 0;
       o_near_cur = dec ? o_near_prev : o_near_cur;
@@ -229,9 +234,9 @@ rollout_bwd_cp_kernel(const RolloutBwdArgs<S> a) {
   auto add_upstream_state = [&](const UpIn& u) {
     UpIn m = u;
     S gXs_row = u.gXs;
-    if constexpr (XS_ONLY && MODE != kCpStream) {      // ONE1: the row's slot holds Xs itself; a bitwise merge, not a select on `one1` (no branch)
+    if constexpr (ONE1) {      // the row's slot holds Xs itself; a bitwise merge on the stamp (no branch)
       const Msk smask = u.lw > zero ? ~(Msk)0 : (Msk)0;
-      gXs_row = bfi(one1_mask, bfi(smask, cp_loss_grad(one1_scale, u.gXs, u.lg, u.lw), zero), u.gXs);
+      gXs_row = bfi(smask, cp_loss_grad(one1_scale, u.gXs, u.lg, u.lw), zero);
     }
     m.gXs = first * gXs_row;
     if constexpr (!XS_ONLY) { m.gXds = first * u.gXds; m.gR0 = first * u.gR0; m.gR1 = first * u.gR1; m.gR2 = first * u.gR2; m.gOm = first * u.gOm; }
@@ -1275,8 +1280,30 @@ int launch_rollout_bwd_cp_variant(const RolloutBwdArgs<S>& a, bool xs_only, hipS
   const bool win = kWin && !win_off && mode == kCpEarly && a.map_shared && a.H == a.W && (a.H & (a.H - 1)) == 0 && threads % 512 == 0;
 #define MF_BCP_W(XS_, GC_) do { if constexpr (kWin) { if (win) { MF_KLAUNCH((rollout_bwd_cp_kernel<S, INTEG, XS_, GC_, kCpEarly, 6, 3, false, kWin>), dim3((unsigned)(threads / 512)), dim3(512), 0, st, a); break; } } MF_BCP(XS_, GC_, kCpEarly); } while (0)
 #define MF_BCP_L(XS_, GC_) do { if (mode == kCpStream) launch_rollout_bwd_cp_stream_any(a, INTEG, xs_only, grid, st); else if (mode == kCpSaved) MF_BCP_Z(XS_, GC_); else if (mode == kCpLate) MF_BCP(XS_, GC_, kCpLate); else MF_BCP_W(XS_, GC_); } while (0)
-  if (xs_only) { if (gc) MF_BCP_L(true, true); else MF_BCP_L(true, false); }
-  else         { if (gc) MF_BCP_L(false, true); else MF_BCP_L(false, false); }
+  // ONE1: the fused physics loss of the one-wave forms (float32; a.loss_gt set by the host for such a launch) -- instantiations of their own
+  bool one1_done = false;
+  if constexpr (std::is_same<S, float>::value) {
+    if (xs_only && a.loss_gt != nullptr && mode != kCpStream) {
+      // (the early-recompute form only -- more than one wave per SIMD: in the record-reading and the late-recompute forms the kernel loses what
+      //  the loss's own two small launches cost, profiles/r6_ab_one_wave_loss.txt; cp_loss_one_wave in rollout_bwd.hip offers the fusion to
+      //  exactly the shapes that run early recompute)
+      MF_REQUIRE(mode == kCpEarly, MF_ERR_UNSUPPORTED, "rollout_bwd: only the early-recompute one-wave form carries a fused loss");
+      one1_done = true;
+#define MF_BCP1(GC_, M_, Z_, W_, G_, B_) MF_KLAUNCH((rollout_bwd_cp_kernel<S, INTEG, true, GC_, M_, 6, 3, Z_, W_, true>), dim3(G_), dim3(B_), 0, st, a)
+#define MF_BCP1_L(GC_) do {                                                                                                   \
+        if (win) MF_BCP1(GC_, kCpEarly, false, kWin, (unsigned)(threads / 512), 512);                                    \
+        else MF_BCP1(GC_, kCpEarly, false, false, wgs, block);                                                                \
+      } while (0)
+      if (gc) MF_BCP1_L(true); else MF_BCP1_L(false);
+#undef MF_BCP1_L
+#undef MF_BCP1
+    }
+  }
+  if (!one1_done) {
+    MF_REQUIRE(a.loss_gt == nullptr || mode == kCpStream, MF_ERR_UNSUPPORTED, "rollout_bwd: the one-wave fused physics loss exists for float32 positions-only launches");
+    if (xs_only) { if (gc) MF_BCP_L(true, true); else MF_BCP_L(true, false); }
+    else         { if (gc) MF_BCP_L(false, true); else MF_BCP_L(false, false); }
+  }
 #undef MF_BCP_L
 #undef MF_BCP_W
 #undef MF_BCP_Z

@@ -92,6 +92,27 @@ def test_record_bytes_query(built_lib):
     assert int(built_lib.mf_rollout_record_bytes(None)) == 0
 
 
+def test_loss_fusable_query(built_lib):
+    """`mf_rollout_loss_fusable` over the batch range of a 4-point body (a host-side policy, answered without a device): 1 = both directions on
+    the streaming component-parallel kernels; 0 = the record-reading and late-recompute one-wave forms (the fused kernel gains nothing there:
+    profiles/r6_ab_one_wave_loss.txt); 3 = the early-recompute form; 2 = the saturated one-point-per-lane kernels."""
+    import ctypes as C
+    from monoforce_amd import _lib
+
+    def q(**kw):
+        d = dict(B=1024, T=500, N=4, H=256, W=256, integrator=1, math_mode=_lib.MF_MATH_FAST, force_stride=4, map_shared=1,
+                 layout=_lib.MF_LAYOUT_TIME_MAJOR)
+        d.update(kw)
+        return int(built_lib.mf_rollout_loss_fusable(C.byref(_lib.MfRolloutDesc(**d))))
+    assert [q(B=b) for b in (1, 1024, 2048)] == [1, 1, 1]
+    assert [q(B=b) for b in (2049, 2304, 4096)] == [0, 0, 0]
+    assert [q(B=b) for b in (4097, 6144, 8192)] == [3, 3, 3]
+    assert [q(B=b) for b in (8193, 16384, 65536)] == [2, 2, 2]
+    assert [q(B=b, integrator=0) for b in (1024, 1025, 4096, 4097, 8192, 16384)] == [1, 0, 0, 3, 3, 2]
+    assert q(has_joints=1) == 0 and q(B=16384, has_joints=1) == 0 and q(math_mode=_lib.MF_MATH_EXACT) == 0
+    assert int(built_lib.mf_rollout_loss_fusable(None)) == 0
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from monoforce_amd import _lib
     monkeypatch.setattr(_lib, '_lib', None)

@@ -90,12 +90,11 @@ def test_fused_loss_in_the_saturated_backward_vs_float64_oracle(integ, scattered
     assert float(cd.grad[rest.to(DEV)].abs().max()) == 0.0                 # a rollout whose ground truth is its own prediction gets exactly nothing
 
 
-@pytest.mark.parametrize('integ', [1, 0])
-@pytest.mark.parametrize('B', [4096, 8192, 2304])
+@pytest.mark.parametrize('integ,B', [(1, 8192), (1, 4608), (1, 6144 + 4), (0, 8192), (0, 4100), (0, 6144)])
 def test_fused_loss_in_the_one_wave_component_parallel_backward(integ, B):
-    """2049 .. 8192 rollouts: the component-parallel backward in its one-wave forms (record read by the computing wave up to 4096 rollouts,
-    early recompute with the LDS window beyond) forms dL/dXs itself (mf_rollout_loss_fusable = 3) -- against the float64 ORACLE on a subset
-    (every other rollout's ground truth = its own prediction) and against the unfused HIP route on random ground truth for all rollouts."""
+    """The component-parallel backward in its EARLY-RECOMPUTE form (4097 .. 8192 rollouts, either integrator: no record, more than one wave per
+    SIMD, cell gradients through the LDS window where the wave count allows) forms dL/dXs itself (mf_rollout_loss_fusable = 3) -- against the float64 ORACLE on a subset (every other rollout's ground truth = its own prediction) and
+    against the unfused HIP route on random ground truth for all rollouts."""
     from monoforce_amd import synthetic as syn, _timing
     from monoforce_amd.losses import physics_loss_fused
     T, sub, every = 60, 16, 10

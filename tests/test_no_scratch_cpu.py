@@ -59,7 +59,8 @@ def test_lds_window_kernels_fit_one_workgroup_of_eight_waves_per_cu(metadata):
     assert 'rollout_bwd_kernel<float, 4, 1, 1, true, false, true, true, true, true, false>' in names       # positions-only, interleaved maps, carry-over
     assert 'rollout_bwd_kernel<float, 4, 1, 1, true, false, true, true, true, true, true>' in names        # ... with the fused physics loss (round 6)
     assert 'rollout_bwd_kernel<float, 4, 1, 0, true, false, false, true, false, true, false>' in names     # dynamics(), plain maps, no carry-over
-    assert 'rollout_bwd_cp_kernel<float, 1, true, false, 0, 6, 3, false, true>' in names            # component-parallel early recompute
+    assert 'rollout_bwd_cp_kernel<float, 1, true, false, 0, 6, 3, false, true, false>' in names     # component-parallel early recompute
+    assert 'rollout_bwd_cp_kernel<float, 1, true, false, 0, 6, 3, false, true, true>' in names      # ... with the fused physics loss (round 6)
     assert len(rows) >= 20, names
     for n, m in rows:
         assert m['scratch'] == 0 and m['vgpr'] + m['agpr'] <= 256, (n, m)

@@ -241,8 +241,8 @@ def test_saturated_positions_only_backward_vs_oracle(integ, friction, scattered,
     if B >= 16384:      # rollout_bwd_kernel<float, 4, 1, INTEG, FAST, JOINTS, CARRY, XS_ONLY, ZMU, WIN, LOSS>
         # (with the window the accumulator carry-over runs from two waves per SIMD up only: 32 768 rollouts, eight-wave workgroups)
         assert 'rollout_bwd_kernel<float, 4, 1, %d, true, false, %s, true, %s, %s, false>' % (integ, 'false' if (win and B < 32768) else 'true', 'true' if friction else 'false', 'true' if win else 'false') in name, name
-    else:               # rollout_bwd_cp_kernel<float, INTEG, XS_ONLY, GCTRL, MODE = early, SLOTS, BATCH, ZMU, WIN>
-        assert 'rollout_bwd_cp_kernel<float, %d, true, true, 0, 6, 3, false%s>' % (integ, ', true' if win else ', false') in name, name
+    else:               # rollout_bwd_cp_kernel<float, INTEG, XS_ONLY, GCTRL, MODE = early, SLOTS, BATCH, ZMU, WIN, ONE1>
+        assert 'rollout_bwd_cp_kernel<float, %d, true, true, 0, 6, 3, false%s, false>' % (integ, ', true' if win else ', false') in name, name
 
     def oracle_grads(dtype):
         zc = z.to(dtype).requires_grad_(True)

@@ -145,11 +145,11 @@ def test_loss_inside_the_rollout_kernels_equals_the_two_kernel_route(B, T, gt_ev
         assert len(set(vals)) == 1, vals
         out.append((vals[0], z.grad.clone(), m.grad.clone(), prob))
     assert out[1][3].loss_in_kernel and out[1][3].spec.fusable
-    if integ == 0 and B > 1024:      # dynamics() streams up to 256 workgroups: beyond, the one-wave forms carry the backward half (round 6: 3; before: 0 = the unfused route)
+    if integ == 0 and B > 1024:      # dynamics() streams up to 256 workgroups: beyond, the same value and gradient through the unfused route (up to 4096 rollouts)
         from monoforce_amd import _lib
         import ctypes as C
         d = _lib.MfRolloutDesc(B=B, T=T, N=4, H=64, W=64, integrator=0, math_mode=_lib.MF_MATH_FAST, force_stride=4, map_shared=1, layout=_lib.MF_LAYOUT_TIME_MAJOR)
-        assert _lib.lib().mf_rollout_loss_fusable(C.byref(d)) == 3
+        assert not _lib.lib().mf_rollout_loss_fusable(C.byref(d))
     assert abs(out[0][0] - out[1][0]) <= 2e-6 * abs(out[0][0]), (out[0][0], out[1][0])
     assert hp.rel_err(out[1][1].cpu(), out[0][1].cpu()) <= 2e-5 and hp.rel_err(out[1][2].cpu(), out[0][2].cpu()) <= 2e-5
     # ... and the value against the reference formula in plain torch on the rollout's outputs

@@ -10,7 +10,7 @@ from monoforce_amd import _timing, synthetic as syn
 from monoforce_amd.train import TerrainFitProblem
 DEV = 'cuda'
 for B in [int(x) for x in os.environ.get('AB_B', '16384,32768').split(',')]:
-    cfg, dp, pts, masks, z, mu, ctrl = build_problem(B, 500, 4, DEV, 1)
+    cfg, dp, pts, masks, z, mu, ctrl = build_problem(B, 500, 4, DEV, int(os.environ.get('AB_INTEG', '1')))
     cd = ctrl.to(DEV)
     zd, md = z.to(DEV).unsqueeze(0), mu.to(DEV).unsqueeze(0)
     zl, ml = z.to(DEV).clone().requires_grad_(True), mu.to(DEV).clone().requires_grad_(True)
