@@ -488,8 +488,9 @@ class Runner:
                 with torch.cuda.stream(side):
                     forward_eager()
                 torch.cuda.current_stream(dev).wait_stream(side)
+                from monoforce_amd.capture import capture
                 fwd_graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(fwd_graph, stream=side, capture_error_mode='thread_local'):
+                with capture(fwd_graph, stream=side, capture_error_mode='thread_local'):
                     forward_eager()
 
             def timed(graph, n=(2 if (self.dist_on and self.backend != 'nccl') else 8) if wl.get('encoder') else 32):      # (gloo test rig: every encoder step carries a host-side exchange)

@@ -30,6 +30,8 @@ import warnings
 
 import torch
 
+from .capture import capture
+
 ARM_AFTER = 3          # identical (forward, physics_loss) cycles before the step is captured
 MAX_MISSES = 4         # replayed forwards in a row that no matching physics_loss followed: disarm
 ENABLED = os.environ.get('MF_API_GRAPH', '1') != '0'
@@ -270,7 +272,7 @@ class ApiStepCache:
             sets = []
             for _ in range(2):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=s, capture_error_mode='thread_local'):
+                with capture(g, stream=s, capture_error_mode='thread_local'):
                     loss, states, forces, grads = step()
                 st = _BufferSet()
                 st.graph, st.loss = g, loss

@@ -16,6 +16,7 @@ only and are built once, outside the graph.
 import torch
 
 from .planner import costs_from_rows, sample_controls
+from .capture import capture
 from .splat import SplatPlan, _LiftPool
 
 __all__ = ['GraphedTerrainPlanner']
@@ -66,7 +67,7 @@ class GraphedTerrainPlanner:
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with capture(self.graph):
             self.out = self._pipeline()
 
     @torch.no_grad()

@@ -6,6 +6,7 @@ import os
 import torch
 
 from . import dist as mfdist
+from .capture import capture
 from .losses import nearest_steps, physics_loss, physics_loss_fused
 
 
@@ -128,7 +129,7 @@ class TerrainFitProblem:
         # thread_local: only this thread's calls are policed during the capture (a process-group watchdog polling its events
         # from another thread must not abort it); the backward's launches come from the autograd thread and are captured with
         # the stream they run on either way
-        with torch.cuda.graph(g, stream=s, capture_error_mode='thread_local'):
+        with capture(g, stream=s, capture_error_mode='thread_local'):
             loss, gz, gmu = fwd_bwd()
         return dict(graph=g, z=z, mu=mu, loss=loss, gz=gz, gmu=gmu)
 
@@ -317,11 +318,11 @@ class EncoderTrainStep:
                     self._restore(snap)
                 torch.cuda.current_stream(dev).wait_stream(s)
                 g, g2 = torch.cuda.CUDAGraph(), None
-                with torch.cuda.graph(g, stream=s, capture_error_mode='thread_local'):
+                with capture(g, stream=s, capture_error_mode='thread_local'):
                     out = self._forward_backward(batch) if split else self._step_eager(batch)
                 if split:
                     g2 = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g2, stream=s, pool=g.pool(), capture_error_mode='thread_local'):
+                    with capture(g2, stream=s, pool=g.pool(), capture_error_mode='thread_local'):
                         self._apply()
             except RuntimeError as e:
                 import warnings

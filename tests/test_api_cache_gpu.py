@@ -153,3 +153,43 @@ def test_every_row_stamped_like_fit_terrain_and_non_contiguous_inputs_stay_launc
     got, n = _fit(dp2, z0, mu0, strided, states_gt, pred_ts, gt_ts, iters=7, enabled=True)
     assert n == 0
     _same(got, ref)
+
+
+def test_capture_holds_the_garbage_collector_off():
+    """monoforce_amd/capture.py: a hipGraph lying in a reference cycle (a discarded cache entry) is collected BEFORE a new capture begins and the
+    cyclic collector stays off until it has ended -- torch 2.10 no longer collects in `torch.cuda.graph.__enter__`, and a collection inside a
+    capture that destroys a graph aborts the process (`~CUDAGraph`: "operation not permitted when stream is capturing";
+    tools/debug_gc_capture.py reproduces it).  `pytest tests -m gpu -q` died of exactly that in the re-capture of
+    test_another_ground_truth_leaves_the_cache_and_stays_correct, by the collector's timing."""
+    import gc
+    import weakref
+    from monoforce_amd.capture import capture
+    x = torch.zeros(256, device=DEV)
+    s = torch.cuda.Stream()
+
+    class Holder:
+        pass
+    h = Holder(); h.me = h
+    h.g = torch.cuda.CUDAGraph()
+    with capture(h.g, stream=s, capture_error_mode='thread_local'):
+        h.y = x * 2
+    wr = weakref.ref(h)
+    del h
+    assert wr() is not None and gc.isenabled()
+    g = torch.cuda.CUDAGraph()
+    with capture(g, stream=s, capture_error_mode='thread_local'):
+        assert wr() is None and not gc.isenabled()
+        z = x + 1
+    assert gc.isenabled()
+    g.replay()
+    torch.cuda.synchronize()
+    assert float(z.min()) == 1.0
+    # the collector's state is put back as it was found, also when the capture body raises
+    gc.disable()
+    try:
+        with pytest.raises(ZeroDivisionError):
+            with capture(torch.cuda.CUDAGraph(), stream=s, capture_error_mode='thread_local'):
+                1 / 0
+        assert not gc.isenabled()
+    finally:
+        gc.enable()
