@@ -21,6 +21,11 @@ def pytest_configure(config):
         torch.set_num_threads(min(int(os.environ['OMP_NUM_THREADS']), torch.get_num_threads()))
     except Exception:
         pass
+    # MF_TEST_GC_STRESS=1: the cyclic collector runs every few allocations -- finalizers land in the middle of everything (stream captures, the
+    # autograd thread's backward): the run that would have shown the abort monoforce_amd/capture.py fixes without waiting for the collector's luck
+    if os.environ.get('MF_TEST_GC_STRESS'):
+        import gc
+        gc.set_threshold(20, 2, 2)
 
 
 @pytest.fixture(scope='session')
