@@ -17,6 +17,7 @@ DEV = 'cuda'
 n_cp = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 n_mw = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 BAR = 2e-3
+SEED0 = int(os.environ.get('SOAK_SEED0', '0'))      # another range of problems
 
 
 def judge(tag, seed, info, got, ref64, ref32):
@@ -41,7 +42,7 @@ def summary(tag, res):
 # ---- cp -------------------------------------------------------------------------------------------------------------------------
 pts4, _ = syn.robot_points_4()
 res = []
-for seed in range(n_cp):
+for seed in range(SEED0, SEED0 + n_cp):
     info, pts, masks, z, mu, ctrl, state, d_max = _cp_case(seed)
     B = info['B']
     base = make_dphysics(pts4, [pts4[:, 1] > 0, pts4[:, 1] <= 0], info['integ'], info['res'], d_max)
@@ -88,7 +89,7 @@ if res:
 
 # ---- mw -------------------------------------------------------------------------------------------------------------------------
 res = []
-for seed in range(n_mw):
+for seed in range(SEED0, SEED0 + n_mw):
     rng = np.random.RandomState(seed)
     N = int(rng.choice([5, 7, 8, 9, 16, 17, 32, 33, 50, 64, 65, 100, 128, 129, 175, 223, 256, 257, 300]))
     B = int(rng.randint(1, 41)); T = int(rng.choice([2, 3, 5, 17, 40, 80, 120]))

@@ -14,7 +14,7 @@ from oracle import dphysics_oracle as orc
 DEV = 'cuda'
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 res_all, worst = [], 0.0
-for seed in range(n):
+for seed in range(int(os.environ.get('SOAK_SEED0', '0')), int(os.environ.get('SOAK_SEED0', '0')) + n):      # (SOAK_SEED0: another range of problems)
     rng = np.random.RandomState(9000 + seed)
     B = int(rng.choice([4608, 6144, 8192, 8192 + 512, 12288, 16384, 16384 + 37, 24576, 32768, 32768 + 4]))
     T = int(rng.randint(20, 121)); H = int(rng.choice([64, 128, 256, 512])); res = 12.8 / H
