@@ -603,7 +603,9 @@ class DPhysics(torch.nn.Module):
         step loses its one remaining loss launch.
         Where the library cannot fuse (mf_rollout_loss_fusable: 1 = float32 fast math, a rigid body of <= 4 points, <= 2048 rollouts --
         dynamics(): <= 1024; 2 = the saturated positions-only backward, > 8192 rollouts of a <= 4-point body, whose forward takes the value
-        from one small launch on its rows; several stamps on one row: never) the same value and gradient come from the unfused route."""
+        from one small launch on its rows; 3 = the early-recompute component-parallel backward, 4097 .. 8192 rollouts, likewise; 0 in between
+        -- 2049 .. 4096 rollouts, dynamics() 1025 .. 4096: the loss's own two launches are cheaper there; several stamps on one row: never)
+        the same value and gradient come from the unfused route."""
         from .losses import physics_loss_fused
         cp64 = z_grid.dtype == torch.float64 and self.points_per_lane == _lib.MF_LANES_COMPONENT      # the validation build of the fast kernels
         ok = (spec.fusable and not self.precise and (z_grid.dtype == torch.float32 or cp64) and spec.w.dtype == z_grid.dtype
