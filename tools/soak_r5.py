@@ -6,8 +6,10 @@ each against oracle/dphysics_oracle.py in float64 on the same float32-valued inp
 max(2e-3, 3 x the distance between the oracle's OWN float32 and float64 gradients of that problem) -- the bar of the test suite.
     python tools/soak_r5.py [n_cp] [n_mw]        (test infrastructure: the oracle is the checker here, as in tests/)"""
 import os, sys
+os.environ.setdefault('OMP_NUM_THREADS', '8')      # the CPU oracle is the referee here: 8 threads run it 5 x faster than 128 (tests/conftest.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+torch.set_num_threads(min(int(os.environ['OMP_NUM_THREADS']), torch.get_num_threads()))
 from tests.test_random_shapes_gpu import _cp_case
 from tests.test_rollout_gpu import make_dphysics
 from tests import helpers as hp

@@ -5,8 +5,10 @@ given (scattered over the map) or default, both integrators, with / without a fr
 rollouts spread over the batch (the last ones included); a problem passes when every gradient is within max(2e-4, 3 x the distance
 between the oracle's own float32 and float64 gradients).      python tools/soak_win.py [n]      (test infrastructure, as tests/)"""
 import os, sys
+os.environ.setdefault('OMP_NUM_THREADS', '8')      # the CPU oracle is the referee here: 8 threads run it 5 x faster than 128 (tests/conftest.py)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+torch.set_num_threads(min(int(os.environ['OMP_NUM_THREADS']), torch.get_num_threads()))
 from tests.test_rollout_gpu import make_dphysics
 from tests import helpers as hp
 from monoforce_amd import synthetic as syn, _timing
