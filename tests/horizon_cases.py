@@ -1,0 +1,48 @@
+"""The divergence HORIZON of a float32 rollout: per rollout, the first step at which an output leaves the float64 oracle's by more than `tol` of
+the rollout's largest value -- for the HIP float32 fast-math kernels and for the oracle's OWN float32 run, on the same inputs at the BASELINE
+batch (1024 rollouts x 500 steps x 4 points, the headline's terrain or a rougher one).  Test infrastructure (imports oracle/): used by
+tests/test_horizon_gpu.py and tools/horizon_stats.py."""
+import numpy as np
+import torch
+
+from monoforce_amd import synthetic as syn
+from oracle import dphysics_oracle as orc
+from tests import helpers as hp
+from tests.test_rollout_gpu import make_dphysics
+
+DEV = 'cuda'
+T, RES, DMAX = 500, 0.05, 6.4
+
+
+def horizons(X, X64, tol):
+    scale = X64.abs().flatten(1).amax(1).clamp_min(1e-30)                 # per rollout
+    err = (X.double() - X64).abs().flatten(2).amax(-1) / scale[:, None]   # [B, T]
+    bad = err > tol
+    first = torch.where(bad.any(1), bad.float().argmax(1), torch.full((X.shape[0],), X.shape[1]))
+    return first, err
+
+
+def case(B, integ, rough, tol=1e-4, what='Xs'):
+    pts, masks = syn.robot_points_4()
+    z = syn.bump_terrain(syn.bump_params(0 if not rough else 11), DMAX, RES) * (1.0 if not rough else 2.0)
+    mu = syn.wave_friction(DMAX, RES)
+    ctrl = syn.const_controls(B, T, seed=0)
+    spec = hp.spec_from(pts, masks, integ, RES, DMAX)
+    with torch.no_grad():
+        o = {}
+        for dt in (torch.float64, torch.float32):
+            (X, _, _, _), (Fs, _) = orc.rollout(spec, z.to(dt).unsqueeze(0).expand(B, -1, -1), ctrl.to(dt), friction=mu.to(dt).unsqueeze(0).expand(B, -1, -1))
+            o[dt] = X if what == 'Xs' else Fs
+        dp = make_dphysics(pts, masks, integ, RES, DMAX)
+        dp.dphys_cfg.traj_sim_time = T * dp.dphys_cfg.dt + 1e-9
+        (Xh, _, _, _), (Fh, _) = dp(z.to(DEV).unsqueeze(0), ctrl.to(DEV), friction=mu.to(DEV).unsqueeze(0))
+    Xh = (Xh if what == 'Xs' else Fh).cpu()[:, :o[torch.float64].shape[1]]
+    h_hip, e_hip = horizons(Xh, o[torch.float64], tol)
+    h_o32, e_o32 = horizons(o[torch.float32], o[torch.float64], tol)
+    q = lambda t: [int(v) for v in np.percentile(t.numpy(), [5, 25, 50, 75, 95])]      # noqa: E731
+    full = lambda t: float((t >= T - 1).float().mean())                                 # noqa: E731
+    worse = float((h_hip < 0.5 * h_o32).float().mean())
+    return dict(what=what, integ=integ, rough=rough, B=B, tol=tol, hip_pct=q(h_hip), o32_pct=q(h_o32), hip_full=full(h_hip), o32_full=full(h_o32),
+                hip_shorter_than_half=worse, median_ratio=float(h_hip.float().median() / h_o32.float().median()),
+                final_err_median=(float(e_hip[:, -1].median()), float(e_o32[:, -1].median())),
+                final_err_p95=(float(np.percentile(e_hip[:, -1].numpy(), 95)), float(np.percentile(e_o32[:, -1].numpy(), 95))))
