@@ -46,3 +46,34 @@ def case(B, integ, rough, tol=1e-4, what='Xs'):
                 hip_shorter_than_half=worse, median_ratio=float(h_hip.float().median() / h_o32.float().median()),
                 final_err_median=(float(e_hip[:, -1].median()), float(e_o32[:, -1].median())),
                 final_err_p95=(float(np.percentile(e_hip[:, -1].numpy(), 95)), float(np.percentile(e_o32[:, -1].numpy(), 95))))
+
+
+def grad_case(B, integ, rough, T_=T, H=None, seed=0):
+    """The BACKWARD over the full horizon: per-rollout control gradients (and the summed map gradients) of sum_b w . Xs_b on one shared map
+    pair -- HIP float32 and the oracle's own float32 autograd against the oracle's float64 autograd.  Returns per-rollout relative errors
+    e_hip[b], e_o32[b] (of gc[b], relative to that rollout's largest float64 entry) and the map-gradient errors of the two float32 runs."""
+    pts, masks = syn.robot_points_4()
+    res = RES if H is None else 2 * DMAX / H
+    z = syn.bump_terrain(syn.bump_params(0 if not rough else 11), DMAX, res) * (1.0 if not rough else 2.0)
+    mu = syn.wave_friction(DMAX, res)
+    ctrl = syn.const_controls(B, T_, seed=seed)
+    spec = hp.spec_from(pts, masks, integ, res, DMAX)
+    wts = syn.probe_weights((B, T_, 3), phase=0.3)
+    out = {}
+    for dt in (torch.float64, torch.float32):
+        leaf = lambda t: t.detach().clone().to(dt).requires_grad_(True)      # noqa: E731  (a copy: .to(float32) of a float32 tensor is the tensor itself)
+        zc, mc, cc = leaf(z), leaf(mu), leaf(ctrl)
+        (X, _, _, _), _ = orc.rollout(spec, zc.unsqueeze(0).expand(B, -1, -1), cc, friction=mc.unsqueeze(0).expand(B, -1, -1))
+        (X * wts.to(dt)[:, :X.shape[1]]).sum().backward()
+        out[dt] = (zc.grad, mc.grad, cc.grad)
+    dp = make_dphysics(pts, masks, integ, res, DMAX)
+    dp.dphys_cfg.traj_sim_time = T_ * dp.dphys_cfg.dt + 1e-9
+    zd, md, cd = (t.detach().clone().to(DEV).requires_grad_(True) for t in (z, mu, ctrl))
+    (Xh, _, _, _), _ = dp(zd.unsqueeze(0), cd, friction=md.unsqueeze(0))
+    (Xh * wts.to(DEV)[:, :Xh.shape[1]]).sum().backward()
+    g64, g32 = out[torch.float64], out[torch.float32]
+    scale = g64[2].abs().flatten(1).amax(1).clamp_min(1e-300)
+    e_hip = (cd.grad.cpu().double() - g64[2]).abs().flatten(1).amax(1) / scale
+    e_o32 = (g32[2].double() - g64[2]).abs().flatten(1).amax(1) / scale
+    maps = {k: (hp.rel_err(a.grad.cpu(), g64[i]), hp.rel_err(g32[i], g64[i])) for i, (k, a) in enumerate((('gz', zd), ('gmu', md)))}
+    return e_hip, e_o32, maps
