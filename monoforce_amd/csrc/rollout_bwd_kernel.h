@@ -156,9 +156,6 @@ __device__ __forceinline__ S xs_loss_term(S xs, S g, S w) {
 template <typename S>
 __device__ __forceinline__ void xs_loss_value_finish(const RolloutBwdArgs<S>& a, S acc) {
   if (a.loss_out == nullptr) return;      // (workgroup-uniform)
-#ifdef MF_XS_LOSS_NOFINISH      // A/B hook: what does the cross-workgroup finish (fences, ticket) cost?
-  if (a.B > 0) return;
-#endif
   __shared__ S wave_sum[8];
   __shared__ unsigned last_wg;
   const int nw = (int)((blockDim.x + 63) >> 6), lane = (int)(threadIdx.x & 63), wv = (int)(threadIdx.x >> 6);
@@ -368,23 +365,13 @@ __device__ __forceinline__ void rollout_bwd_body(const RolloutBwdArgs<S>& a, S* 
   auto add_upstream_state = [&](const UpIn& u) {
     S g[3] = {u.gXs[0], u.gXs[1], u.gXs[2]};
     if constexpr (LOSS) {      // dL/dXs of this row: masked by the stamp, not by a zero weight (an unstamped row of a diverged rollout may hold inf / NaN)
-#ifdef MF_XS_LOSS_BRANCH      // A/B hook (tools/build_variant.sh): a wave-uniform branch around the stamped rows' arithmetic instead of selects
-      g[0] = g[1] = g[2] = zero;
-      if (__builtin_amdgcn_ballot_w64(u.stamped) != 0) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) g[c] = xs_loss_grad(loss_scale, u.gXs[c], u.lg[c], u.lw);
-        const S e2 = xs_loss_term(u.gXs[0], u.lg[0], u.lw) + xs_loss_term(u.gXs[1], u.lg[1], u.lw) + xs_loss_term(u.gXs[2], u.lg[2], u.lw);
-        l_val += gl == 0 ? e2 : zero;
-      }
-#else
+      // (selects, not a wave-uniform branch around the stamped rows' arithmetic: the branch put a vmcnt(0) in front of every row --
+      //  profiles/r6_ab_fused_loss_sat.txt, 1.00 -> 1.21 ms)
 #pragma unroll
       for (int c = 0; c < 3; ++c) g[c] = u.stamped ? xs_loss_grad(loss_scale, u.gXs[c], u.lg[c], u.lw) : zero;
-#ifndef MF_XS_LOSS_NOVALUE    // A/B hook: no value accumulation
       // MF_LOSS_VALUE_IN_BACKWARD: the weighted squared error of the row as well (one lane of the rollout's group counts it)
       const S e2 = xs_loss_term(u.gXs[0], u.lg[0], u.lw) + xs_loss_term(u.gXs[1], u.lg[1], u.lw) + xs_loss_term(u.gXs[2], u.lg[2], u.lw);
       l_val += (u.stamped & (gl == 0)) ? e2 : zero;
-#endif
-#endif
     }
     if constexpr (UNSUM) {
       const S ms = up_lane * a.sink;
