@@ -103,11 +103,11 @@ def _maps(c, t, n, rows):
     return t if rows is None else t[rows]
 
 
-def run_hip(c, dt=torch.float32, rows=None, rows_mask=None, points_per_lane=0):
+def run_hip(c, dt=torch.float32, rows=None, rows_mask=None, points_per_lane=0, precise=False):
     """Gradients (z, mu, controls of the selected rollouts) and outputs of the HIP route.  `rows` (positions in the selection): run ONLY these
     rollouts as their own small batch (other kernels: what the float64 check uses)."""
     from monoforce_amd import _timing
-    dp = make_dphysics(c.pts, c.masks, c.integ, c.res, c.d_max, points_per_lane=points_per_lane)
+    dp = make_dphysics(c.pts, c.masks, c.integ, c.res, c.d_max, points_per_lane=points_per_lane, **(dict(precise=True) if precise else {}))
     dp.dphys_cfg.traj_sim_time = 5.0
     widx = rows                                   # positions in the selection (weights); `rows` below: rollout indices
     rows = None if rows is None else c.sel[rows]
@@ -151,6 +151,49 @@ def run_oracle(c, dt, rows=None, rows_mask=None):
     mask = torch.ones(n) if rows_mask is None else rows_mask
     _loss(c, outs, dt, 'cpu', mask, widx).backward()
     return dict(gz=zc.grad, gmu=(mc.grad if mc is not None else None), gc=cc.grad, Xs=outs[0].detach(), Rs=outs[2].detach())
+
+
+def onehot(n, k):
+    m = torch.zeros(n); m[k] = 1.0
+    return m
+
+
+def single_rollout_errors(c, k, g_hip=None, precise=False, with_diff=False):
+    """Rollout k's OWN contribution to every gradient (the loss restricted to it): HIP float32 -- the SAME kernel and launch as the full problem,
+    only the loss's weights change -- and the oracle's float32, each against the oracle's float64 (run on that rollout alone), relative to the
+    largest float64 entry.  Returns {key: (e_hip, e_o32)}."""
+    n = c.sel.numel()
+    g = g_hip if g_hip is not None else run_hip(c, rows_mask=onehot(n, k), precise=precise)
+    rows = torch.tensor([k])
+    o64, o32 = run_oracle(c, torch.float64, rows=rows), run_oracle(c, torch.float32, rows=rows)
+    out = {}
+    for key in ('gz', 'gmu', 'gc'):
+        if o64[key] is None:
+            continue
+        gh = g[key]
+        gh = gh[k:k + 1] if gh.shape[0] == n and n > 1 else gh      # per-rollout maps / control rows: this rollout's; a shared map: the whole
+        scale = float(o64[key].abs().max())
+        out[key] = (float((gh.double() - o64[key]).abs().max()) / scale, float((o32[key].double() - o64[key]).abs().max()) / scale)
+    if with_diff:      # ... and WHERE the map gradient differs
+        return out, (g['gz'][k:k + 1] if g['gz'].shape[0] == n and n > 1 else g['gz']).double() - o64['gz']
+    return out
+
+
+class truncated:
+    """The same problem stopped after `T_` steps (controls and, for the window problems, the probe weights cut)."""
+    def __init__(self, c, T_):
+        self.c, self.T_ = c, int(T_)
+
+    def __enter__(self):
+        c = self.c
+        self.keep = (c.ctrl, c.wts, c.T)
+        c.ctrl, c.T = c.ctrl[:, :self.T_].contiguous(), self.T_
+        if c.wts is not None:
+            c.wts = c.wts[:, :self.T_].contiguous()
+        return c
+
+    def __exit__(self, *exc):
+        self.c.ctrl, self.c.wts, self.c.T = self.keep
 
 
 if __name__ == '__main__':
