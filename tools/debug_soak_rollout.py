@@ -1,6 +1,7 @@
 """One rollout of a soak problem (written for mw 2006, SOAK_SEED0=2000: rollout 3's map gradient is 1.8 % off in float32 while its positions follow float64 to 1.5e-6 and the
 oracle's own float32 gradient is stable under displacements and point orders.  Where does it come from?  (i) fast math or float32 itself: the
-precise float32 kernels; (ii) when: the error against the horizon."""
+precise float32 kernels; (ii) when: the error against the horizon.)
+    python tools/debug_soak_rollout.py <kind> <seed> <rollout>      (GPU; MONOFORCE_HIP_LIB selects an A/B build of the kernels)"""
 import os, sys
 os.environ.setdefault('OMP_NUM_THREADS', '8')
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
