@@ -150,7 +150,8 @@ def run_oracle(c, dt, rows=None, rows_mask=None):
     outs = list(states) + list(forces)
     mask = torch.ones(n) if rows_mask is None else rows_mask
     _loss(c, outs, dt, 'cpu', mask, widx).backward()
-    return dict(gz=zc.grad, gmu=(mc.grad if mc is not None else None), gc=cc.grad, Xs=outs[0].detach(), Rs=outs[2].detach())
+    return dict(gz=zc.grad, gmu=(mc.grad if mc is not None else None), gc=cc.grad, Xs=outs[0].detach(), Xds=outs[1].detach(), Rs=outs[2].detach(),
+                Om=outs[3].detach())
 
 
 def onehot(n, k):
@@ -176,6 +177,63 @@ def single_rollout_errors(c, k, g_hip=None, precise=False, with_diff=False):
         out[key] = (float((gh.double() - o64[key]).abs().max()) / scale, float((o32[key].double() - o64[key]).abs().max()) / scale)
     if with_diff:      # ... and WHERE the map gradient differs
         return out, (g['gz'][k:k + 1] if g['gz'].shape[0] == n and n > 1 else g['gz']).double() - o64['gz']
+    return out
+
+
+def kink_rows(c, k, o64=None, edge_ulps=4.0, clamp_rel=2e-5):
+    """Output rows of rollout k (float64 oracle) at which the contact model -- evaluated AT that state, for the step that follows -- sits on a
+    kink within float32 resolution: a contact point within `edge_ulps` float32 ulps of a cell edge (the interpolant is continuous there, its
+    slopes and the cells a gradient lands in are not), or an unclamped spring force / friction force / angular acceleration within `clamp_rel`
+    of its clamp (dphysics.py:233,250-251,257: the value is continuous, the derivative switches between 1 and 0).  [(row, kind, margin)]."""
+    dt = torch.float64
+    if o64 is None:
+        o64 = run_oracle(c, dt, rows=torch.tensor([k]))
+        Xs, Xds, Rs, Om = (o64[a][0] for a in ('Xs', 'Xds', 'Rs', 'Om'))
+    else:
+        Xs, Xds, Rs, Om = (o64[a][k] for a in ('Xs', 'Xds', 'Rs', 'Om'))
+    spec = c.spec
+    idx = c.sel[torch.tensor([k])]
+    per = c.z.shape[0] > 1
+    z = (c.z[idx] if per else c.z).to(dt)
+    mu = torch.ones_like(z) if c.mu is None else (c.mu[idx] if per else c.mu).to(dt)
+    ctrl = c.ctrl[idx].to(dt)[0]
+    P = spec.points.to(dt).unsqueeze(0)
+    Iinv = torch.linalg.inv(orc.point_inertia(spec.mass, P))
+    mg = spec.mass * spec.gravity
+    x = Xs - Rs[:, :, 2] * SINK
+    T_ = Xs.shape[0]
+    tq = torch.arange(T_)
+    tc = (tq + 1).clamp_max(ctrl.shape[0] - 1) if c.integ == 0 else tq      # dynamics(): the step that starts from row t is step t + 1
+    p = P @ Rs.transpose(1, 2) + x.unsqueeze(1)                            # [T, N, 3]: the T rows as a batch
+    r = p - x.unsqueeze(1)
+    vp = Xds.unsqueeze(1) + torch.linalg.cross(Om.unsqueeze(1).expand_as(r), r)
+    zq, n = orc.sample_grid(z.expand(T_, -1, -1), p[..., 0], p[..., 1], spec.d_max, spec.grid_res, normals=True)
+    muq = orc.sample_grid(mu.expand(T_, -1, -1), p[..., 0], p[..., 1], spec.d_max, spec.grid_res).unsqueeze(-1)
+    dh = p[..., 2:3] - zq.unsqueeze(-1)
+    cc = torch.sigmoid(-10.0 * dh)
+    vn = (vp * n).sum(2, keepdim=True)
+    F1 = -torch.mul(spec.stiffness * dh + spec.damping * vn, n) * cc / cc.sum(1, keepdim=True)
+    Fs = torch.clamp(F1, -mg, mg)
+    e = orc.unit(Rs[..., 0])
+    tv = orc.track_speeds(ctrl[tc, 0], ctrl[tc, 1], spec.robot_size_y, len(spec.driving_parts))
+    cmd = torch.zeros_like(vp)
+    for j in range(len(spec.driving_parts)):
+        cmd[:, spec.driving_parts[j]] = (tv[:, j].unsqueeze(1) * e).unsqueeze(1)
+    slip = muq * (cmd - vp)
+    Gf = torch.norm(Fs, dim=2).unsqueeze(2) * (slip - (slip * n).sum(2, keepdim=True) * n)
+    wd = (Iinv @ torch.sum(torch.linalg.cross(r, Fs + torch.clamp(Gf, -mg, mg)), 1).unsqueeze(2)).squeeze(2)
+    u = (p[..., :2] + spec.d_max) / spec.grid_res
+    fr = u - torch.floor(u)
+    m_edge = (torch.minimum(fr, 1 - fr) / (2.0 ** -23 * u.abs().clamp_min(1.0))).flatten(1).amin(1)      # in float32 ulps of the coordinate
+    m_F = ((F1.abs() - mg).abs() / mg).flatten(1).amin(1)
+    m_Ff = ((Gf.abs() - mg).abs() / mg).flatten(1).amin(1)
+    m_wd = ((wd.abs() - spec.omega_max).abs() / spec.omega_max).amin(1)
+    out = []
+    for t in range(T_):
+        for kind_, mval, lim in (('cell edge (float32 ulps)', m_edge[t], edge_ulps), ('spring-force clamp', m_F[t], clamp_rel),
+                                 ('friction-force clamp', m_Ff[t], clamp_rel), ('angular-acceleration clamp', m_wd[t], clamp_rel)):
+            if float(mval) <= lim:
+                out.append((t, kind_, float(mval)))
     return out
 
 

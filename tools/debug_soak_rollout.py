@@ -21,8 +21,8 @@ for precise in (False, True):
     scm.make_dphysics = lambda *a, **kw: real(*a, **dict(kw, precise=precise))      # noqa: E731
     try:
         for T_ in (c.T, c.T // 2, c.T // 4, 3 * c.T // 4, 7 * c.T // 8):
-            c.ctrl = full_ctrl[:, :T_].contiguous()
-            e = sc.single_rollout_errors(c, k)
+            with sc.truncated(c, T_) as ct:
+                e = sc.single_rollout_errors(ct, k)
             print('precise' if precise else 'fast   ', 'T', T_, {a: ('%.2e' % v[0], '%.2e' % v[1]) for a, v in e.items()}, flush=True)
     finally:
         scm.make_dphysics = real
