@@ -18,9 +18,9 @@ that a kernel that breaks one of them for a REAL reason is not waved through as 
       3. the positions never part and the oracle's float32 gradient is right: a contact point within a few float32 ULPS of a cell edge (the
          interpolant is continuous there, its slopes and the cells the gradient lands in are not) -- causal: the same problem stopped in front
          of that step has an ordinary gradient;
-      4. none of these: a long cancellation in the clamp cell (off-map contact points all deposit into the last cell), where the fast-math
-         kernels are noisier than IEEE float32 -- asserted as measured: confined to that cell, `precise=True` within the ordinary bar, fast
-         math within 15 x the oracle's own float32 error."""
+      4. none of these: a long cancellation in the clamp cell (off-map contact points all deposit into the last cell), where every float32
+         evaluation order is 1e-3 .. 1e-2 off -- asserted as measured: confined to that cell, the oracle's own float32 >= 1e-3 off there, the
+         kernels within 5 x (precise=True) / 20 x (fast math) of it on the pinned sample."""
 import os
 import subprocess
 import sys
@@ -155,10 +155,13 @@ def test_soak_outlier_is_the_float32_event_the_profiles_describe(kind, seed, rou
             if not rows_hit.numel():
                 # no such point either.  What is left (mw 2035, a robot that starts OFF the map): every off-map contact point deposits its height
                 # gradient in the LAST cell (the reference clamps the flat index, dphysics.py:427-430), step after step with alternating sign --
-                # the cell's value is what is left of a long cancellation, and float32 noise per contribution is amplified by it: the oracle's
-                # own float32 run is 2e-3 off there, the IEEE-arithmetic float32 kernels (precise=True) 4e-3, the fast-math kernels -- whose
-                # reciprocal / rsqrt / exp2 approximations are good to 1-2 ulp, not correctly rounded -- 2e-2.  Held to exactly that: the
-                # difference sits in the clamp cell, precise float32 is within the ordinary bar, fast math within 15 x the oracle's own error
+                # the cell's value is what is left of a long cancellation, and EVERY float32 evaluation is 1e-3 .. 1e-2 off there: over 24
+                # control sequences of this rollout (tools/clamp_cell_noise.py, profiles/r6_clamp_cell_noise.txt) the medians are 2.0e-3 for
+                # the oracle's float32, 3.6e-3 for the IEEE float32 kernels (precise=True), 6.0e-3 for the fast-math kernels, sample by sample
+                # anywhere between 0.1 x and 30 x each other -- and a build of the fast kernels with every approximation replaced by its IEEE
+                # operation gives 2.36e-2 where they give 2.33e-2: it is the evaluation order, not the approximations.  Held to that: the
+                # difference sits in the clamp cell, the oracle's own float32 is >= 1e-3 off there, the kernels within 5 x (IEEE) / 20 x
+                # (fast) of it on this sample (measured: 1.8 x / 10 x), the other gradients within the ordinary bar
                 e_fast, dmap = sc.single_rollout_errors(c, k, with_diff=True)
                 e_prec = sc.single_rollout_errors(c, k, precise=True)
                 dmap = dmap.abs()[0]
@@ -166,8 +169,8 @@ def test_soak_outlier_is_the_float32_event_the_profiles_describe(kind, seed, rou
                 assert float(dmap[-1, -1]) >= 0.5 * float(dmap.max()), (k, float(dmap[-1, -1]), float(dmap.max()))
                 print('rollout', k, 'cancellation in the clamp cell | own gz error: fast %.1e, precise %.1e, oracle float32 %.1e' % (e_fast['gz'][0], e_prec['gz'][0], e_fast['gz'][1]))
                 assert e_fast['gz'][1] >= 1e-3, (k, e_fast['gz'])                       # ... which the oracle's own float32 run shows as well
-                assert e_prec['gz'][0] <= max(3.0 * e_prec['gz'][1], 1e-3), (k, e_prec['gz'])
-                assert e_fast['gz'][0] <= 15.0 * e_fast['gz'][1], (k, e_fast['gz'])
+                assert e_prec['gz'][0] <= max(5.0 * e_prec['gz'][1], 1e-3), (k, e_prec['gz'])
+                assert e_fast['gz'][0] <= 20.0 * e_fast['gz'][1], (k, e_fast['gz'])
                 for key in ('gmu', 'gc'):
                     if key in e_fast:
                         assert e_fast[key][0] <= max(3.0 * e_fast[key][1], 1e-4), (k, key, e_fast[key])
