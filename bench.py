@@ -1013,10 +1013,22 @@ def main():
             others['c4'] = brief(r.run('c4', 5, 4, events_after=True)[0])
             others['c4_aug'] = brief(r.run('c4_aug', 5, 4, events_after=True)[0])
         else:
-            others['strong_c3'] = brief(r.run('c3', short, 3, batch=max(8192 // r.world, 1), events_after=True)[0])
-            others['strong_c3']['scaling'] = 'strong (8192 rollouts in total)'
-            rig = r.backend != 'nccl'      # (the gloo one-GPU test rig: every encoder step carries a host-side exchange of seconds)
-            others['c5'] = brief(r.run('c5', 2 if rig else 5, 1 if rig else 4, events_after=True)[0])
+            # Several ranks: the headline above is what a scaling run is for; the side workloads must not cost it.  An exception every rank
+            # raises alike (a capture the runtime refuses, a shape error) is recorded and the line still goes out; c5 -- the encoder's
+            # data-parallel step, the one workload here with a collective INSIDE the step, run so far only over gloo and over ONE RCCL rank
+            # (tests/test_c5_gpu.py) -- is part of the default multi-rank run only on request (MF_BENCH_C5=1; `--workload c5` measures it
+            # as the headline): a rank-asymmetric failure in it would hang the exchange and with it the line.
+            try:
+                others['strong_c3'] = brief(r.run('c3', short, 3, batch=max(8192 // r.world, 1), events_after=True)[0])
+                others['strong_c3']['scaling'] = 'strong (8192 rollouts in total)'
+            except Exception as e:      # noqa: BLE001
+                others['strong_c3'] = {'error': f'{type(e).__name__}: {str(e).splitlines()[0][:200]}'}
+            if os.environ.get('MF_BENCH_C5'):
+                rig = r.backend != 'nccl'      # (the gloo one-GPU test rig: every encoder step carries a host-side exchange of seconds)
+                try:
+                    others['c5'] = brief(r.run('c5', 2 if rig else 5, 1 if rig else 4, events_after=True)[0])
+                except Exception as e:      # noqa: BLE001
+                    others['c5'] = {'error': f'{type(e).__name__}: {str(e).splitlines()[0][:200]}'}
     if r.rank == 0:
         out = {'metric': 'rollout-steps/sec (batch x horizon) on 256x256 terrain', 'value': res['value'], 'unit': 'rollout-steps/s',
                'n_gpus': r.world, 'world_size': r.dist_world, 'backend': ('rccl' if r.backend == 'nccl' else r.backend) if r.dist_on else None,

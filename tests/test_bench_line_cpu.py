@@ -62,3 +62,14 @@ def test_compact_line_multi_rank_and_no_cpu_baseline():
     assert c['ms_per_step_ranks'] == {'min': 0.39, 'max': 0.41}
     del rec['cpu_baseline']                                  # --no-cpu-baseline: the key is absent, not null
     assert 'cpu_baseline' not in json.loads(bench.compact_line(rec, None))
+
+
+def test_a_failed_side_workload_does_not_cost_the_line():
+    """bench.py records an exception of a multi-rank side workload as {'error': ...} (the headline is what a scaling run is for): the compact
+    line carries null for it and stays valid."""
+    import bench
+    rec = json.load(open(os.path.join(os.path.dirname(__file__), 'golden', 'bench_record_r5i.json')))
+    rec['other_workloads'] = {'strong_c3': {'error': 'RuntimeError: capture refused'}}
+    line = bench.compact_line(rec, 'bench_detail.json')
+    d = json.loads(line)
+    assert len(line) < bench.COMPACT_LIMIT and d['other_ms_per_step'] == {'strong_c3': None} and d['value'] == rec['value']

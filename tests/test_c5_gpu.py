@@ -68,7 +68,7 @@ def test_c5_eight_gloo_ranks_the_real_partition():
 def test_default_eight_rank_line_carries_strong_c3_and_c5():
     """The DEFAULT command at N = 8 on the one-GPU rig: weak headline (1024 rollouts per rank, 8192 in total), `strong_c3`
     (8192 in total = 1024 per rank) and `c5` (8 x 1024 + one sample each) with their exchange times."""
-    out = _bench(['--gpus', '8', '--steps', '3', '--warmup', '1', '--no-cpu-baseline'], {'MF_BENCH_SINGLE_DEVICE': '1', 'MF_BENCH_BACKEND': 'gloo'},
+    out = _bench(['--gpus', '8', '--steps', '3', '--warmup', '1', '--no-cpu-baseline'], {'MF_BENCH_SINGLE_DEVICE': '1', 'MF_BENCH_BACKEND': 'gloo', 'MF_BENCH_C5': '1'},
                  timeout=2400)
     assert out['n_gpus'] == 8 and out['world_size'] == 8 and out['scaling'] == 'weak'
     assert out['config']['rollouts_per_gpu'] == 1024 and out['config']['rollouts_total'] == 8192 and out['comm_ms'] > 0
@@ -87,7 +87,7 @@ def test_c5_one_forced_rccl_rank():
 
 def test_default_multi_rank_line_carries_strong_c3_and_c5():
     """The DEFAULT command at N = 2 (no --no-others): weak-scaling headline + forward_only + strong_c3 + c5."""
-    out = _bench(['--gpus', '2', '--steps', '4', '--warmup', '2', '--no-cpu-baseline'], {'MF_BENCH_SINGLE_DEVICE': '1', 'MF_BENCH_BACKEND': 'gloo'})
+    out = _bench(['--gpus', '2', '--steps', '4', '--warmup', '2', '--no-cpu-baseline'], {'MF_BENCH_SINGLE_DEVICE': '1', 'MF_BENCH_BACKEND': 'gloo', 'MF_BENCH_C5': '1'})
     assert out['n_gpus'] == 2 and out['scaling'] == 'weak' and out['config']['rollouts_total'] == 2048
     ow = out['other_workloads']
     assert set(ow) >= {'strong_c3', 'c5'}
