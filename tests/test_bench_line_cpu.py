@@ -72,4 +72,4 @@ def test_a_failed_side_workload_does_not_cost_the_line():
     rec['other_workloads'] = {'strong_c3': {'error': 'RuntimeError: capture refused'}}
     line = bench.compact_line(rec, 'bench_detail.json')
     d = json.loads(line)
-    assert len(line) < bench.COMPACT_LIMIT and d['other_ms_per_step'] == {'strong_c3': None} and d['value'] == rec['value']
+    assert len(line) < bench.COMPACT_LIMIT and d['other_ms_per_step'] == {'strong_c3': None} and abs(d['value'] - rec['value']) <= 1e-5 * rec['value']
