@@ -22,8 +22,8 @@ def horizons(X, X64, tol):
     return first, err
 
 
-def case(B, integ, rough, tol=1e-4, what='Xs'):
-    pts, masks = syn.robot_points_4()
+def case(B, integ, rough, tol=1e-4, what='Xs', N=4):
+    pts, masks = syn.robot_points_4() if N == 4 else syn.robot_points_box(N, seed=1, n_tracks=2)
     z = syn.bump_terrain(syn.bump_params(0 if not rough else 11), DMAX, RES) * (1.0 if not rough else 2.0)
     mu = syn.wave_friction(DMAX, RES)
     ctrl = syn.const_controls(B, T, seed=0)
@@ -42,7 +42,7 @@ def case(B, integ, rough, tol=1e-4, what='Xs'):
     q = lambda t: [int(v) for v in np.percentile(t.numpy(), [5, 25, 50, 75, 95])]      # noqa: E731
     full = lambda t: float((t >= T - 1).float().mean())                                 # noqa: E731
     worse = float((h_hip < 0.5 * h_o32).float().mean())
-    return dict(what=what, integ=integ, rough=rough, B=B, tol=tol, hip_pct=q(h_hip), o32_pct=q(h_o32), hip_full=full(h_hip), o32_full=full(h_o32),
+    return dict(what=what, N=N, integ=integ, rough=rough, B=B, tol=tol, hip_pct=q(h_hip), o32_pct=q(h_o32), hip_full=full(h_hip), o32_full=full(h_o32),
                 hip_shorter_than_half=worse, median_ratio=float(h_hip.float().median() / h_o32.float().median()),
                 final_err_median=(float(e_hip[:, -1].median()), float(e_o32[:, -1].median())),
                 final_err_p95=(float(np.percentile(e_hip[:, -1].numpy(), 95)), float(np.percentile(e_o32[:, -1].numpy(), 95))))

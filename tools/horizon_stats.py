@@ -17,8 +17,9 @@ from tests.horizon_cases import case
 
 if __name__ == '__main__':
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    N = int(sys.argv[2]) if len(sys.argv) > 2 else 4      # contact points (4: the BASELINE body; 175: the size of the reference's tradr body)
     for integ in (1, 0):
         for rough in (False, True):
             for what in ('Xs', 'Fs'):
                 for tol in (1e-4, 1e-3):
-                    print(case(B, integ, rough, tol, what), flush=True)
+                    print(case(B, integ, rough, tol, what, N), flush=True)
