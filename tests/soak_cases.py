@@ -4,6 +4,7 @@ tests/test_soak_outliers_gpu.py can hold each one to its EXPLANATION instead of 
 
     python -m tests.soak_cases <kind> <seed> <out.pt>      dumps the float32 HIP gradients of the case (the child process of the route-equality test:
                                                             MF_BWD_WIN / MF_MW_BWD are read once per process)"""
+import os
 import sys
 
 import numpy as np
@@ -50,6 +51,13 @@ def build(kind, seed):
         c.pts, c.masks, c.z, c.mu, c.ctrl, c.sel, c.state = pts, masks, z, mu, ctrl, sel, state
         c.wts = syn.probe_weights((sel.numel(), T, 3), phase=0.1 * seed)
         c.all_outputs = False
+    elif kind == 'cp':     # tools/soak_r5.py, the component-parallel generator (tests/test_random_shapes_gpu.py::_cp_case): <= 4 points, the
+        # N-point body run with the 4-point body's inertia and track width on both sides
+        from tests.test_random_shapes_gpu import _cp_case
+        info, pts, masks, z, mu, ctrl, state, d_max = _cp_case(seed)
+        c.B, c.T, c.H, c.res, c.d_max, c.N, c.integ, c.shared = info['B'], info['T'], info['H'], info['res'], d_max, info['N'], info['integ'], info['shared']
+        c.pts, c.masks, c.z, c.mu, c.ctrl, c.sel, c.state = pts, masks, z, mu, ctrl, torch.arange(info['B']), state
+        c.loss_kind, c.all_outputs, c.wts = info['loss'], info['loss'] != 1, None
     else:                  # tools/soak_r5.py, the multi-wave generator
         rng = np.random.RandomState(seed)
         N = int(rng.choice([5, 7, 8, 9, 16, 17, 32, 33, 50, 64, 65, 100, 128, 129, 175, 223, 256, 257, 300]))
@@ -72,7 +80,44 @@ def build(kind, seed):
         c.all_outputs, c.where = not xs_only, str(where)
         c.wts = None
     c.spec = hp.spec_from(c.pts, c.masks, c.integ, c.res, c.d_max)
+    if kind == 'cp':
+        pts4, _ = syn.robot_points_4()
+        c.spec.robot_size_y = float(pts4[:, 1].max() - pts4[:, 1].min())
     return c
+
+
+class _body4:
+    """cp problems: the oracle with the 4-point body's inertia (what the HIP side of the soak runs the N-point body with)."""
+    def __init__(self, c):
+        self.on = c.kind == 'cp'
+
+    def __enter__(self):
+        if self.on:
+            from monoforce_amd import synthetic as syn
+            self.keep = orc.point_inertia
+            P4 = torch.as_tensor(syn.robot_points_4()[0], dtype=torch.float32)
+            orc.point_inertia = lambda mass, P, _pi=self.keep: _pi(mass, P4.to(P).unsqueeze(0))
+
+    def __exit__(self, *exc):
+        if self.on:
+            orc.point_inertia = self.keep
+
+
+def _dphysics(c, points_per_lane, precise):
+    kw = dict(precise=True) if precise else {}
+    if c.kind != 'cp':
+        return make_dphysics(c.pts, c.masks, c.integ, c.res, c.d_max, points_per_lane=points_per_lane, **kw)
+    from monoforce_amd import synthetic as syn
+    pts4, _ = syn.robot_points_4()
+    m4 = [pts4[:, 1] > 0, pts4[:, 1] <= 0]
+    lanes = points_per_lane or (1 if os.environ.get('MF_SOAK_CP_LANES') == '0' else 16)      # (the other float32 route: one point per lane)
+    base = make_dphysics(pts4, m4, c.integ, c.res, c.d_max)
+    dp = make_dphysics(pts4, m4, c.integ, c.res, c.d_max, points_per_lane=lanes, **kw)
+    dp.dphys_cfg.robot_points = torch.as_tensor(c.pts)
+    dp.dphys_cfg.driving_parts = [torch.as_tensor(m) for m in c.masks]
+    dp.x_points = dp.dphys_cfg.robot_points.unsqueeze(0).to(dp.device)
+    dp._cache = {('iinv', dt_): base._iinv(dt_) for dt_ in (torch.float32, torch.float64)}
+    return dp
 
 
 def _loss(c, outs, dt, dev, rows_mask, widx=None):
@@ -84,6 +129,12 @@ def _loss(c, outs, dt, dev, rows_mask, widx=None):
     pick = (lambda w: w) if widx is None else (lambda w: w[widx.to(w.device)])
     if c.kind == 'win':
         return (outs[0] * pick(c.wts.to(dt).to(dev)) * m.view(-1, 1, 1)).sum()
+    if c.kind == 'cp':      # tools/soak_r5.py loss_of: all outputs (hp.probe_loss) / positions only / positions + spring forces
+        W = lambda o, ph: pick(syn.probe_weights((n_full,) + tuple(o.shape[1:]), phase=ph, dtype=dt).to(o.device)) * m.view(-1, *([1] * (o.dim() - 1)))      # noqa: E731
+        if c.loss_kind == 0:
+            return sum((o * W(o, 0.5 + i)).sum() * s_ for i, (o, s_) in enumerate(zip(outs, [1.0, 1.0, 1.0, 1.0, 1e-3, 1e-3])))
+        loss = (outs[0] * W(outs[0], 0.4)).sum()
+        return loss + 1e-3 * (outs[4] * W(outs[4], 1.4)).sum() if c.loss_kind == 2 else loss
     if not c.all_outputs:
         X = outs[0][:, ::3]
         return (X * pick(syn.probe_weights((n_full,) + tuple(X.shape[1:]), 0.3, dtype=dt).to(dev)) * m.view(-1, 1, 1)).sum()
@@ -107,7 +158,7 @@ def run_hip(c, dt=torch.float32, rows=None, rows_mask=None, points_per_lane=0, p
     """Gradients (z, mu, controls of the selected rollouts) and outputs of the HIP route.  `rows` (positions in the selection): run ONLY these
     rollouts as their own small batch (other kernels: what the float64 check uses)."""
     from monoforce_amd import _timing
-    dp = make_dphysics(c.pts, c.masks, c.integ, c.res, c.d_max, points_per_lane=points_per_lane, **(dict(precise=True) if precise else {}))
+    dp = _dphysics(c, points_per_lane, precise)
     dp.dphys_cfg.traj_sim_time = 5.0
     widx = rows                                   # positions in the selection (weights); `rows` below: rollout indices
     rows = None if rows is None else c.sel[rows]
@@ -146,7 +197,8 @@ def run_oracle(c, dt, rows=None, rows_mask=None):
     cc = leaf(c.ctrl[idx])
     st = tuple(t[idx].clone().to(dt) for t in c.state) if c.state is not None else None
     ex = lambda m: None if m is None else (m.expand(n, -1, -1) if m.shape[0] == 1 else m)      # noqa: E731
-    states, forces = orc.rollout(c.spec, ex(zc), cc, state=st, friction=ex(mc))
+    with _body4(c):
+        states, forces = orc.rollout(c.spec, ex(zc), cc, state=st, friction=ex(mc))
     outs = list(states) + list(forces)
     mask = torch.ones(n) if rows_mask is None else rows_mask
     _loss(c, outs, dt, 'cpu', mask, widx).backward()
@@ -180,7 +232,7 @@ def single_rollout_errors(c, k, g_hip=None, precise=False, with_diff=False):
     return out
 
 
-def kink_rows(c, k, o64=None, edge_ulps=4.0, clamp_rel=2e-5):
+def kink_rows(c, k, o64=None, edge_ulps=4.0, clamp_rel=1e-4):
     """Output rows of rollout k (float64 oracle) at which the contact model -- evaluated AT that state, for the step that follows -- sits on a
     kink within float32 resolution: a contact point within `edge_ulps` float32 ulps of a cell edge (the interpolant is continuous there, its
     slopes and the cells a gradient lands in are not), or an unclamped spring force / friction force / angular acceleration within `clamp_rel`
@@ -198,7 +250,8 @@ def kink_rows(c, k, o64=None, edge_ulps=4.0, clamp_rel=2e-5):
     mu = torch.ones_like(z) if c.mu is None else (c.mu[idx] if per else c.mu).to(dt)
     ctrl = c.ctrl[idx].to(dt)[0]
     P = spec.points.to(dt).unsqueeze(0)
-    Iinv = torch.linalg.inv(orc.point_inertia(spec.mass, P))
+    with _body4(c):
+        Iinv = torch.linalg.inv(orc.point_inertia(spec.mass, P))
     mg = spec.mass * spec.gravity
     x = Xs - Rs[:, :, 2] * SINK
     T_ = Xs.shape[0]
