@@ -1,6 +1,7 @@
 """Every soak problem that landed outside the oracle-derived bar ("explained in text files, not pinned by tests"): round 5's three
 -- LDS-window problem 53 (`tools/soak_win.py`, 357 x the bar), multi-wave problems 118 and 146 (`tools/soak_r5.py`, 1.4 x and 10.8 x) -- and the
-five of round 6's third range of 928 problems (SOAK_SEED0=2000, profiles/r6_soak_third_range.txt).  Each is held to exactly its explanation, so
+sixteen of round 6's three further ranges of 928 problems each (SOAK_SEED0=2000 / 3000 / 4000, profiles/r6_soak_third_range.txt; 19 of 3712
+problems in all, among them ONE of the component-parallel kernels).  Each is held to exactly its explanation, so
 that a kernel that breaks one of them for a REAL reason is not waved through as "the known one":
 
   (a) the error sits in at most two rollouts -- found through the control gradients and per-rollout map gradients or, on ONE shared map pair
@@ -9,15 +10,17 @@ that a kernel that breaks one of them for a REAL reason is not waved through as 
       max(2e-4, 3 x the oracle's own float32-vs-float64 distance);
   (b) the same kernels' control flow and indexing are right on those very rollouts: the float64 HIP build agrees with the float64 oracle;
   (c) it is not the kernel family: the other float32 route (register accumulators + atomics for the LDS window: MF_BWD_WIN=0; the general
-      backward for the record-reading multi-wave kernels: MF_MW_BWD=0) gives the same float32 gradients -- or, where the event is narrower than
-      the difference between two kernels' roundings, lands equally far from the oracle, not closer;
+      backward for the record-reading multi-wave kernels: MF_MW_BWD=0; one point per lane for the component-parallel kernels) gives the same
+      float32 gradients -- or, where the event is narrower than the difference between two kernels' roundings, lands equally far from the
+      oracle; where it lands at the ORACLE'S side (what a bug of this route would look like), (d) must find a kink of kind 3 and show it causal;
   (d) it IS a float32 event, one of four kinds:
       1. the float32 positions follow the float64 oracle's up to a step, then PART -- and around that step a contact point of the oracle's
          trajectory lies on a cell edge or outside the map (clamped indices);
       2. float32 cannot referee the rollout at all: the oracle's own float32 gradient is > 1 % off on it;
-      3. the positions never part and the oracle's float32 gradient is right: a contact point within a few float32 ULPS of a cell edge (the
-         interpolant is continuous there, its slopes and the cells the gradient lands in are not) -- causal: the same problem stopped in front
-         of that step has an ordinary gradient;
+      3. the positions never part and the oracle's float32 gradient is right: a KINK within float32 resolution -- a contact point within a few
+         float32 ulps of a cell edge (the interpolant is continuous there, its slopes and the cells the gradient lands in are not), or an
+         unclamped force / angular acceleration within 1e-4 of its clamp (value continuous, derivative 1 or 0) -- causal: the same problem
+         stopped in front of that row has an ordinary gradient;
       4. none of these: a long cancellation in the clamp cell (off-map contact points all deposit into the last cell), where every float32
          evaluation order is 1e-3 .. 1e-2 off -- asserted as measured: confined to that cell, the oracle's own float32 >= 1e-3 off there, the
          kernels within 5 x (precise=True) / 20 x (fast math) of it on the pinned sample."""
