@@ -235,8 +235,10 @@ def single_rollout_errors(c, k, g_hip=None, precise=False, with_diff=False):
 def kink_rows(c, k, o64=None, edge_ulps=4.0, clamp_rel=1e-4):
     """Output rows of rollout k (float64 oracle) at which the contact model -- evaluated AT that state, for the step that follows -- sits on a
     kink within float32 resolution: a contact point within `edge_ulps` float32 ulps of a cell edge (the interpolant is continuous there, its
-    slopes and the cells a gradient lands in are not), or an unclamped spring force / friction force / angular acceleration within `clamp_rel`
-    of its clamp (dphysics.py:233,250-251,257: the value is continuous, the derivative switches between 1 and 0).  [(row, kind, margin)]."""
+    slopes and the cells a gradient lands in are not), an unclamped spring force / friction force / angular acceleration within `clamp_rel`
+    of its clamp (dphysics.py:233,250-251,257: the value is continuous, the derivative switches between 1 and 0), or the spring-damper term
+    k dh + b v_n within `clamp_rel` of zero (the friction force scales with |F_n|, dphysics.py:238: its derivative changes sign there).
+    [(row, kind, margin)]."""
     dt = torch.float64
     if o64 is None:
         o64 = run_oracle(c, dt, rows=torch.tensor([k]))
@@ -265,7 +267,8 @@ def kink_rows(c, k, o64=None, edge_ulps=4.0, clamp_rel=1e-4):
     dh = p[..., 2:3] - zq.unsqueeze(-1)
     cc = torch.sigmoid(-10.0 * dh)
     vn = (vp * n).sum(2, keepdim=True)
-    F1 = -torch.mul(spec.stiffness * dh + spec.damping * vn, n) * cc / cc.sum(1, keepdim=True)
+    A_ = spec.stiffness * dh + spec.damping * vn                       # the spring-damper term: |F_n| = |A| c / sum(c) |n| has a kink at A = 0
+    F1 = -torch.mul(A_, n) * cc / cc.sum(1, keepdim=True)
     Fs = torch.clamp(F1, -mg, mg)
     e = orc.unit(Rs[..., 0])
     tv = orc.track_speeds(ctrl[tc, 0], ctrl[tc, 1], spec.robot_size_y, len(spec.driving_parts))
@@ -281,10 +284,12 @@ def kink_rows(c, k, o64=None, edge_ulps=4.0, clamp_rel=1e-4):
     m_F = ((F1.abs() - mg).abs() / mg).flatten(1).amin(1)
     m_Ff = ((Gf.abs() - mg).abs() / mg).flatten(1).amin(1)
     m_wd = ((wd.abs() - spec.omega_max).abs() / spec.omega_max).amin(1)
+    m_A = (A_.abs() / ((spec.stiffness * dh).abs() + (spec.damping * vn).abs()).clamp_min(1e-30)).flatten(1).amin(1)
     out = []
     for t in range(T_):
         for kind_, mval, lim in (('cell edge (float32 ulps)', m_edge[t], edge_ulps), ('spring-force clamp', m_F[t], clamp_rel),
-                                 ('friction-force clamp', m_Ff[t], clamp_rel), ('angular-acceleration clamp', m_wd[t], clamp_rel)):
+                                 ('friction-force clamp', m_Ff[t], clamp_rel), ('angular-acceleration clamp', m_wd[t], clamp_rel),
+                                 ('sign of the spring-damper term (|F_n| kink)', m_A[t], clamp_rel)):
             if float(mval) <= lim:
                 out.append((t, kind_, float(mval)))
     return out
